@@ -1,0 +1,26 @@
+"""CPU oracle for the quantized-matmul hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``conch_amd/`` may import this package.
+Allowed importers: ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
+leg of ``bench.py`` (as the checker / the timed CPU baseline, never as the product).
+
+Parity status: PINNED.  Every function here is checked against golden vectors under
+``tests/golden/`` that were produced by importing the real reference
+(``/root/reference/conch``) in the authoring container with
+``tests/golden/make_golden.py`` (committed).  See ``tests/test_oracle_golden.py``.
+"""
+
+from oracle.reference import (  # noqa: F401
+    FP8_E4M3FN,
+    FP8_E4M3FNUZ,
+    decode_fp8,
+    dequantize_packed,
+    encode_fp8,
+    mixed_precision_gemm_ref,
+    pack_rows_ref,
+    quantize_weights_ref,
+    scaled_fp8_quant_ref,
+    scaled_gemm_ref,
+    scaled_int8_quant_ref,
+    unpack_rows_ref,
+)

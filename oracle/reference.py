@@ -1,0 +1,263 @@
+"""CPU restatement of the reference's quantized-matmul algorithms (TEST INFRASTRUCTURE).
+
+Each function cites the reference file:line (relative to /root/reference) whose arithmetic it
+restates.  The reference's oracle is itself PyTorch-on-CPU, so the tensor-level functions use
+torch CPU ops in the same order and dtype (that is what fixes the rounding behaviour); the
+bit-level FP8 codec and the pack/unpack helpers are independent numpy integer arithmetic so that
+torch's own casts are cross-checked rather than trusted.
+
+Parity status: pinned by tests/golden/*.npz (generated from the imported reference by
+tests/golden/make_golden.py) -- see tests/test_oracle_golden.py.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+FP8_E4M3FN = "e4m3fn"  # OCP: bias 7, max 448, NaN = S.1111.111, has -0   (gfx950 native)
+FP8_E4M3FNUZ = "e4m3fnuz"  # MI300: bias 8, max 240, NaN = 0x80, no -0
+
+_TORCH_FP8 = {FP8_E4M3FN: torch.float8_e4m3fn, FP8_E4M3FNUZ: torch.float8_e4m3fnuz}
+_FP8_MAX = {FP8_E4M3FN: 448.0, FP8_E4M3FNUZ: 240.0}
+
+
+# --------------------------------------------------------------------------------------
+# Bit-level FP8 E4M3 codec (numpy).  Mirrors what `tensor.to(torch.float8_e4m3*)` does:
+# round-to-nearest-even, NON-saturating (overflow -> NaN), which is why the reference
+# clamps first (conch/reference/quantization/fp8.py:17).
+# --------------------------------------------------------------------------------------
+def decode_fp8(codes: np.ndarray, flavour: str) -> np.ndarray:
+    """uint8 codes -> float32 values."""
+    codes = np.asarray(codes, dtype=np.uint8)
+    sign = (codes >> 7).astype(np.int32)
+    exp = ((codes >> 3) & 0xF).astype(np.int32)
+    man = (codes & 0x7).astype(np.int32)
+    bias = 7 if flavour == FP8_E4M3FN else 8
+    normal = np.ldexp(1.0 + man / 8.0, exp - bias)
+    subnormal = np.ldexp(man / 8.0, 1 - bias)
+    val = np.where(exp == 0, subnormal, normal)
+    val = np.where(sign == 1, -val, val)
+    if flavour == FP8_E4M3FN:
+        val = np.where((codes & 0x7F) == 0x7F, np.nan, val)
+    else:
+        val = np.where(codes == 0x80, np.nan, val)
+    return val.astype(np.float32)
+
+
+def encode_fp8(values: np.ndarray, flavour: str) -> np.ndarray:
+    """float32 values -> uint8 codes, RNE, overflow -> NaN code (torch cast semantics)."""
+    v = np.asarray(values, dtype=np.float32)
+    bias = 7 if flavour == FP8_E4M3FN else 8
+    fmax = _FP8_MAX[flavour]
+    a = np.abs(v).astype(np.float64)
+    sign = np.signbit(v).astype(np.uint8)
+    # exponent of the value, clamped to the subnormal exponent
+    with np.errstate(divide="ignore", invalid="ignore"):
+        e = np.floor(np.log2(np.where(a > 0, a, 1.0))).astype(np.int64)
+    e = np.maximum(e, 1 - bias)
+    # quantum at this exponent is 2^(e-3); round half to even on the integer grid
+    q = a / np.ldexp(1.0, e - 3)
+    r = np.rint(q)  # numpy rint is round-half-even
+    # mantissa overflow (r == 16) bumps the exponent
+    bump = r >= 16
+    e = np.where(bump, e + 1, e)
+    r = np.where(bump, 8, r)
+    is_sub = r < 8
+    exp_field = np.where(is_sub, 0, e + bias).astype(np.int64)
+    man_field = np.where(is_sub, r, r - 8).astype(np.int64)
+    code = (exp_field << 3 | man_field).astype(np.int64)
+    back = np.ldexp(r, e - 3)
+    nan_code = 0x7F if flavour == FP8_E4M3FN else 0x80
+    overflow = back > fmax
+    out = (code | (sign.astype(np.int64) << 7)).astype(np.int64)
+    if flavour == FP8_E4M3FNUZ:
+        # no negative zero: anything that rounds to zero is +0
+        out = np.where(code == 0, 0, out)
+        out = np.where(overflow | np.isnan(v), nan_code, out)
+    else:
+        out = np.where(overflow | np.isnan(v), nan_code | (sign.astype(np.int64) << 7), out)
+    return out.astype(np.uint8)
+
+
+# --------------------------------------------------------------------------------------
+# Static quantisation feeders
+# --------------------------------------------------------------------------------------
+def scaled_int8_quant_ref(x: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    """conch/reference/quantization/int8.py:12-18.
+
+    (x * (1/scale)).clamp(-128, 127).to(int8).  With the (1,)-shaped fp32 scale the tests use,
+    type promotion makes the product fp32; the final cast truncates toward zero.
+    """
+    inv = scale.reciprocal()
+    prod = x * inv
+    lim = torch.iinfo(torch.int8)
+    return prod.clamp(min=lim.min, max=lim.max).to(torch.int8)
+
+
+def scaled_fp8_quant_ref(x: torch.Tensor, scale: torch.Tensor, flavour: str = FP8_E4M3FN) -> torch.Tensor:
+    """conch/reference/quantization/fp8.py:12-18 with the fp8 flavour made explicit.
+
+    The reference picks e4m3fnuz when `is_amd()` (line 14) and e4m3fn otherwise; both are
+    restated so either platform choice can be checked.  fp32 multiply by the reciprocal,
+    clamp to +-finfo.max, RNE cast.
+    """
+    qdtype = _TORCH_FP8[flavour]
+    info = torch.finfo(qdtype)
+    inv = scale.reciprocal()
+    scaled = (x.to(torch.float32) * inv).clamp(min=info.min, max=info.max)
+    return scaled.to(qdtype)
+
+
+# --------------------------------------------------------------------------------------
+# scaled_gemm
+# --------------------------------------------------------------------------------------
+def scaled_gemm_ref(
+    a: torch.Tensor,
+    b: torch.Tensor,
+    scale_a: torch.Tensor,
+    scale_b: torch.Tensor,
+    out_dtype: torch.dtype,
+    bias: torch.Tensor | None = None,
+) -> torch.Tensor:
+    """conch/reference/quantization/scaled_gemm.py:12-27.
+
+    fp32 matmul -> scale_a * out -> scale_b.T * out -> cast -> + bias (in out dtype).
+    The multiplication ORDER matters for bit-parity on int8 inputs.
+    """
+    acc = torch.matmul(a.to(torch.float32), b.to(torch.float32))
+    acc = scale_a * acc
+    acc = scale_b.T * acc
+    res = acc.to(out_dtype)
+    if bias is not None:
+        res = res + bias
+    return res
+
+
+# --------------------------------------------------------------------------------------
+# Weight quantisation / packing (the on-device int4/int8 format and the mixed oracle)
+# --------------------------------------------------------------------------------------
+def _qrange(bits: int, bias: int) -> tuple[int, int]:
+    """Unsigned `bits`-wide storage with a bias: representable values are [-bias, 2^bits-1-bias].
+
+    conch/third_party/vllm/scalar_type.py:153-169 (min()/max() are bias-adjusted).
+    """
+    return -bias, (1 << bits) - 1 - bias
+
+
+def quantize_weights_ref(
+    w: torch.Tensor,
+    bits: int,
+    bias: int,
+    group_size: int,
+    zero_points: bool,
+) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor | None]:
+    """conch/third_party/vllm/quant_utils.py:14-101 for unsigned integer types with a bias
+    (uint4, uint8, uint4b8, uint8b128), grouped along K, ref_zero_points_after_scales=False.
+
+    Returns (w_ref[K,N] in w.dtype, w_q[K,N] int32 incl. bias, w_s[K/G,N] in w.dtype,
+    w_zp[K/G,N] int32 or None).  All arithmetic is done in w.dtype with torch CPU ops, as the
+    reference does, so that the roundings agree bit-for-bit.
+    """
+    k, n = w.shape
+    assert k % group_size == 0
+    groups = k // group_size
+    qmin, qmax = _qrange(bits, bias)
+    # view as [group, within-group, n]; reductions run over the within-group axis
+    wg = w.reshape(groups, group_size, n)
+    hi = wg.amax(dim=1, keepdim=True)
+    lo = wg.amin(dim=1, keepdim=True)
+
+    zp = None
+    if zero_points:
+        assert qmax > 0
+        s = (hi - lo).clamp(min=1e-5) / qmax  # :53
+        zp = torch.round(torch.abs(lo / s)).clamp(qmin, qmax).int()  # :54
+    else:
+        s = torch.max(  # :58-61
+            torch.abs(hi / (qmax if qmax != 0 else float("inf"))),
+            torch.abs(lo / (qmin if qmin != 0 else float("inf"))),
+        )
+
+    q = torch.round(wg / s).int()  # :64
+    if zp is not None:
+        q = q + zp
+    q = torch.clamp(q, qmin, qmax)  # :65
+
+    centred = q - zp if zp is not None else q
+    w_ref = centred.to(w.dtype) * s  # :74  -- ONE rounding multiply after an exact subtraction
+    w_q = q + bias  # :76-77
+
+    return (
+        w_ref.reshape(k, n).contiguous(),
+        w_q.reshape(k, n).contiguous(),
+        s.reshape(groups, n).contiguous(),
+        None if zp is None else zp.reshape(groups, n).contiguous(),
+    )
+
+
+def pack_rows_ref(w_q: np.ndarray | torch.Tensor, bits: int) -> np.ndarray:
+    """conch/third_party/vllm/quant_utils.py:104-125.
+
+    32/bits consecutive K rows go into one 32-bit word: element k sits at word k // pf,
+    bit offset (k % pf) * bits.  Returns int32 [K/pf, N].
+    """
+    q = np.asarray(w_q).astype(np.uint32)
+    pf = 32 // bits
+    k, n = q.shape
+    assert k % pf == 0
+    lanes = q.reshape(k // pf, pf, n)
+    shifts = (np.arange(pf, dtype=np.uint32) * bits).reshape(1, pf, 1)
+    words = np.bitwise_or.reduce(lanes << shifts, axis=1)
+    return words.astype(np.uint32).view(np.int32)
+
+
+def unpack_rows_ref(packed: np.ndarray | torch.Tensor, bits: int) -> np.ndarray:
+    """Inverse of pack_rows_ref: int32 [K/pf, N] -> int32 [K, N] (stored values incl. bias).
+
+    conch/kernels/quantization/gemm.py:192-193 and :320-326 (row k//eps, shift (k%eps)*bits).
+    """
+    p = np.asarray(packed).view(np.uint32)
+    pf = 32 // bits
+    rows, n = p.shape
+    shifts = (np.arange(pf, dtype=np.uint32) * bits).reshape(1, pf, 1)
+    q = (p.reshape(rows, 1, n) >> shifts) & np.uint32((1 << bits) - 1)
+    return q.reshape(rows * pf, n).astype(np.int32)
+
+
+def dequantize_packed(
+    packed: torch.Tensor,
+    w_s: torch.Tensor,
+    w_zp: torch.Tensor | None,
+    bits: int,
+    bias: int,
+    group_size: int,
+) -> torch.Tensor:
+    """The dequantisation `_gemm_kernel` fuses into its K loop, for the two modes reachable
+    from conch.ops (conch/kernels/quantization/gemm.py:176-216, ops/quantization/gemm.py:34-38):
+
+      SYMMETRIC_NO_SHIFT   (w_zp None):  (q - bias).to(meta) * s
+      SYMMETRIC_WITH_SHIFT (w_zp given): ((q - bias).to(meta) - zp.to(meta)) * s
+
+    meta dtype = w_s.dtype (= x.dtype by default, ops gemm.py:127).  (q - bias - zp) is an exact
+    small integer in fp16/bf16, so there is exactly one rounding (the multiply); the result is
+    bit-identical to quantize_weights' w_ref.
+    """
+    q = torch.from_numpy(unpack_rows_ref(packed.cpu().numpy(), bits))
+    k, n = q.shape
+    groups = k // group_size
+    centred = q - bias
+    if w_zp is not None:
+        if w_zp.numel() == 1:
+            centred = centred - int(w_zp.reshape(-1)[0])
+        else:
+            centred = centred - w_zp.reshape(groups, 1, n).expand(groups, group_size, n).reshape(k, n)
+    centred = centred.to(w_s.dtype)
+    scales = w_s.reshape(groups, 1, n).expand(groups, group_size, n).reshape(k, n)
+    return centred * scales
+
+
+def mixed_precision_gemm_ref(a: torch.Tensor, w_ref: torch.Tensor) -> torch.Tensor:
+    """The mixed-precision oracle is `torch.matmul(a, w_ref)` in the activation dtype
+    (tests/mixed_precision_gemm_test.py:70, benchmarks/mixed_precision_gemm_benchmark.py:210)."""
+    return torch.matmul(a, w_ref)

@@ -1,0 +1,130 @@
+"""Pin the CPU oracle (oracle/) to the golden vectors produced by the real reference.
+
+CPU-only.  Every comparison is bit-exact: the oracle restates the reference's torch arithmetic
+in the same order, so even the floating-point outputs must agree to the last bit.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from tests.conftest import DT, from_bits, to_bits
+
+torch.set_num_threads(1)
+
+GRID = [(d, t, h, s) for d in DT for t in (1, 7, 83) for h in (16, 67, 768) for s in (0.1, 2.1)]
+FP8 = {"fn": (oracle.FP8_E4M3FN, torch.float8_e4m3fn), "fnuz": (oracle.FP8_E4M3FNUZ, torch.float8_e4m3fnuz)}
+
+
+@pytest.mark.parametrize(("dname", "tokens", "hidden", "scale"), GRID)
+def test_int8_quant_grid(golden, dname, tokens, hidden, scale):
+    g = golden("quant_int8")
+    key = f"{dname}_t{tokens}_h{hidden}_s{scale}"
+    x = from_bits(g[f"x_{key}"], DT[dname])
+    q = oracle.scaled_int8_quant_ref(x, torch.tensor([scale], dtype=torch.float32))
+    np.testing.assert_array_equal(q.numpy(), g[f"q_{key}"])
+
+
+@pytest.mark.parametrize("dname", list(DT))
+@pytest.mark.parametrize("sname", ["one", "s2p1", "zdim"])
+def test_int8_quant_edges(golden, dname, sname):
+    g = golden("quant_int8")
+    x = from_bits(g[f"edge_x_{dname}_{sname}"], DT[dname])
+    s = torch.from_numpy(g[f"edge_s_{dname}_{sname}"])
+    q = oracle.scaled_int8_quant_ref(x, s)
+    np.testing.assert_array_equal(q.numpy(), g[f"edge_q_{dname}_{sname}"])
+
+
+@pytest.mark.parametrize("flav", list(FP8))
+@pytest.mark.parametrize(("dname", "tokens", "hidden", "scale"), GRID)
+def test_fp8_quant_grid(golden, flav, dname, tokens, hidden, scale):
+    g = golden("quant_fp8")
+    key = f"{dname}_t{tokens}_h{hidden}_s{scale}"
+    x = from_bits(g[f"x_{key}"], DT[dname])
+    q = oracle.scaled_fp8_quant_ref(x, torch.tensor([scale], dtype=torch.float32), FP8[flav][0])
+    np.testing.assert_array_equal(to_bits(q), g[f"q{flav}_{key}"])
+
+
+@pytest.mark.parametrize("flav", list(FP8))
+@pytest.mark.parametrize("dname", list(DT))
+@pytest.mark.parametrize("sname", ["one", "s2p1", "zdim"])
+def test_fp8_quant_edges(golden, flav, dname, sname):
+    g = golden("quant_fp8")
+    x = from_bits(g[f"edge_x_{dname}_{sname}"], DT[dname])
+    s = torch.from_numpy(g[f"edge_s_{dname}_{sname}"])
+    q = oracle.scaled_fp8_quant_ref(x, s, FP8[flav][0])
+    np.testing.assert_array_equal(to_bits(q), g[f"edge_q{flav}_{dname}_{sname}"])
+
+
+@pytest.mark.parametrize("flav", list(FP8))
+def test_fp8_codec_matches_torch_cast(flav):
+    """The numpy bit-level codec agrees with torch's cast on every code and on random floats."""
+    name, tdt = FP8[flav]
+    codes = np.arange(256, dtype=np.uint8)
+    want = torch.from_numpy(codes.copy()).view(tdt).float().numpy()
+    got = oracle.decode_fp8(codes, name)
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
+    np.testing.assert_array_equal(np.nan_to_num(got), np.nan_to_num(want))
+    rng = np.random.default_rng(0)
+    vals = np.concatenate(
+        [
+            (rng.standard_normal(20000) * np.exp(rng.uniform(-12, 7, 20000))).astype(np.float32),
+            want[~np.isnan(want)],
+            # exact midpoints between neighbouring codes (ties-to-even cases)
+            ((want[:-1] + want[1:]) / 2)[~np.isnan(want[:-1] + want[1:])],
+            np.array([0.0, -0.0, 448.0, 464.0, 465.0, 240.0, 248.0, 249.0, 1e9, -1e9], dtype=np.float32),
+        ]
+    ).astype(np.float32)
+    want_codes = torch.from_numpy(vals.copy()).to(tdt).view(torch.uint8).numpy()
+    np.testing.assert_array_equal(oracle.encode_fp8(vals, name), want_codes)
+
+
+IN_T = {"int8": torch.int8, "fn": torch.float8_e4m3fn, "fnuz": torch.float8_e4m3fnuz}
+GEMM_KEYS = [
+    (i, o, sa, sb, b) for i in IN_T for o in ("f16", "bf16") for sa in (1, 0) for sb in (1, 0) for b in (1, 0)
+]
+
+
+@pytest.mark.parametrize(("iname", "oname", "sa_s", "sb_s", "use_bias"), GEMM_KEYS)
+def test_scaled_gemm(golden, iname, oname, sa_s, sb_s, use_bias):
+    g = golden("scaled_gemm")
+    key = f"{iname}_{oname}_sa{sa_s}_sb{sb_s}_b{use_bias}"
+    a = from_bits(g[f"a_{key}"], IN_T[iname])
+    b = from_bits(g[f"bt_{key}"], IN_T[iname]).T
+    sa = torch.from_numpy(g[f"sa_{key}"])
+    sb = torch.from_numpy(g[f"sb_{key}"])
+    bias = from_bits(g[f"bias_{key}"], DT[oname]) if use_bias else None
+    c = oracle.scaled_gemm_ref(a, b, sa, sb, DT[oname], bias)
+    np.testing.assert_array_equal(to_bits(c), g[f"c_{key}"])
+
+
+MIXED_KEYS = [(w, z, d) for w in ("uint4b8", "uint8b128", "uint4", "uint8") for z in (1, 0) for d in ("f16", "bf16")]
+
+
+@pytest.mark.parametrize(("wname", "zp", "dname"), MIXED_KEYS)
+def test_quantize_pack_dequant_mixed(golden, wname, zp, dname):
+    g = golden("mixed_gemm")
+    key = f"{wname}_zp{zp}_{dname}"
+    bits, bias, group = (int(v) for v in g[f"meta_{key}"])
+    dtype = DT[dname]
+    b = from_bits(g[f"b_{key}"], dtype)
+    w_ref, w_q, w_s, w_zp = oracle.quantize_weights_ref(b, bits, bias, group, bool(zp))
+    np.testing.assert_array_equal(w_q.numpy(), g[f"wq_{key}"])
+    np.testing.assert_array_equal(to_bits(w_s), g[f"ws_{key}"])
+    np.testing.assert_array_equal(to_bits(w_ref), g[f"wref_{key}"])
+    if zp:
+        np.testing.assert_array_equal(w_zp.numpy(), g[f"wzp_{key}"])
+    else:
+        assert w_zp is None
+    packed = oracle.pack_rows_ref(w_q.numpy(), bits)
+    np.testing.assert_array_equal(packed, g[f"packed_{key}"])
+    np.testing.assert_array_equal(oracle.unpack_rows_ref(packed, bits), g[f"wq_{key}"])
+    # the kernel-side dequantisation restated from the packed tensor is bit-identical to w_ref
+    deq = oracle.dequantize_packed(torch.from_numpy(packed), w_s, w_zp, bits, bias, group)
+    np.testing.assert_array_equal(to_bits(deq), g[f"wref_{key}"])
+    a = from_bits(g[f"a_{key}"], dtype)
+    c = oracle.mixed_precision_gemm_ref(a, w_ref)
+    np.testing.assert_array_equal(to_bits(c), g[f"c_{key}"])
