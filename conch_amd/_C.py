@@ -1,0 +1,145 @@
+"""ctypes binding of libconch_amd.so -- the C ABI declared in include/conch_amd.h.
+
+PyTorch is used above this layer only for device memory and streams; nothing torch-typed crosses
+the boundary (raw device pointers, sizes, strides, dtype enums, the hipStream_t as void*).
+The library must exist: there is no fallback path (`ConchLibraryError` otherwise).
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+from pathlib import Path
+
+import torch
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("CONCH_AMD_LIBRARY", _PKG / "libconch_amd.so"))
+
+# conch_dtype_t (include/conch_amd.h; values 0..8 follow conch/kernels/quantization/gemm.py:20-31)
+DT_FP32, DT_FP16, DT_BF16, DT_FP8_E4M3FN, DT_INT8, DT_UINT8, DT_INT32, DT_UINT32, DT_FP8_E5M2, DT_FP8_E4M3FNUZ = range(10)
+ZP_NONE, ZP_SCALAR, ZP_TENSOR = range(3)
+TUNE_GEMM_VARIANT = 0
+VARIANT_AUTO, VARIANT_GENERIC, VARIANT_MFMA_SIMPLE, VARIANT_MFMA_PINGPONG = range(4)
+
+TORCH_TO_DT = {
+    torch.float32: DT_FP32,
+    torch.float16: DT_FP16,
+    torch.bfloat16: DT_BF16,
+    torch.float8_e4m3fn: DT_FP8_E4M3FN,
+    torch.float8_e4m3fnuz: DT_FP8_E4M3FNUZ,
+    torch.int8: DT_INT8,
+    torch.uint8: DT_UINT8,
+    torch.int32: DT_INT32,
+    torch.float8_e5m2: DT_FP8_E5M2,
+}
+if hasattr(torch, "uint32"):
+    TORCH_TO_DT[torch.uint32] = DT_UINT32
+
+
+class ConchLibraryError(RuntimeError):
+    """libconch_amd.so is missing or unusable."""
+
+
+class ConchError(RuntimeError):
+    """A C-ABI call returned a non-zero status."""
+
+
+_I64 = c_int64
+_SIGNATURES = {
+    "conch_abi_version": (c_int, []),
+    "conch_last_error": (c_char_p, []),
+    "conch_set_tuning": (c_int, [c_int, c_int]),
+    "conch_get_tuning": (c_int, [c_int]),
+    "conch_device_count": (c_int, []),
+    "conch_static_scaled_int8_quant": (c_int, [c_void_p, c_void_p, c_void_p, _I64, _I64, _I64, _I64, c_int, c_void_p]),
+    "conch_static_scaled_fp8_quant": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, _I64, _I64, _I64, _I64, c_int, c_int, c_void_p],
+    ),
+    "conch_scaled_gemm": (
+        c_int,
+        [c_void_p] * 6 + [_I64] * 11 + [c_int, c_int, c_void_p],
+    ),
+    "conch_time_scaled_gemm": (
+        c_int,
+        [c_void_p] * 6 + [_I64] * 11 + [c_int, c_int, c_void_p, c_int, ctypes.POINTER(c_float)],
+    ),
+    "conch_mixed_precision_gemm": (
+        c_int,
+        [c_void_p] * 5 + [_I64] * 8 + [c_int] * 6 + [c_void_p],
+    ),
+    "conch_time_mixed_precision_gemm": (
+        c_int,
+        [c_void_p] * 5 + [_I64] * 8 + [c_int] * 6 + [c_void_p, c_int, ctypes.POINTER(c_float)],
+    ),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib: ctypes.CDLL | None = None
+
+
+def load() -> ctypes.CDLL:
+    """Load (once) and return the shared library; raise loudly if it is not there."""
+    global _lib  # noqa: PLW0603
+    if _lib is None:
+        if not LIB_PATH.exists():
+            msg = (
+                f"{LIB_PATH} not found: build it with `python -m conch_amd._build` "
+                "(conch_amd has no CPU / PyTorch fallback for its ops)"
+            )
+            raise ConchLibraryError(msg)
+        try:
+            lib = ctypes.CDLL(str(LIB_PATH))
+        except OSError as exc:
+            raise ConchLibraryError(f"cannot load {LIB_PATH}: {exc}") from exc
+        for name, (restype, argtypes) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = lib
+    return _lib
+
+
+def check(status: int, what: str) -> None:
+    """Turn a conch_status_t into a Python exception (include/conch_amd.h error convention)."""
+    if status == 0:
+        return
+    detail = (load().conch_last_error() or b"").decode("utf-8", "replace")
+    if status == 1:
+        raise ValueError(f"{what}: {detail}")
+    if status == 2:
+        raise NotImplementedError(f"{what}: {detail}")
+    raise ConchError(f"{what} failed with status {status}: {detail}")
+
+
+def dtype_id(dtype: torch.dtype) -> int:
+    try:
+        return TORCH_TO_DT[dtype]
+    except KeyError:
+        raise NotImplementedError(f"conch_amd: unsupported dtype {dtype}") from None
+
+
+def require_device(*tensors: torch.Tensor | None) -> None:
+    """The HIP path is the only path: refuse host tensors instead of silently computing on CPU."""
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            msg = "conch_amd ops need tensors on a ROCm device (cuda:N); there is no CPU fallback"
+            raise RuntimeError(msg)
+
+
+def ptr(t: torch.Tensor | None) -> int | None:
+    return None if t is None else t.data_ptr()
+
+
+def current_stream_handle(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def set_gemm_variant(variant: int) -> None:
+    check(load().conch_set_tuning(TUNE_GEMM_VARIANT, variant), "conch_set_tuning")
+
+
+def get_gemm_variant() -> int:
+    return load().conch_get_tuning(TUNE_GEMM_VARIANT)

@@ -1,0 +1,63 @@
+"""Build recipe for libconch_amd.so (hipcc, gfx950 only, in-tree output)."""
+
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+ROOT = PKG.parent
+CSRC = PKG / "csrc"
+LIB = PKG / "libconch_amd.so"
+SOURCES = ["capi.hip", "quant.hip", "gemm_generic.hip", "gemm_mfma.hip", "gemm_mixed.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = [
+    "--offload-arch=gfx950",
+    "-O3",
+    "-std=c++17",
+    "-fPIC",
+    "-fno-fast-math",
+    "-ffp-contract=off",  # the epilogues rely on separately rounded multiplies (bit parity)
+    f"-I{ROOT / 'include'}",
+    f"-I{CSRC}",
+]
+
+
+def _stale(target: Path, deps: list[Path]) -> bool:
+    if not target.exists():
+        return True
+    t = target.stat().st_mtime
+    return any(d.stat().st_mtime > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    """Compile every HIP source for gfx950 and link the shared library.  Returns its path."""
+    headers = sorted(CSRC.glob("*.hpp")) + [ROOT / "include" / "conch_amd.h", Path(__file__)]
+    objdir = PKG / "build"
+    objdir.mkdir(exist_ok=True)
+
+    def compile_one(src: str) -> Path:
+        s = CSRC / src
+        o = objdir / (s.stem + ".o")
+        if force or _stale(o, [s, *headers]):
+            cmd = [HIPCC, *FLAGS, "-c", str(s), "-o", str(o)]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.run(cmd, check=True)
+        return o
+
+    with ThreadPoolExecutor(max_workers=min(4, len(SOURCES))) as pool:
+        objs = list(pool.map(compile_one, SOURCES))
+    if force or _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,198 @@
+// extern "C" entry points of libconch_amd.so (declared in include/conch_amd.h): argument
+// validation, kernel selection, error strings.  No torch types, no exceptions across the boundary.
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+
+#include "common.hpp"
+#include "gemm.hpp"
+
+namespace conch {
+
+static thread_local char g_error[512] = "";
+static std::atomic<int> g_tuning[4] = {};
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_error, sizeof(g_error), fmt, ap);
+  va_end(ap);
+}
+
+int tuning(int key) { return (key >= 0 && key < 4) ? g_tuning[key].load() : 0; }
+
+namespace {
+
+bool is_in8(int dt) {
+  return dt == CONCH_DT_INT8 || dt == CONCH_DT_FP8_E4M3FN || dt == CONCH_DT_FP8_E4M3FNUZ;
+}
+bool is_out16(int dt) { return dt == CONCH_DT_FP16 || dt == CONCH_DT_BF16; }
+
+int check_scaled(const ScaledGemmArgs& p) {
+  CONCH_CHECK_ARG(p.m >= 0 && p.n >= 0 && p.k >= 0, "scaled_gemm: negative shape (%lld,%lld,%lld)",
+                  (long long)p.m, (long long)p.n, (long long)p.k);
+  if (!is_in8(p.in_dtype)) {
+    set_error("scaled_gemm: unsupported input dtype %d (want INT8, FP8_E4M3FN or FP8_E4M3FNUZ)", p.in_dtype);
+    return CONCH_ERR_UNSUPPORTED;
+  }
+  if (!is_out16(p.out_dtype)) {
+    set_error("scaled_gemm: unsupported output dtype %d (want FP16 or BF16)", p.out_dtype);
+    return CONCH_ERR_UNSUPPORTED;
+  }
+  if (p.m == 0 || p.n == 0) return CONCH_OK;
+  CONCH_CHECK_ARG(p.c && p.scale_a && p.scale_b, "scaled_gemm: NULL pointer (c=%p scale_a=%p scale_b=%p)",
+                  p.c, (const void*)p.scale_a, (const void*)p.scale_b);
+  CONCH_CHECK_ARG(p.k == 0 || (p.a && p.b), "scaled_gemm: NULL operand (a=%p b=%p)", p.a, p.b);
+  CONCH_CHECK_ARG(p.scale_a_numel == 1 || p.scale_a_numel == p.m,
+                  "scaled_gemm: scale_a has %lld elements, want 1 or M=%lld", (long long)p.scale_a_numel,
+                  (long long)p.m);
+  CONCH_CHECK_ARG(p.scale_b_numel == 1 || p.scale_b_numel == p.n,
+                  "scaled_gemm: scale_b has %lld elements, want 1 or N=%lld", (long long)p.scale_b_numel,
+                  (long long)p.n);
+  return CONCH_OK;
+}
+
+int run_scaled(const ScaledGemmArgs& p, hipStream_t stream) {
+  if (int rc = check_scaled(p)) return rc;
+  if (p.m == 0 || p.n == 0) return CONCH_OK;
+  const int variant = tuning(CONCH_TUNE_GEMM_VARIANT);
+  const bool fast_ok = scaled_gemm_mfma_supported(p);
+  if (variant == 1 || !fast_ok) {
+    if ((variant == 2 || variant == 3) && !fast_ok) {
+      set_error("scaled_gemm: MFMA variant %d forced but the layout contract is not met "
+                "(need K-contiguous A and B^T, K %% 128 == 0, 16-byte aligned rows)", variant);
+      return CONCH_ERR_UNSUPPORTED;
+    }
+    return launch_scaled_gemm_generic(p, stream);
+  }
+  return launch_scaled_gemm_mfma(p, variant == 2 ? 2 : 3, stream);
+}
+
+int check_mixed(const MixedGemmArgs& p) {
+  CONCH_CHECK_ARG(p.m >= 0 && p.n >= 0 && p.k >= 0, "mixed_precision_gemm: negative shape");
+  if (p.x_dtype != CONCH_DT_FP16 && p.x_dtype != CONCH_DT_BF16) {
+    set_error("mixed_precision_gemm: unsupported activation dtype %d (want FP16 or BF16)", p.x_dtype);
+    return CONCH_ERR_UNSUPPORTED;
+  }
+  if (!is_out16(p.out_dtype)) {
+    set_error("mixed_precision_gemm: unsupported output dtype %d (want FP16 or BF16)", p.out_dtype);
+    return CONCH_ERR_UNSUPPORTED;
+  }
+  CONCH_CHECK_ARG(p.bits == 1 || p.bits == 2 || p.bits == 4 || p.bits == 8 || p.bits == 16 || p.bits == 32,
+                  "mixed_precision_gemm: weight_bits %d does not divide 32", p.bits);
+  CONCH_CHECK_ARG(p.group_size > 0, "mixed_precision_gemm: group_size %d", p.group_size);
+  CONCH_CHECK_ARG(p.zp_mode >= CONCH_ZP_NONE && p.zp_mode <= CONCH_ZP_TENSOR,
+                  "mixed_precision_gemm: bad zp_mode %d", p.zp_mode);
+  if (p.m == 0 || p.n == 0) return CONCH_OK;
+  CONCH_CHECK_ARG(p.c, "mixed_precision_gemm: NULL output");
+  CONCH_CHECK_ARG(p.k == 0 || (p.x && p.w_q && p.w_s), "mixed_precision_gemm: NULL operand");
+  CONCH_CHECK_ARG(p.zp_mode == CONCH_ZP_NONE || p.w_zp, "mixed_precision_gemm: zp_mode %d but w_zp NULL",
+                  p.zp_mode);
+  CONCH_CHECK_ARG(p.k % (32 / p.bits) == 0, "mixed_precision_gemm: K=%lld not a multiple of %d",
+                  (long long)p.k, 32 / p.bits);
+  return CONCH_OK;
+}
+
+int run_mixed(const MixedGemmArgs& p, hipStream_t stream) {
+  if (int rc = check_mixed(p)) return rc;
+  if (p.m == 0 || p.n == 0) return CONCH_OK;
+  const int variant = tuning(CONCH_TUNE_GEMM_VARIANT);
+  const bool fast_ok = mixed_gemm_mfma_supported(p);
+  if (variant == 1 || !fast_ok) {
+    if ((variant == 2 || variant == 3) && !fast_ok) {
+      set_error("mixed_precision_gemm: MFMA variant %d forced but the layout contract is not met", variant);
+      return CONCH_ERR_UNSUPPORTED;
+    }
+    return launch_mixed_gemm_generic(p, stream);
+  }
+  return launch_mixed_gemm_mfma(p, variant == 2 ? 2 : 3, stream);
+}
+
+template <class F>
+int time_loop(F&& launch, hipStream_t stream, int iters, float* avg_ms) {
+  CONCH_CHECK_ARG(iters > 0 && avg_ms, "timing: iters=%d avg_ms=%p", iters, (void*)avg_ms);
+  hipEvent_t e0, e1;
+  CONCH_HIP(hipEventCreate(&e0));
+  CONCH_HIP(hipEventCreate(&e1));
+  int rc = CONCH_OK;
+  CONCH_HIP(hipEventRecord(e0, stream));
+  for (int i = 0; i < iters && rc == CONCH_OK; ++i) rc = launch();
+  CONCH_HIP(hipEventRecord(e1, stream));
+  CONCH_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  CONCH_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *avg_ms = ms / (float)iters;
+  return rc;
+}
+
+}  // namespace
+}  // namespace conch
+
+using namespace conch;
+
+extern "C" int conch_abi_version(void) { return CONCH_AMD_ABI_VERSION; }
+extern "C" const char* conch_last_error(void) { return g_error; }
+
+extern "C" int conch_set_tuning(int key, int value) {
+  CONCH_CHECK_ARG(key >= 0 && key < 4, "conch_set_tuning: unknown key %d", key);
+  g_tuning[key].store(value);
+  return CONCH_OK;
+}
+extern "C" int conch_get_tuning(int key) { return tuning(key); }
+
+extern "C" int conch_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+extern "C" int conch_scaled_gemm(void* c, const void* a, const void* b, const float* scale_a,
+                                 const float* scale_b, const void* bias, int64_t m, int64_t n, int64_t k,
+                                 int64_t a_stride_m, int64_t a_stride_k, int64_t b_stride_k,
+                                 int64_t b_stride_n, int64_t c_stride_m, int64_t c_stride_n,
+                                 int64_t scale_a_numel, int64_t scale_b_numel, int in_dtype, int out_dtype,
+                                 void* stream) {
+  const ScaledGemmArgs p{c, a, b, scale_a, scale_b, bias, m, n, k, a_stride_m, a_stride_k, b_stride_k,
+                         b_stride_n, c_stride_m, c_stride_n, scale_a_numel, scale_b_numel, in_dtype, out_dtype};
+  return run_scaled(p, (hipStream_t)stream);
+}
+
+extern "C" int conch_time_scaled_gemm(void* c, const void* a, const void* b, const float* scale_a,
+                                      const float* scale_b, const void* bias, int64_t m, int64_t n,
+                                      int64_t k, int64_t a_stride_m, int64_t a_stride_k, int64_t b_stride_k,
+                                      int64_t b_stride_n, int64_t c_stride_m, int64_t c_stride_n,
+                                      int64_t scale_a_numel, int64_t scale_b_numel, int in_dtype,
+                                      int out_dtype, void* stream, int iters, float* avg_ms) {
+  const ScaledGemmArgs p{c, a, b, scale_a, scale_b, bias, m, n, k, a_stride_m, a_stride_k, b_stride_k,
+                         b_stride_n, c_stride_m, c_stride_n, scale_a_numel, scale_b_numel, in_dtype, out_dtype};
+  hipStream_t s = (hipStream_t)stream;
+  return time_loop([&] { return run_scaled(p, s); }, s, iters, avg_ms);
+}
+
+extern "C" int conch_mixed_precision_gemm(void* c, const void* x, const int32_t* w_q_packed, const void* w_s,
+                                          const int32_t* w_zp, int64_t m, int64_t n, int64_t k,
+                                          int64_t x_stride_m, int64_t wq_stride_k, int64_t ws_stride_g,
+                                          int64_t wzp_stride_g, int64_t c_stride_m, int weight_bits,
+                                          int weight_bias, int group_size, int zp_mode, int x_dtype,
+                                          int out_dtype, void* stream) {
+  const MixedGemmArgs p{c, x, w_q_packed, w_s, w_zp, m, n, k, x_stride_m, wq_stride_k, ws_stride_g,
+                        wzp_stride_g, c_stride_m, weight_bits, weight_bias, group_size, zp_mode, x_dtype,
+                        out_dtype};
+  return run_mixed(p, (hipStream_t)stream);
+}
+
+extern "C" int conch_time_mixed_precision_gemm(void* c, const void* x, const int32_t* w_q_packed,
+                                               const void* w_s, const int32_t* w_zp, int64_t m, int64_t n,
+                                               int64_t k, int64_t x_stride_m, int64_t wq_stride_k,
+                                               int64_t ws_stride_g, int64_t wzp_stride_g, int64_t c_stride_m,
+                                               int weight_bits, int weight_bias, int group_size, int zp_mode,
+                                               int x_dtype, int out_dtype, void* stream, int iters,
+                                               float* avg_ms) {
+  const MixedGemmArgs p{c, x, w_q_packed, w_s, w_zp, m, n, k, x_stride_m, wq_stride_k, ws_stride_g,
+                        wzp_stride_g, c_stride_m, weight_bits, weight_bias, group_size, zp_mode, x_dtype,
+                        out_dtype};
+  hipStream_t s = (hipStream_t)stream;
+  return time_loop([&] { return run_mixed(p, s); }, s, iters, avg_ms);
+}

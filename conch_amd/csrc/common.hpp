@@ -1,0 +1,150 @@
+// Shared device/host helpers for the gfx950 quantized-matmul kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "conch_amd.h"
+
+namespace conch {
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing (host)
+// ---------------------------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int tuning(int key);
+
+#define CONCH_CHECK_ARG(cond, ...)           \
+  do {                                       \
+    if (!(cond)) {                           \
+      ::conch::set_error(__VA_ARGS__);       \
+      return CONCH_ERR_INVALID_ARGUMENT;     \
+    }                                        \
+  } while (0)
+
+#define CONCH_HIP(expr)                                                                   \
+  do {                                                                                    \
+    hipError_t err__ = (expr);                                                            \
+    if (err__ != hipSuccess) {                                                            \
+      ::conch::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(err__), __FILE__, \
+                         __LINE__);                                                       \
+      return CONCH_ERR_HIP;                                                               \
+    }                                                                                     \
+  } while (0)
+
+inline int check_launch(const char* what) {
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) {
+    set_error("launch of %s failed: %s", what, hipGetErrorString(err));
+    return CONCH_ERR_HIP;
+  }
+  return CONCH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// vector register types (wave64 MFMA operand shapes)
+// ---------------------------------------------------------------------------------------------
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------
+// scalar conversions (device).  float -> half/bf16 are round-to-nearest-even, NaN preserving
+// (hipcc lowers the casts to v_cvt_f16_f32 / v_cvt_pk_bf16_f32 on gfx950).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bits_to_float(uint32_t u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ uint32_t float_to_bits(float f) { return __builtin_bit_cast(uint32_t, f); }
+
+__device__ __forceinline__ float half_bits_to_float(uint16_t h) {
+  return (float)__builtin_bit_cast(_Float16, h);
+}
+__device__ __forceinline__ float bf16_bits_to_float(uint16_t h) {
+  return bits_to_float(((uint32_t)h) << 16);
+}
+__device__ __forceinline__ uint16_t float_to_half_bits(float f) {
+  return __builtin_bit_cast(uint16_t, (_Float16)f);
+}
+__device__ __forceinline__ uint16_t float_to_bf16_bits(float f) {
+  return __builtin_bit_cast(uint16_t, (__bf16)f);
+}
+
+template <int DT>
+__device__ __forceinline__ float load_as_float(const void* p, int64_t idx) {
+  if constexpr (DT == CONCH_DT_FP32) {
+    return ((const float*)p)[idx];
+  } else if constexpr (DT == CONCH_DT_FP16) {
+    return half_bits_to_float(((const uint16_t*)p)[idx]);
+  } else {
+    static_assert(DT == CONCH_DT_BF16, "unsupported dtype");
+    return bf16_bits_to_float(((const uint16_t*)p)[idx]);
+  }
+}
+
+template <int DT>
+__device__ __forceinline__ float bits16_to_float(uint16_t h) {
+  if constexpr (DT == CONCH_DT_FP16) return half_bits_to_float(h);
+  else return bf16_bits_to_float(h);
+}
+template <int DT>
+__device__ __forceinline__ uint16_t float_to_bits16(float f) {
+  if constexpr (DT == CONCH_DT_FP16) return float_to_half_bits(f);
+  else return float_to_bf16_bits(f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// FP8 E4M3 codec (device).  FNUZ=false: OCP e4m3fn (bias 7, NaN 0x7F/0xFF, has -0);
+// FNUZ=true: e4m3fnuz (bias 8, NaN 0x80, no -0).  Encoding is round-to-nearest-even of a value
+// already clamped to +-max (so no overflow handling is needed beyond NaN propagation).
+// ---------------------------------------------------------------------------------------------
+template <bool FNUZ>
+__device__ __forceinline__ float fp8_max() { return FNUZ ? 240.0f : 448.0f; }
+
+template <bool FNUZ>
+__device__ __forceinline__ uint32_t encode_fp8_sw(float v) {
+  constexpr int BIAS = FNUZ ? 8 : 7;
+  const uint32_t u = float_to_bits(v);
+  const uint32_t sign = u >> 31;
+  const uint32_t a = u & 0x7fffffffu;
+  if (a > 0x7f800000u) return FNUZ ? 0x80u : (0x7fu | (sign << 7));
+  uint32_t code;
+  const float av = bits_to_float(a);
+  const float min_normal = bits_to_float((uint32_t)(127 + 1 - BIAS) << 23);
+  if (av < min_normal) {
+    // subnormal grid: multiples of 2^(1-BIAS-3); rint is round-half-even.  8 -> smallest normal.
+    code = (uint32_t)__builtin_rintf(av * bits_to_float((uint32_t)(127 + BIAS + 2) << 23));
+  } else {
+    const uint32_t r = a + 0x7ffffu + ((a >> 20) & 1u);  // RNE on the 20 dropped mantissa bits
+    code = (r >> 20) - ((uint32_t)(127 - BIAS) << 3);
+  }
+  if (FNUZ) return code == 0 ? 0u : (code | (sign << 7));
+  return code | (sign << 7);
+}
+
+template <bool FNUZ>
+__device__ __forceinline__ float decode_fp8_sw(uint32_t c) {
+  constexpr int BIAS = FNUZ ? 8 : 7;
+  const uint32_t sign = (c >> 7) & 1u;
+  const uint32_t e = (c >> 3) & 0xfu;
+  const uint32_t m = c & 7u;
+  if (FNUZ) {
+    if (c == 0x80u) return bits_to_float(0x7fc00000u);
+  } else {
+    if ((c & 0x7fu) == 0x7fu) return bits_to_float(0x7fc00000u | (sign << 31));
+  }
+  float v;
+  if (e == 0) {
+    v = (float)m * bits_to_float((uint32_t)(127 + 1 - BIAS - 3) << 23);
+  } else {
+    v = bits_to_float(((e + 127 - BIAS) << 23) | (m << 20));
+  }
+  return sign ? -v : v;
+}
+
+}  // namespace conch

@@ -1,0 +1,53 @@
+// Argument blocks shared by the GEMM kernels and the C-ABI dispatcher.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace conch {
+
+// scaled_gemm: C = out( sb * (sa * (A @ B)) ) + bias.  Strides in ELEMENTS.
+struct ScaledGemmArgs {
+  void* c;
+  const void* a;
+  const void* b;
+  const float* scale_a;
+  const float* scale_b;
+  const void* bias;
+  int64_t m, n, k;
+  int64_t a_stride_m, a_stride_k;
+  int64_t b_stride_k, b_stride_n;
+  int64_t c_stride_m, c_stride_n;
+  int64_t scale_a_numel, scale_b_numel;
+  int in_dtype, out_dtype;
+};
+
+// mixed_precision_gemm: C = out( X @ dequant(Wq) ).  Strides in ELEMENTS of the respective array.
+struct MixedGemmArgs {
+  void* c;
+  const void* x;
+  const int32_t* w_q;
+  const void* w_s;
+  const int32_t* w_zp;
+  int64_t m, n, k;
+  int64_t x_stride_m;
+  int64_t wq_stride_k;
+  int64_t ws_stride_g;
+  int64_t wzp_stride_g;
+  int64_t c_stride_m;
+  int bits, weight_bias, group_size, zp_mode;
+  int x_dtype, out_dtype;
+};
+
+// gemm_generic.hip
+int launch_scaled_gemm_generic(const ScaledGemmArgs& p, hipStream_t stream);
+int launch_mixed_gemm_generic(const MixedGemmArgs& p, hipStream_t stream);
+
+// gemm_mfma.hip -- LDS-tiled MFMA kernels.  `variant`: 2 = simple double-buffered loop,
+// 3 = 8-phase ping-pong pipeline.  *_supported() say whether the layout contract is met.
+bool scaled_gemm_mfma_supported(const ScaledGemmArgs& p);
+int launch_scaled_gemm_mfma(const ScaledGemmArgs& p, int variant, hipStream_t stream);
+bool mixed_gemm_mfma_supported(const MixedGemmArgs& p);
+int launch_mixed_gemm_mfma(const MixedGemmArgs& p, int variant, hipStream_t stream);
+
+}  // namespace conch

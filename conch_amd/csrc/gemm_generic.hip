@@ -1,0 +1,112 @@
+// Shape- and stride-agnostic GEMM kernels (no MFMA, no alignment requirements).
+//
+// These are the "always correct" device paths: any M/N/K, any element strides, every dtype
+// combination the C ABI accepts.  The dispatcher (capi.hip) uses them when a request does not meet
+// the layout contract of the MFMA kernels (gemm_mfma.hip) and tests use them as an on-device
+// cross-check.  One thread per output element, 16x16 thread tiles.
+#include "common.hpp"
+#include "gemm.hpp"
+
+namespace conch {
+namespace {
+
+template <int IN_DT>
+__device__ __forceinline__ float decode8(uint8_t c) {
+  if constexpr (IN_DT == CONCH_DT_FP8_E4M3FN) return decode_fp8_sw<false>(c);
+  else if constexpr (IN_DT == CONCH_DT_FP8_E4M3FNUZ) return decode_fp8_sw<true>(c);
+  else return (float)(int8_t)c;
+}
+
+template <int IN_DT, int OUT_DT>
+__global__ __launch_bounds__(256) void scaled_gemm_generic_kernel(ScaledGemmArgs p) {
+  const int64_t n = (int64_t)blockIdx.x * 16 + (threadIdx.x & 15);
+  const int64_t m = (int64_t)blockIdx.y * 16 + (threadIdx.x >> 4);
+  if (m >= p.m || n >= p.n) return;
+  const uint8_t* a = (const uint8_t*)p.a + m * p.a_stride_m;
+  const uint8_t* b = (const uint8_t*)p.b + n * p.b_stride_n;
+  float accf;
+  if constexpr (IN_DT == CONCH_DT_INT8) {
+    int acc = 0;  // exact
+    for (int64_t k = 0; k < p.k; ++k)
+      acc += (int)(int8_t)a[k * p.a_stride_k] * (int)(int8_t)b[k * p.b_stride_k];
+    accf = (float)acc;
+  } else {
+    float acc = 0.f;
+    for (int64_t k = 0; k < p.k; ++k)
+      acc = fmaf(decode8<IN_DT>(a[k * p.a_stride_k]), decode8<IN_DT>(b[k * p.b_stride_k]), acc);
+    accf = acc;
+  }
+  // reference/quantization/scaled_gemm.py:20-25: scale_a first, then scale_b, cast, then bias
+  const float sa = p.scale_a[p.scale_a_numel == 1 ? 0 : m];
+  const float sb = p.scale_b[p.scale_b_numel == 1 ? 0 : n];
+  float v = sa * accf;
+  v = sb * v;
+  uint16_t o = float_to_bits16<OUT_DT>(v);
+  if (p.bias) {
+    const float bsum = bits16_to_float<OUT_DT>(o) + bits16_to_float<OUT_DT>(((const uint16_t*)p.bias)[n]);
+    o = float_to_bits16<OUT_DT>(bsum);
+  }
+  ((uint16_t*)p.c)[m * p.c_stride_m + n * p.c_stride_n] = o;
+}
+
+template <int X_DT, int OUT_DT>
+__global__ __launch_bounds__(256) void mixed_gemm_generic_kernel(MixedGemmArgs p) {
+  const int64_t n = (int64_t)blockIdx.x * 16 + (threadIdx.x & 15);
+  const int64_t m = (int64_t)blockIdx.y * 16 + (threadIdx.x >> 4);
+  if (m >= p.m || n >= p.n) return;
+  const int per_word = 32 / p.bits;
+  const uint32_t mask = (p.bits == 32) ? 0xffffffffu : ((1u << p.bits) - 1u);
+  const uint16_t* x = (const uint16_t*)p.x + m * p.x_stride_m;
+  const int zp_scalar = p.zp_mode == CONCH_ZP_SCALAR ? p.w_zp[0] : 0;
+  float acc = 0.f;
+  for (int64_t k = 0; k < p.k; ++k) {
+    const uint32_t word = (uint32_t)p.w_q[(k / per_word) * p.wq_stride_k + n];
+    int q = (int)((word >> ((k % per_word) * p.bits)) & mask) - p.weight_bias;
+    const int64_t g = k / p.group_size;
+    if (p.zp_mode == CONCH_ZP_TENSOR) q -= p.w_zp[g * p.wzp_stride_g + n];
+    else q -= zp_scalar;
+    const float s = bits16_to_float<X_DT>(((const uint16_t*)p.w_s)[g * p.ws_stride_g + n]);
+    // (q exact) * s: the fp32 product is exact, so rounding it to X_DT is the single rounding of
+    // the reference's fp16/bf16 multiply (kernels/quantization/gemm.py:201-210).
+    const float w = bits16_to_float<X_DT>(float_to_bits16<X_DT>((float)q * s));
+    acc = fmaf(bits16_to_float<X_DT>(x[k]), w, acc);
+  }
+  ((uint16_t*)p.c)[m * p.c_stride_m + n] = float_to_bits16<OUT_DT>(acc);
+}
+
+}  // namespace
+
+int launch_scaled_gemm_generic(const ScaledGemmArgs& p, hipStream_t stream) {
+  const dim3 grid((unsigned)((p.n + 15) / 16), (unsigned)((p.m + 15) / 16));
+#define CONCH_LAUNCH(IN, OUT)                                                                  \
+  hipLaunchKernelGGL((scaled_gemm_generic_kernel<IN, OUT>), grid, dim3(256), 0, stream, p);    \
+  return check_launch("scaled_gemm_generic")
+  if (p.out_dtype == CONCH_DT_FP16) {
+    if (p.in_dtype == CONCH_DT_INT8) { CONCH_LAUNCH(CONCH_DT_INT8, CONCH_DT_FP16); }
+    if (p.in_dtype == CONCH_DT_FP8_E4M3FN) { CONCH_LAUNCH(CONCH_DT_FP8_E4M3FN, CONCH_DT_FP16); }
+    if (p.in_dtype == CONCH_DT_FP8_E4M3FNUZ) { CONCH_LAUNCH(CONCH_DT_FP8_E4M3FNUZ, CONCH_DT_FP16); }
+  } else {
+    if (p.in_dtype == CONCH_DT_INT8) { CONCH_LAUNCH(CONCH_DT_INT8, CONCH_DT_BF16); }
+    if (p.in_dtype == CONCH_DT_FP8_E4M3FN) { CONCH_LAUNCH(CONCH_DT_FP8_E4M3FN, CONCH_DT_BF16); }
+    if (p.in_dtype == CONCH_DT_FP8_E4M3FNUZ) { CONCH_LAUNCH(CONCH_DT_FP8_E4M3FNUZ, CONCH_DT_BF16); }
+  }
+#undef CONCH_LAUNCH
+  set_error("scaled_gemm: unsupported dtype combination in=%d out=%d", p.in_dtype, p.out_dtype);
+  return CONCH_ERR_UNSUPPORTED;
+}
+
+int launch_mixed_gemm_generic(const MixedGemmArgs& p, hipStream_t stream) {
+  const dim3 grid((unsigned)((p.n + 15) / 16), (unsigned)((p.m + 15) / 16));
+#define CONCH_LAUNCH(X, OUT)                                                                  \
+  hipLaunchKernelGGL((mixed_gemm_generic_kernel<X, OUT>), grid, dim3(256), 0, stream, p);     \
+  return check_launch("mixed_gemm_generic")
+  if (p.x_dtype == CONCH_DT_FP16 && p.out_dtype == CONCH_DT_FP16) { CONCH_LAUNCH(CONCH_DT_FP16, CONCH_DT_FP16); }
+  if (p.x_dtype == CONCH_DT_FP16 && p.out_dtype == CONCH_DT_BF16) { CONCH_LAUNCH(CONCH_DT_FP16, CONCH_DT_BF16); }
+  if (p.x_dtype == CONCH_DT_BF16 && p.out_dtype == CONCH_DT_BF16) { CONCH_LAUNCH(CONCH_DT_BF16, CONCH_DT_BF16); }
+  if (p.x_dtype == CONCH_DT_BF16 && p.out_dtype == CONCH_DT_FP16) { CONCH_LAUNCH(CONCH_DT_BF16, CONCH_DT_FP16); }
+#undef CONCH_LAUNCH
+  set_error("mixed_precision_gemm: unsupported dtype combination x=%d out=%d", p.x_dtype, p.out_dtype);
+  return CONCH_ERR_UNSUPPORTED;
+}
+
+}  // namespace conch

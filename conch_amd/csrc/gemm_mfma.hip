@@ -1,0 +1,467 @@
+// LDS-tiled MFMA GEMM kernels for gfx950 (MI355X): scaled_gemm (int8 / fp8-e4m3fn inputs).
+//
+// Replaces the GemLite-derived Triton kernel of the reference
+// (conch/kernels/quantization/gemm.py:219-457, tiles 128x64x64, 8 warps) with a CDNA4-first design:
+//
+//   * "NT" layout contract: A is [M][K], B is consumed as B^T = [N][K]; both K-contiguous with
+//     1-byte elements (exactly what the reference's tests/benchmarks pass: b = (N,K).T).
+//   * 256x256 output tile per 512-thread workgroup (8 wave64s as 2(M) x 4(N), 128x64 per wave),
+//     K advanced 128 BYTES per step, so fp8 / int8 / (16-bit, see gemm_mixed) share one geometry.
+//   * operands stream global -> LDS with `buffer_load_dwordx4 ... lds` (LDS-DMA, no VGPR staging):
+//     a 16 KiB "unit" = 128 rows x 128 B, built of 8-row x 128-B subtiles (one wave-instruction
+//     each: full 128-B lines from HBM/L2).  The 16-byte chunks of a row are XOR-swizzled
+//     (chunk ^= (row>>1)&7) on the SOURCE side so that every ds_read_b128 fragment read is
+//     bank-conflict free (tools/lds_bank_check.py).
+//   * fp8 uses v_mfma_scale_f32_16x16x128_f8f6f4 with unit E8M0 scales (the only fp8 form that
+//     reaches the 2x-bf16 rate on gfx950); int8 uses v_mfma_i32_16x16x64_i8 (exact int32).
+//   * MFMA operands are swapped (D rows = n, D cols = m) and the n rows of a unit are permuted at
+//     staging time so that a lane ends up with 8 consecutive n of one output row: 16-byte stores.
+//   * epilogue fused: sb * (sa * float(acc)) in that order (bit-parity with
+//     conch/reference/quantization/scaled_gemm.py:20-25), RNE cast, bias add in the output dtype.
+//   * variant 3 runs the K loop as a 4-phase-per-K-step ping-pong: the two waves that share a SIMD
+//     alternate between an MFMA cluster and a {ds_read, LDS-DMA issue} segment, with counted
+//     vmcnt waits so that four units stay in flight across the raw s_barriers.
+//   * workgroup ids are remapped XCD-aware (8 XCDs, private L2s) on top of a GROUP_M raster.
+#include "common.hpp"
+#include "gemm.hpp"
+
+namespace conch {
+namespace {
+
+constexpr int kThreads = 512;
+constexpr int kTileM = 256;
+constexpr int kTileN = 256;
+constexpr int kStepBytes = 128;                     // K bytes per LDS row / per K step
+constexpr int kUnitBytes = 128 * kStepBytes;        // 16 KiB: 128 rows
+constexpr int kBufBytes = 4 * kUnitBytes;           // U1, V1, V2, U2
+constexpr int kLdsBytes = 2 * kBufBytes;            // double buffered: 128 KiB
+constexpr int kGroupM = 4;
+
+// Stream order of the units of one K step.  U = rows of A (m), V = rows of B^T (n).
+// U1/U2 hold the first/second 64 rows of BOTH wave-rows' 128-row m ranges, V1/V2 the
+// first/second 32 rows of all four wave-columns' 64-row n ranges, so that a unit is needed by
+// every wave in the same phase.
+enum { kU1 = 0, kV1 = 1, kV2 = 2, kU2 = 3 };
+
+enum { kMmaFp8 = 0, kMmaInt8 = 1 };
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+struct Frag {
+  i32x4 lo;  // 16-byte chunk g      of the 128-byte K row
+  i32x4 hi;  // 16-byte chunk g + 4
+};
+
+template <int MMA> struct AccT { typedef f32x4 type; };
+template <> struct AccT<kMmaInt8> { typedef i32x4 type; };
+
+// D (16x16) += rows(fa) x cols(fb) over the 128 K-bytes both fragments hold.  The MFMA pairs
+// element j of k-group g of A with element j of k-group g of B, so any K permutation that is the
+// same on both sides is legal: k-group g holds bytes [16g,16g+16) and [64+16g, 64+16g+16).
+template <int MMA>
+__device__ __forceinline__ void mma_step(typename AccT<MMA>::type& acc, const Frag& fa, const Frag& fb) {
+  if constexpr (MMA == kMmaFp8) {
+    const i32x8 a = {fa.lo[0], fa.lo[1], fa.lo[2], fa.lo[3], fa.hi[0], fa.hi[1], fa.hi[2], fa.hi[3]};
+    const i32x8 b = {fb.lo[0], fb.lo[1], fb.lo[2], fb.lo[3], fb.hi[0], fb.hi[1], fb.hi[2], fb.hi[3]};
+    // cbsz = blgp = 0: both operands fp8 e4m3; E8M0 scale 127 = 2^0 for every 32-element block.
+    acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, acc, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+  } else {
+    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa.lo, fb.lo, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa.hi, fb.hi, acc, 0, 0, 0);
+  }
+}
+
+struct TileCoord {
+  int tm, tn;
+};
+
+// XCD-aware + GROUP_M rasterisation.  Workgroups are dealt round-robin over the 8 XCDs, so ids
+// b and b+8 share an L2: give each XCD a contiguous run of the GROUP_M-ordered tile list
+// (bijective for any grid size).  Pure speed; correctness does not depend on placement.
+__device__ __forceinline__ TileCoord map_tile(int bid, int tiles_m, int tiles_n) {
+  const int nwg = tiles_m * tiles_n;
+  const int xcd = bid & 7;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int per_group = kGroupM * tiles_n;
+  const int group = lin / per_group;
+  const int first_m = group * kGroupM;
+  const int gsz = min(tiles_m - first_m, kGroupM);
+  const int in_group = lin - group * per_group;
+  TileCoord t;
+  t.tm = first_m + in_group % gsz;
+  t.tn = in_group / gsz;
+  return t;
+}
+
+// Per-lane state of the LDS-DMA staging: byte offset of this lane's 16-byte source chunk for each
+// (unit kind, j) wave-instruction, relative to the A / B^T base.
+struct StageOffsets {
+  int off[4][2];
+};
+
+__device__ __forceinline__ StageOffsets make_stage_offsets(int wave, int lane, int bm0, int bn0,
+                                                           int m_max, int n_max, int lda, int ldb) {
+  StageOffsets s;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int rho = 16 * wave + 8 * j + (lane >> 3);    // row of the unit this lane feeds
+    const int chunk = (lane & 7) ^ ((rho >> 1) & 7);    // source chunk that lands at lane&7
+    // U kinds: unit row -> block m
+    const int mrow = (rho >> 6) * 128 + (rho & 63);
+    // V kinds: unit row -> block n, permuted so that MFMA D rows 4g+e of tile t are n = 8g+e+4t
+    const int r5 = rho & 31, r = r5 & 15, t = r5 >> 4;
+    const int nrow = (rho >> 5) * 64 + 8 * (r >> 2) + (r & 3) + 4 * t;
+    s.off[kU1][j] = min(bm0 + mrow, m_max) * lda + chunk * 16;
+    s.off[kU2][j] = min(bm0 + mrow + 64, m_max) * lda + chunk * 16;
+    s.off[kV1][j] = min(bn0 + nrow, n_max) * ldb + chunk * 16;
+    s.off[kV2][j] = min(bn0 + nrow + 32, n_max) * ldb + chunk * 16;
+  }
+  return s;
+}
+
+struct Srcs {
+  __amdgpu_buffer_rsrc_t a;
+  __amdgpu_buffer_rsrc_t b;
+};
+
+// Issue the two LDS-DMA wave-instructions this wave contributes to unit `KIND` of K step `tile`.
+template <int KIND>
+__device__ __forceinline__ void stage_unit(char* lds, const Srcs& src, const StageOffsets& so, int wave,
+                                           int tile) {
+  const int buf = tile & 1;
+  const int koff = tile * kStepBytes;
+  char* dst = lds + buf * kBufBytes + KIND * kUnitBytes + wave * 2048;
+  if constexpr (KIND == kU1 || KIND == kU2) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(src.a, (lds_void_t*)dst, 16, so.off[KIND][0], koff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(src.a, (lds_void_t*)(dst + 1024), 16, so.off[KIND][1], koff, 0, 0);
+  } else {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(src.b, (lds_void_t*)dst, 16, so.off[KIND][0], koff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(src.b, (lds_void_t*)(dst + 1024), 16, so.off[KIND][1], koff, 0, 0);
+  }
+}
+
+// `off` is a byte offset from the (1024-aligned) LDS base; every term of it except the chunk is a
+// multiple of 128, so chunk g+4 = (g ^ swizzle) ^ 4 is simply off ^ 64.
+__device__ __forceinline__ Frag read_frag(const char* lds, int off) {
+  Frag f;
+  f.lo = *(const i32x4*)(lds + off);
+  f.hi = *(const i32x4*)(lds + (off ^ 64));
+  return f;
+}
+
+#define CONCH_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  if constexpr (N == 0) CONCH_VMCNT(0);
+  else if constexpr (N == 2) CONCH_VMCNT(2);
+  else if constexpr (N == 4) CONCH_VMCNT(4);
+  else if constexpr (N == 6) CONCH_VMCNT(6);
+  else if constexpr (N == 8) CONCH_VMCNT(8);
+  // N < 0: no wait
+}
+
+// The register state of one wave: 8 (m) x 4 (n) accumulator tiles of 16x16.
+template <int MMA>
+struct WaveTile {
+  typename AccT<MMA>::type acc[8][4];
+  Frag fm[4];      // current 64-row m sub-half
+  Frag fn[2][2];   // both 32-row n sub-halves
+};
+
+// One phase = {optional fragment reads, optional LDS-DMA issue, counted vmcnt} barrier {MFMAs} barrier.
+// PHASE 0: read n0,m0 -> Q(m0,n0); 1: read n1 -> Q(m0,n1); 2: read m1 -> Q(m1,n1); 3: Q(m1,n0).
+template <int MMA, int PHASE, bool PINGPONG>
+__device__ __forceinline__ void phase_reads(WaveTile<MMA>& w, const char* lds, int buf, int m_base, int n_base) {
+  if constexpr (PHASE == 0) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) w.fn[0][t] = read_frag(lds, buf + kV1 * kUnitBytes + n_base + t * 2048);
+    if constexpr (PINGPONG) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w.fm[i] = read_frag(lds, buf + kU1 * kUnitBytes + m_base + i * 2048);
+  } else if constexpr (PHASE == 1) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) w.fn[1][t] = read_frag(lds, buf + kV2 * kUnitBytes + n_base + t * 2048);
+  } else if constexpr (PHASE == 2) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w.fm[i] = read_frag(lds, buf + kU2 * kUnitBytes + m_base + i * 2048);
+  }
+}
+
+template <int MMA, int PHASE>
+__device__ __forceinline__ void phase_mma(WaveTile<MMA>& w) {
+  constexpr int MH = (PHASE >= 2) ? 1 : 0;                 // m sub-half
+  constexpr int NH = (PHASE == 1 || PHASE == 2) ? 1 : 0;   // n sub-half
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) mma_step<MMA>(w.acc[MH * 4 + i][NH * 2 + t], w.fn[NH][t], w.fm[i]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// epilogue
+// ---------------------------------------------------------------------------------------------
+template <int MMA, int OUT_DT>
+__device__ __forceinline__ void epilogue(const WaveTile<MMA>& w, const ScaledGemmArgs& p, int bm0, int bn0,
+                                         int wr, int wc, int lane) {
+  const int g = lane >> 4, jm = lane & 15;
+  const bool sa_vec = p.scale_a_numel != 1;
+  const bool sb_vec = p.scale_b_numel != 1;
+  const bool vec_store = (p.c_stride_m % 8 == 0) && (((uintptr_t)p.c & 15) == 0);
+  const uint16_t* bias = (const uint16_t*)p.bias;
+#pragma unroll
+  for (int nh = 0; nh < 2; ++nh) {
+    const int n0 = bn0 + wc * 64 + nh * 32 + 8 * g;
+    float sb[8];
+    float bs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int n = min(n0 + e, (int)p.n - 1);
+      sb[e] = p.scale_b[sb_vec ? n : 0];
+      bs[e] = bias ? bits16_to_float<OUT_DT>(bias[n]) : 0.f;
+    }
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+      const int m = bm0 + wr * 128 + mt * 16 + jm;
+      if (m >= p.m) continue;
+      const float sa = p.scale_a[sa_vec ? m : 0];
+      uint16_t o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float accf = (float)w.acc[mt][nh * 2 + (e >> 2)][e & 3];
+        float v = sa * accf;  // scaled_gemm.py:21
+        v = sb[e] * v;        // :22
+        uint16_t h = float_to_bits16<OUT_DT>(v);  // :23
+        if (bias) h = float_to_bits16<OUT_DT>(bits16_to_float<OUT_DT>(h) + bs[e]);  // :24-25
+        o[e] = h;
+      }
+      uint16_t* dst = (uint16_t*)p.c + (int64_t)m * p.c_stride_m + n0;
+      if (vec_store && n0 + 8 <= p.n) {
+        i32x4 pk;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pk[e] = (int)((uint32_t)o[2 * e] | ((uint32_t)o[2 * e + 1] << 16));
+        *(i32x4*)dst = pk;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (n0 + e < p.n) dst[e] = o[e];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+struct BlockSetup {
+  int wave, lane, wr, wc, bm0, bn0, m_base, n_base;
+  StageOffsets so;
+  Srcs src;
+};
+
+__device__ __forceinline__ BlockSetup setup_block(const ScaledGemmArgs& p) {
+  BlockSetup s;
+  s.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  s.lane = threadIdx.x & 63;
+  s.wr = s.wave >> 2;
+  s.wc = s.wave & 3;
+  const int tiles_m = ((int)p.m + kTileM - 1) / kTileM;
+  const int tiles_n = ((int)p.n + kTileN - 1) / kTileN;
+  const TileCoord tc = map_tile(blockIdx.x, tiles_m, tiles_n);
+  s.bm0 = tc.tm * kTileM;
+  s.bn0 = tc.tn * kTileN;
+  const int lda = (int)p.a_stride_m, ldb = (int)p.b_stride_n;
+  s.so = make_stage_offsets(s.wave, s.lane, s.bm0, s.bn0, (int)p.m - 1, (int)p.n - 1, lda, ldb);
+  const uint32_t a_bytes = (uint32_t)((p.m - 1) * p.a_stride_m + p.k);
+  const uint32_t b_bytes = (uint32_t)((p.n - 1) * p.b_stride_n + p.k);
+  s.src.a = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, a_bytes, 0x00020000);
+  s.src.b = __builtin_amdgcn_make_buffer_rsrc((void*)p.b, 0, b_bytes, 0x00020000);
+  // fragment read offsets inside a unit (bytes): row r of a 16-row tile, k-group g
+  const int r = s.lane & 15, g = s.lane >> 4;
+  const int lane_off = (r >> 3) * 1024 + (r & 7) * 128 + ((g ^ ((r >> 1) & 7)) * 16);
+  s.m_base = (s.wr * 8) * 1024 + lane_off;   // wave-row's 64 rows inside a U unit
+  s.n_base = (s.wc * 4) * 1024 + lane_off;   // wave-column's 32 rows inside a V unit
+  return s;
+}
+
+template <int MMA>
+__device__ __forceinline__ void zero_acc(WaveTile<MMA>& w) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w.acc[i][j] = typename AccT<MMA>::type{0, 0, 0, 0};
+}
+
+// Variant 2: plain double-buffered loop -- one barrier per K step, next step's four units issued
+// right after it.  Bring-up / cross-check kernel.
+template <int MMA, int OUT_DT>
+__global__ __launch_bounds__(kThreads, 2) void scaled_gemm_simple_kernel(ScaledGemmArgs p) {
+  __shared__ __attribute__((aligned(1024))) char lds[kLdsBytes];
+  const BlockSetup s = setup_block(p);
+  WaveTile<MMA> w;
+  zero_acc<MMA>(w);
+  const int steps = (int)(p.k / kStepBytes);
+
+  stage_unit<kU1>(lds, s.src, s.so, s.wave, 0);
+  stage_unit<kV1>(lds, s.src, s.so, s.wave, 0);
+  stage_unit<kV2>(lds, s.src, s.so, s.wave, 0);
+  stage_unit<kU2>(lds, s.src, s.so, s.wave, 0);
+  for (int t = 0; t < steps; ++t) {
+    CONCH_VMCNT(0);
+    __builtin_amdgcn_s_barrier();
+    if (t + 1 < steps) {
+      stage_unit<kU1>(lds, s.src, s.so, s.wave, t + 1);
+      stage_unit<kV1>(lds, s.src, s.so, s.wave, t + 1);
+      stage_unit<kV2>(lds, s.src, s.so, s.wave, t + 1);
+      stage_unit<kU2>(lds, s.src, s.so, s.wave, t + 1);
+    }
+    const int buf = (t & 1) * kBufBytes;
+    phase_reads<MMA, 0, false>(w, lds, buf, s.m_base, s.n_base);
+    phase_mma<MMA, 0>(w);
+    phase_reads<MMA, 1, false>(w, lds, buf, s.m_base, s.n_base);
+    phase_mma<MMA, 1>(w);
+    phase_reads<MMA, 2, false>(w, lds, buf, s.m_base, s.n_base);
+    phase_mma<MMA, 2>(w);
+    phase_mma<MMA, 3>(w);
+  }
+  epilogue<MMA, OUT_DT>(w, p, s.bm0, s.bn0, s.wr, s.wc, s.lane);
+}
+
+// Variant 3: 4 phases per K step, two wave groups (waves 0-3 / 4-7 = the two waves of each SIMD)
+// staggered by one barrier so that one group's MFMA cluster overlaps the other's
+// {ds_read, LDS-DMA issue} segment.  Unit s of the stream (4 per K step, order U1,V1,V2,U2) is
+// issued in phase s-6 and first read in phase s-1 (U1: phase s); after issuing, every phase waits
+// vmcnt(8) = "everything but the 4 youngest units has landed", one phase (= one barrier pair)
+// before the unit is read.  A slot is rewritten 8 units later, >= 2 phases after its last read.
+template <int MMA, int ISSUE0, int ISSUE1, int ISSUE2, int ISSUE3, int VM0, int VM1, int VM2, int VM3>
+__device__ __forceinline__ void pingpong_step(WaveTile<MMA>& w, char* lds, const BlockSetup& s, int t) {
+  const int buf = (t & 1) * kBufBytes;
+  // ---- phase 0 ----
+  phase_reads<MMA, 0, true>(w, lds, buf, s.m_base, s.n_base);
+  if constexpr (ISSUE0) stage_unit<kV2>(lds, s.src, s.so, s.wave, t + 1);
+  wait_vmcnt<VM0>();
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_setprio(1);
+  phase_mma<MMA, 0>(w);
+  __builtin_amdgcn_s_setprio(0);
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- phase 1 ----
+  phase_reads<MMA, 1, true>(w, lds, buf, s.m_base, s.n_base);
+  if constexpr (ISSUE1) stage_unit<kU2>(lds, s.src, s.so, s.wave, t + 1);
+  wait_vmcnt<VM1>();
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_setprio(1);
+  phase_mma<MMA, 1>(w);
+  __builtin_amdgcn_s_setprio(0);
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- phase 2 ----
+  phase_reads<MMA, 2, true>(w, lds, buf, s.m_base, s.n_base);
+  if constexpr (ISSUE2) stage_unit<kU1>(lds, s.src, s.so, s.wave, t + 2);
+  wait_vmcnt<VM2>();
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_setprio(1);
+  phase_mma<MMA, 2>(w);
+  __builtin_amdgcn_s_setprio(0);
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- phase 3 ----
+  if constexpr (ISSUE3) stage_unit<kV1>(lds, s.src, s.so, s.wave, t + 2);
+  wait_vmcnt<VM3>();
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_setprio(1);
+  phase_mma<MMA, 3>(w);
+  __builtin_amdgcn_s_setprio(0);
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int MMA, int OUT_DT>
+__global__ __launch_bounds__(kThreads, 2) void scaled_gemm_pingpong_kernel(ScaledGemmArgs p) {
+  __shared__ __attribute__((aligned(1024))) char lds[kLdsBytes];
+  const BlockSetup s = setup_block(p);
+  WaveTile<MMA> w;
+  zero_acc<MMA>(w);
+  const int steps = (int)(p.k / kStepBytes);
+
+  // prologue: units 0..5 (all of K step 0, U1/V1 of K step 1)
+  stage_unit<kU1>(lds, s.src, s.so, s.wave, 0);
+  stage_unit<kV1>(lds, s.src, s.so, s.wave, 0);
+  stage_unit<kV2>(lds, s.src, s.so, s.wave, 0);
+  stage_unit<kU2>(lds, s.src, s.so, s.wave, 0);
+  if (steps > 1) {
+    stage_unit<kU1>(lds, s.src, s.so, s.wave, 1);
+    stage_unit<kV1>(lds, s.src, s.so, s.wave, 1);
+    CONCH_VMCNT(8);  // units 0,1 landed
+  } else {
+    CONCH_VMCNT(4);
+  }
+  __builtin_amdgcn_s_barrier();
+  if (s.wr == 1) __builtin_amdgcn_s_barrier();  // stagger the second wave of every SIMD
+
+  int t = 0;
+  for (; t + 2 < steps; ++t) pingpong_step<MMA, 1, 1, 1, 1, 8, 8, 8, 8>(w, lds, s, t);
+  if (steps >= 2) {
+    pingpong_step<MMA, 1, 1, 0, 0, 8, 8, 6, 4>(w, lds, s, t);
+    ++t;
+  }
+  pingpong_step<MMA, 0, 0, 0, 0, 2, 0, -1, -1>(w, lds, s, t);
+  if (s.wr == 0) __builtin_amdgcn_s_barrier();  // re-balance the barrier count
+
+  epilogue<MMA, OUT_DT>(w, p, s.bm0, s.bn0, s.wr, s.wc, s.lane);
+}
+
+}  // namespace
+
+bool scaled_gemm_mfma_supported(const ScaledGemmArgs& p) {
+  if (p.in_dtype != CONCH_DT_INT8 && p.in_dtype != CONCH_DT_FP8_E4M3FN) return false;
+  if (p.out_dtype != CONCH_DT_FP16 && p.out_dtype != CONCH_DT_BF16) return false;
+  if (p.m < 1 || p.n < 1 || p.k < kStepBytes || p.k % kStepBytes) return false;
+  if (p.a_stride_k != 1 || p.b_stride_k != 1 || p.c_stride_n != 1) return false;
+  if (p.a_stride_m % 16 || p.b_stride_n % 16) return false;
+  if (((uintptr_t)p.a & 15) || ((uintptr_t)p.b & 15) || ((uintptr_t)p.c & 1)) return false;
+  // 32-bit buffer offsets
+  const int64_t lim = (int64_t)1 << 31;
+  if (p.m * p.a_stride_m >= lim || p.n * p.b_stride_n >= lim) return false;
+  if (p.m >= (1 << 24) || p.n >= (1 << 24)) return false;
+  return true;
+}
+
+int launch_scaled_gemm_mfma(const ScaledGemmArgs& p, int variant, hipStream_t stream) {
+  const int tiles_m = (int)((p.m + kTileM - 1) / kTileM);
+  const int tiles_n = (int)((p.n + kTileN - 1) / kTileN);
+  const dim3 grid((unsigned)(tiles_m * tiles_n));
+#define CONCH_LAUNCH(MMA, OUT)                                                                           \
+  do {                                                                                                   \
+    if (variant == 2)                                                                                    \
+      hipLaunchKernelGGL((scaled_gemm_simple_kernel<MMA, OUT>), grid, dim3(kThreads), 0, stream, p);     \
+    else                                                                                                 \
+      hipLaunchKernelGGL((scaled_gemm_pingpong_kernel<MMA, OUT>), grid, dim3(kThreads), 0, stream, p);   \
+    return check_launch("scaled_gemm_mfma");                                                             \
+  } while (0)
+  if (p.in_dtype == CONCH_DT_FP8_E4M3FN) {
+    if (p.out_dtype == CONCH_DT_BF16) CONCH_LAUNCH(kMmaFp8, CONCH_DT_BF16);
+    CONCH_LAUNCH(kMmaFp8, CONCH_DT_FP16);
+  } else {
+    if (p.out_dtype == CONCH_DT_BF16) CONCH_LAUNCH(kMmaInt8, CONCH_DT_BF16);
+    CONCH_LAUNCH(kMmaInt8, CONCH_DT_FP16);
+  }
+#undef CONCH_LAUNCH
+}
+
+// mixed-precision MFMA kernels live in gemm_mixed.hip
+}  // namespace conch

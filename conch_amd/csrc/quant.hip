@@ -1,0 +1,199 @@
+// Static per-tensor quantisation feeders: fp16/bf16/fp32 -> int8 / fp8 (e4m3fn | e4m3fnuz).
+//
+// Replaces conch/kernels/quantization/int8.py:11-97 and fp8.py:13-97 (one Triton program per
+// token row).  These ops are pure HBM streaming (2|4 bytes in, 1 byte out per element), so the
+// gfx950 design is: flat 1-D view when the tensor is contiguous, 16 elements per lane per step
+// (16-byte loads, one 16-byte store), grid capped at 8 blocks per CU with a grid-stride loop.
+// Arithmetic follows the reference ORACLE (conch/reference/quantization/int8.py:12-18,
+// fp8.py:12-18): fp32 multiply by the reciprocal of the scale, clamp, then truncate (int8) or
+// round-to-nearest-even (fp8).
+#include "common.hpp"
+
+namespace conch {
+namespace {
+
+constexpr int kQuantThreads = 256;
+constexpr int kVec = 16;  // elements per lane per step
+
+enum QuantKind { kInt8 = 0, kFp8Fn = 1, kFp8Fnuz = 2 };
+
+template <int KIND>
+__device__ __forceinline__ uint32_t quant_one(float v, float inv) {
+  const float p = v * inv;
+  if constexpr (KIND == kInt8) {
+    // clamp(min=-128,max=127) then C-style truncation, as torch's .to(int8) does.
+    // fminf/fmaxf would swallow NaN; torch.clamp propagates it and the cast of NaN is
+    // implementation-defined, so NaN inputs are outside the contract.
+    const float c = fminf(fmaxf(p, -128.0f), 127.0f);
+    return (uint32_t)(int)c & 0xffu;
+  } else {
+    constexpr bool FNUZ = KIND == kFp8Fnuz;
+    const float mx = fp8_max<FNUZ>();
+    // NaN-propagating clamp (torch.clamp keeps NaN; the cast then yields the NaN code)
+    const float c = (p != p) ? p : fminf(fmaxf(p, -mx), mx);
+    if constexpr (FNUZ) {
+      return encode_fp8_sw<true>(c);
+    } else {
+      // gfx950's v_cvt_pk_fp8_f32 is OCP e4m3fn, RNE; the input is already within +-448.
+      return (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(c, c, 0, false) & 0xffu;
+    }
+  }
+}
+
+template <int KIND>
+__device__ __forceinline__ uint32_t quant_four(float a, float b, float c, float d, float inv) {
+  if constexpr (KIND == kFp8Fn) {
+    const float mx = 448.0f;
+    float v[4] = {a * inv, b * inv, c * inv, d * inv};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (v[i] != v[i]) ? v[i] : fminf(fmaxf(v[i], -mx), mx);
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
+    return (uint32_t)w;
+  } else {
+    return quant_one<KIND>(a, inv) | (quant_one<KIND>(b, inv) << 8) |
+           (quant_one<KIND>(c, inv) << 16) | (quant_one<KIND>(d, inv) << 24);
+  }
+}
+
+// 16 consecutive elements -> 16 floats
+template <int XDT>
+__device__ __forceinline__ void load16(const void* x, int64_t base, float (&f)[kVec]) {
+  if constexpr (XDT == CONCH_DT_FP32) {
+    const f32x4* p = (const f32x4*)((const float*)x + base);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 v = __builtin_nontemporal_load(p + j);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) f[j * 4 + i] = v[i];
+    }
+  } else {
+    const u16x8* p = (const u16x8*)((const uint16_t*)x + base);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const u16x8 v = __builtin_nontemporal_load(p + j);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[j * 8 + i] = bits16_to_float<XDT>(v[i]);
+    }
+  }
+}
+
+// Flat, 16-byte aligned, contiguous view of n elements.
+template <int XDT, int KIND>
+__global__ __launch_bounds__(kQuantThreads) void quant_flat_kernel(uint8_t* __restrict__ out,
+                                                                   const void* __restrict__ x,
+                                                                   const float* __restrict__ scale,
+                                                                   int64_t n) {
+  const float inv = 1.0f / scale[0];
+  const int64_t nvec = n / kVec;
+  const int64_t stride = (int64_t)gridDim.x * kQuantThreads;
+  for (int64_t v = (int64_t)blockIdx.x * kQuantThreads + threadIdx.x; v < nvec; v += stride) {
+    float f[kVec];
+    load16<XDT>(x, v * kVec, f);
+    i32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      o[j] = (int)quant_four<KIND>(f[4 * j], f[4 * j + 1], f[4 * j + 2], f[4 * j + 3], inv);
+    __builtin_nontemporal_store(o, (i32x4*)(out + v * kVec));
+  }
+  // scalar tail (< 16 elements)
+  const int64_t tail0 = nvec * kVec;
+  const int64_t t = tail0 + (int64_t)blockIdx.x * kQuantThreads + threadIdx.x;
+  if (t < n) out[t] = (uint8_t)quant_one<KIND>(load_as_float<XDT>(x, t), inv);
+}
+
+// Row-strided or unaligned tensors: one block walks one row with scalar accesses.
+template <int XDT, int KIND>
+__global__ __launch_bounds__(kQuantThreads) void quant_rows_kernel(uint8_t* __restrict__ out,
+                                                                   const void* __restrict__ x,
+                                                                   const float* __restrict__ scale,
+                                                                   int64_t tokens, int64_t hidden,
+                                                                   int64_t x_row_stride,
+                                                                   int64_t out_row_stride) {
+  const float inv = 1.0f / scale[0];
+  for (int64_t row = blockIdx.x; row < tokens; row += gridDim.x) {
+    const int64_t xb = row * x_row_stride;
+    const int64_t ob = row * out_row_stride;
+    for (int64_t h = threadIdx.x; h < hidden; h += kQuantThreads)
+      out[ob + h] = (uint8_t)quant_one<KIND>(load_as_float<XDT>(x, xb + h), inv);
+  }
+}
+
+template <int XDT, int KIND>
+int launch_quant(uint8_t* out, const void* x, const float* scale, int64_t tokens, int64_t hidden,
+                 int64_t x_row_stride, int64_t out_row_stride, hipStream_t stream) {
+  const int64_t n = tokens * hidden;
+  if (n == 0) return CONCH_OK;
+  const bool flat = x_row_stride == hidden && out_row_stride == hidden &&
+                    ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 16 == 0);
+  if (flat) {
+    const int64_t nvec = n / kVec;
+    int64_t blocks = (nvec + kQuantThreads - 1) / kQuantThreads;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256 * 8) blocks = 256 * 8;  // 8 blocks per CU, grid-stride beyond that
+    hipLaunchKernelGGL((quant_flat_kernel<XDT, KIND>), dim3((unsigned)blocks), dim3(kQuantThreads),
+                       0, stream, out, x, scale, n);
+  } else {
+    int64_t blocks = tokens < 256 * 8 ? tokens : 256 * 8;
+    hipLaunchKernelGGL((quant_rows_kernel<XDT, KIND>), dim3((unsigned)blocks), dim3(kQuantThreads),
+                       0, stream, out, x, scale, tokens, hidden, x_row_stride, out_row_stride);
+  }
+  return check_launch("static_scaled_quant");
+}
+
+template <int KIND>
+int dispatch_xdtype(uint8_t* out, const void* x, const float* scale, int64_t tokens, int64_t hidden,
+                    int64_t xs, int64_t os, int x_dtype, hipStream_t stream) {
+  switch (x_dtype) {
+    case CONCH_DT_FP32:
+      return launch_quant<CONCH_DT_FP32, KIND>(out, x, scale, tokens, hidden, xs, os, stream);
+    case CONCH_DT_FP16:
+      return launch_quant<CONCH_DT_FP16, KIND>(out, x, scale, tokens, hidden, xs, os, stream);
+    case CONCH_DT_BF16:
+      return launch_quant<CONCH_DT_BF16, KIND>(out, x, scale, tokens, hidden, xs, os, stream);
+    default:
+      set_error("static quant: unsupported input dtype %d (want FP32/FP16/BF16)", x_dtype);
+      return CONCH_ERR_UNSUPPORTED;
+  }
+}
+
+int check_quant_args(const void* out, const void* x, const float* scale, int64_t tokens,
+                     int64_t hidden, int64_t xs, int64_t os) {
+  CONCH_CHECK_ARG(tokens >= 0 && hidden >= 0, "static quant: negative shape (%lld, %lld)",
+                  (long long)tokens, (long long)hidden);
+  if (tokens == 0 || hidden == 0) return CONCH_OK;
+  CONCH_CHECK_ARG(out && x && scale, "static quant: NULL pointer (out=%p x=%p scale=%p)", out, x,
+                  (const void*)scale);
+  CONCH_CHECK_ARG(xs >= hidden && os >= hidden,
+                  "static quant: row strides (%lld, %lld) smaller than hidden %lld", (long long)xs,
+                  (long long)os, (long long)hidden);
+  return CONCH_OK;
+}
+
+}  // namespace
+}  // namespace conch
+
+extern "C" int conch_static_scaled_int8_quant(int8_t* out, const void* x, const float* scale,
+                                              int64_t tokens, int64_t hidden, int64_t x_row_stride,
+                                              int64_t out_row_stride, int x_dtype, void* stream) {
+  using namespace conch;
+  if (int rc = check_quant_args(out, x, scale, tokens, hidden, x_row_stride, out_row_stride)) return rc;
+  return dispatch_xdtype<kInt8>((uint8_t*)out, x, scale, tokens, hidden, x_row_stride,
+                                out_row_stride, x_dtype, (hipStream_t)stream);
+}
+
+extern "C" int conch_static_scaled_fp8_quant(uint8_t* out, const void* x, const float* scale,
+                                             int64_t tokens, int64_t hidden, int64_t x_row_stride,
+                                             int64_t out_row_stride, int x_dtype, int fp8_dtype,
+                                             void* stream) {
+  using namespace conch;
+  if (int rc = check_quant_args(out, x, scale, tokens, hidden, x_row_stride, out_row_stride)) return rc;
+  if (fp8_dtype == CONCH_DT_FP8_E4M3FN)
+    return dispatch_xdtype<kFp8Fn>(out, x, scale, tokens, hidden, x_row_stride, out_row_stride,
+                                   x_dtype, (hipStream_t)stream);
+  if (fp8_dtype == CONCH_DT_FP8_E4M3FNUZ)
+    return dispatch_xdtype<kFp8Fnuz>(out, x, scale, tokens, hidden, x_row_stride, out_row_stride,
+                                     x_dtype, (hipStream_t)stream);
+  set_error("static fp8 quant: unsupported fp8 dtype %d (want E4M3FN or E4M3FNUZ)", fp8_dtype);
+  return CONCH_ERR_UNSUPPORTED;
+}

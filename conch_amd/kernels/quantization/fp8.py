@@ -1,0 +1,43 @@
+"""Launcher for the static fp8 (e4m3) quantisation kernel (C-ABI seam).
+
+Mirrors `static_scaled_fp8_quant_launcher` of conch/kernels/quantization/fp8.py:65-97.  The fp8
+flavour is taken from the output tensor's dtype: float8_e4m3fn (gfx950 native, hardware
+conversion) or float8_e4m3fnuz (MI300-era flavour, exact software encoder).
+"""
+
+import torch
+
+from conch_amd import _C
+
+_FP8_DTYPES = (torch.float8_e4m3fn, torch.float8_e4m3fnuz)
+
+
+def static_scaled_fp8_quant_launcher(
+    output_tensor: torch.Tensor,
+    input_tensor: torch.Tensor,
+    scale: torch.Tensor,
+) -> None:
+    """output = fp8(clamp(input * (1/scale), -max, max)) with a per-tensor static scale."""
+    _C.require_device(output_tensor, input_tensor, scale)
+    if output_tensor.dtype not in _FP8_DTYPES:
+        raise ValueError(f"output tensor must be an fp8 e4m3 dtype, got {output_tensor.dtype}")
+    x = input_tensor if input_tensor.dim() == 2 else input_tensor.reshape(-1, input_tensor.shape[-1])
+    out = output_tensor if output_tensor.dim() == 2 else output_tensor.view(-1, output_tensor.shape[-1])
+    if x.stride(-1) != 1:
+        x = x.contiguous()
+    if out.stride(-1) != 1:
+        raise ValueError("output tensor must be contiguous in its last dimension")
+    tokens, hidden = x.shape
+    status = _C.load().conch_static_scaled_fp8_quant(
+        _C.ptr(out),
+        _C.ptr(x),
+        _C.ptr(scale),
+        tokens,
+        hidden,
+        x.stride(0) if tokens > 1 else hidden,
+        out.stride(0) if tokens > 1 else hidden,
+        _C.dtype_id(x.dtype),
+        _C.dtype_id(out.dtype),
+        _C.current_stream_handle(x.device),
+    )
+    _C.check(status, "static_scaled_fp8_quant")

@@ -1,0 +1,235 @@
+"""Launchers and metadata for the quantized GEMMs (C-ABI seam).
+
+Same names and argument meaning as conch/kernels/quantization/gemm.py (enums :20-74, metadata
+dataclasses :460-479 and :548-561, launchers :482 and :564); the Triton kernel behind them is
+replaced by the hand-written gfx950 kernels of csrc/gemm_*.hip, selected inside the C library.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from enum import Enum
+
+import torch
+
+from conch_amd import _C
+
+
+class DType(Enum):
+    """Element-type ids shared with the C ABI (conch_dtype_t)."""
+
+    FP32 = 0
+    FP16 = 1
+    BF16 = 2
+    FP8 = 3
+    INT8 = 4
+    UINT8 = 5
+    INT32 = 6
+    UINT32 = 7
+    FP8E5 = 8
+    FP8FNUZ = 9
+
+
+class WeightGroupMode(Enum):
+    """How group metadata enters the dequantisation."""
+
+    NONE = 0
+    SHIFT = 1
+    SYMMETRIC_NO_SHIFT = 2
+    SYMMETRIC_WITH_SHIFT = 3
+    ASYMMETRIC = 4
+
+
+class ChannelScaleMode(Enum):
+    """Which per-channel scales the epilogue applies."""
+
+    NONE = 0
+    WEIGHT_ONLY = 1
+    ACTIVATION_ONLY = 2
+    WEIGHT_AND_ACTIVATION = 3
+
+
+@dataclass
+class MixedPrecisionMatmulMetadata:
+    m_dim: int
+    k_dim: int
+    n_dim: int
+    weight_size_bits: int
+    weight_bias: int
+    group_size: int
+    elements_per_sample: int
+    zero_is_scalar: bool
+    unpack_mask: int
+    data_contiguous: bool
+    input_dtype: torch.dtype
+    output_dtype: torch.dtype
+    acc_dtype: torch.dtype
+    meta_dtype: torch.dtype
+    channel_scale_mode: ChannelScaleMode
+    weight_group_mode: WeightGroupMode
+
+
+@dataclass
+class ScaledMatmulMetadata:
+    m_dim: int
+    k_dim: int
+    n_dim: int
+    data_contiguous: bool
+    input_dtype: torch.dtype
+    output_dtype: torch.dtype
+    acc_dtype: torch.dtype
+    meta_dtype: torch.dtype
+    channel_scale_mode: ChannelScaleMode
+    weight_group_mode: WeightGroupMode
+
+
+def _as_fp32_vector(scale: torch.Tensor, what: str) -> torch.Tensor:
+    if scale.dtype != torch.float32:
+        raise NotImplementedError(f"{what} must be float32 (got {scale.dtype})")
+    flat = scale.reshape(-1)
+    return flat if flat.stride(0) == 1 else flat.contiguous()
+
+
+def _scaled_gemm_call(
+    fn_name: str,
+    output: torch.Tensor,
+    a: torch.Tensor,
+    b: torch.Tensor,
+    scale_a: torch.Tensor,
+    scale_b: torch.Tensor,
+    metadata: ScaledMatmulMetadata,
+    bias: torch.Tensor | None,
+    extra: tuple = (),
+) -> int:
+    _C.require_device(output, a, b, scale_a, scale_b, bias)
+    if a.dtype != b.dtype:
+        raise ValueError(f"a and b must share a dtype (a: {a.dtype}, b: {b.dtype})")
+    if output.dtype != metadata.output_dtype:
+        raise ValueError(f"output dtype {output.dtype} != metadata.output_dtype {metadata.output_dtype}")
+    sa = _as_fp32_vector(scale_a, "scale_a")
+    sb = _as_fp32_vector(scale_b, "scale_b")
+    if bias is not None:
+        if bias.dtype != output.dtype:
+            bias = bias.to(output.dtype)
+        bias = bias.reshape(-1).contiguous()
+        if bias.numel() != metadata.n_dim:
+            raise ValueError(f"bias has {bias.numel()} elements, want N={metadata.n_dim}")
+    fn = getattr(_C.load(), fn_name)
+    return fn(
+        _C.ptr(output),
+        _C.ptr(a),
+        _C.ptr(b),
+        _C.ptr(sa),
+        _C.ptr(sb),
+        _C.ptr(bias),
+        metadata.m_dim,
+        metadata.n_dim,
+        metadata.k_dim,
+        a.stride(0),
+        a.stride(1),
+        b.stride(0),
+        b.stride(1),
+        output.stride(0),
+        output.stride(1),
+        sa.numel(),
+        sb.numel(),
+        _C.dtype_id(a.dtype),
+        _C.dtype_id(output.dtype),
+        _C.current_stream_handle(a.device),
+        *extra,
+    )
+
+
+def scaled_gemm_launcher(
+    output: torch.Tensor,
+    a: torch.Tensor,
+    b: torch.Tensor,
+    scale_a: torch.Tensor,
+    scale_b: torch.Tensor,
+    metadata: ScaledMatmulMetadata,
+    bias: torch.Tensor | None = None,
+) -> None:
+    """output = cast(scale_b * (scale_a * (a @ b))) [+ bias].
+
+    Same positional arguments as the reference launcher (kernels/quantization/gemm.py:564-571);
+    `bias` is an extension: the reference adds it with a second kernel
+    (ops/quantization/gemm.py:249-250), here the epilogue fuses it with identical rounding.
+    """
+    status = _scaled_gemm_call("conch_scaled_gemm", output, a, b, scale_a, scale_b, metadata, bias)
+    _C.check(status, "scaled_gemm")
+
+
+def _mixed_gemm_call(
+    fn_name: str,
+    output: torch.Tensor,
+    x: torch.Tensor,
+    w_q_packed: torch.Tensor,
+    scales: torch.Tensor,
+    zeros: torch.Tensor | None,
+    metadata: MixedPrecisionMatmulMetadata,
+    extra: tuple = (),
+) -> int:
+    _C.require_device(output, x, w_q_packed, scales, zeros)
+    if metadata.acc_dtype != torch.float32:
+        raise NotImplementedError("mixed_precision_gemm accumulates in float32 only")
+    if metadata.meta_dtype != x.dtype or scales.dtype != x.dtype:
+        raise NotImplementedError("mixed_precision_gemm: scales / meta dtype must equal the activation dtype")
+    if metadata.channel_scale_mode != ChannelScaleMode.NONE:
+        raise NotImplementedError("mixed_precision_gemm: channel scaling is not reachable from conch.ops")
+    if w_q_packed.dtype not in (torch.int32, getattr(torch, "uint32", torch.int32)):
+        raise ValueError(f"Invalid datatype for packed weights: {w_q_packed.dtype}")
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    if w_q_packed.stride(1) != 1:
+        w_q_packed = w_q_packed.contiguous()
+    if scales.stride(-1) != 1:
+        scales = scales.contiguous()
+    if zeros is None or metadata.weight_group_mode == WeightGroupMode.SYMMETRIC_NO_SHIFT:
+        zp_mode, zeros_t, zp_stride = _C.ZP_NONE, None, 0
+    else:
+        if zeros.dtype != torch.int32:
+            zeros = zeros.to(torch.int32)
+        if metadata.zero_is_scalar:
+            zp_mode, zeros_t, zp_stride = _C.ZP_SCALAR, zeros.reshape(-1), 0
+        else:
+            zeros_t = zeros if zeros.stride(-1) == 1 else zeros.contiguous()
+            zp_mode, zp_stride = _C.ZP_TENSOR, zeros_t.stride(0)
+    fn = getattr(_C.load(), fn_name)
+    return fn(
+        _C.ptr(output),
+        _C.ptr(x),
+        _C.ptr(w_q_packed),
+        _C.ptr(scales),
+        _C.ptr(zeros_t),
+        metadata.m_dim,
+        metadata.n_dim,
+        metadata.k_dim,
+        x.stride(0),
+        w_q_packed.stride(0),
+        scales.stride(0) if scales.dim() == 2 else metadata.n_dim,
+        zp_stride,
+        output.stride(0),
+        metadata.weight_size_bits,
+        metadata.weight_bias,
+        metadata.group_size,
+        zp_mode,
+        _C.dtype_id(x.dtype),
+        _C.dtype_id(output.dtype),
+        _C.current_stream_handle(x.device),
+        *extra,
+    )
+
+
+def mixed_precision_gemm_launcher(
+    output: torch.Tensor,
+    x: torch.Tensor,
+    w_q_packed: torch.Tensor,
+    scales: torch.Tensor,
+    zeros: torch.Tensor | None,
+    metadata: MixedPrecisionMatmulMetadata,
+) -> None:
+    """output = x @ dequant(w_q_packed, scales, zeros)  (reference launcher: gemm.py:482-545)."""
+    if output.stride(1) != 1:
+        raise ValueError("output must be contiguous in its last dimension")
+    status = _mixed_gemm_call("conch_mixed_precision_gemm", output, x, w_q_packed, scales, zeros, metadata)
+    _C.check(status, "mixed_precision_gemm")

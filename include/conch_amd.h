@@ -1,0 +1,157 @@
+/*
+ * conch_amd.h -- C ABI of the MI355X-native quantized-matmul hot path.
+ *
+ * This is the drop-in boundary beneath Conch's `conch.ops.quantization` Python API.  The reference
+ * has no FFI of its own for this path: its device boundary is the Triton launchers
+ *   conch/kernels/quantization/gemm.py:564  scaled_gemm_launcher
+ *   conch/kernels/quantization/gemm.py:482  mixed_precision_gemm_launcher
+ *   conch/kernels/quantization/int8.py:63   static_scaled_int8_quant_launcher
+ *   conch/kernels/quantization/fp8.py:65    static_scaled_fp8_quant_launcher
+ * Each entry point below replaces exactly one of those launchers (plus the bias `add_` of
+ * conch/ops/quantization/gemm.py:249-250, which is fused here).  Plain pointers and sizes only:
+ * no torch types, no exceptions.  All pointers are DEVICE pointers unless stated; every call is
+ * asynchronous on `stream` (a hipStream_t passed as void*; NULL = the default stream) and
+ * re-entrant.  Launchers never allocate (docs/conch/structure.md:14-15 of the reference).
+ *
+ * Return value: CONCH_OK (0) or a conch_status_t error; conch_last_error() returns a
+ * thread-local, human-readable description of the last failure on the calling thread.
+ */
+#ifndef CONCH_AMD_H
+#define CONCH_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CONCH_AMD_ABI_VERSION 1
+
+typedef enum conch_status {
+  CONCH_OK = 0,
+  CONCH_ERR_INVALID_ARGUMENT = 1, /* NULL pointer, negative size, bad enum, misaligned stride */
+  CONCH_ERR_UNSUPPORTED = 2,      /* valid request that no kernel implements (dtype combination ...) */
+  CONCH_ERR_HIP = 3,              /* a HIP runtime call failed; see conch_last_error() */
+  CONCH_ERR_NO_DEVICE = 4         /* no gfx950 device visible */
+} conch_status_t;
+
+/* Element types.  Values 0..8 follow the reference's DType enum
+ * (conch/kernels/quantization/gemm.py:20-31); 9 is added because gfx950's native fp8 is OCP
+ * e4m3fn while the reference's AMD choice (MI300X) was e4m3fnuz (conch/ops/quantization/fp8.py:27). */
+typedef enum conch_dtype {
+  CONCH_DT_FP32 = 0,
+  CONCH_DT_FP16 = 1,
+  CONCH_DT_BF16 = 2,
+  CONCH_DT_FP8_E4M3FN = 3, /* OCP fp8: gfx950 MFMA-native */
+  CONCH_DT_INT8 = 4,
+  CONCH_DT_UINT8 = 5,
+  CONCH_DT_INT32 = 6,
+  CONCH_DT_UINT32 = 7,
+  CONCH_DT_FP8_E5M2 = 8,
+  CONCH_DT_FP8_E4M3FNUZ = 9 /* MI300-era fp8: accepted through an exact compat path */
+} conch_dtype_t;
+
+/* How the zero-point argument of the mixed-precision GEMM is to be read
+ * (conch/ops/quantization/gemm.py:34-38,92: None -> SYMMETRIC_NO_SHIFT, tensor -> WITH_SHIFT,
+ * numel()==1 -> zero_is_scalar). */
+typedef enum conch_zp_mode {
+  CONCH_ZP_NONE = 0,
+  CONCH_ZP_SCALAR = 1, /* one int32 on the device */
+  CONCH_ZP_TENSOR = 2  /* int32 [K/group_size, N] */
+} conch_zp_mode_t;
+
+/* Kernel-selection knobs for tests and benchmarks (process-global, not part of the data path). */
+typedef enum conch_tuning_key {
+  CONCH_TUNE_GEMM_VARIANT = 0 /* 0 = auto, 1 = generic (any shape/stride), 2 = LDS-tiled MFMA,
+                                 3 = 8-phase pipelined MFMA */
+} conch_tuning_key_t;
+
+int conch_abi_version(void);
+const char* conch_last_error(void);
+int conch_set_tuning(int key, int value);
+int conch_get_tuning(int key);
+
+/* Number of gfx950 devices visible (0 if none); does not initialise a HIP context on failure. */
+int conch_device_count(void);
+
+/*
+ * static_scaled_int8_quant  (replaces kernels/quantization/int8.py:63-97;
+ * semantics = reference/quantization/int8.py:12-18)
+ *   out[t][h] = (int8) trunc( clamp( (float)x[t][h] * (1.0f / *scale), -128, 127 ) )
+ * x: [tokens][hidden] of x_dtype (FP16/BF16/FP32), rows x_row_stride elements apart, hidden
+ * contiguous; out: int8 [tokens][hidden], rows out_row_stride apart; scale: one fp32 on device.
+ */
+int conch_static_scaled_int8_quant(int8_t* out, const void* x, const float* scale, int64_t tokens,
+                                   int64_t hidden, int64_t x_row_stride, int64_t out_row_stride,
+                                   int x_dtype, void* stream);
+
+/*
+ * static_scaled_fp8_quant  (replaces kernels/quantization/fp8.py:65-97;
+ * semantics = reference/quantization/fp8.py:12-18, i.e. WITH the clamp to +-max)
+ *   out[t][h] = fp8_rne( clamp( (float)x[t][h] * (1.0f / *scale), -max, max ) )
+ * fp8_dtype: CONCH_DT_FP8_E4M3FN (max 448) or CONCH_DT_FP8_E4M3FNUZ (max 240).
+ */
+int conch_static_scaled_fp8_quant(uint8_t* out, const void* x, const float* scale, int64_t tokens,
+                                  int64_t hidden, int64_t x_row_stride, int64_t out_row_stride,
+                                  int x_dtype, int fp8_dtype, void* stream);
+
+/*
+ * scaled_gemm  (replaces kernels/quantization/gemm.py:564-627 + ops/quantization/gemm.py:249-250;
+ * semantics = reference/quantization/scaled_gemm.py:12-27)
+ *   C[m][n] = out_dtype( scale_b[n] * ( scale_a[m] * (float) sum_k A[m][k]*B[k][n] ) ) (+ bias[n])
+ * A: [M][K], B: [K][N], both of in_dtype (INT8 | FP8_E4M3FN | FP8_E4M3FNUZ), arbitrary element
+ * strides (the reference passes B as a transposed view, strides (1, K)); C: [M][N] of out_dtype
+ * (FP16 | BF16); scale_a: fp32, scale_a_numel = 1 or M (element stride 1); scale_b likewise with N;
+ * bias: NULL or [N] of out_dtype, added in out_dtype after the cast exactly as the reference does.
+ * int8 accumulates exactly in int32; fp8 accumulates in fp32.
+ */
+int conch_scaled_gemm(void* c, const void* a, const void* b, const float* scale_a,
+                      const float* scale_b, const void* bias, int64_t m, int64_t n, int64_t k,
+                      int64_t a_stride_m, int64_t a_stride_k, int64_t b_stride_k,
+                      int64_t b_stride_n, int64_t c_stride_m, int64_t c_stride_n,
+                      int64_t scale_a_numel, int64_t scale_b_numel, int in_dtype, int out_dtype,
+                      void* stream);
+
+/*
+ * mixed_precision_gemm  (replaces kernels/quantization/gemm.py:482-545;
+ * dequantisation semantics = kernels/quantization/gemm.py:176-216, bit-identical to the w_ref of
+ * third_party/vllm/quant_utils.py:74)
+ *   W[k][n] = x_dtype( (q[k][n] - weight_bias [- zp[k/G][n]]) ) * w_s[k/G][n]      (one rounding)
+ *   C[m][n] = out_dtype( sum_k X[m][k] * W[k][n] )   accumulated in fp32
+ * X: [M][K] of x_dtype (FP16 | BF16), row stride x_stride_m elements, K contiguous;
+ * w_q_packed: int32 [K*bits/32][N] row-major (row stride wq_stride_k), element k of column n in
+ * word k/(32/bits) at bit (k%(32/bits))*bits (quant_utils.py:119-122); w_s: [K/G][N] of x_dtype
+ * (row stride ws_stride_g); w_zp per zp_mode (row stride wzp_stride_g); C: [M][N] of out_dtype.
+ */
+int conch_mixed_precision_gemm(void* c, const void* x, const int32_t* w_q_packed, const void* w_s,
+                               const int32_t* w_zp, int64_t m, int64_t n, int64_t k,
+                               int64_t x_stride_m, int64_t wq_stride_k, int64_t ws_stride_g,
+                               int64_t wzp_stride_g, int64_t c_stride_m, int weight_bits,
+                               int weight_bias, int group_size, int zp_mode, int x_dtype,
+                               int out_dtype, void* stream);
+
+/*
+ * Timing helper used by bench.py: launches `iters` back-to-back scaled_gemm calls on `stream`
+ * bracketed by HIP events recorded ON THAT STREAM and returns the average milliseconds per call
+ * in *avg_ms (synchronises the stream; not for use inside graph capture).
+ */
+int conch_time_scaled_gemm(void* c, const void* a, const void* b, const float* scale_a,
+                           const float* scale_b, const void* bias, int64_t m, int64_t n, int64_t k,
+                           int64_t a_stride_m, int64_t a_stride_k, int64_t b_stride_k,
+                           int64_t b_stride_n, int64_t c_stride_m, int64_t c_stride_n,
+                           int64_t scale_a_numel, int64_t scale_b_numel, int in_dtype,
+                           int out_dtype, void* stream, int iters, float* avg_ms);
+
+int conch_time_mixed_precision_gemm(void* c, const void* x, const int32_t* w_q_packed,
+                                    const void* w_s, const int32_t* w_zp, int64_t m, int64_t n,
+                                    int64_t k, int64_t x_stride_m, int64_t wq_stride_k,
+                                    int64_t ws_stride_g, int64_t wzp_stride_g, int64_t c_stride_m,
+                                    int weight_bits, int weight_bias, int group_size, int zp_mode,
+                                    int x_dtype, int out_dtype, void* stream, int iters,
+                                    float* avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CONCH_AMD_H */

@@ -1,0 +1,270 @@
+"""GPU parity: scaled_gemm and mixed_precision_gemm vs the CPU oracle, through the public ops.
+
+Matrices follow the reference (tests/scaled_gemm_test.py:31-78, tests/mixed_precision_gemm_test.py:36-77)
+with much tighter bars: int8 inputs are BIT-EXACT (int32 accumulation is exact and the epilogue
+restates the oracle's order of operations); fp8 / mixed results differ from the oracle only by the
+fp32 accumulation order, bounded below in units of the output dtype's epsilon.
+"""
+
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conch_amd import _C
+from conch_amd.ops.quantization.gemm import mixed_precision_gemm, scaled_gemm
+from conch_amd.third_party.vllm.quant_utils import pack_rows, quantize_weights
+from conch_amd.third_party.vllm.scalar_type import scalar_types
+from conch_amd.third_party.vllm.utils import seed_everything
+from tests.conftest import DT, from_bits, to_bits
+
+pytestmark = pytest.mark.gpu
+
+IN_T = {"int8": torch.int8, "fn": torch.float8_e4m3fn, "fnuz": torch.float8_e4m3fnuz}
+SHAPES = [(128, 256, 128), (1024, 1024, 1024), (4096, 2048, 4096)]
+VARIANTS = {"auto": _C.VARIANT_AUTO, "generic": _C.VARIANT_GENERIC, "simple": _C.VARIANT_MFMA_SIMPLE,
+            "pingpong": _C.VARIANT_MFMA_PINGPONG}
+# fp accumulation-order tolerance, relative to max|C| of the case, in output-dtype epsilons
+EPS = {torch.float16: 2.0**-10, torch.bfloat16: 2.0**-7}
+
+
+@pytest.fixture(autouse=True)
+def _reset_variant():
+    yield
+    _C.set_gemm_variant(_C.VARIANT_AUTO)
+
+
+def make_scaled_inputs(m, k, n, in_dtype, out_dtype, sa_scalar, sb_scalar, use_bias):
+    """Recipe of tests/scaled_gemm_test.py:54-73, generated on the CPU (the oracle's side)."""
+    seed_everything(0)
+    sa = torch.rand((1, 1), dtype=torch.float32) if sa_scalar else 0.25 * torch.rand((m, 1))
+    sb = torch.rand((1, 1), dtype=torch.float32) if sb_scalar else 0.25 * torch.rand((n, 1))
+    if in_dtype.is_floating_point:
+        a = (0.25 * torch.rand((m, k), dtype=torch.float32)).to(in_dtype)
+        b = (0.25 * torch.rand((n, k), dtype=torch.float32)).to(in_dtype).T
+    else:
+        a = torch.randint(-32, 32, (m, k), dtype=in_dtype)
+        b = torch.randint(-32, 32, (n, k), dtype=in_dtype).T
+    bias = torch.rand((n,), dtype=out_dtype) if use_bias else None
+    return a, b, sa, sb, bias
+
+
+def check_scaled(got, ref, in_dtype, out_dtype):
+    if in_dtype == torch.int8:
+        np.testing.assert_array_equal(to_bits(got), to_bits(ref))
+        return
+    g, r = got.float().cpu(), ref.float()
+    tol = 2.0 * EPS[out_dtype] * max(r.abs().max().item(), 1e-6)
+    err = (g - r).abs().max().item()
+    assert err <= tol, f"max |diff| {err:.4g} > {tol:.4g}"
+
+
+def run_scaled(a, b, sa, sb, out_dtype, bias):
+    dev = lambda t: None if t is None else t.cuda()  # noqa: E731
+    # b is a transposed view: keep the (1, K) strides on the device like the reference test does
+    b_dev = b.T.contiguous().cuda().T if b.stride(0) == 1 else b.cuda()
+    return scaled_gemm(dev(a), b_dev, dev(sa), dev(sb), out_dtype, dev(bias))
+
+
+@pytest.mark.parametrize(("m", "k", "n"), SHAPES[:2])
+@pytest.mark.parametrize("iname", list(IN_T))
+@pytest.mark.parametrize("oname", ["f16", "bf16"])
+@pytest.mark.parametrize("sa_scalar", [True, False])
+@pytest.mark.parametrize("sb_scalar", [True, False])
+@pytest.mark.parametrize("use_bias", [True, False])
+def test_scaled_gemm_matrix(m, k, n, iname, oname, sa_scalar, sb_scalar, use_bias):
+    a, b, sa, sb, bias = make_scaled_inputs(m, k, n, IN_T[iname], DT[oname], sa_scalar, sb_scalar, use_bias)
+    ref = oracle.scaled_gemm_ref(a, b, sa, sb, DT[oname], bias)
+    got = run_scaled(a, b, sa, sb, DT[oname], bias)
+    assert got.shape == (m, n) and got.dtype == DT[oname]
+    check_scaled(got, ref, IN_T[iname], DT[oname])
+
+
+@pytest.mark.parametrize("iname", list(IN_T))
+@pytest.mark.parametrize(("oname", "sa_scalar", "sb_scalar", "use_bias"),
+                         [("bf16", False, False, True), ("f16", True, False, False), ("bf16", False, True, False)])
+def test_scaled_gemm_large_shape(iname, oname, sa_scalar, sb_scalar, use_bias):
+    m, k, n = SHAPES[2]
+    a, b, sa, sb, bias = make_scaled_inputs(m, k, n, IN_T[iname], DT[oname], sa_scalar, sb_scalar, use_bias)
+    ref = oracle.scaled_gemm_ref(a, b, sa, sb, DT[oname], bias)
+    check_scaled(run_scaled(a, b, sa, sb, DT[oname], bias), ref, IN_T[iname], DT[oname])
+
+
+@pytest.mark.parametrize("variant", ["generic", "simple", "pingpong"])
+@pytest.mark.parametrize("iname", ["int8", "fn"])
+@pytest.mark.parametrize(("m", "k", "n"), [(128, 256, 128), (1024, 1024, 1024), (300, 384, 520), (257, 128, 8),
+                                            (512, 1152, 1376)])
+def test_scaled_gemm_every_kernel_variant(variant, iname, m, k, n):
+    """Each device kernel, including ragged M/N tails (partial tiles, N not a multiple of 256)."""
+    a, b, sa, sb, bias = make_scaled_inputs(m, k, n, IN_T[iname], torch.bfloat16, False, False, True)
+    ref = oracle.scaled_gemm_ref(a, b, sa, sb, torch.bfloat16, bias)
+    _C.set_gemm_variant(VARIANTS[variant])
+    check_scaled(run_scaled(a, b, sa, sb, torch.bfloat16, bias), ref, IN_T[iname], torch.bfloat16)
+
+
+@pytest.mark.parametrize("iname", list(IN_T))
+@pytest.mark.parametrize("key_tail", ["f16_sa1_sb1_b1", "bf16_sa0_sb0_b1", "bf16_sa0_sb1_b0", "f16_sa1_sb0_b0"])
+def test_scaled_gemm_golden_from_reference(golden, iname, key_tail):
+    g = golden("scaled_gemm")
+    key = f"{iname}_{key_tail}"
+    oname = key_tail.split("_")[0]
+    a = from_bits(g[f"a_{key}"], IN_T[iname])
+    b = from_bits(g[f"bt_{key}"], IN_T[iname]).T
+    sa, sb = torch.from_numpy(g[f"sa_{key}"]), torch.from_numpy(g[f"sb_{key}"])
+    bias = from_bits(g[f"bias_{key}"], DT[oname]) if key_tail.endswith("b1") else None
+    got = run_scaled(a, b, sa, sb, DT[oname], bias)
+    check_scaled(got, from_bits(g[f"c_{key}"], DT[oname]).reshape(128, 128), IN_T[iname], DT[oname])
+
+
+def test_scaled_gemm_layouts_and_edge_cases():
+    """Row-major (N-contiguous) B, 0-dim scales, K not a multiple of 128, empty M: all legal inputs."""
+    seed_everything(1)
+    m, k, n = 96, 200, 72
+    a = torch.randint(-32, 32, (m, k), dtype=torch.int8)
+    b = torch.randint(-32, 32, (k, n), dtype=torch.int8)  # row-major: strides (n, 1)
+    sa, sb = torch.tensor(0.37), 0.25 * torch.rand((n, 1))
+    ref = oracle.scaled_gemm_ref(a, b, sa.reshape(1, 1), sb, torch.float16, None)
+    got = scaled_gemm(a.cuda(), b.cuda(), sa.cuda(), sb.cuda(), torch.float16)
+    np.testing.assert_array_equal(to_bits(got), to_bits(ref))
+    empty = scaled_gemm(a[:0].cuda(), b.cuda(), sa.cuda(), sb.cuda(), torch.float16)
+    assert empty.shape == (0, n)
+    with pytest.raises(ValueError):
+        scaled_gemm(a.cuda(), b.cuda().to(torch.uint8).view(torch.float8_e4m3fn), sa.cuda(), sb.cuda(), torch.float16)
+    with pytest.raises(NotImplementedError):
+        scaled_gemm(a.cuda(), b.cuda(), sa.cuda(), sb.cuda(), torch.float32)
+
+
+def test_scaled_gemm_int8_saturated_operands_exact():
+    """Extreme int8 values: |acc| up to 128*128*K exceeds 2^24, the int32 accumulator stays exact."""
+    m, k, n = 256, 2048, 256
+    a = torch.full((m, k), -128, dtype=torch.int8)
+    b = torch.full((n, k), -128, dtype=torch.int8).T
+    a[::3] = 127
+    one = torch.ones((1, 1))
+    got = scaled_gemm(a.cuda(), b.T.contiguous().cuda().T, one.cuda(), one.cuda(), torch.bfloat16)
+    exact = (a.double() @ b.double()).float().to(torch.bfloat16)  # float(int32) then RNE to bf16
+    np.testing.assert_array_equal(to_bits(got), to_bits(exact))
+
+
+def test_scaled_gemm_c2_config_bit_exact():
+    """BASELINE config C2: int8 -> bf16, per-channel scales, M=128 K=4096 N=4096."""
+    a, b, sa, sb, _ = make_scaled_inputs(128, 4096, 4096, torch.int8, torch.bfloat16, False, False, False)
+    ref = oracle.scaled_gemm_ref(a, b, sa, sb, torch.bfloat16, None)
+    np.testing.assert_array_equal(to_bits(run_scaled(a, b, sa, sb, torch.bfloat16, None)), to_bits(ref))
+
+
+def test_scaled_gemm_c3_config_properties():
+    """BASELINE config C3 (fp8 -> bf16, 4096x4096x11008) at full size.
+
+    (1) a band of rows is checked against the oracle; (2) the MFMA kernel agrees with the generic
+    device kernel everywhere up to accumulation order; (3) row-linearity: permuting the rows of A
+    permutes the rows of C bit-for-bit (each output row depends only on its own row of A).
+    """
+    m, k, n = 4096, 4096, 11008
+    a, b, sa, sb, _ = make_scaled_inputs(m, k, n, torch.float8_e4m3fn, torch.bfloat16, False, False, False)
+    a_d, bt_d, sa_d, sb_d = a.cuda(), b.T.contiguous().cuda(), sa.cuda(), sb.cuda()
+    got = scaled_gemm(a_d, bt_d.T, sa_d, sb_d, torch.bfloat16)
+    rows = torch.cat([torch.arange(0, 48), torch.arange(2040, 2072), torch.arange(4080, 4096)])
+    ref = oracle.scaled_gemm_ref(a[rows], b, sa[rows], sb, torch.bfloat16, None)
+    check_scaled(got[rows.cuda()], ref, torch.float8_e4m3fn, torch.bfloat16)
+    _C.set_gemm_variant(_C.VARIANT_GENERIC)
+    slow = scaled_gemm(a_d, bt_d.T, sa_d, sb_d, torch.bfloat16)
+    _C.set_gemm_variant(_C.VARIANT_AUTO)
+    tol = 2.0 * EPS[torch.bfloat16] * slow.float().abs().max().item()
+    assert (got.float() - slow.float()).abs().max().item() <= tol
+    perm = torch.randperm(m, device="cuda")
+    got_p = scaled_gemm(a_d[perm].contiguous(), bt_d.T, sa_d[perm].contiguous(), sb_d, torch.bfloat16)
+    assert torch.equal(got_p, got[perm])
+
+
+# ---------------------------------------------------------------------------------------------
+# mixed precision
+# ---------------------------------------------------------------------------------------------
+WTYPES = {"uint4b8": scalar_types.uint4b8, "uint8b128": scalar_types.uint8b128, "uint4": scalar_types.uint4,
+          "uint8": scalar_types.uint8}
+
+
+def make_mixed_inputs(m, k, n, wtype, use_zp, dtype, group=128):
+    """Recipe of tests/mixed_precision_gemm_test.py:57-70."""
+    seed_everything(0)
+    a = (10 * (torch.rand((m, k), dtype=torch.float32) - 0.3)).to(dtype)
+    b = (10 * (torch.rand((k, n), dtype=torch.float32) - 0.3)).to(dtype)
+    w_ref, w_q, w_s, w_zp = quantize_weights(b, wtype, group, zero_points=use_zp)
+    packed = pack_rows(w_q, wtype.size_bits, *w_q.shape)
+    return a, w_ref, packed, w_s, w_zp
+
+
+def check_mixed(got, a, w_ref, k):
+    """The oracle is torch.matmul(a, w_ref) in the activation dtype; ours accumulates in fp32.
+
+    Bound: |diff| <= 2 eps_out * max|C| (accumulation order + the oracle's own half-precision
+    reduction), far inside the reference's rtol=1e-1 / atol=min(5e-2*sqrt(K), 1)."""
+    ref = oracle.mixed_precision_gemm_ref(a, w_ref).float()
+    exact = (a.double() @ w_ref.double()).float()
+    g = got.float().cpu()
+    scale = exact.abs().max().item()
+    eps = EPS[got.dtype]
+    assert (g - exact).abs().max().item() <= 1.0 * eps * scale
+    assert (g - ref).abs().max().item() <= 3.0 * eps * scale
+    atol = min(5e-2 * math.sqrt(k), 1)
+    torch.testing.assert_close(g, ref, rtol=1e-1, atol=atol)  # the reference's own bar
+
+
+@pytest.mark.parametrize(("m", "k", "n"), SHAPES)
+@pytest.mark.parametrize("wname", list(WTYPES))
+@pytest.mark.parametrize("use_zp", [True, False])
+@pytest.mark.parametrize("dname", ["f16", "bf16"])
+def test_mixed_precision_gemm_matrix(m, k, n, wname, use_zp, dname):
+    if (m, k, n) == SHAPES[2] and (wname in ("uint4", "uint8") or dname == "f16" and use_zp):
+        pytest.skip("large shape: subset only (oracle time)")
+    wt = WTYPES[wname]
+    a, w_ref, packed, w_s, w_zp = make_mixed_inputs(m, k, n, wt, use_zp, DT[dname])
+    got = mixed_precision_gemm(a.cuda(), packed.cuda(), w_s.cuda(), None if w_zp is None else w_zp.cuda(),
+                               wt.size_bits, wt.bias, 128)
+    assert got.shape == (m, n) and got.dtype == DT[dname]
+    check_mixed(got, a, w_ref, k)
+
+
+@pytest.mark.parametrize("wname", list(WTYPES))
+@pytest.mark.parametrize("zp", [1, 0])
+@pytest.mark.parametrize("dname", ["f16", "bf16"])
+def test_mixed_precision_gemm_golden_from_reference(golden, wname, zp, dname):
+    g = golden("mixed_gemm")
+    key = f"{wname}_zp{zp}_{dname}"
+    bits, bias, group = (int(v) for v in g[f"meta_{key}"])
+    dtype = DT[dname]
+    a = from_bits(g[f"a_{key}"], dtype)
+    packed = torch.from_numpy(g[f"packed_{key}"].copy())
+    w_s = from_bits(g[f"ws_{key}"], dtype)
+    w_zp = torch.from_numpy(g[f"wzp_{key}"].copy()) if zp else None
+    got = mixed_precision_gemm(a.cuda(), packed.cuda(), w_s.cuda(), None if w_zp is None else w_zp.cuda(), bits, bias,
+                               group)
+    check_mixed(got, a, from_bits(g[f"wref_{key}"], dtype), a.shape[1])
+
+
+def test_mixed_precision_dequant_is_bit_exact():
+    """X = identity isolates the dequantisation: C must equal w_ref bit-for-bit."""
+    k = n = 256
+    for dname in ("f16", "bf16"):
+        for wname, wt in WTYPES.items():
+            for use_zp in (False, True):
+                _, w_ref, packed, w_s, w_zp = make_mixed_inputs(8, k, n, wt, use_zp, DT[dname])
+                eye = torch.eye(k, dtype=DT[dname])
+                got = mixed_precision_gemm(eye.cuda(), packed.cuda(), w_s.cuda(),
+                                           None if w_zp is None else w_zp.cuda(), wt.size_bits, wt.bias, 128)
+                np.testing.assert_array_equal(to_bits(got), to_bits(w_ref), err_msg=f"{dname} {wname} zp={use_zp}")
+
+
+def test_mixed_precision_scalar_zero_point_and_output_dtype():
+    wt = scalar_types.uint4
+    a, _, packed, w_s, _ = make_mixed_inputs(64, 256, 128, wt, False, torch.float16)
+    zp = torch.tensor([7], dtype=torch.int32)
+    w = oracle.dequantize_packed(packed, w_s, zp, 4, 0, 128)
+    got = mixed_precision_gemm(a.cuda(), packed.cuda(), w_s.cuda(), zp.cuda(), 4, 0, 128, output_dtype=torch.bfloat16)
+    assert got.dtype == torch.bfloat16
+    exact = (a.double() @ w.double()).float()
+    assert (got.float().cpu() - exact).abs().max().item() <= EPS[torch.bfloat16] * exact.abs().max().item()

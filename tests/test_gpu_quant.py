@@ -1,0 +1,135 @@
+"""GPU parity: static int8 / fp8 quantisation kernels vs the CPU oracle (bit-exact).
+
+Mirrors the reference's matrices (tests/int8_quant_kernels_test.py:16-50,
+tests/fp8_quant_kernels_test.py:16-57): dtype x hidden x tokens x scale = 120 cases each.  The
+reference allows atol=1 (int8) / default assert_close on dequantised values (fp8) because Triton's
+cast differs from torch's; the HIP kernels restate the oracle's arithmetic, so the bar here is
+bit-exact codes.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conch_amd.ops.quantization.fp8 import scaled_fp8_quant, static_scaled_fp8_quant
+from conch_amd.ops.quantization.int8 import scaled_int8_quant, static_scaled_int8_quant
+from conch_amd.third_party.vllm.utils import seed_everything
+from tests.conftest import DT, from_bits, to_bits
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.half, torch.bfloat16, torch.float]
+HIDDEN = [16, 67, 768, 5137, 8193]
+TOKENS = [1, 7, 83, 4096]
+SCALES = [0.1, 2.1]
+FP8 = {"fn": (oracle.FP8_E4M3FN, torch.float8_e4m3fn), "fnuz": (oracle.FP8_E4M3FNUZ, torch.float8_e4m3fnuz)}
+
+
+@pytest.mark.parametrize("num_tokens", TOKENS)
+@pytest.mark.parametrize("hidden_size", HIDDEN)
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("scale", SCALES)
+@torch.inference_mode()
+def test_static_scaled_int8_quant(num_tokens, hidden_size, dtype, scale):
+    seed_everything(0)
+    x = torch.rand(num_tokens, hidden_size, dtype=dtype, device="cuda") * 1000
+    scale_arg = torch.tensor([scale], dtype=torch.float32, device="cuda")
+    out, ret_scale = scaled_int8_quant(x, scale_arg)
+    assert ret_scale is scale_arg and out.dtype == torch.int8 and out.shape == x.shape
+    ref = oracle.scaled_int8_quant_ref(x.cpu(), scale_arg.cpu())
+    assert torch.equal(out.cpu(), ref)
+
+
+@pytest.mark.parametrize("flav", list(FP8))
+@pytest.mark.parametrize("num_tokens", TOKENS)
+@pytest.mark.parametrize("hidden_size", HIDDEN)
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("scale", SCALES)
+@torch.inference_mode()
+def test_static_scaled_fp8_quant(flav, num_tokens, hidden_size, dtype, scale):
+    name, tdt = FP8[flav]
+    seed_everything(0)
+    x = torch.rand(num_tokens, hidden_size, dtype=dtype, device="cuda")
+    scale_arg = torch.tensor([scale], dtype=torch.float32, device="cuda")
+    out, ret_scale = scaled_fp8_quant(x, scale_arg, output_dtype=tdt)
+    assert ret_scale is scale_arg and out.dtype == tdt
+    ref = oracle.scaled_fp8_quant_ref(x.cpu(), scale_arg.cpu(), name)
+    np.testing.assert_array_equal(to_bits(out), to_bits(ref))
+
+
+def test_default_fp8_flavour_is_ocp_on_gfx950():
+    x = torch.rand(4, 64, device="cuda")
+    out, _ = scaled_fp8_quant(x, torch.tensor([1.0], device="cuda"))
+    assert out.dtype == torch.float8_e4m3fn
+
+
+@pytest.mark.parametrize("dname", list(DT))
+@pytest.mark.parametrize("sname", ["one", "s2p1"])
+def test_quant_edge_vectors_from_reference(golden, dname, sname):
+    """Ties, negative fractions, overflow both ways, subnormals: golden outputs of the reference."""
+    gi, gf = golden("quant_int8"), golden("quant_fp8")
+    x = from_bits(gi[f"edge_x_{dname}_{sname}"], DT[dname]).cuda()
+    s = torch.from_numpy(gi[f"edge_s_{dname}_{sname}"]).cuda()
+    q, _ = scaled_int8_quant(x, s)
+    np.testing.assert_array_equal(q.cpu().numpy(), gi[f"edge_q_{dname}_{sname}"])
+    for flav, (_, tdt) in FP8.items():
+        q8, _ = scaled_fp8_quant(x, s, output_dtype=tdt)
+        np.testing.assert_array_equal(to_bits(q8), gf[f"edge_q{flav}_{dname}_{sname}"])
+
+
+def test_quant_golden_grid_subset(golden):
+    gi, gf = golden("quant_int8"), golden("quant_fp8")
+    for dname in DT:
+        for tokens, hidden in ((7, 67), (83, 768)):
+            key = f"{dname}_t{tokens}_h{hidden}_s2.1"
+            s = torch.tensor([2.1], device="cuda")
+            q, _ = scaled_int8_quant(from_bits(gi[f"x_{key}"], DT[dname]).cuda(), s)
+            np.testing.assert_array_equal(q.cpu().numpy(), gi[f"q_{key}"])
+            x8 = from_bits(gf[f"x_{key}"], DT[dname]).cuda()
+            for flav, (_, tdt) in FP8.items():
+                q8, _ = scaled_fp8_quant(x8, s, output_dtype=tdt)
+                np.testing.assert_array_equal(to_bits(q8), gf[f"q{flav}_{key}"])
+
+
+def test_fp8_all_codes_roundtrip_and_dense_sweep():
+    """Every finite fp8 value re-encodes to itself; a dense fp32 sweep matches the oracle."""
+    one = torch.tensor([1.0], device="cuda")
+    for name, tdt in FP8.values():
+        codes = np.arange(256, dtype=np.uint8)
+        vals = oracle.decode_fp8(codes, name)
+        finite = ~np.isnan(vals)
+        x = torch.from_numpy(vals[finite]).reshape(1, -1).cuda()
+        q, _ = scaled_fp8_quant(x, one, output_dtype=tdt)
+        ref = oracle.scaled_fp8_quant_ref(x.cpu(), one.cpu(), name)
+        np.testing.assert_array_equal(to_bits(q), to_bits(ref))
+        gen = torch.Generator().manual_seed(1)
+        sweep = (torch.randn(64, 4099, generator=gen) * torch.exp(torch.empty(64, 4099).uniform_(-14, 7, generator=gen)))
+        q, _ = scaled_fp8_quant(sweep.cuda(), one, output_dtype=tdt)
+        ref = oracle.scaled_fp8_quant_ref(sweep, one.cpu(), name)
+        np.testing.assert_array_equal(to_bits(q), to_bits(ref))
+
+
+def test_quant_empty_and_row_strided_inputs():
+    s = torch.tensor([0.7], device="cuda")
+    e, _ = scaled_int8_quant(torch.empty(0, 16, device="cuda"), s)
+    assert e.shape == (0, 16)
+    base = torch.rand(33, 200, device="cuda", dtype=torch.float16) * 300
+    view = base[:, 3:131]  # row stride 200, unaligned start -> strided kernel
+    out = torch.empty(33, 128, dtype=torch.int8, device="cuda")
+    static_scaled_int8_quant(out, view, s)
+    assert torch.equal(out.cpu(), oracle.scaled_int8_quant_ref(view.cpu(), s.cpu()))
+    out8 = torch.empty(33, 128, dtype=torch.float8_e4m3fn, device="cuda")
+    static_scaled_fp8_quant(out8, view, s)
+    np.testing.assert_array_equal(to_bits(out8), to_bits(oracle.scaled_fp8_quant_ref(view.cpu(), s.cpu())))
+
+
+def test_quant_c1_config_bit_exact():
+    """BASELINE config C1: 4096x4096 fp16, scale 2.1 (int8 bench :124-125)."""
+    seed_everything(0)
+    x = torch.rand(4096, 4096, dtype=torch.float16, device="cuda") * 1000
+    s = torch.tensor([2.1], dtype=torch.float32, device="cuda")
+    q, _ = scaled_int8_quant(x, s)
+    assert torch.equal(q.cpu(), oracle.scaled_int8_quant_ref(x.cpu(), s.cpu()))

@@ -1,0 +1,185 @@
+"""CPU-only tests of the host side: C-ABI library surface, format helpers, metadata / error paths."""
+
+from __future__ import annotations
+
+import ctypes
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from conch_amd import _C
+from conch_amd.kernels.quantization.gemm import ChannelScaleMode, WeightGroupMode
+from conch_amd.ops.quantization.fp8 import scaled_fp8_quant
+from conch_amd.ops.quantization.gemm import (
+    create_mixed_precision_metadata,
+    create_scaled_metadata,
+    mixed_precision_gemm,
+    scaled_gemm,
+)
+from conch_amd.ops.quantization.int8 import scaled_int8_quant
+from conch_amd.third_party.vllm.quant_utils import pack_rows, quantize_weights
+from conch_amd.third_party.vllm.scalar_type import scalar_types
+from tests.conftest import DT, ROOT, from_bits, to_bits
+
+WTYPES = {
+    "uint4b8": scalar_types.uint4b8,
+    "uint8b128": scalar_types.uint8b128,
+    "uint4": scalar_types.uint4,
+    "uint8": scalar_types.uint8,
+}
+
+
+def test_library_exports_every_declared_symbol():
+    header = (ROOT / "include" / "conch_amd.h").read_text()
+    declared = set(re.findall(r"\b(conch_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed from include/conch_amd.h"
+    assert declared == set(_C.EXPORTED_SYMBOLS)
+    lib = _C.load()
+    for name in declared:
+        assert isinstance(getattr(lib, name), ctypes._CFuncPtr)  # noqa: SLF001
+    assert lib.conch_abi_version() == 1
+
+
+def test_c_abi_validation_without_gpu():
+    """Argument validation happens before any HIP call, so it can be exercised on a CPU box."""
+    lib = _C.load()
+    rc = lib.conch_scaled_gemm(None, None, None, None, None, None, 4, 4, 4, 4, 1, 1, 4, 4, 1, 1, 1, 77, _C.DT_BF16, None)
+    assert rc == 2 and b"input dtype" in lib.conch_last_error()
+    rc = lib.conch_scaled_gemm(None, None, None, None, None, None, 4, 4, 4, 4, 1, 1, 4, 4, 1, 1, 1, _C.DT_INT8, _C.DT_BF16, None)
+    assert rc == 1 and b"NULL" in lib.conch_last_error()
+    rc = lib.conch_scaled_gemm(None, None, None, None, None, None, -1, 4, 4, 4, 1, 1, 4, 4, 1, 1, 1, _C.DT_INT8, _C.DT_BF16, None)
+    assert rc == 1
+    # empty problems are a no-op
+    assert lib.conch_scaled_gemm(None, None, None, None, None, None, 0, 4, 4, 4, 1, 1, 4, 4, 1, 1, 1, _C.DT_INT8, _C.DT_BF16, None) == 0
+    assert lib.conch_static_scaled_int8_quant(None, None, None, 0, 16, 16, 16, _C.DT_FP16, None) == 0
+    assert lib.conch_static_scaled_int8_quant(None, None, None, 2, 16, 16, 16, _C.DT_FP16, None) == 1
+    rc = lib.conch_mixed_precision_gemm(None, None, None, None, None, 4, 4, 8, 8, 4, 4, 4, 4, 3, 0, 8, 0, _C.DT_FP16, _C.DT_FP16, None)
+    assert rc == 1 and b"weight_bits" in lib.conch_last_error()
+    with pytest.raises(ValueError):
+        _C.check(1, "x")
+    with pytest.raises(NotImplementedError):
+        _C.check(2, "x")
+    with pytest.raises(_C.ConchError):
+        _C.check(3, "x")
+
+
+def test_tuning_knob_roundtrip():
+    _C.set_gemm_variant(_C.VARIANT_GENERIC)
+    assert _C.get_gemm_variant() == _C.VARIANT_GENERIC
+    _C.set_gemm_variant(_C.VARIANT_AUTO)
+    assert _C.get_gemm_variant() == 0
+
+
+def test_ops_refuse_cpu_tensors():
+    """No silent CPU fallback: host tensors are an error."""
+    x = torch.rand(4, 16)
+    s = torch.tensor([1.0])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        scaled_int8_quant(x, s)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        scaled_fp8_quant(x, s)
+    a = torch.zeros(4, 128, dtype=torch.int8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        scaled_gemm(a, a.T.contiguous().T, s, s, torch.bfloat16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        mixed_precision_gemm(torch.zeros(4, 128, dtype=torch.float16), torch.zeros(16, 8, dtype=torch.int32),
+                             torch.ones(1, 8, dtype=torch.float16), None, 4, 8, 128)
+
+
+def test_dynamic_quant_not_implemented():
+    # reference: ops/quantization/int8.py:42-44, fp8.py:46-48
+    with pytest.raises(NotImplementedError):
+        scaled_int8_quant(torch.rand(2, 2))
+    with pytest.raises(NotImplementedError):
+        scaled_fp8_quant(torch.rand(2, 2))
+
+
+def test_scalar_types():
+    assert (scalar_types.uint4b8.size_bits, scalar_types.uint4b8.bias) == (4, 8)
+    assert (scalar_types.uint4b8.min(), scalar_types.uint4b8.max()) == (-8, 7)
+    assert (scalar_types.uint8b128.min(), scalar_types.uint8b128.max()) == (-128, 127)
+    assert (scalar_types.uint4.min(), scalar_types.uint4.max()) == (0, 15)
+    assert (scalar_types.uint8.min(), scalar_types.uint8.max()) == (0, 255)
+    assert str(scalar_types.uint4b8) == "uint4b8" and str(scalar_types.uint8) == "uint8"
+
+
+@pytest.mark.parametrize("wname", list(WTYPES))
+@pytest.mark.parametrize("zp", [1, 0])
+@pytest.mark.parametrize("dname", ["f16", "bf16"])
+def test_quantize_weights_and_pack_rows_match_reference(golden, wname, zp, dname):
+    g = golden("mixed_gemm")
+    key = f"{wname}_zp{zp}_{dname}"
+    wt = WTYPES[wname]
+    b = from_bits(g[f"b_{key}"], DT[dname])
+    w_ref, w_q, w_s, w_zp = quantize_weights(b, wt, 128, zero_points=bool(zp))
+    np.testing.assert_array_equal(to_bits(w_ref), g[f"wref_{key}"])
+    np.testing.assert_array_equal(w_q.numpy(), g[f"wq_{key}"])
+    np.testing.assert_array_equal(to_bits(w_s), g[f"ws_{key}"])
+    if zp:
+        np.testing.assert_array_equal(w_zp.numpy(), g[f"wzp_{key}"])
+    else:
+        assert w_zp is None
+    packed = pack_rows(w_q, wt.size_bits, *w_q.shape)
+    assert packed.dtype == torch.int32
+    np.testing.assert_array_equal(packed.numpy(), g[f"packed_{key}"])
+
+
+def test_pack_rows_rejects_bad_shapes():
+    with pytest.raises(ValueError):
+        pack_rows(torch.zeros(7, 4, dtype=torch.int32), 4, 7, 4)
+    with pytest.raises(ValueError):
+        pack_rows(torch.zeros(8, 4, dtype=torch.int32), 4, 16, 4)
+
+
+def test_scaled_metadata_and_strict_errors():
+    a = torch.zeros(8, 128, dtype=torch.int8)
+    b = torch.zeros(16, 128, dtype=torch.int8).T
+    sa, sb = torch.ones(8, 1), torch.ones(16, 1)
+    md = create_scaled_metadata(a, b, sa, sb, torch.bfloat16, strict=True)
+    assert (md.m_dim, md.k_dim, md.n_dim) == (8, 128, 16)
+    assert md.acc_dtype == torch.int32 and md.meta_dtype == torch.float32
+    assert md.channel_scale_mode == ChannelScaleMode.WEIGHT_AND_ACTIVATION
+    assert md.weight_group_mode == WeightGroupMode.NONE
+    assert not md.data_contiguous  # b is a transposed view
+    f8 = create_scaled_metadata(a.to(torch.float8_e4m3fn), b.to(torch.float8_e4m3fn), sa, sb, torch.float16)
+    assert f8.acc_dtype == torch.float32
+    with pytest.raises(ValueError, match="dimensions of input tensor a"):
+        create_scaled_metadata(a[0], b, sa, sb, torch.bfloat16, strict=True)
+    with pytest.raises(ValueError, match="same datatype"):
+        create_scaled_metadata(a, b.to(torch.uint8), sa, sb, torch.bfloat16, strict=True)
+    with pytest.raises(ValueError, match="scale_a shape"):
+        create_scaled_metadata(a, b, torch.ones(7, 1), sb, torch.bfloat16, strict=True)
+    with pytest.raises(ValueError, match="scale_b"):
+        create_scaled_metadata(a, b, sa, torch.ones(16), torch.bfloat16, strict=True)
+    # non-strict validates nothing
+    create_scaled_metadata(a, b, torch.ones(7, 1), sb, torch.bfloat16)
+
+
+def test_mixed_metadata_and_strict_errors():
+    x = torch.zeros(4, 256, dtype=torch.float16)
+    wq = torch.zeros(32, 8, dtype=torch.int32)
+    ws = torch.ones(2, 8, dtype=torch.float16)
+    zp = torch.zeros(2, 8, dtype=torch.int32)
+    md = create_mixed_precision_metadata(x, wq, ws, None, 4, 8, 128, strict=True)
+    assert (md.m_dim, md.k_dim, md.n_dim) == (4, 256, 8)
+    assert md.elements_per_sample == 8 and md.unpack_mask == 15 and not md.zero_is_scalar
+    assert md.weight_group_mode == WeightGroupMode.SYMMETRIC_NO_SHIFT
+    assert md.output_dtype == torch.float16 and md.acc_dtype == torch.float32 and md.meta_dtype == torch.float16
+    assert md.channel_scale_mode == ChannelScaleMode.NONE and md.data_contiguous
+    md = create_mixed_precision_metadata(x, wq, ws, zp, 4, 8, 128, output_dtype=torch.bfloat16)
+    assert md.weight_group_mode == WeightGroupMode.SYMMETRIC_WITH_SHIFT and md.output_dtype == torch.bfloat16
+    md = create_mixed_precision_metadata(x, wq, ws, torch.zeros(1, dtype=torch.int32), 8, 128, 128)
+    assert md.zero_is_scalar and md.elements_per_sample == 4 and md.unpack_mask == 255
+    with pytest.raises(ValueError, match="w_q_packed"):
+        create_mixed_precision_metadata(x, wq[0], ws, None, 4, 8, 128, strict=True)
+    with pytest.raises(ValueError, match="packed weights"):
+        create_mixed_precision_metadata(x, wq.to(torch.int64), ws, None, 4, 8, 128, strict=True)
+    with pytest.raises(ValueError, match="w_s shape"):
+        create_mixed_precision_metadata(x, wq, ws[:1], None, 4, 8, 128, strict=True)
+    with pytest.raises(ValueError, match="w_zp shape"):
+        create_mixed_precision_metadata(x, wq, ws, zp[:1], 4, 8, 128, strict=True)
+    with pytest.raises(NotImplementedError):
+        create_mixed_precision_metadata(x, wq, ws, None, 4, 8, 128, scaled_activations=True, strict=True)

@@ -1,0 +1,44 @@
+"""Quick per-variant kernel timing on the GPU box (development aid, not the judged bench)."""
+import ctypes
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from conch_amd import _C  # noqa: E402
+from conch_amd.kernels.quantization import gemm as kg  # noqa: E402
+from conch_amd.ops.quantization.gemm import create_scaled_metadata  # noqa: E402
+
+
+def time_scaled(m, k, n, dtype, variant, iters=20):
+    torch.manual_seed(0)
+    if dtype == torch.int8:
+        a = torch.randint(-32, 32, (m, k), dtype=torch.int8, device="cuda")
+        bt = torch.randint(-32, 32, (n, k), dtype=torch.int8, device="cuda")
+    else:
+        a = (0.25 * torch.rand((m, k), device="cuda")).to(dtype)
+        bt = (0.25 * torch.rand((n, k), device="cuda")).to(dtype)
+    sa = 0.25 * torch.rand((m, 1), device="cuda")
+    sb = 0.25 * torch.rand((n, 1), device="cuda")
+    out = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
+    md = create_scaled_metadata(a, bt.T, sa, sb, torch.bfloat16)
+    _C.set_gemm_variant(variant)
+    ms = ctypes.c_float()
+    try:
+        for it in (3, iters):
+            rc = kg._scaled_gemm_call("conch_time_scaled_gemm", out, a, bt.T, sa, sb, md, None, (it, ctypes.byref(ms)))
+            _C.check(rc, "time")
+    finally:
+        _C.set_gemm_variant(0)
+    return ms.value
+
+
+if __name__ == "__main__":
+    shapes = [(4096, 4096, 11008), (8192, 8192, 8192), (128, 4096, 4096), (8192, 8192, 3584)]
+    for dtype in (torch.float8_e4m3fn, torch.int8):
+        for (m, k, n) in shapes:
+            for variant in (2, 3):
+                ms = time_scaled(m, k, n, dtype, variant)
+                tf = 2.0 * m * n * k / (ms * 1e-3) / 1e12
+                print(f"{str(dtype):24s} M={m} K={k} N={n} variant={variant}: {ms*1e3:9.1f} us  {tf:8.1f} TFLOP/s", flush=True)
