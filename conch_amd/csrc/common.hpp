@@ -75,6 +75,14 @@ __device__ __forceinline__ uint16_t float_to_bf16_bits(float f) {
   return __builtin_bit_cast(uint16_t, (__bf16)f);
 }
 
+// Make an fp32 value opaque to the optimiser.  hipcc otherwise folds `(_Float16)(a * b)` into
+// v_fma_mixlo_f16, which rounds the exact product ONCE to fp16; the reference rounds to fp32 first
+// and then to fp16 (torch), and the two differ in rare double-rounding cases.
+__device__ __forceinline__ float pin_f32(float v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
 template <int DT>
 __device__ __forceinline__ float load_as_float(const void* p, int64_t idx) {
   if constexpr (DT == CONCH_DT_FP32) {

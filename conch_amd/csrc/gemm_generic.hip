@@ -40,11 +40,11 @@ __global__ __launch_bounds__(256) void scaled_gemm_generic_kernel(ScaledGemmArgs
   const float sa = p.scale_a[p.scale_a_numel == 1 ? 0 : m];
   const float sb = p.scale_b[p.scale_b_numel == 1 ? 0 : n];
   float v = sa * accf;
-  v = sb * v;
+  v = pin_f32(sb * v);  // rounded to fp32 before the cast, like torch
   uint16_t o = float_to_bits16<OUT_DT>(v);
   if (p.bias) {
     const float bsum = bits16_to_float<OUT_DT>(o) + bits16_to_float<OUT_DT>(((const uint16_t*)p.bias)[n]);
-    o = float_to_bits16<OUT_DT>(bsum);
+    o = float_to_bits16<OUT_DT>(pin_f32(bsum));
   }
   ((uint16_t*)p.c)[m * p.c_stride_m + n * p.c_stride_n] = o;
 }

@@ -231,9 +231,9 @@ __device__ __forceinline__ void epilogue(const WaveTile<MMA>& w, const ScaledGem
       for (int e = 0; e < 8; ++e) {
         const float accf = (float)w.acc[mt][nh * 2 + (e >> 2)][e & 3];
         float v = sa * accf;  // scaled_gemm.py:21
-        v = sb[e] * v;        // :22
+        v = pin_f32(sb[e] * v);  // :22 (rounded to fp32 before the cast, like torch)
         uint16_t h = float_to_bits16<OUT_DT>(v);  // :23
-        if (bias) h = float_to_bits16<OUT_DT>(bits16_to_float<OUT_DT>(h) + bs[e]);  // :24-25
+        if (bias) h = float_to_bits16<OUT_DT>(pin_f32(bits16_to_float<OUT_DT>(h) + bs[e]));  // :24-25
         o[e] = h;
       }
       uint16_t* dst = (uint16_t*)p.c + (int64_t)m * p.c_stride_m + n0;

@@ -1,0 +1,17 @@
+#!/bin/bash
+# rocprofv3 passes for the headline bench (run on the GPU box through gpurun).
+# usage: tools/gpu_profile.sh <tag> [bench args...]   -> gpurun_out/prof_<tag>/
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+TAG="$1"; shift
+OUT="$ROOT/gpurun_out/prof_$TAG"
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+BENCH=("$ROOT/bench.py" --steps 30 --warmup 5 --no-cpu-baseline "$@")
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "${BENCH[@]}" > "$OUT/trace.log" 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
+  --output-format csv -d "$OUT/pmc_sq" -- python3 "${BENCH[@]}" > "$OUT/pmc_sq.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_fetch" -- python3 "${BENCH[@]}" > "$OUT/pmc_fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$OUT/pmc_write" -- python3 "${BENCH[@]}" > "$OUT/pmc_write.log" 2>&1
+# keep only the small summaries
+find "$OUT" -name "*.csv" -size +3M -delete
+ls -R "$OUT" | head -50
