@@ -202,50 +202,88 @@ __device__ __forceinline__ void phase_mma(WaveTile<MMA>& w) {
 // ---------------------------------------------------------------------------------------------
 // epilogue
 // ---------------------------------------------------------------------------------------------
+// The per-row / per-column scales and the bias of the block's 256 rows / 256 columns are parked in
+// the 3 KiB of LDS behind the operand buffers at kernel start (one coalesced load per thread), so
+// the epilogue is LDS reads + arithmetic + 16-byte stores with no dependent global round trips.
+constexpr int kEpiOff = kLdsBytes;            // float sa[256] | float sb[256] | float bias[256]
+constexpr int kLdsTotal = kLdsBytes + 3 * 1024;
+
+struct EpiPrefetch {
+  float v0;
+  uint32_t bias_bits;  // converted when parked, so the load is not waited for here
+};
+
+__device__ __forceinline__ EpiPrefetch epilogue_prefetch(const ScaledGemmArgs& p, int bm0, int bn0) {
+  // branch-free: threads 0-255 fetch scale_a[row], threads 256-511 scale_b[col] (and the bias)
+  EpiPrefetch e;
+  const int t = threadIdx.x;
+  const bool is_b = t >= 256;
+  const int idx = min((is_b ? bn0 : bm0) + (t & 255), (int)(is_b ? p.n : p.m) - 1);
+  const float* base = is_b ? p.scale_b : p.scale_a;
+  const bool vec = (is_b ? p.scale_b_numel : p.scale_a_numel) != 1;
+  e.v0 = base[vec ? idx : 0];
+  uint32_t bits = 0;
+  if (p.bias) bits = ((const uint16_t*)p.bias)[min(bn0 + (t & 255), (int)p.n - 1)];
+  e.bias_bits = bits;
+  return e;
+}
+
+template <int OUT_DT>
+__device__ __forceinline__ void epilogue_park(char* lds, const EpiPrefetch& e) {
+  float* f = (float*)(lds + kEpiOff);
+  const int t = threadIdx.x;
+  uint32_t bits = e.bias_bits;
+  asm volatile("" : "+v"(bits));  // keep the conversion (and so the wait for the load) down here
+  f[t] = e.v0;  // t < 256: sa[t]; else sb[t-256] at f[256 + (t-256)]
+  if (t >= 256) f[t + 256] = bits16_to_float<OUT_DT>((uint16_t)bits);
+}
+
 template <int MMA, int OUT_DT>
-__device__ __forceinline__ void epilogue(const WaveTile<MMA>& w, const ScaledGemmArgs& p, int bm0, int bn0,
-                                         int wr, int wc, int lane) {
+__device__ __forceinline__ void epilogue(const WaveTile<MMA>& w, const ScaledGemmArgs& p, const char* lds,
+                                         int bm0, int bn0, int wr, int wc, int lane) {
   const int g = lane >> 4, jm = lane & 15;
-  const bool sa_vec = p.scale_a_numel != 1;
-  const bool sb_vec = p.scale_b_numel != 1;
   const bool vec_store = (p.c_stride_m % 8 == 0) && (((uintptr_t)p.c & 15) == 0);
-  const uint16_t* bias = (const uint16_t*)p.bias;
+  const bool has_bias = p.bias != nullptr;
+  const float* lsa = (const float*)(lds + kEpiOff);
+  const float* lsb = lsa + 256;
+  const float* lbias = lsa + 512;
 #pragma unroll
   for (int nh = 0; nh < 2; ++nh) {
-    const int n0 = bn0 + wc * 64 + nh * 32 + 8 * g;
-    float sb[8];
-    float bs[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int n = min(n0 + e, (int)p.n - 1);
-      sb[e] = p.scale_b[sb_vec ? n : 0];
-      bs[e] = bias ? bits16_to_float<OUT_DT>(bias[n]) : 0.f;
-    }
+    const int nl = wc * 64 + nh * 32 + 8 * g;  // block-local column of this lane's 8 outputs
+    const int n0 = bn0 + nl;
+    const f32x4 sb_lo = *(const f32x4*)(lsb + nl), sb_hi = *(const f32x4*)(lsb + nl + 4);
+    const f32x4 bs_lo = *(const f32x4*)(lbias + nl), bs_hi = *(const f32x4*)(lbias + nl + 4);
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) {
-      const int m = bm0 + wr * 128 + mt * 16 + jm;
-      if (m >= p.m) continue;
-      const float sa = p.scale_a[sa_vec ? m : 0];
+      const int ml = wr * 128 + mt * 16 + jm;
+      const int m = bm0 + ml;
+      const float sa = lsa[ml];
       uint16_t o[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float accf = (float)w.acc[mt][nh * 2 + (e >> 2)][e & 3];
-        float v = sa * accf;  // scaled_gemm.py:21
-        v = pin_f32(sb[e] * v);  // :22 (rounded to fp32 before the cast, like torch)
+        const float sbe = e < 4 ? sb_lo[e & 3] : sb_hi[e & 3];
+        float v = sa * accf;     // scaled_gemm.py:21
+        v = pin_f32(sbe * v);    // :22 (rounded to fp32 before the cast, like torch)
         uint16_t h = float_to_bits16<OUT_DT>(v);  // :23
-        if (bias) h = float_to_bits16<OUT_DT>(pin_f32(bits16_to_float<OUT_DT>(h) + bs[e]));  // :24-25
+        if (has_bias) {          // :24-25, added in the output dtype
+          const float be = e < 4 ? bs_lo[e & 3] : bs_hi[e & 3];
+          h = float_to_bits16<OUT_DT>(pin_f32(bits16_to_float<OUT_DT>(h) + be));
+        }
         o[e] = h;
       }
-      uint16_t* dst = (uint16_t*)p.c + (int64_t)m * p.c_stride_m + n0;
-      if (vec_store && n0 + 8 <= p.n) {
-        i32x4 pk;
+      if (m < p.m) {
+        uint16_t* dst = (uint16_t*)p.c + (int64_t)m * p.c_stride_m + n0;
+        if (vec_store && n0 + 8 <= p.n) {
+          i32x4 pk;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) pk[e] = (int)((uint32_t)o[2 * e] | ((uint32_t)o[2 * e + 1] << 16));
-        *(i32x4*)dst = pk;
-      } else {
+          for (int e = 0; e < 4; ++e) pk[e] = (int)((uint32_t)o[2 * e] | ((uint32_t)o[2 * e + 1] << 16));
+          *(i32x4*)dst = pk;
+        } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (n0 + e < p.n) dst[e] = o[e];
+          for (int e = 0; e < 8; ++e)
+            if (n0 + e < p.n) dst[e] = o[e];
+        }
       }
     }
   }
@@ -297,12 +335,13 @@ __device__ __forceinline__ void zero_acc(WaveTile<MMA>& w) {
 // right after it.  Bring-up / cross-check kernel.
 template <int MMA, int OUT_DT>
 __global__ __launch_bounds__(kThreads, 2) void scaled_gemm_simple_kernel(ScaledGemmArgs p) {
-  __shared__ __attribute__((aligned(1024))) char lds[kLdsBytes];
+  __shared__ __attribute__((aligned(1024))) char lds[kLdsTotal];
   const BlockSetup s = setup_block(p);
   WaveTile<MMA> w;
   zero_acc<MMA>(w);
   const int steps = (int)(p.k / kStepBytes);
 
+  epilogue_park<OUT_DT>(lds, epilogue_prefetch(p, s.bm0, s.bn0));
   stage_unit<kU1>(lds, s.src, s.so, s.wave, 0);
   stage_unit<kV1>(lds, s.src, s.so, s.wave, 0);
   stage_unit<kV2>(lds, s.src, s.so, s.wave, 0);
@@ -325,7 +364,7 @@ __global__ __launch_bounds__(kThreads, 2) void scaled_gemm_simple_kernel(ScaledG
     phase_mma<MMA, 2>(w);
     phase_mma<MMA, 3>(w);
   }
-  epilogue<MMA, OUT_DT>(w, p, s.bm0, s.bn0, s.wr, s.wc, s.lane);
+  epilogue<MMA, OUT_DT>(w, p, lds, s.bm0, s.bn0, s.wr, s.wc, s.lane);
 }
 
 // Variant 3: 4 phases per K step, two wave groups (waves 0-3 / 4-7 = the two waves of each SIMD)
@@ -392,12 +431,14 @@ __device__ __forceinline__ void pingpong_step(WaveTile<MMA>& w, char* lds, const
 
 template <int MMA, int OUT_DT>
 __global__ __launch_bounds__(kThreads, 2) void scaled_gemm_pingpong_kernel(ScaledGemmArgs p) {
-  __shared__ __attribute__((aligned(1024))) char lds[kLdsBytes];
+  __shared__ __attribute__((aligned(1024))) char lds[kLdsTotal];
   const BlockSetup s = setup_block(p);
   WaveTile<MMA> w;
   zero_acc<MMA>(w);
   const int steps = (int)(p.k / kStepBytes);
 
+  // scales / bias of this block: issue the loads now, park them in LDS behind the prologue DMA
+  const EpiPrefetch epi = epilogue_prefetch(p, s.bm0, s.bn0);
   // prologue: units 0..5 (all of K step 0, U1/V1 of K step 1)
   stage_unit<kU1>(lds, s.src, s.so, s.wave, 0);
   stage_unit<kV1>(lds, s.src, s.so, s.wave, 0);
@@ -406,8 +447,10 @@ __global__ __launch_bounds__(kThreads, 2) void scaled_gemm_pingpong_kernel(Scale
   if (steps > 1) {
     stage_unit<kU1>(lds, s.src, s.so, s.wave, 1);
     stage_unit<kV1>(lds, s.src, s.so, s.wave, 1);
+    epilogue_park<OUT_DT>(lds, epi);
     CONCH_VMCNT(8);  // units 0,1 landed
   } else {
+    epilogue_park<OUT_DT>(lds, epi);
     CONCH_VMCNT(4);
   }
   __builtin_amdgcn_s_barrier();
@@ -422,7 +465,7 @@ __global__ __launch_bounds__(kThreads, 2) void scaled_gemm_pingpong_kernel(Scale
   pingpong_step<MMA, 0, 0, 0, 0, 2, 0, -1, -1>(w, lds, s, t);
   if (s.wr == 0) __builtin_amdgcn_s_barrier();  // re-balance the barrier count
 
-  epilogue<MMA, OUT_DT>(w, p, s.bm0, s.bn0, s.wr, s.wc, s.lane);
+  epilogue<MMA, OUT_DT>(w, p, lds, s.bm0, s.bn0, s.wr, s.wc, s.lane);
 }
 
 }  // namespace
