@@ -24,33 +24,14 @@
 //   * workgroup ids are remapped XCD-aware (8 XCDs, private L2s) on top of a GROUP_M raster.
 #include "common.hpp"
 #include "gemm.hpp"
+#include "mfma_tile.hpp"
 
 namespace conch {
 namespace {
 
-constexpr int kThreads = 512;
-constexpr int kTileM = 256;
-constexpr int kTileN = 256;
-constexpr int kStepBytes = 128;                     // K bytes per LDS row / per K step
-constexpr int kUnitBytes = 128 * kStepBytes;        // 16 KiB: 128 rows
-constexpr int kBufBytes = 4 * kUnitBytes;           // U1, V1, V2, U2
-constexpr int kLdsBytes = 2 * kBufBytes;            // double buffered: 128 KiB
-constexpr int kGroupM = 4;
-
-// Stream order of the units of one K step.  U = rows of A (m), V = rows of B^T (n).
-// U1/U2 hold the first/second 64 rows of BOTH wave-rows' 128-row m ranges, V1/V2 the
-// first/second 32 rows of all four wave-columns' 64-row n ranges, so that a unit is needed by
-// every wave in the same phase.
-enum { kU1 = 0, kV1 = 1, kV2 = 2, kU2 = 3 };
+using namespace tile;
 
 enum { kMmaFp8 = 0, kMmaInt8 = 1 };
-
-typedef __attribute__((address_space(3))) void lds_void_t;
-
-struct Frag {
-  i32x4 lo;  // 16-byte chunk g      of the 128-byte K row
-  i32x4 hi;  // 16-byte chunk g + 4
-};
 
 template <int MMA> struct AccT { typedef f32x4 type; };
 template <> struct AccT<kMmaInt8> { typedef i32x4 type; };
@@ -69,97 +50,6 @@ __device__ __forceinline__ void mma_step(typename AccT<MMA>::type& acc, const Fr
     acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa.lo, fb.lo, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa.hi, fb.hi, acc, 0, 0, 0);
   }
-}
-
-struct TileCoord {
-  int tm, tn;
-};
-
-// XCD-aware + GROUP_M rasterisation.  Workgroups are dealt round-robin over the 8 XCDs, so ids
-// b and b+8 share an L2: give each XCD a contiguous run of the GROUP_M-ordered tile list
-// (bijective for any grid size).  Pure speed; correctness does not depend on placement.
-__device__ __forceinline__ TileCoord map_tile(int bid, int tiles_m, int tiles_n) {
-  const int nwg = tiles_m * tiles_n;
-  const int xcd = bid & 7;
-  const int q = nwg >> 3, r = nwg & 7;
-  const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  const int per_group = kGroupM * tiles_n;
-  const int group = lin / per_group;
-  const int first_m = group * kGroupM;
-  const int gsz = min(tiles_m - first_m, kGroupM);
-  const int in_group = lin - group * per_group;
-  TileCoord t;
-  t.tm = first_m + in_group % gsz;
-  t.tn = in_group / gsz;
-  return t;
-}
-
-// Per-lane state of the LDS-DMA staging: byte offset of this lane's 16-byte source chunk for each
-// (unit kind, j) wave-instruction, relative to the A / B^T base.
-struct StageOffsets {
-  int off[4][2];
-};
-
-__device__ __forceinline__ StageOffsets make_stage_offsets(int wave, int lane, int bm0, int bn0,
-                                                           int m_max, int n_max, int lda, int ldb) {
-  StageOffsets s;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int rho = 16 * wave + 8 * j + (lane >> 3);    // row of the unit this lane feeds
-    const int chunk = (lane & 7) ^ ((rho >> 1) & 7);    // source chunk that lands at lane&7
-    // U kinds: unit row -> block m
-    const int mrow = (rho >> 6) * 128 + (rho & 63);
-    // V kinds: unit row -> block n, permuted so that MFMA D rows 4g+e of tile t are n = 8g+e+4t
-    const int r5 = rho & 31, r = r5 & 15, t = r5 >> 4;
-    const int nrow = (rho >> 5) * 64 + 8 * (r >> 2) + (r & 3) + 4 * t;
-    s.off[kU1][j] = min(bm0 + mrow, m_max) * lda + chunk * 16;
-    s.off[kU2][j] = min(bm0 + mrow + 64, m_max) * lda + chunk * 16;
-    s.off[kV1][j] = min(bn0 + nrow, n_max) * ldb + chunk * 16;
-    s.off[kV2][j] = min(bn0 + nrow + 32, n_max) * ldb + chunk * 16;
-  }
-  return s;
-}
-
-struct Srcs {
-  __amdgpu_buffer_rsrc_t a;
-  __amdgpu_buffer_rsrc_t b;
-};
-
-// Issue the two LDS-DMA wave-instructions this wave contributes to unit `KIND` of K step `tile`.
-template <int KIND>
-__device__ __forceinline__ void stage_unit(char* lds, const Srcs& src, const StageOffsets& so, int wave,
-                                           int tile) {
-  const int buf = tile & 1;
-  const int koff = tile * kStepBytes;
-  char* dst = lds + buf * kBufBytes + KIND * kUnitBytes + wave * 2048;
-  if constexpr (KIND == kU1 || KIND == kU2) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(src.a, (lds_void_t*)dst, 16, so.off[KIND][0], koff, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(src.a, (lds_void_t*)(dst + 1024), 16, so.off[KIND][1], koff, 0, 0);
-  } else {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(src.b, (lds_void_t*)dst, 16, so.off[KIND][0], koff, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(src.b, (lds_void_t*)(dst + 1024), 16, so.off[KIND][1], koff, 0, 0);
-  }
-}
-
-// `off` is a byte offset from the (1024-aligned) LDS base; every term of it except the chunk is a
-// multiple of 128, so chunk g+4 = (g ^ swizzle) ^ 4 is simply off ^ 64.
-__device__ __forceinline__ Frag read_frag(const char* lds, int off) {
-  Frag f;
-  f.lo = *(const i32x4*)(lds + off);
-  f.hi = *(const i32x4*)(lds + (off ^ 64));
-  return f;
-}
-
-#define CONCH_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  if constexpr (N == 0) CONCH_VMCNT(0);
-  else if constexpr (N == 2) CONCH_VMCNT(2);
-  else if constexpr (N == 4) CONCH_VMCNT(4);
-  else if constexpr (N == 6) CONCH_VMCNT(6);
-  else if constexpr (N == 8) CONCH_VMCNT(8);
-  // N < 0: no wait
 }
 
 // The register state of one wave: 8 (m) x 4 (n) accumulator tiles of 16x16.

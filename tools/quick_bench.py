@@ -34,7 +34,35 @@ def time_scaled(m, k, n, dtype, variant, iters=20):
     return ms.value
 
 
+def time_mixed(m, k, n, dtype, bits, variant, iters=20):
+    from conch_amd.ops.quantization.gemm import create_mixed_precision_metadata
+    torch.manual_seed(0)
+    x = (10 * (torch.rand((m, k), device="cuda") - 0.3)).to(dtype)
+    pf = 32 // bits
+    wq = torch.randint(-2**31, 2**31 - 1, (k // pf, n), dtype=torch.int32, device="cuda")
+    ws = (0.1 * torch.rand((k // 128, n), device="cuda") + 0.01).to(dtype)
+    out = torch.empty((m, n), dtype=dtype, device="cuda")
+    md = create_mixed_precision_metadata(x, wq, ws, None, bits, 8 if bits == 4 else 128, 128)
+    _C.set_gemm_variant(variant)
+    ms = ctypes.c_float()
+    try:
+        for it in (3, iters):
+            rc = kg._mixed_gemm_call("conch_time_mixed_precision_gemm", out, x, wq, ws, None, md, (it, ctypes.byref(ms)))
+            _C.check(rc, "time")
+    finally:
+        _C.set_gemm_variant(0)
+    return ms.value
+
+
 if __name__ == "__main__":
+    if "--mixed" in sys.argv:
+        for dtype in (torch.float16, torch.bfloat16):
+            for bits in (4, 8):
+                for (m, k, n) in [(1024, 4096, 11008), (4096, 8192, 4096), (8192, 8192, 8192)]:
+                    ms = time_mixed(m, k, n, dtype, bits, 0)
+                    tf = 2.0 * m * n * k / (ms * 1e-3) / 1e12
+                    print(f"mixed {str(dtype):16s} int{bits} M={m} K={k} N={n}: {ms*1e3:9.1f} us  {tf:8.1f} TFLOP/s", flush=True)
+        sys.exit(0)
     shapes = [(4096, 4096, 11008), (8192, 8192, 8192), (128, 4096, 4096), (8192, 8192, 3584)]
     for dtype in (torch.float8_e4m3fn, torch.int8):
         for (m, k, n) in shapes:
