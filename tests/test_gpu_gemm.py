@@ -8,6 +8,7 @@ fp32 accumulation order, bounded below in units of the output dtype's epsilon.
 
 from __future__ import annotations
 
+import functools
 import math
 
 import numpy as np
@@ -188,13 +189,23 @@ WTYPES = {"uint4b8": scalar_types.uint4b8, "uint8b128": scalar_types.uint8b128, 
           "uint8": scalar_types.uint8}
 
 
-def make_mixed_inputs(m, k, n, wtype, use_zp, dtype, group=128):
-    """Recipe of tests/mixed_precision_gemm_test.py:57-70."""
-    seed_everything(0)
-    a = (10 * (torch.rand((m, k), dtype=torch.float32) - 0.3)).to(dtype)
-    b = (10 * (torch.rand((k, n), dtype=torch.float32) - 0.3)).to(dtype)
+@functools.lru_cache(maxsize=4)
+def _quantized_weights(k, n, wname, use_zp, dtype, group):
+    """Host-side quantisation is the slow part of these tests; cache it across M and activations."""
+    gen = torch.Generator().manual_seed(1234)
+    b = (10 * (torch.rand((k, n), dtype=torch.float32, generator=gen) - 0.3)).to(dtype)
+    wtype = WTYPES[wname]
     w_ref, w_q, w_s, w_zp = quantize_weights(b, wtype, group, zero_points=use_zp)
     packed = pack_rows(w_q, wtype.size_bits, *w_q.shape)
+    return w_ref, packed, w_s, w_zp
+
+
+def make_mixed_inputs(m, k, n, wtype, use_zp, dtype, group=128):
+    """Distributions of tests/mixed_precision_gemm_test.py:57-70 (weights drawn from their own stream)."""
+    seed_everything(0)
+    a = (10 * (torch.rand((m, k), dtype=torch.float32) - 0.3)).to(dtype)
+    wname = next(name for name, t in WTYPES.items() if t is wtype)
+    w_ref, packed, w_s, w_zp = _quantized_weights(k, n, wname, use_zp, dtype, group)
     return a, w_ref, packed, w_s, w_zp
 
 
@@ -219,8 +230,8 @@ def check_mixed(got, a, w_ref, k):
 @pytest.mark.parametrize("use_zp", [True, False])
 @pytest.mark.parametrize("dname", ["f16", "bf16"])
 def test_mixed_precision_gemm_matrix(m, k, n, wname, use_zp, dname):
-    if (m, k, n) == SHAPES[2] and (wname in ("uint4", "uint8") or dname == "f16" and use_zp):
-        pytest.skip("large shape: subset only (oracle time)")
+    if (m, k, n) == SHAPES[2] and not (wname, use_zp, dname) in (("uint4b8", False, "f16"), ("uint8b128", True, "bf16")):
+        pytest.skip("large shape: two representative cases (CPU oracle time)")
     wt = WTYPES[wname]
     a, w_ref, packed, w_s, w_zp = make_mixed_inputs(m, k, n, wt, use_zp, DT[dname])
     got = mixed_precision_gemm(a.cuda(), packed.cuda(), w_s.cuda(), None if w_zp is None else w_zp.cuda(),
