@@ -47,6 +47,9 @@ int launch_mixed_gemm_generic(const MixedGemmArgs& p, hipStream_t stream);
 // 3 = 8-phase ping-pong pipeline.  *_supported() say whether the layout contract is met.
 bool scaled_gemm_mfma_supported(const ScaledGemmArgs& p);
 int launch_scaled_gemm_mfma(const ScaledGemmArgs& p, int variant, hipStream_t stream);
+// gemm_persist.hip -- persistent, N-balanced form (variant 4)
+bool scaled_gemm_persistent_supported(const ScaledGemmArgs& p);
+int launch_scaled_gemm_persistent(const ScaledGemmArgs& p, hipStream_t stream);
 bool mixed_gemm_mfma_supported(const MixedGemmArgs& p);
 int launch_mixed_gemm_mfma(const MixedGemmArgs& p, int variant, hipStream_t stream);
 

@@ -118,7 +118,31 @@ __device__ __forceinline__ void wait_vmcnt() {
   else if constexpr (N == 4) CONCH_VMCNT(4);
   else if constexpr (N == 6) CONCH_VMCNT(6);
   else if constexpr (N == 8) CONCH_VMCNT(8);
+  else if constexpr (N == 16) CONCH_VMCNT(16);
+  else if constexpr (N == 24) CONCH_VMCNT(24);
   // N < 0: no wait
+}
+
+
+enum { kMmaFp8 = 0, kMmaInt8 = 1 };
+
+template <int MMA> struct AccT { typedef f32x4 type; };
+template <> struct AccT<kMmaInt8> { typedef i32x4 type; };
+
+// D (16x16) += rows(fa) x cols(fb) over the 128 K-bytes both fragments hold.  The MFMA pairs
+// element j of k-group g of A with element j of k-group g of B, so any K permutation that is the
+// same on both sides is legal: k-group g holds bytes [16g,16g+16) and [64+16g, 64+16g+16).
+template <int MMA>
+__device__ __forceinline__ void mma_step(typename AccT<MMA>::type& acc, const Frag& fa, const Frag& fb) {
+  if constexpr (MMA == kMmaFp8) {
+    const i32x8 a = {fa.lo[0], fa.lo[1], fa.lo[2], fa.lo[3], fa.hi[0], fa.hi[1], fa.hi[2], fa.hi[3]};
+    const i32x8 b = {fb.lo[0], fb.lo[1], fb.lo[2], fb.lo[3], fb.hi[0], fb.hi[1], fb.hi[2], fb.hi[3]};
+    // cbsz = blgp = 0: both operands fp8 e4m3; E8M0 scale 127 = 2^0 for every 32-element block.
+    acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, acc, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+  } else {
+    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa.lo, fb.lo, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa.hi, fb.hi, acc, 0, 0, 0);
+  }
 }
 
 

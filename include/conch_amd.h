@@ -63,8 +63,9 @@ typedef enum conch_zp_mode {
 
 /* Kernel-selection knobs for tests and benchmarks (process-global, not part of the data path). */
 typedef enum conch_tuning_key {
-  CONCH_TUNE_GEMM_VARIANT = 0 /* 0 = auto, 1 = generic (any shape/stride), 2 = LDS-tiled MFMA,
-                                 3 = 8-phase pipelined MFMA */
+  CONCH_TUNE_GEMM_VARIANT = 0 /* 0 = auto, 1 = generic (any shape/stride), 2 = LDS-tiled MFMA with a
+                                 plain double-buffered loop, 3 = ping-pong pipelined MFMA (one tile per
+                                 workgroup), 4 = persistent N-balanced ping-pong MFMA */
 } conch_tuning_key_t;
 
 int conch_abi_version(void);
