@@ -254,6 +254,7 @@ struct Sched {
   int tiles_m;   // 256-row strips
   int ranges;    // workgroups per strip
   int n_units;   // 64-column units per strip
+  int debug;     // timing experiments only (CONCH_TUNE_DEBUG_FLAGS): 1 = drop A loads, 2 = drop B loads
 };
 
 template <int MMA, int OUT_DT>
@@ -271,8 +272,9 @@ __global__ __launch_bounds__(kThreads, 2) void scaled_gemm_persistent_kernel(Sca
   const uint32_t a_bytes = (uint32_t)((p.m - 1) * p.a_stride_m + p.k);
   const uint32_t b_bytes = (uint32_t)((p.n - 1) * p.b_stride_n + p.k);
   const uint32_t c_bytes = (uint32_t)(((p.m - 1) * p.c_stride_m + p.n) * 2);
-  s.src.a = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, a_bytes, 0x00020000);
-  s.src.b = __builtin_amdgcn_make_buffer_rsrc((void*)p.b, 0, b_bytes, 0x00020000);
+  // a zero-record descriptor makes the range check drop every load through it (traffic-pricing builds)
+  s.src.a = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (sc.debug & 1) ? 0u : a_bytes, 0x00020000);
+  s.src.b = __builtin_amdgcn_make_buffer_rsrc((void*)p.b, 0, (sc.debug & 2) ? 0u : b_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(p.c, 0, c_bytes, 0x00020000);
 
   const TileCoord tc = map_tile(blockIdx.x, sc.tiles_m, sc.ranges);  // (strip, range)
@@ -368,6 +370,7 @@ int launch_scaled_gemm_persistent(const ScaledGemmArgs& p, hipStream_t stream) {
   if (ranges < 1) ranges = 1;
   if (ranges > sc.n_units) ranges = sc.n_units;
   sc.ranges = ranges;
+  sc.debug = tuning(1);
   const dim3 grid((unsigned)(sc.tiles_m * sc.ranges));
 #define CONCH_LAUNCH(MMA, OUT)                                                                              \
   do {                                                                                                      \

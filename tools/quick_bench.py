@@ -55,6 +55,16 @@ def time_mixed(m, k, n, dtype, bits, variant, iters=20):
 
 
 if __name__ == "__main__":
+    if "--drop" in sys.argv:
+        lib = _C.load()
+        for (m, k, n) in [(4096, 4096, 11008), (8192, 8192, 8192)]:
+            for flags in (0, 1, 2, 3):
+                lib.conch_set_tuning(1, flags)
+                ms = time_scaled(m, k, n, torch.float8_e4m3fn, 4)
+                lib.conch_set_tuning(1, 0)
+                tf = 2.0 * m * n * k / (ms * 1e-3) / 1e12
+                print(f"fp8 M={m} K={k} N={n} persistent drop_flags={flags}: {ms*1e3:9.1f} us  {tf:8.1f} TFLOP/s-equivalent", flush=True)
+        sys.exit(0)
     if "--mixed" in sys.argv:
         for dtype in (torch.float16, torch.bfloat16):
             for bits in (4, 8):
