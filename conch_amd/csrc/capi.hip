@@ -70,7 +70,8 @@ int run_scaled(const ScaledGemmArgs& p, hipStream_t stream) {
               "16-byte aligned C rows)");
     return CONCH_ERR_UNSUPPORTED;
   }
-  if ((variant == 0 || variant == 4) && scaled_gemm_persistent_supported(p))
+  // auto = variant 3: measured faster than the persistent form on every shape tried (profiles/README.md)
+  if (variant == 4 && scaled_gemm_persistent_supported(p))
     return launch_scaled_gemm_persistent(p, stream);
   return launch_scaled_gemm_mfma(p, variant == 2 ? 2 : 3, stream);
 }

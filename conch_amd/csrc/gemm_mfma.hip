@@ -68,6 +68,19 @@ __device__ __forceinline__ void phase_mma(WaveTile<MMA>& w) {
     for (int t = 0; t < 2; ++t) mma_step<MMA>(w.acc[MH * 4 + i][NH * 2 + t], w.fn[NH][t], w.fm[i]);
 }
 
+// The MFMA half of a phase: the cluster at raised priority, then the closing barrier.
+// (Measured and rejected: arriving at the barrier 2-4 MFMAs early, a single barrier per phase with
+// group-dependent placement, a 4-wave 512-VGPR in-wave-pipelined tile -- all slower, profiles/README.md.)
+template <int MMA, int PHASE>
+__device__ __forceinline__ void phase_cluster(WaveTile<MMA>& w) {
+  __builtin_amdgcn_s_setprio(1);
+  phase_mma<MMA, PHASE>(w);
+  __builtin_amdgcn_s_setprio(0);
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // ---------------------------------------------------------------------------------------------
 // epilogue
 // ---------------------------------------------------------------------------------------------
@@ -108,7 +121,7 @@ __device__ __forceinline__ void epilogue_park(char* lds, const EpiPrefetch& e) {
 }
 
 template <int MMA, int OUT_DT>
-__device__ __forceinline__ void epilogue(const WaveTile<MMA>& w, const ScaledGemmArgs& p, const char* lds,
+__device__ __forceinline__ void epilogue(const typename AccT<MMA>::type (&acc)[8][4], const ScaledGemmArgs& p, const char* lds,
                                          int bm0, int bn0, int wr, int wc, int lane) {
   const int g = lane >> 4, jm = lane & 15;
   const bool vec_store = (p.c_stride_m % 8 == 0) && (((uintptr_t)p.c & 15) == 0);
@@ -130,7 +143,7 @@ __device__ __forceinline__ void epilogue(const WaveTile<MMA>& w, const ScaledGem
       uint16_t o[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float accf = (float)w.acc[mt][nh * 2 + (e >> 2)][e & 3];
+        const float accf = (float)acc[mt][nh * 2 + (e >> 2)][e & 3];
         const float sbe = e < 4 ? sb_lo[e & 3] : sb_hi[e & 3];
         float v = sa * accf;     // scaled_gemm.py:21
         v = pin_f32(sbe * v);    // :22 (rounded to fp32 before the cast, like torch)
@@ -233,7 +246,7 @@ __global__ __launch_bounds__(kThreads, 2) void scaled_gemm_simple_kernel(ScaledG
     phase_mma<MMA, 2>(w);
     phase_mma<MMA, 3>(w);
   }
-  epilogue<MMA, OUT_DT>(w, p, lds, s.bm0, s.bn0, s.wr, s.wc, s.lane);
+  epilogue<MMA, OUT_DT>(w.acc, p, lds, s.bm0, s.bn0, s.wr, s.wc, s.lane);
 }
 
 // Variant 3: 4 phases per K step, two wave groups (waves 0-3 / 4-7 = the two waves of each SIMD)
@@ -252,12 +265,7 @@ __device__ __forceinline__ void pingpong_step(WaveTile<MMA>& w, char* lds, const
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
-  __builtin_amdgcn_s_setprio(1);
-  phase_mma<MMA, 0>(w);
-  __builtin_amdgcn_s_setprio(0);
-  __builtin_amdgcn_sched_barrier(0);
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
+  phase_cluster<MMA, 0>(w);
   // ---- phase 1 ----
   phase_reads<MMA, 1, true>(w, lds, buf, s.m_base, s.n_base);
   if constexpr (ISSUE1) stage_unit<kU2>(lds, s.src, s.so, s.wave, t + 1);
@@ -265,12 +273,7 @@ __device__ __forceinline__ void pingpong_step(WaveTile<MMA>& w, char* lds, const
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
-  __builtin_amdgcn_s_setprio(1);
-  phase_mma<MMA, 1>(w);
-  __builtin_amdgcn_s_setprio(0);
-  __builtin_amdgcn_sched_barrier(0);
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
+  phase_cluster<MMA, 1>(w);
   // ---- phase 2 ----
   phase_reads<MMA, 2, true>(w, lds, buf, s.m_base, s.n_base);
   if constexpr (ISSUE2) stage_unit<kU1>(lds, s.src, s.so, s.wave, t + 2);
@@ -278,24 +281,14 @@ __device__ __forceinline__ void pingpong_step(WaveTile<MMA>& w, char* lds, const
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
-  __builtin_amdgcn_s_setprio(1);
-  phase_mma<MMA, 2>(w);
-  __builtin_amdgcn_s_setprio(0);
-  __builtin_amdgcn_sched_barrier(0);
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
+  phase_cluster<MMA, 2>(w);
   // ---- phase 3 ----
   if constexpr (ISSUE3) stage_unit<kV1>(lds, s.src, s.so, s.wave, t + 2);
   wait_vmcnt<VM3>();
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
-  __builtin_amdgcn_s_setprio(1);
-  phase_mma<MMA, 3>(w);
-  __builtin_amdgcn_s_setprio(0);
-  __builtin_amdgcn_sched_barrier(0);
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
+  phase_cluster<MMA, 3>(w);
 }
 
 template <int MMA, int OUT_DT>
@@ -334,7 +327,7 @@ __global__ __launch_bounds__(kThreads, 2) void scaled_gemm_pingpong_kernel(Scale
   pingpong_step<MMA, 0, 0, 0, 0, 2, 0, -1, -1>(w, lds, s, t);
   if (s.wr == 0) __builtin_amdgcn_s_barrier();  // re-balance the barrier count
 
-  epilogue<MMA, OUT_DT>(w, p, lds, s.bm0, s.bn0, s.wr, s.wc, s.lane);
+  epilogue<MMA, OUT_DT>(w.acc, p, lds, s.bm0, s.bn0, s.wr, s.wc, s.lane);
 }
 
 }  // namespace
@@ -362,7 +355,7 @@ int launch_scaled_gemm_mfma(const ScaledGemmArgs& p, int variant, hipStream_t st
     if (variant == 2)                                                                                    \
       hipLaunchKernelGGL((scaled_gemm_simple_kernel<MMA, OUT>), grid, dim3(kThreads), 0, stream, p);     \
     else                                                                                                 \
-      hipLaunchKernelGGL((scaled_gemm_pingpong_kernel<MMA, OUT>), grid, dim3(kThreads), 0, stream, p);   \
+      hipLaunchKernelGGL((scaled_gemm_pingpong_kernel<MMA, OUT>), grid, dim3(kThreads), 0, stream, p); \
     return check_launch("scaled_gemm_mfma");                                                             \
   } while (0)
   if (p.in_dtype == CONCH_DT_FP8_E4M3FN) {

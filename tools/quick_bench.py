@@ -55,6 +55,32 @@ def time_mixed(m, k, n, dtype, bits, variant, iters=20):
 
 
 if __name__ == "__main__":
+    if "--ab" in sys.argv:
+        # interleaved A/B after a warm-up (clocks ramp for ~20 ms): median of 7 rounds of 50 launches
+        import statistics
+        variants = [int(v) for v in sys.argv[sys.argv.index("--ab") + 1].split(",")]
+        for dtype in (torch.float8_e4m3fn, torch.int8):
+            for (m, k, n) in [(4096, 4096, 11008), (8192, 8192, 8192), (8192, 8192, 3584)]:
+                for _ in range(10):
+                    time_scaled(m, k, n, dtype, variants[0], iters=50)
+                res = {v: [] for v in variants}
+                for _ in range(7):
+                    for v in variants:
+                        res[v].append(time_scaled(m, k, n, dtype, v, iters=50))
+                line = "  ".join(f"v{v}: {statistics.median(r)*1e3:7.1f} us ({2.0*m*n*k/(statistics.median(r)*1e-3)/1e12:6.0f} TF)"
+                                 for v, r in res.items())
+                print(f"{str(dtype):22s} {m}x{k}x{n}  {line}", flush=True)
+        sys.exit(0)
+    if "--trend" in sys.argv:
+        import time
+        for variant in (3, 4, 3, 4):
+            t0 = time.time()
+            out = []
+            for i in range(40):
+                ms = time_scaled(4096, 4096, 11008, torch.float8_e4m3fn, variant, iters=50)
+                out.append(f"{ms*1e3:.1f}")
+            print(f"variant {variant} ({time.time()-t0:.2f}s):", " ".join(out), flush=True)
+        sys.exit(0)
     if "--drop" in sys.argv:
         lib = _C.load()
         for (m, k, n) in [(4096, 4096, 11008), (8192, 8192, 8192)]:
