@@ -54,11 +54,14 @@ HBM_PEAK_GBS = 8000.0
 
 WORKLOADS = {
     # name: (kind, M, K, N)
+    "c1": ("quant_int8", 4096, 0, 4096),
     "c3": ("scaled_fp8", 4096, 4096, 11008),
     "c2": ("scaled_int8", 128, 4096, 4096),
     "c4": ("mixed_int4", 1024, 4096, 11008),
+    "c4readme": ("mixed_int4", 4096, 8192, 4096),
     "c5": ("scaled_fp8", 8192, 8192, 28672),
 }
+CLOCK_RAMP_S = 0.15  # the GPU needs ~20 ms of load to leave its idle clocks; ramp before the W warm-up steps
 
 
 def dist_env() -> tuple[int, int, int]:
@@ -174,7 +177,12 @@ def barrier_sync(world: int) -> None:
 
 
 def timed_region(fn, steps: int, warmup: int, world: int, device: torch.device) -> float:
-    """W warm-up calls, then exactly `steps` calls between barrier+synchronize; max over ranks (s)."""
+    """Clock ramp, W warm-up calls, then exactly `steps` calls between barrier+synchronize; max over ranks (s)."""
+    t_end = time.perf_counter() + CLOCK_RAMP_S
+    while time.perf_counter() < t_end:
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize()
     for _ in range(warmup):
         fn()
     barrier_sync(world)
@@ -216,11 +224,60 @@ def nshard_c5(world: int, rank: int, device: torch.device, steps: int, warmup: i
     }
 
 
+def run_quant_bench(args, tokens: int, hidden: int, device: torch.device, world: int, rank: int) -> None:
+    """C1: static int8 quantisation of a 4096x4096 fp16 tensor (HBM-bound feeder)."""
+    from conch_amd.ops.quantization.int8 import scaled_int8_quant
+
+    torch.manual_seed(rank)
+    x = torch.rand(tokens, hidden, dtype=torch.float16, device=device) * 1000
+    scale = torch.tensor([2.1], dtype=torch.float32, device=device)
+    elapsed = timed_region(lambda: scaled_int8_quant(x, scale), args.steps, args.warmup, world, device)
+    bytes_alg = tokens * hidden * 3
+    # kernel-only time: events on the current stream around back-to-back launches into a reused output
+    from conch_amd.ops.quantization.int8 import static_scaled_int8_quant
+
+    out = torch.empty_like(x, dtype=torch.int8)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(100):
+        static_scaled_int8_quant(out, x, scale)
+    e1.record()
+    torch.cuda.synchronize()
+    k_ms = e0.elapsed_time(e1) / 100
+    result = {
+        "metric": "GB/s, static_scaled_int8_quant 4096x4096 fp16 (bytes = 2 in + 1 out per element)",
+        "value": round(bytes_alg * args.steps * world / elapsed / 1e9, 1), "unit": "GB/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"static_scaled_int8_quant fp16 [{tokens}x{hidden}], scale 2.1"},
+        "roofline": {"bound": "hbm", "achieved": round(bytes_alg / (k_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(bytes_alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "traffic": load_traffic("c1"), "kernel_avg_ms": round(k_ms, 5), "algorithmic_bytes": bytes_alg},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        import oracle
+
+        xc, sc = x.cpu(), scale.cpu()
+        oracle.scaled_int8_quant_ref(xc, sc)
+        times = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            oracle.scaled_int8_quant_ref(xc, sc)
+            times.append(time.perf_counter() - t0)
+        med = sorted(times)[2]
+        result["cpu_baseline"] = {"value": round(bytes_alg / med / 1e9, 2), "unit": "GB/s", "cores": torch.get_num_threads(),
+                                  "kind": "port", "sample": f"full tensor, median of 5 runs, {med * 1e3:.1f} ms each"}
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -249,6 +306,10 @@ def main() -> None:
                 "config": {"workload": res["workload"]}, "detail": res}))
         if world > 1:
             torch.distributed.destroy_process_group()
+        return
+
+    if kind == "quant_int8":
+        run_quant_bench(args, m, n, device, world, rank)
         return
 
     flops = 2.0 * m * n * k
@@ -302,7 +363,8 @@ def main() -> None:
         "config": {
             "workload": desc,
             "parallelism": "single GPU" if world == 1 else f"dp{world} over tokens (M={m} per rank, weights replicated)",
-            "gemm_variant": "auto (8-phase ping-pong MFMA kernel)",
+            "gemm_variant": "auto (ping-pong MFMA kernel, variant 3)",
+            "clock_ramp_s": CLOCK_RAMP_S,
         },
         "roofline": roofline,
     }

@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 passes for the headline bench (run on the GPU box through gpurun).
+# rocprofv3 passes for one bench workload (run on the GPU box through gpurun).
 # usage: tools/gpu_profile.sh <tag> [bench args...]   -> gpurun_out/prof_<tag>/
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 TAG="$1"; shift
@@ -12,6 +12,7 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_AC
   --output-format csv -d "$OUT/pmc_sq" -- python3 "${BENCH[@]}" > "$OUT/pmc_sq.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_fetch" -- python3 "${BENCH[@]}" > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$OUT/pmc_write" -- python3 "${BENCH[@]}" > "$OUT/pmc_write.log" 2>&1
+python3 "$ROOT/tools/summarize_prof.py" "$OUT" > "$OUT/summary.txt" 2>&1
 # keep only the small summaries
-find "$OUT" -name "*.csv" -size +3M -delete
-ls -R "$OUT" | head -50
+find "$OUT" -name "*_kernel_trace.csv" -delete
+find "$OUT" -name "*.csv" -size +1M -delete
