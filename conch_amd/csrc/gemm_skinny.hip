@@ -1,0 +1,155 @@
+// Skinny-M scaled GEMM (M <= 256): the decode-shaped case, e.g. BASELINE config C2
+// (int8 -> bf16, M=128, K=4096, N=4096), which is HBM / latency bound (18 MB, AI = 233 FLOP/B).
+//
+// The 256x256-tile kernels would put such a problem on N/256 = 16 CUs.  Here every workgroup owns a
+// 128(M) x 16(N) block of C, so N/16 = 256 workgroups stream B^T once, each 64 KiB slice by exactly
+// one CU; A (<= 1 MB) is re-read by every workgroup but stays L2-resident.  Inside a workgroup the K
+// range is split over the four waves (no barrier in the main loop, each wave is an independent
+// stream): per 128-byte K step a wave loads 8 A fragments and 1 B^T fragment straight from global
+// memory into registers (no LDS round trip: nothing is shared between waves), double-buffered one
+// step ahead, and issues 8 (fp8) / 16 (int8) 16x16 MFMAs.  The four partial accumulators are summed
+// through LDS in a fixed order (exact for int32, deterministic for fp32) and the usual fused
+// epilogue (sb * (sa * acc), cast, + bias) writes 8-byte pieces of C rows.
+#include "common.hpp"
+#include "gemm.hpp"
+#include "mfma_tile.hpp"
+
+namespace conch {
+namespace {
+
+using namespace tile;
+
+constexpr int kSkThreads = 256;
+constexpr int kSkM = 128;   // rows per workgroup (8 MFMA tiles)
+constexpr int kSkN = 16;    // columns per workgroup (1 MFMA tile)
+constexpr int kSkWaves = 4; // K split
+
+struct SkFrags {
+  Frag a[8];
+  Frag b;
+};
+
+__device__ __forceinline__ i32x4 ld16(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+  return __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
+}
+
+__device__ __forceinline__ void sk_load(SkFrags& f, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb,
+                                        const int (&voff_a)[8], int voff_b, int k) {
+  f.b.lo = ld16(rb, voff_b, k);
+  f.b.hi = ld16(rb, voff_b, k + 64);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    f.a[i].lo = ld16(ra, voff_a[i], k);
+    f.a[i].hi = ld16(ra, voff_a[i], k + 64);
+  }
+}
+
+template <int MMA>
+__device__ __forceinline__ void sk_mma(typename AccT<MMA>::type (&acc)[8], const SkFrags& f) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) mma_step<MMA>(acc[i], f.b, f.a[i]);  // D rows = n, D cols = m
+}
+
+template <int MMA, int OUT_DT>
+__global__ __launch_bounds__(kSkThreads, 1) void scaled_gemm_skinny_kernel(ScaledGemmArgs p) {
+  __shared__ __attribute__((aligned(16))) int red[kSkWaves][8][64][4];  // 32 KiB of partial accumulators
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * kSkN, m0 = blockIdx.y * kSkM;
+
+  const uint32_t a_bytes = (uint32_t)((p.m - 1) * p.a_stride_m + p.k);
+  const uint32_t b_bytes = (uint32_t)((p.n - 1) * p.b_stride_n + p.k);
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.b, 0, b_bytes, 0x00020000);
+  // lane (r, g) holds bytes [16g,16g+16) and [64+16g, ...) of row r of every fragment's 128-byte K step
+  int voff_a[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) voff_a[i] = min(m0 + i * 16 + r, (int)p.m - 1) * (int)p.a_stride_m + 16 * g;
+  const int voff_b = min(n0 + r, (int)p.n - 1) * (int)p.b_stride_n + 16 * g;
+
+  typename AccT<MMA>::type acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = typename AccT<MMA>::type{0, 0, 0, 0};
+
+  const int k_per_wave = (int)(p.k / kSkWaves);  // multiple of 256 (dispatcher): an even number of steps
+  const int k_begin = wave * k_per_wave, k_end = k_begin + k_per_wave;
+  SkFrags f0, f1;
+  sk_load(f0, ra, rb, voff_a, voff_b, k_begin);
+  for (int k = k_begin; k < k_end; k += 2 * kStepBytes) {
+    sk_load(f1, ra, rb, voff_a, voff_b, k + kStepBytes);
+    sk_mma<MMA>(acc, f0);
+    if (k + 2 * kStepBytes < k_end) sk_load(f0, ra, rb, voff_a, voff_b, k + 2 * kStepBytes);
+    sk_mma<MMA>(acc, f1);
+  }
+
+  // cross-wave reduction through LDS, fixed order 0+1+2+3
+#pragma unroll
+  for (int i = 0; i < 8; ++i) *(i32x4*)&red[wave][i][lane][0] = __builtin_bit_cast(i32x4, acc[i]);
+  __syncthreads();
+  const bool has_bias = p.bias != nullptr;
+  const bool sa_vec = p.scale_a_numel != 1, sb_vec = p.scale_b_numel != 1;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int mt = wave * 2 + j;
+    typename AccT<MMA>::type sum = __builtin_bit_cast(typename AccT<MMA>::type, *(const i32x4*)&red[0][mt][lane][0]);
+#pragma unroll
+    for (int w = 1; w < kSkWaves; ++w)
+      sum += __builtin_bit_cast(typename AccT<MMA>::type, *(const i32x4*)&red[w][mt][lane][0]);
+    const int m = m0 + mt * 16 + r;
+    const int nb = n0 + 4 * g;
+    if (m >= p.m) continue;
+    const float sa = p.scale_a[sa_vec ? m : 0];
+    uint16_t o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int n = min(nb + e, (int)p.n - 1);
+      const float sb = p.scale_b[sb_vec ? n : 0];
+      float v = sa * (float)sum[e];   // scaled_gemm.py:21
+      v = pin_f32(sb * v);            // :22
+      uint16_t h = float_to_bits16<OUT_DT>(v);  // :23
+      if (has_bias)                   // :24-25
+        h = float_to_bits16<OUT_DT>(pin_f32(bits16_to_float<OUT_DT>(h) + bits16_to_float<OUT_DT>(((const uint16_t*)p.bias)[n])));
+      o[e] = h;
+    }
+    uint16_t* dst = (uint16_t*)p.c + (int64_t)m * p.c_stride_m + nb;
+    if (nb + 4 <= p.n && (((uintptr_t)dst) & 7) == 0) {
+      i32x2 pk;
+      pk[0] = (int)((uint32_t)o[0] | ((uint32_t)o[1] << 16));
+      pk[1] = (int)((uint32_t)o[2] | ((uint32_t)o[3] << 16));
+      *(i32x2*)dst = pk;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (nb + e < p.n) dst[e] = o[e];
+    }
+  }
+}
+
+}  // namespace
+
+bool scaled_gemm_skinny_supported(const ScaledGemmArgs& p) {
+  if (!scaled_gemm_mfma_supported(p)) return false;
+  if (p.m > 2 * kSkM) return false;                      // beyond two row blocks the tiled kernels win
+  if (p.k % (2 * kStepBytes * kSkWaves)) return false;   // K/4 per wave, an even number of 128-byte steps
+  return true;
+}
+
+int launch_scaled_gemm_skinny(const ScaledGemmArgs& p, hipStream_t stream) {
+  const dim3 grid((unsigned)((p.n + kSkN - 1) / kSkN), (unsigned)((p.m + kSkM - 1) / kSkM));
+#define CONCH_LAUNCH(MMA, OUT)                                                                          \
+  do {                                                                                                  \
+    hipLaunchKernelGGL((scaled_gemm_skinny_kernel<MMA, OUT>), grid, dim3(kSkThreads), 0, stream, p);    \
+    return check_launch("scaled_gemm_skinny");                                                          \
+  } while (0)
+  if (p.in_dtype == CONCH_DT_FP8_E4M3FN) {
+    if (p.out_dtype == CONCH_DT_BF16) CONCH_LAUNCH(kMmaFp8, CONCH_DT_BF16);
+    CONCH_LAUNCH(kMmaFp8, CONCH_DT_FP16);
+  } else {
+    if (p.out_dtype == CONCH_DT_BF16) CONCH_LAUNCH(kMmaInt8, CONCH_DT_BF16);
+    CONCH_LAUNCH(kMmaInt8, CONCH_DT_FP16);
+  }
+#undef CONCH_LAUNCH
+}
+
+}  // namespace conch

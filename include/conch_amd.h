@@ -65,7 +65,8 @@ typedef enum conch_zp_mode {
 typedef enum conch_tuning_key {
   CONCH_TUNE_GEMM_VARIANT = 0 /* 0 = auto, 1 = generic (any shape/stride), 2 = LDS-tiled MFMA with a
                                  plain double-buffered loop, 3 = ping-pong pipelined MFMA (one tile per
-                                 workgroup), 4 = persistent N-balanced ping-pong MFMA */
+                                 workgroup), 4 = persistent N-balanced ping-pong MFMA, 5 = skinny-M
+                                 (M <= 256) register-streaming MFMA */
   ,
   CONCH_TUNE_DEBUG_FLAGS = 1 /* timing experiments only (results become wrong): 1 = drop A loads,
                                 2 = drop B loads in the persistent scaled GEMM */
