@@ -58,26 +58,18 @@ int run_scaled(const ScaledGemmArgs& p, hipStream_t stream) {
   const int variant = tuning(CONCH_TUNE_GEMM_VARIANT);
   const bool fast_ok = scaled_gemm_mfma_supported(p);
   if (variant == 1 || !fast_ok) {
-    if ((variant >= 2 && variant <= 5) && !fast_ok) {
+    if ((variant >= 2 && variant <= 4) && !fast_ok) {
       set_error("scaled_gemm: MFMA variant %d forced but the layout contract is not met "
                 "(need K-contiguous A and B^T, K %% 128 == 0, 16-byte aligned rows)", variant);
       return CONCH_ERR_UNSUPPORTED;
     }
     return launch_scaled_gemm_generic(p, stream);
   }
-  if (variant == 4 && !scaled_gemm_persistent_supported(p)) {
-    set_error("scaled_gemm: persistent variant forced but its contract is not met (K >= 256, N %% 8 == 0, "
-              "16-byte aligned C rows)");
-    return CONCH_ERR_UNSUPPORTED;
-  }
-  if (variant == 5 && !scaled_gemm_skinny_supported(p)) {
+  if (variant == 4 && !scaled_gemm_skinny_supported(p)) {
     set_error("scaled_gemm: skinny variant forced but its contract is not met (M <= 256, K %% 1024 == 0)");
     return CONCH_ERR_UNSUPPORTED;
   }
-  if ((variant == 0 || variant == 5) && scaled_gemm_skinny_supported(p)) return launch_scaled_gemm_skinny(p, stream);
-  // auto = variant 3: measured faster than the persistent form on every shape tried (profiles/README.md)
-  if (variant == 4 && scaled_gemm_persistent_supported(p))
-    return launch_scaled_gemm_persistent(p, stream);
+  if ((variant == 0 || variant == 4) && scaled_gemm_skinny_supported(p)) return launch_scaled_gemm_skinny(p, stream);
   return launch_scaled_gemm_mfma(p, variant == 2 ? 2 : 3, stream);
 }
 

@@ -63,13 +63,9 @@ typedef enum conch_zp_mode {
 
 /* Kernel-selection knobs for tests and benchmarks (process-global, not part of the data path). */
 typedef enum conch_tuning_key {
-  CONCH_TUNE_GEMM_VARIANT = 0 /* 0 = auto, 1 = generic (any shape/stride), 2 = LDS-tiled MFMA with a
-                                 plain double-buffered loop, 3 = ping-pong pipelined MFMA (one tile per
-                                 workgroup), 4 = persistent N-balanced ping-pong MFMA, 5 = skinny-M
-                                 (M <= 256) register-streaming MFMA */
-  ,
-  CONCH_TUNE_DEBUG_FLAGS = 1 /* timing experiments only (results become wrong): 1 = drop A loads,
-                                2 = drop B loads in the persistent scaled GEMM */
+  CONCH_TUNE_GEMM_VARIANT = 0 /* 0 = auto, 1 = generic (any shape/stride), 2 = LDS-tiled MFMA with a plain
+                                 double-buffered loop, 3 = ping-pong pipelined LDS-tiled MFMA (the default
+                                 for M > 256), 4 = skinny-M (M <= 256) register-streaming MFMA */
 } conch_tuning_key_t;
 
 int conch_abi_version(void);
