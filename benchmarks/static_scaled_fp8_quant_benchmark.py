@@ -1,0 +1,43 @@
+"""static_scaled_fp8_quant microbenchmark (CLI of the reference's benchmarks/static_scaled_fp8_quant_benchmark.py:22-123)."""
+
+import click
+import torch
+
+from _common import DTYPES, report_match, run_pair, torch_fp8_quant
+from conch_amd.ops.quantization.fp8 import scaled_fp8_quant
+from conch_amd.platforms import current_platform
+from conch_amd.third_party.vllm.utils import seed_everything
+
+
+@click.command()
+@click.option("--hidden-size", default=4068, type=int)
+@click.option("--num-tokens", default=4096, type=int)
+@click.option("--scale", default=2.1, type=float)
+@click.option("--dtype", "dtype_name", default="float16", type=click.Choice(sorted(DTYPES)))
+@click.option("--fnuz", is_flag=True, help="emit the MI300-era float8_e4m3fnuz instead of OCP float8_e4m3fn")
+@click.option("--iteration-time-ms", default=2000, type=int)
+@click.option("--warmup-time-ms", default=500, type=int)
+@click.option("--verbose", is_flag=True)
+@click.option("--gpu", default="cuda:0")
+@click.option("--csv", is_flag=True)
+def main(hidden_size, num_tokens, scale, dtype_name, fnuz, iteration_time_ms, warmup_time_ms, verbose, gpu, csv):
+    seed_everything(0)
+    device = torch.device(gpu)
+    dtype = DTYPES[dtype_name]
+    fp8 = torch.float8_e4m3fnuz if fnuz else current_platform.fp8_dtype()
+    x = torch.rand(num_tokens, hidden_size, dtype=dtype, device=device)
+    s = torch.tensor([scale], dtype=torch.float32, device=device)
+    out, _ = scaled_fp8_quant(x, s, output_dtype=fp8)
+    ref = torch_fp8_quant(x, s, fp8)
+    report_match(torch.equal(out.view(torch.uint8), ref.view(torch.uint8)))
+    if verbose:
+        print(out)
+    params = {"hidden_size": hidden_size, "num_tokens": num_tokens, "scale": scale, "dtype": dtype_name,
+              "fp8": str(fp8)}
+    run_pair("static_scaled_fp8_quant", lambda: scaled_fp8_quant(x, s, output_dtype=fp8),
+             lambda: torch_fp8_quant(x, s, fp8), params, iteration_time_ms, warmup_time_ms, csv,
+             nbytes=float(x.numel() * (x.element_size() + 1)))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,38 @@
+"""static_scaled_int8_quant microbenchmark (CLI of the reference's benchmarks/static_scaled_int8_quant_benchmark.py:17-114)."""
+
+import click
+import torch
+
+from _common import DTYPES, report_match, run_pair, torch_int8_quant
+from conch_amd.ops.quantization.int8 import scaled_int8_quant
+from conch_amd.third_party.vllm.utils import seed_everything
+
+
+@click.command()
+@click.option("--hidden-size", default=4608, type=int)
+@click.option("--num-tokens", default=4096, type=int)
+@click.option("--scale", default=2.1, type=float)
+@click.option("--dtype", "dtype_name", default="float16", type=click.Choice(sorted(DTYPES)))
+@click.option("--iteration-time-ms", default=2000, type=int)
+@click.option("--warmup-time-ms", default=500, type=int)
+@click.option("--verbose", is_flag=True)
+@click.option("--gpu", default="cuda:0")
+@click.option("--csv", is_flag=True)
+def main(hidden_size, num_tokens, scale, dtype_name, iteration_time_ms, warmup_time_ms, verbose, gpu, csv):
+    seed_everything(0)
+    device = torch.device(gpu)
+    dtype = DTYPES[dtype_name]
+    x = torch.rand(num_tokens, hidden_size, dtype=dtype, device=device) * 1000
+    s = torch.tensor([scale], dtype=torch.float32, device=device)
+    out, _ = scaled_int8_quant(x, s)
+    ref = torch_int8_quant(x, s)
+    report_match(bool((out.int() - ref.int()).abs().max().item() <= 1))
+    if verbose:
+        print(out)
+    params = {"hidden_size": hidden_size, "num_tokens": num_tokens, "scale": scale, "dtype": dtype_name}
+    run_pair("static_scaled_int8_quant", lambda: scaled_int8_quant(x, s), lambda: torch_int8_quant(x, s), params,
+             iteration_time_ms, warmup_time_ms, csv, nbytes=float(x.numel() * (x.element_size() + 1)))
+
+
+if __name__ == "__main__":
+    main()
