@@ -289,6 +289,9 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
+    ap.add_argument("--all-ranks-on-device0", action="store_true",
+                    help="dry-run aid: put every rank on cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
     rank, local_rank, world = dist_env()
@@ -297,10 +300,15 @@ def main() -> None:
               file=sys.stderr)
         sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path is the only path)"
+    if args.all_ranks_on_device0:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        torch.distributed.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=device)
+        else:
+            torch.distributed.init_process_group(args.backend)
 
     kind, m, k, n = WORKLOADS[args.workload]
     result: dict = {}
