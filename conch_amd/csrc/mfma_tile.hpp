@@ -137,8 +137,10 @@ __device__ __forceinline__ void mma_step(typename AccT<MMA>::type& acc, const Fr
   if constexpr (MMA == kMmaFp8) {
     const i32x8 a = {fa.lo[0], fa.lo[1], fa.lo[2], fa.lo[3], fa.hi[0], fa.hi[1], fa.hi[2], fa.hi[3]};
     const i32x8 b = {fb.lo[0], fb.lo[1], fb.lo[2], fb.lo[3], fb.hi[0], fb.hi[1], fb.hi[2], fb.hi[3]};
-    // cbsz = blgp = 0: both operands fp8 e4m3; E8M0 scale 127 = 2^0 for every 32-element block.
-    acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, acc, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+    // cbsz = blgp = 0: both operands fp8 e4m3.  With both scale operands the constant 0 hipcc selects
+    // the UNSCALED v_mfma_f32_16x16x128_f8f6f4 (one 8-byte instruction, products taken as they are)
+    // instead of the v_mfma_ld_scale_b32 + v_mfma_scale pair with E8M0 scales of 2^0.
+    acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, acc, 0, 0, 0, 0, 0, 0);
   } else {
     acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa.lo, fb.lo, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa.hi, fb.hi, acc, 0, 0, 0);
