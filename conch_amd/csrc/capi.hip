@@ -52,25 +52,37 @@ int check_scaled(const ScaledGemmArgs& p) {
   return CONCH_OK;
 }
 
-int run_scaled(const ScaledGemmArgs& p, hipStream_t stream) {
-  if (int rc = check_scaled(p)) return rc;
-  if (p.m == 0 || p.n == 0) return CONCH_OK;
-  const int variant = tuning(CONCH_TUNE_GEMM_VARIANT);
-  const bool fast_ok = scaled_gemm_mfma_supported(p);
-  if (variant == 1 || !fast_ok) {
-    if ((variant >= 2 && variant <= 4) && !fast_ok) {
-      set_error("scaled_gemm: MFMA variant %d forced but the layout contract is not met "
-                "(need K-contiguous A and B^T, K %% 128 == 0, 16-byte aligned rows)", variant);
-      return CONCH_ERR_UNSUPPORTED;
-    }
-    return launch_scaled_gemm_generic(p, stream);
-  }
+int run_scaled_fast(const ScaledGemmArgs& p, int variant, hipStream_t stream) {
   if (variant == 4 && !scaled_gemm_skinny_supported(p)) {
     set_error("scaled_gemm: skinny variant forced but its contract is not met (M <= 256, K %% 1024 == 0)");
     return CONCH_ERR_UNSUPPORTED;
   }
   if ((variant == 0 || variant == 4) && scaled_gemm_skinny_supported(p)) return launch_scaled_gemm_skinny(p, stream);
   return launch_scaled_gemm_mfma(p, variant == 2 ? 2 : 3, stream);
+}
+
+int run_scaled(const ScaledGemmArgs& p, hipStream_t stream) {
+  if (int rc = check_scaled(p)) return rc;
+  if (p.m == 0 || p.n == 0) return CONCH_OK;
+  const int variant = tuning(CONCH_TUNE_GEMM_VARIANT);
+  if (variant != 1 && scaled_gemm_mfma_supported(p)) return run_scaled_fast(p, variant, stream);
+  if (variant >= 2 && variant <= 4) {
+    set_error("scaled_gemm: MFMA variant %d forced but the layout contract is not met "
+              "(need K-contiguous A and B^T, K %% 128 == 0, 16-byte aligned rows)", variant);
+    return CONCH_ERR_UNSUPPORTED;
+  }
+  if (variant == 0) {
+    // legal but non-native layout (row-major [K][N] weights, odd K, misaligned views): repack, then MFMA
+    ScaledGemmArgs q;
+    void* scratch = nullptr;
+    if (repack_for_mfma(p, &q, &scratch, stream) == CONCH_OK && scaled_gemm_mfma_supported(q)) {
+      const int rc = run_scaled_fast(q, 0, stream);
+      CONCH_HIP(hipFreeAsync(scratch, stream));
+      return rc;
+    }
+    if (scratch) CONCH_HIP(hipFreeAsync(scratch, stream));
+  }
+  return launch_scaled_gemm_generic(p, stream);
 }
 
 int check_mixed(const MixedGemmArgs& p) {

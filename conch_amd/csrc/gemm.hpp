@@ -50,6 +50,8 @@ int launch_scaled_gemm_mfma(const ScaledGemmArgs& p, int variant, hipStream_t st
 // gemm_skinny.hip -- M <= 256: 128x16 blocks, K split over the waves, register streaming (variant 4)
 bool scaled_gemm_skinny_supported(const ScaledGemmArgs& p);
 int launch_scaled_gemm_skinny(const ScaledGemmArgs& p, hipStream_t stream);
+// repack.hip -- copy operands into the MFMA layout contract (stream-ordered scratch)
+int repack_for_mfma(const ScaledGemmArgs& p, ScaledGemmArgs* q, void** scratch, hipStream_t stream);
 bool mixed_gemm_mfma_supported(const MixedGemmArgs& p);
 int launch_mixed_gemm_mfma(const MixedGemmArgs& p, int variant, hipStream_t stream);
 

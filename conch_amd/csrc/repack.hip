@@ -1,0 +1,90 @@
+// Operand repacking for the MFMA kernels' layout contract.
+//
+// The MFMA GEMMs want both operands K-contiguous with K a multiple of 128 bytes and 16-byte aligned
+// rows -- what the reference's own tests and benchmarks pass (b = (N, K).T).  Any other legal input
+// (row-major [K][N] weights, a transposed activation view, K = 200, a misaligned slice) is first
+// copied into that layout in stream-ordered scratch memory (hipMallocAsync on the caller's stream,
+// so the call stays asynchronous and graph-capturable), K zero-padded: zeros add nothing to int8 or
+// fp8 dot products.  One 64x64-byte LDS tile per workgroup, reads coalesced along whichever source
+// dimension has the smaller stride, writes coalesced along K.  HBM-bound, one pass.
+#include "common.hpp"
+#include "gemm.hpp"
+
+namespace conch {
+namespace {
+
+constexpr int kRpTile = 64;
+
+// dst[r][k] (row stride kp, k < kp, zero for k >= K) = src[r * sr + k * sk]
+__global__ __launch_bounds__(256) void repack_rows_kernel(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src,
+                                                          int64_t rows, int64_t k_dim, int64_t kp, int64_t sr,
+                                                          int64_t sk) {
+  __shared__ uint8_t tile[kRpTile][kRpTile + 4];  // [r][k]
+  const int64_t k0 = (int64_t)blockIdx.x * kRpTile, r0 = (int64_t)blockIdx.y * kRpTile;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+  const bool k_fast = sk <= sr;
+#pragma unroll 4
+  for (int i = ty; i < kRpTile; i += 4) {
+    const int rr = k_fast ? i : tx, kk = k_fast ? tx : i;
+    const int64_t r = r0 + rr, k = k0 + kk;
+    uint8_t v = 0;
+    if (r < rows && k < k_dim) v = src[r * sr + k * sk];
+    tile[rr][kk] = v;
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int i = ty; i < kRpTile; i += 4) {
+    const int64_t r = r0 + i, k = k0 + tx;
+    if (r < rows && k < kp) dst[r * kp + k] = tile[i][tx];
+  }
+}
+
+bool k_major_ok(const void* ptr, int64_t stride_k, int64_t stride_row, int64_t k_dim, int64_t k_mult) {
+  return stride_k == 1 && stride_row % 16 == 0 && ((uintptr_t)ptr & 15) == 0 && k_dim % k_mult == 0;
+}
+
+}  // namespace
+
+// Decide whether repacking makes `p` eligible for the MFMA kernels; if so fill `q` (a copy of p that
+// points into scratch) and launch the copies.  *scratch must be released with hipFreeAsync by the caller.
+int repack_for_mfma(const ScaledGemmArgs& p, ScaledGemmArgs* q, void** scratch, hipStream_t stream) {
+  *scratch = nullptr;
+  *q = p;
+  if (p.in_dtype != CONCH_DT_INT8 && p.in_dtype != CONCH_DT_FP8_E4M3FN) return CONCH_ERR_UNSUPPORTED;
+  if (p.c_stride_n != 1 || p.k < 1) return CONCH_ERR_UNSUPPORTED;
+  const int64_t k_mult = p.m <= 256 ? 1024 : 128;  // skinny kernel: K/4 per wave in 256-byte pairs
+  const int64_t kp = (p.k + k_mult - 1) / k_mult * k_mult;
+  const bool fix_a = !k_major_ok(p.a, p.a_stride_k, p.a_stride_m, p.k, k_mult);
+  const bool fix_b = !k_major_ok(p.b, p.b_stride_k, p.b_stride_n, p.k, k_mult);
+  if (!fix_a && !fix_b) return CONCH_ERR_UNSUPPORTED;  // something else is wrong with the request
+  const bool pad = kp != p.k;
+  const bool copy_a = fix_a || pad, copy_b = fix_b || pad;
+  const size_t a_bytes = copy_a ? (size_t)(p.m * kp + 255) / 256 * 256 : 0;
+  const size_t b_bytes = copy_b ? (size_t)(p.n * kp + 255) / 256 * 256 : 0;
+  if (p.m * kp >= ((int64_t)1 << 31) || p.n * kp >= ((int64_t)1 << 31)) return CONCH_ERR_UNSUPPORTED;
+  void* ws = nullptr;
+  CONCH_HIP(hipMallocAsync(&ws, a_bytes + b_bytes, stream));
+  *scratch = ws;
+  const dim3 block(256);
+  if (copy_a) {
+    const dim3 grid((unsigned)((kp + kRpTile - 1) / kRpTile), (unsigned)((p.m + kRpTile - 1) / kRpTile));
+    hipLaunchKernelGGL(repack_rows_kernel, grid, block, 0, stream, (uint8_t*)ws, (const uint8_t*)p.a, p.m, p.k, kp,
+                       p.a_stride_m, p.a_stride_k);
+    q->a = ws;
+    q->a_stride_m = kp;
+    q->a_stride_k = 1;
+  }
+  if (copy_b) {
+    uint8_t* bt = (uint8_t*)ws + a_bytes;
+    const dim3 grid((unsigned)((kp + kRpTile - 1) / kRpTile), (unsigned)((p.n + kRpTile - 1) / kRpTile));
+    hipLaunchKernelGGL(repack_rows_kernel, grid, block, 0, stream, bt, (const uint8_t*)p.b, p.n, p.k, kp,
+                       p.b_stride_n, p.b_stride_k);
+    q->b = bt;
+    q->b_stride_n = kp;
+    q->b_stride_k = 1;
+  }
+  q->k = kp;
+  return check_launch("repack_rows");
+}
+
+}  // namespace conch

@@ -142,6 +142,41 @@ def test_scaled_gemm_layouts_and_edge_cases():
         scaled_gemm(a.cuda(), b.cuda(), sa.cuda(), sb.cuda(), torch.float32)
 
 
+@pytest.mark.parametrize("iname", ["int8", "fn"])
+@pytest.mark.parametrize(("m", "k", "n"), [(300, 200, 520), (96, 1000, 72), (1024, 384, 256), (130, 4096, 64)])
+@pytest.mark.parametrize("layout", ["b_row_major", "a_transposed", "misaligned_views", "odd_k_only"])
+def test_scaled_gemm_non_native_layouts_are_repacked(iname, m, k, n, layout):
+    """Legal inputs outside the MFMA layout contract (row-major [K][N] weights, a transposed activation
+    view, slices that start at odd byte offsets, K not a multiple of 128) are repacked on the device and
+    still run on the MFMA kernels; results must match the oracle exactly as for native layouts."""
+    seed_everything(2)
+    dt = IN_T[iname]
+    if dt == torch.int8:
+        a = torch.randint(-32, 32, (m, k), dtype=dt)
+        b = torch.randint(-32, 32, (k, n), dtype=dt)
+    else:
+        a = (0.25 * torch.rand((m, k))).to(dt)
+        b = (0.25 * torch.rand((k, n))).to(dt)
+    sa, sb = 0.25 * torch.rand((m, 1)), 0.25 * torch.rand((n, 1))
+    bias = torch.rand((n,), dtype=torch.bfloat16)
+    ref = oracle.scaled_gemm_ref(a, b, sa, sb, torch.bfloat16, bias)
+    a_d, b_d = a.cuda(), b.cuda()  # both row-major: b has strides (n, 1)
+    if layout == "a_transposed":
+        a_d = a.T.contiguous().cuda().T  # strides (1, m)
+        b_d = b.T.contiguous().cuda().T  # native for b
+    elif layout == "misaligned_views":
+        big_a = torch.zeros((m + 3, k + 37), dtype=torch.uint8).view(dt).cuda()
+        big_a[1:m + 1, 5:k + 5] = a.cuda()
+        a_d = big_a[1:m + 1, 5:k + 5]
+        big_b = torch.zeros((n + 2, k + 11), dtype=torch.uint8).view(dt).cuda()
+        big_b[1:n + 1, 3:k + 3] = b.T.cuda()
+        b_d = big_b[1:n + 1, 3:k + 3].T
+    elif layout == "odd_k_only":
+        b_d = b.T.contiguous().cuda().T
+    got = scaled_gemm(a_d, b_d, sa.cuda(), sb.cuda(), torch.bfloat16, bias.cuda())
+    check_scaled(got, ref, dt, torch.bfloat16)
+
+
 def test_scaled_gemm_int8_saturated_operands_exact():
     """Extreme int8 values: |acc| up to 128*128*K exceeds 2^24, the int32 accumulator stays exact."""
     m, k, n = 256, 2048, 256
