@@ -108,7 +108,7 @@ struct WeightRegs {
 
 template <int BITS, int ZP>
 __device__ __forceinline__ void load_weights(WeightRegs<BITS>& r, const MixedGemmArgs& p, int step, int n1, int n2,
-                                             int cp) {
+                                             int cp, bool v2_valid) {
   constexpr int kWordRowsPerStep = kStepK * BITS / 32;  // 8 (int4) or 16 (int8)
   constexpr int kWpc = WeightRegs<BITS>::kWordsPerChunk;
   const int k0 = step * kStepK;
@@ -116,6 +116,7 @@ __device__ __forceinline__ void load_weights(WeightRegs<BITS>& r, const MixedGem
   const int ncol[2] = {n1, n2};
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
+    if (u == 1 && !v2_valid) continue;  // this thread's V2 row is outside a narrow tile
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const int chunk = cp + 4 * c;
@@ -133,9 +134,10 @@ __device__ __forceinline__ void load_weights(WeightRegs<BITS>& r, const MixedGem
 
 template <int X_DT, int BITS>
 __device__ __forceinline__ void convert_weights(const WeightRegs<BITS>& r, char* lds, int buf, int row_off, int swz,
-                                                int cp, int off_base) {
+                                                int cp, int off_base, bool v2_valid) {
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
+    if (u == 1 && !v2_valid) continue;
     const int kind = u == 0 ? kV1 : kV2;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -153,8 +155,11 @@ struct MixedTile {
   Frag fn[2][2];
 };
 
-template <int X_DT, int PHASE>
+// NT = 16-column MFMA tiles per wave (tile width 64*NT): tiles 0,1 form the first n sub-half, tiles
+// 2..NT-1 the second.
+template <int X_DT, int PHASE, int NT>
 __device__ __forceinline__ void mixed_phase(MixedTile& w, const char* lds, int buf, int m_base, int n_base) {
+  constexpr int N1 = NT - 2;  // tiles in the second sub-half
   if constexpr (PHASE == 0) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) w.fn[0][t] = read_frag(lds, buf + kV1 * kUnitBytes + n_base + t * 2048);
@@ -162,29 +167,31 @@ __device__ __forceinline__ void mixed_phase(MixedTile& w, const char* lds, int b
     for (int i = 0; i < 4; ++i) w.fm[i] = read_frag(lds, buf + kU1 * kUnitBytes + m_base + i * 2048);
   } else if constexpr (PHASE == 1) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) w.fn[1][t] = read_frag(lds, buf + kV2 * kUnitBytes + n_base + t * 2048);
+    for (int t = 0; t < N1; ++t) w.fn[1][t] = read_frag(lds, buf + kV2 * kUnitBytes + n_base + t * 2048);
   } else if constexpr (PHASE == 2) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) w.fm[i] = read_frag(lds, buf + kU2 * kUnitBytes + m_base + i * 2048);
   }
   constexpr int MH = (PHASE >= 2) ? 1 : 0;
   constexpr int NH = (PHASE == 1 || PHASE == 2) ? 1 : 0;
+  constexpr int CNT = NH == 0 ? 2 : N1;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int t = 0; t < 2; ++t) mma16<X_DT>(w.acc[MH * 4 + i][NH * 2 + t], w.fn[NH][t], w.fm[i]);
+    for (int t = 0; t < CNT; ++t) mma16<X_DT>(w.acc[MH * 4 + i][NH * 2 + t], w.fn[NH][t], w.fm[i]);
 }
 
-template <int X_DT, int OUT_DT, int BITS, int ZP>
+template <int X_DT, int OUT_DT, int BITS, int ZP, int NT>
 __global__ __launch_bounds__(kThreads, 2) void mixed_gemm_kernel(MixedGemmArgs p) {
+  constexpr int kTileW = 64 * NT;  // columns per workgroup
   __shared__ __attribute__((aligned(1024))) char lds[kLdsBytes];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int wr = wave >> 2, wc = wave & 3;
   const int tiles_m = ((int)p.m + kTileM - 1) / kTileM;
-  const int tiles_n = ((int)p.n + kTileN - 1) / kTileN;
+  const int tiles_n = ((int)p.n + kTileW - 1) / kTileW;
   const TileCoord tc = map_tile(blockIdx.x, tiles_m, tiles_n);
-  const int bm0 = tc.tm * kTileM, bn0 = tc.tn * kTileN;
+  const int bm0 = tc.tm * kTileM, bn0 = tc.tn * kTileW;
 
   // activations: LDS-DMA units (byte strides: 2 bytes per element)
   const int ldx = (int)p.x_stride_m * 2;
@@ -197,9 +204,13 @@ __global__ __launch_bounds__(kThreads, 2) void mixed_gemm_kernel(MixedGemmArgs p
   const int rho = threadIdx.x & 127;
   const int cp = threadIdx.x >> 7;
   const int r5 = rho & 31, r = r5 & 15, tq = r5 >> 4;
-  const int nrow = (rho >> 5) * 64 + 8 * (r >> 2) + (r & 3) + 4 * tq;  // same permutation as the LDS-DMA V units
-  const int n1 = min(bn0 + nrow, (int)p.n - 1);
-  const int n2 = min(bn0 + nrow + 32, (int)p.n - 1);
+  // wave-column rho>>5 owns columns [16*NT*wc, 16*NT*(wc+1)); a PAIR of MFMA tiles is interleaved (rows 4g+e
+  // of tile t <-> n = 8g+e+4t: a lane ends up with 8 consecutive n), a LONE third tile (NT == 3) is plain
+  const int wcol = (rho >> 5) * 16 * NT;
+  const int pair = 8 * (r >> 2) + (r & 3) + 4 * tq;
+  const int n1 = min(bn0 + wcol + pair, (int)p.n - 1);
+  const int n2 = min(bn0 + wcol + 32 + (NT == 4 ? pair : r), (int)p.n - 1);
+  const bool v2_valid = NT == 4 || (NT == 3 && tq == 0);
   const int w_row_off = (rho >> 3) * 1024 + (rho & 7) * 128;
   const int w_swz = (rho >> 1) & 7;
   const int off_base = p.weight_bias + (ZP == CONCH_ZP_SCALAR ? p.w_zp[0] : 0);
@@ -222,9 +233,9 @@ __global__ __launch_bounds__(kThreads, 2) void mixed_gemm_kernel(MixedGemmArgs p
   // prologue: step 0 operands into buffer 0, step 1 weights into registers
   stage_unit<kU1>(lds, src, so, wave, 0);
   stage_unit<kU2>(lds, src, so, wave, 0);
-  load_weights<BITS, ZP>(regs, p, 0, n1, n2, cp);
-  convert_weights<X_DT, BITS>(regs, lds, 0, w_row_off, w_swz, cp, off_base);
-  if (steps > 1) load_weights<BITS, ZP>(regs, p, 1, n1, n2, cp);
+  load_weights<BITS, ZP>(regs, p, 0, n1, n2, cp, v2_valid);
+  convert_weights<X_DT, BITS>(regs, lds, 0, w_row_off, w_swz, cp, off_base, v2_valid);
+  if (steps > 1) load_weights<BITS, ZP>(regs, p, 1, n1, n2, cp, v2_valid);
 
   for (int t = 0; t < steps; ++t) {
     // everything this wave staged for step t (LDS-DMA and ds_write) is complete ...
@@ -235,62 +246,99 @@ __global__ __launch_bounds__(kThreads, 2) void mixed_gemm_kernel(MixedGemmArgs p
     if (t + 1 < steps) {
       stage_unit<kU1>(lds, src, so, wave, t + 1);
       stage_unit<kU2>(lds, src, so, wave, t + 1);
-      convert_weights<X_DT, BITS>(regs, lds, nbuf, w_row_off, w_swz, cp, off_base);
-      if (t + 2 < steps) load_weights<BITS, ZP>(regs, p, t + 2, n1, n2, cp);
+      convert_weights<X_DT, BITS>(regs, lds, nbuf, w_row_off, w_swz, cp, off_base, v2_valid);
+      if (t + 2 < steps) load_weights<BITS, ZP>(regs, p, t + 2, n1, n2, cp, v2_valid);
     }
-    mixed_phase<X_DT, 0>(w, lds, buf, m_base, n_base);
-    mixed_phase<X_DT, 1>(w, lds, buf, m_base, n_base);
-    mixed_phase<X_DT, 2>(w, lds, buf, m_base, n_base);
-    mixed_phase<X_DT, 3>(w, lds, buf, m_base, n_base);
+    mixed_phase<X_DT, 0, NT>(w, lds, buf, m_base, n_base);
+    mixed_phase<X_DT, 1, NT>(w, lds, buf, m_base, n_base);
+    mixed_phase<X_DT, 2, NT>(w, lds, buf, m_base, n_base);
+    mixed_phase<X_DT, 3, NT>(w, lds, buf, m_base, n_base);
   }
 
-  // epilogue: cast and store, 8 consecutive n per lane
+  // epilogue: cast and store; a pair of tiles gives a lane 8 consecutive n (16-byte store), a lone tile 4
   const int g = lane >> 4, jm = lane & 15;
   const bool vec_store = (p.c_stride_m % 8 == 0) && (((uintptr_t)p.c & 15) == 0);
 #pragma unroll
   for (int nh = 0; nh < 2; ++nh) {
-    const int n0 = bn0 + wc * 64 + nh * 32 + 8 * g;
+    if (nh == 1 && NT == 2) continue;
+    const bool pair_h = nh == 0 || NT == 4;
+    const int width = pair_h ? 8 : 4;
+    const int n0 = bn0 + wc * 16 * NT + nh * 32 + width * g;
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) {
       const int m = bm0 + wr * 128 + mt * 16 + jm;
       if (m >= p.m) continue;
       uint16_t o[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = float_to_bits16<OUT_DT>(pin_f32(w.acc[mt][nh * 2 + (e >> 2)][e & 3]));
+      for (int e = 0; e < 8; ++e) o[e] = float_to_bits16<OUT_DT>(pin_f32(w.acc[mt][nh * 2 + (pair_h ? (e >> 2) : 0)][e & 3]));
       uint16_t* dst = (uint16_t*)p.c + (int64_t)m * p.c_stride_m + n0;
-      if (vec_store && n0 + 8 <= p.n) {
+      if (pair_h && vec_store && n0 + 8 <= p.n) {
         i32x4 pk;
 #pragma unroll
         for (int e = 0; e < 4; ++e) pk[e] = (int)((uint32_t)o[2 * e] | ((uint32_t)o[2 * e + 1] << 16));
         *(i32x4*)dst = pk;
+      } else if (!pair_h && vec_store && n0 + 4 <= p.n) {
+        i32x2 pk;
+        pk[0] = (int)((uint32_t)o[0] | ((uint32_t)o[1] << 16));
+        pk[1] = (int)((uint32_t)o[2] | ((uint32_t)o[3] << 16));
+        *(i32x2*)dst = pk;
       } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-          if (n0 + e < p.n) dst[e] = o[e];
+          if (e < width && n0 + e < p.n) dst[e] = o[e];
       }
     }
   }
 }
 
-template <int X_DT, int OUT_DT, int BITS>
-int launch_zp(const MixedGemmArgs& p, dim3 grid, hipStream_t stream) {
+template <int X_DT, int OUT_DT, int BITS, int NT>
+int launch_zp(const MixedGemmArgs& p, hipStream_t stream) {
+  const int tiles_m = (int)((p.m + kTileM - 1) / kTileM);
+  const int tiles_n = (int)((p.n + 64 * NT - 1) / (64 * NT));
+  const dim3 grid((unsigned)(tiles_m * tiles_n));
   switch (p.zp_mode) {
     case CONCH_ZP_NONE:
-      hipLaunchKernelGGL((mixed_gemm_kernel<X_DT, OUT_DT, BITS, CONCH_ZP_NONE>), grid, dim3(kThreads), 0, stream, p);
+      hipLaunchKernelGGL((mixed_gemm_kernel<X_DT, OUT_DT, BITS, CONCH_ZP_NONE, NT>), grid, dim3(kThreads), 0, stream, p);
       break;
     case CONCH_ZP_SCALAR:
-      hipLaunchKernelGGL((mixed_gemm_kernel<X_DT, OUT_DT, BITS, CONCH_ZP_SCALAR>), grid, dim3(kThreads), 0, stream, p);
+      hipLaunchKernelGGL((mixed_gemm_kernel<X_DT, OUT_DT, BITS, CONCH_ZP_SCALAR, NT>), grid, dim3(kThreads), 0, stream, p);
       break;
     default:
-      hipLaunchKernelGGL((mixed_gemm_kernel<X_DT, OUT_DT, BITS, CONCH_ZP_TENSOR>), grid, dim3(kThreads), 0, stream, p);
+      hipLaunchKernelGGL((mixed_gemm_kernel<X_DT, OUT_DT, BITS, CONCH_ZP_TENSOR, NT>), grid, dim3(kThreads), 0, stream, p);
       break;
   }
   return check_launch("mixed_gemm_mfma");
 }
 
+// Tile width 64*NT, NT in {4, 3, 2}: the width that needs the least (rounds of workgroups) x (work per
+// workgroup).  C4 (1024 x 11008): 256-wide = 172 tiles (67 % of 256 CUs busy), 192-wide = 232 tiles in
+// ONE round at 3/4 of the work each.
+int pick_nt(const MixedGemmArgs& p, int num_cus) {
+  const int64_t tiles_m = (p.m + kTileM - 1) / kTileM;
+  int best = 4;
+  double best_cost = 1e30;
+  for (int nt = 4; nt >= 2; --nt) {
+    const int64_t tiles = tiles_m * ((p.n + 64 * nt - 1) / (64 * nt));
+    const int64_t rounds = (tiles + num_cus - 1) / num_cus;
+    const double cost = (double)rounds * (nt + 0.35);  // + fixed per-tile cost: narrower tiles re-stage A more often
+    if (cost < best_cost - 1e-9) {
+      best_cost = cost;
+      best = nt;
+    }
+  }
+  return best;
+}
+
+template <int X_DT, int OUT_DT, int BITS>
+int launch_nt(const MixedGemmArgs& p, int nt, hipStream_t stream) {
+  if (nt == 3) return launch_zp<X_DT, OUT_DT, BITS, 3>(p, stream);
+  if (nt == 2) return launch_zp<X_DT, OUT_DT, BITS, 2>(p, stream);
+  return launch_zp<X_DT, OUT_DT, BITS, 4>(p, stream);
+}
+
 template <int X_DT, int OUT_DT>
-int launch_bits(const MixedGemmArgs& p, dim3 grid, hipStream_t stream) {
-  return p.bits == 4 ? launch_zp<X_DT, OUT_DT, 4>(p, grid, stream) : launch_zp<X_DT, OUT_DT, 8>(p, grid, stream);
+int launch_bits(const MixedGemmArgs& p, int nt, hipStream_t stream) {
+  return p.bits == 4 ? launch_nt<X_DT, OUT_DT, 4>(p, nt, stream) : launch_nt<X_DT, OUT_DT, 8>(p, nt, stream);
 }
 
 }  // namespace
@@ -310,15 +358,21 @@ bool mixed_gemm_mfma_supported(const MixedGemmArgs& p) {
 }
 
 int launch_mixed_gemm_mfma(const MixedGemmArgs& p, int /*variant*/, hipStream_t stream) {
-  const int tiles_m = (int)((p.m + kTileM - 1) / kTileM);
-  const int tiles_n = (int)((p.n + kTileN - 1) / kTileN);
-  const dim3 grid((unsigned)(tiles_m * tiles_n));
-  if (p.x_dtype == CONCH_DT_FP16) {
-    return p.out_dtype == CONCH_DT_FP16 ? launch_bits<CONCH_DT_FP16, CONCH_DT_FP16>(p, grid, stream)
-                                        : launch_bits<CONCH_DT_FP16, CONCH_DT_BF16>(p, grid, stream);
+  static int num_cus = 0;
+  if (num_cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    num_cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+               prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
   }
-  return p.out_dtype == CONCH_DT_BF16 ? launch_bits<CONCH_DT_BF16, CONCH_DT_BF16>(p, grid, stream)
-                                      : launch_bits<CONCH_DT_BF16, CONCH_DT_FP16>(p, grid, stream);
+  const int forced = tuning(1);  // CONCH_TUNE_MIXED_TILE_NT: 0 = auto, 2..4 = force
+  const int nt = (forced >= 2 && forced <= 4) ? forced : pick_nt(p, num_cus);
+  if (p.x_dtype == CONCH_DT_FP16) {
+    return p.out_dtype == CONCH_DT_FP16 ? launch_bits<CONCH_DT_FP16, CONCH_DT_FP16>(p, nt, stream)
+                                        : launch_bits<CONCH_DT_FP16, CONCH_DT_BF16>(p, nt, stream);
+  }
+  return p.out_dtype == CONCH_DT_BF16 ? launch_bits<CONCH_DT_BF16, CONCH_DT_BF16>(p, nt, stream)
+                                      : launch_bits<CONCH_DT_BF16, CONCH_DT_FP16>(p, nt, stream);
 }
 
 }  // namespace conch

@@ -66,6 +66,8 @@ typedef enum conch_tuning_key {
   CONCH_TUNE_GEMM_VARIANT = 0 /* 0 = auto, 1 = generic (any shape/stride), 2 = LDS-tiled MFMA with a plain
                                  double-buffered loop, 3 = ping-pong pipelined LDS-tiled MFMA (the default
                                  for M > 256), 4 = skinny-M (M <= 256) register-streaming MFMA */
+  ,
+  CONCH_TUNE_MIXED_TILE_NT = 1 /* mixed_precision_gemm tile width in 64-column units: 0 = auto, 2..4 = force */
 } conch_tuning_key_t;
 
 int conch_abi_version(void);

@@ -295,6 +295,23 @@ def test_mixed_precision_gemm_golden_from_reference(golden, wname, zp, dname):
     check_mixed(got, a, from_bits(g[f"wref_{key}"], dtype), a.shape[1])
 
 
+@pytest.mark.parametrize("nt", [2, 3, 4])
+@pytest.mark.parametrize(("m", "k", "n"), [(300, 256, 520), (1024, 512, 1376), (64, 128, 200)])
+@pytest.mark.parametrize(("wname", "use_zp", "dname"), [("uint4b8", False, "f16"), ("uint4", True, "bf16"),
+                                                         ("uint8b128", True, "f16"), ("uint8", False, "bf16")])
+def test_mixed_precision_every_tile_width(nt, m, k, n, wname, use_zp, dname):
+    """The MFMA kernel at each tile width (64*nt columns), ragged M / N included."""
+    wt = WTYPES[wname]
+    a, w_ref, packed, w_s, w_zp = make_mixed_inputs(m, k, n, wt, use_zp, DT[dname])
+    _C.check(_C.load().conch_set_tuning(1, nt), "set_tuning")
+    try:
+        got = mixed_precision_gemm(a.cuda(), packed.cuda(), w_s.cuda(), None if w_zp is None else w_zp.cuda(),
+                                   wt.size_bits, wt.bias, 128)
+    finally:
+        _C.load().conch_set_tuning(1, 0)
+    check_mixed(got, a, w_ref, k)
+
+
 def test_mixed_precision_dequant_is_bit_exact():
     """X = identity isolates the dequantisation: C must equal w_ref bit-for-bit."""
     k = n = 256

@@ -81,6 +81,19 @@ if __name__ == "__main__":
                 out.append(f"{ms*1e3:.1f}")
             print(f"variant {variant} ({time.time()-t0:.2f}s):", " ".join(out), flush=True)
         sys.exit(0)
+    if "--mixednt" in sys.argv:
+        import statistics
+        lib = _C.load()
+        for (m, k, n) in [(1024, 4096, 11008), (4096, 8192, 4096), (2048, 4096, 11008)]:
+            for _ in range(10):
+                time_mixed(m, k, n, torch.float16, 4, 0, iters=30)
+            res = {}
+            for nt in (0, 4, 3, 2):
+                lib.conch_set_tuning(1, nt)
+                res[nt] = statistics.median([time_mixed(m, k, n, torch.float16, 4, 0, iters=50) for _ in range(5)])
+            lib.conch_set_tuning(1, 0)
+            print(f"mixed int4 fp16 {m}x{k}x{n}: " + "  ".join(f"nt{nt}: {t*1e3:.1f}us ({2.0*m*n*k/(t*1e-3)/1e12:.0f} TF)" for nt, t in res.items()), flush=True)
+        sys.exit(0)
     if "--mixed" in sys.argv:
         for dtype in (torch.float16, torch.bfloat16):
             for bits in (4, 8):
