@@ -295,18 +295,22 @@ def test_mixed_precision_gemm_golden_from_reference(golden, wname, zp, dname):
     check_mixed(got, a, from_bits(g[f"wref_{key}"], dtype), a.shape[1])
 
 
+@pytest.mark.parametrize("variant", ["auto", "simple"])
 @pytest.mark.parametrize("nt", [2, 3, 4])
-@pytest.mark.parametrize(("m", "k", "n"), [(300, 256, 520), (1024, 512, 1376), (64, 128, 200)])
+@pytest.mark.parametrize(("m", "k", "n"), [(300, 256, 520), (1024, 512, 1376), (64, 128, 200), (512, 64, 256)])
 @pytest.mark.parametrize(("wname", "use_zp", "dname"), [("uint4b8", False, "f16"), ("uint4", True, "bf16"),
                                                          ("uint8b128", True, "f16"), ("uint8", False, "bf16")])
-def test_mixed_precision_every_tile_width(nt, m, k, n, wname, use_zp, dname):
-    """The MFMA kernel at each tile width (64*nt columns), ragged M / N included."""
+def test_mixed_precision_every_tile_width(variant, nt, m, k, n, wname, use_zp, dname):
+    """Both MFMA loop forms (ping-pong = auto, plain loop = variant 2) at each tile width (64*nt columns),
+    ragged M / N and the shortest K (one and two K steps) included."""
     wt = WTYPES[wname]
-    a, w_ref, packed, w_s, w_zp = make_mixed_inputs(m, k, n, wt, use_zp, DT[dname])
+    group = 64 if k < 128 else 128
+    a, w_ref, packed, w_s, w_zp = make_mixed_inputs(m, k, n, wt, use_zp, DT[dname], group)
+    _C.set_gemm_variant(VARIANTS[variant])
     _C.check(_C.load().conch_set_tuning(1, nt), "set_tuning")
     try:
         got = mixed_precision_gemm(a.cuda(), packed.cuda(), w_s.cuda(), None if w_zp is None else w_zp.cuda(),
-                                   wt.size_bits, wt.bias, 128)
+                                   wt.size_bits, wt.bias, group)
     finally:
         _C.load().conch_set_tuning(1, 0)
     check_mixed(got, a, w_ref, k)

@@ -87,12 +87,14 @@ if __name__ == "__main__":
         for (m, k, n) in [(1024, 4096, 11008), (4096, 8192, 4096), (2048, 4096, 11008)]:
             for _ in range(10):
                 time_mixed(m, k, n, torch.float16, 4, 0, iters=30)
-            res = {}
-            for nt in (0, 4, 3, 2):
-                lib.conch_set_tuning(1, nt)
-                res[nt] = statistics.median([time_mixed(m, k, n, torch.float16, 4, 0, iters=50) for _ in range(5)])
-            lib.conch_set_tuning(1, 0)
-            print(f"mixed int4 fp16 {m}x{k}x{n}: " + "  ".join(f"nt{nt}: {t*1e3:.1f}us ({2.0*m*n*k/(t*1e-3)/1e12:.0f} TF)" for nt, t in res.items()), flush=True)
+            for dtype, bits in ((torch.float16, 4), (torch.bfloat16, 4), (torch.float16, 8)):
+                res = {}
+                for variant in (0, 2):
+                    for nt in (0, 4, 3):
+                        lib.conch_set_tuning(1, nt)
+                        res[(variant, nt)] = statistics.median([time_mixed(m, k, n, dtype, bits, variant, iters=50) for _ in range(5)])
+                lib.conch_set_tuning(1, 0)
+                print(f"mixed int{bits} {str(dtype)[6:]} {m}x{k}x{n}: " + "  ".join(f"v{v}/nt{nt}: {t*1e3:.1f}us ({2.0*m*n*k/(t*1e-3)/1e12:.0f} TF)" for (v, nt), t in res.items()), flush=True)
         sys.exit(0)
     if "--mixed" in sys.argv:
         for dtype in (torch.float16, torch.bfloat16):
