@@ -620,7 +620,9 @@ int launch_mixed_gemm_mfma(const MixedGemmArgs& p, int variant, hipStream_t stre
   }
   const int forced = tuning(1);  // CONCH_TUNE_MIXED_TILE_NT: 0 = auto, 2..4 = force
   const int nt = (forced >= 2 && forced <= 4) ? forced : pick_nt(p, num_cus);
-  const bool pp = variant != 2 && p.k >= 2 * kStepK;  // variant 2 = the plain one-barrier-per-K-step loop
+  // auto = the plain one-barrier-per-K-step loop: measured equal or faster than the ping-pong form on
+  // every shape tried (C4 106 vs 113 us, README shape 252 vs 247 us); variant 3 forces ping-pong
+  const bool pp = variant == 3 && p.k >= 2 * kStepK;
   if (p.x_dtype == CONCH_DT_FP16) {
     return p.out_dtype == CONCH_DT_FP16 ? launch_bits<CONCH_DT_FP16, CONCH_DT_FP16>(p, nt, pp, stream)
                                         : launch_bits<CONCH_DT_FP16, CONCH_DT_BF16>(p, nt, pp, stream);

@@ -295,13 +295,13 @@ def test_mixed_precision_gemm_golden_from_reference(golden, wname, zp, dname):
     check_mixed(got, a, from_bits(g[f"wref_{key}"], dtype), a.shape[1])
 
 
-@pytest.mark.parametrize("variant", ["auto", "simple"])
+@pytest.mark.parametrize("variant", ["auto", "pingpong"])
 @pytest.mark.parametrize("nt", [2, 3, 4])
 @pytest.mark.parametrize(("m", "k", "n"), [(300, 256, 520), (1024, 512, 1376), (64, 128, 200), (512, 64, 256)])
 @pytest.mark.parametrize(("wname", "use_zp", "dname"), [("uint4b8", False, "f16"), ("uint4", True, "bf16"),
                                                          ("uint8b128", True, "f16"), ("uint8", False, "bf16")])
 def test_mixed_precision_every_tile_width(variant, nt, m, k, n, wname, use_zp, dname):
-    """Both MFMA loop forms (ping-pong = auto, plain loop = variant 2) at each tile width (64*nt columns),
+    """Both MFMA loop forms (plain loop = auto, ping-pong = variant 3) at each tile width (64*nt columns),
     ragged M / N and the shortest K (one and two K steps) included."""
     wt = WTYPES[wname]
     group = 64 if k < 128 else 128

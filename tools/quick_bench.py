@@ -89,7 +89,7 @@ if __name__ == "__main__":
                 time_mixed(m, k, n, torch.float16, 4, 0, iters=30)
             for dtype, bits in ((torch.float16, 4), (torch.bfloat16, 4), (torch.float16, 8)):
                 res = {}
-                for variant in (0, 2):
+                for variant in (0, 3):
                     for nt in (0, 4, 3):
                         lib.conch_set_tuning(1, nt)
                         res[(variant, nt)] = statistics.median([time_mixed(m, k, n, dtype, bits, variant, iters=50) for _ in range(5)])
