@@ -126,6 +126,157 @@ __global__ __launch_bounds__(kSkThreads, 1) void scaled_gemm_skinny_kernel(Scale
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Split-K form.  The in-workgroup K split above makes every workgroup read ALL of A (M x K bytes from
+// L2): 256 x 512 KB = 128 MB for C2, and the per-CU load path (~30 GB/s of 64-byte row pieces into
+// registers) becomes the limit.  Here the K range is split ACROSS workgroups instead: workgroup
+// (n-block of 64 columns, k-slice) reads only its K slice of A -- once, through a 4-slot LDS-DMA ring
+// shared by its four waves (full 128-byte lines, same swizzled image as the tiled kernels) -- and each
+// wave streams its own 16 columns of B^T into registers.  Partial accumulators go to fp32 / int32
+// slabs [slice][M][N] in stream-ordered scratch; a second tiny kernel adds the slices in a fixed
+// order (exact for int32, deterministic for fp32) and applies the fused epilogue.  C2: 64 n-blocks x
+// 4 slices = 256 workgroups, 192 KB of operands each.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSpN = 64;        // columns per workgroup (16 per wave)
+constexpr int kSpRing = 4;      // LDS ring slots of one 16 KiB A unit (128 rows x 128 bytes)
+constexpr int kSpAhead = 2;     // units in flight
+
+template <int MMA>
+__global__ __launch_bounds__(kSkThreads, 2) void skinny_splitk_kernel(ScaledGemmArgs p, int* __restrict__ slabs,
+                                                                      int k_per_slice) {
+  __shared__ __attribute__((aligned(1024))) char lds[kSpRing * kUnitBytes];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * kSpN + wave * 16, m0 = blockIdx.z * kSkM;
+  const int slice = blockIdx.y;
+  const int k_begin = slice * k_per_slice;
+  const int steps = k_per_slice / kStepBytes;
+
+  const uint32_t a_bytes = (uint32_t)((p.m - 1) * p.a_stride_m + p.k);
+  const uint32_t b_bytes = (uint32_t)((p.n - 1) * p.b_stride_n + p.k);
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.b, 0, b_bytes, 0x00020000);
+
+  // A unit staging: wave w feeds unit rows [32w, 32w+32) = 4 subtiles of 8 rows x 128 bytes
+  int voff_a[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int rho = 32 * wave + 8 * j + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((rho >> 1) & 7);
+    voff_a[j] = min(m0 + rho, (int)p.m - 1) * (int)p.a_stride_m + chunk * 16;
+  }
+  const int voff_b = min(n0 + r, (int)p.n - 1) * (int)p.b_stride_n + 16 * g;
+  const int lane_off = (r >> 3) * 1024 + (r & 7) * 128 + ((g ^ ((r >> 1) & 7)) * 16);
+
+  auto stage_a = [&](int s) {
+    char* dst = lds + (s % kSpRing) * kUnitBytes + wave * 4096;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(dst + j * 1024), 16, voff_a[j],
+                                               k_begin + s * kStepBytes, 0, 0);
+  };
+  auto load_b = [&](Frag& f, int s) {
+    f.lo = ld16(rb, voff_b, k_begin + s * kStepBytes);
+    f.hi = ld16(rb, voff_b, k_begin + s * kStepBytes + 64);
+  };
+
+  typename AccT<MMA>::type acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = typename AccT<MMA>::type{0, 0, 0, 0};
+
+  // prologue: units 0,1 and their B fragments in flight (6 VMEM ops per step: 2 register loads + 4 DMA)
+  Frag fb0, fb1;
+  load_b(fb0, 0);
+  stage_a(0);
+  if (steps > 1) {
+    load_b(fb1, 1);
+    stage_a(1);
+  }
+  for (int s = 0; s < steps; s += 2) {
+    // ---- even step: uses fb0, prefetches step s+2 into fb0's successor below
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int cur = s + half;
+      if (cur >= steps) break;
+      // unit `cur` landed: everything older than the ops of the later steps already issued
+      if (cur + 1 < steps) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // every wave's quarter of unit `cur` is visible; slot (cur+2)%4 is free
+      Frag fb_next;
+      const bool more = cur + kSpAhead < steps;
+      if (more) {
+        load_b(fb_next, cur + kSpAhead);
+        stage_a(cur + kSpAhead);
+      }
+      const int base = (cur % kSpRing) * kUnitBytes + lane_off;
+      const Frag& fb = half == 0 ? fb0 : fb1;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const Frag fa = read_frag(lds, base + i * 2048);
+        mma_step<MMA>(acc[i], fb, fa);  // D rows = n, D cols = m
+      }
+      if (more) {
+        if (half == 0) fb0 = fb_next;
+        else fb1 = fb_next;
+      }
+    }
+  }
+
+  // partial sums -> slab [slice][M][N] (4-byte elements); lane: m = m0 + 16 i + r, n = n0 + 4 g + e
+  int* slab = slabs + (int64_t)slice * p.m * p.n;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = m0 + i * 16 + r;
+    const int n = n0 + 4 * g;
+    if (m < p.m && n + 4 <= p.n) *(i32x4*)(slab + (int64_t)m * p.n + n) = __builtin_bit_cast(i32x4, acc[i]);
+  }
+}
+
+// out[m][n..n+3] = epilogue( sum over slices, in slice order )
+template <int MMA, int OUT_DT>
+__global__ __launch_bounds__(256) void skinny_reduce_kernel(ScaledGemmArgs p, const int* __restrict__ slabs, int slices) {
+  const int64_t quad = (int64_t)blockIdx.x * 256 + threadIdx.x;  // 4 consecutive n
+  const int64_t quads_per_row = p.n / 4;
+  if (quad >= p.m * quads_per_row) return;
+  const int m = (int)(quad / quads_per_row), n = (int)(quad % quads_per_row) * 4;
+  typename AccT<MMA>::type sum = __builtin_bit_cast(typename AccT<MMA>::type, *(const i32x4*)(slabs + (int64_t)m * p.n + n));
+  for (int s = 1; s < slices; ++s)
+    sum += __builtin_bit_cast(typename AccT<MMA>::type, *(const i32x4*)(slabs + ((int64_t)s * p.m + m) * p.n + n));
+  const float sa = p.scale_a[p.scale_a_numel != 1 ? m : 0];
+  uint16_t o[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float sb = p.scale_b[p.scale_b_numel != 1 ? n + e : 0];
+    float v = sa * (float)sum[e];   // scaled_gemm.py:21
+    v = pin_f32(sb * v);            // :22
+    uint16_t h = float_to_bits16<OUT_DT>(v);  // :23
+    if (p.bias)                     // :24-25
+      h = float_to_bits16<OUT_DT>(pin_f32(bits16_to_float<OUT_DT>(h) + bits16_to_float<OUT_DT>(((const uint16_t*)p.bias)[n + e])));
+    o[e] = h;
+  }
+  uint16_t* dst = (uint16_t*)p.c + (int64_t)m * p.c_stride_m + n;
+  if ((((uintptr_t)dst) & 7) == 0) {
+    i32x2 pk;
+    pk[0] = (int)((uint32_t)o[0] | ((uint32_t)o[1] << 16));
+    pk[1] = (int)((uint32_t)o[2] | ((uint32_t)o[3] << 16));
+    *(i32x2*)dst = pk;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dst[e] = o[e];
+  }
+}
+
+int splitk_slices(const ScaledGemmArgs& p) {
+  // enough (n-block, slice) pairs to fill the chip, slices of whole 128-byte steps, at most 8
+  if (p.n % 4 || p.m > 2 * kSkM) return 1;
+  const int64_t blocks = ((p.n + kSpN - 1) / kSpN) * ((p.m + kSkM - 1) / kSkM);
+  int best = 1;
+  for (int s = 2; s <= 8; s *= 2)
+    if (p.k % ((int64_t)s * kStepBytes) == 0 && p.k / s >= 4 * kStepBytes && blocks * s <= 320) best = s;
+  return best;
+}
+
 }  // namespace
 
 bool scaled_gemm_skinny_supported(const ScaledGemmArgs& p) {
@@ -135,7 +286,36 @@ bool scaled_gemm_skinny_supported(const ScaledGemmArgs& p) {
   return true;
 }
 
+template <int MMA, int OUT_DT>
+int launch_splitk(const ScaledGemmArgs& p, int slices, hipStream_t stream) {
+  void* ws = nullptr;
+  const size_t bytes = (size_t)slices * p.m * p.n * 4;
+  if (hipMallocAsync(&ws, bytes, stream) != hipSuccess) {
+    (void)hipGetLastError();
+    return -1;  // caller falls back to the in-workgroup K split
+  }
+  const dim3 grid((unsigned)((p.n + kSpN - 1) / kSpN), (unsigned)slices, (unsigned)((p.m + kSkM - 1) / kSkM));
+  hipLaunchKernelGGL((skinny_splitk_kernel<MMA>), grid, dim3(kSkThreads), 0, stream, p, (int*)ws, (int)(p.k / slices));
+  const int64_t quads = p.m * (p.n / 4);
+  hipLaunchKernelGGL((skinny_reduce_kernel<MMA, OUT_DT>), dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, p,
+                     (const int*)ws, slices);
+  const int rc = check_launch("scaled_gemm_skinny_splitk");
+  CONCH_HIP(hipFreeAsync(ws, stream));
+  return rc;
+}
+
 int launch_scaled_gemm_skinny(const ScaledGemmArgs& p, hipStream_t stream) {
+  const int slices = tuning(2) == 1 ? 1 : splitk_slices(p);  // CONCH_TUNE_SKINNY_NO_SPLITK = 1 disables split-K
+  if (slices > 1) {
+    int rc;
+    if (p.in_dtype == CONCH_DT_FP8_E4M3FN)
+      rc = p.out_dtype == CONCH_DT_BF16 ? launch_splitk<kMmaFp8, CONCH_DT_BF16>(p, slices, stream)
+                                        : launch_splitk<kMmaFp8, CONCH_DT_FP16>(p, slices, stream);
+    else
+      rc = p.out_dtype == CONCH_DT_BF16 ? launch_splitk<kMmaInt8, CONCH_DT_BF16>(p, slices, stream)
+                                        : launch_splitk<kMmaInt8, CONCH_DT_FP16>(p, slices, stream);
+    if (rc >= 0) return rc;
+  }
   const dim3 grid((unsigned)((p.n + kSkN - 1) / kSkN), (unsigned)((p.m + kSkM - 1) / kSkM));
 #define CONCH_LAUNCH(MMA, OUT)                                                                          \
   do {                                                                                                  \

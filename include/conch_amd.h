@@ -68,6 +68,8 @@ typedef enum conch_tuning_key {
                                  for M > 256), 4 = skinny-M (M <= 256) register-streaming MFMA */
   ,
   CONCH_TUNE_MIXED_TILE_NT = 1 /* mixed_precision_gemm tile width in 64-column units: 0 = auto, 2..4 = force */
+  ,
+  CONCH_TUNE_SKINNY_NO_SPLITK = 2 /* 1 = keep the skinny-M scaled GEMM's K split inside the workgroup */
 } conch_tuning_key_t;
 
 int conch_abi_version(void);
