@@ -137,21 +137,38 @@ __global__ __launch_bounds__(kSkThreads, 1) void scaled_gemm_skinny_kernel(Scale
 // order (exact for int32, deterministic for fp32) and applies the fused epilogue.  C2: 64 n-blocks x
 // 4 slices = 256 workgroups, 192 KB of operands each.
 // ---------------------------------------------------------------------------------------------
-constexpr int kSpN = 64;        // columns per workgroup (16 per wave)
-constexpr int kSpRing = 4;      // LDS ring slots of one 16 KiB A unit (128 rows x 128 bytes)
-constexpr int kSpAhead = 2;     // units in flight
+constexpr int kSpN = 64;          // columns per workgroup (16 per wave)
+constexpr int kSpSteps = 8;       // 128-byte K steps per slice: a slice is 1024 bytes of K
+constexpr int kSpSliceK = kSpSteps * kStepBytes;
 
+template <int MMA, int S>
+__device__ __forceinline__ void sp_consume(typename AccT<MMA>::type (&acc)[8], const Frag (&fb)[8], const char* lds,
+                                           int lane_off) {
+  if constexpr (S < 8) {
+    wait_vmcnt_n<6 * (7 - S)>();    // step S of this wave has landed ...
+    __builtin_amdgcn_s_barrier();   // ... and so has every other wave's quarter of unit S
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const Frag fa = read_frag(lds, S * kUnitBytes + lane_off + i * 2048);
+      mma_step<MMA>(acc[i], fb[S], fa);  // D rows = n, D cols = m
+    }
+    sp_consume<MMA, S + 1>(acc, fb, lds, lane_off);
+  }
+}
+
+// The whole slice is put in flight at once -- 8 A units (128 KiB of LDS, LDS-DMA) and 8 B^T fragments
+// (64 VGPRs) per wave -- so the slice costs one memory latency plus its transfer time instead of a
+// latency per K step; the steps are then consumed in issue order with counted vmcnt waits
+// (6 VMEM operations per step and wave: 2 register loads + 4 DMA).
 template <int MMA>
-__global__ __launch_bounds__(kSkThreads, 2) void skinny_splitk_kernel(ScaledGemmArgs p, int* __restrict__ slabs,
-                                                                      int k_per_slice) {
-  __shared__ __attribute__((aligned(1024))) char lds[kSpRing * kUnitBytes];
+__global__ __launch_bounds__(kSkThreads, 1) void skinny_splitk_kernel(ScaledGemmArgs p, int* __restrict__ slabs) {
+  __shared__ __attribute__((aligned(1024))) char lds[kSpSteps * kUnitBytes];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int r = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * kSpN + wave * 16, m0 = blockIdx.z * kSkM;
   const int slice = blockIdx.y;
-  const int k_begin = slice * k_per_slice;
-  const int steps = k_per_slice / kStepBytes;
+  const int k_begin = slice * kSpSliceK;
 
   const uint32_t a_bytes = (uint32_t)((p.m - 1) * p.a_stride_m + p.k);
   const uint32_t b_bytes = (uint32_t)((p.n - 1) * p.b_stride_n + p.k);
@@ -169,59 +186,23 @@ __global__ __launch_bounds__(kSkThreads, 2) void skinny_splitk_kernel(ScaledGemm
   const int voff_b = min(n0 + r, (int)p.n - 1) * (int)p.b_stride_n + 16 * g;
   const int lane_off = (r >> 3) * 1024 + (r & 7) * 128 + ((g ^ ((r >> 1) & 7)) * 16);
 
-  auto stage_a = [&](int s) {
-    char* dst = lds + (s % kSpRing) * kUnitBytes + wave * 4096;
+  Frag fb[kSpSteps];
+#pragma unroll
+  for (int s = 0; s < kSpSteps; ++s) {
+    fb[s].lo = ld16(rb, voff_b, k_begin + s * kStepBytes);
+    fb[s].hi = ld16(rb, voff_b, k_begin + s * kStepBytes + 64);
+    char* dst = lds + s * kUnitBytes + wave * 4096;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(dst + j * 1024), 16, voff_a[j],
                                                k_begin + s * kStepBytes, 0, 0);
-  };
-  auto load_b = [&](Frag& f, int s) {
-    f.lo = ld16(rb, voff_b, k_begin + s * kStepBytes);
-    f.hi = ld16(rb, voff_b, k_begin + s * kStepBytes + 64);
-  };
+  }
 
   typename AccT<MMA>::type acc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = typename AccT<MMA>::type{0, 0, 0, 0};
 
-  // prologue: units 0,1 and their B fragments in flight (6 VMEM ops per step: 2 register loads + 4 DMA)
-  Frag fb0, fb1;
-  load_b(fb0, 0);
-  stage_a(0);
-  if (steps > 1) {
-    load_b(fb1, 1);
-    stage_a(1);
-  }
-  for (int s = 0; s < steps; s += 2) {
-    // ---- even step: uses fb0, prefetches step s+2 into fb0's successor below
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const int cur = s + half;
-      if (cur >= steps) break;
-      // unit `cur` landed: everything older than the ops of the later steps already issued
-      if (cur + 1 < steps) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();  // every wave's quarter of unit `cur` is visible; slot (cur+2)%4 is free
-      Frag fb_next;
-      const bool more = cur + kSpAhead < steps;
-      if (more) {
-        load_b(fb_next, cur + kSpAhead);
-        stage_a(cur + kSpAhead);
-      }
-      const int base = (cur % kSpRing) * kUnitBytes + lane_off;
-      const Frag& fb = half == 0 ? fb0 : fb1;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const Frag fa = read_frag(lds, base + i * 2048);
-        mma_step<MMA>(acc[i], fb, fa);  // D rows = n, D cols = m
-      }
-      if (more) {
-        if (half == 0) fb0 = fb_next;
-        else fb1 = fb_next;
-      }
-    }
-  }
+  sp_consume<MMA, 0>(acc, fb, lds, lane_off);
 
   // partial sums -> slab [slice][M][N] (4-byte elements); lane: m = m0 + 16 i + r, n = n0 + 4 g + e
   int* slab = slabs + (int64_t)slice * p.m * p.n;
@@ -268,13 +249,9 @@ __global__ __launch_bounds__(256) void skinny_reduce_kernel(ScaledGemmArgs p, co
 }
 
 int splitk_slices(const ScaledGemmArgs& p) {
-  // enough (n-block, slice) pairs to fill the chip, slices of whole 128-byte steps, at most 8
-  if (p.n % 4 || p.m > 2 * kSkM) return 1;
-  const int64_t blocks = ((p.n + kSpN - 1) / kSpN) * ((p.m + kSkM - 1) / kSkM);
-  int best = 1;
-  for (int s = 2; s <= 8; s *= 2)
-    if (p.k % ((int64_t)s * kStepBytes) == 0 && p.k / s >= 4 * kStepBytes && blocks * s <= 320) best = s;
-  return best;
+  // slices of exactly 1024 K-bytes (K % 1024 == 0 is part of the skinny contract)
+  if (p.n % 4 || p.m > 2 * kSkM || p.k % kSpSliceK) return 0;
+  return (int)(p.k / kSpSliceK);
 }
 
 }  // namespace
@@ -295,7 +272,7 @@ int launch_splitk(const ScaledGemmArgs& p, int slices, hipStream_t stream) {
     return -1;  // caller falls back to the in-workgroup K split
   }
   const dim3 grid((unsigned)((p.n + kSpN - 1) / kSpN), (unsigned)slices, (unsigned)((p.m + kSkM - 1) / kSkM));
-  hipLaunchKernelGGL((skinny_splitk_kernel<MMA>), grid, dim3(kSkThreads), 0, stream, p, (int*)ws, (int)(p.k / slices));
+  hipLaunchKernelGGL((skinny_splitk_kernel<MMA>), grid, dim3(kSkThreads), 0, stream, p, (int*)ws);
   const int64_t quads = p.m * (p.n / 4);
   hipLaunchKernelGGL((skinny_reduce_kernel<MMA, OUT_DT>), dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, p,
                      (const int*)ws, slices);
@@ -305,8 +282,8 @@ int launch_splitk(const ScaledGemmArgs& p, int slices, hipStream_t stream) {
 }
 
 int launch_scaled_gemm_skinny(const ScaledGemmArgs& p, hipStream_t stream) {
-  const int slices = tuning(2) == 1 ? 1 : splitk_slices(p);  // CONCH_TUNE_SKINNY_NO_SPLITK = 1 disables split-K
-  if (slices > 1) {
+  const int slices = tuning(2) == 1 ? 0 : splitk_slices(p);  // CONCH_TUNE_SKINNY_NO_SPLITK = 1 disables split-K
+  if (slices >= 1) {
     int rc;
     if (p.in_dtype == CONCH_DT_FP8_E4M3FN)
       rc = p.out_dtype == CONCH_DT_BF16 ? launch_splitk<kMmaFp8, CONCH_DT_BF16>(p, slices, stream)

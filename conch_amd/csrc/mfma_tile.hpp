@@ -124,6 +124,13 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 
+// counted wait with an arbitrary compile-time count
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_n() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 enum { kMmaFp8 = 0, kMmaInt8 = 1 };
 
 template <int MMA> struct AccT { typedef f32x4 type; };
