@@ -3,6 +3,9 @@
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <map>
+#include <mutex>
+#include <utility>
 
 #include "common.hpp"
 #include "gemm.hpp"
@@ -20,6 +23,30 @@ void set_error(const char* fmt, ...) {
 }
 
 int tuning(int key) { return (key >= 0 && key < 4) ? g_tuning[key].load() : 0; }
+
+int get_scratch(hipStream_t stream, int slot, size_t bytes, void** out) {
+  struct Buf {
+    void* ptr = nullptr;
+    size_t size = 0;
+  };
+  static std::mutex mu;
+  static std::map<std::pair<hipStream_t, int>, Buf> pool;
+  std::lock_guard<std::mutex> lock(mu);
+  Buf& b = pool[{stream, slot}];
+  if (b.size < bytes) {
+    if (b.ptr) {
+      CONCH_HIP(hipStreamSynchronize(stream));  // work still using the old buffer
+      CONCH_HIP(hipFree(b.ptr));
+      b.ptr = nullptr;
+      b.size = 0;
+    }
+    const size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+    CONCH_HIP(hipMalloc(&b.ptr, want));
+    b.size = want;
+  }
+  *out = b.ptr;
+  return CONCH_OK;
+}
 
 namespace {
 
@@ -75,12 +102,8 @@ int run_scaled(const ScaledGemmArgs& p, hipStream_t stream) {
     // legal but non-native layout (row-major [K][N] weights, odd K, misaligned views): repack, then MFMA
     ScaledGemmArgs q;
     void* scratch = nullptr;
-    if (repack_for_mfma(p, &q, &scratch, stream) == CONCH_OK && scaled_gemm_mfma_supported(q)) {
-      const int rc = run_scaled_fast(q, 0, stream);
-      CONCH_HIP(hipFreeAsync(scratch, stream));
-      return rc;
-    }
-    if (scratch) CONCH_HIP(hipFreeAsync(scratch, stream));
+    if (repack_for_mfma(p, &q, &scratch, stream) == CONCH_OK && scaled_gemm_mfma_supported(q))
+      return run_scaled_fast(q, 0, stream);
   }
   return launch_scaled_gemm_generic(p, stream);
 }

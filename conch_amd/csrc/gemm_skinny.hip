@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kSkThreads, 1) void scaled_gemm_skinny_kernel(Scale
 // (n-block of 64 columns, k-slice) reads only its K slice of A -- once, through a 4-slot LDS-DMA ring
 // shared by its four waves (full 128-byte lines, same swizzled image as the tiled kernels) -- and each
 // wave streams its own 16 columns of B^T into registers.  Partial accumulators go to fp32 / int32
-// slabs [slice][M][N] in stream-ordered scratch; a second tiny kernel adds the slices in a fixed
+// slabs [slice][M][N] in library-owned scratch; a second tiny kernel adds the slices in a fixed
 // order (exact for int32, deterministic for fp32) and applies the fused epilogue.  C2: 64 n-blocks x
 // 4 slices = 256 workgroups, 192 KB of operands each.
 // ---------------------------------------------------------------------------------------------
@@ -267,7 +267,7 @@ template <int MMA, int OUT_DT>
 int launch_splitk(const ScaledGemmArgs& p, int slices, hipStream_t stream) {
   void* ws = nullptr;
   const size_t bytes = (size_t)slices * p.m * p.n * 4;
-  if (hipMallocAsync(&ws, bytes, stream) != hipSuccess) {
+  if (get_scratch(stream, 1, bytes, &ws) != CONCH_OK) {
     (void)hipGetLastError();
     return -1;  // caller falls back to the in-workgroup K split
   }
@@ -276,9 +276,7 @@ int launch_splitk(const ScaledGemmArgs& p, int slices, hipStream_t stream) {
   const int64_t quads = p.m * (p.n / 4);
   hipLaunchKernelGGL((skinny_reduce_kernel<MMA, OUT_DT>), dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, p,
                      (const int*)ws, slices);
-  const int rc = check_launch("scaled_gemm_skinny_splitk");
-  CONCH_HIP(hipFreeAsync(ws, stream));
-  return rc;
+  return check_launch("scaled_gemm_skinny_splitk");
 }
 
 int launch_scaled_gemm_skinny(const ScaledGemmArgs& p, hipStream_t stream) {

@@ -3,9 +3,8 @@
 // The MFMA GEMMs want both operands K-contiguous with K a multiple of 128 bytes and 16-byte aligned
 // rows -- what the reference's own tests and benchmarks pass (b = (N, K).T).  Any other legal input
 // (row-major [K][N] weights, a transposed activation view, K = 200, a misaligned slice) is first
-// copied into that layout in stream-ordered scratch memory (hipMallocAsync on the caller's stream,
-// so the call stays asynchronous and graph-capturable), K zero-padded: zeros add nothing to int8 or
-// fp8 dot products.  One 64x64-byte LDS tile per workgroup, reads coalesced along whichever source
+// copied into that layout in library-owned scratch memory (get_scratch: per stream, grown on demand,
+// the call stays asynchronous), K zero-padded: zeros add nothing to int8 or fp8 dot products.  One 64x64-byte LDS tile per workgroup, reads coalesced along whichever source
 // dimension has the smaller stride, writes coalesced along K.  HBM-bound, one pass.
 #include "common.hpp"
 #include "gemm.hpp"
@@ -46,7 +45,7 @@ bool k_major_ok(const void* ptr, int64_t stride_k, int64_t stride_row, int64_t k
 }  // namespace
 
 // Decide whether repacking makes `p` eligible for the MFMA kernels; if so fill `q` (a copy of p that
-// points into scratch) and launch the copies.  *scratch must be released with hipFreeAsync by the caller.
+// points into scratch) and launch the copies.  *scratch is library-owned (get_scratch), nothing to release.
 int repack_for_mfma(const ScaledGemmArgs& p, ScaledGemmArgs* q, void** scratch, hipStream_t stream) {
   *scratch = nullptr;
   *q = p;
@@ -63,7 +62,7 @@ int repack_for_mfma(const ScaledGemmArgs& p, ScaledGemmArgs* q, void** scratch, 
   const size_t b_bytes = copy_b ? (size_t)(p.n * kp + 255) / 256 * 256 : 0;
   if (p.m * kp >= ((int64_t)1 << 31) || p.n * kp >= ((int64_t)1 << 31)) return CONCH_ERR_UNSUPPORTED;
   void* ws = nullptr;
-  CONCH_HIP(hipMallocAsync(&ws, a_bytes + b_bytes, stream));
+  if (int rc = get_scratch(stream, 0, a_bytes + b_bytes, &ws)) return rc;
   *scratch = ws;
   const dim3 block(256);
   if (copy_a) {
