@@ -84,7 +84,10 @@ int run_scaled_fast(const ScaledGemmArgs& p, int variant, hipStream_t stream) {
     set_error("scaled_gemm: skinny variant forced but its contract is not met (M <= 256, K %% 1024 == 0)");
     return CONCH_ERR_UNSUPPORTED;
   }
-  if ((variant == 0 || variant == 4) && scaled_gemm_skinny_supported(p)) return launch_scaled_gemm_skinny(p, stream);
+  // auto: skinny up to N = 16384; beyond that the 256-wide tiles already fill enough CUs and stream B^T
+  // faster (M=32, K=8192, N=28672: tiled 65-70 us, skinny split-K 75-80 us)
+  if ((variant == 4 || (variant == 0 && p.n <= 16384)) && scaled_gemm_skinny_supported(p))
+    return launch_scaled_gemm_skinny(p, stream);
   return launch_scaled_gemm_mfma(p, variant == 2 ? 2 : 3, stream);
 }
 
