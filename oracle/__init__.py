@@ -4,6 +4,10 @@ TEST INFRASTRUCTURE ONLY.  Nothing under ``conch_amd/`` may import this package.
 Allowed importers: ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
 leg of ``bench.py`` (as the checker / the timed CPU baseline, never as the product).
 
+Two independent restatements: `oracle/reference.py` (torch CPU ops in the reference's order + a numpy
+bit-level FP8 codec) and `oracle/oracle_c.c` (plain C scalar loops with hand-written IEEE rounding, built
+by `oracle/build_c.py`, no torch involved).
+
 Parity status: PINNED.  Every function here is checked against golden vectors under
 ``tests/golden/`` that were produced by importing the real reference
 (``/root/reference/conch``) in the authoring container with
