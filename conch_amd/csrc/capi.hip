@@ -107,6 +107,9 @@ int run_scaled(const ScaledGemmArgs& p, hipStream_t stream) {
     void* scratch = nullptr;
     if (repack_for_mfma(p, &q, &scratch, stream) == CONCH_OK && scaled_gemm_mfma_supported(q))
       return run_scaled_fast(q, 0, stream);
+    // MI300-era e4m3fnuz operands: exact expansion to bf16, then the tiled kernel on bf16 MFMA
+    if (p.in_dtype == CONCH_DT_FP8_E4M3FNUZ && expand_fnuz_to_bf16(p, &q, stream) == CONCH_OK)
+      return launch_scaled_gemm_mfma_bf16(q, stream);
   }
   return launch_scaled_gemm_generic(p, stream);
 }

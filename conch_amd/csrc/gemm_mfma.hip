@@ -368,5 +368,18 @@ int launch_scaled_gemm_mfma(const ScaledGemmArgs& p, int variant, hipStream_t st
 #undef CONCH_LAUNCH
 }
 
+// e4m3fnuz compat path: operands already expanded to bf16 (exact) by repack.hip; `p` is in BYTE units
+// (k = 2 * K elements, strides in bytes) and satisfies the tile contract by construction.
+int launch_scaled_gemm_mfma_bf16(const ScaledGemmArgs& p, hipStream_t stream) {
+  const int tiles_m = (int)((p.m + kTileM - 1) / kTileM);
+  const int tiles_n = (int)((p.n + kTileN - 1) / kTileN);
+  const dim3 grid((unsigned)(tiles_m * tiles_n));
+  if (p.out_dtype == CONCH_DT_BF16)
+    hipLaunchKernelGGL((scaled_gemm_pingpong_kernel<kMmaBf16, CONCH_DT_BF16>), grid, dim3(kThreads), 0, stream, p);
+  else
+    hipLaunchKernelGGL((scaled_gemm_pingpong_kernel<kMmaBf16, CONCH_DT_FP16>), grid, dim3(kThreads), 0, stream, p);
+  return check_launch("scaled_gemm_mfma_bf16");
+}
+
 // mixed-precision MFMA kernels live in gemm_mixed.hip
 }  // namespace conch

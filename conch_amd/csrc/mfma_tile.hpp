@@ -131,7 +131,7 @@ __device__ __forceinline__ void wait_vmcnt_n() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-enum { kMmaFp8 = 0, kMmaInt8 = 1 };
+enum { kMmaFp8 = 0, kMmaInt8 = 1, kMmaBf16 = 2 };
 
 template <int MMA> struct AccT { typedef f32x4 type; };
 template <> struct AccT<kMmaInt8> { typedef i32x4 type; };
@@ -148,6 +148,10 @@ __device__ __forceinline__ void mma_step(typename AccT<MMA>::type& acc, const Fr
     // the UNSCALED v_mfma_f32_16x16x128_f8f6f4 (one 8-byte instruction, products taken as they are)
     // instead of the v_mfma_ld_scale_b32 + v_mfma_scale pair with E8M0 scales of 2^0.
     acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, acc, 0, 0, 0, 0, 0, 0);
+  } else if constexpr (MMA == kMmaBf16) {
+    // 128-byte K step = 64 bf16: chunk g holds k = 8g..8g+7, chunk g+4 holds k = 32+8g.. (e4m3fnuz compat path)
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa.lo), __builtin_bit_cast(bf16x8, fb.lo), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa.hi), __builtin_bit_cast(bf16x8, fb.hi), acc, 0, 0, 0);
   } else {
     acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa.lo, fb.lo, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa.hi, fb.hi, acc, 0, 0, 0);

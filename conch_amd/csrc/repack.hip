@@ -38,6 +38,31 @@ __global__ __launch_bounds__(256) void repack_rows_kernel(uint8_t* __restrict__ 
   }
 }
 
+// e4m3fnuz -> bf16 (every e4m3 value is exactly representable), K-contiguous, zero padded:
+// dst[r][k] (bf16, row stride kp elements) = decode_fnuz(src[r * sr + k * sk])
+__global__ __launch_bounds__(256) void fnuz_to_bf16_rows_kernel(uint16_t* __restrict__ dst, const uint8_t* __restrict__ src,
+                                                                int64_t rows, int64_t k_dim, int64_t kp, int64_t sr,
+                                                                int64_t sk) {
+  __shared__ uint8_t tile[kRpTile][kRpTile + 4];  // [r][k]
+  const int64_t k0 = (int64_t)blockIdx.x * kRpTile, r0 = (int64_t)blockIdx.y * kRpTile;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const bool k_fast = sk <= sr;
+#pragma unroll 4
+  for (int i = ty; i < kRpTile; i += 4) {
+    const int rr = k_fast ? i : tx, kk = k_fast ? tx : i;
+    const int64_t r = r0 + rr, k = k0 + kk;
+    uint8_t v = 0;
+    if (r < rows && k < k_dim) v = src[r * sr + k * sk];
+    tile[rr][kk] = v;
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int i = ty; i < kRpTile; i += 4) {
+    const int64_t r = r0 + i, k = k0 + tx;
+    if (r < rows && k < kp) dst[r * kp + k] = float_to_bf16_bits(decode_fp8_sw<true>(tile[i][tx]));
+  }
+}
+
 bool k_major_ok(const void* ptr, int64_t stride_k, int64_t stride_row, int64_t k_dim, int64_t k_mult) {
   return stride_k == 1 && stride_row % 16 == 0 && ((uintptr_t)ptr & 15) == 0 && k_dim % k_mult == 0;
 }
@@ -84,6 +109,39 @@ int repack_for_mfma(const ScaledGemmArgs& p, ScaledGemmArgs* q, void** scratch, 
   }
   q->k = kp;
   return check_launch("repack_rows");
+}
+
+// e4m3fnuz operands: expand both to bf16 in scratch (exact) and describe them to the tiled MFMA kernel in
+// BYTE units (a 128-byte K step = 64 elements).  The MI300-era flavour cannot use gfx950's OCP fp8 MFMA
+// (different bias, 0x7F/0xFF are numbers, 0x80 is NaN), so it runs at the bf16 MFMA rate instead.
+int expand_fnuz_to_bf16(const ScaledGemmArgs& p, ScaledGemmArgs* q, hipStream_t stream) {
+  *q = p;
+  if (p.in_dtype != CONCH_DT_FP8_E4M3FNUZ || p.c_stride_n != 1 || p.k < 1) return CONCH_ERR_UNSUPPORTED;
+  const int64_t kp = (p.k + 63) / 64 * 64;  // elements; 128-byte steps
+  if (p.m * kp * 2 >= ((int64_t)1 << 31) || p.n * kp * 2 >= ((int64_t)1 << 31)) return CONCH_ERR_UNSUPPORTED;
+  if (p.m >= (1 << 24) || p.n >= (1 << 24) || ((uintptr_t)p.c & 1)) return CONCH_ERR_UNSUPPORTED;
+  const size_t a_bytes = (size_t)(p.m * kp * 2 + 255) / 256 * 256;
+  const size_t b_bytes = (size_t)(p.n * kp * 2 + 255) / 256 * 256;
+  void* ws = nullptr;
+  if (int rc = get_scratch(stream, 0, a_bytes + b_bytes, &ws)) return rc;
+  const dim3 block(256);
+  {
+    const dim3 grid((unsigned)((kp + kRpTile - 1) / kRpTile), (unsigned)((p.m + kRpTile - 1) / kRpTile));
+    hipLaunchKernelGGL(fnuz_to_bf16_rows_kernel, grid, block, 0, stream, (uint16_t*)ws, (const uint8_t*)p.a, p.m, p.k,
+                       kp, p.a_stride_m, p.a_stride_k);
+  }
+  uint8_t* bt = (uint8_t*)ws + a_bytes;
+  {
+    const dim3 grid((unsigned)((kp + kRpTile - 1) / kRpTile), (unsigned)((p.n + kRpTile - 1) / kRpTile));
+    hipLaunchKernelGGL(fnuz_to_bf16_rows_kernel, grid, block, 0, stream, (uint16_t*)bt, (const uint8_t*)p.b, p.n, p.k,
+                       kp, p.b_stride_n, p.b_stride_k);
+  }
+  q->a = ws;
+  q->b = bt;
+  q->a_stride_m = q->b_stride_n = kp * 2;  // bytes
+  q->a_stride_k = q->b_stride_k = 1;
+  q->k = kp * 2;                            // bytes
+  return check_launch("fnuz_to_bf16_rows");
 }
 
 }  // namespace conch

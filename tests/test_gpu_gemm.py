@@ -275,7 +275,12 @@ def test_mixed_precision_gemm_matrix(m, k, n, wname, use_zp, dname):
     got = mixed_precision_gemm(a.cuda(), packed.cuda(), w_s.cuda(), None if w_zp is None else w_zp.cuda(),
                                wt.size_bits, wt.bias, 128)
     assert got.shape == (m, n) and got.dtype == DT[dname]
-    check_mixed(got, a, w_ref, k)
+    if m > 1024:
+        # half-precision matmul on the CPU is very slow (minutes for 4096 rows): check three bands of rows
+        rows = torch.cat([torch.arange(0, 64), torch.arange(m // 2 - 32, m // 2 + 32), torch.arange(m - 64, m)])
+        check_mixed(got[rows.cuda()], a[rows], w_ref, k)
+    else:
+        check_mixed(got, a, w_ref, k)
 
 
 @pytest.mark.parametrize("wname", list(WTYPES))
