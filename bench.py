@@ -380,7 +380,7 @@ def main() -> None:
         "config": {
             "workload": desc,
             "parallelism": "single GPU" if world == 1 else f"dp{world} over tokens (M={m} per rank, weights replicated)",
-            "gemm_variant": "auto (ping-pong MFMA kernel, variant 3)",
+            "gemm_variant": "auto",
             "clock_ramp_s": CLOCK_RAMP_S,
         },
         "roofline": roofline,
