@@ -151,7 +151,7 @@ int run_mixed(const MixedGemmArgs& p, hipStream_t stream) {
     }
     return launch_mixed_gemm_generic(p, stream);
   }
-  return launch_mixed_gemm_mfma(p, variant == 2 ? 2 : 3, stream);
+  return launch_mixed_gemm_mfma(p, variant, stream);  // 0/2 = plain loop (default), 3 = ping-pong
 }
 
 template <class F>
