@@ -88,7 +88,7 @@ int run_scaled_fast(const ScaledGemmArgs& p, int variant, hipStream_t stream) {
   // faster (M=32, K=8192, N=28672: tiled 65-70 us, skinny split-K 75-80 us)
   if ((variant == 4 || (variant == 0 && p.n <= 16384)) && scaled_gemm_skinny_supported(p))
     return launch_scaled_gemm_skinny(p, stream);
-  return launch_scaled_gemm_mfma(p, variant == 2 ? 2 : 3, stream);
+  return launch_scaled_gemm_mfma(p, (variant == 2 || variant == 3) ? variant : 5, stream);
 }
 
 int run_scaled(const ScaledGemmArgs& p, hipStream_t stream) {
@@ -96,7 +96,7 @@ int run_scaled(const ScaledGemmArgs& p, hipStream_t stream) {
   if (p.m == 0 || p.n == 0) return CONCH_OK;
   const int variant = tuning(CONCH_TUNE_GEMM_VARIANT);
   if (variant != 1 && scaled_gemm_mfma_supported(p)) return run_scaled_fast(p, variant, stream);
-  if (variant >= 2 && variant <= 4) {
+  if (variant >= 2 && variant <= 5) {
     set_error("scaled_gemm: MFMA variant %d forced but the layout contract is not met "
               "(need K-contiguous A and B^T, K %% 128 == 0, 16-byte aligned rows)", variant);
     return CONCH_ERR_UNSUPPORTED;

@@ -28,7 +28,7 @@ pytestmark = pytest.mark.gpu
 IN_T = {"int8": torch.int8, "fn": torch.float8_e4m3fn, "fnuz": torch.float8_e4m3fnuz}
 SHAPES = [(128, 256, 128), (1024, 1024, 1024), (4096, 2048, 4096)]
 VARIANTS = {"auto": _C.VARIANT_AUTO, "generic": _C.VARIANT_GENERIC, "simple": _C.VARIANT_MFMA_SIMPLE,
-            "pingpong": _C.VARIANT_MFMA_PINGPONG, "skinny": _C.VARIANT_MFMA_SKINNY}
+            "pingpong": _C.VARIANT_MFMA_PINGPONG, "skinny": _C.VARIANT_MFMA_SKINNY, "pingpong2": _C.VARIANT_MFMA_PINGPONG2}
 # fp accumulation-order tolerance, relative to max|C| of the case, in output-dtype epsilons
 EPS = {torch.float16: 2.0**-10, torch.bfloat16: 2.0**-7}
 
@@ -95,13 +95,15 @@ def test_scaled_gemm_large_shape(iname, oname, sa_scalar, sb_scalar, use_bias):
     check_scaled(run_scaled(a, b, sa, sb, DT[oname], bias), ref, IN_T[iname], DT[oname])
 
 
-@pytest.mark.parametrize("variant", ["generic", "simple", "pingpong", "skinny"])
+@pytest.mark.parametrize("variant", ["generic", "simple", "pingpong", "pingpong2", "skinny"])
 @pytest.mark.parametrize("iname", ["int8", "fn"])
 @pytest.mark.parametrize(("m", "k", "n"), [(128, 256, 128), (1024, 1024, 1024), (300, 384, 520), (257, 128, 8),
                                             (512, 1152, 1376), (2304, 512, 4672), (4096, 256, 11008),
                                             (128, 1024, 4096), (200, 2048, 520), (1, 1024, 24), (256, 3072, 1376)])
 def test_scaled_gemm_every_kernel_variant(variant, iname, m, k, n):
     """Each device kernel, including ragged M/N tails (partial tiles, N not a multiple of 256 / 16)."""
+    if variant == "pingpong2" and k < 256:
+        pytest.skip("two-phase ping-pong stages two K steps in its prologue (K >= 256)")
     if variant == "skinny" and (m > 256 or k % 1024):
         pytest.skip("skinny kernel: M <= 256 and K a multiple of 1024")
     a, b, sa, sb, bias = make_scaled_inputs(m, k, n, IN_T[iname], torch.bfloat16, False, False, True)
