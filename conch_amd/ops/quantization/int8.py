@@ -1,38 +1,23 @@
-"""Int8 quantization (public API; mirrors conch/ops/quantization/int8.py:11-48)."""
+"""Int8 quantization, public API (names and signatures of conch/ops/quantization/int8.py:11-48)."""
 
 import torch
 
 from conch_amd.kernels.quantization.int8 import static_scaled_int8_quant_launcher
+from conch_amd.ops.quantization._static_quant import quantize_into, quantize_new
+
+_OUT = (torch.int8,)
 
 
-def static_scaled_int8_quant(
-    output_tensor: torch.Tensor,
-    input_tensor: torch.Tensor,
-    scale: torch.Tensor,
-) -> None:
-    """Quantize `input_tensor` to int8 into `output_tensor` with the static per-tensor `scale`.
+def static_scaled_int8_quant(output_tensor: torch.Tensor, input_tensor: torch.Tensor, scale: torch.Tensor) -> None:
+    """output_tensor[t, h] = int8(clamp(input_tensor[t, h] / scale, -128, 127)), written in place.
 
-    Args:
-        output_tensor: int8 tensor to write, shape (num_tokens, hidden_size).
-        input_tensor: fp16/bf16/fp32 tensor to quantize, same shape.
-        scale: fp32 tensor with one element.
+    `output_tensor`: int8, shape (num_tokens, hidden_size); `input_tensor`: fp16/bf16/fp32, same shape;
+    `scale`: fp32 tensor holding the one static per-tensor scale.
     """
-    assert output_tensor.shape == input_tensor.shape  # noqa: S101
-    assert scale.numel() == 1  # noqa: S101
-
-    static_scaled_int8_quant_launcher(output_tensor, input_tensor, scale)
+    quantize_into(output_tensor, input_tensor, scale, static_scaled_int8_quant_launcher, _OUT)
 
 
-def scaled_int8_quant(
-    input_tensor: torch.Tensor,
-    scale: torch.Tensor | None = None,
-) -> tuple[torch.Tensor, torch.Tensor]:
-    """Scaled int8 quantization; returns (quantized tensor, the same `scale` object)."""
-    if scale is None:
-        error_msg = "Dynamic int8 quantization not yet implemented"
-        raise NotImplementedError(error_msg)
-
-    # every element is written by the kernel, so no memset is needed (the reference zero-fills)
-    output_tensor = torch.empty_like(input_tensor, dtype=torch.int8)
-    static_scaled_int8_quant(output_tensor, input_tensor, scale)
-    return output_tensor, scale
+def scaled_int8_quant(input_tensor: torch.Tensor, scale: torch.Tensor | None = None) -> tuple[torch.Tensor, torch.Tensor]:
+    """Quantize to int8 with a static scale; returns (int8 tensor, scale).  Dynamic (scale=None) is not implemented."""
+    return quantize_new(input_tensor, scale, torch.int8, static_scaled_int8_quant_launcher, _OUT,
+                        "Dynamic int8 quantization not yet implemented")
