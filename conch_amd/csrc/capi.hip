@@ -142,16 +142,17 @@ int check_mixed(const MixedGemmArgs& p) {
 int run_mixed(const MixedGemmArgs& p, hipStream_t stream) {
   if (int rc = check_mixed(p)) return rc;
   if (p.m == 0 || p.n == 0) return CONCH_OK;
+  // variant 1 forces the generic kernel; every other value means the LDS-tiled MFMA kernel (gemm_mixed.hip)
   const int variant = tuning(CONCH_TUNE_GEMM_VARIANT);
   const bool fast_ok = mixed_gemm_mfma_supported(p);
   if (variant == 1 || !fast_ok) {
-    if ((variant == 2 || variant == 3) && !fast_ok) {
+    if (variant >= 2 && !fast_ok) {
       set_error("mixed_precision_gemm: MFMA variant %d forced but the layout contract is not met", variant);
       return CONCH_ERR_UNSUPPORTED;
     }
     return launch_mixed_gemm_generic(p, stream);
   }
-  return launch_mixed_gemm_mfma(p, variant, stream);  // 0/2 = plain loop (default), 3 = ping-pong
+  return launch_mixed_gemm_mfma(p, stream);
 }
 
 template <class F>

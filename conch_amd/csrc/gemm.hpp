@@ -55,6 +55,6 @@ int repack_for_mfma(const ScaledGemmArgs& p, ScaledGemmArgs* q, void** scratch, 
 int expand_fnuz_to_bf16(const ScaledGemmArgs& p, ScaledGemmArgs* q, hipStream_t stream);
 int launch_scaled_gemm_mfma_bf16(const ScaledGemmArgs& p, hipStream_t stream);
 bool mixed_gemm_mfma_supported(const MixedGemmArgs& p);
-int launch_mixed_gemm_mfma(const MixedGemmArgs& p, int variant, hipStream_t stream);
+int launch_mixed_gemm_mfma(const MixedGemmArgs& p, hipStream_t stream);
 
 }  // namespace conch

@@ -3,21 +3,32 @@
 // Replaces the mixed-precision instantiation of the reference's Triton kernel
 // (conch/kernels/quantization/gemm.py:219-457 via mixed_precision_gemm_launcher :482-545).
 //
-// Same 256x256 / 8-wave geometry as the scaled GEMM (mfma_tile.hpp), K advanced 64 elements
-// (128 bytes of fp16/bf16) per step, MFMA = v_mfma_f32_16x16x32_{f16,bf16}:
+// Same 256 x (64 NT) / 8-wave geometry as the scaled GEMM (mfma_tile.hpp), K advanced 64 elements (128 bytes
+// of fp16/bf16) per step, MFMA = v_mfma_f32_16x16x32_{f16,bf16}, one workgroup barrier per K step:
 //   * activations X stream global -> LDS by LDS-DMA (U units), exactly like the scaled GEMM's A;
-//   * packed weights are read ONCE per workgroup as 32-bit words straight from the [K/pf][N] tensor
-//     (a word holds 8 (int4) / 4 (int8) consecutive k of one column = one 16-byte / 8-byte piece of
-//     that column's LDS row), dequantised IN REGISTERS and written to the V units with
-//     ds_write_b128, so the MFMA loop reads both operands from LDS with conflict-free ds_read_b128;
-//   * dequantisation is bit-identical to the reference's w_ref (quant_utils.py:74,
-//     kernels gemm.py:192-210): (q - bias - zp) is formed exactly, then ONE rounding multiply by the
-//     fp16/bf16 group scale.  fp16 uses the 0x6400 magic-number trick (1024+q as an fp16 bit
-//     pattern), v_pk_add_f16 and v_pk_mul_f16; bf16 multiplies in fp32 (exact 8x8-bit product)
-//     and rounds once with v_cvt_pk_bf16_f32;
-//   * the weight words / scales / zero-points of K step t+2 are prefetched into registers while
-//     step t is multiplied; step t+1's are converted right after the step's barrier.
+//   * packed weights are read ONCE per workgroup as 32-bit words straight from the [K/pf][N] tensor (a word
+//     holds 8 (int4) / 4 (int8) consecutive k of one column = one 16-byte / 8-byte piece of that column's LDS
+//     row) by buffer loads whose per-step advance is a scalar offset, dequantised IN REGISTERS and written to
+//     the V units with ds_write_b128, so the MFMA loop reads both operands from LDS with conflict-free
+//     ds_read_b128;
+//   * dequantisation is bit-identical to the reference's w_ref (quant_utils.py:74, kernels gemm.py:192-210):
+//     (q - bias - zp) is formed exactly, then ONE rounding multiply by the fp16/bf16 group scale (ChunkDequant);
+//   * every wave dequantises the weights of step t+1 BETWEEN the MFMAs of step t.  A v_mfma_f32_16x16x32
+//     occupies the matrix pipe for 16 cycles and the SIMD's vector issue for 8 of them, so two 4-cycle VALU
+//     instructions per MFMA are free: the ~100 VALU instructions of a step's dequantisation fit under its
+//     32-64 MFMAs.  (Converting right after the barrier, then multiplying, exposes that VALU time -- both waves
+//     of a SIMD convert at once: C4 104 us against 85 us.)  The step is written as SLOTS -- one MFMA, then a
+//     two-to-four-instruction slice of the dequantisation, a fragment read or a VMEM instruction -- fenced by
+//     sched_barrier(0), and the K loop is peeled so that its body is one basic block;
+//   * the two waves of a SIMD (w and w + 4) issue the step's VMEM work (4 LDS-DMA pieces, the weight loads of
+//     step t+2) at different slots: while one pays the LDS-DMA issue cost the other has the matrix pipe;
+//   * work items are (unit row, chunk) pairs dealt so that every thread converts the same number of chunks
+//     for every tile width (NT = 3: two chunks of V1 and ONE of V2 -- threads with tq = 1 take chunk cp + 4 of
+//     the row their tq = 0 neighbour owns), so there is no divergent branch in the loop;
 //   * fp32 accumulation, RNE cast, 16-byte stores (8 consecutive n per lane).
+// Tried and dropped (profiles/README.md): a ping-pong K loop with the dequantisation in the load segments, a
+// three-stage X ring (LDS-DMA two steps ahead, 160 KiB of LDS), a sched_group_barrier pattern over the whole
+// step instead of the hand-made slots.
 #include "common.hpp"
 #include "gemm.hpp"
 #include "mfma_tile.hpp"
@@ -29,403 +40,11 @@ using namespace tile;
 
 constexpr int kStepK = 64;  // k elements per step (128 bytes of 16-bit)
 
-template <int X_DT>
-__device__ __forceinline__ void mma16(f32x4& acc, const Frag& fa, const Frag& fb) {
-  if constexpr (X_DT == CONCH_DT_FP16) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fa.lo), __builtin_bit_cast(f16x8, fb.lo), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fa.hi), __builtin_bit_cast(f16x8, fb.hi), acc, 0, 0, 0);
-  } else {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa.lo), __builtin_bit_cast(bf16x8, fb.lo), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa.hi), __builtin_bit_cast(bf16x8, fb.hi), acc, 0, 0, 0);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// in-register dequantisation of one 16-byte LDS chunk (8 consecutive k of one column)
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t pk_sub_mul_f16(uint32_t v, uint32_t sub, uint32_t scale) {
-  f16x2 x = __builtin_bit_cast(f16x2, v);
-  x = x - __builtin_bit_cast(f16x2, sub);    // exact: (1024 + q) - (1024 + bias + zp)
-  x = x * __builtin_bit_cast(f16x2, scale);  // the single rounding
-  return __builtin_bit_cast(uint32_t, x);
-}
-
-// 8 nibbles / 2x4 bytes -> 8 halves in k order.  `off` = weight_bias + zero point (an integer),
-// `scale_bits` = the group scale's 16-bit pattern.
-template <int X_DT, int BITS>
-__device__ __forceinline__ i32x4 dequant_chunk(uint32_t w0, uint32_t w1, int off, uint32_t scale_bits) {
-  i32x4 out;
-  if constexpr (X_DT == CONCH_DT_FP16) {
-    constexpr uint32_t kMagic = 0x64006400u;  // fp16 1024.0 in both halves: 1024 + q has q in the mantissa LSBs
-    const uint32_t sub1 = (uint32_t)float_to_half_bits((float)(1024 + off));
-    const uint32_t sub = sub1 | (sub1 << 16);
-    const uint32_t sc = scale_bits | (scale_bits << 16);
-    if constexpr (BITS == 4) {
-      const uint32_t a = pk_sub_mul_f16((w0 & 0x000f000fu) | kMagic, sub, sc);          // k0, k4
-      const uint32_t b = pk_sub_mul_f16(((w0 >> 4) & 0x000f000fu) | kMagic, sub, sc);   // k1, k5
-      const uint32_t c = pk_sub_mul_f16(((w0 >> 8) & 0x000f000fu) | kMagic, sub, sc);   // k2, k6
-      const uint32_t d = pk_sub_mul_f16(((w0 >> 12) & 0x000f000fu) | kMagic, sub, sc);  // k3, k7
-      out[0] = (int)((a & 0xffffu) | (b << 16));
-      out[1] = (int)((c & 0xffffu) | (d << 16));
-      out[2] = (int)((a >> 16) | (b & 0xffff0000u));
-      out[3] = (int)((c >> 16) | (d & 0xffff0000u));
-    } else {
-      const uint32_t e0 = pk_sub_mul_f16((w0 & 0x00ff00ffu) | kMagic, sub, sc);         // k0, k2
-      const uint32_t f0 = pk_sub_mul_f16(((w0 >> 8) & 0x00ff00ffu) | kMagic, sub, sc);  // k1, k3
-      const uint32_t e1 = pk_sub_mul_f16((w1 & 0x00ff00ffu) | kMagic, sub, sc);         // k4, k6
-      const uint32_t f1 = pk_sub_mul_f16(((w1 >> 8) & 0x00ff00ffu) | kMagic, sub, sc);  // k5, k7
-      out[0] = (int)((e0 & 0xffffu) | (f0 << 16));
-      out[1] = (int)((e0 >> 16) | (f0 & 0xffff0000u));
-      out[2] = (int)((e1 & 0xffffu) | (f1 << 16));
-      out[3] = (int)((e1 >> 16) | (f1 & 0xffff0000u));
-    }
-  } else {
-    const float s = bf16_bits_to_float((uint16_t)scale_bits);
-    uint16_t h[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      int q;
-      if constexpr (BITS == 4) q = (int)((w0 >> (4 * j)) & 0xfu);
-      else q = (int)(((j < 4 ? w0 : w1) >> (8 * (j & 3))) & 0xffu);
-      // (q - off) is exact in fp32 and in bf16; the fp32 product is exact, so the cast is the one rounding
-      h[j] = float_to_bf16_bits((float)(q - off) * s);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) out[j] = (int)((uint32_t)h[2 * j] | ((uint32_t)h[2 * j + 1] << 16));
-  }
-  return out;
-}
-
-// Weight words, scale and zero-point of one thread for one K step: the thread owns unit row
-// rho = tid & 127 of V1 (column n1) and of V2 (column n2 = n1 + 32) and chunks cp, cp + 4.
-template <int BITS>
-struct WeightRegs {
-  static constexpr int kWordsPerChunk = BITS == 4 ? 1 : 2;
-  uint32_t w[2][2][kWordsPerChunk];  // [unit V1/V2][chunk cp / cp+4][word]
-  uint32_t scale[2];
-  int zp[2];
-};
-
-template <int BITS, int ZP>
-__device__ __forceinline__ void load_weights(WeightRegs<BITS>& r, const MixedGemmArgs& p, int step, int n1, int n2,
-                                             int cp, bool v2_valid) {
-  constexpr int kWordRowsPerStep = kStepK * BITS / 32;  // 8 (int4) or 16 (int8)
-  constexpr int kWpc = WeightRegs<BITS>::kWordsPerChunk;
-  const int k0 = step * kStepK;
-  const int64_t g = k0 / p.group_size;
-  const int ncol[2] = {n1, n2};
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    if (u == 1 && !v2_valid) continue;  // this thread's V2 row is outside a narrow tile
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int chunk = cp + 4 * c;
-#pragma unroll
-      for (int i = 0; i < kWpc; ++i) {
-        const int64_t row = (int64_t)step * kWordRowsPerStep + chunk * kWpc + i;
-        r.w[u][c][i] = (uint32_t)p.w_q[row * p.wq_stride_k + ncol[u]];
-      }
-    }
-    r.scale[u] = ((const uint16_t*)p.w_s)[g * p.ws_stride_g + ncol[u]];
-    if constexpr (ZP == CONCH_ZP_TENSOR) r.zp[u] = p.w_zp[g * p.wzp_stride_g + ncol[u]];
-    else r.zp[u] = 0;
-  }
-}
-
-template <int X_DT, int BITS>
-__device__ __forceinline__ void convert_weights(const WeightRegs<BITS>& r, char* lds, int buf, int row_off, int swz,
-                                                int cp, int off_base, bool v2_valid) {
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    if (u == 1 && !v2_valid) continue;
-    const int kind = u == 0 ? kV1 : kV2;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int chunk = cp + 4 * c;
-      const uint32_t w1 = WeightRegs<BITS>::kWordsPerChunk == 2 ? r.w[u][c][WeightRegs<BITS>::kWordsPerChunk - 1] : 0u;
-      const i32x4 v = dequant_chunk<X_DT, BITS>(r.w[u][c][0], w1, off_base + r.zp[u], r.scale[u]);
-      *(i32x4*)(lds + buf + kind * kUnitBytes + row_off + ((chunk ^ swz) * 16)) = v;
-    }
-  }
-}
-
 struct MixedTile {
   f32x4 acc[8][4];
   Frag fm[4];
   Frag fn[2][2];
 };
-
-// NT = 16-column MFMA tiles per wave (tile width 64*NT): tiles 0,1 form the first n sub-half, tiles
-// 2..NT-1 the second.
-template <int X_DT, int PHASE, int NT>
-__device__ __forceinline__ void mixed_phase(MixedTile& w, const char* lds, int buf, int m_base, int n_base) {
-  constexpr int N1 = NT - 2;  // tiles in the second sub-half
-  if constexpr (PHASE == 0) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t) w.fn[0][t] = read_frag(lds, buf + kV1 * kUnitBytes + n_base + t * 2048);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) w.fm[i] = read_frag(lds, buf + kU1 * kUnitBytes + m_base + i * 2048);
-  } else if constexpr (PHASE == 1) {
-#pragma unroll
-    for (int t = 0; t < N1; ++t) w.fn[1][t] = read_frag(lds, buf + kV2 * kUnitBytes + n_base + t * 2048);
-  } else if constexpr (PHASE == 2) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) w.fm[i] = read_frag(lds, buf + kU2 * kUnitBytes + m_base + i * 2048);
-  }
-  constexpr int MH = (PHASE >= 2) ? 1 : 0;
-  constexpr int NH = (PHASE == 1 || PHASE == 2) ? 1 : 0;
-  constexpr int CNT = NH == 0 ? 2 : N1;
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int t = 0; t < CNT; ++t) mma16<X_DT>(w.acc[MH * 4 + i][NH * 2 + t], w.fn[NH][t], w.fm[i]);
-}
-
-template <int X_DT, int OUT_DT, int BITS, int ZP, int NT>
-__global__ __launch_bounds__(kThreads, 2) void mixed_gemm_kernel(MixedGemmArgs p) {
-  constexpr int kTileW = 64 * NT;  // columns per workgroup
-  __shared__ __attribute__((aligned(1024))) char lds[kLdsBytes];
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  const int wr = wave >> 2, wc = wave & 3;
-  const int tiles_m = ((int)p.m + kTileM - 1) / kTileM;
-  const int tiles_n = ((int)p.n + kTileW - 1) / kTileW;
-  const TileCoord tc = map_tile(blockIdx.x, tiles_m, tiles_n);
-  const int bm0 = tc.tm * kTileM, bn0 = tc.tn * kTileW;
-
-  // activations: LDS-DMA units (byte strides: 2 bytes per element)
-  const int ldx = (int)p.x_stride_m * 2;
-  const StageOffsets so = make_stage_offsets(wave, lane, bm0, bn0, (int)p.m - 1, 0, ldx, 0);
-  Srcs src;
-  src.a = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (uint32_t)(((p.m - 1) * p.x_stride_m + p.k) * 2), 0x00020000);
-  src.b = src.a;
-
-  // weights: this thread's unit row / columns / chunk pair
-  const int rho = threadIdx.x & 127;
-  const int cp = threadIdx.x >> 7;
-  const int r5 = rho & 31, r = r5 & 15, tq = r5 >> 4;
-  // wave-column rho>>5 owns columns [16*NT*wc, 16*NT*(wc+1)); a PAIR of MFMA tiles is interleaved (rows 4g+e
-  // of tile t <-> n = 8g+e+4t: a lane ends up with 8 consecutive n), a LONE third tile (NT == 3) is plain
-  const int wcol = (rho >> 5) * 16 * NT;
-  const int pair = 8 * (r >> 2) + (r & 3) + 4 * tq;
-  const int n1 = min(bn0 + wcol + pair, (int)p.n - 1);
-  const int n2 = min(bn0 + wcol + 32 + (NT == 4 ? pair : r), (int)p.n - 1);
-  const bool v2_valid = NT == 4 || (NT == 3 && tq == 0);
-  const int w_row_off = (rho >> 3) * 1024 + (rho & 7) * 128;
-  const int w_swz = (rho >> 1) & 7;
-  const int off_base = p.weight_bias + (ZP == CONCH_ZP_SCALAR ? p.w_zp[0] : 0);
-
-  // fragment read offsets
-  const int fr = lane & 15, fg = lane >> 4;
-  const int lane_off = (fr >> 3) * 1024 + (fr & 7) * 128 + ((fg ^ ((fr >> 1) & 7)) * 16);
-  const int m_base = (wr * 8) * 1024 + lane_off;
-  const int n_base = (wc * 4) * 1024 + lane_off;
-
-  MixedTile w;
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) w.acc[i][j] = f32x4{0, 0, 0, 0};
-
-  const int steps = (int)(p.k / kStepK);
-  WeightRegs<BITS> regs;
-
-  // prologue: step 0 operands into buffer 0, step 1 weights into registers
-  stage_unit<kU1>(lds, src, so, wave, 0);
-  stage_unit<kU2>(lds, src, so, wave, 0);
-  load_weights<BITS, ZP>(regs, p, 0, n1, n2, cp, v2_valid);
-  convert_weights<X_DT, BITS>(regs, lds, 0, w_row_off, w_swz, cp, off_base, v2_valid);
-  if (steps > 1) load_weights<BITS, ZP>(regs, p, 1, n1, n2, cp, v2_valid);
-
-  for (int t = 0; t < steps; ++t) {
-    // everything this wave staged for step t (LDS-DMA and ds_write) is complete ...
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // ... and every wave is done reading the other buffer
-    const int buf = (t & 1) * kBufBytes;
-    const int nbuf = ((t + 1) & 1) * kBufBytes;
-    if (t + 1 < steps) {
-      stage_unit<kU1>(lds, src, so, wave, t + 1);
-      stage_unit<kU2>(lds, src, so, wave, t + 1);
-      convert_weights<X_DT, BITS>(regs, lds, nbuf, w_row_off, w_swz, cp, off_base, v2_valid);
-      if (t + 2 < steps) load_weights<BITS, ZP>(regs, p, t + 2, n1, n2, cp, v2_valid);
-    }
-    mixed_phase<X_DT, 0, NT>(w, lds, buf, m_base, n_base);
-    mixed_phase<X_DT, 1, NT>(w, lds, buf, m_base, n_base);
-    mixed_phase<X_DT, 2, NT>(w, lds, buf, m_base, n_base);
-    mixed_phase<X_DT, 3, NT>(w, lds, buf, m_base, n_base);
-  }
-
-  // epilogue: cast and store; a pair of tiles gives a lane 8 consecutive n (16-byte store), a lone tile 4
-  const int g = lane >> 4, jm = lane & 15;
-  const bool vec_store = (p.c_stride_m % 8 == 0) && (((uintptr_t)p.c & 15) == 0);
-#pragma unroll
-  for (int nh = 0; nh < 2; ++nh) {
-    if (nh == 1 && NT == 2) continue;
-    const bool pair_h = nh == 0 || NT == 4;
-    const int width = pair_h ? 8 : 4;
-    const int n0 = bn0 + wc * 16 * NT + nh * 32 + width * g;
-#pragma unroll
-    for (int mt = 0; mt < 8; ++mt) {
-      const int m = bm0 + wr * 128 + mt * 16 + jm;
-      if (m >= p.m) continue;
-      uint16_t o[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = float_to_bits16<OUT_DT>(pin_f32(w.acc[mt][nh * 2 + (pair_h ? (e >> 2) : 0)][e & 3]));
-      uint16_t* dst = (uint16_t*)p.c + (int64_t)m * p.c_stride_m + n0;
-      if (pair_h && vec_store && n0 + 8 <= p.n) {
-        i32x4 pk;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) pk[e] = (int)((uint32_t)o[2 * e] | ((uint32_t)o[2 * e + 1] << 16));
-        *(i32x4*)dst = pk;
-      } else if (!pair_h && vec_store && n0 + 4 <= p.n) {
-        i32x2 pk;
-        pk[0] = (int)((uint32_t)o[0] | ((uint32_t)o[1] << 16));
-        pk[1] = (int)((uint32_t)o[2] | ((uint32_t)o[3] << 16));
-        *(i32x2*)dst = pk;
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (e < width && n0 + e < p.n) dst[e] = o[e];
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Ping-pong form (variant 3, the default): the K loop of gemm_mfma.hip's variant 3 -- 4 phases per K
-// step, {load segment} barrier {MFMA cluster} barrier, waves 4-7 one barrier behind waves 0-3 -- with
-// the weight units produced in the load segments: the packed words of V unit s are loaded to
-// registers in phase s-6, dequantised and written to LDS in phase s-3, read as fragments in phase
-// s-1.  A wave's dequantisation VALU work therefore overlaps the MFMA cluster of the other wave on
-// its SIMD instead of both waves converting, then both multiplying.
-// Counted waits: of any four consecutive units two are LDS-DMA (2 VMEM ops each per wave) and two
-// are register loads (NV1 / NV2 ops), so "all but the 4 youngest units" = vmcnt(4 + NV1 + NV2).
-// ---------------------------------------------------------------------------------------------
-template <int BITS>
-struct UnitRegs {
-  static constexpr int kWpc = BITS == 4 ? 1 : 2;
-  uint32_t w[2][kWpc];  // [chunk cp / cp+4][word]
-  uint32_t scale;
-  int zp;
-};
-
-template <int BITS, int ZP>
-constexpr int unit_vmem_ops() { return 2 * UnitRegs<BITS>::kWpc + 1 + (ZP == CONCH_ZP_TENSOR ? 1 : 0); }
-
-template <int BITS, int ZP>
-__device__ __forceinline__ void load_unit(UnitRegs<BITS>& r, const MixedGemmArgs& p, int step, int ncol, int cp,
-                                          bool valid) {
-  constexpr int kWordRowsPerStep = kStepK * BITS / 32;
-  constexpr int kWpc = UnitRegs<BITS>::kWpc;
-  if (!valid) return;
-  const int64_t g = (step * kStepK) / p.group_size;
-#pragma unroll
-  for (int c = 0; c < 2; ++c)
-#pragma unroll
-    for (int i = 0; i < kWpc; ++i) {
-      const int64_t row = (int64_t)step * kWordRowsPerStep + (cp + 4 * c) * kWpc + i;
-      r.w[c][i] = (uint32_t)p.w_q[row * p.wq_stride_k + ncol];
-    }
-  r.scale = ((const uint16_t*)p.w_s)[g * p.ws_stride_g + ncol];
-  if constexpr (ZP == CONCH_ZP_TENSOR) r.zp = p.w_zp[g * p.wzp_stride_g + ncol];
-  else r.zp = 0;
-}
-
-template <int X_DT, int BITS, int KIND>
-__device__ __forceinline__ void convert_unit(const UnitRegs<BITS>& r, char* lds, int buf, int row_off, int swz, int cp,
-                                             int off_base, bool valid) {
-  if (!valid) return;
-#pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    const uint32_t w1 = UnitRegs<BITS>::kWpc == 2 ? r.w[c][UnitRegs<BITS>::kWpc - 1] : 0u;
-    const i32x4 v = dequant_chunk<X_DT, BITS>(r.w[c][0], w1, off_base + r.zp, r.scale);
-    *(i32x4*)(lds + buf + KIND * kUnitBytes + row_off + (((cp + 4 * c) ^ swz) * 16)) = v;
-  }
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vm() {
-  if constexpr (N >= 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-struct MixedCtx {
-  int wave, wr, m_base, n_base;
-  StageOffsets so;
-  Srcs src;
-  int n1, n2, cp, w_row_off, w_swz, off_base;
-  bool v2_valid;
-};
-
-template <int X_DT, int PHASE, int NT>
-__device__ __forceinline__ void mixed_reads(MixedTile& w, const char* lds, int buf, int m_base, int n_base) {
-  if constexpr (PHASE == 0) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t) w.fn[0][t] = read_frag(lds, buf + kV1 * kUnitBytes + n_base + t * 2048);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) w.fm[i] = read_frag(lds, buf + kU1 * kUnitBytes + m_base + i * 2048);
-  } else if constexpr (PHASE == 1) {
-#pragma unroll
-    for (int t = 0; t < NT - 2; ++t) w.fn[1][t] = read_frag(lds, buf + kV2 * kUnitBytes + n_base + t * 2048);
-  } else if constexpr (PHASE == 2) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) w.fm[i] = read_frag(lds, buf + kU2 * kUnitBytes + m_base + i * 2048);
-  }
-}
-
-template <int X_DT, int PHASE, int NT>
-__device__ __forceinline__ void mixed_cluster(MixedTile& w) {
-  constexpr int MH = (PHASE >= 2) ? 1 : 0;
-  constexpr int NH = (PHASE == 1 || PHASE == 2) ? 1 : 0;
-  constexpr int CNT = NH == 0 ? 2 : NT - 2;
-  __builtin_amdgcn_sched_barrier(0);
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
-  __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int t = 0; t < CNT; ++t) mma16<X_DT>(w.acc[MH * 4 + i][NH * 2 + t], w.fn[NH][t], w.fm[i]);
-  __builtin_amdgcn_s_setprio(0);
-  // this wave's ds_writes (dequantised weights) must have landed before the barrier that publishes them
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
-}
-
-// MODE 0: steady (steps t+1 and t+2 exist); 1: penultimate (t+1 exists); 2: last.
-template <int X_DT, int BITS, int ZP, int NT, int MODE>
-__device__ __forceinline__ void mixed_pp_step(MixedTile& w, UnitRegs<BITS>& rv1, UnitRegs<BITS>& rv2, char* lds,
-                                              const MixedGemmArgs& p, const MixedCtx& c, int t) {
-  constexpr int NV1 = unit_vmem_ops<BITS, ZP>();
-  constexpr int NV2 = NT == 2 ? 0 : NV1;
-  constexpr int kSteadyVm = 4 + NV1 + NV2;
-  constexpr bool NEXT = MODE <= 1;    // K step t+1 exists
-  constexpr bool NEXT2 = MODE == 0;   // K step t+2 exists
-  const int buf = (t & 1) * kBufBytes, nbuf = ((t + 1) & 1) * kBufBytes;
-  // ---- phase 0: reads V1,U1; issue V2(t+1) words
-  mixed_reads<X_DT, 0, NT>(w, lds, buf, c.m_base, c.n_base);
-  if constexpr (NEXT && NT > 2) load_unit<BITS, ZP>(rv2, p, t + 1, c.n2, c.cp, c.v2_valid);
-  wait_vm<MODE <= 1 ? kSteadyVm : 2>();
-  mixed_cluster<X_DT, 0, NT>(w);
-  // ---- phase 1: reads V2; issue U2(t+1) DMA
-  mixed_reads<X_DT, 1, NT>(w, lds, buf, c.m_base, c.n_base);
-  if constexpr (NEXT) stage_unit<kU2>(lds, c.src, c.so, c.wave, t + 1);
-  wait_vm<MODE <= 1 ? kSteadyVm : 0>();
-  mixed_cluster<X_DT, 1, NT>(w);
-  // ---- phase 2: reads U2; issue U1(t+2) DMA; dequantise V1(t+1) (loaded three phases ago)
-  mixed_reads<X_DT, 2, NT>(w, lds, buf, c.m_base, c.n_base);
-  if constexpr (NEXT2) stage_unit<kU1>(lds, c.src, c.so, c.wave, t + 2);
-  if constexpr (NEXT) convert_unit<X_DT, BITS, kV1>(rv1, lds, nbuf, c.w_row_off, c.w_swz, c.cp, c.off_base, true);
-  wait_vm<MODE == 0 ? kSteadyVm : (MODE == 1 ? NV1 + NV2 + 2 : -1)>();
-  mixed_cluster<X_DT, 2, NT>(w);
-  // ---- phase 3: issue V1(t+2) words; dequantise V2(t+1)
-  if constexpr (NEXT && NT > 2) convert_unit<X_DT, BITS, kV2>(rv2, lds, nbuf, c.w_row_off, c.w_swz, c.cp, c.off_base, c.v2_valid);
-  if constexpr (NEXT2) load_unit<BITS, ZP>(rv1, p, t + 2, c.n1, c.cp, true);
-  wait_vm<MODE == 0 ? kSteadyVm : (MODE == 1 ? NV2 + 2 : -1)>();
-  mixed_cluster<X_DT, 3, NT>(w);
-}
 
 template <int X_DT, int OUT_DT, int NT>
 __device__ __forceinline__ void mixed_epilogue(const MixedTile& w, const MixedGemmArgs& p, int bm0, int bn0, int wr,
@@ -466,37 +85,348 @@ __device__ __forceinline__ void mixed_epilogue(const MixedTile& w, const MixedGe
   }
 }
 
+// Weight words, scales and zero points of one thread for one K step.
+template <int BITS, int NT>
+struct WeightRegs {
+  static constexpr int kWpc = BITS == 4 ? 1 : 2;
+  uint32_t w[NT][kWpc];  // items 0,1: V1 chunks cp, cp+4; items 2..: V2
+  uint32_t scale[2];
+  int zp[2];
+};
+
+struct WeightLane {  // per-lane constants
+  int vq[4];         // byte offset of each item's first word in w_q, less the wave-uniform (step, cp) part
+  int vs[2];         // byte offsets of the lane's V1 / V2 column in a row of w_s
+  int vz[2];         // ... of w_zp
+  int lds[4];        // byte offset, inside a weight buffer, of each item's 16-byte destination
+};
+
+struct WeightSrc {   // wave-uniform
+  __amdgpu_buffer_rsrc_t q, s, z;
+  int q_row;         // bytes per word row of w_q
+  int q_step;        // bytes per K step of w_q
+  int s_group;       // bytes per group row of w_s
+  int z_group;       // bytes per group row of w_zp
+  int steps_per_group;
+};
+
+struct WeightCursor {  // wave-uniform position of the NEXT weight load
+  int q, s, z, left;
+};
+
+__device__ __forceinline__ void advance(WeightCursor& c, const WeightSrc& u) {
+  const bool wrap = c.left == 1;
+  c.q += u.q_step;
+  c.left = wrap ? u.steps_per_group : c.left - 1;
+  c.s += wrap ? u.s_group : 0;
+  c.z += wrap ? u.z_group : 0;
+}
+
+template <int BITS, int ZP, int NT>
+__device__ __forceinline__ void load_weights(WeightRegs<BITS, NT>& r, const WeightLane& ln, const WeightSrc& u, const WeightCursor& c) {
+  constexpr int kWpc = WeightRegs<BITS, NT>::kWpc;
+#pragma unroll
+  for (int it = 0; it < NT; ++it)
+#pragma unroll
+    for (int i = 0; i < kWpc; ++i) r.w[it][i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(u.q, ln.vq[it], c.q + i * u.q_row, 0);
+#pragma unroll
+  for (int un = 0; un < (NT > 2 ? 2 : 1); ++un) {
+    r.scale[un] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(u.s, ln.vs[un], c.s, 0);
+    if constexpr (ZP == CONCH_ZP_TENSOR) r.zp[un] = (int)__builtin_amdgcn_raw_buffer_load_b32(u.z, ln.vz[un], c.z, 0);
+    else r.zp[un] = 0;
+  }
+}
+
+template <int X_DT, int BITS>
+struct ChunkDequant {
+  static constexpr bool kHalf = X_DT == CONCH_DT_FP16;
+  static constexpr int kSlices = kHalf ? 10 : 12;  // the last one is the ds_write_b128
+  uint32_t w0, w1, sub, sc;
+  uint32_t a, b, c, d;
+  float fa[2], fb[2], fc[2], fd[2], fs;
+  i32x4 out;
+
+  static __device__ __forceinline__ uint32_t pk_sub(uint32_t v, uint32_t s) {
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(f16x2, v) - __builtin_bit_cast(f16x2, s));
+  }
+  static __device__ __forceinline__ uint32_t pk_mul(uint32_t v, uint32_t s) {
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(f16x2, v) * __builtin_bit_cast(f16x2, s));
+  }
+  static __device__ __forceinline__ void widen(uint32_t v, float (&f)[2]) {
+    const f16x2 h = __builtin_bit_cast(f16x2, v);
+    f[0] = (float)h[0];
+    f[1] = (float)h[1];
+  }
+  static __device__ __forceinline__ int pack_bf16(float lo, float hi) {
+    return (int)((uint32_t)float_to_bf16_bits(lo) | ((uint32_t)float_to_bf16_bits(hi) << 16));
+  }
+  // output dword j of the chunk is the pair (k 2j, k 2j+1)
+  static constexpr int kOutLoP = 0, kOutHiP = BITS == 4 ? 2 : 1, kOutLoQ = BITS == 4 ? 1 : 2, kOutHiQ = 3;
+
+  __device__ __forceinline__ void slice(int s, uint32_t word0, uint32_t word1, int off, uint32_t scale_bits, char* dst) {
+    constexpr uint32_t kMagic = 0x64006400u;
+    constexpr uint32_t kLowHalves = 0x05040100u, kHighHalves = 0x07060302u;
+    constexpr uint32_t kMask = BITS == 4 ? 0x000f000fu : 0x00ff00ffu;
+    constexpr int kShift = BITS == 4 ? 4 : 8;
+    if (s == 0) {
+      w0 = word0;
+      w1 = BITS == 4 ? (word0 >> 8) : word1;
+      const uint32_t sub1 = (uint32_t)float_to_half_bits((float)(1024 + off));
+      sub = sub1 | (sub1 << 16);
+      if constexpr (kHalf) sc = scale_bits | (scale_bits << 16);
+      else fs = bf16_bits_to_float((uint16_t)scale_bits);
+    } else if (s == 1) {
+      a = (w0 & kMask) | kMagic;
+      b = ((w0 >> kShift) & kMask) | kMagic;
+    } else if (s == 2) {
+      c = (w1 & kMask) | kMagic;
+      d = ((w1 >> kShift) & kMask) | kMagic;
+    } else if (s == 3) {
+      a = pk_sub(a, sub);
+      b = pk_sub(b, sub);
+    } else if (s == 4) {
+      c = pk_sub(c, sub);
+      d = pk_sub(d, sub);
+    } else if constexpr (kHalf) {
+      if (s == 5) {
+        a = pk_mul(a, sc);
+        b = pk_mul(b, sc);
+      } else if (s == 6) {
+        c = pk_mul(c, sc);
+        d = pk_mul(d, sc);
+      } else if (s == 7) {
+        out[kOutLoP] = (int)__builtin_amdgcn_perm(b, a, kLowHalves);
+        out[kOutHiP] = (int)__builtin_amdgcn_perm(b, a, kHighHalves);
+      } else if (s == 8) {
+        out[kOutLoQ] = (int)__builtin_amdgcn_perm(d, c, kLowHalves);
+        out[kOutHiQ] = (int)__builtin_amdgcn_perm(d, c, kHighHalves);
+      } else if (s == 9) {
+        *(i32x4*)dst = out;
+      }
+    } else {
+      if (s == 5) {
+        widen(a, fa);
+        widen(b, fb);
+      } else if (s == 6) {
+        widen(c, fc);
+        widen(d, fd);
+      } else if (s == 7) {
+        fa[0] *= fs; fa[1] *= fs; fb[0] *= fs; fb[1] *= fs;
+      } else if (s == 8) {
+        fc[0] *= fs; fc[1] *= fs; fd[0] *= fs; fd[1] *= fs;
+      } else if (s == 9) {
+        out[kOutLoP] = pack_bf16(fa[0], fb[0]);
+        out[kOutHiP] = pack_bf16(fa[1], fb[1]);
+      } else if (s == 10) {
+        out[kOutLoQ] = pack_bf16(fc[0], fd[0]);
+        out[kOutHiQ] = pack_bf16(fc[1], fd[1]);
+      } else if (s == 11) {
+        *(i32x4*)dst = out;
+      }
+    }
+  }
+};
+
+template <int X_DT>
+__device__ __forceinline__ void mma1(f32x4& acc, const Frag& fa, const Frag& fb, int h) {
+  const i32x4 a = h == 0 ? fa.lo : fa.hi, b = h == 0 ? fb.lo : fb.hi;
+  if constexpr (X_DT == CONCH_DT_FP16) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+  else acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+
+// LDS layout of the interleaved form (160 KiB): a ring of THREE X stages (U1 + U2 = 32 KiB each) and two weight
+// buffers (V1 + V2 = 32 KiB each).  X of step t+2 is requested during step t, so an LDS-DMA piece has two full
+// steps to land; the weights of step t+2 are loaded to registers during step t, dequantised during step t+1.
+// LDS: two stages, each X (U1 + U2 = 32 KiB) followed by the dequantised weights (V1 + V2 = 32 KiB).
+constexpr int kXBytes = 2 * kUnitBytes;
+constexpr int kStageBytes = 2 * kXBytes;
+constexpr int kMixedLdsBytes = 2 * kStageBytes;  // 128 KiB
+
+template <int UNIT2, int J>
+__device__ __forceinline__ void stage_x_piece(char* lds, const Srcs& src, const StageOffsets& so, int wave, int tile) {
+  char* dst = lds + (tile & 1) * kStageBytes + UNIT2 * kUnitBytes + wave * 2048 + J * 1024;
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(src.a, (lds_void_t*)dst, 16, so.off[UNIT2 ? kU2 : kU1][J], tile * kStepBytes, 0, 0);
+}
+
+struct LoopCtx {
+  Srcs src;
+  StageOffsets so;
+  WeightLane ln;
+  WeightSrc ws;
+  int wave, m_base, n_base, off_base;
+};
+
+// One K step.  MODE 0: steps t+1 and t+2 exist; 1: t+1 exists; 2: last step.  ISSUE = the slot at which this
+// wave starts issuing the step's VMEM work.
+template <int X_DT, int BITS, int ZP, int NT, int MODE, int ISSUE>
+__device__ __forceinline__ void mixed_step(MixedTile& w, WeightRegs<BITS, NT>& regs, char* lds, const LoopCtx& c, WeightCursor& cur, int t) {
+  constexpr int N1 = NT - 2;
+  constexpr int kWpc = WeightRegs<BITS, NT>::kWpc;
+  constexpr int kSlices = ChunkDequant<X_DT, BITS>::kSlices;
+  static_assert(kSlices <= 16, "more slices per chunk than MFMA slots per chunk");
+  // everything this wave staged for step t (LDS-DMA, ds_write) and loaded for step t+1 is complete ...
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // ... and every wave is done reading the other stage
+  const int ubuf = (t & 1) * kStageBytes, vbuf = ubuf + kXBytes;
+  const int vnext = ((t + 1) & 1) * kStageBytes + kXBytes;
+  // phase-0 fragment reads first: their LDS latency passes under the first slots
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) w.fn[0][tt] = read_frag(lds, vbuf + c.n_base + tt * 2048);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w.fm[i] = read_frag(lds, ubuf + c.m_base + i * 2048);
+  __builtin_amdgcn_sched_barrier(0);
+  WeightRegs<BITS, NT> next;
+
+  ChunkDequant<X_DT, BITS> cv[NT];
+  int slot = 0;  // a constant in every unrolled copy
+  auto tail = [&](int sl) {
+    // the step's VMEM work from slot ISSUE on: one per slot the four LDS-DMA pieces of X of step t+1, then the
+    // packed words / scales / zero points of step t+2
+    if constexpr (MODE <= 1) {
+      if (sl == ISSUE + 0) stage_x_piece<0, 0>(lds, c.src, c.so, c.wave, t + 1);
+      if (sl == ISSUE + 1) stage_x_piece<0, 1>(lds, c.src, c.so, c.wave, t + 1);
+      if (sl == ISSUE + 2) stage_x_piece<1, 0>(lds, c.src, c.so, c.wave, t + 1);
+      if (sl == ISSUE + 3) stage_x_piece<1, 1>(lds, c.src, c.so, c.wave, t + 1);
+    }
+    if constexpr (MODE == 0) {
+      if (sl == ISSUE + 4) {
+        load_weights<BITS, ZP, NT>(next, c.ln, c.ws, cur);
+        advance(cur, c.ws);
+      }
+    }
+    if constexpr (MODE <= 1) {
+      const int it = sl / kSlices, sub = sl % kSlices;
+      if (it < NT) {
+        const int un = it < 2 ? 0 : 1;
+        cv[it].slice(sub, regs.w[it][0], regs.w[it][kWpc - 1], c.off_base + regs.zp[un], regs.scale[un], lds + vnext + c.ln.lds[it]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // phase 0: (m rows 0-63 of the wave) x (n tiles 0,1); the V2 fragments of phase 1 -- or, for the narrowest
+  // tile, the U2 fragments -- are fetched underneath
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        mma1<X_DT>(w.acc[i][tt], w.fn[0][tt], w.fm[i], h);
+        const int idx = (i * 2 + tt) * 2 + h;
+        if constexpr (N1 > 0) {
+          if (idx >= 2 && idx < 2 + N1) w.fn[1][idx - 2] = read_frag(lds, vbuf + kUnitBytes + c.n_base + (idx - 2) * 2048);
+        } else {
+          if (idx % 4 == 3) w.fm[i] = read_frag(lds, ubuf + kUnitBytes + c.m_base + i * 2048);
+        }
+        tail(slot++);
+      }
+  // phase 1: same m rows x n tiles 2..; each U1 fragment is replaced by its U2 counterpart after its last use
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int tt = 0; tt < N1; ++tt)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        mma1<X_DT>(w.acc[i][2 + tt], w.fn[1][tt], w.fm[i], h);
+        if (tt == N1 - 1 && h == 1) w.fm[i] = read_frag(lds, ubuf + kUnitBytes + c.m_base + i * 2048);
+        tail(slot++);
+      }
+  // phase 2: m rows 64-127 x n tiles 2..
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int tt = 0; tt < N1; ++tt)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        mma1<X_DT>(w.acc[4 + i][2 + tt], w.fn[1][tt], w.fm[i], h);
+        tail(slot++);
+      }
+  // phase 3: m rows 64-127 x n tiles 0,1
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        mma1<X_DT>(w.acc[4 + i][tt], w.fn[0][tt], w.fm[i], h);
+        tail(slot++);
+      }
+  if constexpr (MODE == 0) regs = next;
+}
+
+template <int X_DT, int BITS, int ZP, int NT, int ISSUE>
+__device__ __forceinline__ void mixed_mainloop(MixedTile& w, WeightRegs<BITS, NT>& regs, char* lds, const LoopCtx& c, WeightCursor& cur, int steps) {
+  int t = 0;
+  for (; t + 2 < steps; ++t) mixed_step<X_DT, BITS, ZP, NT, 0, ISSUE>(w, regs, lds, c, cur, t);
+  if (steps > 1) {
+    mixed_step<X_DT, BITS, ZP, NT, 1, ISSUE>(w, regs, lds, c, cur, t);
+    ++t;
+  }
+  mixed_step<X_DT, BITS, ZP, NT, 2, ISSUE>(w, regs, lds, c, cur, t);
+}
+
 template <int X_DT, int OUT_DT, int BITS, int ZP, int NT>
-__global__ __launch_bounds__(kThreads, 2) void mixed_gemm_pp_kernel(MixedGemmArgs p) {
+__global__ __launch_bounds__(kThreads, 2) void mixed_gemm_kernel(MixedGemmArgs p) {
   constexpr int kTileW = 64 * NT;
-  constexpr int NV1 = unit_vmem_ops<BITS, ZP>();
-  __shared__ __attribute__((aligned(1024))) char lds[kLdsBytes];
-  MixedCtx c;
+  constexpr int kWpc = WeightRegs<BITS, NT>::kWpc;
+  constexpr int kWordRowsPerStep = kStepK * BITS / 32;
+  __shared__ __attribute__((aligned(1024))) char lds[kMixedLdsBytes];
+  LoopCtx c;
   c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  c.wr = c.wave >> 2;
-  const int wc = c.wave & 3;
+  const int wr = c.wave >> 2, wc = c.wave & 3;
   const int tiles_m = ((int)p.m + kTileM - 1) / kTileM;
   const int tiles_n = ((int)p.n + kTileW - 1) / kTileW;
   const TileCoord tc = map_tile(blockIdx.x, tiles_m, tiles_n);
   const int bm0 = tc.tm * kTileM, bn0 = tc.tn * kTileW;
+
+  // activations: LDS-DMA units (byte strides: 2 bytes per element)
   c.so = make_stage_offsets(c.wave, lane, bm0, bn0, (int)p.m - 1, 0, (int)p.x_stride_m * 2, 0);
   c.src.a = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (uint32_t)(((p.m - 1) * p.x_stride_m + p.k) * 2), 0x00020000);
   c.src.b = c.src.a;
+
+  // weight work items of this thread: unit row rho of V1, chunks cp and cp + 4; V2: see the file header.
+  // Wave-column rho>>5 owns columns [16*NT*wc', 16*NT*(wc'+1)); a PAIR of MFMA tiles is interleaved (rows 4g+e of
+  // tile t <-> n = 8g+e+4t: a lane ends up with 8 consecutive n), a LONE third tile (NT == 3) is plain.
   const int rho = threadIdx.x & 127;
-  c.cp = threadIdx.x >> 7;
+  const int cp = c.wave >> 1;  // = threadIdx.x >> 7, wave-uniform
   const int r5 = rho & 31, r = r5 & 15, tq = r5 >> 4;
   const int wcol = (rho >> 5) * 16 * NT;
   const int pair = 8 * (r >> 2) + (r & 3) + 4 * tq;
-  c.n1 = min(bn0 + wcol + pair, (int)p.n - 1);
-  c.n2 = min(bn0 + wcol + 32 + (NT == 4 ? pair : r), (int)p.n - 1);
-  c.v2_valid = NT == 4 || (NT == 3 && tq == 0);
-  c.w_row_off = (rho >> 3) * 1024 + (rho & 7) * 128;
-  c.w_swz = (rho >> 1) & 7;
+  const int row2 = NT == 4 ? rho : (rho & ~16);
+  const int n1 = min(bn0 + wcol + pair, (int)p.n - 1);
+  const int n2 = min(bn0 + wcol + 32 + (NT == 4 ? pair : r), (int)p.n - 1);
+  {
+    const int row[4] = {rho, rho, row2, row2};
+    const int dchunk[4] = {0, 4, NT == 4 ? 0 : 4 * tq, 4};  // chunk - cp
+    const int ncol[4] = {n1, n1, n2, n2};
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int chunk = cp + dchunk[it];
+      c.ln.vq[it] = (dchunk[it] * kWpc * (int)p.wq_stride_k + ncol[it]) * 4;
+      c.ln.lds[it] = (it < 2 ? 0 : kUnitBytes) + (row[it] >> 3) * 1024 + (row[it] & 7) * 128 + ((chunk ^ ((row[it] >> 1) & 7)) * 16);
+    }
+    c.ln.vs[0] = n1 * 2; c.ln.vs[1] = n2 * 2;
+    c.ln.vz[0] = n1 * 4; c.ln.vz[1] = n2 * 4;
+  }
+  const int64_t word_rows = p.k * BITS / 32, groups = p.k / p.group_size;
+  c.ws.q = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_q, 0, (uint32_t)(((word_rows - 1) * p.wq_stride_k + p.n) * 4), 0x00020000);
+  c.ws.s = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_s, 0, (uint32_t)(((groups - 1) * p.ws_stride_g + p.n) * 2), 0x00020000);
+  c.ws.z = c.ws.s;
+  if constexpr (ZP == CONCH_ZP_TENSOR)
+    c.ws.z = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_zp, 0, (uint32_t)(((groups - 1) * p.wzp_stride_g + p.n) * 4), 0x00020000);
+  c.ws.q_row = (int)p.wq_stride_k * 4;
+  c.ws.q_step = kWordRowsPerStep * c.ws.q_row;
+  c.ws.s_group = (int)p.ws_stride_g * 2;
+  c.ws.z_group = (int)p.wzp_stride_g * 4;
+  c.ws.steps_per_group = p.group_size / kStepK;
+  WeightCursor cur = {cp * kWpc * c.ws.q_row, 0, 0, c.ws.steps_per_group};
   c.off_base = p.weight_bias + (ZP == CONCH_ZP_SCALAR ? p.w_zp[0] : 0);
+
+  // fragment read offsets
   const int fr = lane & 15, fg = lane >> 4;
   const int lane_off = (fr >> 3) * 1024 + (fr & 7) * 128 + ((fg ^ ((fr >> 1) & 7)) * 16);
-  c.m_base = (c.wr * 8) * 1024 + lane_off;
+  c.m_base = (wr * 8) * 1024 + lane_off;
   c.n_base = (wc * 4) * 1024 + lane_off;
 
   MixedTile w;
@@ -504,51 +434,40 @@ __global__ __launch_bounds__(kThreads, 2) void mixed_gemm_pp_kernel(MixedGemmArg
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) w.acc[i][j] = f32x4{0, 0, 0, 0};
-  const int steps = (int)(p.k / kStepK);  // >= 2 (dispatcher)
-  UnitRegs<BITS> rv1, rv2;
 
-  // prologue: units 0..5 = U1,V1,V2,U2 of step 0 (weights dequantised here) and U1, V1-words of step 1
-  stage_unit<kU1>(lds, c.src, c.so, c.wave, 0);
-  stage_unit<kU2>(lds, c.src, c.so, c.wave, 0);
-  load_unit<BITS, ZP>(rv1, p, 0, c.n1, c.cp, true);
-  if constexpr (NT > 2) load_unit<BITS, ZP>(rv2, p, 0, c.n2, c.cp, c.v2_valid);
-  stage_unit<kU1>(lds, c.src, c.so, c.wave, 1);
-  convert_unit<X_DT, BITS, kV1>(rv1, lds, 0, c.w_row_off, c.w_swz, c.cp, c.off_base, true);
-  if constexpr (NT > 2) convert_unit<X_DT, BITS, kV2>(rv2, lds, 0, c.w_row_off, c.w_swz, c.cp, c.off_base, c.v2_valid);
-  load_unit<BITS, ZP>(rv1, p, 1, c.n1, c.cp, true);
-  wait_vm<NV1>();  // everything but the step-1 weight words (the youngest NV1 ops) has landed
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  if (c.wr == 1) __builtin_amdgcn_s_barrier();  // stagger the second wave of every SIMD
+  const int steps = (int)(p.k / kStepK);
+  WeightRegs<BITS, NT> regs;
+  // prologue: X and weights of step 0 (converted at once), weights of step 1 to registers
+  stage_x_piece<0, 0>(lds, c.src, c.so, c.wave, 0);
+  stage_x_piece<0, 1>(lds, c.src, c.so, c.wave, 0);
+  stage_x_piece<1, 0>(lds, c.src, c.so, c.wave, 0);
+  stage_x_piece<1, 1>(lds, c.src, c.so, c.wave, 0);
+  load_weights<BITS, ZP, NT>(regs, c.ln, c.ws, cur);
+  advance(cur, c.ws);
+#pragma unroll
+  for (int it = 0; it < NT; ++it) {
+    ChunkDequant<X_DT, BITS> cv;
+#pragma unroll
+    for (int sl = 0; sl < ChunkDequant<X_DT, BITS>::kSlices; ++sl)
+      cv.slice(sl, regs.w[it][0], regs.w[it][kWpc - 1], c.off_base + regs.zp[it < 2 ? 0 : 1], regs.scale[it < 2 ? 0 : 1], lds + kXBytes + c.ln.lds[it]);
+  }
+  if (steps > 1) {
+    load_weights<BITS, ZP, NT>(regs, c.ln, c.ws, cur);
+    advance(cur, c.ws);
+  }
 
-  int t = 0;
-  for (; t + 2 < steps; ++t) mixed_pp_step<X_DT, BITS, ZP, NT, 0>(w, rv1, rv2, lds, p, c, t);
-  mixed_pp_step<X_DT, BITS, ZP, NT, 1>(w, rv1, rv2, lds, p, c, t);
-  mixed_pp_step<X_DT, BITS, ZP, NT, 2>(w, rv1, rv2, lds, p, c, t + 1);
-  if (c.wr == 0) __builtin_amdgcn_s_barrier();  // re-balance the barrier count
+  // The two waves of a SIMD (w and w + 4) issue their VMEM work at different places of the step.
+  if (wr == 0) mixed_mainloop<X_DT, BITS, ZP, NT, 0>(w, regs, lds, c, cur, steps);
+  else mixed_mainloop<X_DT, BITS, ZP, NT, 4 * NT>(w, regs, lds, c, cur, steps);
 
-  mixed_epilogue<X_DT, OUT_DT, NT>(w, p, bm0, bn0, c.wr, wc, lane);
+  mixed_epilogue<X_DT, OUT_DT, NT>(w, p, bm0, bn0, wr, wc, lane);
 }
 
 template <int X_DT, int OUT_DT, int BITS, int NT>
-int launch_zp(const MixedGemmArgs& p, bool pingpong, hipStream_t stream) {
+int launch_zp(const MixedGemmArgs& p, hipStream_t stream) {
   const int tiles_m = (int)((p.m + kTileM - 1) / kTileM);
   const int tiles_n = (int)((p.n + 64 * NT - 1) / (64 * NT));
   const dim3 grid((unsigned)(tiles_m * tiles_n));
-  if (pingpong) {
-    switch (p.zp_mode) {
-      case CONCH_ZP_NONE:
-        hipLaunchKernelGGL((mixed_gemm_pp_kernel<X_DT, OUT_DT, BITS, CONCH_ZP_NONE, NT>), grid, dim3(kThreads), 0, stream, p);
-        break;
-      case CONCH_ZP_SCALAR:
-        hipLaunchKernelGGL((mixed_gemm_pp_kernel<X_DT, OUT_DT, BITS, CONCH_ZP_SCALAR, NT>), grid, dim3(kThreads), 0, stream, p);
-        break;
-      default:
-        hipLaunchKernelGGL((mixed_gemm_pp_kernel<X_DT, OUT_DT, BITS, CONCH_ZP_TENSOR, NT>), grid, dim3(kThreads), 0, stream, p);
-        break;
-    }
-    return check_launch("mixed_gemm_pingpong");
-  }
   switch (p.zp_mode) {
     case CONCH_ZP_NONE:
       hipLaunchKernelGGL((mixed_gemm_kernel<X_DT, OUT_DT, BITS, CONCH_ZP_NONE, NT>), grid, dim3(kThreads), 0, stream, p);
@@ -583,15 +502,15 @@ int pick_nt(const MixedGemmArgs& p, int num_cus) {
 }
 
 template <int X_DT, int OUT_DT, int BITS>
-int launch_nt(const MixedGemmArgs& p, int nt, bool pp, hipStream_t stream) {
-  if (nt == 3) return launch_zp<X_DT, OUT_DT, BITS, 3>(p, pp, stream);
-  if (nt == 2) return launch_zp<X_DT, OUT_DT, BITS, 2>(p, pp, stream);
-  return launch_zp<X_DT, OUT_DT, BITS, 4>(p, pp, stream);
+int launch_nt(const MixedGemmArgs& p, int nt, hipStream_t stream) {
+  if (nt == 3) return launch_zp<X_DT, OUT_DT, BITS, 3>(p, stream);
+  if (nt == 2) return launch_zp<X_DT, OUT_DT, BITS, 2>(p, stream);
+  return launch_zp<X_DT, OUT_DT, BITS, 4>(p, stream);
 }
 
 template <int X_DT, int OUT_DT>
-int launch_bits(const MixedGemmArgs& p, int nt, bool pp, hipStream_t stream) {
-  return p.bits == 4 ? launch_nt<X_DT, OUT_DT, 4>(p, nt, pp, stream) : launch_nt<X_DT, OUT_DT, 8>(p, nt, pp, stream);
+int launch_bits(const MixedGemmArgs& p, int nt, hipStream_t stream) {
+  return p.bits == 4 ? launch_nt<X_DT, OUT_DT, 4>(p, nt, stream) : launch_nt<X_DT, OUT_DT, 8>(p, nt, stream);
 }
 
 }  // namespace
@@ -607,10 +526,14 @@ bool mixed_gemm_mfma_supported(const MixedGemmArgs& p) {
   const int64_t lim = (int64_t)1 << 31;
   if (p.m * p.x_stride_m * 2 >= lim) return false;
   if (p.m >= (1 << 24) || p.n >= (1 << 24)) return false;
+  // the weight arrays are addressed through 32-bit buffer offsets
+  const int64_t lim32 = (int64_t)1 << 32;
+  if (((p.k * p.bits / 32) * p.wq_stride_k + p.n) * 4 >= lim32 || ((p.k / p.group_size) * p.ws_stride_g + p.n) * 2 >= lim32) return false;
+  if (p.zp_mode == CONCH_ZP_TENSOR && ((p.k / p.group_size) * p.wzp_stride_g + p.n) * 4 >= lim32) return false;
   return true;
 }
 
-int launch_mixed_gemm_mfma(const MixedGemmArgs& p, int variant, hipStream_t stream) {
+int launch_mixed_gemm_mfma(const MixedGemmArgs& p, hipStream_t stream) {
   static int num_cus = 0;
   if (num_cus == 0) {
     int dev = 0;
@@ -620,15 +543,12 @@ int launch_mixed_gemm_mfma(const MixedGemmArgs& p, int variant, hipStream_t stre
   }
   const int forced = tuning(1);  // CONCH_TUNE_MIXED_TILE_NT: 0 = auto, 2..4 = force
   const int nt = (forced >= 2 && forced <= 4) ? forced : pick_nt(p, num_cus);
-  // auto = the plain one-barrier-per-K-step loop: measured equal or faster than the ping-pong form on
-  // every shape tried (C4 106 vs 113 us, README shape 252 vs 247 us); variant 3 forces ping-pong
-  const bool pp = variant == 3 && p.k >= 2 * kStepK;
   if (p.x_dtype == CONCH_DT_FP16) {
-    return p.out_dtype == CONCH_DT_FP16 ? launch_bits<CONCH_DT_FP16, CONCH_DT_FP16>(p, nt, pp, stream)
-                                        : launch_bits<CONCH_DT_FP16, CONCH_DT_BF16>(p, nt, pp, stream);
+    return p.out_dtype == CONCH_DT_FP16 ? launch_bits<CONCH_DT_FP16, CONCH_DT_FP16>(p, nt, stream)
+                                        : launch_bits<CONCH_DT_FP16, CONCH_DT_BF16>(p, nt, stream);
   }
-  return p.out_dtype == CONCH_DT_BF16 ? launch_bits<CONCH_DT_BF16, CONCH_DT_BF16>(p, nt, pp, stream)
-                                      : launch_bits<CONCH_DT_BF16, CONCH_DT_FP16>(p, nt, pp, stream);
+  return p.out_dtype == CONCH_DT_BF16 ? launch_bits<CONCH_DT_BF16, CONCH_DT_BF16>(p, nt, stream)
+                                      : launch_bits<CONCH_DT_BF16, CONCH_DT_FP16>(p, nt, stream);
 }
 
 }  // namespace conch

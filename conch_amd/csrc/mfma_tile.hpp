@@ -100,6 +100,16 @@ __device__ __forceinline__ void stage_unit(char* lds, const Srcs& src, const Sta
   }
 }
 
+// One of the two wave-instructions of stage_unit (J = 0 / 1), for loops that spread the issue over several slots.
+template <int KIND, int J>
+__device__ __forceinline__ void stage_piece(char* lds, const Srcs& src, const StageOffsets& so, int wave, int tile) {
+  char* dst = lds + (tile & 1) * kBufBytes + KIND * kUnitBytes + wave * 2048 + J * 1024;
+  if constexpr (KIND == kU1 || KIND == kU2)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(src.a, (lds_void_t*)dst, 16, so.off[KIND][J], tile * kStepBytes, 0, 0);
+  else
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(src.b, (lds_void_t*)dst, 16, so.off[KIND][J], tile * kStepBytes, 0, 0);
+}
+
 // `off` is a byte offset from the (1024-aligned) LDS base; every term of it except the chunk is a
 // multiple of 128, so chunk g+4 = (g ^ swizzle) ^ 4 is simply off ^ 64.
 __device__ __forceinline__ Frag read_frag(const char* lds, int off) {

@@ -302,13 +302,13 @@ def test_mixed_precision_gemm_golden_from_reference(golden, wname, zp, dname):
     check_mixed(got, a, from_bits(g[f"wref_{key}"], dtype), a.shape[1])
 
 
-@pytest.mark.parametrize("variant", ["auto", "pingpong"])
+@pytest.mark.parametrize("variant", ["auto"])
 @pytest.mark.parametrize("nt", [2, 3, 4])
 @pytest.mark.parametrize(("m", "k", "n"), [(300, 256, 520), (1024, 512, 1376), (64, 128, 200), (512, 64, 256)])
 @pytest.mark.parametrize(("wname", "use_zp", "dname"), [("uint4b8", False, "f16"), ("uint4", True, "bf16"),
                                                          ("uint8b128", True, "f16"), ("uint8", False, "bf16")])
 def test_mixed_precision_every_tile_width(variant, nt, m, k, n, wname, use_zp, dname):
-    """Both MFMA loop forms (plain loop = auto, ping-pong = variant 3) at each tile width (64*nt columns),
+    """The MFMA kernel at each tile width (64*nt columns),
     ragged M / N and the shortest K (one and two K steps) included."""
     wt = WTYPES[wname]
     group = 64 if k < 128 else 128
@@ -323,9 +323,11 @@ def test_mixed_precision_every_tile_width(variant, nt, m, k, n, wname, use_zp, d
     check_mixed(got, a, w_ref, k)
 
 
-def test_mixed_precision_dequant_is_bit_exact():
-    """X = identity isolates the dequantisation: C must equal w_ref bit-for-bit."""
+@pytest.mark.parametrize("variant", ["auto", "generic"])
+def test_mixed_precision_dequant_is_bit_exact(variant):
+    """X = identity isolates the dequantisation: C must equal w_ref bit-for-bit, MFMA and generic kernels."""
     k = n = 256
+    _C.set_gemm_variant(VARIANTS[variant])
     for dname in ("f16", "bf16"):
         for wname, wt in WTYPES.items():
             for use_zp in (False, True):

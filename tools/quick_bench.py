@@ -81,6 +81,21 @@ if __name__ == "__main__":
                 out.append(f"{ms*1e3:.1f}")
             print(f"variant {variant} ({time.time()-t0:.2f}s):", " ".join(out), flush=True)
         sys.exit(0)
+    if "--mixedab" in sys.argv:
+        # interleaved A/B of the mixed-GEMM loop forms: --mixedab 0,6
+        import statistics
+        variants = [int(v) for v in sys.argv[sys.argv.index("--mixedab") + 1].split(",")]
+        for (m, k, n) in [(1024, 4096, 11008), (4096, 8192, 4096), (2048, 4096, 11008), (256, 4096, 4096), (8192, 8192, 8192)]:
+            for _ in range(10):
+                time_mixed(m, k, n, torch.float16, 4, variants[0], iters=30)
+            for dtype, bits in ((torch.float16, 4), (torch.bfloat16, 4), (torch.float16, 8), (torch.bfloat16, 8)):
+                res = {v: [] for v in variants}
+                for _ in range(5):
+                    for v in variants:
+                        res[v].append(time_mixed(m, k, n, dtype, bits, v, iters=40))
+                print(f"mixed int{bits} {str(dtype)[6:]} {m}x{k}x{n}: " + "  ".join(
+                    f"v{v}: {statistics.median(t)*1e3:.1f}us ({2.0*m*n*k/(statistics.median(t)*1e-3)/1e12:.0f} TF)" for v, t in res.items()), flush=True)
+        sys.exit(0)
     if "--mixednt" in sys.argv:
         import statistics
         lib = _C.load()
