@@ -33,17 +33,26 @@ def _stale(target: Path, deps: list[Path]) -> bool:
     return any(d.stat().st_mtime > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> Path:
-    """Compile every HIP source for gfx950 and link the shared library.  Returns its path."""
+PROBE_LIB = PKG / "libconch_amd_probe.so"
+
+
+def build(force: bool = False, verbose: bool = False, probe: bool = False) -> Path:
+    """Compile every HIP source for gfx950 and link the shared library.  Returns its path.
+
+    `probe=True` builds the DIAGNOSTIC twin libconch_amd_probe.so (-DCONCH_CLOCK_PROBE: in-kernel clock stamps
+    around the GEMM K loops, read by tools/clock_probe.py); the product library never contains them.
+    """
     headers = sorted(CSRC.glob("*.hpp")) + [ROOT / "include" / "conch_amd.h", Path(__file__)]
-    objdir = PKG / "build"
+    objdir = PKG / ("build_probe" if probe else "build")
     objdir.mkdir(exist_ok=True)
+    flags = [*FLAGS, "-DCONCH_CLOCK_PROBE"] if probe else FLAGS
+    lib = PROBE_LIB if probe else LIB
 
     def compile_one(src: str) -> Path:
         s = CSRC / src
         o = objdir / (s.stem + ".o")
         if force or _stale(o, [s, *headers]):
-            cmd = [HIPCC, *FLAGS, "-c", str(s), "-o", str(o)]
+            cmd = [HIPCC, *flags, "-c", str(s), "-o", str(o)]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.run(cmd, check=True)
@@ -51,13 +60,13 @@ def build(force: bool = False, verbose: bool = False) -> Path:
 
     with ThreadPoolExecutor(max_workers=min(4, len(SOURCES))) as pool:
         objs = list(pool.map(compile_one, SOURCES))
-    if force or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]
+    if force or _stale(lib, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(lib), *map(str, objs)]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, probe="--probe" in sys.argv))

@@ -61,6 +61,30 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 
+#ifdef CONCH_CLOCK_PROBE
+// Diagnostic build only (tools/clock_probe.py builds a second library with -DCONCH_CLOCK_PROBE; the shipped
+// library contains none of this).  Thread 0 of a workgroup stamps the shader clock (s_memtime) and the constant
+// 100 MHz reference clock (s_memrealtime) at kernel entry (2), before (0) and after (1) the K loop and after the
+// epilogue (3) into a buffer nothing else reads:
+// in-kernel clock = d(memtime) / d(memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS item 6).
+constexpr int kProbeBlocks = 4096;
+__device__ __forceinline__ void probe_stamp(unsigned long long* slot) {
+  slot[0] = __builtin_amdgcn_s_memtime();
+  slot[1] = __builtin_amdgcn_s_memrealtime();
+}
+#define CONCH_PROBE(buf, which)                                                                    \
+  do {                                                                                             \
+    if (threadIdx.x == 0 && blockIdx.x < kProbeBlocks) probe_stamp(&(buf)[blockIdx.x * 8 + 2 * (which)]); \
+  } while (0)
+#define CONCH_PROBE_READER(fn, buf)                                                                \
+  extern "C" int fn(unsigned long long* out, int n_blocks) {                                       \
+    if (n_blocks > conch::kProbeBlocks) n_blocks = conch::kProbeBlocks;                            \
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(buf), sizeof(unsigned long long) * 8 * n_blocks); \
+  }
+#else
+#define CONCH_PROBE(buf, which) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // scalar conversions (device).  float -> half/bf16 are round-to-nearest-even, NaN preserving
 // (hipcc lowers the casts to v_cvt_f16_f32 / v_cvt_pk_bf16_f32 on gfx950).
@@ -87,6 +111,25 @@ __device__ __forceinline__ uint16_t float_to_bf16_bits(float f) {
 __device__ __forceinline__ float pin_f32(float v) {
   asm volatile("" : "+v"(v));
   return v;
+}
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x2 pin_f32x2(f32x2 v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
+// Two fp32 -> two fp16 / bf16 (RNE) in one dword, element 0 in the low half: v_cvt_pk_{f16,bf16}_f32 on gfx950.
+template <int DT>
+__device__ __forceinline__ uint32_t pack2_bits16(f32x2 v) {
+  if constexpr (DT == CONCH_DT_FP16) return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+  else return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+template <int DT>
+__device__ __forceinline__ f32x2 unpack2_bits16(uint32_t w) {
+  if constexpr (DT == CONCH_DT_FP16) return __builtin_convertvector(__builtin_bit_cast(f16x2, w), f32x2);
+  else return f32x2{bits_to_float(w << 16), bits_to_float(w & 0xffff0000u)};
 }
 
 template <int DT>

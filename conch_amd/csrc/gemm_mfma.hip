@@ -141,31 +141,31 @@ __device__ __forceinline__ void epilogue(const typename AccT<MMA>::type (&acc)[8
       const int ml = wr * 128 + mt * 16 + jm;
       const int m = bm0 + ml;
       const float sa = lsa[ml];
-      uint16_t o[8];
+      // two adjacent columns at a time: v_pk_mul_f32 x 2 and ONE packed convert per output dword, the same
+      // IEEE operations per element as the scalar form (fp32 product, fp32 product, RNE cast, bias in the output dtype)
+      i32x4 pk;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float accf = (float)acc[mt][nh * 2 + (e >> 2)][e & 3];
-        const float sbe = e < 4 ? sb_lo[e & 3] : sb_hi[e & 3];
-        float v = sa * accf;     // scaled_gemm.py:21
-        v = pin_f32(sbe * v);    // :22 (rounded to fp32 before the cast, like torch)
-        uint16_t h = float_to_bits16<OUT_DT>(v);  // :23
-        if (has_bias) {          // :24-25, added in the output dtype
-          const float be = e < 4 ? bs_lo[e & 3] : bs_hi[e & 3];
-          h = float_to_bits16<OUT_DT>(pin_f32(bits16_to_float<OUT_DT>(h) + be));
+      for (int e2 = 0; e2 < 4; ++e2) {
+        const int e = 2 * e2;
+        const f32x2 a2 = {(float)acc[mt][nh * 2 + (e >> 2)][e & 3], (float)acc[mt][nh * 2 + (e >> 2)][(e & 3) + 1]};
+        const f32x2 sb2 = e < 4 ? f32x2{sb_lo[e & 3], sb_lo[(e & 3) + 1]} : f32x2{sb_hi[e & 3], sb_hi[(e & 3) + 1]};
+        f32x2 v = f32x2{sa, sa} * a2;  // scaled_gemm.py:21
+        v = pin_f32x2(sb2 * v);        // :22 (rounded to fp32 before the cast, like torch)
+        uint32_t h = pack2_bits16<OUT_DT>(v);  // :23
+        if (has_bias) {                // :24-25, added in the output dtype
+          const f32x2 b2 = e < 4 ? f32x2{bs_lo[e & 3], bs_lo[(e & 3) + 1]} : f32x2{bs_hi[e & 3], bs_hi[(e & 3) + 1]};
+          h = pack2_bits16<OUT_DT>(pin_f32x2(unpack2_bits16<OUT_DT>(h) + b2));
         }
-        o[e] = h;
+        pk[e2] = (int)h;
       }
       if (m < p.m) {
         uint16_t* dst = (uint16_t*)p.c + (int64_t)m * p.c_stride_m + n0;
         if (vec_store && n0 + 8 <= p.n) {
-          i32x4 pk;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) pk[e] = (int)((uint32_t)o[2 * e] | ((uint32_t)o[2 * e + 1] << 16));
           *(i32x4*)dst = pk;
         } else {
 #pragma unroll
           for (int e = 0; e < 8; ++e)
-            if (n0 + e < p.n) dst[e] = o[e];
+            if (n0 + e < p.n) dst[e] = (uint16_t)((uint32_t)pk[e >> 1] >> (16 * (e & 1)));
         }
       }
     }
@@ -384,9 +384,14 @@ __device__ __forceinline__ void pp2_step(WaveTile<MMA>& w, char* lds, const Bloc
   pp2_cluster<MMA>(w, 1);
 }
 
+#ifdef CONCH_CLOCK_PROBE
+__device__ unsigned long long g_probe_scaled[kProbeBlocks * 8];
+#endif
+
 template <int MMA, int OUT_DT>
 __global__ __launch_bounds__(kThreads, 2) void scaled_gemm_pp2_kernel(ScaledGemmArgs p) {
   __shared__ __attribute__((aligned(1024))) char lds[kLdsTotal];
+  CONCH_PROBE(g_probe_scaled, 2);
   const BlockSetup s = setup_block(p);
   WaveTile<MMA> w;
   zero_acc<MMA>(w);
@@ -404,13 +409,16 @@ __global__ __launch_bounds__(kThreads, 2) void scaled_gemm_pp2_kernel(ScaledGemm
   __builtin_amdgcn_s_barrier();
   if (s.wr == 1) __builtin_amdgcn_s_barrier();  // stagger the second wave of every SIMD
 
+  CONCH_PROBE(g_probe_scaled, 0);
   int t = 0;
   for (; t + 2 < steps; ++t) pp2_step<MMA, 1, 1, 8, 6>(w, lds, s, t);
   pp2_step<MMA, 1, 0, 8, 2>(w, lds, s, t);
   pp2_step<MMA, 0, 0, 0, -1>(w, lds, s, t + 1);
+  CONCH_PROBE(g_probe_scaled, 1);
   if (s.wr == 0) __builtin_amdgcn_s_barrier();  // re-balance the barrier count
 
   epilogue<MMA, OUT_DT>(w.acc, p, lds, s.bm0, s.bn0, s.wr, s.wc, s.lane);
+  CONCH_PROBE(g_probe_scaled, 3);
 }
 
 }  // namespace
@@ -468,3 +476,7 @@ int launch_scaled_gemm_mfma_bf16(const ScaledGemmArgs& p, hipStream_t stream) {
 
 // mixed-precision MFMA kernels live in gemm_mixed.hip
 }  // namespace conch
+
+#ifdef CONCH_CLOCK_PROBE
+CONCH_PROBE_READER(conch_debug_probe_scaled, conch::g_probe_scaled)
+#endif

@@ -62,24 +62,22 @@ __device__ __forceinline__ void mixed_epilogue(const MixedTile& w, const MixedGe
     for (int mt = 0; mt < 8; ++mt) {
       const int m = bm0 + wr * 128 + mt * 16 + jm;
       if (m >= p.m) continue;
-      uint16_t o[8];
+      i32x4 pk;  // one packed convert per output dword
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = float_to_bits16<OUT_DT>(pin_f32(w.acc[mt][nh * 2 + (pair_h ? (e >> 2) : 0)][e & 3]));
+      for (int e2 = 0; e2 < 4; ++e2) {
+        const int e = 2 * e2;
+        const f32x4& a = w.acc[mt][nh * 2 + (pair_h ? (e >> 2) : 0)];
+        pk[e2] = (int)pack2_bits16<OUT_DT>(f32x2{a[e & 3], a[(e & 3) + 1]});
+      }
       uint16_t* dst = (uint16_t*)p.c + (int64_t)m * p.c_stride_m + n0;
       if (pair_h && vec_store && n0 + 8 <= p.n) {
-        i32x4 pk;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) pk[e] = (int)((uint32_t)o[2 * e] | ((uint32_t)o[2 * e + 1] << 16));
         *(i32x4*)dst = pk;
       } else if (!pair_h && vec_store && n0 + 4 <= p.n) {
-        i32x2 pk;
-        pk[0] = (int)((uint32_t)o[0] | ((uint32_t)o[1] << 16));
-        pk[1] = (int)((uint32_t)o[2] | ((uint32_t)o[3] << 16));
-        *(i32x2*)dst = pk;
+        *(i32x2*)dst = i32x2{pk[0], pk[1]};
       } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-          if (e < width && n0 + e < p.n) dst[e] = o[e];
+          if (e < width && n0 + e < p.n) dst[e] = (uint16_t)((uint32_t)pk[e >> 1] >> (16 * (e & 1)));
       }
     }
   }
@@ -365,6 +363,10 @@ __device__ __forceinline__ void mixed_mainloop(MixedTile& w, WeightRegs<BITS, NT
   mixed_step<X_DT, BITS, ZP, NT, 2, ISSUE>(w, regs, lds, c, cur, t);
 }
 
+#ifdef CONCH_CLOCK_PROBE
+__device__ unsigned long long g_probe_mixed[kProbeBlocks * 8];
+#endif
+
 template <int X_DT, int OUT_DT, int BITS, int ZP, int NT>
 __global__ __launch_bounds__(kThreads, 2) void mixed_gemm_kernel(MixedGemmArgs p) {
   constexpr int kTileW = 64 * NT;
@@ -457,8 +459,10 @@ __global__ __launch_bounds__(kThreads, 2) void mixed_gemm_kernel(MixedGemmArgs p
   }
 
   // The two waves of a SIMD (w and w + 4) issue their VMEM work at different places of the step.
+  CONCH_PROBE(g_probe_mixed, 0);
   if (wr == 0) mixed_mainloop<X_DT, BITS, ZP, NT, 0>(w, regs, lds, c, cur, steps);
   else mixed_mainloop<X_DT, BITS, ZP, NT, 4 * NT>(w, regs, lds, c, cur, steps);
+  CONCH_PROBE(g_probe_mixed, 1);
 
   mixed_epilogue<X_DT, OUT_DT, NT>(w, p, bm0, bn0, wr, wc, lane);
 }
@@ -552,3 +556,7 @@ int launch_mixed_gemm_mfma(const MixedGemmArgs& p, hipStream_t stream) {
 }
 
 }  // namespace conch
+
+#ifdef CONCH_CLOCK_PROBE
+CONCH_PROBE_READER(conch_debug_probe_mixed, conch::g_probe_mixed)
+#endif

@@ -1,0 +1,128 @@
+"""In-kernel clock of the GEMM K loops under sustained load (development aid; MI355X_MICROARCH.md DVFS item 6).
+
+Loads the DIAGNOSTIC twin of the library (`python -m conch_amd._build --probe`, built on the CPU side so that it
+travels to the GPU box), launches a workload back to back for a few seconds on random data and reads the
+s_memtime / s_memrealtime stamps thread 0 of every workgroup took around its K loop:
+    clock = d(memtime) / d(memrealtime) x 100 MHz,  loop time = d(memrealtime) / 100 MHz.
+Prints the median over workgroups, the K-loop share of the launch, and the MFMA-pipe occupancy of the loop at THAT
+clock (flops / (CUs x flops-per-clock-per-CU x clock x loop time)).
+
+usage: python tools/clock_probe.py [seconds]
+"""
+import ctypes
+import statistics
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+
+from conch_amd import _C, _build  # noqa: E402
+
+_C.LIB_PATH = _build.PROBE_LIB
+from conch_amd.kernels.quantization import gemm as kg  # noqa: E402
+from conch_amd.ops.quantization.gemm import create_mixed_precision_metadata, create_scaled_metadata  # noqa: E402
+
+SECONDS = float(sys.argv[1]) if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else 2.5
+N_CU = 256
+
+
+def read_probe(fn_name: str, blocks: int):
+    lib = _C.load()
+    fn = getattr(lib, fn_name)
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    blocks = min(blocks, 4096)
+    buf = (ctypes.c_ulonglong * (8 * blocks))()
+    rc = fn(buf, blocks)
+    assert rc == 0, rc
+    clocks, loops, spans = [], [], []
+    for b in range(blocks):
+        t0, r0, t1, r1, _, r_in, _, r_out = buf[8 * b:8 * b + 8]
+        if r1 > r0:
+            clocks.append((t1 - t0) / (r1 - r0) * 0.1)  # GHz
+            loops.append((r1 - r0) * 0.01)  # us
+            spans.append((r0, r1, r_in, r_out))
+    if "--timeline" in sys.argv and spans:
+        # K-loop start / end of the workgroups of the LAST launch, in start order, relative to the first start
+        spans.sort()
+        base = spans[0][0]
+        picks = sorted({0, len(spans) // 8, len(spans) // 4, 255, 256, 300, 400, 511, 512, 600, len(spans) - 1} & set(range(len(spans))))
+        print("    timeline (us since the first K loop started): " + "  ".join(
+            f"#{i}: {(spans[i][0] - base) * 0.01:.1f}-{(spans[i][1] - base) * 0.01:.1f}" for i in picks))
+        if spans[0][2]:
+            pro = statistics.median((s[0] - s[2]) * 0.01 for s in spans)
+            epi = statistics.median((s[3] - s[1]) * 0.01 for s in spans if s[3])
+            first_in = min(s[2] for s in spans)
+            print(f"    entry -> K loop (prologue) {pro:.2f} us median; K loop end -> epilogue stores issued {epi:.2f} us median; "
+                  f"first entry at {(first_in - base) * 0.01:.1f} us")
+            outs = sorted(s[3] for s in spans if s[3])
+            ins = sorted(s[2] for s in spans)
+            if len(ins) > 300:
+                print(f"    workgroup #256 enters {(ins[256] - outs[0]) * 0.01:.2f} us after the first workgroup left")
+        ends = sorted(s[1] for s in spans)
+        print(f"    last K loop ends at {(ends[-1] - base) * 0.01:.1f} us; starts span {(spans[-1][0] - base) * 0.01:.1f} us")
+    return statistics.median(clocks), statistics.median(loops), max(loops)
+
+
+def sustained(launch, seconds):
+    torch.cuda.synchronize()
+    t0 = time.time()
+    n = 0
+    while time.time() - t0 < seconds:
+        for _ in range(50):
+            launch()
+        n += 50
+        torch.cuda.synchronize()
+    return (time.time() - t0) / n * 1e6  # us per launch (host clock, includes launch gaps)
+
+
+def scaled_case(m, k, n, dtype, flops_per_clk_cu):
+    torch.manual_seed(0)
+    if dtype == torch.int8:
+        a = torch.randint(-32, 32, (m, k), dtype=torch.int8, device="cuda")
+        b = torch.randint(-32, 32, (n, k), dtype=torch.int8, device="cuda").T
+    else:
+        a = (0.25 * torch.rand((m, k), device="cuda")).to(dtype)
+        b = (0.25 * torch.rand((n, k), device="cuda")).to(dtype).T
+    sa = 0.25 * torch.rand((m, 1), device="cuda")
+    sb = 0.25 * torch.rand((n, 1), device="cuda")
+    out = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
+    md = create_scaled_metadata(a, b, sa, sb, out.dtype)
+    us = sustained(lambda: kg.scaled_gemm_launcher(out, a, b, sa, sb, md), SECONDS)
+    tiles = -(-m // 256) * -(-n // 256)
+    ghz, loop_us, loop_max = read_probe("conch_debug_probe_scaled", tiles)
+    rounds = -(-tiles // N_CU)
+    # per-workgroup occupancy of its CU's matrix pipes during its own K loop
+    occ = (2.0 * 256 * 256 * k) / (flops_per_clk_cu * ghz * 1e9 * loop_us * 1e-6)
+    print(f"scaled {str(dtype)[6:]:14s} {m}x{k}x{n}: {us:7.1f} us/launch  clock {ghz:.2f} GHz  K loop {loop_us:.1f} us median "
+          f"({loop_max:.1f} max) x {rounds} rounds  pipe occupancy in the loop {occ * 100:.0f} %  "
+          f"({2.0 * m * n * k / us / 1e6:.0f} TFLOP/s)", flush=True)
+
+
+def mixed_case(m, k, n, dtype, bits):
+    torch.manual_seed(0)
+    x = (10 * (torch.rand((m, k), device="cuda") - 0.3)).to(dtype)
+    pf = 32 // bits
+    wq = torch.randint(-2**31, 2**31 - 1, (k // pf, n), dtype=torch.int32, device="cuda")
+    ws = (0.1 * torch.rand((k // 128, n), device="cuda") + 0.01).to(dtype)
+    out = torch.empty((m, n), dtype=dtype, device="cuda")
+    md = create_mixed_precision_metadata(x, wq, ws, None, bits, 8 if bits == 4 else 128, 128)
+    us = sustained(lambda: kg.mixed_precision_gemm_launcher(out, x, wq, ws, None, md), SECONDS)
+    nt = _C.load().conch_get_tuning(1) or None
+    ghz, loop_us, loop_max = read_probe("conch_debug_probe_mixed", 4096)
+    print(f"mixed int{bits} {str(dtype)[6:]:9s} {m}x{k}x{n}: {us:7.1f} us/launch  clock {ghz:.2f} GHz  K loop {loop_us:.1f} us median "
+          f"({loop_max:.1f} max)  ({2.0 * m * n * k / us / 1e6:.0f} TFLOP/s)", flush=True)
+
+
+if __name__ == "__main__":
+    # dense peak per CU per clock: 5e15 / 256 / 2.4e9 (fp8, int8), half that for fp16 / bf16
+    scaled_case(4096, 4096, 11008, torch.float8_e4m3fn, 8138.0)
+    scaled_case(8192, 8192, 8192, torch.float8_e4m3fn, 8138.0)
+    scaled_case(4096, 4096, 11008, torch.int8, 8138.0)
+    mixed_case(1024, 4096, 11008, torch.float16, 4)
+    mixed_case(4096, 8192, 4096, torch.float16, 4)
+    mixed_case(8192, 8192, 8192, torch.float16, 4)
