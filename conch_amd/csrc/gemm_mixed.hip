@@ -247,6 +247,9 @@ __device__ __forceinline__ void stage_x_piece(char* lds, const Srcs& src, const 
 }
 
 struct LoopCtx {
+#ifdef CONCH_CLOCK_PROBE
+  mutable unsigned long long wait_cycles = 0, barrier_cycles = 0;  // diagnostic build: time at the step-top wait / barrier
+#endif
   Srcs src;
   StageOffsets so;
   WeightLane ln;
@@ -256,23 +259,27 @@ struct LoopCtx {
 
 // One K step.  MODE 0: steps t+1 and t+2 exist; 1: t+1 exists; 2: last step.  ISSUE = the slot at which this
 // wave starts issuing the step's VMEM work.
-template <int X_DT, int BITS, int ZP, int NT, int MODE, int ISSUE>
+template <int X_DT, int BITS, int ZP, int NT, int MODE, int ISSUE, bool DEFER>
 __device__ __forceinline__ void mixed_step(MixedTile& w, WeightRegs<BITS, NT>& regs, char* lds, const LoopCtx& c, WeightCursor& cur, int t) {
   constexpr int N1 = NT - 2;
   constexpr int kWpc = WeightRegs<BITS, NT>::kWpc;
   constexpr int kSlices = ChunkDequant<X_DT, BITS>::kSlices;
   static_assert(kSlices <= 16, "more slices per chunk than MFMA slots per chunk");
   // everything this wave staged for step t (LDS-DMA, ds_write) and loaded for step t+1 is complete ...
+#ifdef CONCH_CLOCK_PROBE
+  const unsigned long long probe_a = __builtin_amdgcn_s_memtime();
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  const unsigned long long probe_b = __builtin_amdgcn_s_memtime();
+  __builtin_amdgcn_s_barrier();
+  const unsigned long long probe_c = __builtin_amdgcn_s_memtime();
+  c.wait_cycles += probe_b - probe_a;
+  c.barrier_cycles += probe_c - probe_b;
+#else
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // ... and every wave is done reading the other stage
+#endif
   const int ubuf = (t & 1) * kStageBytes, vbuf = ubuf + kXBytes;
   const int vnext = ((t + 1) & 1) * kStageBytes + kXBytes;
-  // phase-0 fragment reads first: their LDS latency passes under the first slots
-#pragma unroll
-  for (int tt = 0; tt < 2; ++tt) w.fn[0][tt] = read_frag(lds, vbuf + c.n_base + tt * 2048);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) w.fm[i] = read_frag(lds, ubuf + c.m_base + i * 2048);
-  __builtin_amdgcn_sched_barrier(0);
   WeightRegs<BITS, NT> next;
 
   ChunkDequant<X_DT, BITS> cv[NT];
@@ -301,6 +308,29 @@ __device__ __forceinline__ void mixed_step(MixedTile& w, WeightRegs<BITS, NT>& r
     }
     __builtin_amdgcn_sched_barrier(0);
   };
+  // phase 3 = (m rows 64-127) x (n tiles 0,1): 16 MFMAs on fragments that are in registers when phase 2 ends
+  auto phase3 = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          mma1<X_DT>(w.acc[4 + i][tt], w.fn[0][tt], w.fm[i], h);
+          tail(slot++);
+        }
+  };
+  // DEFER (waves 4-7, the second wave of every SIMD): the previous step's phase 3 runs here, after the barrier,
+  // and needs no LDS access, so the matrix pipe has work while the other wave of the SIMD waits for its first
+  // fragments, and the two waves' read bursts, LDS-DMA issue and ds_writes no longer coincide.  (At t = 0 the
+  // fragment registers hold zeros: sixteen MFMAs that add nothing.)
+  if constexpr (DEFER) phase3();
+  // phase-0 fragment reads, ahead of the slots that hide their latency
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) w.fn[0][tt] = read_frag(lds, vbuf + c.n_base + tt * 2048);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w.fm[i] = read_frag(lds, ubuf + c.m_base + i * 2048);
+  __builtin_amdgcn_sched_barrier(0);
   // phase 0: (m rows 0-63 of the wave) x (n tiles 0,1); the V2 fragments of phase 1 -- or, for the narrowest
   // tile, the U2 fragments -- are fetched underneath
 #pragma unroll
@@ -339,28 +369,33 @@ __device__ __forceinline__ void mixed_step(MixedTile& w, WeightRegs<BITS, NT>& r
         mma1<X_DT>(w.acc[4 + i][2 + tt], w.fn[1][tt], w.fm[i], h);
         tail(slot++);
       }
-  // phase 3: m rows 64-127 x n tiles 0,1
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        mma1<X_DT>(w.acc[4 + i][tt], w.fn[0][tt], w.fm[i], h);
-        tail(slot++);
-      }
+  if constexpr (!DEFER) phase3();
   if constexpr (MODE == 0) regs = next;
 }
 
-template <int X_DT, int BITS, int ZP, int NT, int ISSUE>
+template <int X_DT, int BITS, int ZP, int NT, int ISSUE, bool DEFER>
 __device__ __forceinline__ void mixed_mainloop(MixedTile& w, WeightRegs<BITS, NT>& regs, char* lds, const LoopCtx& c, WeightCursor& cur, int steps) {
+  if constexpr (DEFER) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w.fm[i] = Frag{i32x4{0, 0, 0, 0}, i32x4{0, 0, 0, 0}};
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) w.fn[0][tt] = Frag{i32x4{0, 0, 0, 0}, i32x4{0, 0, 0, 0}};
+  }
   int t = 0;
-  for (; t + 2 < steps; ++t) mixed_step<X_DT, BITS, ZP, NT, 0, ISSUE>(w, regs, lds, c, cur, t);
+  for (; t + 2 < steps; ++t) mixed_step<X_DT, BITS, ZP, NT, 0, ISSUE, DEFER>(w, regs, lds, c, cur, t);
   if (steps > 1) {
-    mixed_step<X_DT, BITS, ZP, NT, 1, ISSUE>(w, regs, lds, c, cur, t);
+    mixed_step<X_DT, BITS, ZP, NT, 1, ISSUE, DEFER>(w, regs, lds, c, cur, t);
     ++t;
   }
-  mixed_step<X_DT, BITS, ZP, NT, 2, ISSUE>(w, regs, lds, c, cur, t);
+  mixed_step<X_DT, BITS, ZP, NT, 2, ISSUE, DEFER>(w, regs, lds, c, cur, t);
+  if constexpr (DEFER) {  // the last step's phase 3
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) mma1<X_DT>(w.acc[4 + i][tt], w.fn[0][tt], w.fm[i], h);
+  }
 }
 
 #ifdef CONCH_CLOCK_PROBE
@@ -460,9 +495,15 @@ __global__ __launch_bounds__(kThreads, 2) void mixed_gemm_kernel(MixedGemmArgs p
 
   // The two waves of a SIMD (w and w + 4) issue their VMEM work at different places of the step.
   CONCH_PROBE(g_probe_mixed, 0);
-  if (wr == 0) mixed_mainloop<X_DT, BITS, ZP, NT, 0>(w, regs, lds, c, cur, steps);
-  else mixed_mainloop<X_DT, BITS, ZP, NT, 4 * NT>(w, regs, lds, c, cur, steps);
+  if (wr == 0) mixed_mainloop<X_DT, BITS, ZP, NT, 0, false>(w, regs, lds, c, cur, steps);
+  else mixed_mainloop<X_DT, BITS, ZP, NT, 16, true>(w, regs, lds, c, cur, steps);
   CONCH_PROBE(g_probe_mixed, 1);
+#ifdef CONCH_CLOCK_PROBE
+  if (threadIdx.x == 0 && blockIdx.x < kProbeBlocks) {  // slots 4..7 of the block: cycles at the step-top wait / barrier (wave 0)
+    g_probe_mixed[blockIdx.x * 8 + 4] = c.wait_cycles;
+    g_probe_mixed[blockIdx.x * 8 + 5] = c.barrier_cycles;
+  }
+#endif
 
   mixed_epilogue<X_DT, OUT_DT, NT>(w, p, bm0, bn0, wr, wc, lane);
 }

@@ -103,6 +103,20 @@ def scaled_case(m, k, n, dtype, flops_per_clk_cu):
           f"({2.0 * m * n * k / us / 1e6:.0f} TFLOP/s)", flush=True)
 
 
+def mixed_stalls(blocks=256):
+    """Diagnostic counters of the mixed kernel: wave 0's cycles at the step-top s_waitcnt and at the barrier."""
+    lib = _C.load()
+    fn = lib.conch_debug_probe_mixed
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    buf = (ctypes.c_ulonglong * (8 * blocks))()
+    assert fn(buf, blocks) == 0
+    rows = [(buf[8 * b + 2] - buf[8 * b], buf[8 * b + 4], buf[8 * b + 5]) for b in range(blocks) if buf[8 * b + 2] > buf[8 * b]]
+    tot = statistics.median(r[0] for r in rows)
+    print(f"    wave 0 of a workgroup: K loop {tot:.0f} cycles, of which {statistics.median(r[1] for r in rows) / tot * 100:.1f} % at the "
+          f"step-top s_waitcnt and {statistics.median(r[2] for r in rows) / tot * 100:.1f} % at the barrier")
+
+
 def mixed_case(m, k, n, dtype, bits):
     torch.manual_seed(0)
     x = (10 * (torch.rand((m, k), device="cuda") - 0.3)).to(dtype)
@@ -116,6 +130,7 @@ def mixed_case(m, k, n, dtype, bits):
     ghz, loop_us, loop_max = read_probe("conch_debug_probe_mixed", 4096)
     print(f"mixed int{bits} {str(dtype)[6:]:9s} {m}x{k}x{n}: {us:7.1f} us/launch  clock {ghz:.2f} GHz  K loop {loop_us:.1f} us median "
           f"({loop_max:.1f} max)  ({2.0 * m * n * k / us / 1e6:.0f} TFLOP/s)", flush=True)
+    mixed_stalls()
 
 
 if __name__ == "__main__":

@@ -11,6 +11,13 @@ from conch_amd.kernels.quantization import gemm as kg  # noqa: E402
 from conch_amd.ops.quantization.gemm import create_scaled_metadata  # noqa: E402
 
 
+# development aid: CONCH_LIB=<path> times another build of the library (same-box comparison of two builds)
+import os
+from pathlib import Path
+if os.environ.get("CONCH_LIB"):
+    _C.LIB_PATH = Path(os.environ["CONCH_LIB"])
+
+
 def time_scaled(m, k, n, dtype, variant, iters=20):
     torch.manual_seed(0)
     if dtype == torch.int8:
