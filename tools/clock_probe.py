@@ -53,13 +53,13 @@ def read_probe(fn_name: str, blocks: int):
         picks = sorted({0, len(spans) // 8, len(spans) // 4, 255, 256, 300, 400, 511, 512, 600, len(spans) - 1} & set(range(len(spans))))
         print("    timeline (us since the first K loop started): " + "  ".join(
             f"#{i}: {(spans[i][0] - base) * 0.01:.1f}-{(spans[i][1] - base) * 0.01:.1f}" for i in picks))
-        if spans[0][2]:
+        if any(sp[3] > sp[1] for sp in spans):  # kernels that also stamp entry (2) and exit (3)
             pro = statistics.median((s[0] - s[2]) * 0.01 for s in spans)
-            epi = statistics.median((s[3] - s[1]) * 0.01 for s in spans if s[3])
+            epi = statistics.median((s[3] - s[1]) * 0.01 for s in spans if s[3] > s[1])
             first_in = min(s[2] for s in spans)
             print(f"    entry -> K loop (prologue) {pro:.2f} us median; K loop end -> epilogue stores issued {epi:.2f} us median; "
                   f"first entry at {(first_in - base) * 0.01:.1f} us")
-            outs = sorted(s[3] for s in spans if s[3])
+            outs = sorted(s[3] for s in spans if s[3] > s[1])
             ins = sorted(s[2] for s in spans)
             if len(ins) > 300:
                 print(f"    workgroup #256 enters {(ins[256] - outs[0]) * 0.01:.2f} us after the first workgroup left")
