@@ -222,6 +222,31 @@ def test_scaled_gemm_c3_config_properties():
     assert torch.equal(got_p, got[perm])
 
 
+def test_scaled_gemm_c5_config_shard_invariance():
+    """BASELINE config C5 (fp8 -> bf16, 8192x8192x28672, N-sharded over 8 ranks) at full size on one GPU.
+
+    (1) the column block a rank would compute (N/8 = 3584 columns, rank 0, 3 and 7) from ITS slice of B / scale_b
+    equals the same columns of the full product bit-for-bit -- the property the multi-GPU path rests on
+    (no reduction, so sharding must not change a single bit); (2) a band of rows of the full product
+    against the CPU oracle.
+    """
+    m, k, n, world = 8192, 8192, 28672, 8
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    a = (0.25 * torch.rand((m, k), device="cuda", generator=gen)).to(torch.float8_e4m3fn)
+    bt = (0.25 * torch.rand((n, k), device="cuda", generator=gen)).to(torch.float8_e4m3fn)
+    sa = 0.25 * torch.rand((m, 1), device="cuda", generator=gen)
+    sb = 0.25 * torch.rand((n, 1), device="cuda", generator=gen)
+    full = scaled_gemm(a, bt.T, sa, sb, torch.bfloat16)
+    shard = n // world
+    for rank in (0, 3, 7):
+        lo, hi = rank * shard, (rank + 1) * shard
+        part = scaled_gemm(a, bt[lo:hi].T, sa, sb[lo:hi], torch.bfloat16)
+        assert torch.equal(part, full[:, lo:hi]), f"rank {rank}"
+    rows = torch.cat([torch.arange(0, 16), torch.arange(8176, 8192)])
+    ref = oracle.scaled_gemm_ref(a[rows.cuda()].cpu(), bt.cpu().T, sa[rows.cuda()].cpu(), sb.cpu(), torch.bfloat16, None)
+    check_scaled(full[rows.cuda()], ref, torch.float8_e4m3fn, torch.bfloat16)
+
+
 # ---------------------------------------------------------------------------------------------
 # mixed precision
 # ---------------------------------------------------------------------------------------------
@@ -283,6 +308,35 @@ def test_mixed_precision_gemm_matrix(m, k, n, wname, use_zp, dname):
         check_mixed(got[rows.cuda()], a[rows], w_ref, k)
     else:
         check_mixed(got, a, w_ref, k)
+
+
+def test_mixed_precision_c4_config_properties():
+    """BASELINE config C4 (uint4b8, group 128, fp16, 1024x4096x11008) at full size.
+
+    (1) bands of rows against the oracle; (2) the MFMA kernel against the generic device kernel everywhere (same
+    dequantised weights bit-for-bit, accumulation order differs); (3) permuting the rows of X permutes the rows of C
+    bit-for-bit; (4) a column block computed from its own slice of the packed weights / scales equals the same
+    columns of the full product bit-for-bit (N-sharding invariance, 11008 / 8 = 1376 columns: ragged 192-wide tiles).
+    """
+    m, k, n = 1024, 4096, 11008
+    wt = scalar_types.uint4b8
+    a, w_ref, packed, w_s, _ = make_mixed_inputs(m, k, n, wt, False, torch.float16)
+    a_d, p_d, s_d = a.cuda(), packed.cuda(), w_s.cuda()
+    got = mixed_precision_gemm(a_d, p_d, s_d, None, wt.size_bits, wt.bias, 128)
+    rows = torch.cat([torch.arange(0, 64), torch.arange(480, 544), torch.arange(960, 1024)])
+    check_mixed(got[rows.cuda()], a[rows], w_ref, k)
+    _C.set_gemm_variant(_C.VARIANT_GENERIC)
+    slow = mixed_precision_gemm(a_d, p_d, s_d, None, wt.size_bits, wt.bias, 128)
+    _C.set_gemm_variant(_C.VARIANT_AUTO)
+    tol = 2.0 * EPS[torch.float16] * slow.float().abs().max().item()
+    assert (got.float() - slow.float()).abs().max().item() <= tol
+    perm = torch.randperm(m, device="cuda")
+    assert torch.equal(mixed_precision_gemm(a_d[perm].contiguous(), p_d, s_d, None, wt.size_bits, wt.bias, 128), got[perm])
+    shard = n // 8
+    for rank in (0, 5, 7):
+        lo, hi = rank * shard, (rank + 1) * shard
+        part = mixed_precision_gemm(a_d, p_d[:, lo:hi].contiguous(), s_d[:, lo:hi].contiguous(), None, wt.size_bits, wt.bias, 128)
+        assert torch.equal(part, got[:, lo:hi]), f"rank {rank}"
 
 
 @pytest.mark.parametrize("wname", list(WTYPES))
