@@ -1,0 +1,65 @@
+"""Vendor-library comparators on the GPU box (development aid, not part of the product or of bench.py):
+hipBLASLt through torch._scaled_mm (fp8, per-row / per-column scales) and through torch.matmul (fp16 GEMM on weights
+that are ALREADY dequantised -- the upper bound for a fused int4 kernel), timed like tools/quick_bench.py
+(back-to-back launches after a clock ramp, HIP events)."""
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from conch_amd.ops.quantization.gemm import mixed_precision_gemm, scaled_gemm  # noqa: E402
+
+
+def timeit(fn, iters=100, rounds=5):
+    for _ in range(300):
+        fn()
+    torch.cuda.synchronize()
+    best = []
+    for _ in range(rounds):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(iters):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        best.append(s.elapsed_time(e) / iters)
+    return sorted(best)[len(best) // 2]
+
+
+def fp8_case(m, k, n):
+    torch.manual_seed(0)
+    a = (0.25 * torch.rand((m, k), device="cuda")).to(torch.float8_e4m3fn)
+    bt = (0.25 * torch.rand((n, k), device="cuda")).to(torch.float8_e4m3fn)
+    sa = 0.25 * torch.rand((m, 1), device="cuda")
+    sb = 0.25 * torch.rand((n, 1), device="cuda")
+    ours = timeit(lambda: scaled_gemm(a, bt.T, sa, sb, torch.bfloat16))
+    line = f"fp8 {m}x{k}x{n}: conch_amd {ours * 1e3:.1f} us ({2.0 * m * n * k / ours / 1e9:.0f} TFLOP/s)"
+    try:
+        ref = timeit(lambda: torch._scaled_mm(a, bt.T, scale_a=sa, scale_b=sb.T.contiguous(), out_dtype=torch.bfloat16))
+        got = scaled_gemm(a, bt.T, sa, sb, torch.bfloat16).float()
+        lib = torch._scaled_mm(a, bt.T, scale_a=sa, scale_b=sb.T.contiguous(), out_dtype=torch.bfloat16).float()
+        line += (f"   torch._scaled_mm (hipBLASLt, row-wise scales) {ref * 1e3:.1f} us ({2.0 * m * n * k / ref / 1e9:.0f} TFLOP/s)"
+                 f"   max|diff| {(got - lib).abs().max().item():.3g} of max|C| {lib.abs().max().item():.3g}")
+    except Exception as exc:  # noqa: BLE001
+        line += f"   torch._scaled_mm unavailable: {str(exc)[:120]}"
+    print(line, flush=True)
+
+
+def fp16_case(m, k, n):
+    torch.manual_seed(0)
+    x = (10 * (torch.rand((m, k), device="cuda") - 0.3)).to(torch.float16)
+    w = (0.1 * torch.rand((k, n), device="cuda")).to(torch.float16)
+    wq = torch.randint(-2**31, 2**31 - 1, (k // 8, n), dtype=torch.int32, device="cuda")
+    ws = (0.1 * torch.rand((k // 128, n), device="cuda") + 0.01).to(torch.float16)
+    ours = timeit(lambda: mixed_precision_gemm(x, wq, ws, None, 4, 8, 128))
+    ref = timeit(lambda: torch.matmul(x, w))
+    print(f"int4 x fp16 {m}x{k}x{n}: conch_amd (fused dequantisation) {ours * 1e3:.1f} us ({2.0 * m * n * k / ours / 1e9:.0f} TFLOP/s)"
+          f"   torch.matmul fp16 on dequantised weights (hipBLASLt / rocBLAS) {ref * 1e3:.1f} us ({2.0 * m * n * k / ref / 1e9:.0f} TFLOP/s)", flush=True)
+
+
+if __name__ == "__main__":
+    for shape in [(4096, 4096, 11008), (8192, 8192, 8192), (8192, 8192, 3584)]:
+        fp8_case(*shape)
+    for shape in [(1024, 4096, 11008), (4096, 8192, 4096), (8192, 8192, 8192)]:
+        fp16_case(*shape)
