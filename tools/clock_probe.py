@@ -80,9 +80,12 @@ def sustained(launch, seconds):
     return (time.time() - t0) / n * 1e6  # us per launch (host clock, includes launch gaps)
 
 
-def scaled_case(m, k, n, dtype, flops_per_clk_cu):
+def scaled_case(m, k, n, dtype, flops_per_clk_cu, zeros=False):
     torch.manual_seed(0)
-    if dtype == torch.int8:
+    if zeros:  # all-zero operands: the same instruction stream at the lowest switching activity (DVFS check)
+        a = torch.zeros((m, k), device="cuda").to(dtype)
+        b = torch.zeros((n, k), device="cuda").to(dtype).T
+    elif dtype == torch.int8:
         a = torch.randint(-32, 32, (m, k), dtype=torch.int8, device="cuda")
         b = torch.randint(-32, 32, (n, k), dtype=torch.int8, device="cuda").T
     else:
@@ -98,7 +101,7 @@ def scaled_case(m, k, n, dtype, flops_per_clk_cu):
     rounds = -(-tiles // N_CU)
     # per-workgroup occupancy of its CU's matrix pipes during its own K loop
     occ = (2.0 * 256 * 256 * k) / (flops_per_clk_cu * ghz * 1e9 * loop_us * 1e-6)
-    print(f"scaled {str(dtype)[6:]:14s} {m}x{k}x{n}: {us:7.1f} us/launch  clock {ghz:.2f} GHz  K loop {loop_us:.1f} us median "
+    print(f"scaled {str(dtype)[6:]:14s}{' ZEROS' if zeros else ''} {m}x{k}x{n}: {us:7.1f} us/launch  clock {ghz:.2f} GHz  K loop {loop_us:.1f} us median "
           f"({loop_max:.1f} max) x {rounds} rounds  pipe occupancy in the loop {occ * 100:.0f} %  "
           f"({2.0 * m * n * k / us / 1e6:.0f} TFLOP/s)", flush=True)
 
@@ -136,6 +139,9 @@ def mixed_case(m, k, n, dtype, bits):
 if __name__ == "__main__":
     # dense peak per CU per clock: 5e15 / 256 / 2.4e9 (fp8, int8), half that for fp16 / bf16
     scaled_case(4096, 4096, 11008, torch.float8_e4m3fn, 8138.0)
+    if "--zeros" in sys.argv:
+        scaled_case(4096, 4096, 11008, torch.float8_e4m3fn, 8138.0, zeros=True)
+        scaled_case(8192, 8192, 8192, torch.float8_e4m3fn, 8138.0, zeros=True)
     scaled_case(8192, 8192, 8192, torch.float8_e4m3fn, 8138.0)
     scaled_case(4096, 4096, 11008, torch.int8, 8138.0)
     mixed_case(1024, 4096, 11008, torch.float16, 4)
