@@ -114,6 +114,26 @@ int run_scaled(const ScaledGemmArgs& p, hipStream_t stream) {
   return launch_scaled_gemm_generic(p, stream);
 }
 
+// scaled_gemm_silu_and_mul: `p` describes the OUTPUT (n columns); B / scale_b / bias have 2n columns [gate | up].
+int run_scaled_silu(const ScaledGemmArgs& p, hipStream_t stream) {
+  ScaledGemmArgs wide = p;  // the plain GEMM the fused op contains: checks and the unfused fallback run on it
+  wide.fuse_silu = 0;
+  wide.n = 2 * p.n;
+  if (int rc = check_scaled(wide)) return rc;
+  CONCH_CHECK_ARG(p.c_stride_n == 1, "scaled_gemm_silu_and_mul: C must have unit column stride (got %lld)", (long long)p.c_stride_n);
+  if (p.m == 0 || p.n == 0) return CONCH_OK;
+  const int variant = tuning(CONCH_TUNE_GEMM_VARIANT);
+  if (variant != 1 && variant != 2 && scaled_gemm_mfma_supported(p)) return launch_scaled_gemm_mfma(p, 5, stream);
+  // any other layout / dtype / K: the plain GEMM into stream-ordered scratch, then the elementwise tail
+  void* tmp = nullptr;
+  if (int rc = get_scratch(stream, 3, (size_t)p.m * (size_t)wide.n * 2, &tmp)) return rc;
+  wide.c = tmp;
+  wide.c_stride_m = wide.n;
+  wide.c_stride_n = 1;
+  if (int rc = run_scaled(wide, stream)) return rc;
+  return launch_silu_and_mul(p.c, tmp, p.m, p.n, wide.n, p.c_stride_m, p.out_dtype, stream);
+}
+
 int check_mixed(const MixedGemmArgs& p) {
   CONCH_CHECK_ARG(p.m >= 0 && p.n >= 0 && p.k >= 0, "mixed_precision_gemm: negative shape");
   if (p.x_dtype != CONCH_DT_FP16 && p.x_dtype != CONCH_DT_BF16) {
@@ -204,6 +224,31 @@ extern "C" int conch_scaled_gemm(void* c, const void* a, const void* b, const fl
   const ScaledGemmArgs p{c, a, b, scale_a, scale_b, bias, m, n, k, a_stride_m, a_stride_k, b_stride_k,
                          b_stride_n, c_stride_m, c_stride_n, scale_a_numel, scale_b_numel, in_dtype, out_dtype};
   return run_scaled(p, (hipStream_t)stream);
+}
+
+extern "C" int conch_scaled_gemm_silu_and_mul(void* c, const void* a, const void* b, const float* scale_a,
+                                              const float* scale_b, const void* bias, int64_t m, int64_t n_out, int64_t k,
+                                              int64_t a_stride_m, int64_t a_stride_k, int64_t b_stride_k,
+                                              int64_t b_stride_n, int64_t c_stride_m, int64_t c_stride_n,
+                                              int64_t scale_a_numel, int64_t scale_b_numel, int in_dtype, int out_dtype,
+                                              void* stream) {
+  ScaledGemmArgs p{c, a, b, scale_a, scale_b, bias, m, n_out, k, a_stride_m, a_stride_k, b_stride_k,
+                   b_stride_n, c_stride_m, c_stride_n, scale_a_numel, scale_b_numel, in_dtype, out_dtype};
+  p.fuse_silu = 1;
+  return run_scaled_silu(p, (hipStream_t)stream);
+}
+
+extern "C" int conch_time_scaled_gemm_silu_and_mul(void* c, const void* a, const void* b, const float* scale_a,
+                                                   const float* scale_b, const void* bias, int64_t m, int64_t n_out,
+                                                   int64_t k, int64_t a_stride_m, int64_t a_stride_k, int64_t b_stride_k,
+                                                   int64_t b_stride_n, int64_t c_stride_m, int64_t c_stride_n,
+                                                   int64_t scale_a_numel, int64_t scale_b_numel, int in_dtype,
+                                                   int out_dtype, void* stream, int iters, float* avg_ms) {
+  ScaledGemmArgs p{c, a, b, scale_a, scale_b, bias, m, n_out, k, a_stride_m, a_stride_k, b_stride_k,
+                   b_stride_n, c_stride_m, c_stride_n, scale_a_numel, scale_b_numel, in_dtype, out_dtype};
+  p.fuse_silu = 1;
+  hipStream_t s = (hipStream_t)stream;
+  return time_loop([&] { return run_scaled_silu(p, s); }, s, iters, avg_ms);
 }
 
 extern "C" int conch_time_scaled_gemm(void* c, const void* a, const void* b, const float* scale_a,

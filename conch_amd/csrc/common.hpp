@@ -132,6 +132,14 @@ __device__ __forceinline__ f32x2 unpack2_bits16(uint32_t w) {
   else return f32x2{bits_to_float(w << 16), bits_to_float(w & 0xffff0000u)};
 }
 
+// silu(g) = g / (1 + exp(-g)) in fp32 on the transcendental unit (v_exp_f32, v_rcp_f32: 1 ulp, no denormals).  The
+// denominator is scaled by 2^-32 before the reciprocal and the quotient by 2^-32 after it (both exact), so that the
+// reciprocal of a denominator near FLT_MAX (g ~ -88, silu ~ 1e-37: still a normal number) is not flushed to zero.
+__device__ __forceinline__ float silu_f32(float g) {
+  const float e = __builtin_amdgcn_exp2f(g * -1.44269504088896340736f);  // exp(-g); +inf for g < -88.7 -> silu = -0
+  return (g * __builtin_amdgcn_rcpf((1.0f + e) * 0x1p-32f)) * 0x1p-32f;
+}
+
 template <int DT>
 __device__ __forceinline__ float load_as_float(const void* p, int64_t idx) {
   if constexpr (DT == CONCH_DT_FP32) {

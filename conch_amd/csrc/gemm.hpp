@@ -20,6 +20,9 @@ struct ScaledGemmArgs {
   int64_t c_stride_m, c_stride_n;
   int64_t scale_a_numel, scale_b_numel;
   int in_dtype, out_dtype;
+  // 1 = fused gate/up FFN form (conch_scaled_gemm_silu_and_mul): B, scale_b and bias have 2n columns [gate | up], C has
+  // n columns, C[i][j] = silu(gemm[i][j]) * gemm[i][n + j] with the reference's roundings (oracle: scaled_gemm_silu_and_mul_ref)
+  int fuse_silu = 0;
 };
 
 // mixed_precision_gemm: C = out( X @ dequant(Wq) ).  Strides in ELEMENTS of the respective array.
@@ -54,6 +57,9 @@ int launch_scaled_gemm_skinny(const ScaledGemmArgs& p, hipStream_t stream);
 int repack_for_mfma(const ScaledGemmArgs& p, ScaledGemmArgs* q, void** scratch, hipStream_t stream);
 int expand_fnuz_to_bf16(const ScaledGemmArgs& p, ScaledGemmArgs* q, hipStream_t stream);
 int launch_scaled_gemm_mfma_bf16(const ScaledGemmArgs& p, hipStream_t stream);
+// quant.hip -- elementwise silu(x[:, :n]) * x[:, n:] on a 16-bit [m][2n] matrix (the unfused tail of the FFN pair)
+int launch_silu_and_mul(void* out, const void* x, int64_t m, int64_t n, int64_t x_stride_m, int64_t out_stride_m, int dtype,
+                        hipStream_t stream);
 bool mixed_gemm_mfma_supported(const MixedGemmArgs& p);
 int launch_mixed_gemm_mfma(const MixedGemmArgs& p, hipStream_t stream);
 

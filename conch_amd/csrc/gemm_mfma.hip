@@ -97,16 +97,20 @@ struct EpiPrefetch {
 };
 
 __device__ __forceinline__ EpiPrefetch epilogue_prefetch(const ScaledGemmArgs& p, int bm0, int bn0) {
-  // branch-free: threads 0-255 fetch scale_a[row], threads 256-511 scale_b[col] (and the bias)
+  // branch-free: threads 0-255 fetch scale_a[row], threads 256-511 scale_b[col] (and the bias).  Fused gate/up form:
+  // the tile has 128 output columns; slots 0-127 take their gate columns, slots 128-255 the up columns n further right
   EpiPrefetch e;
   const int t = threadIdx.x;
   const bool is_b = t >= 256;
-  const int idx = min((is_b ? bn0 : bm0) + (t & 255), (int)(is_b ? p.n : p.m) - 1);
+  const int tt = t & 255;
+  int col = min(bn0 + tt, (int)p.n - 1);
+  if (p.fuse_silu) col = tt < 128 ? min(bn0 + tt, (int)p.n - 1) : (int)p.n + min(bn0 + tt - 128, (int)p.n - 1);
+  const int idx = is_b ? col : min(bm0 + tt, (int)p.m - 1);
   const float* base = is_b ? p.scale_b : p.scale_a;
   const bool vec = (is_b ? p.scale_b_numel : p.scale_a_numel) != 1;
   e.v0 = base[vec ? idx : 0];
   uint32_t bits = 0;
-  if (p.bias) bits = ((const uint16_t*)p.bias)[min(bn0 + (t & 255), (int)p.n - 1)];
+  if (p.bias) bits = ((const uint16_t*)p.bias)[col];
   e.bias_bits = bits;
   return e;
 }
@@ -172,6 +176,80 @@ __device__ __forceinline__ void epilogue(const typename AccT<MMA>::type (&acc)[8
   }
 }
 
+// Fused gate/up epilogue (scaled_gemm_silu_and_mul): the lane's accumulator tiles 0,1 are the gate values and tiles 2,3
+// the up values of the SAME eight output columns (make_stage_offsets with v2_delta = n).  Per pair of columns:
+//   g = cast(sb_g * (sa * acc_g)) [+ bias_g],  u = cast(sb_u * (sa * acc_u)) [+ bias_u]      -- the reference's scaled_gemm
+//   s = cast(g / (1 + exp(-g))),  y = cast(s * u)                                            -- its silu_and_mul
+// with every cast an RNE rounding to the output dtype, as torch rounds after each op of the unfused pair.  exp and the
+// reciprocal are the hardware's v_exp_f32 / v_rcp_f32 (1 ulp each, in fp32): the result can differ from the CPU oracle by
+// one output ulp on a few elements in 10^4 (bound asserted in tests/test_gpu_gemm.py).
+template <int OUT_DT>
+__device__ __forceinline__ uint32_t silu_mul2(uint32_t g_bits, uint32_t u_bits) {
+  const f32x2 g = unpack2_bits16<OUT_DT>(g_bits);
+  f32x2 s;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) s[i] = silu_f32(g[i]);
+  const f32x2 sr = unpack2_bits16<OUT_DT>(pack2_bits16<OUT_DT>(pin_f32x2(s)));
+  return pack2_bits16<OUT_DT>(pin_f32x2(sr * unpack2_bits16<OUT_DT>(u_bits)));
+}
+
+template <int MMA, int OUT_DT>
+__device__ __forceinline__ void epilogue_silu(const typename AccT<MMA>::type (&acc)[8][4], const ScaledGemmArgs& p, const char* lds,
+                                              int bm0, int bn0, int wr, int wc, int lane) {
+  const int g = lane >> 4, jm = lane & 15;
+  const bool vec_store = (p.c_stride_m % 8 == 0) && (((uintptr_t)p.c & 15) == 0);
+  const bool has_bias = p.bias != nullptr;
+  const float* lsa = (const float*)(lds + kEpiOff);
+  const float* lsb = lsa + 256;
+  const float* lbias = lsa + 512;
+  const int nl = wc * 32 + 8 * g;  // tile-local output column of this lane's 8 outputs; gate constants at nl, up at 128 + nl
+  const int n0 = bn0 + nl;
+  f32x4 sbv[2][2], bsv[2][2];      // [gate / up][low / high four columns]
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      sbv[h][q] = *(const f32x4*)(lsb + 128 * h + nl + 4 * q);
+      bsv[h][q] = *(const f32x4*)(lbias + 128 * h + nl + 4 * q);
+    }
+#pragma unroll
+  for (int mt = 0; mt < 8; ++mt) {
+    const int ml = wr * 128 + mt * 16 + jm;
+    const int m = bm0 + ml;
+    const float sa = lsa[ml];
+    i32x4 pk;
+#pragma unroll
+    for (int e2 = 0; e2 < 4; ++e2) {
+      const int e = 2 * e2;
+      uint32_t gu[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const f32x2 a2 = {(float)acc[mt][2 * h + (e >> 2)][e & 3], (float)acc[mt][2 * h + (e >> 2)][(e & 3) + 1]};
+        const f32x2 sb2 = {sbv[h][e >> 2][e & 3], sbv[h][e >> 2][(e & 3) + 1]};
+        f32x2 v = f32x2{sa, sa} * a2;
+        v = pin_f32x2(sb2 * v);
+        uint32_t hb = pack2_bits16<OUT_DT>(v);
+        if (has_bias) {
+          const f32x2 b2 = {bsv[h][e >> 2][e & 3], bsv[h][e >> 2][(e & 3) + 1]};
+          hb = pack2_bits16<OUT_DT>(pin_f32x2(unpack2_bits16<OUT_DT>(hb) + b2));
+        }
+        gu[h] = hb;
+      }
+      pk[e2] = (int)silu_mul2<OUT_DT>(gu[0], gu[1]);
+    }
+    if (m < p.m) {
+      uint16_t* dst = (uint16_t*)p.c + (int64_t)m * p.c_stride_m + n0;
+      if (vec_store && n0 + 8 <= p.n) {
+        *(i32x4*)dst = pk;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (n0 + e < p.n) dst[e] = (uint16_t)((uint32_t)pk[e >> 1] >> (16 * (e & 1)));
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
@@ -187,15 +265,19 @@ __device__ __forceinline__ BlockSetup setup_block(const ScaledGemmArgs& p) {
   s.lane = threadIdx.x & 63;
   s.wr = s.wave >> 2;
   s.wc = s.wave & 3;
+  // fused gate/up form: a tile is 256 rows x 128 OUTPUT columns (128 gate + 128 up columns of B)
+  const int tile_n = p.fuse_silu ? kTileN / 2 : kTileN;
   const int tiles_m = ((int)p.m + kTileM - 1) / kTileM;
-  const int tiles_n = ((int)p.n + kTileN - 1) / kTileN;
+  const int tiles_n = ((int)p.n + tile_n - 1) / tile_n;
   const TileCoord tc = map_tile(blockIdx.x, tiles_m, tiles_n);
   s.bm0 = tc.tm * kTileM;
-  s.bn0 = tc.tn * kTileN;
+  s.bn0 = tc.tn * tile_n;
   const int lda = (int)p.a_stride_m, ldb = (int)p.b_stride_n;
-  s.so = make_stage_offsets(s.wave, s.lane, s.bm0, s.bn0, (int)p.m - 1, (int)p.n - 1, lda, ldb);
+  if (p.fuse_silu) s.so = make_stage_offsets(s.wave, s.lane, s.bm0, s.bn0, (int)p.m - 1, (int)p.n - 1, lda, ldb, 32, (int)p.n);
+  else s.so = make_stage_offsets(s.wave, s.lane, s.bm0, s.bn0, (int)p.m - 1, (int)p.n - 1, lda, ldb);
+  const int64_t b_cols = p.fuse_silu ? 2 * p.n : p.n;
   const uint32_t a_bytes = (uint32_t)((p.m - 1) * p.a_stride_m + p.k);
-  const uint32_t b_bytes = (uint32_t)((p.n - 1) * p.b_stride_n + p.k);
+  const uint32_t b_bytes = (uint32_t)((b_cols - 1) * p.b_stride_n + p.k);
   s.src.a = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, a_bytes, 0x00020000);
   s.src.b = __builtin_amdgcn_make_buffer_rsrc((void*)p.b, 0, b_bytes, 0x00020000);
   // fragment read offsets inside a unit (bytes): row r of a 16-row tile, k-group g
@@ -388,7 +470,7 @@ __device__ __forceinline__ void pp2_step(WaveTile<MMA>& w, char* lds, const Bloc
 __device__ unsigned long long g_probe_scaled[kProbeBlocks * 8];
 #endif
 
-template <int MMA, int OUT_DT>
+template <int MMA, int OUT_DT, bool SILU>
 __global__ __launch_bounds__(kThreads, 2) void scaled_gemm_pp2_kernel(ScaledGemmArgs p) {
   __shared__ __attribute__((aligned(1024))) char lds[kLdsTotal];
   CONCH_PROBE(g_probe_scaled, 2);
@@ -417,7 +499,8 @@ __global__ __launch_bounds__(kThreads, 2) void scaled_gemm_pp2_kernel(ScaledGemm
   CONCH_PROBE(g_probe_scaled, 1);
   if (s.wr == 0) __builtin_amdgcn_s_barrier();  // re-balance the barrier count
 
-  epilogue<MMA, OUT_DT>(w.acc, p, lds, s.bm0, s.bn0, s.wr, s.wc, s.lane);
+  if constexpr (SILU) epilogue_silu<MMA, OUT_DT>(w.acc, p, lds, s.bm0, s.bn0, s.wr, s.wc, s.lane);
+  else epilogue<MMA, OUT_DT>(w.acc, p, lds, s.bm0, s.bn0, s.wr, s.wc, s.lane);
   CONCH_PROBE(g_probe_scaled, 3);
 }
 
@@ -432,21 +515,27 @@ bool scaled_gemm_mfma_supported(const ScaledGemmArgs& p) {
   if (((uintptr_t)p.a & 15) || ((uintptr_t)p.b & 15) || ((uintptr_t)p.c & 1)) return false;
   // 32-bit buffer offsets
   const int64_t lim = (int64_t)1 << 31;
-  if (p.m * p.a_stride_m >= lim || p.n * p.b_stride_n >= lim) return false;
-  if (p.m >= (1 << 24) || p.n >= (1 << 24)) return false;
+  const int64_t b_cols = p.fuse_silu ? 2 * p.n : p.n;
+  if (p.m * p.a_stride_m >= lim || b_cols * p.b_stride_n >= lim) return false;
+  if (p.m >= (1 << 24) || b_cols >= (1 << 24)) return false;
+  if (p.fuse_silu && p.k < 2 * kStepBytes) return false;  // the fused epilogue lives in the two-phase kernel only
   return true;
 }
 
 int launch_scaled_gemm_mfma(const ScaledGemmArgs& p, int variant, hipStream_t stream) {
+  const int tile_n = p.fuse_silu ? kTileN / 2 : kTileN;
   const int tiles_m = (int)((p.m + kTileM - 1) / kTileM);
-  const int tiles_n = (int)((p.n + kTileN - 1) / kTileN);
+  const int tiles_n = (int)((p.n + tile_n - 1) / tile_n);
+  if (p.fuse_silu) variant = 5;
   const dim3 grid((unsigned)(tiles_m * tiles_n));
 #define CONCH_LAUNCH(MMA, OUT)                                                                           \
   do {                                                                                                   \
     if (variant == 2)                                                                                    \
       hipLaunchKernelGGL((scaled_gemm_simple_kernel<MMA, OUT>), grid, dim3(kThreads), 0, stream, p);     \
+    else if (p.fuse_silu)                                                                                \
+      hipLaunchKernelGGL((scaled_gemm_pp2_kernel<MMA, OUT, true>), grid, dim3(kThreads), 0, stream, p);  \
     else if (variant != 3 && p.k >= 2 * kStepBytes)                                                      \
-      hipLaunchKernelGGL((scaled_gemm_pp2_kernel<MMA, OUT>), grid, dim3(kThreads), 0, stream, p);        \
+      hipLaunchKernelGGL((scaled_gemm_pp2_kernel<MMA, OUT, false>), grid, dim3(kThreads), 0, stream, p); \
     else                                                                                                 \
       hipLaunchKernelGGL((scaled_gemm_pingpong_kernel<MMA, OUT>), grid, dim3(kThreads), 0, stream, p); \
     return check_launch("scaled_gemm_mfma");                                                             \

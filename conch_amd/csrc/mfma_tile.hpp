@@ -59,8 +59,14 @@ struct StageOffsets {
   int off[4][2];
 };
 
+// `wave_col_cols` = columns a wave-column owns in V1 (and again in V2), `v2_delta` = column distance from a V1 row to
+// the V2 row of the same unit row.  Plain GEMM: 64-column wave-columns whose second 32 columns sit in V2 (32, 32 -- the
+// defaults).  Fused gate/up GEMM (scaled_gemm_silu_and_mul): a wave-column owns 32 OUTPUT columns, V1 holds their gate
+// columns and V2 the matching up columns n_out further right, so that a lane's accumulators hold gate and up of the same
+// eight outputs.  V1 rows are clamped to n_max, V2 rows follow their V1 row.
 __device__ __forceinline__ StageOffsets make_stage_offsets(int wave, int lane, int bm0, int bn0,
-                                                           int m_max, int n_max, int lda, int ldb) {
+                                                           int m_max, int n_max, int lda, int ldb,
+                                                           int wave_col_cols = 64, int v2_delta = 32) {
   StageOffsets s;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -70,11 +76,17 @@ __device__ __forceinline__ StageOffsets make_stage_offsets(int wave, int lane, i
     const int mrow = (rho >> 6) * 128 + (rho & 63);
     // V kinds: unit row -> block n, permuted so that MFMA D rows 4g+e of tile t are n = 8g+e+4t
     const int r5 = rho & 31, r = r5 & 15, t = r5 >> 4;
-    const int nrow = (rho >> 5) * 64 + 8 * (r >> 2) + (r & 3) + 4 * t;
+    const int nrow = (rho >> 5) * wave_col_cols + 8 * (r >> 2) + (r & 3) + 4 * t;
     s.off[kU1][j] = min(bm0 + mrow, m_max) * lda + chunk * 16;
     s.off[kU2][j] = min(bm0 + mrow + 64, m_max) * lda + chunk * 16;
-    s.off[kV1][j] = min(bn0 + nrow, n_max) * ldb + chunk * 16;
-    s.off[kV2][j] = min(bn0 + nrow + 32, n_max) * ldb + chunk * 16;
+    if (v2_delta == 32) {
+      s.off[kV1][j] = min(bn0 + nrow, n_max) * ldb + chunk * 16;
+      s.off[kV2][j] = min(bn0 + nrow + 32, n_max) * ldb + chunk * 16;
+    } else {
+      const int n1 = min(bn0 + nrow, n_max);
+      s.off[kV1][j] = n1 * ldb + chunk * 16;
+      s.off[kV2][j] = (n1 + v2_delta) * ldb + chunk * 16;
+    }
   }
   return s;
 }

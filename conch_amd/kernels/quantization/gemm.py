@@ -100,7 +100,9 @@ def _scaled_gemm_call(
     metadata: ScaledMatmulMetadata,
     bias: torch.Tensor | None,
     extra: tuple = (),
+    n_out: int | None = None,
 ) -> int:
+    """`n_out`: columns of `output` when they are not metadata.n_dim (the fused gate/up form passes N / 2)."""
     _C.require_device(output, a, b, scale_a, scale_b, bias)
     if a.dtype != b.dtype:
         raise ValueError(f"a and b must share a dtype (a: {a.dtype}, b: {b.dtype})")
@@ -123,7 +125,7 @@ def _scaled_gemm_call(
         _C.ptr(sb),
         _C.ptr(bias),
         metadata.m_dim,
-        metadata.n_dim,
+        metadata.n_dim if n_out is None else n_out,
         metadata.k_dim,
         a.stride(0),
         a.stride(1),
@@ -157,6 +159,32 @@ def scaled_gemm_launcher(
     """
     status = _scaled_gemm_call("conch_scaled_gemm", output, a, b, scale_a, scale_b, metadata, bias)
     _C.check(status, "scaled_gemm")
+
+
+def scaled_gemm_silu_and_mul_launcher(
+    output: torch.Tensor,
+    a: torch.Tensor,
+    b: torch.Tensor,
+    scale_a: torch.Tensor,
+    scale_b: torch.Tensor,
+    metadata: ScaledMatmulMetadata,
+    bias: torch.Tensor | None = None,
+) -> None:
+    """output[:, j] = silu(G[:, j]) * G[:, N/2 + j] with G = scaled_gemm(a, b, ...), in one launch.
+
+    The FFN pair `silu_and_mul(scaled_gemm(...))` of the reference (scaled_gemm_launcher,
+    kernels/quantization/gemm.py:564-627, then silu_and_mul_launcher, ops/activation/silu_and_mul.py:11-29) with the
+    same roundings.  `metadata` describes the GEMM (n_dim = 2 x output columns).
+    """
+    if metadata.n_dim % 2:
+        raise ValueError(f"scaled_gemm_silu_and_mul: B needs an even number of columns [gate | up], got {metadata.n_dim}")
+    if output.shape != (metadata.m_dim, metadata.n_dim // 2):
+        raise ValueError(f"output shape {tuple(output.shape)} != ({metadata.m_dim}, {metadata.n_dim // 2})")
+    if output.stride(1) != 1:
+        raise ValueError("scaled_gemm_silu_and_mul: output needs unit column stride")
+    status = _scaled_gemm_call("conch_scaled_gemm_silu_and_mul", output, a, b, scale_a, scale_b, metadata, bias,
+                               n_out=metadata.n_dim // 2)
+    _C.check(status, "scaled_gemm_silu_and_mul")
 
 
 def _mixed_gemm_call(

@@ -9,10 +9,15 @@ from __future__ import annotations
 
 import torch
 
-from conch_amd.kernels.quantization.gemm import mixed_precision_gemm_launcher, scaled_gemm_launcher
+from conch_amd.kernels.quantization.gemm import (
+    mixed_precision_gemm_launcher,
+    scaled_gemm_launcher,
+    scaled_gemm_silu_and_mul_launcher,
+)
 from conch_amd.ops.quantization._metadata import create_mixed_precision_metadata, create_scaled_metadata
 
-__all__ = ["create_mixed_precision_metadata", "create_scaled_metadata", "mixed_precision_gemm", "scaled_gemm"]
+__all__ = ["create_mixed_precision_metadata", "create_scaled_metadata", "mixed_precision_gemm", "scaled_gemm",
+           "scaled_gemm_silu_and_mul"]
 
 
 def mixed_precision_gemm(x: torch.Tensor, w_q_packed: torch.Tensor, w_s: torch.Tensor, w_zp: torch.Tensor | None,
@@ -37,4 +42,18 @@ def scaled_gemm(a: torch.Tensor, b: torch.Tensor, scale_a: torch.Tensor, scale_b
     out = a.new_empty((meta.m_dim, meta.n_dim), dtype=output_dtype)
     # bias goes into the kernel epilogue (the reference runs a separate in-place add afterwards)
     scaled_gemm_launcher(out, a, b, scale_a, scale_b, meta, bias=bias)
+    return out
+
+
+def scaled_gemm_silu_and_mul(a: torch.Tensor, b: torch.Tensor, scale_a: torch.Tensor, scale_b: torch.Tensor,
+                             output_dtype: torch.dtype, bias: torch.Tensor | None = None, strict: bool = False) -> torch.Tensor:
+    """silu_and_mul(scaled_gemm(a, b, scale_a, scale_b, output_dtype, bias)) in one launch.
+
+    `b` is (K, 2d) = [gate | up]; the result is (M, d): silu(G[:, :d]) * G[:, d:] where G is what `scaled_gemm` would
+    return -- never written to memory.  Same arguments as `scaled_gemm`; the reference runs the two ops
+    (conch.ops.quantization.gemm.scaled_gemm, conch.ops.activation.silu_and_mul) back to back.
+    """
+    meta = create_scaled_metadata(a, b, scale_a, scale_b, output_dtype, strict=strict)
+    out = a.new_empty((meta.m_dim, meta.n_dim // 2), dtype=output_dtype)
+    scaled_gemm_silu_and_mul_launcher(out, a, b, scale_a, scale_b, meta, bias=bias)
     return out

@@ -121,6 +121,23 @@ int conch_scaled_gemm(void* c, const void* a, const void* b, const float* scale_
                       void* stream);
 
 /*
+ * scaled_gemm_silu_and_mul  (the FFN pair `silu_and_mul(scaled_gemm(a, b, ...))` in one launch;
+ * replaces scaled_gemm_launcher, kernels/quantization/gemm.py:564-627, followed by silu_and_mul_launcher,
+ * conch/ops/activation/silu_and_mul.py:11-29; semantics = reference/quantization/scaled_gemm.py:12-27 then
+ * reference/activation/silu_and_mul.py:13-16, every intermediate rounded to out_dtype as torch does)
+ *   G = conch_scaled_gemm(...) with N = 2 * n_out columns [gate | up]          (never written to memory)
+ *   C[m][j] = out_dtype( out_dtype( silu((float) G[m][j]) ) * (float) G[m][n_out + j] ),   j < n_out
+ * B: [K][2 n_out]; scale_b_numel = 1 or 2 n_out; bias NULL or [2 n_out]; C: [M][n_out], unit column stride.
+ * Layouts outside the tiled kernel's contract run the plain GEMM into library scratch followed by an elementwise pass.
+ */
+int conch_scaled_gemm_silu_and_mul(void* c, const void* a, const void* b, const float* scale_a,
+                                   const float* scale_b, const void* bias, int64_t m, int64_t n_out, int64_t k,
+                                   int64_t a_stride_m, int64_t a_stride_k, int64_t b_stride_k,
+                                   int64_t b_stride_n, int64_t c_stride_m, int64_t c_stride_n,
+                                   int64_t scale_a_numel, int64_t scale_b_numel, int in_dtype, int out_dtype,
+                                   void* stream);
+
+/*
  * mixed_precision_gemm  (replaces kernels/quantization/gemm.py:482-545;
  * dequantisation semantics = kernels/quantization/gemm.py:176-216, bit-identical to the w_ref of
  * third_party/vllm/quant_utils.py:74)
@@ -145,6 +162,12 @@ int conch_mixed_precision_gemm(void* c, const void* x, const int32_t* w_q_packed
  */
 int conch_time_scaled_gemm(void* c, const void* a, const void* b, const float* scale_a,
                            const float* scale_b, const void* bias, int64_t m, int64_t n, int64_t k,
+                           int64_t a_stride_m, int64_t a_stride_k, int64_t b_stride_k,
+                           int64_t b_stride_n, int64_t c_stride_m, int64_t c_stride_n,
+                           int64_t scale_a_numel, int64_t scale_b_numel, int in_dtype,
+                           int out_dtype, void* stream, int iters, float* avg_ms);
+int conch_time_scaled_gemm_silu_and_mul(void* c, const void* a, const void* b, const float* scale_a,
+                           const float* scale_b, const void* bias, int64_t m, int64_t n_out, int64_t k,
                            int64_t a_stride_m, int64_t a_stride_k, int64_t b_stride_k,
                            int64_t b_stride_n, int64_t c_stride_m, int64_t c_stride_n,
                            int64_t scale_a_numel, int64_t scale_b_numel, int in_dtype,

@@ -25,6 +25,8 @@ from oracle.reference import (  # noqa: F401
     quantize_weights_ref,
     scaled_fp8_quant_ref,
     scaled_gemm_ref,
+    scaled_gemm_silu_and_mul_ref,
     scaled_int8_quant_ref,
+    silu_and_mul_ref,
     unpack_rows_ref,
 )

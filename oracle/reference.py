@@ -134,6 +134,29 @@ def scaled_gemm_ref(
     return res
 
 
+def silu_and_mul_ref(x: torch.Tensor) -> torch.Tensor:
+    """conch/reference/activation/silu_and_mul.py:13-16: silu(x[..., :d]) * x[..., d:], d = last dim // 2.
+
+    In a 16-bit dtype torch rounds after each of the two ops: silu is evaluated in fp32 and rounded to the tensor
+    dtype, the product of the two 16-bit tensors is rounded again.
+    """
+    d = x.shape[-1] // 2
+    return torch.nn.functional.silu(x[..., :d]) * x[..., d:]
+
+
+def scaled_gemm_silu_and_mul_ref(
+    a: torch.Tensor,
+    b: torch.Tensor,
+    scale_a: torch.Tensor,
+    scale_b: torch.Tensor,
+    out_dtype: torch.dtype,
+    bias: torch.Tensor | None = None,
+) -> torch.Tensor:
+    """The FFN pair the fused op replaces: the reference's scaled_gemm
+    (reference/quantization/scaled_gemm.py:12-27) on B = [gate | up], then its silu_and_mul."""
+    return silu_and_mul_ref(scaled_gemm_ref(a, b, scale_a, scale_b, out_dtype, bias))
+
+
 # --------------------------------------------------------------------------------------
 # Weight quantisation / packing (the on-device int4/int8 format and the mixed oracle)
 # --------------------------------------------------------------------------------------

@@ -161,11 +161,36 @@ def gen_mixed() -> None:
     np.savez_compressed(OUT / "mixed_gemm.npz", **out)
 
 
+def gen_scaled_gemm_silu() -> None:
+    """the FFN pair scaled_gemm -> silu_and_mul, both from the reference.
+
+    Input: the reference's scaled_gemm outputs already stored in scaled_gemm.npz (c_<key>, 128 x 128: 64 gate + 64 up
+    columns); output: conch.reference.activation.silu_and_mul.silu_and_mul (reference/activation/silu_and_mul.py:13-16)
+    applied to them.  Only the new outputs are stored (y_<key>, 128 x 64).
+    """
+    from conch.reference.activation.silu_and_mul import silu_and_mul as ref_silu_and_mul
+
+    g = np.load(OUT / "scaled_gemm.npz")
+    out: dict[str, np.ndarray] = {}
+    for name in g.files:
+        if not name.startswith("c_"):
+            continue
+        key = name[2:]
+        odt = torch.float16 if "_f16_" in key else torch.bfloat16
+        c = torch.from_numpy(g[name].view(np.int16).copy()).view(odt)
+        out[f"y_{key}"] = bits(ref_silu_and_mul(c))
+    np.savez_compressed(OUT / "scaled_gemm_silu.npz", **out)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference checkout is only available in the authoring container"
     torch.set_num_threads(1)  # deterministic reduction order for the fp matmuls
+    if "--only-silu" in sys.argv:
+        gen_scaled_gemm_silu()
+        sys.exit(0)
     gen_quant()
     gen_scaled_gemm()
     gen_mixed()
+    gen_scaled_gemm_silu()
     for f in sorted(OUT.glob("*.npz")):
         print(f.name, f.stat().st_size)

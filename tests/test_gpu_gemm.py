@@ -17,7 +17,7 @@ import torch
 
 import oracle
 from conch_amd import _C
-from conch_amd.ops.quantization.gemm import mixed_precision_gemm, scaled_gemm
+from conch_amd.ops.quantization.gemm import mixed_precision_gemm, scaled_gemm, scaled_gemm_silu_and_mul
 from conch_amd.third_party.vllm.quant_utils import pack_rows, quantize_weights
 from conch_amd.third_party.vllm.scalar_type import scalar_types
 from conch_amd.third_party.vllm.utils import seed_everything
@@ -245,6 +245,94 @@ def test_scaled_gemm_c5_config_shard_invariance():
     rows = torch.cat([torch.arange(0, 16), torch.arange(8176, 8192)])
     ref = oracle.scaled_gemm_ref(a[rows.cuda()].cpu(), bt.cpu().T, sa[rows.cuda()].cpu(), sb.cpu(), torch.bfloat16, None)
     check_scaled(full[rows.cuda()], ref, torch.float8_e4m3fn, torch.bfloat16)
+
+
+# ---------------------------------------------------------------------------------------------
+# scaled_gemm_silu_and_mul: the FFN pair in one launch
+# ---------------------------------------------------------------------------------------------
+MANT = {torch.float16: 10, torch.bfloat16: 7}
+
+
+def check_silu(got, ref, out_dtype, exact_gemm):
+    """Against the CPU oracle (torch silu: libm-grade expf; device: v_exp_f32 / v_rcp_f32, 1 ulp each in fp32).
+
+    When the GEMM part is exact (int8): every element within TWO output ulps of the oracle (silu rounded to the output
+    dtype may land on the neighbouring value, which moves the rounded product by up to two ulps) and at most 0.2 % of the
+    elements off at all; with fp8 inputs the accumulation-order tolerance of the plain GEMM (2 eps of max|G|) feeds
+    through silu'(g) * u, so the bound is relative to max|y| like check_scaled's.
+    """
+    g, r = got.float().cpu(), ref.float()
+    # overflowed elements (fp16 output of the int8 recipe): same infinities / NaNs in the same places, bounds on the rest
+    fin = torch.isfinite(r)
+    assert torch.equal(torch.isnan(g), torch.isnan(r))
+    assert torch.equal(g[~fin & ~torch.isnan(r)], r[~fin & ~torch.isnan(r)])
+    g, r = g[fin], r[fin]
+    if exact_gemm:
+        ulp = torch.maximum(torch.ldexp(torch.ones_like(r), torch.frexp(r)[1] - 1 - MANT[out_dtype]),
+                            torch.full_like(r, 2.0 ** -24))
+        assert ((g - r).abs() <= 2 * ulp).all(), f"max |diff| / ulp = {((g - r).abs() / ulp).max().item():.2f}"
+        assert (g != r).float().mean().item() <= 2e-3
+    else:
+        tol = 4.0 * EPS[out_dtype] * max(r.abs().max().item(), 1e-6)
+        assert (g - r).abs().max().item() <= tol
+
+
+def run_silu(a, b, sa, sb, out_dtype, bias):
+    dev = lambda t: None if t is None else t.cuda()  # noqa: E731
+    b_dev = b.T.contiguous().cuda().T if b.stride(0) == 1 else b.cuda()
+    return scaled_gemm_silu_and_mul(dev(a), b_dev, dev(sa), dev(sb), out_dtype, dev(bias))
+
+
+@pytest.mark.parametrize("iname", list(IN_T))
+@pytest.mark.parametrize("oname", ["f16", "bf16"])
+@pytest.mark.parametrize("key_tail", ["sa1_sb1_b1", "sa0_sb0_b1", "sa0_sb0_b0", "sa1_sb0_b0"])
+def test_scaled_gemm_silu_golden_from_reference(golden, iname, oname, key_tail):
+    """Inputs of the reference-generated scaled_gemm fixtures, expected outputs = the reference's silu_and_mul of the
+    reference's scaled_gemm (tests/golden/scaled_gemm_silu.npz).  e4m3fnuz takes the unfused fallback."""
+    g, y = golden("scaled_gemm"), golden("scaled_gemm_silu")
+    key = f"{iname}_{oname}_{key_tail}"
+    a = from_bits(g[f"a_{key}"], IN_T[iname])
+    b = from_bits(g[f"bt_{key}"], IN_T[iname]).T
+    sa, sb = torch.from_numpy(g[f"sa_{key}"]), torch.from_numpy(g[f"sb_{key}"])
+    bias = from_bits(g[f"bias_{key}"], DT[oname]) if key_tail.endswith("b1") else None
+    got = run_silu(a, b, sa, sb, DT[oname], bias)
+    assert got.shape == (128, 64) and got.dtype == DT[oname]
+    check_silu(got, from_bits(y[f"y_{key}"], DT[oname]), DT[oname], exact_gemm=iname == "int8")
+
+
+@pytest.mark.parametrize("iname", ["int8", "fn"])
+@pytest.mark.parametrize(("m", "k", "d"), [(1024, 1024, 512), (300, 384, 260), (257, 256, 8), (512, 1152, 1376), (64, 2048, 96)])
+def test_scaled_gemm_silu_shapes_fused_equals_unfused(iname, m, k, d):
+    """Ragged M / d (partial tiles, d not a multiple of 8 or 128): (1) against the oracle; (2) the fused kernel equals the
+    library's own unfused pair (plain GEMM into scratch + elementwise pass, forced with variant 2) bit for bit -- the
+    fused tile only re-pairs columns, every output sees the same MFMA sequence and the same epilogue arithmetic."""
+    a, b, sa, sb, bias = make_scaled_inputs(m, k, 2 * d, IN_T[iname], torch.bfloat16, False, False, True)
+    ref = oracle.scaled_gemm_silu_and_mul_ref(a, b, sa, sb, torch.bfloat16, bias)
+    got = run_silu(a, b, sa, sb, torch.bfloat16, bias)
+    check_silu(got, ref, torch.bfloat16, exact_gemm=iname == "int8")
+    _C.set_gemm_variant(_C.VARIANT_MFMA_SIMPLE)
+    unfused = run_silu(a, b, sa, sb, torch.bfloat16, bias)
+    _C.set_gemm_variant(_C.VARIANT_AUTO)
+    assert torch.equal(got, unfused)
+
+
+def test_scaled_gemm_silu_llama_ffn_shape():
+    """The C3 weights as a gate/up pair (Llama-7B FFN: K = 4096, d = 11008, 4096 tokens) at full size: fused equals
+    unfused bit for bit everywhere; bands of rows against the oracle."""
+    m, k, d = 4096, 4096, 11008
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    a = (0.25 * torch.rand((m, k), device="cuda", generator=gen)).to(torch.float8_e4m3fn)
+    bt = (0.25 * torch.rand((2 * d, k), device="cuda", generator=gen) - 0.125).to(torch.float8_e4m3fn)
+    sa = 0.25 * torch.rand((m, 1), device="cuda", generator=gen)
+    sb = 0.25 * torch.rand((2 * d, 1), device="cuda", generator=gen)
+    got = scaled_gemm_silu_and_mul(a, bt.T, sa, sb, torch.bfloat16)
+    _C.set_gemm_variant(_C.VARIANT_MFMA_SIMPLE)
+    unfused = scaled_gemm_silu_and_mul(a, bt.T, sa, sb, torch.bfloat16)
+    _C.set_gemm_variant(_C.VARIANT_AUTO)
+    assert torch.equal(got, unfused)
+    rows = torch.cat([torch.arange(0, 24), torch.arange(4072, 4096)])
+    ref = oracle.scaled_gemm_silu_and_mul_ref(a[rows.cuda()].cpu(), bt.cpu().T, sa[rows.cuda()].cpu(), sb.cpu(), torch.bfloat16, None)
+    check_silu(got[rows.cuda()], ref, torch.bfloat16, exact_gemm=False)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -101,6 +101,21 @@ def test_scaled_gemm(golden, iname, oname, sa_s, sb_s, use_bias):
     np.testing.assert_array_equal(to_bits(c), g[f"c_{key}"])
 
 
+@pytest.mark.parametrize(("iname", "oname", "sa_s", "sb_s", "use_bias"), GEMM_KEYS)
+def test_scaled_gemm_silu_and_mul(golden, iname, oname, sa_s, sb_s, use_bias):
+    """The FFN pair (scaled_gemm -> silu_and_mul), expected outputs from the reference's two functions."""
+    g, y = golden("scaled_gemm"), golden("scaled_gemm_silu")
+    key = f"{iname}_{oname}_sa{sa_s}_sb{sb_s}_b{use_bias}"
+    a = from_bits(g[f"a_{key}"], IN_T[iname])
+    b = from_bits(g[f"bt_{key}"], IN_T[iname]).T
+    sa = torch.from_numpy(g[f"sa_{key}"])
+    sb = torch.from_numpy(g[f"sb_{key}"])
+    bias = from_bits(g[f"bias_{key}"], DT[oname]) if use_bias else None
+    got = oracle.scaled_gemm_silu_and_mul_ref(a, b, sa, sb, DT[oname], bias)
+    assert got.shape == (a.shape[0], b.shape[1] // 2)
+    np.testing.assert_array_equal(to_bits(got), y[f"y_{key}"])
+
+
 MIXED_KEYS = [(w, z, d) for w in ("uint4b8", "uint8b128", "uint4", "uint8") for z in (1, 0) for d in ("f16", "bf16")]
 
 

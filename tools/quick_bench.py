@@ -103,6 +103,50 @@ if __name__ == "__main__":
                 print(f"mixed int{bits} {str(dtype)[6:]} {m}x{k}x{n}: " + "  ".join(
                     f"v{v}: {statistics.median(t)*1e3:.1f}us ({2.0*m*n*k/(statistics.median(t)*1e-3)/1e12:.0f} TF)" for v, t in res.items()), flush=True)
         sys.exit(0)
+    if "--silu" in sys.argv:
+        # FFN pair: fused scaled_gemm_silu_and_mul against the unfused pair (default scaled_gemm on [gate | up], then
+        # torch's silu-and-mul on the result), back-to-back launches after a warm-up, HIP events
+        import statistics
+        from conch_amd.ops.quantization.gemm import scaled_gemm, scaled_gemm_silu_and_mul
+
+        def ev(fn, iters=50):
+            s0, e0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s0.record()
+            for _ in range(iters):
+                fn()
+            e0.record()
+            torch.cuda.synchronize()
+            return s0.elapsed_time(e0) / iters * 1e3
+
+        for dtype in (torch.float8_e4m3fn, torch.int8):
+            for (m, k, d) in [(4096, 4096, 11008), (8192, 8192, 14336), (1024, 4096, 11008)]:
+                torch.manual_seed(0)
+                if dtype == torch.int8:
+                    a = torch.randint(-32, 32, (m, k), dtype=torch.int8, device="cuda")
+                    bt = torch.randint(-32, 32, (2 * d, k), dtype=torch.int8, device="cuda")
+                else:
+                    a = (0.25 * torch.rand((m, k), device="cuda")).to(dtype)
+                    bt = (0.25 * torch.rand((2 * d, k), device="cuda") - 0.125).to(dtype)
+                sa = 0.01 * torch.rand((m, 1), device="cuda")
+                sb = 0.01 * torch.rand((2 * d, 1), device="cuda")
+                fused = lambda: scaled_gemm_silu_and_mul(a, bt.T, sa, sb, torch.bfloat16)  # noqa: E731
+                gemm = lambda: scaled_gemm(a, bt.T, sa, sb, torch.bfloat16)  # noqa: E731
+
+                def pair():
+                    g = scaled_gemm(a, bt.T, sa, sb, torch.bfloat16)
+                    return torch.nn.functional.silu(g[:, :d]) * g[:, d:]
+
+                for _ in range(200):
+                    fused()
+                res = {"fused": [], "gemm only": [], "gemm + torch silu*mul": []}
+                for _ in range(5):
+                    res["fused"].append(ev(fused))
+                    res["gemm only"].append(ev(gemm))
+                    res["gemm + torch silu*mul"].append(ev(pair))
+                flops = 2.0 * m * (2 * d) * k
+                print(f"{str(dtype)[6:]:14s} M={m} K={k} d={d}: " + "  ".join(
+                    f"{name} {statistics.median(v):.1f} us ({flops / statistics.median(v) / 1e6:.0f} TFLOP/s)" for name, v in res.items()), flush=True)
+        sys.exit(0)
     if "--mixednt" in sys.argv:
         import statistics
         lib = _C.load()
