@@ -79,6 +79,10 @@ _SIGNATURES = {
         c_int,
         [c_void_p] * 5 + [_I64] * 8 + [c_int] * 6 + [c_void_p],
     ),
+    "conch_mixed_precision_gemm_silu_and_mul": (
+        c_int,
+        [c_void_p] * 5 + [_I64] * 8 + [c_int] * 6 + [c_void_p],
+    ),
     "conch_time_mixed_precision_gemm": (
         c_int,
         [c_void_p] * 5 + [_I64] * 8 + [c_int] * 6 + [c_void_p, c_int, ctypes.POINTER(c_float)],

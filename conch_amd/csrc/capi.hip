@@ -175,6 +175,23 @@ int run_mixed(const MixedGemmArgs& p, hipStream_t stream) {
   return launch_mixed_gemm_mfma(p, stream);
 }
 
+// mixed_precision_gemm_silu_and_mul: `p` describes the OUTPUT (n columns); Wq / w_s / w_zp have 2n columns [gate | up].
+int run_mixed_silu(const MixedGemmArgs& p, hipStream_t stream) {
+  MixedGemmArgs wide = p;
+  wide.fuse_silu = 0;
+  wide.n = 2 * p.n;
+  if (int rc = check_mixed(wide)) return rc;
+  if (p.m == 0 || p.n == 0) return CONCH_OK;
+  const int variant = tuning(CONCH_TUNE_GEMM_VARIANT);
+  if (variant != 1 && variant != 2 && mixed_gemm_mfma_supported(p)) return launch_mixed_gemm_mfma(p, stream);
+  void* tmp = nullptr;
+  if (int rc = get_scratch(stream, 3, (size_t)p.m * (size_t)wide.n * 2, &tmp)) return rc;
+  wide.c = tmp;
+  wide.c_stride_m = wide.n;
+  if (int rc = run_mixed(wide, stream)) return rc;
+  return launch_silu_and_mul(p.c, tmp, p.m, p.n, wide.n, p.c_stride_m, p.out_dtype, stream);
+}
+
 template <class F>
 int time_loop(F&& launch, hipStream_t stream, int iters, float* avg_ms) {
   CONCH_CHECK_ARG(iters > 0 && avg_ms, "timing: iters=%d avg_ms=%p", iters, (void*)avg_ms);
@@ -273,6 +290,18 @@ extern "C" int conch_mixed_precision_gemm(void* c, const void* x, const int32_t*
                         wzp_stride_g, c_stride_m, weight_bits, weight_bias, group_size, zp_mode, x_dtype,
                         out_dtype};
   return run_mixed(p, (hipStream_t)stream);
+}
+
+extern "C" int conch_mixed_precision_gemm_silu_and_mul(void* c, const void* x, const int32_t* w_q_packed, const void* w_s,
+                                                       const int32_t* w_zp, int64_t m, int64_t n_out, int64_t k,
+                                                       int64_t x_stride_m, int64_t wq_stride_k, int64_t ws_stride_g,
+                                                       int64_t wzp_stride_g, int64_t c_stride_m, int weight_bits,
+                                                       int weight_bias, int group_size, int zp_mode, int x_dtype,
+                                                       int out_dtype, void* stream) {
+  MixedGemmArgs p{c, x, w_q_packed, w_s, w_zp, m, n_out, k, x_stride_m, wq_stride_k, ws_stride_g,
+                  wzp_stride_g, c_stride_m, weight_bits, weight_bias, group_size, zp_mode, x_dtype, out_dtype};
+  p.fuse_silu = 1;
+  return run_mixed_silu(p, (hipStream_t)stream);
 }
 
 extern "C" int conch_time_mixed_precision_gemm(void* c, const void* x, const int32_t* w_q_packed,

@@ -40,6 +40,9 @@ struct MixedGemmArgs {
   int64_t c_stride_m;
   int bits, weight_bias, group_size, zp_mode;
   int x_dtype, out_dtype;
+  // 1 = fused gate/up FFN form (conch_mixed_precision_gemm_silu_and_mul): Wq / w_s / w_zp have 2n columns [gate | up],
+  // C has n columns, C[i][j] = silu(G[i][j]) * G[i][n + j] with G = the plain product rounded to out_dtype
+  int fuse_silu = 0;
 };
 
 // gemm_generic.hip

@@ -83,6 +83,39 @@ __device__ __forceinline__ void mixed_epilogue(const MixedTile& w, const MixedGe
   }
 }
 
+// Fused gate/up epilogue: g = cast(acc_gate), u = cast(acc_up) (what the plain kernel would store), then the reference's
+// silu_and_mul with its roundings: s = cast(silu(g)), y = cast(s * u) (reference/activation/silu_and_mul.py:13-16).
+template <int OUT_DT>
+__device__ __forceinline__ void mixed_epilogue_silu(const MixedTile& w, const MixedGemmArgs& p, int bm0, int bn0, int wr, int wc, int lane) {
+  const int g = lane >> 4, jm = lane & 15;
+  const bool vec_store = (p.c_stride_m % 8 == 0) && (((uintptr_t)p.c & 15) == 0);
+  const int n0 = bn0 + wc * 32 + 8 * g;
+#pragma unroll
+  for (int mt = 0; mt < 8; ++mt) {
+    const int m = bm0 + wr * 128 + mt * 16 + jm;
+    if (m >= p.m) continue;
+    i32x4 pk;
+#pragma unroll
+    for (int e2 = 0; e2 < 4; ++e2) {
+      const int e = 2 * e2;
+      const f32x4& ag = w.acc[mt][e >> 2];
+      const f32x4& au = w.acc[mt][2 + (e >> 2)];
+      const f32x2 gv = unpack2_bits16<OUT_DT>(pack2_bits16<OUT_DT>(f32x2{ag[e & 3], ag[(e & 3) + 1]}));
+      const uint32_t ub = pack2_bits16<OUT_DT>(f32x2{au[e & 3], au[(e & 3) + 1]});
+      const f32x2 sv = unpack2_bits16<OUT_DT>(pack2_bits16<OUT_DT>(pin_f32x2(f32x2{silu_f32(gv[0]), silu_f32(gv[1])})));
+      pk[e2] = (int)pack2_bits16<OUT_DT>(pin_f32x2(sv * unpack2_bits16<OUT_DT>(ub)));
+    }
+    uint16_t* dst = (uint16_t*)p.c + (int64_t)m * p.c_stride_m + n0;
+    if (vec_store && n0 + 8 <= p.n) {
+      *(i32x4*)dst = pk;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (n0 + e < p.n) dst[e] = (uint16_t)((uint32_t)pk[e >> 1] >> (16 * (e & 1)));
+    }
+  }
+}
+
 // Weight words, scales and zero points of one thread for one K step.
 template <int BITS, int NT>
 struct WeightRegs {
@@ -402,9 +435,13 @@ __device__ __forceinline__ void mixed_mainloop(MixedTile& w, WeightRegs<BITS, NT
 __device__ unsigned long long g_probe_mixed[kProbeBlocks * 8];
 #endif
 
-template <int X_DT, int OUT_DT, int BITS, int ZP, int NT>
+template <int X_DT, int OUT_DT, int BITS, int ZP, int NT, bool SILU = false>
 __global__ __launch_bounds__(kThreads, 2) void mixed_gemm_kernel(MixedGemmArgs p) {
-  constexpr int kTileW = 64 * NT;
+  static_assert(!SILU || NT == 4, "the fused gate/up form pairs the V1 and V2 units of a full-width tile");
+  // SILU (conch_mixed_precision_gemm_silu_and_mul): a tile is 256 rows x 128 OUTPUT columns; a wave-column owns 32 of
+  // them, V1 holds their gate columns and V2 the up columns p.n further right, so accumulator tiles 0,1 / 2,3 of a lane
+  // are gate / up of the same eight outputs (same construction as gemm_mfma.hip's fused epilogue).
+  constexpr int kTileW = SILU ? 128 : 64 * NT;
   constexpr int kWpc = WeightRegs<BITS, NT>::kWpc;
   constexpr int kWordRowsPerStep = kStepK * BITS / 32;
   __shared__ __attribute__((aligned(1024))) char lds[kMixedLdsBytes];
@@ -428,11 +465,12 @@ __global__ __launch_bounds__(kThreads, 2) void mixed_gemm_kernel(MixedGemmArgs p
   const int rho = threadIdx.x & 127;
   const int cp = c.wave >> 1;  // = threadIdx.x >> 7, wave-uniform
   const int r5 = rho & 31, r = r5 & 15, tq = r5 >> 4;
-  const int wcol = (rho >> 5) * 16 * NT;
+  const int wcol = (rho >> 5) * (SILU ? 32 : 16 * NT);
   const int pair = 8 * (r >> 2) + (r & 3) + 4 * tq;
   const int row2 = NT == 4 ? rho : (rho & ~16);
   const int n1 = min(bn0 + wcol + pair, (int)p.n - 1);
-  const int n2 = min(bn0 + wcol + 32 + (NT == 4 ? pair : r), (int)p.n - 1);
+  const int n2 = SILU ? n1 + (int)p.n : min(bn0 + wcol + 32 + (NT == 4 ? pair : r), (int)p.n - 1);
+  const int64_t w_cols = SILU ? 2 * p.n : p.n;  // columns of the weight / scale / zero-point arrays
   {
     const int row[4] = {rho, rho, row2, row2};
     const int dchunk[4] = {0, 4, NT == 4 ? 0 : 4 * tq, 4};  // chunk - cp
@@ -447,11 +485,11 @@ __global__ __launch_bounds__(kThreads, 2) void mixed_gemm_kernel(MixedGemmArgs p
     c.ln.vz[0] = n1 * 4; c.ln.vz[1] = n2 * 4;
   }
   const int64_t word_rows = p.k * BITS / 32, groups = p.k / p.group_size;
-  c.ws.q = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_q, 0, (uint32_t)(((word_rows - 1) * p.wq_stride_k + p.n) * 4), 0x00020000);
-  c.ws.s = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_s, 0, (uint32_t)(((groups - 1) * p.ws_stride_g + p.n) * 2), 0x00020000);
+  c.ws.q = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_q, 0, (uint32_t)(((word_rows - 1) * p.wq_stride_k + w_cols) * 4), 0x00020000);
+  c.ws.s = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_s, 0, (uint32_t)(((groups - 1) * p.ws_stride_g + w_cols) * 2), 0x00020000);
   c.ws.z = c.ws.s;
   if constexpr (ZP == CONCH_ZP_TENSOR)
-    c.ws.z = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_zp, 0, (uint32_t)(((groups - 1) * p.wzp_stride_g + p.n) * 4), 0x00020000);
+    c.ws.z = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_zp, 0, (uint32_t)(((groups - 1) * p.wzp_stride_g + w_cols) * 4), 0x00020000);
   c.ws.q_row = (int)p.wq_stride_k * 4;
   c.ws.q_step = kWordRowsPerStep * c.ws.q_row;
   c.ws.s_group = (int)p.ws_stride_g * 2;
@@ -505,12 +543,30 @@ __global__ __launch_bounds__(kThreads, 2) void mixed_gemm_kernel(MixedGemmArgs p
   }
 #endif
 
-  mixed_epilogue<X_DT, OUT_DT, NT>(w, p, bm0, bn0, wr, wc, lane);
+  if constexpr (SILU) mixed_epilogue_silu<OUT_DT>(w, p, bm0, bn0, wr, wc, lane);
+  else mixed_epilogue<X_DT, OUT_DT, NT>(w, p, bm0, bn0, wr, wc, lane);
 }
 
 template <int X_DT, int OUT_DT, int BITS, int NT>
 int launch_zp(const MixedGemmArgs& p, hipStream_t stream) {
   const int tiles_m = (int)((p.m + kTileM - 1) / kTileM);
+  if constexpr (NT == 4) {
+    if (p.fuse_silu) {
+      const dim3 grid((unsigned)(tiles_m * (int)((p.n + 127) / 128)));
+      switch (p.zp_mode) {
+        case CONCH_ZP_NONE:
+          hipLaunchKernelGGL((mixed_gemm_kernel<X_DT, OUT_DT, BITS, CONCH_ZP_NONE, 4, true>), grid, dim3(kThreads), 0, stream, p);
+          break;
+        case CONCH_ZP_SCALAR:
+          hipLaunchKernelGGL((mixed_gemm_kernel<X_DT, OUT_DT, BITS, CONCH_ZP_SCALAR, 4, true>), grid, dim3(kThreads), 0, stream, p);
+          break;
+        default:
+          hipLaunchKernelGGL((mixed_gemm_kernel<X_DT, OUT_DT, BITS, CONCH_ZP_TENSOR, 4, true>), grid, dim3(kThreads), 0, stream, p);
+          break;
+      }
+      return check_launch("mixed_gemm_mfma_silu");
+    }
+  }
   const int tiles_n = (int)((p.n + 64 * NT - 1) / (64 * NT));
   const dim3 grid((unsigned)(tiles_m * tiles_n));
   switch (p.zp_mode) {
@@ -573,8 +629,9 @@ bool mixed_gemm_mfma_supported(const MixedGemmArgs& p) {
   if (p.m >= (1 << 24) || p.n >= (1 << 24)) return false;
   // the weight arrays are addressed through 32-bit buffer offsets
   const int64_t lim32 = (int64_t)1 << 32;
-  if (((p.k * p.bits / 32) * p.wq_stride_k + p.n) * 4 >= lim32 || ((p.k / p.group_size) * p.ws_stride_g + p.n) * 2 >= lim32) return false;
-  if (p.zp_mode == CONCH_ZP_TENSOR && ((p.k / p.group_size) * p.wzp_stride_g + p.n) * 4 >= lim32) return false;
+  const int64_t w_cols = p.fuse_silu ? 2 * p.n : p.n;
+  if (((p.k * p.bits / 32) * p.wq_stride_k + w_cols) * 4 >= lim32 || ((p.k / p.group_size) * p.ws_stride_g + w_cols) * 2 >= lim32) return false;
+  if (p.zp_mode == CONCH_ZP_TENSOR && ((p.k / p.group_size) * p.wzp_stride_g + w_cols) * 4 >= lim32) return false;
   return true;
 }
 
@@ -587,7 +644,7 @@ int launch_mixed_gemm_mfma(const MixedGemmArgs& p, hipStream_t stream) {
                prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
   }
   const int forced = tuning(1);  // CONCH_TUNE_MIXED_TILE_NT: 0 = auto, 2..4 = force
-  const int nt = (forced >= 2 && forced <= 4) ? forced : pick_nt(p, num_cus);
+  const int nt = p.fuse_silu ? 4 : (forced >= 2 && forced <= 4) ? forced : pick_nt(p, num_cus);
   if (p.x_dtype == CONCH_DT_FP16) {
     return p.out_dtype == CONCH_DT_FP16 ? launch_bits<CONCH_DT_FP16, CONCH_DT_FP16>(p, nt, stream)
                                         : launch_bits<CONCH_DT_FP16, CONCH_DT_BF16>(p, nt, stream);

@@ -196,7 +196,9 @@ def _mixed_gemm_call(
     zeros: torch.Tensor | None,
     metadata: MixedPrecisionMatmulMetadata,
     extra: tuple = (),
+    n_out: int | None = None,
 ) -> int:
+    """`n_out`: columns of `output` when they are not metadata.n_dim (the fused gate/up form passes N / 2)."""
     _C.require_device(output, x, w_q_packed, scales, zeros)
     if metadata.acc_dtype != torch.float32:
         raise NotImplementedError("mixed_precision_gemm accumulates in float32 only")
@@ -230,7 +232,7 @@ def _mixed_gemm_call(
         _C.ptr(scales),
         _C.ptr(zeros_t),
         metadata.m_dim,
-        metadata.n_dim,
+        metadata.n_dim if n_out is None else n_out,
         metadata.k_dim,
         x.stride(0),
         w_q_packed.stride(0),
@@ -261,3 +263,26 @@ def mixed_precision_gemm_launcher(
         raise ValueError("output must be contiguous in its last dimension")
     status = _mixed_gemm_call("conch_mixed_precision_gemm", output, x, w_q_packed, scales, zeros, metadata)
     _C.check(status, "mixed_precision_gemm")
+
+
+def mixed_precision_gemm_silu_and_mul_launcher(
+    output: torch.Tensor,
+    x: torch.Tensor,
+    w_q_packed: torch.Tensor,
+    scales: torch.Tensor,
+    zeros: torch.Tensor | None,
+    metadata: MixedPrecisionMatmulMetadata,
+) -> None:
+    """output[:, j] = silu(G[:, j]) * G[:, N/2 + j] with G = mixed_precision_gemm(x, w_q_packed, ...), in one launch.
+
+    The FFN pair `silu_and_mul(mixed_precision_gemm(...))` of the reference (mixed_precision_gemm_launcher,
+    kernels/quantization/gemm.py:482-545, then silu_and_mul_launcher, ops/activation/silu_and_mul.py:11-29) with the same
+    roundings.  `metadata` describes the GEMM (n_dim = 2 x output columns).
+    """
+    if metadata.n_dim % 2:
+        raise ValueError(f"mixed_precision_gemm_silu_and_mul: the weights need an even number of columns [gate | up], got {metadata.n_dim}")
+    if output.shape != (metadata.m_dim, metadata.n_dim // 2) or output.stride(1) != 1:
+        raise ValueError(f"output must be a ({metadata.m_dim}, {metadata.n_dim // 2}) tensor with unit column stride")
+    status = _mixed_gemm_call("conch_mixed_precision_gemm_silu_and_mul", output, x, w_q_packed, scales, zeros, metadata,
+                              n_out=metadata.n_dim // 2)
+    _C.check(status, "mixed_precision_gemm_silu_and_mul")

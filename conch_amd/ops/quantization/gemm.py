@@ -11,13 +11,14 @@ import torch
 
 from conch_amd.kernels.quantization.gemm import (
     mixed_precision_gemm_launcher,
+    mixed_precision_gemm_silu_and_mul_launcher,
     scaled_gemm_launcher,
     scaled_gemm_silu_and_mul_launcher,
 )
 from conch_amd.ops.quantization._metadata import create_mixed_precision_metadata, create_scaled_metadata
 
 __all__ = ["create_mixed_precision_metadata", "create_scaled_metadata", "mixed_precision_gemm", "scaled_gemm",
-           "scaled_gemm_silu_and_mul"]
+           "scaled_gemm_silu_and_mul", "mixed_precision_gemm_silu_and_mul"]
 
 
 def mixed_precision_gemm(x: torch.Tensor, w_q_packed: torch.Tensor, w_s: torch.Tensor, w_zp: torch.Tensor | None,
@@ -56,4 +57,18 @@ def scaled_gemm_silu_and_mul(a: torch.Tensor, b: torch.Tensor, scale_a: torch.Te
     meta = create_scaled_metadata(a, b, scale_a, scale_b, output_dtype, strict=strict)
     out = a.new_empty((meta.m_dim, meta.n_dim // 2), dtype=output_dtype)
     scaled_gemm_silu_and_mul_launcher(out, a, b, scale_a, scale_b, meta, bias=bias)
+    return out
+
+
+def mixed_precision_gemm_silu_and_mul(x: torch.Tensor, w_q_packed: torch.Tensor, w_s: torch.Tensor, w_zp: torch.Tensor | None,
+                                      weight_size_bits: int, weight_bias: int, group_size: int, *,
+                                      output_dtype: torch.dtype | None = None, strict: bool = False) -> torch.Tensor:
+    """silu_and_mul(mixed_precision_gemm(x, w_q_packed, ...)) in one launch.
+
+    The packed weights, scales and zero points have 2d columns [gate | up]; the result is (M, d).
+    """
+    meta = create_mixed_precision_metadata(x, w_q_packed, w_s, w_zp, weight_size_bits, weight_bias, group_size,
+                                           output_dtype=output_dtype, strict=strict)
+    out = x.new_empty((meta.m_dim, meta.n_dim // 2), dtype=meta.output_dtype)
+    mixed_precision_gemm_silu_and_mul_launcher(out, x, w_q_packed, w_s, w_zp, meta)
     return out

@@ -156,6 +156,19 @@ int conch_mixed_precision_gemm(void* c, const void* x, const int32_t* w_q_packed
                                int out_dtype, void* stream);
 
 /*
+ * mixed_precision_gemm_silu_and_mul  (SURVEY.md 8(f) N3 for the int4 / int8-weight FFN: the reference's pair
+ * mixed_precision_gemm (kernels/quantization/gemm.py:482-545) + silu_and_mul (ops/activation/silu_and_mul.py:11-29)
+ * in one launch).  w_q_packed / w_s / w_zp have 2 n_out columns [gate | up]; C: [M][n_out]:
+ *   C[m][j] = out_dtype( out_dtype( silu((float) G[m][j]) ) * (float) G[m][n_out + j] ),  G = conch_mixed_precision_gemm(...)
+ */
+int conch_mixed_precision_gemm_silu_and_mul(void* c, const void* x, const int32_t* w_q_packed, const void* w_s,
+                               const int32_t* w_zp, int64_t m, int64_t n_out, int64_t k,
+                               int64_t x_stride_m, int64_t wq_stride_k, int64_t ws_stride_g,
+                               int64_t wzp_stride_g, int64_t c_stride_m, int weight_bits,
+                               int weight_bias, int group_size, int zp_mode, int x_dtype,
+                               int out_dtype, void* stream);
+
+/*
  * Timing helper used by bench.py: launches `iters` back-to-back scaled_gemm calls on `stream`
  * bracketed by HIP events recorded ON THAT STREAM and returns the average milliseconds per call
  * in *avg_ms (synchronises the stream; not for use inside graph capture).

@@ -21,6 +21,7 @@ from oracle.reference import (  # noqa: F401
     dequantize_packed,
     encode_fp8,
     mixed_precision_gemm_ref,
+    mixed_precision_gemm_silu_and_mul_ref,
     pack_rows_ref,
     quantize_weights_ref,
     scaled_fp8_quant_ref,

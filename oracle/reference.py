@@ -284,3 +284,9 @@ def mixed_precision_gemm_ref(a: torch.Tensor, w_ref: torch.Tensor) -> torch.Tens
     """The mixed-precision oracle is `torch.matmul(a, w_ref)` in the activation dtype
     (tests/mixed_precision_gemm_test.py:70, benchmarks/mixed_precision_gemm_benchmark.py:210)."""
     return torch.matmul(a, w_ref)
+
+
+def mixed_precision_gemm_silu_and_mul_ref(a: torch.Tensor, w_ref: torch.Tensor) -> torch.Tensor:
+    """The int4 / int8-weight FFN pair: the mixed GEMM oracle on [gate | up] weights, then the
+    reference's silu_and_mul (reference/activation/silu_and_mul.py:13-16)."""
+    return silu_and_mul_ref(mixed_precision_gemm_ref(a, w_ref))

@@ -180,6 +180,17 @@ def gen_scaled_gemm_silu() -> None:
         c = torch.from_numpy(g[name].view(np.int16).copy()).view(odt)
         out[f"y_{key}"] = bits(ref_silu_and_mul(c))
     np.savez_compressed(OUT / "scaled_gemm_silu.npz", **out)
+    # the same for the mixed-precision GEMM outputs (c_<key> of mixed_gemm.npz, 32 x 128 -> 32 x 64)
+    g = np.load(OUT / "mixed_gemm.npz")
+    out = {}
+    for name in g.files:
+        if not name.startswith("c_"):
+            continue
+        key = name[2:]
+        odt = torch.float16 if key.endswith("_f16") else torch.bfloat16
+        c = torch.from_numpy(g[name].view(np.int16).copy()).view(odt)
+        out[f"y_{key}"] = bits(ref_silu_and_mul(c))
+    np.savez_compressed(OUT / "mixed_gemm_silu.npz", **out)
 
 
 if __name__ == "__main__":

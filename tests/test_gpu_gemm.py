@@ -17,7 +17,12 @@ import torch
 
 import oracle
 from conch_amd import _C
-from conch_amd.ops.quantization.gemm import mixed_precision_gemm, scaled_gemm, scaled_gemm_silu_and_mul
+from conch_amd.ops.quantization.gemm import (
+    mixed_precision_gemm,
+    mixed_precision_gemm_silu_and_mul,
+    scaled_gemm,
+    scaled_gemm_silu_and_mul,
+)
 from conch_amd.third_party.vllm.quant_utils import pack_rows, quantize_weights
 from conch_amd.third_party.vllm.scalar_type import scalar_types
 from conch_amd.third_party.vllm.utils import seed_everything
@@ -489,3 +494,72 @@ def test_mixed_precision_scalar_zero_point_and_output_dtype():
     assert got.dtype == torch.bfloat16
     exact = (a.double() @ w.double()).float()
     assert (got.float().cpu() - exact).abs().max().item() <= EPS[torch.bfloat16] * exact.abs().max().item()
+
+
+# ---------------------------------------------------------------------------------------------
+# mixed_precision_gemm_silu_and_mul (SURVEY.md 8(f) N3 for int4 / int8 weights)
+# ---------------------------------------------------------------------------------------------
+def check_mixed_silu(got, a, w_ref, min_representable=0.5):
+    """y = silu(g) * u amplifies the GEMM's accumulation-order tolerance (2 eps of max|G|, check_mixed) by up to
+    max(|u|, |g|): bound 4 eps * max|G|^2-scale, i.e. relative to max|y| of the exact pair; plus the pair computed from
+    OUR plain GEMM output must match to 2 output ulps (hardware exp / rcp against libm, as for the scaled form)."""
+    exact_g = a.double() @ w_ref.double()
+    d = exact_g.shape[1] // 2
+    exact = (torch.nn.functional.silu(exact_g[:, :d]) * exact_g[:, d:]).float()
+    g = got.float().cpu()
+    eps = EPS[got.dtype]
+    # the test recipe's magnitudes (|G| ~ 1e3) overflow fp16 in the product: those elements must be inf / huge on both
+    # sides; the bound is asserted on the representable ones
+    ok = exact.abs() < 3.0e4 if got.dtype == torch.float16 else torch.ones_like(exact, dtype=torch.bool)
+    assert ok.float().mean().item() >= min_representable
+    assert torch.isfinite(g[ok]).all() and (g[~ok].abs() > 2.0e4).all()
+    if ok.any():
+        assert (g[ok] - exact[ok]).abs().max().item() <= 6.0 * eps * exact[ok].abs().max().item()
+
+
+@pytest.mark.parametrize("wname", list(WTYPES))
+@pytest.mark.parametrize("zp", [1, 0])
+@pytest.mark.parametrize("dname", ["f16", "bf16"])
+def test_mixed_precision_silu_golden_from_reference(golden, wname, zp, dname):
+    """Fixture inputs generated by the reference; expected = the reference's silu_and_mul of its matmul(a, w_ref)."""
+    g, y = golden("mixed_gemm"), golden("mixed_gemm_silu")
+    key = f"{wname}_zp{zp}_{dname}"
+    bits, bias, group = (int(v) for v in g[f"meta_{key}"])
+    dtype = DT[dname]
+    a = from_bits(g[f"a_{key}"], dtype)
+    packed = torch.from_numpy(g[f"packed_{key}"].copy())
+    w_s = from_bits(g[f"ws_{key}"], dtype)
+    w_zp = torch.from_numpy(g[f"wzp_{key}"].copy()) if zp else None
+    got = mixed_precision_gemm_silu_and_mul(a.cuda(), packed.cuda(), w_s.cuda(), None if w_zp is None else w_zp.cuda(), bits, bias, group)
+    assert got.shape == (32, 64) and got.dtype == dtype
+    want = from_bits(y[f"y_{key}"], dtype).float()
+    # fp16: most products of the reference recipe (|G| ~ 1e3) overflow; compare the representable ones.  The oracle's G is a
+    # half-precision CPU matmul (up to 4 bf16 ulps from the exact product, SURVEY.md R4), doubled by the product.
+    ok = torch.isfinite(want) & (want.abs() < 3.0e4) if dtype == torch.float16 else torch.isfinite(want)
+    if ok.any():
+        tol = 12.0 * EPS[dtype] * want[ok].abs().max().item()
+        assert (got.float().cpu()[ok] - want[ok]).abs().max().item() <= tol
+    check_mixed_silu(got, a, from_bits(g[f"wref_{key}"], dtype), min_representable=0.0)
+
+
+@pytest.mark.parametrize(("m", "k", "d"), [(300, 256, 260), (1024, 512, 688), (64, 128, 100), (512, 64, 128)])
+@pytest.mark.parametrize(("wname", "use_zp", "dname"), [("uint4b8", False, "f16"), ("uint4", True, "bf16"),
+                                                         ("uint8b128", True, "f16"), ("uint8", False, "bf16")])
+def test_mixed_precision_silu_fused_equals_unfused(m, k, d, wname, use_zp, dname):
+    """Ragged M / d and the shortest K: against the exact pair, and bit-for-bit against the library's own unfused pair
+    (plain MFMA kernel at the 256-column tile into scratch + elementwise pass, forced with variant 2)."""
+    wt = WTYPES[wname]
+    group = 64 if k < 128 else 128
+    a, w_ref, packed, w_s, w_zp = make_mixed_inputs(m, k, 2 * d, wt, use_zp, DT[dname], group)
+    a = (a.float() * (0.02 if k >= 256 else 0.05)).to(DT[dname])  # |G| ~ 10..50: gate values where silu is not linear, products inside fp16
+    args = (a.cuda(), packed.cuda(), w_s.cuda(), None if w_zp is None else w_zp.cuda(), wt.size_bits, wt.bias, group)
+    got = mixed_precision_gemm_silu_and_mul(*args)
+    check_mixed_silu(got, a, w_ref)
+    _C.set_gemm_variant(_C.VARIANT_MFMA_SIMPLE)
+    _C.check(_C.load().conch_set_tuning(1, 4), "set_tuning")
+    try:
+        unfused = mixed_precision_gemm_silu_and_mul(*args)
+    finally:
+        _C.load().conch_set_tuning(1, 0)
+        _C.set_gemm_variant(_C.VARIANT_AUTO)
+    assert torch.equal(got, unfused)

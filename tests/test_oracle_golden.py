@@ -143,3 +143,6 @@ def test_quantize_pack_dequant_mixed(golden, wname, zp, dname):
     a = from_bits(g[f"a_{key}"], dtype)
     c = oracle.mixed_precision_gemm_ref(a, w_ref)
     np.testing.assert_array_equal(to_bits(c), g[f"c_{key}"])
+    # the FFN pair (mixed GEMM -> the reference's silu_and_mul)
+    y = oracle.mixed_precision_gemm_silu_and_mul_ref(a, w_ref)
+    np.testing.assert_array_equal(to_bits(y), golden("mixed_gemm_silu")[f"y_{key}"])

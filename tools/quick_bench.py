@@ -146,6 +146,29 @@ if __name__ == "__main__":
                 flops = 2.0 * m * (2 * d) * k
                 print(f"{str(dtype)[6:]:14s} M={m} K={k} d={d}: " + "  ".join(
                     f"{name} {statistics.median(v):.1f} us ({flops / statistics.median(v) / 1e6:.0f} TFLOP/s)" for name, v in res.items()), flush=True)
+        from conch_amd.ops.quantization.gemm import mixed_precision_gemm, mixed_precision_gemm_silu_and_mul
+        for (m, k, d) in [(4096, 4096, 11008), (1024, 4096, 11008)]:
+            torch.manual_seed(0)
+            x = (0.5 * (torch.rand((m, k), device="cuda") - 0.3)).to(torch.float16)
+            wq = torch.randint(-2**31, 2**31 - 1, (k // 8, 2 * d), dtype=torch.int32, device="cuda")
+            ws = (0.01 * torch.rand((k // 128, 2 * d), device="cuda") + 0.001).to(torch.float16)
+            fused = lambda: mixed_precision_gemm_silu_and_mul(x, wq, ws, None, 4, 8, 128)  # noqa: E731
+            gemm = lambda: mixed_precision_gemm(x, wq, ws, None, 4, 8, 128)  # noqa: E731
+
+            def pair():
+                g = mixed_precision_gemm(x, wq, ws, None, 4, 8, 128)
+                return torch.nn.functional.silu(g[:, :d]) * g[:, d:]
+
+            for _ in range(100):
+                fused()
+            res = {"fused": [], "gemm only": [], "gemm + torch silu*mul": []}
+            for _ in range(5):
+                res["fused"].append(ev(fused))
+                res["gemm only"].append(ev(gemm))
+                res["gemm + torch silu*mul"].append(ev(pair))
+            flops = 2.0 * m * (2 * d) * k
+            print(f"int4 x fp16    M={m} K={k} d={d}: " + "  ".join(
+                f"{name} {statistics.median(v):.1f} us ({flops / statistics.median(v) / 1e6:.0f} TFLOP/s)" for name, v in res.items()), flush=True)
         sys.exit(0)
     if "--mixednt" in sys.argv:
         import statistics
