@@ -194,10 +194,12 @@ struct ChunkDequant {
   // output dword j of the chunk is the pair (k 2j, k 2j+1)
   static constexpr int kOutLoP = 0, kOutHiP = BITS == 4 ? 2 : 1, kOutLoQ = BITS == 4 ? 1 : 2, kOutHiQ = 3;
 
-  __device__ __forceinline__ void slice(int s, uint32_t word0, uint32_t word1, int off, uint32_t scale_bits, char* dst) {
-    constexpr uint32_t kMagic = 0x64006400u;
+  // `mask` (a VGPR) and `magic` (an SGPR) hold 0x000f000f / 0x00ff00ff and 0x64006400 as VALUES the compiler cannot see:
+  // with literals it emits v_and_b32 + v_or_b32 (a VOP3 instruction cannot carry a 32-bit literal on gfx9); with
+  // registers (x & mask) | magic is ONE v_and_or_b32 -- 16 fewer VALU instructions per K step and thread
+  __device__ __forceinline__ void slice(int s, uint32_t word0, uint32_t word1, int off, uint32_t scale_bits, char* dst,
+                                        uint32_t mask, uint32_t magic) {
     constexpr uint32_t kLowHalves = 0x05040100u, kHighHalves = 0x07060302u;
-    constexpr uint32_t kMask = BITS == 4 ? 0x000f000fu : 0x00ff00ffu;
     constexpr int kShift = BITS == 4 ? 4 : 8;
     if (s == 0) {
       w0 = word0;
@@ -207,11 +209,11 @@ struct ChunkDequant {
       if constexpr (kHalf) sc = scale_bits | (scale_bits << 16);
       else fs = bf16_bits_to_float((uint16_t)scale_bits);
     } else if (s == 1) {
-      a = (w0 & kMask) | kMagic;
-      b = ((w0 >> kShift) & kMask) | kMagic;
+      a = (w0 & mask) | magic;
+      b = ((w0 >> kShift) & mask) | magic;
     } else if (s == 2) {
-      c = (w1 & kMask) | kMagic;
-      d = ((w1 >> kShift) & kMask) | kMagic;
+      c = (w1 & mask) | magic;
+      d = ((w1 >> kShift) & mask) | magic;
     } else if (s == 3) {
       a = pk_sub(a, sub);
       b = pk_sub(b, sub);
@@ -288,6 +290,8 @@ struct LoopCtx {
   WeightLane ln;
   WeightSrc ws;
   int wave, m_base, n_base, off_base;
+  int m_base_hi, n_base_hi;        // the same fragment offsets with the 16-byte chunk index + 4 (byte offset ^ 64)
+  uint32_t and_mask, or_magic;     // ChunkDequant::slice's constants, opaque to the compiler
 };
 
 // One K step.  MODE 0: steps t+1 and t+2 exist; 1: t+1 exists; 2: last step.  ISSUE = the slot at which this
@@ -313,6 +317,17 @@ __device__ __forceinline__ void mixed_step(MixedTile& w, WeightRegs<BITS, NT>& r
 #endif
   const int ubuf = (t & 1) * kStageBytes, vbuf = ubuf + kXBytes;
   const int vnext = ((t + 1) & 1) * kStageBytes + kXBytes;
+  // four per-step base addresses (X / weights, chunk g / g + 4); every fragment read is base + an immediate offset
+  const char* ulo = lds + ubuf + c.m_base;
+  const char* uhi = lds + ubuf + c.m_base_hi;
+  const char* vlo = lds + vbuf + c.n_base;
+  const char* vhi = lds + vbuf + c.n_base_hi;
+  auto frag = [](const char* lo, const char* hi, int off) {
+    Frag f;
+    f.lo = *(const i32x4*)(lo + off);
+    f.hi = *(const i32x4*)(hi + off);
+    return f;
+  };
   WeightRegs<BITS, NT> next;
 
   ChunkDequant<X_DT, BITS> cv[NT];
@@ -336,7 +351,7 @@ __device__ __forceinline__ void mixed_step(MixedTile& w, WeightRegs<BITS, NT>& r
       const int it = sl / kSlices, sub = sl % kSlices;
       if (it < NT) {
         const int un = it < 2 ? 0 : 1;
-        cv[it].slice(sub, regs.w[it][0], regs.w[it][kWpc - 1], c.off_base + regs.zp[un], regs.scale[un], lds + vnext + c.ln.lds[it]);
+        cv[it].slice(sub, regs.w[it][0], regs.w[it][kWpc - 1], c.off_base + regs.zp[un], regs.scale[un], lds + vnext + c.ln.lds[it], c.and_mask, c.or_magic);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -360,9 +375,9 @@ __device__ __forceinline__ void mixed_step(MixedTile& w, WeightRegs<BITS, NT>& r
   if constexpr (DEFER) phase3();
   // phase-0 fragment reads, ahead of the slots that hide their latency
 #pragma unroll
-  for (int tt = 0; tt < 2; ++tt) w.fn[0][tt] = read_frag(lds, vbuf + c.n_base + tt * 2048);
+  for (int tt = 0; tt < 2; ++tt) w.fn[0][tt] = frag(vlo, vhi, tt * 2048);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) w.fm[i] = read_frag(lds, ubuf + c.m_base + i * 2048);
+  for (int i = 0; i < 4; ++i) w.fm[i] = frag(ulo, uhi, i * 2048);
   __builtin_amdgcn_sched_barrier(0);
   // phase 0: (m rows 0-63 of the wave) x (n tiles 0,1); the V2 fragments of phase 1 -- or, for the narrowest
   // tile, the U2 fragments -- are fetched underneath
@@ -375,9 +390,9 @@ __device__ __forceinline__ void mixed_step(MixedTile& w, WeightRegs<BITS, NT>& r
         mma1<X_DT>(w.acc[i][tt], w.fn[0][tt], w.fm[i], h);
         const int idx = (i * 2 + tt) * 2 + h;
         if constexpr (N1 > 0) {
-          if (idx >= 2 && idx < 2 + N1) w.fn[1][idx - 2] = read_frag(lds, vbuf + kUnitBytes + c.n_base + (idx - 2) * 2048);
+          if (idx >= 2 && idx < 2 + N1) w.fn[1][idx - 2] = frag(vlo, vhi, kUnitBytes + (idx - 2) * 2048);
         } else {
-          if (idx % 4 == 3) w.fm[i] = read_frag(lds, ubuf + kUnitBytes + c.m_base + i * 2048);
+          if (idx % 4 == 3) w.fm[i] = frag(ulo, uhi, kUnitBytes + i * 2048);
         }
         tail(slot++);
       }
@@ -389,7 +404,7 @@ __device__ __forceinline__ void mixed_step(MixedTile& w, WeightRegs<BITS, NT>& r
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         mma1<X_DT>(w.acc[i][2 + tt], w.fn[1][tt], w.fm[i], h);
-        if (tt == N1 - 1 && h == 1) w.fm[i] = read_frag(lds, ubuf + kUnitBytes + c.m_base + i * 2048);
+        if (tt == N1 - 1 && h == 1) w.fm[i] = frag(ulo, uhi, kUnitBytes + i * 2048);
         tail(slot++);
       }
   // phase 2: m rows 64-127 x n tiles 2..
@@ -503,6 +518,11 @@ __global__ __launch_bounds__(kThreads, 2) void mixed_gemm_kernel(MixedGemmArgs p
   const int lane_off = (fr >> 3) * 1024 + (fr & 7) * 128 + ((fg ^ ((fr >> 1) & 7)) * 16);
   c.m_base = (wr * 8) * 1024 + lane_off;
   c.n_base = (wc * 4) * 1024 + lane_off;
+  c.m_base_hi = c.m_base ^ 64;
+  c.n_base_hi = c.n_base ^ 64;
+  c.and_mask = BITS == 4 ? 0x000f000fu : 0x00ff00ffu;
+  c.or_magic = 0x64006400u;
+  asm volatile("" : "+v"(c.and_mask), "+s"(c.or_magic));
 
   MixedTile w;
 #pragma unroll
@@ -524,7 +544,7 @@ __global__ __launch_bounds__(kThreads, 2) void mixed_gemm_kernel(MixedGemmArgs p
     ChunkDequant<X_DT, BITS> cv;
 #pragma unroll
     for (int sl = 0; sl < ChunkDequant<X_DT, BITS>::kSlices; ++sl)
-      cv.slice(sl, regs.w[it][0], regs.w[it][kWpc - 1], c.off_base + regs.zp[it < 2 ? 0 : 1], regs.scale[it < 2 ? 0 : 1], lds + kXBytes + c.ln.lds[it]);
+      cv.slice(sl, regs.w[it][0], regs.w[it][kWpc - 1], c.off_base + regs.zp[it < 2 ? 0 : 1], regs.scale[it < 2 ? 0 : 1], lds + kXBytes + c.ln.lds[it], c.and_mask, c.or_magic);
   }
   if (steps > 1) {
     load_weights<BITS, ZP, NT>(regs, c.ln, c.ws, cur);
