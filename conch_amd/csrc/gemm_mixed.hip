@@ -171,10 +171,11 @@ __device__ __forceinline__ void load_weights(WeightRegs<BITS, NT>& r, const Weig
 template <int X_DT, int BITS>
 struct ChunkDequant {
   static constexpr bool kHalf = X_DT == CONCH_DT_FP16;
-  static constexpr int kSlices = kHalf ? 10 : 12;  // the last one is the ds_write_b128
+  static constexpr int kSlices = 10;  // the last one is the ds_write_b128
   uint32_t w0, w1, sub, sc;
   uint32_t a, b, c, d;
-  float fa[2], fb[2], fc[2], fd[2], fs;
+  f32x2 p_lo, p_hi, q_lo, q_hi;  // bf16 path: (a.lo, b.lo), (a.hi, b.hi), (c.lo, d.lo), (c.hi, d.hi) widened to fp32
+  float fs;
   i32x4 out;
 
   static __device__ __forceinline__ uint32_t pk_sub(uint32_t v, uint32_t s) {
@@ -183,13 +184,12 @@ struct ChunkDequant {
   static __device__ __forceinline__ uint32_t pk_mul(uint32_t v, uint32_t s) {
     return __builtin_bit_cast(uint32_t, __builtin_bit_cast(f16x2, v) * __builtin_bit_cast(f16x2, s));
   }
-  static __device__ __forceinline__ void widen(uint32_t v, float (&f)[2]) {
-    const f16x2 h = __builtin_bit_cast(f16x2, v);
-    f[0] = (float)h[0];
-    f[1] = (float)h[1];
-  }
-  static __device__ __forceinline__ int pack_bf16(float lo, float hi) {
-    return (int)((uint32_t)float_to_bf16_bits(lo) | ((uint32_t)float_to_bf16_bits(hi) << 16));
+  // the fp32 pairs are formed the way they are packed again: (element of a, element of b) -> one output dword, so the
+  // scale multiply is a v_pk_mul_f32 and the rounding ONE v_cvt_pk_bf16_f32 per dword
+  static __device__ __forceinline__ void widen(uint32_t x, uint32_t y, f32x2& lo, f32x2& hi) {
+    const f16x2 hx = __builtin_bit_cast(f16x2, x), hy = __builtin_bit_cast(f16x2, y);
+    lo = f32x2{(float)hx[0], (float)hy[0]};
+    hi = f32x2{(float)hx[1], (float)hy[1]};
   }
   // output dword j of the chunk is the pair (k 2j, k 2j+1)
   static constexpr int kOutLoP = 0, kOutHiP = BITS == 4 ? 2 : 1, kOutLoQ = BITS == 4 ? 1 : 2, kOutHiQ = 3;
@@ -238,22 +238,16 @@ struct ChunkDequant {
       }
     } else {
       if (s == 5) {
-        widen(a, fa);
-        widen(b, fb);
+        widen(a, b, p_lo, p_hi);
       } else if (s == 6) {
-        widen(c, fc);
-        widen(d, fd);
+        widen(c, d, q_lo, q_hi);
       } else if (s == 7) {
-        fa[0] *= fs; fa[1] *= fs; fb[0] *= fs; fb[1] *= fs;
+        out[kOutLoP] = (int)pack2_bits16<CONCH_DT_BF16>(p_lo * f32x2{fs, fs});
+        out[kOutHiP] = (int)pack2_bits16<CONCH_DT_BF16>(p_hi * f32x2{fs, fs});
       } else if (s == 8) {
-        fc[0] *= fs; fc[1] *= fs; fd[0] *= fs; fd[1] *= fs;
+        out[kOutLoQ] = (int)pack2_bits16<CONCH_DT_BF16>(q_lo * f32x2{fs, fs});
+        out[kOutHiQ] = (int)pack2_bits16<CONCH_DT_BF16>(q_hi * f32x2{fs, fs});
       } else if (s == 9) {
-        out[kOutLoP] = pack_bf16(fa[0], fb[0]);
-        out[kOutHiP] = pack_bf16(fa[1], fb[1]);
-      } else if (s == 10) {
-        out[kOutLoQ] = pack_bf16(fc[0], fd[0]);
-        out[kOutHiQ] = pack_bf16(fc[1], fd[1]);
-      } else if (s == 11) {
         *(i32x4*)dst = out;
       }
     }
