@@ -17,7 +17,9 @@ from conch_amd.ops.quantization.gemm import (
     create_mixed_precision_metadata,
     create_scaled_metadata,
     mixed_precision_gemm,
+    mixed_precision_gemm_silu_and_mul,
     scaled_gemm,
+    scaled_gemm_silu_and_mul,
 )
 from conch_amd.ops.quantization.int8 import scaled_int8_quant
 from conch_amd.third_party.vllm.quant_utils import pack_rows, quantize_weights
@@ -64,6 +66,32 @@ def test_c_abi_validation_without_gpu():
         _C.check(2, "x")
     with pytest.raises(_C.ConchError):
         _C.check(3, "x")
+
+
+def test_fused_ffn_ops_validation_without_gpu():
+    """scaled_gemm_silu_and_mul / mixed_precision_gemm_silu_and_mul: C-ABI checks and host-side argument errors."""
+    lib = _C.load()
+    # the contained GEMM is validated on its 2 * n_out columns: bad dtype -> unsupported, NULL pointers -> invalid
+    rc = lib.conch_scaled_gemm_silu_and_mul(None, None, None, None, None, None, 4, 4, 4, 4, 1, 1, 4, 4, 1, 1, 1, 77, _C.DT_BF16, None)
+    assert rc == 2 and b"input dtype" in lib.conch_last_error()
+    rc = lib.conch_scaled_gemm_silu_and_mul(None, None, None, None, None, None, 4, 4, 4, 4, 1, 1, 4, 4, 1, 1, 1, _C.DT_INT8, _C.DT_BF16, None)
+    assert rc == 1 and b"NULL" in lib.conch_last_error()
+    assert lib.conch_scaled_gemm_silu_and_mul(None, None, None, None, None, None, 0, 4, 4, 4, 1, 1, 4, 4, 1, 1, 1, _C.DT_INT8, _C.DT_BF16, None) == 0
+    rc = lib.conch_mixed_precision_gemm_silu_and_mul(None, None, None, None, None, 4, 4, 8, 8, 4, 4, 4, 4, 3, 0, 8, 0, _C.DT_FP16, _C.DT_FP16, None)
+    assert rc == 1 and b"weight_bits" in lib.conch_last_error()
+    # host side: B / the packed weights need an even number of columns [gate | up]; host tensors are refused
+    s = torch.tensor([1.0])
+    a = torch.zeros(4, 128, dtype=torch.int8)
+    b_odd = torch.zeros(7, 128, dtype=torch.int8).T
+    with pytest.raises(ValueError, match="even number of columns"):
+        scaled_gemm_silu_and_mul(a, b_odd, s, s, torch.bfloat16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        scaled_gemm_silu_and_mul(a, torch.zeros(8, 128, dtype=torch.int8).T, s, s, torch.bfloat16)
+    x = torch.zeros(4, 128, dtype=torch.float16)
+    with pytest.raises(ValueError, match="even number of columns"):
+        mixed_precision_gemm_silu_and_mul(x, torch.zeros(16, 7, dtype=torch.int32), torch.ones(1, 7, dtype=torch.float16), None, 4, 8, 128)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        mixed_precision_gemm_silu_and_mul(x, torch.zeros(16, 8, dtype=torch.int32), torch.ones(1, 8, dtype=torch.float16), None, 4, 8, 128)
 
 
 def test_tuning_knob_roundtrip():
