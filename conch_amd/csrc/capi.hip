@@ -84,10 +84,19 @@ int run_scaled_fast(const ScaledGemmArgs& p, int variant, hipStream_t stream) {
     set_error("scaled_gemm: skinny variant forced but its contract is not met (M <= 256, K %% 1024 == 0)");
     return CONCH_ERR_UNSUPPORTED;
   }
-  // auto: skinny up to N = 16384; beyond that the 256-wide tiles already fill enough CUs and stream B^T
-  // faster (M=32, K=8192, N=28672: tiled 65-70 us, skinny split-K 75-80 us)
-  if ((variant == 4 || (variant == 0 && p.n <= 16384)) && scaled_gemm_skinny_supported(p))
-    return launch_scaled_gemm_skinny(p, stream);
+  // auto: whichever of the two is cheaper by a cost model fitted to a sweep over M in 16..256, K in {4096, 8192},
+  // N in 4096..28672, int8 and fp8 (tools/quick_bench.py --skinnysweep, profiles/README.md): the split-K kernel costs
+  // ~5.5 us + c(M) x N x K (it re-reads the A slice per 64-column block; two row blocks above M = 128), the tiled kernel
+  // one 256x256 tile time (~8.5 ns per K byte) per round of workgroups whatever N is
+  bool use_skinny = variant == 4;
+  if (variant == 0 && scaled_gemm_skinny_supported(p)) {
+    const double c = p.m <= 16 ? 2.6 : p.m <= 64 ? 3.3 : p.m <= 128 ? 4.4 : p.m <= 192 ? 8.5 : 9.7;
+    const double skinny_us = 5.5 + c * 1e-7 * (double)p.n * (double)p.k;
+    const int64_t tiles = ((p.m + 255) / 256) * ((p.n + 255) / 256);
+    const double tiled_us = (double)((tiles + 255) / 256) * 8.5e-3 * (double)p.k;
+    use_skinny = skinny_us < tiled_us;
+  }
+  if (use_skinny && scaled_gemm_skinny_supported(p)) return launch_scaled_gemm_skinny(p, stream);
   return launch_scaled_gemm_mfma(p, (variant == 2 || variant == 3) ? variant : 5, stream);
 }
 

@@ -170,6 +170,23 @@ if __name__ == "__main__":
             print(f"int4 x fp16    M={m} K={k} d={d}: " + "  ".join(
                 f"{name} {statistics.median(v):.1f} us ({flops / statistics.median(v) / 1e6:.0f} TFLOP/s)" for name, v in res.items()), flush=True)
         sys.exit(0)
+    if "--skinnysweep" in sys.argv:
+        # skinny split-K (variant 4) against the 256x256 tiled kernel (variant 5) on small-M shapes
+        import statistics
+        for dtype in (torch.int8, torch.float8_e4m3fn):
+            for k in (4096, 8192):
+                for n in (4096, 11008, 16384, 28672):
+                    for m in (16, 64, 128, 192, 256):
+                        res = {}
+                        for v in (4, 5):
+                            try:
+                                for _ in range(3):
+                                    time_scaled(m, k, n, dtype, v, iters=30)
+                                res[v] = statistics.median([time_scaled(m, k, n, dtype, v, iters=40) for _ in range(3)]) * 1e3
+                            except Exception:  # noqa: BLE001
+                                res[v] = float("nan")
+                        print(f"{str(dtype)[6:]:14s} M={m:4d} K={k} N={n:6d}: skinny {res[4]:7.1f} us   tiled {res[5]:7.1f} us   {'SKINNY' if res[4] < res[5] else 'TILED'}", flush=True)
+        sys.exit(0)
     if "--mixednt" in sys.argv:
         import statistics
         lib = _C.load()

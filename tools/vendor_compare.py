@@ -58,7 +58,26 @@ def fp16_case(m, k, n):
           f"   torch.matmul fp16 on dequantised weights (hipBLASLt / rocBLAS) {ref * 1e3:.1f} us ({2.0 * m * n * k / ref / 1e9:.0f} TFLOP/s)", flush=True)
 
 
+def int8_case(m, k, n):
+    """C2-style decode shape: ours (scales + cast fused) against torch._int_mm (hipBLASLt int8 -> int32, no epilogue)."""
+    torch.manual_seed(0)
+    a = torch.randint(-32, 32, (m, k), dtype=torch.int8, device="cuda")
+    bt = torch.randint(-32, 32, (n, k), dtype=torch.int8, device="cuda")
+    sa = 0.25 * torch.rand((m, 1), device="cuda")
+    sb = 0.25 * torch.rand((n, 1), device="cuda")
+    ours = timeit(lambda: scaled_gemm(a, bt.T, sa, sb, torch.bfloat16))
+    line = f"int8 {m}x{k}x{n}: conch_amd (scales + bf16 cast fused) {ours * 1e3:.1f} us"
+    try:
+        ref = timeit(lambda: torch._int_mm(a, bt.T))
+        line += f"   torch._int_mm (int32 result, no epilogue) {ref * 1e3:.1f} us"
+    except Exception as exc:  # noqa: BLE001
+        line += f"   torch._int_mm unavailable: {str(exc)[:100]}"
+    print(line, flush=True)
+
+
 if __name__ == "__main__":
+    for shape in [(128, 4096, 4096), (32, 8192, 8192), (256, 4096, 11008)]:
+        int8_case(*shape)
     for shape in [(4096, 4096, 11008), (8192, 8192, 8192), (8192, 8192, 3584)]:
         fp8_case(*shape)
     for shape in [(1024, 4096, 11008), (4096, 8192, 4096), (8192, 8192, 8192)]:
