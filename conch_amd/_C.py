@@ -22,7 +22,7 @@ DT_FP32, DT_FP16, DT_BF16, DT_FP8_E4M3FN, DT_INT8, DT_UINT8, DT_INT32, DT_UINT32
 ZP_NONE, ZP_SCALAR, ZP_TENSOR = range(3)
 TUNE_GEMM_VARIANT = 0
 (VARIANT_AUTO, VARIANT_GENERIC, VARIANT_MFMA_SIMPLE, VARIANT_MFMA_PINGPONG, VARIANT_MFMA_SKINNY,
- VARIANT_MFMA_PINGPONG2) = range(6)
+ VARIANT_MFMA_PINGPONG2, VARIANT_MFMA_MID) = range(7)
 
 TORCH_TO_DT = {
     torch.float32: DT_FP32,

@@ -84,19 +84,35 @@ int run_scaled_fast(const ScaledGemmArgs& p, int variant, hipStream_t stream) {
     set_error("scaled_gemm: skinny variant forced but its contract is not met (M <= 256, K %% 1024 == 0)");
     return CONCH_ERR_UNSUPPORTED;
   }
-  // auto: whichever of the two is cheaper by a cost model fitted to a sweep over M in 16..256, K in {4096, 8192},
-  // N in 4096..28672, int8 and fp8 (tools/quick_bench.py --skinnysweep, profiles/README.md): the split-K kernel costs
-  // ~5.5 us + c(M) x N x K (it re-reads the A slice per 64-column block; two row blocks above M = 128), the tiled kernel
-  // one 256x256 tile time (~8.5 ns per K byte) per round of workgroups whatever N is
+  // auto: the cheapest of three kernels by a cost model fitted to a 112-point sweep over M in 16..1024, K in {4096, 8192},
+  // N in 4096..28672, int8 and fp8 (tools/quick_bench.py --skinnysweep, profiles/r01/skinny_tiled_mid_sweep.txt), in us:
+  //   split-K skinny  5.5 + c(M) N K            (re-reads the A slice per 64-column block; two row blocks above M = 128)
+  //   256x256 tiles   rounds x (34 + 0.05 t) K/4096,  t = tiles per round of 256 workgroups (a lone tile is bound by its
+  //                   CU's L2 -> LDS rate; a full round shares the L2 / Infinity Cache)
+  //   128x128 tiles   rounds x (19 + 0.0176 t) K/4096, t = tiles per round of 512 workgroups (two per CU)
+  const double kscale = (double)p.k / 4096.0;
+  const int64_t tiles256 = ((p.m + 255) / 256) * ((p.n + 255) / 256);
+  const int64_t rounds256 = (tiles256 + 255) / 256;
+  const double tiled_us = (double)rounds256 * (34.0 + 0.05 * (double)tiles256 / (double)rounds256) * kscale;
+  const int64_t tiles128 = ((p.m + 127) / 128) * ((p.n + 127) / 128);
+  const int64_t rounds128 = (tiles128 + 511) / 512;
+  const double mid_us = (double)rounds128 * (19.0 + 0.0176 * (double)tiles128 / (double)rounds128) * kscale;
   bool use_skinny = variant == 4;
-  if (variant == 0 && scaled_gemm_skinny_supported(p)) {
-    const double c = p.m <= 16 ? 2.6 : p.m <= 64 ? 3.3 : p.m <= 128 ? 4.4 : p.m <= 192 ? 8.5 : 9.7;
-    const double skinny_us = 5.5 + c * 1e-7 * (double)p.n * (double)p.k;
-    const int64_t tiles = ((p.m + 255) / 256) * ((p.n + 255) / 256);
-    const double tiled_us = (double)((tiles + 255) / 256) * 8.5e-3 * (double)p.k;
-    use_skinny = skinny_us < tiled_us;
+  bool use_mid = variant == 6;
+  if (variant == 0) {
+    double best = tiled_us;
+    if (mid_us < best) {
+      best = mid_us;
+      use_mid = true;
+    }
+    if (scaled_gemm_skinny_supported(p)) {
+      const double c = p.m <= 16 ? 2.6 : p.m <= 64 ? 3.3 : p.m <= 128 ? 4.4 : p.m <= 192 ? 8.5 : 9.7;
+      const double skinny_us = 5.5 + c * 1e-7 * (double)p.n * (double)p.k;
+      if (skinny_us < best) use_skinny = true;
+    }
   }
   if (use_skinny && scaled_gemm_skinny_supported(p)) return launch_scaled_gemm_skinny(p, stream);
+  if (use_mid) return launch_scaled_gemm_mid(p, stream);
   return launch_scaled_gemm_mfma(p, (variant == 2 || variant == 3) ? variant : 5, stream);
 }
 
@@ -105,7 +121,7 @@ int run_scaled(const ScaledGemmArgs& p, hipStream_t stream) {
   if (p.m == 0 || p.n == 0) return CONCH_OK;
   const int variant = tuning(CONCH_TUNE_GEMM_VARIANT);
   if (variant != 1 && scaled_gemm_mfma_supported(p)) return run_scaled_fast(p, variant, stream);
-  if (variant >= 2 && variant <= 5) {
+  if (variant >= 2 && variant <= 6) {
     set_error("scaled_gemm: MFMA variant %d forced but the layout contract is not met "
               "(need K-contiguous A and B^T, K %% 128 == 0, 16-byte aligned rows)", variant);
     return CONCH_ERR_UNSUPPORTED;

@@ -53,6 +53,8 @@ int launch_mixed_gemm_generic(const MixedGemmArgs& p, hipStream_t stream);
 // 3 = 8-phase ping-pong pipeline.  *_supported() say whether the layout contract is met.
 bool scaled_gemm_mfma_supported(const ScaledGemmArgs& p);
 int launch_scaled_gemm_mfma(const ScaledGemmArgs& p, int variant, hipStream_t stream);
+// gemm_mid.hip -- 128x128 tiles, two workgroups per CU, for shapes with few 256x256 tiles (variant 6); same contract
+int launch_scaled_gemm_mid(const ScaledGemmArgs& p, hipStream_t stream);
 // gemm_skinny.hip -- M <= 256: 128x16 blocks, K split over the waves, register streaming (variant 4)
 bool scaled_gemm_skinny_supported(const ScaledGemmArgs& p);
 int launch_scaled_gemm_skinny(const ScaledGemmArgs& p, hipStream_t stream);

@@ -1,0 +1,175 @@
+// scaled_gemm for shapes with few 256x256 tiles (M of a few hundred rows): 128x128 tiles, 4 waves, two workgroups per CU.
+//
+// A lone 256x256 tile is bound by its CU's L2 -> LDS rate (64 KiB per K step at ~60 GB/s: 35 us at K = 4096 whatever
+// N is), so a problem with 43 such tiles leaves 213 CUs idle.  Here a tile is 128 rows x 128 columns (32 KiB per K
+// step): four times as many workgroups for the same problem, 64 KiB of LDS and 4 waves each, so two fit on a CU and one
+// workgroup's LDS-DMA overlaps the other's MFMAs without any ping-pong choreography -- a plain double-buffered loop,
+// one barrier per K step.  Same LDS image (8-row x 128-byte subtiles, (row>>1)&7 source-side swizzle, conflict-free
+// ds_read_b128), same swapped MFMA operands and V-row permutation (a lane owns 8 consecutive n: 16-byte stores), same
+// epilogue arithmetic as gemm_mfma.hip.  Replaces the same reference kernel (kernels/quantization/gemm.py:219-457).
+#include "common.hpp"
+#include "gemm.hpp"
+#include "mfma_tile.hpp"
+
+namespace conch {
+namespace {
+
+using namespace tile;
+
+constexpr int kMidThreads = 256;
+constexpr int kMidTile = 128;
+constexpr int kMidBuf = 2 * kUnitBytes;                 // U (128 rows of A) + V (128 rows of B^T)
+constexpr int kMidEpi = 2 * kMidBuf;                    // float sa[128] | sb[128] | bias[128]
+constexpr int kMidLds = kMidEpi + 3 * 128 * 4;          // 64 KiB + 1.5 KiB
+
+struct MidOffsets {
+  int u[4], v[4];  // byte offset of this lane's 16-byte source chunk for the wave's four pieces of a unit
+};
+
+template <int MMA, int OUT_DT>
+__global__ __launch_bounds__(kMidThreads, 2) void scaled_gemm_mid_kernel(ScaledGemmArgs p) {
+  __shared__ __attribute__((aligned(1024))) char lds[kMidLds];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int tiles_m = ((int)p.m + kMidTile - 1) / kMidTile;
+  const int tiles_n = ((int)p.n + kMidTile - 1) / kMidTile;
+  const TileCoord tc = map_tile(blockIdx.x, tiles_m, tiles_n);
+  const int bm0 = tc.tm * kMidTile, bn0 = tc.tn * kMidTile;
+
+  Srcs src;
+  src.a = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (uint32_t)((p.m - 1) * p.a_stride_m + p.k), 0x00020000);
+  src.b = __builtin_amdgcn_make_buffer_rsrc((void*)p.b, 0, (uint32_t)((p.n - 1) * p.b_stride_n + p.k), 0x00020000);
+  // staging: wave w feeds unit rows [32w, 32w + 32) = four 8-row subtiles of both units
+  MidOffsets so;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int rho = 32 * wave + 8 * j + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((rho >> 1) & 7);
+    const int r5 = rho & 31, r = r5 & 15, t = r5 >> 4;
+    const int nrow = (rho >> 5) * 32 + 8 * (r >> 2) + (r & 3) + 4 * t;  // MFMA D rows 4g+e of tile t <-> n = 8g+e+4t
+    so.u[j] = min(bm0 + rho, (int)p.m - 1) * (int)p.a_stride_m + chunk * 16;
+    so.v[j] = min(bn0 + nrow, (int)p.n - 1) * (int)p.b_stride_n + chunk * 16;
+  }
+  auto stage = [&](int step) {
+    char* dst = lds + (step & 1) * kMidBuf + wave * 4096;
+    const int koff = step * kStepBytes;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(src.a, (lds_void_t*)(dst + j * 1024), 16, so.u[j], koff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(src.b, (lds_void_t*)(dst + kUnitBytes + j * 1024), 16, so.v[j], koff, 0, 0);
+    }
+  };
+
+  // epilogue constants: threads 0-127 fetch scale_a[row], 128-255 scale_b[col] and the bias
+  {
+    const int t = threadIdx.x, tt = t & 127;
+    const bool is_b = t >= 128;
+    const int idx = is_b ? min(bn0 + tt, (int)p.n - 1) : min(bm0 + tt, (int)p.m - 1);
+    const float* base = is_b ? p.scale_b : p.scale_a;
+    const bool vec = (is_b ? p.scale_b_numel : p.scale_a_numel) != 1;
+    const float v0 = base[vec ? idx : 0];
+    uint32_t bits = 0;
+    if (p.bias) bits = ((const uint16_t*)p.bias)[min(bn0 + tt, (int)p.n - 1)];
+    stage(0);
+    float* f = (float*)(lds + kMidEpi);
+    f[t] = v0;
+    if (is_b) f[t + 128] = bits16_to_float<OUT_DT>((uint16_t)bits);
+  }
+
+  const int r = lane & 15, g = lane >> 4;
+  const int lane_off = (r >> 3) * 1024 + (r & 7) * 128 + ((g ^ ((r >> 1) & 7)) * 16);
+  const int m_base = (wr * 8) * 1024 + lane_off;               // the wave's 64 rows of U
+  const int n_base = kUnitBytes + (wc * 8) * 1024 + lane_off;  // the wave's 64 rows of V
+
+  typename AccT<MMA>::type acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[i][t] = typename AccT<MMA>::type{0, 0, 0, 0};
+
+  const int steps = (int)(p.k / kStepBytes);
+  for (int t = 0; t < steps; ++t) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this wave's pieces of step t have landed ...
+    __builtin_amdgcn_s_barrier();                                // ... and every wave is done with the other buffer
+    if (t + 1 < steps) stage(t + 1);
+    const int buf = (t & 1) * kMidBuf;
+    Frag fn[4], fm[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) fn[q] = read_frag(lds, buf + n_base + q * 2048);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fm[i] = read_frag(lds, buf + m_base + i * 2048);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) mma_step<MMA>(acc[i][q], fn[q], fm[i]);  // D rows = n, D cols = m
+  }
+
+  // epilogue: sb * (sa * acc), RNE cast, bias in the output dtype (reference/quantization/scaled_gemm.py:21-25)
+  const bool vec_store = (p.c_stride_m % 8 == 0) && (((uintptr_t)p.c & 15) == 0);
+  const bool has_bias = p.bias != nullptr;
+  const float* lsa = (const float*)(lds + kMidEpi);
+  const float* lsb = lsa + 128;
+  const float* lbias = lsa + 256;
+#pragma unroll
+  for (int nh = 0; nh < 2; ++nh) {
+    const int nl = wc * 64 + nh * 32 + 8 * g;
+    const int n0 = bn0 + nl;
+    const f32x4 sb_lo = *(const f32x4*)(lsb + nl), sb_hi = *(const f32x4*)(lsb + nl + 4);
+    const f32x4 bs_lo = *(const f32x4*)(lbias + nl), bs_hi = *(const f32x4*)(lbias + nl + 4);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int ml = wr * 64 + mt * 16 + r;
+      const int m = bm0 + ml;
+      const float sa = lsa[ml];
+      i32x4 pk;
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2) {
+        const int e = 2 * e2;
+        const f32x2 a2 = {(float)acc[mt][nh * 2 + (e >> 2)][e & 3], (float)acc[mt][nh * 2 + (e >> 2)][(e & 3) + 1]};
+        const f32x2 sb2 = e < 4 ? f32x2{sb_lo[e & 3], sb_lo[(e & 3) + 1]} : f32x2{sb_hi[e & 3], sb_hi[(e & 3) + 1]};
+        f32x2 v = f32x2{sa, sa} * a2;
+        v = pin_f32x2(sb2 * v);
+        uint32_t h = pack2_bits16<OUT_DT>(v);
+        if (has_bias) {
+          const f32x2 b2 = e < 4 ? f32x2{bs_lo[e & 3], bs_lo[(e & 3) + 1]} : f32x2{bs_hi[e & 3], bs_hi[(e & 3) + 1]};
+          h = pack2_bits16<OUT_DT>(pin_f32x2(unpack2_bits16<OUT_DT>(h) + b2));
+        }
+        pk[e2] = (int)h;
+      }
+      if (m < p.m) {
+        uint16_t* dst = (uint16_t*)p.c + (int64_t)m * p.c_stride_m + n0;
+        if (vec_store && n0 + 8 <= p.n) {
+          *(i32x4*)dst = pk;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (n0 + e < p.n) dst[e] = (uint16_t)((uint32_t)pk[e >> 1] >> (16 * (e & 1)));
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// Same layout contract as the 256x256 kernels (scaled_gemm_mfma_supported).
+int launch_scaled_gemm_mid(const ScaledGemmArgs& p, hipStream_t stream) {
+  const int tiles_m = (int)((p.m + kMidTile - 1) / kMidTile);
+  const int tiles_n = (int)((p.n + kMidTile - 1) / kMidTile);
+  const dim3 grid((unsigned)(tiles_m * tiles_n));
+#define CONCH_LAUNCH_MID(MMA, OUT)                                                                         \
+  do {                                                                                                     \
+    hipLaunchKernelGGL((scaled_gemm_mid_kernel<MMA, OUT>), grid, dim3(kMidThreads), 0, stream, p);          \
+    return check_launch("scaled_gemm_mid");                                                                \
+  } while (0)
+  if (p.in_dtype == CONCH_DT_FP8_E4M3FN) {
+    if (p.out_dtype == CONCH_DT_BF16) CONCH_LAUNCH_MID(kMmaFp8, CONCH_DT_BF16);
+    CONCH_LAUNCH_MID(kMmaFp8, CONCH_DT_FP16);
+  }
+  if (p.out_dtype == CONCH_DT_BF16) CONCH_LAUNCH_MID(kMmaInt8, CONCH_DT_BF16);
+  CONCH_LAUNCH_MID(kMmaInt8, CONCH_DT_FP16);
+#undef CONCH_LAUNCH_MID
+}
+
+}  // namespace conch

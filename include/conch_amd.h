@@ -66,7 +66,8 @@ typedef enum conch_tuning_key {
   CONCH_TUNE_GEMM_VARIANT = 0 /* 0 = auto, 1 = generic (any shape/stride), 2 = LDS-tiled MFMA with a plain
                                  double-buffered loop, 3 = ping-pong pipelined LDS-tiled MFMA, four phases per
                                  K step, 4 = skinny-M (M <= 256) split-K MFMA, 5 = ping-pong, two phases per K
-                                 step (the default for M > 256).  mixed_precision_gemm has one LDS-tiled MFMA
+                                 step (the default for M > 256), 6 = 128x128 tiles, two workgroups per CU (shapes with few
+                                 256x256 tiles).  mixed_precision_gemm has one LDS-tiled MFMA
                                  kernel: 1 = generic, any other value = that kernel */
   ,
   CONCH_TUNE_MIXED_TILE_NT = 1 /* mixed_precision_gemm tile width in 64-column units: 0 = auto, 2..4 = force */

@@ -33,7 +33,8 @@ pytestmark = pytest.mark.gpu
 IN_T = {"int8": torch.int8, "fn": torch.float8_e4m3fn, "fnuz": torch.float8_e4m3fnuz}
 SHAPES = [(128, 256, 128), (1024, 1024, 1024), (4096, 2048, 4096)]
 VARIANTS = {"auto": _C.VARIANT_AUTO, "generic": _C.VARIANT_GENERIC, "simple": _C.VARIANT_MFMA_SIMPLE,
-            "pingpong": _C.VARIANT_MFMA_PINGPONG, "skinny": _C.VARIANT_MFMA_SKINNY, "pingpong2": _C.VARIANT_MFMA_PINGPONG2}
+            "pingpong": _C.VARIANT_MFMA_PINGPONG, "skinny": _C.VARIANT_MFMA_SKINNY, "pingpong2": _C.VARIANT_MFMA_PINGPONG2,
+            "mid": _C.VARIANT_MFMA_MID}
 # fp accumulation-order tolerance, relative to max|C| of the case, in output-dtype epsilons
 EPS = {torch.float16: 2.0**-10, torch.bfloat16: 2.0**-7}
 
@@ -100,7 +101,7 @@ def test_scaled_gemm_large_shape(iname, oname, sa_scalar, sb_scalar, use_bias):
     check_scaled(run_scaled(a, b, sa, sb, DT[oname], bias), ref, IN_T[iname], DT[oname])
 
 
-@pytest.mark.parametrize("variant", ["generic", "simple", "pingpong", "pingpong2", "skinny"])
+@pytest.mark.parametrize("variant", ["generic", "simple", "pingpong", "pingpong2", "mid", "skinny"])
 @pytest.mark.parametrize("iname", ["int8", "fn"])
 @pytest.mark.parametrize(("m", "k", "n"), [(128, 256, 128), (1024, 1024, 1024), (300, 384, 520), (257, 128, 8),
                                             (512, 1152, 1376), (2304, 512, 4672), (4096, 256, 11008),

@@ -176,16 +176,16 @@ if __name__ == "__main__":
         for dtype in (torch.int8, torch.float8_e4m3fn):
             for k in (4096, 8192):
                 for n in (4096, 11008, 16384, 28672):
-                    for m in (16, 64, 128, 192, 256):
+                    for m in (16, 64, 128, 256, 384, 512, 1024):
                         res = {}
-                        for v in (4, 5):
+                        for v in (4, 5, 6):
                             try:
                                 for _ in range(3):
                                     time_scaled(m, k, n, dtype, v, iters=30)
                                 res[v] = statistics.median([time_scaled(m, k, n, dtype, v, iters=40) for _ in range(3)]) * 1e3
                             except Exception:  # noqa: BLE001
                                 res[v] = float("nan")
-                        print(f"{str(dtype)[6:]:14s} M={m:4d} K={k} N={n:6d}: skinny {res[4]:7.1f} us   tiled {res[5]:7.1f} us   {'SKINNY' if res[4] < res[5] else 'TILED'}", flush=True)
+                        print(f"{str(dtype)[6:]:14s} M={m:4d} K={k} N={n:6d}: skinny {res[4]:7.1f} us   tiled {res[5]:7.1f} us   mid {res[6]:7.1f} us   {min(res, key=lambda v: res[v] if res[v] == res[v] else 1e9)}", flush=True)
         sys.exit(0)
     if "--mixednt" in sys.argv:
         import statistics
