@@ -84,9 +84,9 @@ int run_scaled_fast(const ScaledGemmArgs& p, int variant, hipStream_t stream) {
     set_error("scaled_gemm: skinny variant forced but its contract is not met (M <= 256, K %% 1024 == 0)");
     return CONCH_ERR_UNSUPPORTED;
   }
-  // auto: the cheapest of three kernels by a cost model fitted to a 112-point sweep over M in 16..1024, K in {4096, 8192},
-  // N in 4096..28672, int8 and fp8 (tools/quick_bench.py --skinnysweep, profiles/r01/skinny_tiled_mid_sweep.txt), in us:
-  //   split-K skinny  5.5 + c(M) N K            (re-reads the A slice per 64-column block; two row blocks above M = 128)
+  // auto: the cheapest of three kernels by a cost model fitted to two 112-point sweeps over M in 8..1024, K in {4096, 8192},
+  // N in 4096..28672, int8 and fp8 (tools/quick_bench.py --skinnysweep, profiles/r01/skinny_tiled_mid_sweep*.txt), in us:
+  //   split-K skinny  4.5-5.5 + c(M) N K        (re-reads the A slice per 64-column block; two row blocks above M = 128)
   //   256x256 tiles   rounds x (34 + 0.05 t) K/4096,  t = tiles per round of 256 workgroups (a lone tile is bound by its
   //                   CU's L2 -> LDS rate; a full round shares the L2 / Infinity Cache)
   //   128x128 tiles   rounds x (19 + 0.0176 t) K/4096, t = tiles per round of 512 workgroups (two per CU)
@@ -106,8 +106,9 @@ int run_scaled_fast(const ScaledGemmArgs& p, int variant, hipStream_t stream) {
       use_mid = true;
     }
     if (scaled_gemm_skinny_supported(p)) {
-      const double c = p.m <= 16 ? 2.6 : p.m <= 64 ? 3.3 : p.m <= 128 ? 4.4 : p.m <= 192 ? 8.5 : 9.7;
-      const double skinny_us = 5.5 + c * 1e-7 * (double)p.n * (double)p.k;
+      const double c = p.m <= 16 ? 1.7 : p.m <= 32 ? 2.0 : p.m <= 48 ? 2.3 : p.m <= 64 ? 2.5 : p.m <= 96 ? 4.3 : p.m <= 128 ? 4.8
+                       : p.m <= 192 ? 8.5 : 9.7;  // steps at the 32- / 64- / 128-row forms and at the second row block
+      const double skinny_us = (p.m <= 64 ? 4.5 : 5.5) + c * 1e-7 * (double)p.n * (double)p.k;
       if (skinny_us < best) use_skinny = true;
     }
   }

@@ -141,32 +141,36 @@ constexpr int kSpN = 64;          // columns per workgroup (16 per wave)
 constexpr int kSpSteps = 8;       // 128-byte K steps per slice: a slice is 1024 bytes of K
 constexpr int kSpSliceK = kSpSteps * kStepBytes;
 
-template <int MMA, int S>
-__device__ __forceinline__ void sp_consume(typename AccT<MMA>::type (&acc)[8], const Frag (&fb)[8], const char* lds,
+// ROWS = rows of A a workgroup handles (32, 64 or 128): a decode batch of 32 rows stages, multiplies and writes a quarter
+// of what the 128-row form does.  Per step and wave: 2 register loads of B^T + ROWS/32 LDS-DMA pieces of A.
+template <int MMA, int ROWS, int S>
+__device__ __forceinline__ void sp_consume(typename AccT<MMA>::type (&acc)[ROWS / 16], const Frag (&fb)[8], const char* lds,
                                            int lane_off) {
+  constexpr int kOps = 2 + ROWS / 32;
   if constexpr (S < 8) {
-    wait_vmcnt_n<6 * (7 - S)>();    // step S of this wave has landed ...
-    __builtin_amdgcn_s_barrier();   // ... and so has every other wave's quarter of unit S
+    wait_vmcnt_n<kOps * (7 - S)>();  // step S of this wave has landed ...
+    __builtin_amdgcn_s_barrier();    // ... and so has every other wave's quarter of unit S
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const Frag fa = read_frag(lds, S * kUnitBytes + lane_off + i * 2048);
+    for (int i = 0; i < ROWS / 16; ++i) {
+      const Frag fa = read_frag(lds, S * (ROWS * kStepBytes) + lane_off + i * 2048);
       mma_step<MMA>(acc[i], fb[S], fa);  // D rows = n, D cols = m
     }
-    sp_consume<MMA, S + 1>(acc, fb, lds, lane_off);
+    sp_consume<MMA, ROWS, S + 1>(acc, fb, lds, lane_off);
   }
 }
 
-// The whole slice is put in flight at once -- 8 A units (128 KiB of LDS, LDS-DMA) and 8 B^T fragments
+// The whole slice is put in flight at once -- 8 A units (ROWS x 128 bytes each, LDS-DMA) and 8 B^T fragments
 // (64 VGPRs) per wave -- so the slice costs one memory latency plus its transfer time instead of a
-// latency per K step; the steps are then consumed in issue order with counted vmcnt waits
-// (6 VMEM operations per step and wave: 2 register loads + 4 DMA).
-template <int MMA>
+// latency per K step; the steps are then consumed in issue order with counted vmcnt waits.
+template <int MMA, int ROWS>
 __global__ __launch_bounds__(kSkThreads, 1) void skinny_splitk_kernel(ScaledGemmArgs p, int* __restrict__ slabs) {
-  __shared__ __attribute__((aligned(1024))) char lds[kSpSteps * kUnitBytes];
+  constexpr int kUnit = ROWS * kStepBytes;  // one K step of A
+  constexpr int kPieces = ROWS / 32;        // 8-row x 128-byte subtiles a wave feeds per step
+  __shared__ __attribute__((aligned(1024))) char lds[kSpSteps * kUnit];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int r = lane & 15, g = lane >> 4;
-  const int n0 = blockIdx.x * kSpN + wave * 16, m0 = blockIdx.z * kSkM;
+  const int n0 = blockIdx.x * kSpN + wave * 16, m0 = blockIdx.z * ROWS;
   const int slice = blockIdx.y;
   const int k_begin = slice * kSpSliceK;
 
@@ -175,11 +179,11 @@ __global__ __launch_bounds__(kSkThreads, 1) void skinny_splitk_kernel(ScaledGemm
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.b, 0, b_bytes, 0x00020000);
 
-  // A unit staging: wave w feeds unit rows [32w, 32w+32) = 4 subtiles of 8 rows x 128 bytes
-  int voff_a[4];
+  // A unit staging: wave w feeds unit rows [ROWS/4 * w, ROWS/4 * (w + 1)) = kPieces subtiles of 8 rows x 128 bytes
+  int voff_a[4];  // the first kPieces are used (a dependent array bound here makes hipcc's host pass drop the kernel's stub)
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int rho = 32 * wave + 8 * j + (lane >> 3);
+  for (int j = 0; j < kPieces; ++j) {
+    const int rho = (ROWS / 4) * wave + 8 * j + (lane >> 3);
     const int chunk = (lane & 7) ^ ((rho >> 1) & 7);
     voff_a[j] = min(m0 + rho, (int)p.m - 1) * (int)p.a_stride_m + chunk * 16;
   }
@@ -191,23 +195,25 @@ __global__ __launch_bounds__(kSkThreads, 1) void skinny_splitk_kernel(ScaledGemm
   for (int s = 0; s < kSpSteps; ++s) {
     fb[s].lo = ld16(rb, voff_b, k_begin + s * kStepBytes);
     fb[s].hi = ld16(rb, voff_b, k_begin + s * kStepBytes + 64);
-    char* dst = lds + s * kUnitBytes + wave * 4096;
+    char* dst = lds + s * kUnit + wave * (ROWS / 4) * kStepBytes;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < kPieces; ++j)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(dst + j * 1024), 16, voff_a[j],
                                                k_begin + s * kStepBytes, 0, 0);
+    // the counted waits below count VMEM operations in THIS order, step by step: no reordering across steps
+    __builtin_amdgcn_sched_barrier(0);
   }
 
-  typename AccT<MMA>::type acc[8];
+  typename AccT<MMA>::type acc[ROWS / 16];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) acc[i] = typename AccT<MMA>::type{0, 0, 0, 0};
+  for (int i = 0; i < ROWS / 16; ++i) acc[i] = typename AccT<MMA>::type{0, 0, 0, 0};
 
-  sp_consume<MMA, 0>(acc, fb, lds, lane_off);
+  sp_consume<MMA, ROWS, 0>(acc, fb, lds, lane_off);
 
   // partial sums -> slab [slice][M][N] (4-byte elements); lane: m = m0 + 16 i + r, n = n0 + 4 g + e
   int* slab = slabs + (int64_t)slice * p.m * p.n;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < ROWS / 16; ++i) {
     const int m = m0 + i * 16 + r;
     const int n = n0 + 4 * g;
     if (m < p.m && n + 4 <= p.n) *(i32x4*)(slab + (int64_t)m * p.n + n) = __builtin_bit_cast(i32x4, acc[i]);
@@ -248,6 +254,20 @@ __global__ __launch_bounds__(256) void skinny_reduce_kernel(ScaledGemmArgs p, co
   }
 }
 
+// launches the partial-sum kernel for a runtime (operand type, row count) pair
+void launch_splitk_partials(int mma, int rows, dim3 grid, const ScaledGemmArgs& p, int* ws, hipStream_t stream) {
+  const dim3 block(kSkThreads);
+  if (mma == kMmaFp8) {
+    if (rows == 32) hipLaunchKernelGGL((skinny_splitk_kernel<kMmaFp8, 32>), grid, block, 0, stream, p, ws);
+    else if (rows == 64) hipLaunchKernelGGL((skinny_splitk_kernel<kMmaFp8, 64>), grid, block, 0, stream, p, ws);
+    else hipLaunchKernelGGL((skinny_splitk_kernel<kMmaFp8, 128>), grid, block, 0, stream, p, ws);
+  } else {
+    if (rows == 32) hipLaunchKernelGGL((skinny_splitk_kernel<kMmaInt8, 32>), grid, block, 0, stream, p, ws);
+    else if (rows == 64) hipLaunchKernelGGL((skinny_splitk_kernel<kMmaInt8, 64>), grid, block, 0, stream, p, ws);
+    else hipLaunchKernelGGL((skinny_splitk_kernel<kMmaInt8, 128>), grid, block, 0, stream, p, ws);
+  }
+}
+
 int splitk_slices(const ScaledGemmArgs& p) {
   // slices of exactly 1024 K-bytes (K % 1024 == 0 is part of the skinny contract)
   if (p.n % 4 || p.m > 2 * kSkM || p.k % kSpSliceK) return 0;
@@ -271,8 +291,9 @@ int launch_splitk(const ScaledGemmArgs& p, int slices, hipStream_t stream) {
     (void)hipGetLastError();
     return -1;  // caller falls back to the in-workgroup K split
   }
-  const dim3 grid((unsigned)((p.n + kSpN - 1) / kSpN), (unsigned)slices, (unsigned)((p.m + kSkM - 1) / kSkM));
-  hipLaunchKernelGGL((skinny_splitk_kernel<MMA>), grid, dim3(kSkThreads), 0, stream, p, (int*)ws);
+  const int rows = p.m <= 32 ? 32 : p.m <= 64 ? 64 : 128;
+  const dim3 grid((unsigned)((p.n + kSpN - 1) / kSpN), (unsigned)slices, (unsigned)((p.m + rows - 1) / rows));
+  launch_splitk_partials(MMA, rows, grid, p, (int*)ws, stream);
   const int64_t quads = p.m * (p.n / 4);
   hipLaunchKernelGGL((skinny_reduce_kernel<MMA, OUT_DT>), dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, p,
                      (const int*)ws, slices);

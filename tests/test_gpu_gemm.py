@@ -105,7 +105,8 @@ def test_scaled_gemm_large_shape(iname, oname, sa_scalar, sb_scalar, use_bias):
 @pytest.mark.parametrize("iname", ["int8", "fn"])
 @pytest.mark.parametrize(("m", "k", "n"), [(128, 256, 128), (1024, 1024, 1024), (300, 384, 520), (257, 128, 8),
                                             (512, 1152, 1376), (2304, 512, 4672), (4096, 256, 11008),
-                                            (128, 1024, 4096), (200, 2048, 520), (1, 1024, 24), (256, 3072, 1376)])
+                                            (128, 1024, 4096), (200, 2048, 520), (1, 1024, 24), (256, 3072, 1376),
+                                            (48, 1024, 520), (20, 2048, 4096), (33, 1024, 64)])
 def test_scaled_gemm_every_kernel_variant(variant, iname, m, k, n):
     """Each device kernel, including ragged M/N tails (partial tiles, N not a multiple of 256 / 16)."""
     if variant == "pingpong2" and k < 256:

@@ -175,8 +175,8 @@ if __name__ == "__main__":
         import statistics
         for dtype in (torch.int8, torch.float8_e4m3fn):
             for k in (4096, 8192):
-                for n in (4096, 11008, 16384, 28672):
-                    for m in (16, 64, 128, 256, 384, 512, 1024):
+                for n in (4096, 8192, 16384, 28672):
+                    for m in (8, 16, 32, 48, 64, 96, 128):
                         res = {}
                         for v in (4, 5, 6):
                             try:
