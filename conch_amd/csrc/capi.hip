@@ -188,9 +188,18 @@ int check_mixed(const MixedGemmArgs& p) {
 int run_mixed(const MixedGemmArgs& p, hipStream_t stream) {
   if (int rc = check_mixed(p)) return rc;
   if (p.m == 0 || p.n == 0) return CONCH_OK;
-  // variant 1 forces the generic kernel; every other value means the LDS-tiled MFMA kernel (gemm_mixed.hip)
+  // variant 1 forces the generic kernel, 4 the decode-batch kernel (gemm_mixed_skinny.hip: M <= 64), any other non-zero
+  // value the LDS-tiled MFMA kernel (gemm_mixed.hip); auto = decode-batch kernel when its contract is met, else tiled
   const int variant = tuning(CONCH_TUNE_GEMM_VARIANT);
   const bool fast_ok = mixed_gemm_mfma_supported(p);
+  if (variant == 4 && !mixed_gemm_skinny_supported(p)) {
+    set_error("mixed_precision_gemm: skinny variant forced but its contract is not met (M <= 64, K %% 1024 == 0, N %% 4 == 0)");
+    return CONCH_ERR_UNSUPPORTED;
+  }
+  // auto: the decode-batch kernel up to 32 rows, and up to 64 rows while N x K < 9e7 (it re-stages the X slice per
+  // 64-column block: 64x4096x28672 ties with the tiled kernel at 58 us; profiles/r01/mixed_decode.txt)
+  const bool decode = variant == 4 || (variant == 0 && (p.m <= 32 || (double)p.n * (double)p.k < 9.0e7));
+  if (decode && mixed_gemm_skinny_supported(p)) return launch_mixed_gemm_skinny(p, stream);
   if (variant == 1 || !fast_ok) {
     if (variant >= 2 && !fast_ok) {
       set_error("mixed_precision_gemm: MFMA variant %d forced but the layout contract is not met", variant);
@@ -209,7 +218,9 @@ int run_mixed_silu(const MixedGemmArgs& p, hipStream_t stream) {
   if (int rc = check_mixed(wide)) return rc;
   if (p.m == 0 || p.n == 0) return CONCH_OK;
   const int variant = tuning(CONCH_TUNE_GEMM_VARIANT);
-  if (variant != 1 && variant != 2 && mixed_gemm_mfma_supported(p)) return launch_mixed_gemm_mfma(p, stream);
+  // decode batches: the unfused pair on the decode-batch GEMM beats the fused 256-row tile
+  const bool decode = variant == 0 && mixed_gemm_skinny_supported(wide) && (p.m <= 32 || (double)wide.n * (double)p.k < 9.0e7);
+  if (!decode && variant != 1 && variant != 2 && mixed_gemm_mfma_supported(p)) return launch_mixed_gemm_mfma(p, stream);
   void* tmp = nullptr;
   if (int rc = get_scratch(stream, 3, (size_t)p.m * (size_t)wide.n * 2, &tmp)) return rc;
   wide.c = tmp;

@@ -67,5 +67,8 @@ int launch_silu_and_mul(void* out, const void* x, int64_t m, int64_t n, int64_t 
                         hipStream_t stream);
 bool mixed_gemm_mfma_supported(const MixedGemmArgs& p);
 int launch_mixed_gemm_mfma(const MixedGemmArgs& p, hipStream_t stream);
+// gemm_mixed_skinny.hip -- decode batches (M <= 64, K % 1024 == 0): weights straight to MFMA registers, split-K (variant 4)
+bool mixed_gemm_skinny_supported(const MixedGemmArgs& p);
+int launch_mixed_gemm_skinny(const MixedGemmArgs& p, hipStream_t stream);
 
 }  // namespace conch

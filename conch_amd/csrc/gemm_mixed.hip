@@ -32,11 +32,13 @@
 #include "common.hpp"
 #include "gemm.hpp"
 #include "mfma_tile.hpp"
+#include "mixed_dequant.hpp"
 
 namespace conch {
 namespace {
 
 using namespace tile;
+using mixed::ChunkDequant;
 
 constexpr int kStepK = 64;  // k elements per step (128 bytes of 16-bit)
 
@@ -167,92 +169,6 @@ __device__ __forceinline__ void load_weights(WeightRegs<BITS, NT>& r, const Weig
     else r.zp[un] = 0;
   }
 }
-
-template <int X_DT, int BITS>
-struct ChunkDequant {
-  static constexpr bool kHalf = X_DT == CONCH_DT_FP16;
-  static constexpr int kSlices = 10;  // the last one is the ds_write_b128
-  uint32_t w0, w1, sub, sc;
-  uint32_t a, b, c, d;
-  f32x2 p_lo, p_hi, q_lo, q_hi;  // bf16 path: (a.lo, b.lo), (a.hi, b.hi), (c.lo, d.lo), (c.hi, d.hi) widened to fp32
-  float fs;
-  i32x4 out;
-
-  static __device__ __forceinline__ uint32_t pk_sub(uint32_t v, uint32_t s) {
-    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(f16x2, v) - __builtin_bit_cast(f16x2, s));
-  }
-  static __device__ __forceinline__ uint32_t pk_mul(uint32_t v, uint32_t s) {
-    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(f16x2, v) * __builtin_bit_cast(f16x2, s));
-  }
-  // the fp32 pairs are formed the way they are packed again: (element of a, element of b) -> one output dword, so the
-  // scale multiply is a v_pk_mul_f32 and the rounding ONE v_cvt_pk_bf16_f32 per dword
-  static __device__ __forceinline__ void widen(uint32_t x, uint32_t y, f32x2& lo, f32x2& hi) {
-    const f16x2 hx = __builtin_bit_cast(f16x2, x), hy = __builtin_bit_cast(f16x2, y);
-    lo = f32x2{(float)hx[0], (float)hy[0]};
-    hi = f32x2{(float)hx[1], (float)hy[1]};
-  }
-  // output dword j of the chunk is the pair (k 2j, k 2j+1)
-  static constexpr int kOutLoP = 0, kOutHiP = BITS == 4 ? 2 : 1, kOutLoQ = BITS == 4 ? 1 : 2, kOutHiQ = 3;
-
-  // `mask` (a VGPR) and `magic` (an SGPR) hold 0x000f000f / 0x00ff00ff and 0x64006400 as VALUES the compiler cannot see:
-  // with literals it emits v_and_b32 + v_or_b32 (a VOP3 instruction cannot carry a 32-bit literal on gfx9); with
-  // registers (x & mask) | magic is ONE v_and_or_b32 -- 16 fewer VALU instructions per K step and thread
-  __device__ __forceinline__ void slice(int s, uint32_t word0, uint32_t word1, int off, uint32_t scale_bits, char* dst,
-                                        uint32_t mask, uint32_t magic) {
-    constexpr uint32_t kLowHalves = 0x05040100u, kHighHalves = 0x07060302u;
-    constexpr int kShift = BITS == 4 ? 4 : 8;
-    if (s == 0) {
-      w0 = word0;
-      w1 = BITS == 4 ? (word0 >> 8) : word1;
-      const uint32_t sub1 = (uint32_t)float_to_half_bits((float)(1024 + off));
-      sub = sub1 | (sub1 << 16);
-      if constexpr (kHalf) sc = scale_bits | (scale_bits << 16);
-      else fs = bf16_bits_to_float((uint16_t)scale_bits);
-    } else if (s == 1) {
-      a = (w0 & mask) | magic;
-      b = ((w0 >> kShift) & mask) | magic;
-    } else if (s == 2) {
-      c = (w1 & mask) | magic;
-      d = ((w1 >> kShift) & mask) | magic;
-    } else if (s == 3) {
-      a = pk_sub(a, sub);
-      b = pk_sub(b, sub);
-    } else if (s == 4) {
-      c = pk_sub(c, sub);
-      d = pk_sub(d, sub);
-    } else if constexpr (kHalf) {
-      if (s == 5) {
-        a = pk_mul(a, sc);
-        b = pk_mul(b, sc);
-      } else if (s == 6) {
-        c = pk_mul(c, sc);
-        d = pk_mul(d, sc);
-      } else if (s == 7) {
-        out[kOutLoP] = (int)__builtin_amdgcn_perm(b, a, kLowHalves);
-        out[kOutHiP] = (int)__builtin_amdgcn_perm(b, a, kHighHalves);
-      } else if (s == 8) {
-        out[kOutLoQ] = (int)__builtin_amdgcn_perm(d, c, kLowHalves);
-        out[kOutHiQ] = (int)__builtin_amdgcn_perm(d, c, kHighHalves);
-      } else if (s == 9) {
-        *(i32x4*)dst = out;
-      }
-    } else {
-      if (s == 5) {
-        widen(a, b, p_lo, p_hi);
-      } else if (s == 6) {
-        widen(c, d, q_lo, q_hi);
-      } else if (s == 7) {
-        out[kOutLoP] = (int)pack2_bits16<CONCH_DT_BF16>(p_lo * f32x2{fs, fs});
-        out[kOutHiP] = (int)pack2_bits16<CONCH_DT_BF16>(p_hi * f32x2{fs, fs});
-      } else if (s == 8) {
-        out[kOutLoQ] = (int)pack2_bits16<CONCH_DT_BF16>(q_lo * f32x2{fs, fs});
-        out[kOutHiQ] = (int)pack2_bits16<CONCH_DT_BF16>(q_hi * f32x2{fs, fs});
-      } else if (s == 9) {
-        *(i32x4*)dst = out;
-      }
-    }
-  }
-};
 
 template <int X_DT>
 __device__ __forceinline__ void mma1(f32x4& acc, const Frag& fa, const Frag& fb, int h) {

@@ -1,0 +1,205 @@
+// mixed_precision_gemm for decode batches (M <= 64): packed int4 / int8 weights straight from global memory into the
+// MFMA operand registers, activations staged once per workgroup, K split across workgroups.
+//
+// The LDS-tiled kernel (gemm_mixed.hip) walks K in 64-element steps over a 256-row tile: for a handful of rows it is a
+// latency chain of K/64 steps on N/192 CUs (~55 us at K = 4096 whatever M is) while the weights -- 22.5 MB at C4's N, K --
+// could stream in a few microseconds.  Here:
+//   * workgroup = (64-column block, 1024-element K slice), 4 waves x 16 columns; grid = N/64 x K/1024 workgroups;
+//   * a lane of the MFMA's weight operand is (column n0 + lane%16, k-group lane/16): its 8 consecutive k are exactly ONE
+//     packed int4 word (two int8 words) of the [K/pf][N] tensor -- 16 lanes read 64 contiguous bytes of a word row -- so
+//     the weights need no LDS and no transposition: load, dequantise (mixed_dequant.hpp, bit-identical to w_ref), multiply;
+//   * the whole slice is requested up front (2 x 16 words, scales / zero points per K step, and the slice of X by LDS-DMA
+//     into the same swizzled 8-row x 128-byte image the other kernels use), then consumed;
+//   * partial sums go to fp32 slabs [slice][M][N] in library scratch; mixed_skinny_reduce_kernel adds the slices in a
+//     fixed order and casts (the reference's result type, kernels/quantization/gemm.py:482-545).
+// ROWS (16 / 32 / 64) = rows of X a workgroup stages and multiplies.
+#include "common.hpp"
+#include "gemm.hpp"
+#include "mfma_tile.hpp"
+#include "mixed_dequant.hpp"
+
+namespace conch {
+namespace {
+
+using namespace tile;
+using mixed::ChunkDequant;
+
+constexpr int kMsThreads = 256;
+constexpr int kMsN = 64;                  // columns per workgroup
+constexpr int kMsStepK = 64;              // k elements per step (128 bytes of fp16 / bf16)
+constexpr int kMsSteps = 16;              // steps per slice
+constexpr int kMsSliceK = kMsSteps * kMsStepK;
+
+template <int X_DT, int BITS>
+__device__ __forceinline__ i32x4 dequant8(uint32_t w0, uint32_t w1, int off, uint32_t scale_bits, uint32_t mask, uint32_t magic) {
+  ChunkDequant<X_DT, BITS> cv;
+#pragma unroll
+  for (int s = 0; s + 1 < ChunkDequant<X_DT, BITS>::kSlices; ++s) cv.slice(s, w0, w1, off, scale_bits, nullptr, mask, magic);
+  return cv.out;
+}
+
+template <int X_DT, int BITS, int ZP, int ROWS>
+__global__ __launch_bounds__(kMsThreads) void mixed_skinny_kernel(MixedGemmArgs p, float* __restrict__ slabs) {
+  constexpr int kUnit = ROWS * 128;            // one K step of X
+  constexpr int kWpc = BITS == 4 ? 1 : 2;      // 32-bit words per 8-k chunk
+  constexpr int kWordRows = kMsStepK * BITS / 32;  // word rows per K step (8 / 16)
+  __shared__ __attribute__((aligned(1024))) char lds[kMsSteps * kUnit];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 15, g = lane >> 4;
+  const int nw = blockIdx.x * kMsN + wave * 16;       // first column of this wave
+  const int n = min(nw + r, (int)p.n - 1);            // this lane's weight column
+  const int k0 = blockIdx.y * kMsSliceK;
+  const int m0 = blockIdx.z * ROWS;
+
+  // ---- X slice -> LDS (8-row x 128-byte subtiles, source-side swizzle); piece q = rows 8q..8q+7 of a step
+  const __amdgpu_buffer_rsrc_t rx =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (uint32_t)(((p.m - 1) * p.x_stride_m + p.k) * 2), 0x00020000);
+  constexpr int kPieces = ROWS / 8;  // per step; dealt round-robin to the four waves
+#pragma unroll
+  for (int s = 0; s < kMsSteps; ++s)
+#pragma unroll
+    for (int q = 0; q < kPieces; ++q) {
+      if ((q & 3) != wave) continue;  // wave-uniform
+      const int row = 8 * q + (lane >> 3);
+      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+      const int voff = min(m0 + row, (int)p.m - 1) * (int)p.x_stride_m * 2 + chunk * 16;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t*)(lds + s * kUnit + q * 1024), 16, voff, (k0 + s * kMsStepK) * 2, 0, 0);
+    }
+
+  // ---- weights, scales, zero points of the whole slice -> registers
+  const int64_t word_rows = p.k * BITS / 32, groups = p.k / p.group_size;
+  const __amdgpu_buffer_rsrc_t rq =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.w_q, 0, (uint32_t)(((word_rows - 1) * p.wq_stride_k + p.n) * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.w_s, 0, (uint32_t)(((groups - 1) * p.ws_stride_g + p.n) * 2), 0x00020000);
+  __amdgpu_buffer_rsrc_t rz = rs;
+  if constexpr (ZP == CONCH_ZP_TENSOR)
+    rz = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_zp, 0, (uint32_t)(((groups - 1) * p.wzp_stride_g + p.n) * 4), 0x00020000);
+  const int q_row = (int)p.wq_stride_k * 4;                         // bytes per word row
+  const int vq = (g * kWpc) * q_row + n * 4;                        // this lane's k-group inside a half step
+  const int q_base = (k0 * BITS / 32) * q_row;
+  uint32_t wq[kMsSteps][2][kWpc];
+  uint32_t sc[kMsSteps];
+  int zp[kMsSteps];
+#pragma unroll
+  for (int s = 0; s < kMsSteps; ++s) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < kWpc; ++i)
+        wq[s][h][i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rq, vq, q_base + (s * kWordRows + h * (kWordRows / 2) + i) * q_row, 0);
+    const int grp = (k0 + s * kMsStepK) / p.group_size;
+    sc[s] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs, n * 2, grp * (int)p.ws_stride_g * 2, 0);
+    if constexpr (ZP == CONCH_ZP_TENSOR) zp[s] = (int)__builtin_amdgcn_raw_buffer_load_b32(rz, n * 4, grp * (int)p.wzp_stride_g * 4, 0);
+    else zp[s] = 0;
+  }
+  const int off_base = p.weight_bias + (ZP == CONCH_ZP_SCALAR ? p.w_zp[0] : 0);
+  uint32_t and_mask = BITS == 4 ? 0x000f000fu : 0x00ff00ffu, or_magic = 0x64006400u;
+  asm volatile("" : "+v"(and_mask), "+s"(or_magic));
+
+  f32x4 acc[ROWS / 16];
+#pragma unroll
+  for (int i = 0; i < ROWS / 16; ++i) acc[i] = f32x4{0, 0, 0, 0};
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA pieces (and its register loads) have landed
+  __builtin_amdgcn_s_barrier();                     // ... and so have the other waves' pieces
+
+  const int lane_off = (r >> 3) * 1024 + (r & 7) * 128 + ((g ^ ((r >> 1) & 7)) * 16);
+#pragma unroll
+  for (int s = 0; s < kMsSteps; ++s) {
+    // the lane's 8 + 8 weights of this step: k = 8g..8g+7 (first half step) and 32 + 8g.. (second), column n
+    const i32x4 w_lo = dequant8<X_DT, BITS>(wq[s][0][0], wq[s][0][kWpc - 1], off_base + zp[s], sc[s], and_mask, or_magic);
+    const i32x4 w_hi = dequant8<X_DT, BITS>(wq[s][1][0], wq[s][1][kWpc - 1], off_base + zp[s], sc[s], and_mask, or_magic);
+#pragma unroll
+    for (int i = 0; i < ROWS / 16; ++i) {
+      const Frag fx = read_frag(lds, s * kUnit + lane_off + i * 2048);
+      if constexpr (X_DT == CONCH_DT_FP16) {
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w_lo), __builtin_bit_cast(f16x8, fx.lo), acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w_hi), __builtin_bit_cast(f16x8, fx.hi), acc[i], 0, 0, 0);
+      } else {
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w_lo), __builtin_bit_cast(bf16x8, fx.lo), acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w_hi), __builtin_bit_cast(bf16x8, fx.hi), acc[i], 0, 0, 0);
+      }
+    }
+  }
+
+  // D rows = n (4g + e), D columns = m (lane % 16): four consecutive n of one row per lane
+  float* slab = slabs + (int64_t)blockIdx.y * p.m * p.n;
+#pragma unroll
+  for (int i = 0; i < ROWS / 16; ++i) {
+    const int m = m0 + i * 16 + r;
+    const int nn = nw + 4 * g;
+    if (m < p.m && nn + 4 <= p.n) *(f32x4*)(slab + (int64_t)m * p.n + nn) = acc[i];
+  }
+}
+
+// out[m][n..n+3] = cast( sum over slices, in slice order )
+template <int OUT_DT>
+__global__ __launch_bounds__(256) void mixed_skinny_reduce_kernel(MixedGemmArgs p, const float* __restrict__ slabs, int slices) {
+  const int64_t quad = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t quads_per_row = p.n / 4;
+  if (quad >= p.m * quads_per_row) return;
+  const int m = (int)(quad / quads_per_row), n = (int)(quad % quads_per_row) * 4;
+  f32x4 sum = *(const f32x4*)(slabs + (int64_t)m * p.n + n);
+  for (int s = 1; s < slices; ++s) sum += *(const f32x4*)(slabs + ((int64_t)s * p.m + m) * p.n + n);
+  i32x2 pk;
+  pk[0] = (int)pack2_bits16<OUT_DT>(f32x2{sum[0], sum[1]});
+  pk[1] = (int)pack2_bits16<OUT_DT>(f32x2{sum[2], sum[3]});
+  uint16_t* dst = (uint16_t*)p.c + (int64_t)m * p.c_stride_m + n;
+  if ((((uintptr_t)dst) & 7) == 0) {
+    *(i32x2*)dst = pk;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dst[e] = (uint16_t)((uint32_t)pk[e >> 1] >> (16 * (e & 1)));
+  }
+}
+
+template <int X_DT, int BITS, int ZP>
+void launch_rows(const MixedGemmArgs& p, int rows, dim3 grid, float* ws, hipStream_t stream) {
+  const dim3 block(kMsThreads);
+  if (rows == 16) hipLaunchKernelGGL((mixed_skinny_kernel<X_DT, BITS, ZP, 16>), grid, block, 0, stream, p, ws);
+  else if (rows == 32) hipLaunchKernelGGL((mixed_skinny_kernel<X_DT, BITS, ZP, 32>), grid, block, 0, stream, p, ws);
+  else hipLaunchKernelGGL((mixed_skinny_kernel<X_DT, BITS, ZP, 64>), grid, block, 0, stream, p, ws);
+}
+
+template <int X_DT, int BITS>
+void launch_zp_mode(const MixedGemmArgs& p, int rows, dim3 grid, float* ws, hipStream_t stream) {
+  if (p.zp_mode == CONCH_ZP_NONE) launch_rows<X_DT, BITS, CONCH_ZP_NONE>(p, rows, grid, ws, stream);
+  else if (p.zp_mode == CONCH_ZP_SCALAR) launch_rows<X_DT, BITS, CONCH_ZP_SCALAR>(p, rows, grid, ws, stream);
+  else launch_rows<X_DT, BITS, CONCH_ZP_TENSOR>(p, rows, grid, ws, stream);
+}
+
+}  // namespace
+
+bool mixed_gemm_skinny_supported(const MixedGemmArgs& p) {
+  if (!mixed_gemm_mfma_supported(p)) return false;  // dtypes, bits in {4, 8}, alignment, 32-bit buffer offsets
+  if (p.fuse_silu) return false;
+  if (p.m > 64 || p.n % 4) return false;
+  if (p.k % kMsSliceK) return false;                 // whole 1024-element slices (group_size % 64 == 0 is in the base contract)
+  if ((((uintptr_t)p.c) & 1) || p.c_stride_m < p.n) return false;
+  return true;
+}
+
+int launch_mixed_gemm_skinny(const MixedGemmArgs& p, hipStream_t stream) {
+  const int slices = (int)(p.k / kMsSliceK);
+  const int rows = p.m <= 16 ? 16 : p.m <= 32 ? 32 : 64;
+  void* ws = nullptr;
+  if (int rc = get_scratch(stream, 2, (size_t)slices * p.m * p.n * 4, &ws)) return rc;
+  const dim3 grid((unsigned)((p.n + kMsN - 1) / kMsN), (unsigned)slices, (unsigned)((p.m + rows - 1) / rows));
+  if (p.x_dtype == CONCH_DT_FP16) {
+    if (p.bits == 4) launch_zp_mode<CONCH_DT_FP16, 4>(p, rows, grid, (float*)ws, stream);
+    else launch_zp_mode<CONCH_DT_FP16, 8>(p, rows, grid, (float*)ws, stream);
+  } else {
+    if (p.bits == 4) launch_zp_mode<CONCH_DT_BF16, 4>(p, rows, grid, (float*)ws, stream);
+    else launch_zp_mode<CONCH_DT_BF16, 8>(p, rows, grid, (float*)ws, stream);
+  }
+  const int64_t quads = p.m * (p.n / 4);
+  if (p.out_dtype == CONCH_DT_FP16)
+    hipLaunchKernelGGL((mixed_skinny_reduce_kernel<CONCH_DT_FP16>), dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, p, (const float*)ws, slices);
+  else
+    hipLaunchKernelGGL((mixed_skinny_reduce_kernel<CONCH_DT_BF16>), dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, p, (const float*)ws, slices);
+  return check_launch("mixed_gemm_skinny");
+}
+
+}  // namespace conch

@@ -565,3 +565,43 @@ def test_mixed_precision_silu_fused_equals_unfused(m, k, d, wname, use_zp, dname
         _C.load().conch_set_tuning(1, 0)
         _C.set_gemm_variant(_C.VARIANT_AUTO)
     assert torch.equal(got, unfused)
+
+
+# ---------------------------------------------------------------------------------------------
+# decode-batch kernel of mixed_precision_gemm (M <= 64, gemm_mixed_skinny.hip)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize(("m", "k", "n"), [(1, 1024, 64), (16, 2048, 520), (20, 1024, 4096), (33, 4096, 1376), (64, 2048, 256), (48, 1024, 100)])
+@pytest.mark.parametrize(("wname", "use_zp", "dname"), [("uint4b8", False, "f16"), ("uint4", True, "bf16"),
+                                                         ("uint8b128", True, "f16"), ("uint8", False, "bf16")])
+def test_mixed_precision_decode_batches(m, k, n, wname, use_zp, dname):
+    """The automatic choice for M <= 64, K % 1024 == 0, N % 4 == 0 (forced with variant 4 so that a contract change cannot
+    silently skip it): against the oracle, and against the LDS-tiled kernel (other summation order: 2 eps of max|C|)."""
+    wt = WTYPES[wname]
+    a, w_ref, packed, w_s, w_zp = make_mixed_inputs(m, k, n, wt, use_zp, DT[dname])
+    args = (a.cuda(), packed.cuda(), w_s.cuda(), None if w_zp is None else w_zp.cuda(), wt.size_bits, wt.bias, 128)
+    _C.set_gemm_variant(_C.VARIANT_MFMA_SKINNY)
+    got = mixed_precision_gemm(*args)
+    check_mixed(got, a, w_ref, k)
+    _C.set_gemm_variant(_C.VARIANT_MFMA_PINGPONG2)
+    tiled = mixed_precision_gemm(*args)
+    _C.set_gemm_variant(_C.VARIANT_AUTO)
+    assert torch.equal(mixed_precision_gemm(*args), got)  # auto = the decode-batch kernel
+    tol = 2.0 * EPS[DT[dname]] * tiled.float().abs().max().item()
+    assert (got.float() - tiled.float()).abs().max().item() <= tol
+
+
+def test_mixed_precision_decode_dequant_is_bit_exact():
+    """Unit-vector activations isolate the dequantisation in the decode-batch kernel: row i of C must be row j_i of w_ref
+    bit for bit (the same claim test_mixed_precision_dequant_is_bit_exact makes for the tiled and generic kernels)."""
+    k, n = 1024, 256
+    rows = torch.tensor([0, 1, 7, 8, 31, 32, 63, 64, 127, 128, 500, 511, 512, 777, 1000, 1023])
+    for dname in ("f16", "bf16"):
+        for wname, wt in WTYPES.items():
+            for use_zp in (False, True):
+                _, w_ref, packed, w_s, w_zp = make_mixed_inputs(8, k, n, wt, use_zp, DT[dname])
+                x = torch.zeros((len(rows), k), dtype=DT[dname])
+                x[torch.arange(len(rows)), rows] = 1.0
+                _C.set_gemm_variant(_C.VARIANT_MFMA_SKINNY)
+                got = mixed_precision_gemm(x.cuda(), packed.cuda(), w_s.cuda(), None if w_zp is None else w_zp.cuda(),
+                                           wt.size_bits, wt.bias, 128)
+                np.testing.assert_array_equal(to_bits(got), to_bits(w_ref[rows]), err_msg=f"{dname} {wname} zp={use_zp}")

@@ -187,6 +187,20 @@ if __name__ == "__main__":
                                 res[v] = float("nan")
                         print(f"{str(dtype)[6:]:14s} M={m:4d} K={k} N={n:6d}: skinny {res[4]:7.1f} us   tiled {res[5]:7.1f} us   mid {res[6]:7.1f} us   {min(res, key=lambda v: res[v] if res[v] == res[v] else 1e9)}", flush=True)
         sys.exit(0)
+    if "--mixeddecode" in sys.argv:
+        # decode-batch mixed kernel (variant 4) against the LDS-tiled kernel (variant 5)
+        import statistics
+        for (k, n) in [(4096, 4096), (4096, 11008), (8192, 8192), (4096, 28672)]:
+            for m in (1, 16, 32, 64):
+                for dtype, bits in ((torch.float16, 4), (torch.bfloat16, 8)):
+                    res = {}
+                    for v in (4, 5):
+                        for _ in range(3):
+                            time_mixed(m, k, n, dtype, bits, v, iters=20)
+                        res[v] = statistics.median([time_mixed(m, k, n, dtype, bits, v, iters=40) for _ in range(3)]) * 1e3
+                    wbytes = k * n * bits / 8
+                    print(f"int{bits} {str(dtype)[6:]:9s} M={m:3d} K={k} N={n:6d}: decode kernel {res[4]:7.1f} us ({wbytes / res[4] / 1e6:.2f} TB/s of weights)   tiled {res[5]:7.1f} us", flush=True)
+        sys.exit(0)
     if "--mixednt" in sys.argv:
         import statistics
         lib = _C.load()
