@@ -1,0 +1,64 @@
+"""Randomised cross-check of the automatic kernel choice against the generic device kernel (development aid).
+
+scaled_gemm: int8 bit-for-bit, fp8 within 2 eps of max|C|; mixed_precision_gemm: 2 eps of max|C|.  Shapes are drawn so
+that every dispatcher branch (split-K 32/64/128 rows, 128x128 tiles, 256x256 tiles, repack, generic; decode-batch and tiled
+mixed kernels) is hit.  usage: python tools/fuzz_dispatch.py [cases] [seed]
+"""
+import random
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from conch_amd import _C  # noqa: E402
+from conch_amd.ops.quantization.gemm import mixed_precision_gemm, scaled_gemm  # noqa: E402
+
+CASES = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+random.seed(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+EPS = {torch.float16: 2.0**-10, torch.bfloat16: 2.0**-7}
+bad = 0
+for case in range(CASES):
+    m = random.choice([1, 3, 16, 17, 32, 33, 48, 64, 65, 100, 128, 129, 192, 256, 257, 300, 512, 700, 1024, 1500])
+    k = random.choice([128, 256, 384, 1024, 1152, 2048, 3072, 4096])
+    n = random.choice([8, 24, 64, 100, 128, 260, 520, 1376, 2048, 4096, 4100, 11008])
+    out_dt = random.choice([torch.float16, torch.bfloat16])
+    torch.manual_seed(case)
+    if random.random() < 0.6:
+        in_dt = random.choice([torch.int8, torch.float8_e4m3fn])
+        if in_dt == torch.int8:
+            a = torch.randint(-32, 32, (m, k), dtype=torch.int8, device="cuda")
+            bt = torch.randint(-32, 32, (n, k), dtype=torch.int8, device="cuda")
+        else:
+            a = (0.25 * torch.rand((m, k), device="cuda") - 0.1).to(in_dt)
+            bt = (0.25 * torch.rand((n, k), device="cuda") - 0.1).to(in_dt)
+        sa = 0.01 * torch.rand((m, 1), device="cuda") if random.random() < 0.7 else torch.tensor([[0.01]], device="cuda")
+        sb = 0.01 * torch.rand((n, 1), device="cuda") if random.random() < 0.7 else torch.tensor([[0.02]], device="cuda")
+        bias = torch.rand((n,), device="cuda").to(out_dt) if random.random() < 0.5 else None
+        got = scaled_gemm(a, bt.T, sa, sb, out_dt, bias)
+        _C.set_gemm_variant(_C.VARIANT_GENERIC)
+        ref = scaled_gemm(a, bt.T, sa, sb, out_dt, bias)
+        _C.set_gemm_variant(_C.VARIANT_AUTO)
+        if in_dt == torch.int8:
+            ok = torch.equal(got, ref)
+        else:
+            ok = (got.float() - ref.float()).abs().max().item() <= 2 * EPS[out_dt] * max(ref.float().abs().max().item(), 1e-6)
+        what = f"scaled {in_dt} {m}x{k}x{n} -> {out_dt} bias={bias is not None}"
+    else:
+        bits = random.choice([4, 8])
+        k = max(k // 128 * 128, 128)
+        x = (torch.rand((m, k), device="cuda") - 0.3).to(out_dt)
+        wq = torch.randint(-2**31, 2**31 - 1, (k * bits // 32, n), dtype=torch.int32, device="cuda")
+        ws = (0.05 * torch.rand((k // 128, n), device="cuda") + 0.01).to(out_dt)
+        zp = torch.randint(0, 2**bits, (k // 128, n), dtype=torch.int32, device="cuda") if random.random() < 0.5 else None
+        got = mixed_precision_gemm(x, wq, ws, zp, bits, 0 if zp is not None else 2 ** (bits - 1), 128)
+        _C.set_gemm_variant(_C.VARIANT_GENERIC)
+        ref = mixed_precision_gemm(x, wq, ws, zp, bits, 0 if zp is not None else 2 ** (bits - 1), 128)
+        _C.set_gemm_variant(_C.VARIANT_AUTO)
+        ok = (got.float() - ref.float()).abs().max().item() <= 2 * EPS[out_dt] * max(ref.float().abs().max().item(), 1e-6)
+        what = f"mixed int{bits} {m}x{k}x{n} {out_dt} zp={zp is not None}"
+    if not ok or not torch.isfinite(got.float()).all():
+        bad += 1
+        print("MISMATCH", what, flush=True)
+print(f"{CASES} cases, {bad} mismatches")
+sys.exit(1 if bad else 0)
