@@ -1,6 +1,6 @@
 """Headline benchmark: scaled GEMM fp8(e4m3fn) x fp8 -> bf16, M=4096 K=4096 N=11008 (BASELINE.json C3).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4|c5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4|c5|c1|c4readme|c4decode|midm]
 
 One "step" = one `scaled_gemm` call (public op: output allocation + fused GEMM/scale/cast kernel) on
 synthetic inputs that are already resident in HBM, built with the reference benchmark's recipe
@@ -60,6 +60,9 @@ WORKLOADS = {
     "c4": ("mixed_int4", 1024, 4096, 11008),
     "c4readme": ("mixed_int4", 4096, 8192, 4096),
     "c5": ("scaled_fp8", 8192, 8192, 28672),
+    # not BASELINE configs: profiling handles for the small-M kernels (decode-batch mixed kernel, 128x128-tile scaled kernel)
+    "c4decode": ("mixed_int4", 16, 4096, 11008),
+    "midm": ("scaled_int8", 256, 4096, 11008),
 }
 CLOCK_RAMP_S = 0.15  # the GPU needs ~20 ms of load to leave its idle clocks; ramp before the W warm-up steps
 
