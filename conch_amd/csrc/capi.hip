@@ -79,17 +79,15 @@ int check_scaled(const ScaledGemmArgs& p) {
   return CONCH_OK;
 }
 
-int run_scaled_fast(const ScaledGemmArgs& p, int variant, hipStream_t stream) {
-  if (variant == 4 && !scaled_gemm_skinny_supported(p)) {
-    set_error("scaled_gemm: skinny variant forced but its contract is not met (M <= 256, K %% 1024 == 0)");
-    return CONCH_ERR_UNSUPPORTED;
-  }
-  // auto: the cheapest of three kernels by a cost model fitted to two 112-point sweeps over M in 8..1024, K in {4096, 8192},
-  // N in 4096..28672, int8 and fp8 (tools/quick_bench.py --skinnysweep, profiles/r01/skinny_tiled_mid_sweep*.txt), in us:
-  //   split-K skinny  4.5-5.5 + c(M) N K        (re-reads the A slice per 64-column block; two row blocks above M = 128)
-  //   256x256 tiles   rounds x (34 + 0.05 t) K/4096,  t = tiles per round of 256 workgroups (a lone tile is bound by its
-  //                   CU's L2 -> LDS rate; a full round shares the L2 / Infinity Cache)
-  //   128x128 tiles   rounds x (19 + 0.0176 t) K/4096, t = tiles per round of 512 workgroups (two per CU)
+enum ScaledKernel { kKernelTiled = 0, kKernelMid = 1, kKernelSkinny = 2 };
+
+// The cheapest of three kernels by a cost model fitted to two 112-point sweeps over M in 8..1024, K in {4096, 8192},
+// N in 4096..28672, int8 and fp8 (tools/quick_bench.py --skinnysweep, profiles/r01/skinny_tiled_mid_sweep*.txt), in us:
+//   split-K skinny  4.5-5.5 + c(M) N K        (re-reads the A slice per 64-column block; two row blocks above M = 128)
+//   256x256 tiles   rounds x (34 + 0.05 t) K/4096,  t = tiles per round of 256 workgroups (a lone tile is bound by its
+//                   CU's L2 -> LDS rate; a full round shares the L2 / Infinity Cache)
+//   128x128 tiles   rounds x (19 + 0.0176 t) K/4096, t = tiles per round of 512 workgroups (two per CU)
+ScaledKernel choose_scaled_kernel(const ScaledGemmArgs& p) {
   const double kscale = (double)p.k / 4096.0;
   const int64_t tiles256 = ((p.m + 255) / 256) * ((p.n + 255) / 256);
   const int64_t rounds256 = (tiles256 + 255) / 256;
@@ -97,23 +95,29 @@ int run_scaled_fast(const ScaledGemmArgs& p, int variant, hipStream_t stream) {
   const int64_t tiles128 = ((p.m + 127) / 128) * ((p.n + 127) / 128);
   const int64_t rounds128 = (tiles128 + 511) / 512;
   const double mid_us = (double)rounds128 * (19.0 + 0.0176 * (double)tiles128 / (double)rounds128) * kscale;
-  bool use_skinny = variant == 4;
-  bool use_mid = variant == 6;
-  if (variant == 0) {
-    double best = tiled_us;
-    if (mid_us < best) {
-      best = mid_us;
-      use_mid = true;
-    }
-    if (scaled_gemm_skinny_supported(p)) {
-      const double c = p.m <= 16 ? 1.7 : p.m <= 32 ? 2.0 : p.m <= 48 ? 2.3 : p.m <= 64 ? 2.5 : p.m <= 96 ? 4.3 : p.m <= 128 ? 4.8
-                       : p.m <= 192 ? 8.5 : 9.7;  // steps at the 32- / 64- / 128-row forms and at the second row block
-      const double skinny_us = (p.m <= 64 ? 4.5 : 5.5) + c * 1e-7 * (double)p.n * (double)p.k;
-      if (skinny_us < best) use_skinny = true;
-    }
+  ScaledKernel pick = kKernelTiled;
+  double best = tiled_us;
+  if (mid_us < best) {
+    best = mid_us;
+    pick = kKernelMid;
   }
-  if (use_skinny && scaled_gemm_skinny_supported(p)) return launch_scaled_gemm_skinny(p, stream);
-  if (use_mid) return launch_scaled_gemm_mid(p, stream);
+  if (scaled_gemm_skinny_supported(p)) {
+    const double c = p.m <= 16 ? 1.7 : p.m <= 32 ? 2.0 : p.m <= 48 ? 2.3 : p.m <= 64 ? 2.5 : p.m <= 96 ? 4.3 : p.m <= 128 ? 4.8
+                     : p.m <= 192 ? 8.5 : 9.7;  // steps at the 32- / 64- / 128-row forms and at the second row block
+    const double skinny_us = (p.m <= 64 ? 4.5 : 5.5) + c * 1e-7 * (double)p.n * (double)p.k;
+    if (skinny_us < best) pick = kKernelSkinny;
+  }
+  return pick;
+}
+
+int run_scaled_fast(const ScaledGemmArgs& p, int variant, hipStream_t stream) {
+  if (variant == 4 && !scaled_gemm_skinny_supported(p)) {
+    set_error("scaled_gemm: skinny variant forced but its contract is not met (M <= 256, K %% 1024 == 0)");
+    return CONCH_ERR_UNSUPPORTED;
+  }
+  const ScaledKernel pick = variant == 4 ? kKernelSkinny : variant == 6 ? kKernelMid : variant == 0 ? choose_scaled_kernel(p) : kKernelTiled;
+  if (pick == kKernelSkinny && scaled_gemm_skinny_supported(p)) return launch_scaled_gemm_skinny(p, stream);
+  if (pick == kKernelMid) return launch_scaled_gemm_mid(p, stream);
   return launch_scaled_gemm_mfma(p, (variant == 2 || variant == 3) ? variant : 5, stream);
 }
 
@@ -149,7 +153,20 @@ int run_scaled_silu(const ScaledGemmArgs& p, hipStream_t stream) {
   CONCH_CHECK_ARG(p.c_stride_n == 1, "scaled_gemm_silu_and_mul: C must have unit column stride (got %lld)", (long long)p.c_stride_n);
   if (p.m == 0 || p.n == 0) return CONCH_OK;
   const int variant = tuning(CONCH_TUNE_GEMM_VARIANT);
-  if (variant != 1 && variant != 2 && scaled_gemm_mfma_supported(p)) return launch_scaled_gemm_mfma(p, 5, stream);
+  // decode batches: the split-K kernel on the wide problem with the silu fused into its reduce kernel (the fused tile of
+  // gemm_mfma.hip is a 256-row tile: 35 us at K = 4096 whatever M is)
+  bool unfused_pair = variant == 1 || variant == 2;
+  if (variant == 0 && scaled_gemm_mfma_supported(wide)) {
+    const ScaledKernel pick = choose_scaled_kernel(wide);
+    if (pick == kKernelSkinny && scaled_gemm_skinny_fused_supported(wide)) {
+      ScaledGemmArgs q = wide;  // n = 2d for the partial sums; c / c_stride_m describe the d-column result
+      q.fuse_silu = 1;
+      return launch_scaled_gemm_skinny(q, stream);
+    }
+    // few 256-row tiles: the 128x128-tile kernel on the wide problem plus the elementwise pass beats the fused 256-row tile
+    if (pick != kKernelTiled) unfused_pair = true;
+  }
+  if (!unfused_pair && scaled_gemm_mfma_supported(p)) return launch_scaled_gemm_mfma(p, 5, stream);
   // any other layout / dtype / K: the plain GEMM into stream-ordered scratch, then the elementwise tail
   void* tmp = nullptr;
   if (int rc = get_scratch(stream, 3, (size_t)p.m * (size_t)wide.n * 2, &tmp)) return rc;
@@ -219,8 +236,17 @@ int run_mixed_silu(const MixedGemmArgs& p, hipStream_t stream) {
   if (p.m == 0 || p.n == 0) return CONCH_OK;
   const int variant = tuning(CONCH_TUNE_GEMM_VARIANT);
   // decode batches: the unfused pair on the decode-batch GEMM beats the fused 256-row tile
-  const bool decode = variant == 0 && mixed_gemm_skinny_supported(wide) && (p.m <= 32 || (double)wide.n * (double)p.k < 9.0e7);
-  if (!decode && variant != 1 && variant != 2 && mixed_gemm_mfma_supported(p)) return launch_mixed_gemm_mfma(p, stream);
+  // decode batches: the decode-batch kernel on the wide problem with the silu fused into its reduce kernel
+  MixedGemmArgs probe = wide;  // the contract check wants a C row that holds n columns; the fused reduce writes only d
+  probe.c_stride_m = wide.n;
+  const bool decode = variant == 0 && mixed_gemm_skinny_supported(probe) && wide.n % 8 == 0 &&
+                      (p.m <= 32 || (double)wide.n * (double)p.k < 9.0e7);
+  if (decode) {
+    MixedGemmArgs q = wide;  // n = 2d for the partial sums; c / c_stride_m describe the d-column result
+    q.fuse_silu = 1;
+    return launch_mixed_gemm_skinny(q, stream);
+  }
+  if (variant != 1 && variant != 2 && mixed_gemm_mfma_supported(p)) return launch_mixed_gemm_mfma(p, stream);
   void* tmp = nullptr;
   if (int rc = get_scratch(stream, 3, (size_t)p.m * (size_t)wide.n * 2, &tmp)) return rc;
   wide.c = tmp;

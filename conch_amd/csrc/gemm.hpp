@@ -58,6 +58,7 @@ int launch_scaled_gemm_mid(const ScaledGemmArgs& p, hipStream_t stream);
 // gemm_skinny.hip -- M <= 256: 128x16 blocks, K split over the waves, register streaming (variant 4)
 bool scaled_gemm_skinny_supported(const ScaledGemmArgs& p);
 int launch_scaled_gemm_skinny(const ScaledGemmArgs& p, hipStream_t stream);
+bool scaled_gemm_skinny_fused_supported(const ScaledGemmArgs& wide);  // silu_and_mul fused into the split-K reduce kernel
 // repack.hip -- copy operands into the MFMA layout contract (stream-ordered scratch)
 int repack_for_mfma(const ScaledGemmArgs& p, ScaledGemmArgs* q, void** scratch, hipStream_t stream);
 int expand_fnuz_to_bf16(const ScaledGemmArgs& p, ScaledGemmArgs* q, hipStream_t stream);

@@ -155,6 +155,30 @@ __global__ __launch_bounds__(256) void mixed_skinny_reduce_kernel(MixedGemmArgs 
   }
 }
 
+// The same with the gate/up FFN fusion (conch_mixed_precision_gemm_silu_and_mul at decode batch sizes): the slabs hold the
+// plain product for n = 2d columns [gate | up]; g, u, silu(g) and the product are rounded like silu_and_mul_kernel does.
+template <int OUT_DT>
+__global__ __launch_bounds__(256) void mixed_skinny_reduce_silu_kernel(MixedGemmArgs p, const float* __restrict__ slabs, int slices) {
+  const int64_t d = p.n / 2;
+  const int64_t quad = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t quads_per_row = d / 4;
+  if (quad >= p.m * quads_per_row) return;
+  const int m = (int)(quad / quads_per_row), j0 = (int)(quad % quads_per_row) * 4;
+  f32x4 g = *(const f32x4*)(slabs + (int64_t)m * p.n + j0), u = *(const f32x4*)(slabs + (int64_t)m * p.n + d + j0);
+  for (int s = 1; s < slices; ++s) {
+    g += *(const f32x4*)(slabs + ((int64_t)s * p.m + m) * p.n + j0);
+    u += *(const f32x4*)(slabs + ((int64_t)s * p.m + m) * p.n + d + j0);
+  }
+  uint16_t* dst = (uint16_t*)p.c + (int64_t)m * p.c_stride_m + j0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float gr = bits16_to_float<OUT_DT>(float_to_bits16<OUT_DT>(g[e]));
+    const float ur = bits16_to_float<OUT_DT>(float_to_bits16<OUT_DT>(u[e]));
+    const float sr = bits16_to_float<OUT_DT>(float_to_bits16<OUT_DT>(pin_f32(silu_f32(gr))));
+    dst[e] = float_to_bits16<OUT_DT>(pin_f32(sr * ur));
+  }
+}
+
 template <int X_DT, int BITS, int ZP>
 void launch_rows(const MixedGemmArgs& p, int rows, dim3 grid, float* ws, hipStream_t stream) {
   const dim3 block(kMsThreads);
@@ -193,6 +217,14 @@ int launch_mixed_gemm_skinny(const MixedGemmArgs& p, hipStream_t stream) {
   } else {
     if (p.bits == 4) launch_zp_mode<CONCH_DT_BF16, 4>(p, rows, grid, (float*)ws, stream);
     else launch_zp_mode<CONCH_DT_BF16, 8>(p, rows, grid, (float*)ws, stream);
+  }
+  if (p.fuse_silu) {  // p.n = 2d columns [gate | up], C has d (caller: mixed_gemm_skinny_supported(wide) && d % 4 == 0)
+    const int64_t oquads = p.m * (p.n / 8);
+    if (p.out_dtype == CONCH_DT_FP16)
+      hipLaunchKernelGGL((mixed_skinny_reduce_silu_kernel<CONCH_DT_FP16>), dim3((unsigned)((oquads + 255) / 256)), dim3(256), 0, stream, p, (const float*)ws, slices);
+    else
+      hipLaunchKernelGGL((mixed_skinny_reduce_silu_kernel<CONCH_DT_BF16>), dim3((unsigned)((oquads + 255) / 256)), dim3(256), 0, stream, p, (const float*)ws, slices);
+    return check_launch("mixed_gemm_skinny_silu");
   }
   const int64_t quads = p.m * (p.n / 4);
   if (p.out_dtype == CONCH_DT_FP16)

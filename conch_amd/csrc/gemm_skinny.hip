@@ -254,6 +254,43 @@ __global__ __launch_bounds__(256) void skinny_reduce_kernel(ScaledGemmArgs p, co
   }
 }
 
+// The same with the gate/up FFN fusion (conch_scaled_gemm_silu_and_mul at decode batch sizes): the slabs hold the plain
+// product for n = 2d columns [gate | up]; thread = 4 consecutive OUTPUT columns j: g and u get the scaled_gemm epilogue
+// (scales, cast, bias), then the reference's silu_and_mul roundings -- exactly what silu_and_mul_kernel does to a stored G.
+template <int MMA, int OUT_DT>
+__global__ __launch_bounds__(256) void skinny_reduce_silu_kernel(ScaledGemmArgs p, const int* __restrict__ slabs, int slices) {
+  const int64_t d = p.n / 2;
+  const int64_t quad = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t quads_per_row = d / 4;
+  if (quad >= p.m * quads_per_row) return;
+  const int m = (int)(quad / quads_per_row), j0 = (int)(quad % quads_per_row) * 4;
+  const float sa = p.scale_a[p.scale_a_numel != 1 ? m : 0];
+  uint16_t gu[2][4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int n = j0 + h * (int)d;
+    typename AccT<MMA>::type sum = __builtin_bit_cast(typename AccT<MMA>::type, *(const i32x4*)(slabs + (int64_t)m * p.n + n));
+    for (int s = 1; s < slices; ++s)
+      sum += __builtin_bit_cast(typename AccT<MMA>::type, *(const i32x4*)(slabs + ((int64_t)s * p.m + m) * p.n + n));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float sb = p.scale_b[p.scale_b_numel != 1 ? n + e : 0];
+      float v = sa * (float)sum[e];
+      v = pin_f32(sb * v);
+      uint16_t hb = float_to_bits16<OUT_DT>(v);
+      if (p.bias)
+        hb = float_to_bits16<OUT_DT>(pin_f32(bits16_to_float<OUT_DT>(hb) + bits16_to_float<OUT_DT>(((const uint16_t*)p.bias)[n + e])));
+      gu[h][e] = hb;
+    }
+  }
+  uint16_t* dst = (uint16_t*)p.c + (int64_t)m * p.c_stride_m + j0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float s = bits16_to_float<OUT_DT>(float_to_bits16<OUT_DT>(pin_f32(silu_f32(bits16_to_float<OUT_DT>(gu[0][e])))));
+    dst[e] = float_to_bits16<OUT_DT>(pin_f32(s * bits16_to_float<OUT_DT>(gu[1][e])));
+  }
+}
+
 // launches the partial-sum kernel for a runtime (operand type, row count) pair
 void launch_splitk_partials(int mma, int rows, dim3 grid, const ScaledGemmArgs& p, int* ws, hipStream_t stream) {
   const dim3 block(kSkThreads);
@@ -276,6 +313,11 @@ int splitk_slices(const ScaledGemmArgs& p) {
 
 }  // namespace
 
+// `wide` = the plain GEMM on [gate | up] (n = 2d): can the split-K form run it with the silu fused into its reduce kernel?
+bool scaled_gemm_skinny_fused_supported(const ScaledGemmArgs& wide) {
+  return scaled_gemm_skinny_supported(wide) && wide.n % 8 == 0 && splitk_slices(wide) >= 1;
+}
+
 bool scaled_gemm_skinny_supported(const ScaledGemmArgs& p) {
   if (!scaled_gemm_mfma_supported(p)) return false;
   if (p.m > 2 * kSkM) return false;                      // beyond two row blocks the tiled kernels win
@@ -295,13 +337,21 @@ int launch_splitk(const ScaledGemmArgs& p, int slices, hipStream_t stream) {
   const dim3 grid((unsigned)((p.n + kSpN - 1) / kSpN), (unsigned)slices, (unsigned)((p.m + rows - 1) / rows));
   launch_splitk_partials(MMA, rows, grid, p, (int*)ws, stream);
   const int64_t quads = p.m * (p.n / 4);
+  if (p.fuse_silu) {  // p.n = 2d columns [gate | up], C has d
+    const int64_t oquads = p.m * (p.n / 8);
+    hipLaunchKernelGGL((skinny_reduce_silu_kernel<MMA, OUT_DT>), dim3((unsigned)((oquads + 255) / 256)), dim3(256), 0, stream, p,
+                       (const int*)ws, slices);
+    return check_launch("scaled_gemm_skinny_splitk_silu");
+  }
   hipLaunchKernelGGL((skinny_reduce_kernel<MMA, OUT_DT>), dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, p,
                      (const int*)ws, slices);
   return check_launch("scaled_gemm_skinny_splitk");
 }
 
 int launch_scaled_gemm_skinny(const ScaledGemmArgs& p, hipStream_t stream) {
-  const int slices = tuning(2) == 1 ? 0 : splitk_slices(p);  // CONCH_TUNE_SKINNY_NO_SPLITK = 1 disables split-K
+  // fuse_silu: `p` is the WIDE problem (n = 2d) whose reduce kernel writes the d-column FFN result (the caller has checked
+  // scaled_gemm_skinny_fused_supported); only the split-K form has a reduce kernel
+  const int slices = (tuning(2) == 1 && !p.fuse_silu) ? 0 : splitk_slices(p);  // CONCH_TUNE_SKINNY_NO_SPLITK = 1 disables split-K
   if (slices >= 1) {
     int rc;
     if (p.in_dtype == CONCH_DT_FP8_E4M3FN)

@@ -308,7 +308,8 @@ def test_scaled_gemm_silu_golden_from_reference(golden, iname, oname, key_tail):
 
 
 @pytest.mark.parametrize("iname", ["int8", "fn"])
-@pytest.mark.parametrize(("m", "k", "d"), [(1024, 1024, 512), (300, 384, 260), (257, 256, 8), (512, 1152, 1376), (64, 2048, 96)])
+@pytest.mark.parametrize(("m", "k", "d"), [(1024, 1024, 512), (300, 384, 260), (257, 256, 8), (512, 1152, 1376), (64, 2048, 96),
+                                            (16, 1024, 1376), (33, 2048, 260)])
 def test_scaled_gemm_silu_shapes_fused_equals_unfused(iname, m, k, d):
     """Ragged M / d (partial tiles, d not a multiple of 8 or 128): (1) against the oracle; (2) the fused kernel equals the
     library's own unfused pair (plain GEMM into scratch + elementwise pass, forced with variant 2) bit for bit -- the
@@ -320,7 +321,13 @@ def test_scaled_gemm_silu_shapes_fused_equals_unfused(iname, m, k, d):
     _C.set_gemm_variant(_C.VARIANT_MFMA_SIMPLE)
     unfused = run_silu(a, b, sa, sb, torch.bfloat16, bias)
     _C.set_gemm_variant(_C.VARIANT_AUTO)
-    assert torch.equal(got, unfused)
+    if m <= 64 and k % 1024 == 0 and iname != "int8":
+        # decode batch: auto runs the split-K kernel with the silu fused into its reduce kernel -- another fp32 summation
+        # order than the tiled kernel of the unfused pair
+        tol = 4.0 * EPS[torch.bfloat16] * unfused.float().abs().max().item()
+        assert (got.float() - unfused.float()).abs().max().item() <= tol
+    else:
+        assert torch.equal(got, unfused)
 
 
 def test_scaled_gemm_silu_llama_ffn_shape():
@@ -544,7 +551,8 @@ def test_mixed_precision_silu_golden_from_reference(golden, wname, zp, dname):
     check_mixed_silu(got, a, from_bits(g[f"wref_{key}"], dtype), min_representable=0.0)
 
 
-@pytest.mark.parametrize(("m", "k", "d"), [(300, 256, 260), (1024, 512, 688), (64, 128, 100), (512, 64, 128)])
+@pytest.mark.parametrize(("m", "k", "d"), [(300, 256, 260), (1024, 512, 688), (64, 128, 100), (512, 64, 128), (16, 1024, 260),
+                                            (48, 2048, 1376)])
 @pytest.mark.parametrize(("wname", "use_zp", "dname"), [("uint4b8", False, "f16"), ("uint4", True, "bf16"),
                                                          ("uint8b128", True, "f16"), ("uint8", False, "bf16")])
 def test_mixed_precision_silu_fused_equals_unfused(m, k, d, wname, use_zp, dname):
@@ -564,7 +572,12 @@ def test_mixed_precision_silu_fused_equals_unfused(m, k, d, wname, use_zp, dname
     finally:
         _C.load().conch_set_tuning(1, 0)
         _C.set_gemm_variant(_C.VARIANT_AUTO)
-    assert torch.equal(got, unfused)
+    if m <= 64 and k % 1024 == 0:
+        # decode batch: the decode-batch kernel with the silu fused into its reduce kernel (other summation order)
+        tol = 4.0 * EPS[DT[dname]] * unfused.float().abs().max().item()
+        assert (got.float() - unfused.float()).abs().max().item() <= tol
+    else:
+        assert torch.equal(got, unfused)
 
 
 # ---------------------------------------------------------------------------------------------
