@@ -20,7 +20,7 @@ LIB_PATH = Path(os.environ.get("CONCH_AMD_LIBRARY", _PKG / "libconch_amd.so"))
 # conch_dtype_t (include/conch_amd.h; values 0..8 follow conch/kernels/quantization/gemm.py:20-31)
 DT_FP32, DT_FP16, DT_BF16, DT_FP8_E4M3FN, DT_INT8, DT_UINT8, DT_INT32, DT_UINT32, DT_FP8_E5M2, DT_FP8_E4M3FNUZ = range(10)
 ZP_NONE, ZP_SCALAR, ZP_TENSOR = range(3)
-TUNE_GEMM_VARIANT = 0
+TUNE_GEMM_VARIANT, TUNE_MIXED_TILE_NT, TUNE_SKINNY_NO_SPLITK, TUNE_SKINNY_MODE, TUNE_TILE_SCHEDULE = range(5)
 (VARIANT_AUTO, VARIANT_GENERIC, VARIANT_MFMA_SIMPLE, VARIANT_MFMA_PINGPONG, VARIANT_MFMA_SKINNY,
  VARIANT_MFMA_PINGPONG2, VARIANT_MFMA_MID) = range(7)
 
@@ -54,8 +54,16 @@ _SIGNATURES = {
     "conch_set_tuning": (c_int, [c_int, c_int]),
     "conch_get_tuning": (c_int, [c_int]),
     "conch_device_count": (c_int, []),
+    "conch_scaled_gemm_workspace_bytes": (_I64, [_I64, _I64, _I64]),
+    "conch_mixed_precision_gemm_workspace_bytes": (_I64, [_I64, _I64, _I64]),
+    "conch_reserve_scratch": (c_int, [c_void_p, _I64]),
     "conch_static_scaled_int8_quant": (c_int, [c_void_p, c_void_p, c_void_p, _I64, _I64, _I64, _I64, c_int, c_void_p]),
     "conch_static_scaled_fp8_quant": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, _I64, _I64, _I64, _I64, c_int, c_int, c_void_p],
+    ),
+    "conch_dynamic_scaled_int8_quant": (c_int, [c_void_p, c_void_p, c_void_p, _I64, _I64, _I64, _I64, c_int, c_void_p]),
+    "conch_dynamic_scaled_fp8_quant": (
         c_int,
         [c_void_p, c_void_p, c_void_p, _I64, _I64, _I64, _I64, c_int, c_int, c_void_p],
     ),
@@ -93,25 +101,31 @@ EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 _lib: ctypes.CDLL | None = None
 
 
+def load_library(path: Path) -> ctypes.CDLL:
+    """dlopen `path` and declare every entry point of include/conch_amd.h on it (no caching: bench.py also opens the
+    diagnostic twin of the library this way)."""
+    if not Path(path).exists():
+        msg = (
+            f"{path} not found: build it with `python -m conch_amd._build` "
+            "(conch_amd has no CPU / PyTorch fallback for its ops)"
+        )
+        raise ConchLibraryError(msg)
+    try:
+        lib = ctypes.CDLL(str(path))
+    except OSError as exc:
+        raise ConchLibraryError(f"cannot load {path}: {exc}") from exc
+    for name, (restype, argtypes) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    return lib
+
+
 def load() -> ctypes.CDLL:
     """Load (once) and return the shared library; raise loudly if it is not there."""
     global _lib  # noqa: PLW0603
     if _lib is None:
-        if not LIB_PATH.exists():
-            msg = (
-                f"{LIB_PATH} not found: build it with `python -m conch_amd._build` "
-                "(conch_amd has no CPU / PyTorch fallback for its ops)"
-            )
-            raise ConchLibraryError(msg)
-        try:
-            lib = ctypes.CDLL(str(LIB_PATH))
-        except OSError as exc:
-            raise ConchLibraryError(f"cannot load {LIB_PATH}: {exc}") from exc
-        for name, (restype, argtypes) in _SIGNATURES.items():
-            fn = getattr(lib, name)
-            fn.restype = restype
-            fn.argtypes = argtypes
-        _lib = lib
+        _lib = load_library(LIB_PATH)
     return _lib
 
 
@@ -140,6 +154,46 @@ def require_device(*tensors: torch.Tensor | None) -> None:
         if t is not None and not t.is_cuda:
             msg = "conch_amd ops need tensors on a ROCm device (cuda:N); there is no CPU fallback"
             raise RuntimeError(msg)
+
+
+def on_device_of(*tensors: torch.Tensor | None):
+    """Context that makes the tensors' device current for the C call (the library launches on the CURRENT device and keys
+    its scratch by it); a no-op -- and no Python overhead beyond one comparison -- when it already is.  All tensors must
+    live on ONE device."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise ValueError(f"conch_amd: tensors on different devices ({dev} and {t.device})")
+    if dev is None or dev.index is None or dev.index == torch.cuda.current_device():
+        return _NULL_CONTEXT
+    return torch.cuda.device(dev)
+
+
+class _NullContext:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NULL_CONTEXT = _NullContext()
+
+
+def set_tuning(key: int, value: int) -> None:
+    check(load().conch_set_tuning(key, value), "conch_set_tuning")
+
+
+def reserve_scratch(nbytes: int, device: torch.device | None = None) -> None:
+    """Pre-allocate the library's scratch for torch's current stream (see include/conch_amd.h, "Library scratch"): after
+    this, calls whose workspace need is <= nbytes neither allocate nor synchronise (graph-capture safe)."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    with torch.cuda.device(device):
+        check(load().conch_reserve_scratch(current_stream_handle(device), int(nbytes)), "conch_reserve_scratch")
 
 
 def ptr(t: torch.Tensor | None) -> int | None:

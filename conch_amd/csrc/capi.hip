@@ -1,11 +1,13 @@
 // extern "C" entry points of libconch_amd.so (declared in include/conch_amd.h): argument
 // validation, kernel selection, error strings.  No torch types, no exceptions across the boundary.
+#include <algorithm>
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <map>
 #include <mutex>
 #include <utility>
+#include <vector>
 
 #include "common.hpp"
 #include "gemm.hpp"
@@ -13,7 +15,7 @@
 namespace conch {
 
 static thread_local char g_error[512] = "";
-static std::atomic<int> g_tuning[4] = {};
+static std::atomic<int> g_tuning[8] = {};
 
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -22,26 +24,69 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-int tuning(int key) { return (key >= 0 && key < 4) ? g_tuning[key].load() : 0; }
+int tuning(int key) { return (key >= 0 && key < 8) ? g_tuning[key].load() : 0; }
 
-int get_scratch(hipStream_t stream, int slot, size_t bytes, void** out) {
-  struct Buf {
-    void* ptr = nullptr;
-    size_t size = 0;
-  };
-  static std::mutex mu;
-  static std::map<std::pair<hipStream_t, int>, Buf> pool;
-  std::lock_guard<std::mutex> lock(mu);
-  Buf& b = pool[{stream, slot}];
+int device_cu_count() {
+  static std::atomic<int> cache[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int n = cache[dev].load();
+  if (n == 0) {
+    int v = 0;
+    n = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    cache[dev].store(n);
+  }
+  return n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Library-owned device scratch.  One buffer per (device, stream, slot).  A buffer that has been handed to a kernel is
+// NEVER freed or moved while the process lives: a grown slot gets a fresh allocation (at least twice the old size, so
+// the retired ones sum to less than the live one) and the old pointer is kept on a retired list, because launches
+// already enqueued -- or captured into a hipGraph -- still read it.  Growth allocates with hipMalloc, which is not
+// legal inside stream capture: a call that would have to grow a slot while `stream` is capturing fails with
+// CONCH_ERR_INVALID_ARGUMENT instead (reserve first: conch_reserve_scratch).  No host synchronisation anywhere.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct ScratchKey {
+  int device;
+  hipStream_t stream;
+  int slot;
+  bool operator<(const ScratchKey& o) const {
+    if (device != o.device) return device < o.device;
+    if (stream != o.stream) return stream < o.stream;
+    return slot < o.slot;
+  }
+};
+struct ScratchBuf {
+  void* ptr = nullptr;
+  size_t size = 0;
+};
+std::mutex g_scratch_mu;
+std::map<ScratchKey, ScratchBuf> g_scratch;
+std::vector<void*> g_scratch_retired;
+}  // namespace
+
+int get_scratch(hipStream_t stream, int slot, size_t bytes, void** out, bool zero_on_alloc) {
+  int device = 0;
+  CONCH_HIP(hipGetDevice(&device));
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  ScratchBuf& b = g_scratch[ScratchKey{device, stream, slot}];
   if (b.size < bytes) {
-    if (b.ptr) {
-      CONCH_HIP(hipStreamSynchronize(stream));  // work still using the old buffer
-      CONCH_HIP(hipFree(b.ptr));
-      b.ptr = nullptr;
-      b.size = 0;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+      set_error("scratch slot %d needs %zu bytes (has %zu) while the stream is being captured: call "
+                "conch_reserve_scratch(stream, bytes) before capture", slot, bytes, b.size);
+      return CONCH_ERR_INVALID_ARGUMENT;
     }
-    const size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
-    CONCH_HIP(hipMalloc(&b.ptr, want));
+    (void)hipGetLastError();
+    size_t want = bytes > 2 * b.size ? bytes : 2 * b.size;
+    want = (want + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+    void* fresh = nullptr;
+    CONCH_HIP(hipMalloc(&fresh, want));
+    if (zero_on_alloc) CONCH_HIP(hipMemset(fresh, 0, want));
+    if (b.ptr) g_scratch_retired.push_back(b.ptr);  // still referenced by enqueued / captured work
+    b.ptr = fresh;
     b.size = want;
   }
   *out = b.ptr;
@@ -169,7 +214,7 @@ int run_scaled_silu(const ScaledGemmArgs& p, hipStream_t stream) {
   if (!unfused_pair && scaled_gemm_mfma_supported(p)) return launch_scaled_gemm_mfma(p, 5, stream);
   // any other layout / dtype / K: the plain GEMM into stream-ordered scratch, then the elementwise tail
   void* tmp = nullptr;
-  if (int rc = get_scratch(stream, 3, (size_t)p.m * (size_t)wide.n * 2, &tmp)) return rc;
+  if (int rc = get_scratch(stream, kScratchWide, (size_t)p.m * (size_t)wide.n * 2, &tmp)) return rc;
   wide.c = tmp;
   wide.c_stride_m = wide.n;
   wide.c_stride_n = 1;
@@ -248,7 +293,7 @@ int run_mixed_silu(const MixedGemmArgs& p, hipStream_t stream) {
   }
   if (variant != 1 && variant != 2 && mixed_gemm_mfma_supported(p)) return launch_mixed_gemm_mfma(p, stream);
   void* tmp = nullptr;
-  if (int rc = get_scratch(stream, 3, (size_t)p.m * (size_t)wide.n * 2, &tmp)) return rc;
+  if (int rc = get_scratch(stream, kScratchWide, (size_t)p.m * (size_t)wide.n * 2, &tmp)) return rc;
   wide.c = tmp;
   wide.c_stride_m = wide.n;
   if (int rc = run_mixed(wide, stream)) return rc;
@@ -283,11 +328,37 @@ extern "C" int conch_abi_version(void) { return CONCH_AMD_ABI_VERSION; }
 extern "C" const char* conch_last_error(void) { return g_error; }
 
 extern "C" int conch_set_tuning(int key, int value) {
-  CONCH_CHECK_ARG(key >= 0 && key < 4, "conch_set_tuning: unknown key %d", key);
+  CONCH_CHECK_ARG(key >= 0 && key < 8, "conch_set_tuning: unknown key %d", key);
   g_tuning[key].store(value);
   return CONCH_OK;
 }
 extern "C" int conch_get_tuning(int key) { return tuning(key); }
+
+// Worst case over every kernel the dispatcher may pick for this shape (any layout, either fp8 flavour, fused FFN form
+// included): split-K slabs (M <= 256), K-contiguous / bf16-expanded operand copies, the [M][N] intermediate of an unfused pair.
+extern "C" int64_t conch_scaled_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k) {
+  if (m <= 0 || n <= 0 || k < 0) return 0;
+  const int64_t kpad = (k + 127) / 128 * 128;
+  int64_t need = 2 * (m + n) * kpad + 512;                      // repack.hip: both operands, 2 bytes per element at most
+  if (m <= 256) need = std::max(need, (k / 1024 + 1) * m * n * 4);  // gemm_skinny.hip slabs
+  need = std::max(need, m * n * 2);                             // unfused silu pair: `n` = the wide width there
+  return need + ((int64_t)1 << 20);
+}
+
+extern "C" int64_t conch_mixed_precision_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k) {
+  if (m <= 0 || n <= 0 || k < 0) return 0;
+  int64_t need = m * n * 2;
+  if (m <= 64) need = std::max(need, (k / 1024 + 1) * m * n * 4);  // gemm_mixed_skinny.hip slabs
+  return need + ((int64_t)1 << 20);
+}
+
+extern "C" int conch_reserve_scratch(void* stream, int64_t bytes) {
+  CONCH_CHECK_ARG(bytes >= 0, "conch_reserve_scratch: negative size");
+  void* ignored = nullptr;
+  for (int slot = 0; slot < kScratchCounters; ++slot)
+    if (int rc = get_scratch((hipStream_t)stream, slot, (size_t)bytes, &ignored)) return rc;
+  return get_scratch((hipStream_t)stream, kScratchCounters, (size_t)64 * 1024, &ignored, /*zero_on_alloc=*/true);
+}
 
 extern "C" int conch_device_count(void) {
   int n = 0;

@@ -32,11 +32,24 @@ int tuning(int key);
     }                                                                                     \
   } while (0)
 
-// Library-owned device scratch, one buffer per (stream, slot), grown on demand and kept for the life
-// of the process (stream-ordered hipMallocAsync/hipFreeAsync per call measured ~10 us on ROCm 7.2).
-// A buffer is only ever used by work enqueued on its own stream, so reuse is ordered by the stream.
-// Growing allocates with hipMalloc: do the first call of a given size outside graph capture.
-int get_scratch(hipStream_t stream, int slot, size_t bytes, void** out);
+// Library-owned device scratch, one buffer per (device, stream, slot), grown on demand and kept for the life of the
+// process (stream-ordered hipMallocAsync/hipFreeAsync per call measured ~10 us on ROCm 7.2).  A buffer is only ever used
+// by work enqueued on its own stream, so reuse is ordered by the stream; a grown slot never frees the old buffer (work
+// already enqueued or captured into a graph may still use it).  Growth is refused while the stream is being captured
+// (conch_reserve_scratch beforehand makes every entry point allocation-free).  `zero_on_alloc`: the buffer holds
+// self-resetting arrival counters (all zero between launches).
+enum ScratchSlot {
+  kScratchRepack = 0,     // repack.hip: K-contiguous / bf16-expanded operand copies
+  kScratchSplitK = 1,     // gemm_skinny.hip: split-K partial slabs
+  kScratchMixedSplitK = 2,  // gemm_mixed_skinny.hip: split-K partial slabs
+  kScratchWide = 3,       // unfused FFN pair: the [M][2d] intermediate
+  kScratchCounters = 4,   // split-K arrival counters (zeroed at allocation, reset by the last arriver)
+  kScratchSlots = 5
+};
+int get_scratch(hipStream_t stream, int slot, size_t bytes, void** out, bool zero_on_alloc = false);
+
+// Compute units of the CURRENT device (cached per device id; 256 if the query fails).
+int device_cu_count();
 
 inline int check_launch(const char* what) {
   hipError_t err = hipGetLastError();
@@ -53,6 +66,7 @@ inline int check_launch(const char* what) {
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));

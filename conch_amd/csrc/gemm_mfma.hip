@@ -42,7 +42,9 @@ struct WaveTile {
 
 // One phase = {optional fragment reads, optional LDS-DMA issue, counted vmcnt} barrier {MFMAs} barrier.
 // PHASE 0: read n0,m0 -> Q(m0,n0); 1: read n1 -> Q(m0,n1); 2: read m1 -> Q(m1,n1); 3: Q(m1,n0).
-template <int MMA, int PHASE, bool PINGPONG>
+// NT = 16-column MFMA tiles per wave and 16-row m tile: 4 (256-column workgroup tile) or 3 (192-column tile: the V2 unit
+// holds ONE 16-row n tile per wave-column instead of two)
+template <int MMA, int PHASE, bool PINGPONG, int NT = 4>
 __device__ __forceinline__ void phase_reads(WaveTile<MMA>& w, const char* lds, int buf, int m_base, int n_base) {
   if constexpr (PHASE == 0) {
 #pragma unroll
@@ -52,21 +54,22 @@ __device__ __forceinline__ void phase_reads(WaveTile<MMA>& w, const char* lds, i
     for (int i = 0; i < 4; ++i) w.fm[i] = read_frag(lds, buf + kU1 * kUnitBytes + m_base + i * 2048);
   } else if constexpr (PHASE == 1) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) w.fn[1][t] = read_frag(lds, buf + kV2 * kUnitBytes + n_base + t * 2048);
+    for (int t = 0; t < NT - 2; ++t) w.fn[1][t] = read_frag(lds, buf + kV2 * kUnitBytes + n_base + t * 2048);
   } else if constexpr (PHASE == 2) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) w.fm[i] = read_frag(lds, buf + kU2 * kUnitBytes + m_base + i * 2048);
   }
 }
 
-template <int MMA, int PHASE>
+template <int MMA, int PHASE, int NT = 4>
 __device__ __forceinline__ void phase_mma(WaveTile<MMA>& w) {
   constexpr int MH = (PHASE >= 2) ? 1 : 0;                 // m sub-half
   constexpr int NH = (PHASE == 1 || PHASE == 2) ? 1 : 0;   // n sub-half
+  constexpr int TN = NH == 1 ? NT - 2 : 2;                 // 16-row n tiles of this sub-half
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int t = 0; t < 2; ++t) mma_step<MMA>(w.acc[MH * 4 + i][NH * 2 + t], w.fn[NH][t], w.fm[i]);
+    for (int t = 0; t < TN; ++t) mma_step<MMA>(w.acc[MH * 4 + i][NH * 2 + t], w.fn[NH][t], w.fm[i]);
 }
 
 // The MFMA half of a phase: the cluster at raised priority, then the closing barrier.
@@ -125,7 +128,7 @@ __device__ __forceinline__ void epilogue_park(char* lds, const EpiPrefetch& e) {
   if (t >= 256) f[t + 256] = bits16_to_float<OUT_DT>((uint16_t)bits);
 }
 
-template <int MMA, int OUT_DT>
+template <int MMA, int OUT_DT, int NT = 4>
 __device__ __forceinline__ void epilogue(const typename AccT<MMA>::type (&acc)[8][4], const ScaledGemmArgs& p, const char* lds,
                                          int bm0, int bn0, int wr, int wc, int lane) {
   const int g = lane >> 4, jm = lane & 15;
@@ -134,9 +137,42 @@ __device__ __forceinline__ void epilogue(const typename AccT<MMA>::type (&acc)[8
   const float* lsa = (const float*)(lds + kEpiOff);
   const float* lsb = lsa + 256;
   const float* lbias = lsa + 512;
+  if constexpr (NT == 3) {
+    // 192-column tile, second sub-half: ONE MFMA tile per m tile, D rows 4g+e = columns 4g+e of the wave-column's last 16
+    const int nl = wc * 48 + 32 + 4 * g;
+    const int n0 = bn0 + nl;
+    const f32x4 sb4 = *(const f32x4*)(lsb + nl), bs4 = *(const f32x4*)(lbias + nl);
 #pragma unroll
-  for (int nh = 0; nh < 2; ++nh) {
-    const int nl = wc * 64 + nh * 32 + 8 * g;  // block-local column of this lane's 8 outputs
+    for (int mt = 0; mt < 8; ++mt) {
+      const int ml = wr * 128 + mt * 16 + jm;
+      const int m = bm0 + ml;
+      const float sa = lsa[ml];
+      i32x2 pk;
+#pragma unroll
+      for (int e2 = 0; e2 < 2; ++e2) {
+        const int e = 2 * e2;
+        const f32x2 a2 = {(float)acc[mt][2][e], (float)acc[mt][2][e + 1]};
+        f32x2 v = f32x2{sa, sa} * a2;
+        v = pin_f32x2(f32x2{sb4[e], sb4[e + 1]} * v);
+        uint32_t h = pack2_bits16<OUT_DT>(v);
+        if (has_bias) h = pack2_bits16<OUT_DT>(pin_f32x2(unpack2_bits16<OUT_DT>(h) + f32x2{bs4[e], bs4[e + 1]}));
+        pk[e2] = (int)h;
+      }
+      if (m < p.m) {
+        uint16_t* dst = (uint16_t*)p.c + (int64_t)m * p.c_stride_m + n0;
+        if (vec_store && n0 + 4 <= p.n) {
+          *(i32x2*)dst = pk;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n0 + e < p.n) dst[e] = (uint16_t)((uint32_t)pk[e >> 1] >> (16 * (e & 1)));
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int nh = 0; nh < (NT == 3 ? 1 : 2); ++nh) {
+    const int nl = wc * (NT == 3 ? 48 : 64) + nh * 32 + 8 * g;  // block-local column of this lane's 8 outputs
     const int n0 = bn0 + nl;
     const f32x4 sb_lo = *(const f32x4*)(lsb + nl), sb_hi = *(const f32x4*)(lsb + nl + 4);
     const f32x4 bs_lo = *(const f32x4*)(lbias + nl), bs_hi = *(const f32x4*)(lbias + nl + 4);
@@ -254,13 +290,14 @@ __device__ __forceinline__ void epilogue_silu(const typename AccT<MMA>::type (&a
 // kernels
 // ---------------------------------------------------------------------------------------------
 struct BlockSetup {
-  int wave, lane, wr, wc, bm0, bn0, m_base, n_base;
+  int wave, lane, wr, wc, bm0, bn0, m_base, n_base, narrow;
   StageOffsets so;
   Srcs src;
 };
 
-__device__ __forceinline__ BlockSetup setup_block(const ScaledGemmArgs& p) {
+__device__ __forceinline__ BlockSetup setup_block(const ScaledGemmArgs& p, const TileSchedule* ts = nullptr) {
   BlockSetup s;
+  s.narrow = 0;
   s.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   s.lane = threadIdx.x & 63;
   s.wr = s.wave >> 2;
@@ -269,11 +306,19 @@ __device__ __forceinline__ BlockSetup setup_block(const ScaledGemmArgs& p) {
   const int tile_n = p.fuse_silu ? kTileN / 2 : kTileN;
   const int tiles_m = ((int)p.m + kTileM - 1) / kTileM;
   const int tiles_n = ((int)p.n + tile_n - 1) / tile_n;
-  const TileCoord tc = map_tile(blockIdx.x, tiles_m, tiles_n);
-  s.bm0 = tc.tm * kTileM;
-  s.bn0 = tc.tn * tile_n;
+  if (ts) {
+    const TilePlace tp = place_tile(blockIdx.x, *ts);
+    s.bm0 = tp.tm * kTileM;
+    s.bn0 = tp.n0;
+    s.narrow = tp.narrow;
+  } else {
+    const TileCoord tc = map_tile(blockIdx.x, tiles_m, tiles_n);
+    s.bm0 = tc.tm * kTileM;
+    s.bn0 = tc.tn * tile_n;
+  }
   const int lda = (int)p.a_stride_m, ldb = (int)p.b_stride_n;
-  if (p.fuse_silu) s.so = make_stage_offsets(s.wave, s.lane, s.bm0, s.bn0, (int)p.m - 1, (int)p.n - 1, lda, ldb, 32, (int)p.n);
+  if (s.narrow) s.so = make_stage_offsets(s.wave, s.lane, s.bm0, s.bn0, (int)p.m - 1, (int)p.n - 1, lda, ldb, 48, 32);
+  else if (p.fuse_silu) s.so = make_stage_offsets(s.wave, s.lane, s.bm0, s.bn0, (int)p.m - 1, (int)p.n - 1, lda, ldb, 32, (int)p.n);
   else s.so = make_stage_offsets(s.wave, s.lane, s.bm0, s.bn0, (int)p.m - 1, (int)p.n - 1, lda, ldb);
   const int64_t b_cols = p.fuse_silu ? 2 * p.n : p.n;
   const uint32_t a_bytes = (uint32_t)((p.m - 1) * p.a_stride_m + p.k);
@@ -424,7 +469,11 @@ __global__ __launch_bounds__(kThreads, 2) void scaled_gemm_pingpong_kernel(Scale
 // waits vmcnt(8) (units <= U2(t) landed), B waits vmcnt(6) (units <= V2(t+1)).  A slot is re-targeted
 // one phase after its last read, so the reads are retired (lgkmcnt(0)) before the phase's first barrier.
 // ---------------------------------------------------------------------------------------------
-template <int MMA>
+#ifdef CONCH_CLOCK_PROBE
+__device__ unsigned long long g_probe_scaled[kProbeBlocks * 8];
+#endif
+
+template <int MMA, int NT>
 __device__ __forceinline__ void pp2_cluster(WaveTile<MMA>& w, int which) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this phase's fragment reads have left LDS
   __builtin_amdgcn_sched_barrier(0);
@@ -432,11 +481,11 @@ __device__ __forceinline__ void pp2_cluster(WaveTile<MMA>& w, int which) {
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_setprio(1);
   if (which == 0) {
-    phase_mma<MMA, 0>(w);
-    phase_mma<MMA, 1>(w);
+    phase_mma<MMA, 0, NT>(w);
+    phase_mma<MMA, 1, NT>(w);
   } else {
-    phase_mma<MMA, 2>(w);
-    phase_mma<MMA, 3>(w);
+    phase_mma<MMA, 2, NT>(w);
+    phase_mma<MMA, 3, NT>(w);
   }
   __builtin_amdgcn_s_setprio(0);
   __builtin_amdgcn_sched_barrier(0);
@@ -444,18 +493,18 @@ __device__ __forceinline__ void pp2_cluster(WaveTile<MMA>& w, int which) {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int MMA, int ISSUE_A, int ISSUE_B, int VM_A, int VM_B>
+template <int MMA, int NT, int ISSUE_A, int ISSUE_B, int VM_A, int VM_B>
 __device__ __forceinline__ void pp2_step(WaveTile<MMA>& w, char* lds, const BlockSetup& s, int t) {
   const int buf = (t & 1) * kBufBytes;
   // ---- phase A ----
   phase_reads<MMA, 0, true>(w, lds, buf, s.m_base, s.n_base);
-  phase_reads<MMA, 1, true>(w, lds, buf, s.m_base, s.n_base);
+  phase_reads<MMA, 1, true, NT>(w, lds, buf, s.m_base, s.n_base);
   if constexpr (ISSUE_A) {
     stage_unit<kV2>(lds, s.src, s.so, s.wave, t + 1);
     stage_unit<kU2>(lds, s.src, s.so, s.wave, t + 1);
   }
   wait_vmcnt<VM_A>();
-  pp2_cluster<MMA>(w, 0);
+  pp2_cluster<MMA, NT>(w, 0);
   // ---- phase B ----
   phase_reads<MMA, 2, true>(w, lds, buf, s.m_base, s.n_base);
   if constexpr (ISSUE_B) {
@@ -463,18 +512,30 @@ __device__ __forceinline__ void pp2_step(WaveTile<MMA>& w, char* lds, const Bloc
     stage_unit<kV1>(lds, s.src, s.so, s.wave, t + 2);
   }
   wait_vmcnt<VM_B>();
-  pp2_cluster<MMA>(w, 1);
+  pp2_cluster<MMA, NT>(w, 1);
 }
 
-#ifdef CONCH_CLOCK_PROBE
-__device__ unsigned long long g_probe_scaled[kProbeBlocks * 8];
-#endif
+// K loop + epilogue of one tile; NT = 4 (256 columns) or 3 (192 columns: 24 instead of 32 MFMAs per wave and K step, the same
+// staging stream and waits)
+template <int MMA, int OUT_DT, bool SILU, int NT>
+__device__ __forceinline__ void pp2_tile(const ScaledGemmArgs& p, char* lds, const BlockSetup& s, WaveTile<MMA>& w, int steps) {
+  CONCH_PROBE(g_probe_scaled, 0);
+  int t = 0;
+  for (; t + 2 < steps; ++t) pp2_step<MMA, NT, 1, 1, 8, 6>(w, lds, s, t);
+  pp2_step<MMA, NT, 1, 0, 8, 2>(w, lds, s, t);
+  pp2_step<MMA, NT, 0, 0, 0, -1>(w, lds, s, t + 1);
+  CONCH_PROBE(g_probe_scaled, 1);
+  if (s.wr == 0) __builtin_amdgcn_s_barrier();  // re-balance the barrier count
+
+  if constexpr (SILU) epilogue_silu<MMA, OUT_DT>(w.acc, p, lds, s.bm0, s.bn0, s.wr, s.wc, s.lane);
+  else epilogue<MMA, OUT_DT, NT>(w.acc, p, lds, s.bm0, s.bn0, s.wr, s.wc, s.lane);
+}
 
 template <int MMA, int OUT_DT, bool SILU>
-__global__ __launch_bounds__(kThreads, 2) void scaled_gemm_pp2_kernel(ScaledGemmArgs p) {
+__global__ __launch_bounds__(kThreads, 2) void scaled_gemm_pp2_kernel(ScaledGemmArgs p, TileSchedule ts) {
   __shared__ __attribute__((aligned(1024))) char lds[kLdsTotal];
   CONCH_PROBE(g_probe_scaled, 2);
-  const BlockSetup s = setup_block(p);
+  const BlockSetup s = SILU ? setup_block(p) : setup_block(p, &ts);
   WaveTile<MMA> w;
   zero_acc<MMA>(w);
   const int steps = (int)(p.k / kStepBytes);  // >= 2 (dispatcher)
@@ -491,16 +552,14 @@ __global__ __launch_bounds__(kThreads, 2) void scaled_gemm_pp2_kernel(ScaledGemm
   __builtin_amdgcn_s_barrier();
   if (s.wr == 1) __builtin_amdgcn_s_barrier();  // stagger the second wave of every SIMD
 
-  CONCH_PROBE(g_probe_scaled, 0);
-  int t = 0;
-  for (; t + 2 < steps; ++t) pp2_step<MMA, 1, 1, 8, 6>(w, lds, s, t);
-  pp2_step<MMA, 1, 0, 8, 2>(w, lds, s, t);
-  pp2_step<MMA, 0, 0, 0, -1>(w, lds, s, t + 1);
-  CONCH_PROBE(g_probe_scaled, 1);
-  if (s.wr == 0) __builtin_amdgcn_s_barrier();  // re-balance the barrier count
-
-  if constexpr (SILU) epilogue_silu<MMA, OUT_DT>(w.acc, p, lds, s.bm0, s.bn0, s.wr, s.wc, s.lane);
-  else epilogue<MMA, OUT_DT>(w.acc, p, lds, s.bm0, s.bn0, s.wr, s.wc, s.lane);
+  if constexpr (!SILU) {
+    if (s.narrow) {  // workgroup-uniform
+      pp2_tile<MMA, OUT_DT, false, 3>(p, lds, s, w, steps);
+      CONCH_PROBE(g_probe_scaled, 3);
+      return;
+    }
+  }
+  pp2_tile<MMA, OUT_DT, SILU, 4>(p, lds, s, w, steps);
   CONCH_PROBE(g_probe_scaled, 3);
 }
 
@@ -522,20 +581,73 @@ bool scaled_gemm_mfma_supported(const ScaledGemmArgs& p) {
   return true;
 }
 
+// Greedy (dispatch-order) makespan, in units of one 256-column tile's K loop, of t4 wide tiles followed by t3 narrow ones
+// on `cus` workgroup slots; `e` = the fixed per-tile cost (epilogue store burst, re-entry, prologue) in the same unit.
+static double schedule_makespan(int64_t t4, int64_t t3, int cus, double e) {
+  const double c4 = 1.0 + e, c3 = 0.75 + e;
+  const int64_t r4 = t4 / cus, rem4 = t4 % cus;
+  // group A: slots free after r4 wide rounds; group B: the rem4 slots that run one more wide tile
+  double ta = (double)r4 * c4, tb = ta + c4;
+  int64_t na = cus - rem4, nb = rem4;
+  double end = rem4 ? tb : ta;
+  while (t3 > 0) {
+    const bool use_a = nb == 0 || ta <= tb;
+    double& t = use_a ? ta : tb;
+    const int64_t slots = use_a ? na : nb;
+    const int64_t take = t3 < slots ? t3 : slots;
+    t += c3;
+    if (t > end) end = t;
+    t3 -= take;
+  }
+  return end;
+}
+
+// CONCH_TUNE_TILE_SCHEDULE: 0 = auto, 1 = uniform 256-column tiles, 2 = force the best two-width schedule
+static TileSchedule choose_tile_schedule(const ScaledGemmArgs& p) {
+  const int tiles_m = (int)((p.m + kTileM - 1) / kTileM);
+  const int tiles_n = (int)((p.n + kTileN - 1) / kTileN);
+  TileSchedule uni{tiles_m, tiles_n, 0};
+  const int mode = tuning(CONCH_TUNE_TILE_SCHEDULE);
+  if (mode == 1 || p.fuse_silu) return uni;
+  const int cus = device_cu_count();
+  // per-tile fixed cost: ~6 us (C-store burst, re-entry, first LDS-DMA landing) against 36.8 us of K loop at K = 4096
+  const double e = 0.163 * 4096.0 / (double)p.k;
+  const double t_uni = (double)(((int64_t)tiles_m * tiles_n + cus - 1) / cus) * (1.0 + e);
+  double best = t_uni * (mode == 2 ? 10.0 : 0.98);  // auto: only for a gain above 2 %
+  TileSchedule pick = uni;
+  const int a_max = (int)(p.n / kTileN);
+  for (int a = a_max; a >= 0; --a) {
+    const int64_t rest = p.n - (int64_t)a * kTileN;
+    const int b = (int)((rest + 191) / 192);
+    if ((int64_t)tiles_m * b < 8) continue;  // place_tile wants at least one narrow tile per XCD
+    const double t = schedule_makespan((int64_t)tiles_m * a, (int64_t)tiles_m * b, cus, e);
+    if (t < best - 1e-9) {
+      best = t;
+      pick = TileSchedule{tiles_m, a, b};
+    }
+  }
+  return pick;
+}
+
 int launch_scaled_gemm_mfma(const ScaledGemmArgs& p, int variant, hipStream_t stream) {
   const int tile_n = p.fuse_silu ? kTileN / 2 : kTileN;
   const int tiles_m = (int)((p.m + kTileM - 1) / kTileM);
   const int tiles_n = (int)((p.n + tile_n - 1) / tile_n);
   if (p.fuse_silu) variant = 5;
-  const dim3 grid((unsigned)(tiles_m * tiles_n));
+  dim3 grid((unsigned)(tiles_m * tiles_n));
+  TileSchedule ts{tiles_m, tiles_n, 0};
+  if (!p.fuse_silu && variant != 2 && variant != 3 && p.k >= 2 * kStepBytes) {
+    ts = choose_tile_schedule(p);
+    grid = dim3((unsigned)(ts.tiles_m * (ts.big_cols + ts.narrow_cols)));
+  }
 #define CONCH_LAUNCH(MMA, OUT)                                                                           \
   do {                                                                                                   \
     if (variant == 2)                                                                                    \
       hipLaunchKernelGGL((scaled_gemm_simple_kernel<MMA, OUT>), grid, dim3(kThreads), 0, stream, p);     \
     else if (p.fuse_silu)                                                                                \
-      hipLaunchKernelGGL((scaled_gemm_pp2_kernel<MMA, OUT, true>), grid, dim3(kThreads), 0, stream, p);  \
+      hipLaunchKernelGGL((scaled_gemm_pp2_kernel<MMA, OUT, true>), grid, dim3(kThreads), 0, stream, p, ts);  \
     else if (variant != 3 && p.k >= 2 * kStepBytes)                                                      \
-      hipLaunchKernelGGL((scaled_gemm_pp2_kernel<MMA, OUT, false>), grid, dim3(kThreads), 0, stream, p); \
+      hipLaunchKernelGGL((scaled_gemm_pp2_kernel<MMA, OUT, false>), grid, dim3(kThreads), 0, stream, p, ts); \
     else                                                                                                 \
       hipLaunchKernelGGL((scaled_gemm_pingpong_kernel<MMA, OUT>), grid, dim3(kThreads), 0, stream, p); \
     return check_launch("scaled_gemm_mfma");                                                             \

@@ -568,13 +568,7 @@ bool mixed_gemm_mfma_supported(const MixedGemmArgs& p) {
 }
 
 int launch_mixed_gemm_mfma(const MixedGemmArgs& p, hipStream_t stream) {
-  static int num_cus = 0;
-  if (num_cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    num_cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-               prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-  }
+  const int num_cus = device_cu_count();
   const int forced = tuning(1);  // CONCH_TUNE_MIXED_TILE_NT: 0 = auto, 2..4 = force
   const int nt = p.fuse_silu ? 4 : (forced >= 2 && forced <= 4) ? forced : pick_nt(p, num_cus);
   if (p.x_dtype == CONCH_DT_FP16) {

@@ -209,7 +209,7 @@ int launch_mixed_gemm_skinny(const MixedGemmArgs& p, hipStream_t stream) {
   const int slices = (int)(p.k / kMsSliceK);
   const int rows = p.m <= 16 ? 16 : p.m <= 32 ? 32 : 64;
   void* ws = nullptr;
-  if (int rc = get_scratch(stream, 2, (size_t)slices * p.m * p.n * 4, &ws)) return rc;
+  if (int rc = get_scratch(stream, kScratchMixedSplitK, (size_t)slices * p.m * p.n * 4, &ws)) return rc;
   const dim3 grid((unsigned)((p.n + kMsN - 1) / kMsN), (unsigned)slices, (unsigned)((p.m + rows - 1) / rows));
   if (p.x_dtype == CONCH_DT_FP16) {
     if (p.bits == 4) launch_zp_mode<CONCH_DT_FP16, 4>(p, rows, grid, (float*)ws, stream);

@@ -143,36 +143,69 @@ constexpr int kSpSliceK = kSpSteps * kStepBytes;
 
 // ROWS = rows of A a workgroup handles (32, 64 or 128): a decode batch of 32 rows stages, multiplies and writes a quarter
 // of what the 128-row form does.  Per step and wave: 2 register loads of B^T + ROWS/32 LDS-DMA pieces of A.
-template <int MMA, int ROWS, int S>
-__device__ __forceinline__ void sp_consume(typename AccT<MMA>::type (&acc)[ROWS / 16], const Frag (&fb)[8], const char* lds,
+template <int MMA, int ROWS, int STEPS, int S>
+__device__ __forceinline__ void sp_consume(typename AccT<MMA>::type (&acc)[ROWS / 16], const Frag (&fb)[STEPS], const char* lds,
                                            int lane_off) {
   constexpr int kOps = 2 + ROWS / 32;
-  if constexpr (S < 8) {
-    wait_vmcnt_n<kOps * (7 - S)>();  // step S of this wave has landed ...
-    __builtin_amdgcn_s_barrier();    // ... and so has every other wave's quarter of unit S
+  if constexpr (S < STEPS) {
+    wait_vmcnt_n<kOps * (STEPS - 1 - S)>();  // step S of this wave has landed ...
+    __builtin_amdgcn_s_barrier();            // ... and so has every other wave's quarter of unit S
 #pragma unroll
     for (int i = 0; i < ROWS / 16; ++i) {
       const Frag fa = read_frag(lds, S * (ROWS * kStepBytes) + lane_off + i * 2048);
       mma_step<MMA>(acc[i], fb[S], fa);  // D rows = n, D cols = m
     }
-    sp_consume<MMA, ROWS, S + 1>(acc, fb, lds, lane_off);
+    sp_consume<MMA, ROWS, STEPS, S + 1>(acc, fb, lds, lane_off);
   }
 }
 
-// The whole slice is put in flight at once -- 8 A units (ROWS x 128 bytes each, LDS-DMA) and 8 B^T fragments
-// (64 VGPRs) per wave -- so the slice costs one memory latency plus its transfer time instead of a
+// scale / cast / bias of four consecutive columns of one row (scaled_gemm.py:21-25), packed as 2 dwords
+template <int OUT_DT, class ACC>
+__device__ __forceinline__ i32x2 sp_epilogue4(const ScaledGemmArgs& p, const ACC& sum, int m, int n) {
+  const float sa = p.scale_a[p.scale_a_numel != 1 ? m : 0];
+  uint16_t o[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float sb = p.scale_b[p.scale_b_numel != 1 ? n + e : 0];
+    float v = sa * (float)sum[e];   // scaled_gemm.py:21
+    v = pin_f32(sb * v);            // :22
+    uint16_t h = float_to_bits16<OUT_DT>(v);  // :23
+    if (p.bias)                     // :24-25
+      h = float_to_bits16<OUT_DT>(pin_f32(bits16_to_float<OUT_DT>(h) + bits16_to_float<OUT_DT>(((const uint16_t*)p.bias)[n + e])));
+    o[e] = h;
+  }
+  i32x2 pk;
+  pk[0] = (int)((uint32_t)o[0] | ((uint32_t)o[1] << 16));
+  pk[1] = (int)((uint32_t)o[2] | ((uint32_t)o[3] << 16));
+  return pk;
+}
+
+// The whole slice is put in flight at once -- STEPS A units (ROWS x 128 bytes each, LDS-DMA) and STEPS B^T fragments
+// (8 VGPRs each) per wave -- so the slice costs one memory latency plus its transfer time instead of a
 // latency per K step; the steps are then consumed in issue order with counted vmcnt waits.
-template <int MMA, int ROWS>
-__global__ __launch_bounds__(kSkThreads, 1) void skinny_splitk_kernel(ScaledGemmArgs p, int* __restrict__ slabs) {
+//
+// FUSED = the reduce of the slices runs in the same launch (BASELINE config C2: one launch instead of two, no second
+// pass over the slabs by a second grid).  Protocol (MI355X_MICROARCH.md, inter-workgroup visibility, first row of the
+// table of measured hand-offs; cdna_hip_programming.md section 5, in-launch split-K reduction): every wave stores its
+// partial tile WRITE-THROUGH (sc1) and drains its own stores (s_waitcnt vmcnt(0)); workgroup barrier; ONE lane draws a
+// ticket from the tile's agent-scope counter; the workgroup that draws the last ticket re-reads the other slices' slabs
+// with sc1 loads (they bypass this CU's L1, so no acquire is needed) and adds them IN SLICE ORDER -- its own slice from
+// registers, bit-identical to what it stored -- then runs the fused epilogue and puts the counter back to zero.
+// Placement-independent: nothing here depends on which XCD or CU a slice runs on.  The LDS request is kept above half
+// of the CU's 160 KiB so that one workgroup runs per CU (the regime the hand-off was measured in).
+template <int MMA, int OUT_DT, int ROWS, int STEPS, bool FUSED>
+__global__ __launch_bounds__(kSkThreads, 1) void skinny_splitk_kernel(ScaledGemmArgs p, int* __restrict__ slabs,
+                                                                       unsigned* __restrict__ counters) {
   constexpr int kUnit = ROWS * kStepBytes;  // one K step of A
   constexpr int kPieces = ROWS / 32;        // 8-row x 128-byte subtiles a wave feeds per step
-  __shared__ __attribute__((aligned(1024))) char lds[kSpSteps * kUnit];
+  constexpr int kLds = (FUSED && STEPS * kUnit < 84 * 1024) ? 84 * 1024 : STEPS * kUnit;
+  __shared__ __attribute__((aligned(1024))) char lds[kLds];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int r = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * kSpN + wave * 16, m0 = blockIdx.z * ROWS;
   const int slice = blockIdx.y;
-  const int k_begin = slice * kSpSliceK;
+  const int k_begin = slice * (STEPS * kStepBytes);
 
   const uint32_t a_bytes = (uint32_t)((p.m - 1) * p.a_stride_m + p.k);
   const uint32_t b_bytes = (uint32_t)((p.n - 1) * p.b_stride_n + p.k);
@@ -190,9 +223,9 @@ __global__ __launch_bounds__(kSkThreads, 1) void skinny_splitk_kernel(ScaledGemm
   const int voff_b = min(n0 + r, (int)p.n - 1) * (int)p.b_stride_n + 16 * g;
   const int lane_off = (r >> 3) * 1024 + (r & 7) * 128 + ((g ^ ((r >> 1) & 7)) * 16);
 
-  Frag fb[kSpSteps];
+  Frag fb[STEPS];
 #pragma unroll
-  for (int s = 0; s < kSpSteps; ++s) {
+  for (int s = 0; s < STEPS; ++s) {
     fb[s].lo = ld16(rb, voff_b, k_begin + s * kStepBytes);
     fb[s].hi = ld16(rb, voff_b, k_begin + s * kStepBytes + 64);
     char* dst = lds + s * kUnit + wave * (ROWS / 4) * kStepBytes;
@@ -208,15 +241,76 @@ __global__ __launch_bounds__(kSkThreads, 1) void skinny_splitk_kernel(ScaledGemm
 #pragma unroll
   for (int i = 0; i < ROWS / 16; ++i) acc[i] = typename AccT<MMA>::type{0, 0, 0, 0};
 
-  sp_consume<MMA, ROWS, 0>(acc, fb, lds, lane_off);
+  sp_consume<MMA, ROWS, STEPS, 0>(acc, fb, lds, lane_off);
 
   // partial sums -> slab [slice][M][N] (4-byte elements); lane: m = m0 + 16 i + r, n = n0 + 4 g + e
-  int* slab = slabs + (int64_t)slice * p.m * p.n;
+  const int n = n0 + 4 * g;
+  const int64_t slab_elems = p.m * p.n;
+  if constexpr (!FUSED) {
+    int* slab = slabs + (int64_t)slice * slab_elems;
 #pragma unroll
-  for (int i = 0; i < ROWS / 16; ++i) {
-    const int m = m0 + i * 16 + r;
-    const int n = n0 + 4 * g;
-    if (m < p.m && n + 4 <= p.n) *(i32x4*)(slab + (int64_t)m * p.n + n) = __builtin_bit_cast(i32x4, acc[i]);
+    for (int i = 0; i < ROWS / 16; ++i) {
+      const int m = m0 + i * 16 + r;
+      if (m < p.m && n + 4 <= p.n) *(i32x4*)(slab + (int64_t)m * p.n + n) = __builtin_bit_cast(i32x4, acc[i]);
+    }
+  } else {
+    const int slices = (int)gridDim.y;
+    const uint32_t slab_bytes = (uint32_t)(slab_elems * 4);
+    // one descriptor over all slabs (the launcher keeps slices x M x N x 4 below 2 GiB); slice s at scalar offset s x slab_bytes
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)slabs, 0, slab_bytes * (uint32_t)slices, 0x00020000);
+    int voff_s[ROWS / 16];
+#pragma unroll
+    for (int i = 0; i < ROWS / 16; ++i) voff_s[i] = (min(m0 + i * 16 + r, (int)p.m - 1) * (int)p.n + min(n, (int)p.n - 4)) * 4;
+#pragma unroll
+    for (int i = 0; i < ROWS / 16; ++i) {
+      const int m = m0 + i * 16 + r;
+      if (m < p.m && n + 4 <= p.n)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i]), rs, voff_s[i], slice * (int)slab_bytes, 16);  // sc1
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its own write-through stores
+    __syncthreads();
+    unsigned* flag = (unsigned*)lds;  // the operand ring is dead: every wave's last ds_read fed an MFMA before the barrier
+    unsigned* cnt = counters + (blockIdx.z * gridDim.x + blockIdx.x);
+    if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (*flag != (unsigned)(slices - 1)) return;  // workgroup-uniform
+    // Last arriver: add the slices IN SLICE ORDER (exact for int32, deterministic for fp32), four slices of loads in
+    // flight at a time.  Every slice is loaded, this workgroup's own included (its stores are at L2 like the others'):
+    // a per-slice "registers or load" choice would make hipcc branch around, and drain, every load.
+    typename AccT<MMA>::type sum[ROWS / 16];
+    for (int sb = 0; sb < slices; sb += 4) {
+      u32x4 part[4][ROWS / 16];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int soff = min(sb + j, slices - 1) * (int)slab_bytes;
+#pragma unroll
+        for (int i = 0; i < ROWS / 16; ++i) part[j][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_s[i], soff, 16);  // sc1
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool first = sb + j == 0, live = sb + j < slices;
+#pragma unroll
+        for (int i = 0; i < ROWS / 16; ++i) {
+          const typename AccT<MMA>::type v = __builtin_bit_cast(typename AccT<MMA>::type, part[j][i]);
+          sum[i] = first ? v : live ? sum[i] + v : sum[i];
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < ROWS / 16; ++i) {
+      const int m = m0 + i * 16 + r;
+      if (m < p.m && n + 4 <= p.n) {
+        const i32x2 pk = sp_epilogue4<OUT_DT>(p, sum[i], m, n);
+        uint16_t* dst = (uint16_t*)p.c + (int64_t)m * p.c_stride_m + n;
+        if ((((uintptr_t)dst) & 7) == 0) {
+          *(i32x2*)dst = pk;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dst[e] = (uint16_t)((uint32_t)pk[e >> 1] >> (16 * (e & 1)));
+        }
+      }
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
   }
 }
 
@@ -291,19 +385,23 @@ __global__ __launch_bounds__(256) void skinny_reduce_silu_kernel(ScaledGemmArgs 
   }
 }
 
-// launches the partial-sum kernel for a runtime (operand type, row count) pair
-void launch_splitk_partials(int mma, int rows, dim3 grid, const ScaledGemmArgs& p, int* ws, hipStream_t stream) {
+// launches the split-K kernel for a runtime (row count, steps per slice) pair
+template <int MMA, int OUT_DT, bool FUSED>
+void launch_splitk_kernel(int rows, int steps, dim3 grid, const ScaledGemmArgs& p, int* ws, unsigned* counters, hipStream_t stream) {
   const dim3 block(kSkThreads);
-  if (mma == kMmaFp8) {
-    if (rows == 32) hipLaunchKernelGGL((skinny_splitk_kernel<kMmaFp8, 32>), grid, block, 0, stream, p, ws);
-    else if (rows == 64) hipLaunchKernelGGL((skinny_splitk_kernel<kMmaFp8, 64>), grid, block, 0, stream, p, ws);
-    else hipLaunchKernelGGL((skinny_splitk_kernel<kMmaFp8, 128>), grid, block, 0, stream, p, ws);
-  } else {
-    if (rows == 32) hipLaunchKernelGGL((skinny_splitk_kernel<kMmaInt8, 32>), grid, block, 0, stream, p, ws);
-    else if (rows == 64) hipLaunchKernelGGL((skinny_splitk_kernel<kMmaInt8, 64>), grid, block, 0, stream, p, ws);
-    else hipLaunchKernelGGL((skinny_splitk_kernel<kMmaInt8, 128>), grid, block, 0, stream, p, ws);
+  if constexpr (FUSED) {
+    if (steps == 16) {  // 2048-byte slices: half the slabs, rows split instead (rows <= 64: 16 units of 64 rows fill the LDS)
+      if (rows == 32) hipLaunchKernelGGL((skinny_splitk_kernel<MMA, OUT_DT, 32, 16, true>), grid, block, 0, stream, p, ws, counters);
+      else hipLaunchKernelGGL((skinny_splitk_kernel<MMA, OUT_DT, 64, 16, true>), grid, block, 0, stream, p, ws, counters);
+      return;
+    }
   }
+  if (rows == 32) hipLaunchKernelGGL((skinny_splitk_kernel<MMA, OUT_DT, 32, kSpSteps, FUSED>), grid, block, 0, stream, p, ws, counters);
+  else if (rows == 64) hipLaunchKernelGGL((skinny_splitk_kernel<MMA, OUT_DT, 64, kSpSteps, FUSED>), grid, block, 0, stream, p, ws, counters);
+  else hipLaunchKernelGGL((skinny_splitk_kernel<MMA, OUT_DT, 128, kSpSteps, FUSED>), grid, block, 0, stream, p, ws, counters);
 }
+
+constexpr int kSpMaxTiles = 16384;  // arrival counters per (device, stream): 64 KiB
 
 int splitk_slices(const ScaledGemmArgs& p) {
   // slices of exactly 1024 K-bytes (K % 1024 == 0 is part of the skinny contract)
@@ -325,17 +423,35 @@ bool scaled_gemm_skinny_supported(const ScaledGemmArgs& p) {
   return true;
 }
 
+// CONCH_TUNE_SKINNY_MODE: 0 = auto, 1 = two launches (partials, then the reduce kernel), 2 = one launch with
+// 1024-byte slices, 3 = one launch with 2048-byte slices and <= 64-row blocks
 template <int MMA, int OUT_DT>
 int launch_splitk(const ScaledGemmArgs& p, int slices, hipStream_t stream) {
-  void* ws = nullptr;
-  const size_t bytes = (size_t)slices * p.m * p.n * 4;
-  if (get_scratch(stream, 1, bytes, &ws) != CONCH_OK) {
-    (void)hipGetLastError();
-    return -1;  // caller falls back to the in-workgroup K split
+  int mode = tuning(CONCH_TUNE_SKINNY_MODE);
+  int rows = p.m <= 32 ? 32 : p.m <= 64 ? 64 : 128;
+  if (mode == 0) mode = 2;
+  int steps = kSpSteps;
+  if (mode == 3 && p.k % (2 * kSpSliceK) == 0) {
+    steps = 2 * kSpSteps;
+    slices /= 2;
+    rows = p.m <= 32 ? 32 : 64;
+  } else if (mode == 3) {
+    mode = 2;
   }
-  const int rows = p.m <= 32 ? 32 : p.m <= 64 ? 64 : 128;
   const dim3 grid((unsigned)((p.n + kSpN - 1) / kSpN), (unsigned)slices, (unsigned)((p.m + rows - 1) / rows));
-  launch_splitk_partials(MMA, rows, grid, p, (int*)ws, stream);
+  const size_t bytes = (size_t)slices * p.m * p.n * 4;
+  // the in-launch reduce addresses all slabs through one 32-bit buffer descriptor and needs one counter per tile; the
+  // gate/up fusion combines two tiles per output and keeps its reduce kernel
+  if (p.fuse_silu || bytes >= ((size_t)1 << 31) || (size_t)grid.x * grid.z > (size_t)kSpMaxTiles) mode = 1;
+  void* ws = nullptr;
+  if (int rc = get_scratch(stream, kScratchSplitK, bytes, &ws)) return rc;
+  if (mode != 1) {
+    void* counters = nullptr;
+    if (int rc = get_scratch(stream, kScratchCounters, (size_t)kSpMaxTiles * 4, &counters, /*zero_on_alloc=*/true)) return rc;
+    launch_splitk_kernel<MMA, OUT_DT, true>(rows, steps, grid, p, (int*)ws, (unsigned*)counters, stream);
+    return check_launch("scaled_gemm_skinny_splitk_fused");
+  }
+  launch_splitk_kernel<MMA, CONCH_DT_BF16, false>(rows, steps, grid, p, (int*)ws, nullptr, stream);
   const int64_t quads = p.m * (p.n / 4);
   if (p.fuse_silu) {  // p.n = 2d columns [gate | up], C has d
     const int64_t oquads = p.m * (p.n / 8);
@@ -351,7 +467,7 @@ int launch_splitk(const ScaledGemmArgs& p, int slices, hipStream_t stream) {
 int launch_scaled_gemm_skinny(const ScaledGemmArgs& p, hipStream_t stream) {
   // fuse_silu: `p` is the WIDE problem (n = 2d) whose reduce kernel writes the d-column FFN result (the caller has checked
   // scaled_gemm_skinny_fused_supported); only the split-K form has a reduce kernel
-  const int slices = (tuning(2) == 1 && !p.fuse_silu) ? 0 : splitk_slices(p);  // CONCH_TUNE_SKINNY_NO_SPLITK = 1 disables split-K
+  const int slices = (tuning(CONCH_TUNE_SKINNY_NO_SPLITK) == 1 && !p.fuse_silu) ? 0 : splitk_slices(p);  // CONCH_TUNE_SKINNY_NO_SPLITK = 1 disables split-K
   if (slices >= 1) {
     int rc;
     if (p.in_dtype == CONCH_DT_FP8_E4M3FN)
@@ -360,7 +476,7 @@ int launch_scaled_gemm_skinny(const ScaledGemmArgs& p, hipStream_t stream) {
     else
       rc = p.out_dtype == CONCH_DT_BF16 ? launch_splitk<kMmaInt8, CONCH_DT_BF16>(p, slices, stream)
                                         : launch_splitk<kMmaInt8, CONCH_DT_FP16>(p, slices, stream);
-    if (rc >= 0) return rc;
+    return rc;  // a scratch failure is an error, not a reason to fall through: the in-workgroup kernel has no fused reduce
   }
   const dim3 grid((unsigned)((p.n + kSkN - 1) / kSkN), (unsigned)((p.m + kSkM - 1) / kSkM));
 #define CONCH_LAUNCH(MMA, OUT)                                                                          \

@@ -37,11 +37,7 @@ struct TileCoord {
 // XCD-aware + GROUP_M rasterisation.  Workgroups are dealt round-robin over the 8 XCDs, so ids
 // b and b+8 share an L2: give each XCD a contiguous run of the GROUP_M-ordered tile list
 // (bijective for any grid size).  Pure speed; correctness does not depend on placement.
-__device__ __forceinline__ TileCoord map_tile(int bid, int tiles_m, int tiles_n) {
-  const int nwg = tiles_m * tiles_n;
-  const int xcd = bid & 7;
-  const int q = nwg >> 3, r = nwg & 7;
-  const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+__device__ __forceinline__ TileCoord raster_tile(int lin, int tiles_m, int tiles_n) {
   const int per_group = kGroupM * tiles_n;
   const int group = lin / per_group;
   const int first_m = group * kGroupM;
@@ -50,6 +46,62 @@ __device__ __forceinline__ TileCoord map_tile(int bid, int tiles_m, int tiles_n)
   TileCoord t;
   t.tm = first_m + in_group % gsz;
   t.tn = in_group / gsz;
+  return t;
+}
+
+__device__ __forceinline__ TileCoord map_tile(int bid, int tiles_m, int tiles_n) {
+  const int nwg = tiles_m * tiles_n;
+  const int xcd = bid & 7;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  return raster_tile(lin, tiles_m, tiles_n);
+}
+
+// Two-width tile schedule of the 256-row scaled GEMM (gemm_mfma.hip): `big_cols` tile columns of 256 output columns,
+// then `narrow_cols` tile columns of 192 (the last one possibly masked).  With uniform 256-wide tiles a problem whose
+// tile count is not a multiple of the CU count idles most of the chip in its last round (C3: 688 tiles on 256 CUs = 2.69
+// rounds run as 3); a narrow tile costs 3/4 of a wide one, so [512 wide + 240 narrow] runs as 2 + 0.75 rounds.  Every
+// XCD walks ITS share of the wide tiles first and of the narrow tiles last (longest first: the greedy dispatcher then ends
+// all CUs together).  narrow_cols == 0 is the plain uniform schedule.
+struct TileSchedule {
+  int tiles_m;
+  int big_cols;
+  int narrow_cols;
+};
+
+struct TilePlace {
+  int tm;
+  int n0;      // first output column
+  int narrow;  // 1 = 192-column tile
+};
+
+__device__ __forceinline__ TilePlace place_tile(int bid, const TileSchedule& ts) {
+  TilePlace t;
+  if (ts.narrow_cols == 0) {
+    const TileCoord c = map_tile(bid, ts.tiles_m, ts.big_cols);
+    t.tm = c.tm;
+    t.n0 = c.tn * kTileN;
+    t.narrow = 0;
+    return t;
+  }
+  const int t4 = ts.tiles_m * ts.big_cols, t3 = ts.tiles_m * ts.narrow_cols;
+  const int nwg = t4 + t3;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int w0 = xcd * q + min(xcd, r);            // tiles of any width given to XCDs below this one
+  const int b0 = (xcd * t4) >> 3;                  // wide tiles given to XCDs below this one
+  const int b1 = ((xcd + 1) * t4) >> 3;
+  if (idx < b1 - b0) {
+    const TileCoord c = raster_tile(b0 + idx, ts.tiles_m, ts.big_cols);
+    t.tm = c.tm;
+    t.n0 = c.tn * kTileN;
+    t.narrow = 0;
+  } else {
+    const TileCoord c = raster_tile((w0 - b0) + idx - (b1 - b0), ts.tiles_m, ts.narrow_cols);
+    t.tm = c.tm;
+    t.n0 = ts.big_cols * kTileN + c.tn * (kTileN * 3 / 4);
+    t.narrow = 1;
+  }
   return t;
 }
 
@@ -79,7 +131,13 @@ __device__ __forceinline__ StageOffsets make_stage_offsets(int wave, int lane, i
     const int nrow = (rho >> 5) * wave_col_cols + 8 * (r >> 2) + (r & 3) + 4 * t;
     s.off[kU1][j] = min(bm0 + mrow, m_max) * lda + chunk * 16;
     s.off[kU2][j] = min(bm0 + mrow + 64, m_max) * lda + chunk * 16;
-    if (v2_delta == 32) {
+    if (wave_col_cols == 48) {
+      // 192-column tile: a wave-column owns 48 columns -- 32 in V1 (both 16-row MFMA tiles, permuted as above) and 16 in V2
+      // (ONE MFMA tile, rows in plain order: D rows 4g+e = n 4g+e, four consecutive columns per lane); the second 16 rows
+      // of a wave-column's V2 share are never multiplied and re-stage the first sixteen
+      s.off[kV1][j] = min(bn0 + nrow, n_max) * ldb + chunk * 16;
+      s.off[kV2][j] = min(bn0 + (rho >> 5) * 48 + 32 + r, n_max) * ldb + chunk * 16;
+    } else if (v2_delta == 32) {
       s.off[kV1][j] = min(bn0 + nrow, n_max) * ldb + chunk * 16;
       s.off[kV2][j] = min(bn0 + nrow + 32, n_max) * ldb + chunk * 16;
     } else {

@@ -87,7 +87,7 @@ int repack_for_mfma(const ScaledGemmArgs& p, ScaledGemmArgs* q, void** scratch, 
   const size_t b_bytes = copy_b ? (size_t)(p.n * kp + 255) / 256 * 256 : 0;
   if (p.m * kp >= ((int64_t)1 << 31) || p.n * kp >= ((int64_t)1 << 31)) return CONCH_ERR_UNSUPPORTED;
   void* ws = nullptr;
-  if (int rc = get_scratch(stream, 0, a_bytes + b_bytes, &ws)) return rc;
+  if (int rc = get_scratch(stream, kScratchRepack, a_bytes + b_bytes, &ws)) return rc;
   *scratch = ws;
   const dim3 block(256);
   if (copy_a) {
@@ -123,7 +123,7 @@ int expand_fnuz_to_bf16(const ScaledGemmArgs& p, ScaledGemmArgs* q, hipStream_t 
   const size_t a_bytes = (size_t)(p.m * kp * 2 + 255) / 256 * 256;
   const size_t b_bytes = (size_t)(p.n * kp * 2 + 255) / 256 * 256;
   void* ws = nullptr;
-  if (int rc = get_scratch(stream, 0, a_bytes + b_bytes, &ws)) return rc;
+  if (int rc = get_scratch(stream, kScratchRepack, a_bytes + b_bytes, &ws)) return rc;
   const dim3 block(256);
   {
     const dim3 grid((unsigned)((kp + kRpTile - 1) / kRpTile), (unsigned)((p.m + kRpTile - 1) / kRpTile));

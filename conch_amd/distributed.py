@@ -4,13 +4,23 @@ The reference has no distributed code at all; this is the multi-GPU form of the 
 Output column j depends only on B[:, j], scale_b[j] and bias[j], so N is partitioned into
 `world_size` contiguous column blocks: every rank holds all of A / scale_a and its block of
 B / scale_b / bias, computes its [M, N/G] block of C with the single-GPU kernel (no reduction, so
-every element is bit-identical to the single-GPU result), and ONE collective -- an all-gather of the
-blocks over RCCL/xGMI -- assembles C.
+every element is bit-identical to the single-GPU result), and ONE kind of collective -- an all-gather of the
+blocks over RCCL/xGMI -- assembles C.  One process per GPU; backend "nccl" is RCCL on ROCm, "gloo" is used by
+the CPU tests.
 
-Layout: an all-gather concatenates along dim 0, so the gathered tensor is
-[G, M, N/G] ("column-block major").  `gathered_blocks()` returns that zero-copy view for consumers
-that are themselves column-parallel; `__call__` returns the row-major [M, N] tensor (one permuting
-copy).  One process per GPU; backend "nccl" is RCCL on ROCm, "gloo" is used by the CPU tests.
+Data movement, designed for xGMI (point-to-point links: the gather, not the GEMM, is the long pole at C5 --
+58.7 MB per rank against a 0.15 ms GEMM):
+
+* M is cut into `panels` row panels.  The GEMM of panel p writes its [h, N/G] block STRAIGHT into this rank's slot
+  of the panel's gather buffer (the kernels take any output row stride / base), so the all-gather is in place and
+  nothing is copied before it.
+* The all-gather of panel p runs on a side stream while the GEMM of panel p+1 runs on the compute stream.
+* An all-gather concatenates along dim 0, so a gathered panel is [G, h, N/G] ("column-block major").
+  `gathered_blocks()` hands that layout out as is, for consumers that are themselves column-parallel.  `__call__`
+  returns the row-major [M, N] tensor: each gathered panel is unpacked into it ([G, h, N/G] -> rows) on the side
+  stream, behind its own gather and under the next panel's gather -- the one whole-matrix permuting copy of round 1
+  is gone.  With world_size == 1 the GEMM writes the row-major result directly (column offset + row stride N) and
+  there is no gather and no copy.
 """
 
 from __future__ import annotations
@@ -29,18 +39,33 @@ def shard_bounds(n: int, world_size: int, rank: int) -> tuple[int, int]:
     return rank * per, (rank + 1) * per
 
 
-def _default_gemm(a, b, scale_a, scale_b, output_dtype, bias):
-    from conch_amd.ops.quantization.gemm import scaled_gemm
+def _default_gemm_into(out, a, b, scale_a, scale_b, bias):
+    """The product path: the public launcher writing into a caller-provided (possibly strided) output view."""
+    from conch_amd.kernels.quantization.gemm import scaled_gemm_launcher
+    from conch_amd.ops.quantization._metadata import create_scaled_metadata
 
-    return scaled_gemm(a, b, scale_a, scale_b, output_dtype, bias)
+    meta = create_scaled_metadata(a, b, scale_a, scale_b, out.dtype)
+    scaled_gemm_launcher(out, a, b, scale_a, scale_b, meta, bias=bias)
+
+
+def default_panels(m: int, n_local: int, tile: int = 256, cus: int = 256) -> int:
+    """Row panels per call: as many as keep every panel's GEMM at >= ~0.85 of one full round of 256x256 tiles (a panel
+    below one round idles CUs; C5 on 8 GPUs: 32 x 14 tiles -> 2 panels of 224 tiles)."""
+    tiles_n = -(-n_local // tile)
+    tiles_m = -(-m // tile)
+    best = 1
+    for p in range(2, 9):
+        if tiles_m % p == 0 and (tiles_m // p) * tiles_n >= 0.85 * cus:
+            best = p
+    return best
 
 
 class NShardedScaledGemm:
     """scaled_gemm with B, scale_b and bias sharded on N and C all-gathered.
 
-    Buffers are allocated once (288 GB of HBM per GPU: the gathered C of config C5 is 470 MB) and
-    reused by every call, so a call is: one GEMM launch + one all-gather (+ one permuting copy for
-    the row-major form).
+    Buffers are allocated once (288 GB of HBM per GPU: the gathered C of config C5 is 470 MB, its staging another
+    470 MB) and reused by every call.  `gemm_fn(a, b, scale_a, scale_b, output_dtype, bias) -> Tensor` may be injected
+    (the CPU tests pass the oracle); the default writes through the public launcher into the gather buffer.
     """
 
     def __init__(
@@ -51,30 +76,85 @@ class NShardedScaledGemm:
         device: torch.device,
         group: dist.ProcessGroup | None = None,
         gemm_fn: Callable | None = None,
+        panels: int | None = None,
     ) -> None:
         self.group = group
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.m, self.n = m, n
         self.lo, self.hi = shard_bounds(n, self.world_size, self.rank)
+        self.n_local = self.hi - self.lo
         self.output_dtype = output_dtype
-        self.gemm_fn = gemm_fn or _default_gemm
-        self._blocks = torch.empty((self.world_size, m, self.hi - self.lo), dtype=output_dtype, device=device)
+        self.device = torch.device(device)
+        self.gemm_fn = gemm_fn
+        self.panels = panels if panels is not None else default_panels(m, self.n_local)
+        if self.panels < 1 or m % self.panels:
+            raise ValueError(f"M={m} is not divisible into {self.panels} panels")
+        self.h = m // self.panels
+        g = self.world_size
+        self._c = torch.empty((m, n), dtype=output_dtype, device=self.device)  # row-major result
+        # gather staging, one [G, h, N/G] buffer per panel (unused when world_size == 1)
+        self._stage = torch.empty((self.panels, g, self.h, self.n_local), dtype=output_dtype, device=self.device) if g > 1 else None
+        self._side = torch.cuda.Stream(self.device) if self.device.type == "cuda" and g > 1 else None
+
+    # -- the local product -------------------------------------------------------------------------------------------
+    def _gemm_into(self, out: torch.Tensor, a, b_shard, scale_a, scale_b_shard, bias_shard) -> None:
+        if self.gemm_fn is None:
+            _default_gemm_into(out, a, b_shard, scale_a, scale_b_shard, bias_shard)
+        else:
+            out.copy_(self.gemm_fn(a, b_shard, scale_a, scale_b_shard, self.output_dtype, bias_shard))
+
+    def _panel_inputs(self, p: int, a, scale_a):
+        rows = slice(p * self.h, (p + 1) * self.h)
+        return a[rows], (scale_a[rows] if scale_a.numel() > 1 else scale_a)
 
     def local_gemm(self, a, b_shard, scale_a, scale_b_shard, bias_shard=None) -> torch.Tensor:
-        """This rank's [M, N/G] block of C (b_shard: [K, N/G], any strides)."""
-        return self.gemm_fn(a, b_shard, scale_a, scale_b_shard, self.output_dtype, bias_shard)
+        """This rank's [M, N/G] block of C (b_shard: [K, N/G], any strides), as a view of the row-major result buffer."""
+        out = self._c[:, self.lo : self.hi]
+        self._gemm_into(out, a, b_shard, scale_a, scale_b_shard, bias_shard)
+        return out
+
+    # -- the exchange ------------------------------------------------------------------------------------------------
+    def _run(self, a, b_shard, scale_a, scale_b_shard, bias_shard, unpack: bool) -> None:
+        if self.world_size == 1:
+            self.local_gemm(a, b_shard, scale_a, scale_b_shard, bias_shard)
+            return
+        cuda = self._side is not None
+        main = torch.cuda.current_stream(self.device) if cuda else None
+        for p in range(self.panels):
+            a_p, sa_p = self._panel_inputs(p, a, scale_a)
+            slot = self._stage[p, self.rank]  # [h, N/G], contiguous: the in-place input of the panel's all-gather
+            self._gemm_into(slot, a_p, b_shard, sa_p, scale_b_shard, bias_shard)
+            if cuda:
+                ready = torch.cuda.Event()
+                ready.record(main)
+                self._side.wait_event(ready)
+                with torch.cuda.stream(self._side):
+                    self._gather_panel(p, slot, unpack)
+            else:
+                self._gather_panel(p, slot, unpack)
+        if cuda:
+            done = torch.cuda.Event()
+            done.record(self._side)
+            main.wait_event(done)
+
+    def _gather_panel(self, p: int, slot: torch.Tensor, unpack: bool) -> None:
+        g = self.world_size
+        dist.all_gather_into_tensor(self._stage[p].view(g * self.h, self.n_local), slot, group=self.group)
+        if unpack:  # [G, h, N/G] -> rows [h, G * N/G] of the row-major result
+            rows = self._c[p * self.h : (p + 1) * self.h]
+            rows.view(self.h, g, self.n_local).copy_(self._stage[p].permute(1, 0, 2))
 
     def gathered_blocks(self, a, b_shard, scale_a, scale_b_shard, bias_shard=None) -> torch.Tensor:
-        """[G, M, N/G]: block g holds columns [g*N/G, (g+1)*N/G) of C."""
-        c_loc = self.local_gemm(a, b_shard, scale_a, scale_b_shard, bias_shard)
+        """[panels, G, M/panels, N/G]: [p, g] holds rows of panel p, columns [g*N/G, (g+1)*N/G) of C -- the layout the
+        all-gather produces, with no copy at all (for column-parallel consumers)."""
         if self.world_size == 1:
-            self._blocks[0].copy_(c_loc)
-        else:
-            dist.all_gather_into_tensor(self._blocks.view(-1, self.hi - self.lo), c_loc.contiguous(), group=self.group)
-        return self._blocks
+            c = self.local_gemm(a, b_shard, scale_a, scale_b_shard, bias_shard)
+            return c.view(self.panels, self.h, 1, self.n_local).permute(0, 2, 1, 3)
+        self._run(a, b_shard, scale_a, scale_b_shard, bias_shard, unpack=False)
+        return self._stage
 
     def __call__(self, a, b_shard, scale_a, scale_b_shard, bias_shard=None) -> torch.Tensor:
         """Row-major [M, N] C, identical on every rank."""
-        blocks = self.gathered_blocks(a, b_shard, scale_a, scale_b_shard, bias_shard)
-        return blocks.permute(1, 0, 2).reshape(self.m, self.n)
+        self._run(a, b_shard, scale_a, scale_b_shard, bias_shard, unpack=True)
+        return self._c

@@ -101,13 +101,22 @@ def _scaled_gemm_call(
     bias: torch.Tensor | None,
     extra: tuple = (),
     n_out: int | None = None,
+    lib=None,
 ) -> int:
-    """`n_out`: columns of `output` when they are not metadata.n_dim (the fused gate/up form passes N / 2)."""
+    """`n_out`: columns of `output` when they are not metadata.n_dim (the fused gate/up form passes N / 2); `lib`: a
+    library handle other than the default one (bench.py times the diagnostic twin through the same marshalling)."""
     _C.require_device(output, a, b, scale_a, scale_b, bias)
     if a.dtype != b.dtype:
         raise ValueError(f"a and b must share a dtype (a: {a.dtype}, b: {b.dtype})")
     if output.dtype != metadata.output_dtype:
         raise ValueError(f"output dtype {output.dtype} != metadata.output_dtype {metadata.output_dtype}")
+    # the launcher trusts `metadata` for M, N, K (as the reference's does): a mismatch with the tensors would be an
+    # out-of-bounds access on the device, so it is checked here
+    if tuple(a.shape) != (metadata.m_dim, metadata.k_dim) or tuple(b.shape) != (metadata.k_dim, metadata.n_dim):
+        raise ValueError(f"a {tuple(a.shape)} / b {tuple(b.shape)} do not match metadata (M, K, N) = "
+                         f"({metadata.m_dim}, {metadata.k_dim}, {metadata.n_dim})")
+    if tuple(output.shape) != (metadata.m_dim, metadata.n_dim if n_out is None else n_out):
+        raise ValueError(f"output shape {tuple(output.shape)} does not match metadata")
     sa = _as_fp32_vector(scale_a, "scale_a")
     sb = _as_fp32_vector(scale_b, "scale_b")
     if bias is not None:
@@ -116,30 +125,15 @@ def _scaled_gemm_call(
         bias = bias.reshape(-1).contiguous()
         if bias.numel() != metadata.n_dim:
             raise ValueError(f"bias has {bias.numel()} elements, want N={metadata.n_dim}")
-    fn = getattr(_C.load(), fn_name)
-    return fn(
-        _C.ptr(output),
-        _C.ptr(a),
-        _C.ptr(b),
-        _C.ptr(sa),
-        _C.ptr(sb),
-        _C.ptr(bias),
-        metadata.m_dim,
-        metadata.n_dim if n_out is None else n_out,
-        metadata.k_dim,
-        a.stride(0),
-        a.stride(1),
-        b.stride(0),
-        b.stride(1),
-        output.stride(0),
-        output.stride(1),
-        sa.numel(),
-        sb.numel(),
-        _C.dtype_id(a.dtype),
-        _C.dtype_id(output.dtype),
-        _C.current_stream_handle(a.device),
-        *extra,
+    args = (
+        _C.ptr(output), _C.ptr(a), _C.ptr(b), _C.ptr(sa), _C.ptr(sb), _C.ptr(bias),
+        metadata.m_dim, metadata.n_dim if n_out is None else n_out, metadata.k_dim,
+        a.stride(0), a.stride(1), b.stride(0), b.stride(1), output.stride(0), output.stride(1),
+        sa.numel(), sb.numel(), _C.dtype_id(a.dtype), _C.dtype_id(output.dtype),
+        _C.current_stream_handle(a.device), *extra,
     )
+    with _C.on_device_of(output, a, b, sa, sb, bias):
+        return getattr(lib or _C.load(), fn_name)(*args)
 
 
 def scaled_gemm_launcher(
@@ -197,6 +191,7 @@ def _mixed_gemm_call(
     metadata: MixedPrecisionMatmulMetadata,
     extra: tuple = (),
     n_out: int | None = None,
+    lib=None,
 ) -> int:
     """`n_out`: columns of `output` when they are not metadata.n_dim (the fused gate/up form passes N / 2)."""
     _C.require_device(output, x, w_q_packed, scales, zeros)
@@ -214,40 +209,33 @@ def _mixed_gemm_call(
         w_q_packed = w_q_packed.contiguous()
     if scales.stride(-1) != 1:
         scales = scales.contiguous()
+    if tuple(x.shape) != (metadata.m_dim, metadata.k_dim) or w_q_packed.shape[0] * metadata.elements_per_sample != metadata.k_dim \
+            or w_q_packed.shape[1] != metadata.n_dim:
+        raise ValueError(f"x {tuple(x.shape)} / w_q_packed {tuple(w_q_packed.shape)} do not match metadata (M, K, N) = "
+                         f"({metadata.m_dim}, {metadata.k_dim}, {metadata.n_dim})")
+    if tuple(output.shape) != (metadata.m_dim, metadata.n_dim if n_out is None else n_out):
+        raise ValueError(f"output shape {tuple(output.shape)} does not match metadata")
     if zeros is None or metadata.weight_group_mode == WeightGroupMode.SYMMETRIC_NO_SHIFT:
         zp_mode, zeros_t, zp_stride = _C.ZP_NONE, None, 0
     else:
+        if zeros.dtype.is_floating_point or zeros.dtype == torch.bool:
+            raise ValueError(f"zero points must be integers (got {zeros.dtype}): they are subtracted before the scale")
         if zeros.dtype != torch.int32:
-            zeros = zeros.to(torch.int32)
+            zeros = zeros.to(torch.int32)  # exact: every integer dtype torch has fits the packed weights' range
         if metadata.zero_is_scalar:
             zp_mode, zeros_t, zp_stride = _C.ZP_SCALAR, zeros.reshape(-1), 0
         else:
             zeros_t = zeros if zeros.stride(-1) == 1 else zeros.contiguous()
             zp_mode, zp_stride = _C.ZP_TENSOR, zeros_t.stride(0)
-    fn = getattr(_C.load(), fn_name)
-    return fn(
-        _C.ptr(output),
-        _C.ptr(x),
-        _C.ptr(w_q_packed),
-        _C.ptr(scales),
-        _C.ptr(zeros_t),
-        metadata.m_dim,
-        metadata.n_dim if n_out is None else n_out,
-        metadata.k_dim,
-        x.stride(0),
-        w_q_packed.stride(0),
-        scales.stride(0) if scales.dim() == 2 else metadata.n_dim,
-        zp_stride,
-        output.stride(0),
-        metadata.weight_size_bits,
-        metadata.weight_bias,
-        metadata.group_size,
-        zp_mode,
-        _C.dtype_id(x.dtype),
-        _C.dtype_id(output.dtype),
-        _C.current_stream_handle(x.device),
-        *extra,
+    args = (
+        _C.ptr(output), _C.ptr(x), _C.ptr(w_q_packed), _C.ptr(scales), _C.ptr(zeros_t),
+        metadata.m_dim, metadata.n_dim if n_out is None else n_out, metadata.k_dim,
+        x.stride(0), w_q_packed.stride(0), scales.stride(0) if scales.dim() == 2 else metadata.n_dim, zp_stride,
+        output.stride(0), metadata.weight_size_bits, metadata.weight_bias, metadata.group_size, zp_mode,
+        _C.dtype_id(x.dtype), _C.dtype_id(output.dtype), _C.current_stream_handle(x.device), *extra,
     )
+    with _C.on_device_of(output, x, w_q_packed, scales, zeros_t):
+        return getattr(lib or _C.load(), fn_name)(*args)
 
 
 def mixed_precision_gemm_launcher(

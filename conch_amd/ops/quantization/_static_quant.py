@@ -23,16 +23,23 @@ def quantize_into(out: torch.Tensor, x: torch.Tensor, scale: torch.Tensor, launc
     launcher(out, x, scale)
 
 
-def quantize_new(x: torch.Tensor, scale: torch.Tensor | None, out_dtype: torch.dtype, launcher: Launcher,
-                 allowed_out_dtypes: tuple[torch.dtype, ...], dynamic_message: str) -> tuple[torch.Tensor, torch.Tensor]:
-    """`scaled_*_quant`: allocate, quantise, hand back (result, the SAME scale object).
+DynamicLauncher = Callable[[torch.Tensor, torch.Tensor, torch.Tensor], None]
 
-    `scale=None` would mean dynamic per-token quantisation, which the reference does not implement
-    either (int8.py:42-44, fp8.py:46-48): same NotImplementedError.  The output is not zero-filled first
-    (the reference uses zeros_like): the kernel writes every element.
+
+def quantize_new(x: torch.Tensor, scale: torch.Tensor | None, out_dtype: torch.dtype, launcher: Launcher,
+                 allowed_out_dtypes: tuple[torch.dtype, ...], dynamic_launcher: DynamicLauncher) -> tuple[torch.Tensor, torch.Tensor]:
+    """`scaled_*_quant`: allocate, quantise, hand back (result, scale).
+
+    Static (`scale` given): returns the SAME scale object, like the reference (int8.py:48, fp8.py:58).  The output is not
+    zero-filled first (the reference uses zeros_like): the kernel writes every element.
+    Dynamic (`scale=None`; the reference raises NotImplementedError, int8.py:42-44, fp8.py:46-48): one scale per token,
+    scale[t] = absmax(x[t]) / QMAX, returned with shape x.shape[:-1] + (1,) -- for a 2-D input exactly the (M, 1) fp32
+    `scale_a` of `scaled_gemm`.
     """
-    if scale is None:
-        raise NotImplementedError(dynamic_message)
     out = torch.empty_like(x, dtype=out_dtype)
+    if scale is None:
+        scales = torch.empty((*x.shape[:-1], 1), dtype=torch.float32, device=x.device)
+        dynamic_launcher(out, scales, x)
+        return out, scales
     quantize_into(out, x, scale, launcher, allowed_out_dtypes)
     return out, scale

@@ -8,7 +8,7 @@ optional `output_dtype` to request float8_e4m3fnuz explicitly.
 
 import torch
 
-from conch_amd.kernels.quantization.fp8 import static_scaled_fp8_quant_launcher
+from conch_amd.kernels.quantization.fp8 import dynamic_scaled_fp8_quant_launcher, static_scaled_fp8_quant_launcher
 from conch_amd.ops.quantization._static_quant import quantize_into, quantize_new
 from conch_amd.platforms import current_platform
 
@@ -22,7 +22,11 @@ def static_scaled_fp8_quant(output_tensor: torch.Tensor, input_tensor: torch.Ten
 
 def scaled_fp8_quant(input_tensor: torch.Tensor, scale: torch.Tensor | None = None,
                      output_dtype: torch.dtype | None = None) -> tuple[torch.Tensor, torch.Tensor]:
-    """Quantize to fp8 e4m3 with a static scale; returns (fp8 tensor, scale).  Dynamic (scale=None) is not implemented."""
+    """Quantize to fp8 e4m3; returns (fp8 tensor, scale).
+
+    `scale` given: static per-tensor quantisation (the reference's only mode).  `scale=None`: dynamic per-token
+    quantisation, scale[t] = absmax(x[t]) / finfo(dtype).max (the reference raises NotImplementedError here).
+    """
     dtype = output_dtype if output_dtype is not None else current_platform.fp8_dtype()
     return quantize_new(input_tensor, scale, dtype, static_scaled_fp8_quant_launcher, _OUT,
-                        "Dynamic quantization not implemented yet")
+                        dynamic_scaled_fp8_quant_launcher)

@@ -2,7 +2,7 @@
 
 import torch
 
-from conch_amd.kernels.quantization.int8 import static_scaled_int8_quant_launcher
+from conch_amd.kernels.quantization.int8 import dynamic_scaled_int8_quant_launcher, static_scaled_int8_quant_launcher
 from conch_amd.ops.quantization._static_quant import quantize_into, quantize_new
 
 _OUT = (torch.int8,)
@@ -18,6 +18,10 @@ def static_scaled_int8_quant(output_tensor: torch.Tensor, input_tensor: torch.Te
 
 
 def scaled_int8_quant(input_tensor: torch.Tensor, scale: torch.Tensor | None = None) -> tuple[torch.Tensor, torch.Tensor]:
-    """Quantize to int8 with a static scale; returns (int8 tensor, scale).  Dynamic (scale=None) is not implemented."""
+    """Quantize to int8; returns (int8 tensor, scale).
+
+    `scale` given: static per-tensor quantisation (the reference's only mode).  `scale=None`: dynamic per-token
+    quantisation, scale[t] = absmax(x[t]) / 127 (the reference raises NotImplementedError here).
+    """
     return quantize_new(input_tensor, scale, torch.int8, static_scaled_int8_quant_launcher, _OUT,
-                        "Dynamic int8 quantization not yet implemented")
+                        dynamic_scaled_int8_quant_launcher)

@@ -11,7 +11,19 @@
  * conch/ops/quantization/gemm.py:249-250, which is fused here).  Plain pointers and sizes only:
  * no torch types, no exceptions.  All pointers are DEVICE pointers unless stated; every call is
  * asynchronous on `stream` (a hipStream_t passed as void*; NULL = the default stream) and
- * re-entrant.  Launchers never allocate (docs/conch/structure.md:14-15 of the reference).
+ * re-entrant.  Launchers never allocate USER-VISIBLE memory (docs/conch/structure.md:14-15 of the reference).
+ *
+ * Library scratch.  Some paths need device scratch the caller does not see: the split-K slabs of the skinny-M kernels
+ * (M <= 256 scaled, M <= 64 mixed), K-contiguous copies of operands in non-native layouts, the bf16 expansion of
+ * e4m3fnuz operands, the [M][2d] intermediate of an FFN pair that cannot use the fused epilogue.  It is owned by the
+ * library, one buffer per (device, stream, slot), allocated with hipMalloc the first time a call needs more than the
+ * slot holds and never freed or moved afterwards (enqueued and graph-captured launches keep using the old buffer).
+ * Consequences: (1) a call that must grow a slot does a hipMalloc -- no stream or device synchronisation -- and so is
+ * NOT legal inside hipStreamBeginCapture; it fails with CONCH_ERR_INVALID_ARGUMENT there instead of breaking the
+ * capture; (2) after conch_reserve_scratch(stream, bytes) with bytes >= conch_*_workspace_bytes() of every shape that
+ * will be used, every entry point is allocation-free, synchronisation-free and graph-capture safe on that stream.
+ * The tiled MFMA kernels on native layouts (K-contiguous A and B^T, K % 128 == 0, M > 256) never use scratch.
+ * The device a call runs on is the CURRENT device (hipSetDevice), which must be the one the pointers live on.
  *
  * Return value: CONCH_OK (0) or a conch_status_t error; conch_last_error() returns a
  * thread-local, human-readable description of the last failure on the calling thread.
@@ -73,6 +85,13 @@ typedef enum conch_tuning_key {
   CONCH_TUNE_MIXED_TILE_NT = 1 /* mixed_precision_gemm tile width in 64-column units: 0 = auto, 2..4 = force */
   ,
   CONCH_TUNE_SKINNY_NO_SPLITK = 2 /* 1 = keep the skinny-M scaled GEMM's K split inside the workgroup */
+  ,
+  CONCH_TUNE_SKINNY_MODE = 3 /* split-K skinny-M scaled GEMM: 0 = auto, 1 = two launches (partial sums, then a reduce
+                                kernel), 2 = ONE launch (the last-arriving slice of a tile reduces it), 1024-byte K slices,
+                                3 = one launch, 2048-byte slices and <= 64-row blocks */
+  ,
+  CONCH_TUNE_TILE_SCHEDULE = 4 /* 256x256-tile scaled GEMM: 0 = auto, 1 = uniform 256-column tiles (round-1 form),
+                                 2 = N-balanced strips (256-column tiles plus one narrower tail tile per strip) */
 } conch_tuning_key_t;
 
 int conch_abi_version(void);
@@ -82,6 +101,13 @@ int conch_get_tuning(int key);
 
 /* Number of gfx950 devices visible (0 if none); does not initialise a HIP context on failure. */
 int conch_device_count(void);
+
+/* Upper bound of the library scratch, per slot, any call with this shape may need (see "Library scratch" above).
+ * For the fused FFN entry points pass n = 2 * n_out. */
+int64_t conch_scaled_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k);
+int64_t conch_mixed_precision_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k);
+/* Grow every scratch slot of (current device, stream) to at least `bytes` now (hipMalloc; not inside capture). */
+int conch_reserve_scratch(void* stream, int64_t bytes);
 
 /*
  * static_scaled_int8_quant  (replaces kernels/quantization/int8.py:63-97;
@@ -103,6 +129,20 @@ int conch_static_scaled_int8_quant(int8_t* out, const void* x, const float* scal
 int conch_static_scaled_fp8_quant(uint8_t* out, const void* x, const float* scale, int64_t tokens,
                                   int64_t hidden, int64_t x_row_stride, int64_t out_row_stride,
                                   int x_dtype, int fp8_dtype, void* stream);
+
+/*
+ * Dynamic per-token quantisation.  The reference's wrappers stop at
+ * `scale is None -> NotImplementedError` (conch/ops/quantization/int8.py:41-44, fp8.py:46-48); these entry points are
+ * what a launcher behind that branch would bind.  Per token row t:
+ *   scale_out[t] = max_h |x[t][h]| / QMAX  (fp32; QMAX = 127 | 448 e4m3fn | 240 e4m3fnuz; 1.0 for an all-zero row)
+ *   out[t][h]    = the static op above applied with scale_out[t]
+ * scale_out: fp32 [tokens], contiguous -- viewed as (tokens, 1) it is the per-row scale_a of conch_scaled_gemm.
+ */
+int conch_dynamic_scaled_int8_quant(int8_t* out, float* scale_out, const void* x, int64_t tokens, int64_t hidden,
+                                    int64_t x_row_stride, int64_t out_row_stride, int x_dtype, void* stream);
+int conch_dynamic_scaled_fp8_quant(uint8_t* out, float* scale_out, const void* x, int64_t tokens, int64_t hidden,
+                                   int64_t x_row_stride, int64_t out_row_stride, int x_dtype, int fp8_dtype,
+                                   void* stream);
 
 /*
  * scaled_gemm  (replaces kernels/quantization/gemm.py:564-627 + ops/quantization/gemm.py:249-250;

@@ -19,6 +19,9 @@ from oracle.reference import (  # noqa: F401
     FP8_E4M3FNUZ,
     decode_fp8,
     dequantize_packed,
+    dynamic_quant_scale_ref,
+    dynamic_scaled_fp8_quant_ref,
+    dynamic_scaled_int8_quant_ref,
     encode_fp8,
     mixed_precision_gemm_ref,
     mixed_precision_gemm_silu_and_mul_ref,

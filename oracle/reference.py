@@ -109,6 +109,35 @@ def scaled_fp8_quant_ref(x: torch.Tensor, scale: torch.Tensor, flavour: str = FP
     return scaled.to(qdtype)
 
 
+def dynamic_quant_scale_ref(x: torch.Tensor, qmax: float) -> torch.Tensor:
+    """Per-token scale of the dynamic feeders: absmax over the last dim, in fp32, divided by the
+    largest quantised magnitude; 1.0 for an all-zero row (so that the row quantises to zeros instead of NaN).
+
+    The reference has no dynamic path (conch/ops/quantization/int8.py:41-44, fp8.py:46-48 raise); THIS definition is
+    the build's own.  The shape (..., 1) fp32 is what scaled_gemm takes as a per-row `scale_a`
+    (conch/ops/quantization/gemm.py:199-206)."""
+    absmax = x.to(torch.float32).abs().amax(dim=-1, keepdim=True)
+    return torch.where(absmax > 0, absmax / qmax, torch.ones_like(absmax))
+
+
+def dynamic_scaled_int8_quant_ref(x: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    """scale[t] = absmax[t] / 127, then the STATIC op's arithmetic row by row (conch/reference/quantization/int8.py:12-18:
+    `(x * scale.reciprocal()).clamp(-128, 127).to(int8)`, fp32 product because the scale is a non-0-dim fp32 tensor)."""
+    scale = dynamic_quant_scale_ref(x, 127.0)
+    lim = torch.iinfo(torch.int8)
+    q = (x * scale.reciprocal()).clamp(min=lim.min, max=lim.max).to(torch.int8)
+    return q, scale
+
+
+def dynamic_scaled_fp8_quant_ref(x: torch.Tensor, flavour: str = FP8_E4M3FN) -> tuple[torch.Tensor, torch.Tensor]:
+    """scale[t] = absmax[t] / finfo.max, then conch/reference/quantization/fp8.py:12-18 row by row."""
+    qdtype = _TORCH_FP8[flavour]
+    info = torch.finfo(qdtype)
+    scale = dynamic_quant_scale_ref(x, _FP8_MAX[flavour])
+    q = (x.to(torch.float32) * scale.reciprocal()).clamp(min=info.min, max=info.max).to(qdtype)
+    return q, scale
+
+
 # --------------------------------------------------------------------------------------
 # scaled_gemm
 # --------------------------------------------------------------------------------------

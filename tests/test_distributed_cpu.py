@@ -40,16 +40,26 @@ def _worker(rank: int, world: int, port: int, in_dtype_name: str) -> None:
         sa, sb = 0.25 * torch.rand(m, 1), 0.25 * torch.rand(n, 1)
         bias = torch.rand(n, dtype=torch.bfloat16)
         full = oracle.scaled_gemm_ref(a, b, sa, sb, torch.bfloat16, bias)
-        op = NShardedScaledGemm(m, n, torch.bfloat16, torch.device("cpu"), gemm_fn=oracle.scaled_gemm_ref)
         lo, hi = shard_bounds(n, world, rank)
-        assert (op.lo, op.hi) == (lo, hi)
-        got = op(a, b[:, lo:hi], sa, sb[lo:hi], bias[lo:hi])
-        assert got.shape == (m, n)
-        assert torch.equal(got.view(torch.int16), full.view(torch.int16)), f"rank {rank}: gathered C differs"
-        blocks = op.gathered_blocks(a, b[:, lo:hi], sa, sb[lo:hi], bias[lo:hi])
-        for g in range(world):
-            glo, ghi = shard_bounds(n, world, g)
-            assert torch.equal(blocks[g].view(torch.int16), full[:, glo:ghi].contiguous().view(torch.int16))
+        for panels in (1, 3):  # one gather, and three row panels of 16 (gather of panel p behind the GEMM of panel p+1)
+            op = NShardedScaledGemm(m, n, torch.bfloat16, torch.device("cpu"), gemm_fn=oracle.scaled_gemm_ref, panels=panels)
+            assert (op.lo, op.hi) == (lo, hi)
+            for _ in range(2):  # buffers are reused across calls
+                got = op(a, b[:, lo:hi], sa, sb[lo:hi], bias[lo:hi])
+                assert got.shape == (m, n)
+                assert torch.equal(got.view(torch.int16), full.view(torch.int16)), f"rank {rank}: gathered C differs"
+            blocks = op.gathered_blocks(a, b[:, lo:hi], sa, sb[lo:hi], bias[lo:hi])
+            assert blocks.shape == (panels, world, m // panels, n // world)
+            for p in range(panels):
+                rows = slice(p * (m // panels), (p + 1) * (m // panels))
+                for g in range(world):
+                    glo, ghi = shard_bounds(n, world, g)
+                    assert torch.equal(blocks[p, g].view(torch.int16), full[rows, glo:ghi].contiguous().view(torch.int16))
+        # scalar scale_a is not sliced per panel
+        op = NShardedScaledGemm(m, n, torch.bfloat16, torch.device("cpu"), gemm_fn=oracle.scaled_gemm_ref, panels=2)
+        s1 = torch.tensor([[0.5]])
+        want = oracle.scaled_gemm_ref(a, b, s1, sb, torch.bfloat16, None)
+        assert torch.equal(op(a, b[:, lo:hi], s1, sb[lo:hi]).view(torch.int16), want.view(torch.int16))
     finally:
         dist.destroy_process_group()
 
@@ -64,3 +74,23 @@ def test_shard_bounds():
     assert shard_bounds(28672, 8, 7) == (25088, 28672)
     with pytest.raises(ValueError):
         shard_bounds(100, 8, 0)
+
+
+def test_world1_writes_row_major_result_directly():
+    """No process group: the local GEMM lands in the row-major buffer, gathered_blocks() is a view of it."""
+    from conch_amd.distributed import default_panels
+
+    torch.manual_seed(0)
+    m, k, n = 32, 64, 48
+    a = torch.randint(-32, 32, (m, k), dtype=torch.int8)
+    b = torch.randint(-32, 32, (n, k), dtype=torch.int8).T
+    sa, sb = 0.25 * torch.rand(m, 1), 0.25 * torch.rand(n, 1)
+    full = oracle.scaled_gemm_ref(a, b, sa, sb, torch.bfloat16, None)
+    op = NShardedScaledGemm(m, n, torch.bfloat16, torch.device("cpu"), gemm_fn=oracle.scaled_gemm_ref, panels=2)
+    got = op(a, b, sa, sb)
+    assert torch.equal(got.view(torch.int16), full.view(torch.int16))
+    blocks = op.gathered_blocks(a, b, sa, sb)
+    assert blocks.shape == (2, 1, 16, 48) and torch.equal(blocks[1, 0].view(torch.int16), full[16:].view(torch.int16))
+    # C5 on 8 GPUs: 32 x 14 tiles per rank -> two panels of 224 tiles; C3 on one GPU: no split
+    assert default_panels(8192, 3584) == 2
+    assert default_panels(256, 3584) == 1

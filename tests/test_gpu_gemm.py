@@ -60,7 +60,11 @@ def make_scaled_inputs(m, k, n, in_dtype, out_dtype, sa_scalar, sb_scalar, use_b
     return a, b, sa, sb, bias
 
 
-def check_scaled(got, ref, in_dtype, out_dtype):
+def check_scaled(got, ref, in_dtype, out_dtype, inputs=None):
+    """int8: bit-exact.  fp8: a global bound and -- when `inputs` = (a, b, sa, sb, bias) is given -- a PER-ELEMENT bound, so
+    that an error confined to rows / columns with tiny scales cannot hide under max|C|:
+        |got - ref| <= 2 eps_out (|ref| + |bias|)  +  |sa_m sb_n| * K 2^-24 * sum_k |a_mk| |b_kn|
+    (two roundings to the output dtype at most one ulp apart each, plus the worst-case fp32 accumulation-order error)."""
     if in_dtype == torch.int8:
         np.testing.assert_array_equal(to_bits(got), to_bits(ref))
         return
@@ -68,6 +72,15 @@ def check_scaled(got, ref, in_dtype, out_dtype):
     tol = 2.0 * EPS[out_dtype] * max(r.abs().max().item(), 1e-6)
     err = (g - r).abs().max().item()
     assert err <= tol, f"max |diff| {err:.4g} > {tol:.4g}"
+    if inputs is not None:
+        a, b, sa, sb, bias = inputs
+        k = a.shape[1]
+        s_abs = a.float().abs() @ b.float().abs()
+        scale = (sa.reshape(-1, 1) if sa.numel() > 1 else sa.reshape(1, 1)).abs() * (sb.reshape(1, -1) if sb.numel() > 1 else sb.reshape(1, 1)).abs()
+        bound = 2.0 * EPS[out_dtype] * (r.abs() + (bias.float().abs().reshape(1, -1) if bias is not None else 0.0)) \
+            + scale * (k * 2.0**-24) * s_abs + 1e-30
+        excess = ((g - r).abs() - bound).max().item()
+        assert excess <= 0, f"per-element bound exceeded by {excess:.4g}"
 
 
 def run_scaled(a, b, sa, sb, out_dtype, bias):
@@ -88,17 +101,103 @@ def test_scaled_gemm_matrix(m, k, n, iname, oname, sa_scalar, sb_scalar, use_bia
     ref = oracle.scaled_gemm_ref(a, b, sa, sb, DT[oname], bias)
     got = run_scaled(a, b, sa, sb, DT[oname], bias)
     assert got.shape == (m, n) and got.dtype == DT[oname]
-    check_scaled(got, ref, IN_T[iname], DT[oname])
+    check_scaled(got, ref, IN_T[iname], DT[oname], (a, b, sa, sb, bias))
 
 
-@pytest.mark.parametrize("iname", list(IN_T))
-@pytest.mark.parametrize(("oname", "sa_scalar", "sb_scalar", "use_bias"),
-                         [("bf16", False, False, True), ("f16", True, False, False), ("bf16", False, True, False)])
+@pytest.mark.parametrize("iname", ["int8", "fn"])
+@pytest.mark.parametrize("oname", ["f16", "bf16"])
+@pytest.mark.parametrize("sa_scalar", [True, False])
+@pytest.mark.parametrize("sb_scalar", [True, False])
+@pytest.mark.parametrize("use_bias", [True, False])
 def test_scaled_gemm_large_shape(iname, oname, sa_scalar, sb_scalar, use_bias):
+    """The reference's third shape (4096, 2048, 4096), all 16 scale / bias / dtype combinations (tests/scaled_gemm_test.py:31-50)."""
     m, k, n = SHAPES[2]
     a, b, sa, sb, bias = make_scaled_inputs(m, k, n, IN_T[iname], DT[oname], sa_scalar, sb_scalar, use_bias)
     ref = oracle.scaled_gemm_ref(a, b, sa, sb, DT[oname], bias)
-    check_scaled(run_scaled(a, b, sa, sb, DT[oname], bias), ref, IN_T[iname], DT[oname])
+    check_scaled(run_scaled(a, b, sa, sb, DT[oname], bias), ref, IN_T[iname], DT[oname], (a, b, sa, sb, bias))
+
+
+@pytest.mark.parametrize(("oname", "sa_scalar", "sb_scalar", "use_bias"),
+                         [("bf16", False, False, True), ("f16", True, False, False), ("bf16", False, True, False)])
+def test_scaled_gemm_large_shape_fnuz(oname, sa_scalar, sb_scalar, use_bias):
+    m, k, n = SHAPES[2]
+    a, b, sa, sb, bias = make_scaled_inputs(m, k, n, IN_T["fnuz"], DT[oname], sa_scalar, sb_scalar, use_bias)
+    ref = oracle.scaled_gemm_ref(a, b, sa, sb, DT[oname], bias)
+    check_scaled(run_scaled(a, b, sa, sb, DT[oname], bias), ref, IN_T["fnuz"], DT[oname], (a, b, sa, sb, bias))
+
+
+def test_scaled_gemm_small_scale_rows_and_columns():
+    """Rows / columns whose scales are 1e-6 of the rest: a kernel that is wrong only there passes any max|C| bound."""
+    m, k, n = 512, 1024, 768
+    a, b, sa, sb, bias = make_scaled_inputs(m, k, n, IN_T["fn"], torch.bfloat16, False, False, False)
+    sa[::7] *= 1e-6
+    sb[::5] *= 1e-6
+    ref = oracle.scaled_gemm_ref(a, b, sa, sb, torch.bfloat16, None)
+    check_scaled(run_scaled(a, b, sa, sb, torch.bfloat16, None), ref, IN_T["fn"], torch.bfloat16, (a, b, sa, sb, None))
+
+
+# ---------------------------------------------------------------------------------------------
+# tile schedules of the 256-row kernel and launch forms of the split-K kernel: the schedule / launch form moves WORK,
+# never the order in which one output element accumulates its K products -> results are bit-identical across them
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture
+def _reset_tuning():
+    yield
+    _C.set_tuning(_C.TUNE_TILE_SCHEDULE, 0)
+    _C.set_tuning(_C.TUNE_SKINNY_MODE, 0)
+
+
+@pytest.mark.parametrize("iname", ["int8", "fn"])
+@pytest.mark.parametrize(("m", "k", "n"), [(4096, 512, 11008), (512, 256, 2000), (300, 384, 1376), (2304, 512, 4672), (256, 256, 3584),
+                                            (1024, 384, 968), (8192, 256, 3584)])
+def test_two_width_tile_schedule_is_bit_identical_and_correct(_reset_tuning, iname, m, k, n):
+    a, b, sa, sb, bias = make_scaled_inputs(m, k, n, IN_T[iname], torch.bfloat16, False, False, True)
+    _C.set_gemm_variant(_C.VARIANT_MFMA_PINGPONG2)
+    _C.set_tuning(_C.TUNE_TILE_SCHEDULE, 1)
+    uniform = run_scaled(a, b, sa, sb, torch.bfloat16, bias)
+    _C.set_tuning(_C.TUNE_TILE_SCHEDULE, 2)
+    balanced = run_scaled(a, b, sa, sb, torch.bfloat16, bias)
+    np.testing.assert_array_equal(to_bits(balanced), to_bits(uniform))
+    ref = oracle.scaled_gemm_ref(a, b, sa, sb, torch.bfloat16, bias)
+    check_scaled(balanced, ref, IN_T[iname], torch.bfloat16, (a, b, sa, sb, bias))
+
+
+@pytest.mark.parametrize("mode", [2, 3])
+@pytest.mark.parametrize("iname", ["int8", "fn"])
+@pytest.mark.parametrize(("m", "k", "n"), [(128, 4096, 4096), (1, 1024, 24), (20, 2048, 4096), (33, 1024, 64), (48, 2048, 520),
+                                            (200, 2048, 520), (256, 8192, 1376), (64, 4096, 11008), (100, 3072, 260)])
+def test_one_launch_splitk_is_bit_identical_to_two_launches(_reset_tuning, mode, iname, m, k, n):
+    a, b, sa, sb, bias = make_scaled_inputs(m, k, n, IN_T[iname], torch.bfloat16, False, False, True)
+    _C.set_gemm_variant(_C.VARIANT_MFMA_SKINNY)
+    _C.set_tuning(_C.TUNE_SKINNY_MODE, 1)
+    two = run_scaled(a, b, sa, sb, torch.bfloat16, bias)
+    _C.set_tuning(_C.TUNE_SKINNY_MODE, mode)
+    for _ in range(3):  # the arrival counters must come back to zero after every launch
+        one = run_scaled(a, b, sa, sb, torch.bfloat16, bias)
+        if iname == "int8" or mode == 2:
+            np.testing.assert_array_equal(to_bits(one), to_bits(two))  # same slices, same order
+    ref = oracle.scaled_gemm_ref(a, b, sa, sb, torch.bfloat16, bias)
+    check_scaled(one, ref, IN_T[iname], torch.bfloat16, (a, b, sa, sb, bias))
+
+
+def test_one_launch_splitk_under_uneven_load(_reset_tuning):
+    """The hand-off must not depend on timing or placement: run it while another stream keeps the chip unevenly busy, many
+    times, against the two-launch result."""
+    a, b, sa, sb, bias = make_scaled_inputs(128, 4096, 4096, torch.int8, torch.bfloat16, False, False, False)
+    _C.set_gemm_variant(_C.VARIANT_MFMA_SKINNY)
+    _C.set_tuning(_C.TUNE_SKINNY_MODE, 1)
+    want = to_bits(run_scaled(a, b, sa, sb, torch.bfloat16, bias))
+    _C.set_tuning(_C.TUNE_SKINNY_MODE, 2)
+    ad, bd, sad, sbd = a.cuda(), b.T.contiguous().cuda().T, sa.cuda(), sb.cuda()
+    noise_a = torch.randn(3000, 3000, device="cuda")
+    side = torch.cuda.Stream()
+    for i in range(40):
+        with torch.cuda.stream(side):
+            for _ in range(1 + i % 3):
+                noise_a @ noise_a
+        got = scaled_gemm(ad, bd, sad, sbd, torch.bfloat16)
+        np.testing.assert_array_equal(to_bits(got), want)
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("variant", ["generic", "simple", "pingpong", "pingpong2", "mid", "skinny"])

@@ -133,3 +133,94 @@ def test_quant_c1_config_bit_exact():
     s = torch.tensor([2.1], dtype=torch.float32, device="cuda")
     q, _ = scaled_int8_quant(x, s)
     assert torch.equal(q.cpu(), oracle.scaled_int8_quant_ref(x.cpu(), s.cpu()))
+
+
+# ---------------------------------------------------------------------------------------------
+# dynamic per-token quantisation: scale=None
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("num_tokens", TOKENS)
+@pytest.mark.parametrize("hidden_size", [16, 67, 768, 1024, 2064, 5137, 8192, 8193, 16400])
+@pytest.mark.parametrize("dtype", DTYPES)
+@torch.inference_mode()
+def test_dynamic_int8_quant(num_tokens, hidden_size, dtype):
+    seed_everything(0)
+    x = ((torch.rand(num_tokens, hidden_size, dtype=torch.float32, device="cuda") - 0.4) * 1000).to(dtype)
+    if num_tokens > 2:
+        x[1] = 0  # an all-zero row quantises to zeros with scale 1
+    q, s = scaled_int8_quant(x)
+    assert q.dtype == torch.int8 and q.shape == x.shape and s.shape == (num_tokens, 1) and s.dtype == torch.float32
+    ref_q, ref_s = oracle.dynamic_scaled_int8_quant_ref(x.cpu())
+    assert torch.equal(s.cpu().view(torch.int32), ref_s.view(torch.int32))
+    assert torch.equal(q.cpu(), ref_q)
+
+
+@pytest.mark.parametrize("flav", list(FP8))
+@pytest.mark.parametrize("num_tokens", [1, 7, 83])
+@pytest.mark.parametrize("hidden_size", [16, 67, 768, 2064, 5137, 8200])
+@pytest.mark.parametrize("dtype", DTYPES)
+@torch.inference_mode()
+def test_dynamic_fp8_quant(flav, num_tokens, hidden_size, dtype):
+    name, tdt = FP8[flav]
+    seed_everything(0)
+    x = ((torch.rand(num_tokens, hidden_size, dtype=torch.float32, device="cuda") - 0.4) * 3).to(dtype)
+    q, s = scaled_fp8_quant(x, None, output_dtype=tdt)
+    ref_q, ref_s = oracle.dynamic_scaled_fp8_quant_ref(x.cpu(), name)
+    assert torch.equal(s.cpu().view(torch.int32), ref_s.view(torch.int32))
+    np.testing.assert_array_equal(to_bits(q), to_bits(ref_q))
+
+
+@pytest.mark.parametrize(("dname", "tokens", "hidden"), [(d, t, h) for d in DT for t, h in ((1, 16), (7, 67), (5, 768), (3, 2064), (2, 8200))])
+def test_dynamic_quant_golden(golden, dname, tokens, hidden):
+    """Rows of the REAL reference's static oracle at scale = absmax / QMAX (tests/golden/make_golden_r2.py)."""
+    g = golden("quant_dynamic")
+    key = f"{dname}_t{tokens}_h{hidden}"
+    x = from_bits(g[f"x_{key}"], DT[dname]).cuda()
+    q, s = scaled_int8_quant(x)
+    np.testing.assert_array_equal(q.cpu().numpy(), g[f"qi8_{key}"])
+    np.testing.assert_array_equal(s.cpu().reshape(-1).numpy().view(np.uint32), g[f"si8_{key}"].view(np.uint32))
+    for flav, (_, tdt) in FP8.items():
+        q8, s8 = scaled_fp8_quant(x, None, output_dtype=tdt)
+        np.testing.assert_array_equal(to_bits(q8), g[f"q{flav}_{key}"])
+        np.testing.assert_array_equal(s8.cpu().reshape(-1).numpy().view(np.uint32), g[f"s{flav}_{key}"].view(np.uint32))
+
+
+def test_dynamic_quant_3d_and_strided_input():
+    x = torch.randn(3, 5, 96, device="cuda", dtype=torch.float16)
+    q, s = scaled_int8_quant(x)
+    assert q.shape == x.shape and s.shape == (3, 5, 1)
+    ref_q, ref_s = oracle.dynamic_scaled_int8_quant_ref(x.cpu())
+    assert torch.equal(q.cpu(), ref_q) and torch.equal(s.cpu(), ref_s)
+    wide = torch.randn(9, 256, device="cuda", dtype=torch.bfloat16)
+    view = wide[:, 32:160]  # row stride 256, 16-byte aligned start: the vector kernel with a row stride
+    q, s = scaled_int8_quant(view)
+    ref_q, ref_s = oracle.dynamic_scaled_int8_quant_ref(view.cpu())
+    assert torch.equal(q.cpu(), ref_q) and torch.equal(s.cpu(), ref_s)
+
+
+@pytest.mark.parametrize("kind", ["int8", "fp8"])
+def test_dynamic_quant_feeds_scaled_gemm(kind):
+    """End to end: activations quantised per token on the device, their (M, 1) scales handed to scaled_gemm as scale_a."""
+    from conch_amd.ops.quantization.gemm import scaled_gemm
+
+    seed_everything(0)
+    m, k, n = 96, 1024, 256
+    x = torch.randn(m, k, device="cuda", dtype=torch.bfloat16)
+    w = torch.randn(n, k, device="cuda", dtype=torch.float32)
+    if kind == "int8":
+        xq, sx = scaled_int8_quant(x)
+        ws = w.abs().amax(dim=1, keepdim=True) / 127
+        wq = (w / ws).round().clamp(-128, 127).to(torch.int8)
+    else:
+        xq, sx = scaled_fp8_quant(x)
+        ws = w.abs().amax(dim=1, keepdim=True) / 448
+        wq = (w / ws).to(torch.float8_e4m3fn)
+    out = scaled_gemm(xq, wq.T, sx, ws, torch.bfloat16)
+    ref = oracle.scaled_gemm_ref(xq.cpu(), wq.cpu().T, sx.cpu(), ws.cpu(), torch.bfloat16)
+    if kind == "int8":
+        assert torch.equal(out.cpu().view(torch.int16), ref.view(torch.int16))
+    else:
+        torch.testing.assert_close(out.cpu().float(), ref.float(), rtol=0, atol=2 * 2.0**-7 * ref.float().abs().max().item())
+    # and the quantised pipeline approximates the unquantised product
+    exact = x.float() @ w.T
+    rel = (out.float() - exact).norm() / exact.norm()
+    assert rel < (0.02 if kind == "int8" else 0.06)

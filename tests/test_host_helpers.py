@@ -117,12 +117,23 @@ def test_ops_refuse_cpu_tensors():
                              torch.ones(1, 8, dtype=torch.float16), None, 4, 8, 128)
 
 
-def test_dynamic_quant_not_implemented():
-    # reference: ops/quantization/int8.py:42-44, fp8.py:46-48
-    with pytest.raises(NotImplementedError):
+def test_dynamic_quant_needs_a_device():
+    # scale=None is dynamic per-token quantisation here (the reference raises NotImplementedError:
+    # ops/quantization/int8.py:42-44, fp8.py:46-48); like every op it refuses host tensors
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
         scaled_int8_quant(torch.rand(2, 2))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
         scaled_fp8_quant(torch.rand(2, 2))
+
+
+def test_workspace_queries_and_reserve_validation():
+    lib = _C.load()
+    # split-K slabs dominate a decode-shaped call, operand copies a prefill-shaped one
+    assert lib.conch_scaled_gemm_workspace_bytes(128, 4096, 4096) >= 4 * 128 * 4096 * 4
+    assert lib.conch_scaled_gemm_workspace_bytes(4096, 11008, 4096) >= 2 * (4096 + 11008) * 4096
+    assert lib.conch_mixed_precision_gemm_workspace_bytes(16, 11008, 4096) >= 4 * 16 * 11008 * 4
+    assert lib.conch_scaled_gemm_workspace_bytes(0, 4, 4) == 0
+    assert lib.conch_reserve_scratch(None, -1) == 1
 
 
 def test_scalar_types():

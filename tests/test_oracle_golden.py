@@ -146,3 +146,22 @@ def test_quantize_pack_dequant_mixed(golden, wname, zp, dname):
     # the FFN pair (mixed GEMM -> the reference's silu_and_mul)
     y = oracle.mixed_precision_gemm_silu_and_mul_ref(a, w_ref)
     np.testing.assert_array_equal(to_bits(y), golden("mixed_gemm_silu")[f"y_{key}"])
+
+
+DYN_CASES = [(d, t, h) for d in DT for t, h in ((1, 16), (7, 67), (5, 768), (3, 2064), (2, 8200))]
+
+
+@pytest.mark.parametrize(("dname", "tokens", "hidden"), DYN_CASES)
+def test_dynamic_quant_rows_equal_reference_static_oracle(golden, dname, tokens, hidden):
+    """SURVEY.md 8(f) N1.  Golden: the REAL reference's static oracle applied row by row with scale = absmax / QMAX
+    (tests/golden/make_golden_r2.py); the oracle's vectorised restatement must reproduce codes AND scales bit for bit."""
+    g = golden("quant_dynamic")
+    key = f"{dname}_t{tokens}_h{hidden}"
+    x = from_bits(g[f"x_{key}"], DT[dname])
+    q, s = oracle.dynamic_scaled_int8_quant_ref(x)
+    np.testing.assert_array_equal(q.numpy(), g[f"qi8_{key}"])
+    np.testing.assert_array_equal(s.reshape(-1).numpy().view(np.uint32), g[f"si8_{key}"].view(np.uint32))
+    for flav, (name, _) in FP8.items():
+        q8, s8 = oracle.dynamic_scaled_fp8_quant_ref(x, name)
+        np.testing.assert_array_equal(to_bits(q8), g[f"q{flav}_{key}"])
+        np.testing.assert_array_equal(s8.reshape(-1).numpy().view(np.uint32), g[f"s{flav}_{key}"].view(np.uint32))

@@ -6,8 +6,12 @@ TAG="$1"; shift
 OUT="$ROOT/gpurun_out/prof_$TAG"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH=("$ROOT/bench.py" --steps 30 --warmup 5 --no-cpu-baseline "$@")
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "${BENCH[@]}" > "$OUT/trace.log" 2>&1
+# kernel-trace pass: the bench's sustained leg (>= 2 s of back-to-back launches) dominates the per-kernel average, so the
+# summary's avg_ns is the steady-state launch duration bench.py reports as kernel_sustained_ms / frac_sustained
+TRACE=("$ROOT/bench.py" --steps 30 --warmup 5 --no-cpu-baseline --no-cold --no-probe "$@")
+# counter passes: few launches (counter collection serialises dispatches)
+BENCH=("$ROOT/bench.py" --steps 30 --warmup 5 --no-cpu-baseline --quick "$@")
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "${TRACE[@]}" > "$OUT/trace.log" 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
   --output-format csv -d "$OUT/pmc_sq" -- python3 "${BENCH[@]}" > "$OUT/pmc_sq.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_fetch" -- python3 "${BENCH[@]}" > "$OUT/pmc_fetch.log" 2>&1
