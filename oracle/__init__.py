@@ -15,19 +15,31 @@ Parity status: PINNED.  Every function here is checked against golden vectors un
 """
 
 from oracle.reference import (  # noqa: F401
+    CHANNEL_ACTIVATION_ONLY,
+    CHANNEL_NONE,
+    CHANNEL_WEIGHT_AND_ACTIVATION,
+    CHANNEL_WEIGHT_ONLY,
+    GROUP_ASYMMETRIC,
+    GROUP_NONE,
+    GROUP_SHIFT,
+    GROUP_SYMMETRIC_NO_SHIFT,
+    GROUP_SYMMETRIC_WITH_SHIFT,
     FP8_E4M3FN,
     FP8_E4M3FNUZ,
     decode_fp8,
+    dequantize_modes_ref,
     dequantize_packed,
     dynamic_quant_scale_ref,
     dynamic_scaled_fp8_quant_ref,
     dynamic_scaled_int8_quant_ref,
     encode_fp8,
+    mixed_precision_gemm_modes_ref,
     mixed_precision_gemm_ref,
     mixed_precision_gemm_silu_and_mul_ref,
     pack_rows_ref,
     quantize_weights_ref,
     scaled_fp8_quant_ref,
+    scaled_gemm_modes_ref,
     scaled_gemm_ref,
     scaled_gemm_silu_and_mul_ref,
     scaled_int8_quant_ref,

@@ -309,6 +309,88 @@ def dequantize_packed(
     return centred * scales
 
 
+# weight-group / channel-scale modes of the reference kernel (conch/kernels/quantization/gemm.py:34-41, :68-74)
+GROUP_NONE, GROUP_SHIFT, GROUP_SYMMETRIC_NO_SHIFT, GROUP_SYMMETRIC_WITH_SHIFT, GROUP_ASYMMETRIC = range(5)
+CHANNEL_NONE, CHANNEL_WEIGHT_ONLY, CHANNEL_ACTIVATION_ONLY, CHANNEL_WEIGHT_AND_ACTIVATION = range(4)
+
+
+def dequantize_modes_ref(
+    packed: torch.Tensor,
+    scales: torch.Tensor | None,
+    zeros: torch.Tensor | None,
+    bits: int,
+    bias: int,
+    group_size: int,
+    group_mode: int,
+    meta_dtype: torch.dtype,
+) -> torch.Tensor:
+    """`_dequantize` for EVERY weight-group mode (conch/kernels/quantization/gemm.py:176-216), each operation carried out
+    in `meta_dtype` exactly as the kernel does (torch's fp16 / bf16 elementwise ops are correctly rounded, like the GPU's):
+
+      unpack            b = ((w >> shift) & mask).to(meta); b -= weight_bias                          :192-194
+      SHIFT             b -= zeros                                                                     :197-198
+      SYMMETRIC_NO_SHIFT    b = b * scales                                                             :201-202
+      SYMMETRIC_WITH_SHIFT  b = (b - zeros) * scales                                                   :205-210
+      ASYMMETRIC        b = fma(b, scales, zeros)   -- ONE rounding: evaluated in float64, rounded to meta    :213-214
+
+    `zeros`: None | one element | [K/G, N], any dtype, converted to meta on load (:363-371); `scales`: [K/G, N] meta.
+    Returns [K, N] in meta_dtype (the kernel then casts to the activation dtype, which is the same here).
+    """
+    q = torch.from_numpy(unpack_rows_ref(packed.cpu().numpy(), bits))
+    k, n = q.shape
+    b = q.to(meta_dtype) - bias  # both steps in meta arithmetic (:192-194)
+
+    def per_row(t: torch.Tensor) -> torch.Tensor:
+        t = t.to(meta_dtype)
+        return t.reshape(1, 1).expand(k, n) if t.numel() == 1 else t.repeat_interleave(group_size, dim=0)
+
+    if group_mode == GROUP_NONE:
+        return b
+    if group_mode == GROUP_SHIFT:
+        return b - per_row(zeros)
+    if group_mode == GROUP_SYMMETRIC_NO_SHIFT:
+        return b * per_row(scales)
+    if group_mode == GROUP_SYMMETRIC_WITH_SHIFT:
+        return (b - per_row(zeros)) * per_row(scales)
+    if group_mode == GROUP_ASYMMETRIC:
+        return (b.double() * per_row(scales).double() + per_row(zeros).double()).to(meta_dtype)
+    raise ValueError(f"unknown weight group mode {group_mode}")
+
+
+def mixed_precision_gemm_modes_ref(
+    x: torch.Tensor,
+    w: torch.Tensor,
+    channel_scales: torch.Tensor | None,
+    channel_mode: int,
+    out_dtype: torch.dtype,
+) -> torch.Tensor:
+    """x @ w with fp32 accumulation, then the kernel's channel scaling (conch/kernels/quantization/gemm.py:408-416) and the
+    cast (:457).  WEIGHT_ONLY: `acc.to(meta) * scales_b[None, :]` -- the accumulator is ROUNDED to the meta dtype first and
+    the product is rounded again.  (ACTIVATION_ONLY / WEIGHT_AND_ACTIVATION need the activation scales only the scaled
+    launcher passes: scaled_gemm_modes_ref.)"""
+    acc = x.float() @ w.float()
+    if channel_mode == CHANNEL_NONE:
+        return acc.to(out_dtype)
+    if channel_mode == CHANNEL_WEIGHT_ONLY:
+        meta = w.dtype
+        return (acc.to(meta) * channel_scales.reshape(1, -1).to(meta)).to(out_dtype)
+    raise ValueError(f"channel mode {channel_mode} is not reachable through the mixed-precision launcher")
+
+
+def scaled_gemm_modes_ref(a, b, scale_a, scale_b, out_dtype, channel_mode: int) -> torch.Tensor:
+    """The scaled launcher with a hand-set ChannelScaleMode (conch/kernels/quantization/gemm.py:408-440): the accumulator
+    times nothing (NONE), scales_b (WEIGHT_ONLY), scales_a (ACTIVATION_ONLY) or both, in fp32 (meta dtype = scale_a's),
+    then the cast.  WEIGHT_AND_ACTIVATION is scaled_gemm itself, in the PyTorch oracle's order sb * (sa * acc)."""
+    acc = a.float() @ b.float()
+    if channel_mode == CHANNEL_WEIGHT_ONLY:
+        acc = acc * scale_b.reshape(1, -1)
+    elif channel_mode == CHANNEL_ACTIVATION_ONLY:
+        acc = acc * scale_a.reshape(-1, 1)
+    elif channel_mode == CHANNEL_WEIGHT_AND_ACTIVATION:
+        acc = scale_b.reshape(1, -1) * (scale_a.reshape(-1, 1) * acc)
+    return acc.to(out_dtype)
+
+
 def mixed_precision_gemm_ref(a: torch.Tensor, w_ref: torch.Tensor) -> torch.Tensor:
     """The mixed-precision oracle is `torch.matmul(a, w_ref)` in the activation dtype
     (tests/mixed_precision_gemm_test.py:70, benchmarks/mixed_precision_gemm_benchmark.py:210)."""

@@ -89,7 +89,109 @@ def gen_dynamic() -> None:
     np.savez_compressed(OUT / "quant_dynamic.npz", **out)
 
 
-GENERATORS = {"dyn": gen_dynamic}
+def _pack(wq: torch.Tensor, bits: int) -> torch.Tensor:
+    """conch.third_party.vllm.quant_utils.pack_rows for any power-of-two width (it accepts 1/2/4/8 already)."""
+    from conch.third_party.vllm.quant_utils import pack_rows
+
+    return pack_rows(wq, bits, *wq.shape)
+
+
+def gen_modes() -> None:
+    """The reference's OWN Triton kernel (`_gemm_kernel`, conch/kernels/quantization/gemm.py:219-457) run through its
+    launchers on CPU by Triton's interpreter, for the kernel modes conch.ops never selects.
+
+    fp16 only: the interpreter stores bf16 as raw uint16 and has no bf16 constants, so it cannot run the bf16 form.
+    One deviation from the stock interpreter, for ASYMMETRIC only: its `create_fma` evaluates tl.fma as the UNFUSED numpy
+    expression x*y+z (two roundings in fp16), which no GPU lowering of tl.fma does; it is replaced by the fused form
+    (exact in float64, rounded once).  Everything else is the stock interpreter.
+
+    Activations: the K x K identity (the output IS the dequantised weight matrix, so the dequantisation arithmetic is
+    pinned bit for bit) and a random matrix (the accumulation, pinned to fp32-accumulate tolerance by the tests).
+    """
+    import dataclasses
+
+    from triton.runtime import interpreter as tri
+
+    from conch.kernels.quantization.gemm import (
+        ChannelScaleMode,
+        WeightGroupMode,
+        mixed_precision_gemm_launcher,
+        scaled_gemm_launcher,
+    )
+    from conch.ops.quantization.gemm import create_mixed_precision_metadata, create_scaled_metadata
+
+    def fused_fma(self, x, y, z):
+        r = x.data.astype(np.float64) * y.data.astype(np.float64) + z.data.astype(np.float64)
+        return tri.TensorHandle(r.astype(z.data.dtype), z.dtype.scalar)
+
+    tri.InterpreterBuilder.create_fma = fused_fma
+
+    out: dict[str, np.ndarray] = {}
+    dt = torch.float16
+    k, n, group = 128, 64, 64
+    seed_everything(0)
+    x_rand = (2 * torch.rand(32, k) - 1).to(dt)
+    x_eye = torch.eye(k, dtype=dt)
+    out["x_rand"] = bits(x_rand)
+    for nbits, bias in ((2, 2), (4, 8), (4, 0), (8, 128), (8, 0)):
+        seed_everything(nbits * 16 + bias)
+        wq = torch.randint(0, 2**nbits, (k, n), dtype=torch.int32)
+        packed = _pack(wq, nbits)
+        ws = (torch.rand(k // group, n) * 0.37 + 0.01).to(dt)
+        zi = torch.randint(0, 2**nbits, (k // group, n), dtype=torch.int32)
+        zs = torch.tensor([3], dtype=torch.int32)
+        zf = (torch.rand(k // group, n) * 5 - 2.5).to(dt)
+        cs = (torch.rand(1, n) * 1.5 + 0.25).to(dt)  # per-column scale for ChannelScaleMode.WEIGHT_ONLY
+        tag = f"b{nbits}_bias{bias}"
+        out[f"packed_{tag}"] = bits(packed)
+        out[f"ws_{tag}"] = bits(ws)
+        out[f"zi_{tag}"] = bits(zi)
+        out[f"zf_{tag}"] = bits(zf)
+        out[f"cs_{tag}"] = bits(cs)
+        cases = [
+            ("none", WeightGroupMode.NONE, ChannelScaleMode.NONE, ws, None),
+            ("shift", WeightGroupMode.SHIFT, ChannelScaleMode.NONE, ws, zi),
+            ("shift_scalar", WeightGroupMode.SHIFT, ChannelScaleMode.NONE, ws, zs),
+            ("sym", WeightGroupMode.SYMMETRIC_NO_SHIFT, ChannelScaleMode.NONE, ws, None),
+            ("symshift", WeightGroupMode.SYMMETRIC_WITH_SHIFT, ChannelScaleMode.NONE, ws, zi),
+            ("symshift_scalar", WeightGroupMode.SYMMETRIC_WITH_SHIFT, ChannelScaleMode.NONE, ws, zs),
+            ("asym", WeightGroupMode.ASYMMETRIC, ChannelScaleMode.NONE, ws, zf),
+            ("none_wonly", WeightGroupMode.NONE, ChannelScaleMode.WEIGHT_ONLY, cs, None),
+            ("shift_wonly", WeightGroupMode.SHIFT, ChannelScaleMode.WEIGHT_ONLY, cs, zi),
+        ]
+        for name, gmode, cmode, scales, zeros in cases:
+            for xname, x in (("eye", x_eye), ("rand", x_rand)):
+                md = create_mixed_precision_metadata(x, packed, ws, zeros, nbits, bias, group)
+                md = dataclasses.replace(md, weight_group_mode=gmode, channel_scale_mode=cmode,
+                                         zero_is_scalar=zeros is not None and zeros.numel() == 1)
+                c = torch.zeros(x.shape[0], n, dtype=dt)
+                mixed_precision_gemm_launcher(c, x, packed, scales, zeros, md)
+                out[f"c_{tag}_{name}_{xname}"] = bits(c)
+    # scaled launcher: the four channel-scale modes on int8 operands
+    seed_everything(5)
+    m2, k2, n2 = 128, 128, 64
+    a = torch.randint(-32, 32, (m2, k2), dtype=torch.int8)
+    b = torch.randint(-32, 32, (n2, k2), dtype=torch.int8).T
+    sa = 0.25 * torch.rand((m2, 1), dtype=torch.float32)
+    sb = 0.25 * torch.rand((n2, 1), dtype=torch.float32)
+    out["sc_a"], out["sc_bt"], out["sc_sa"], out["sc_sb"] = bits(a), bits(b.T), sa.numpy().copy(), sb.numpy().copy()
+    # fp16 outputs only: the interpreter stores bf16 as raw uint16 and casts into it with a numpy integer astype
+    for odt_name, odt in (("f16", torch.float16),):
+        for cname, cmode in (("none", ChannelScaleMode.NONE), ("wonly", ChannelScaleMode.WEIGHT_ONLY),
+                             ("aonly", ChannelScaleMode.ACTIVATION_ONLY), ("wa", ChannelScaleMode.WEIGHT_AND_ACTIVATION)):
+            md = dataclasses.replace(create_scaled_metadata(a, b, sa, sb, odt), channel_scale_mode=cmode)
+            c = torch.zeros(m2, n2, dtype=odt)
+            # the launcher passes an EMPTY dummy zeros tensor with zero_is_scalar=True (gemm.py:578,:331-332): a GPU reads
+            # a garbage word it never uses, the CPU interpreter dereferences a null pointer -> give the dummy one element
+            real_tensor = torch.tensor
+            with mock.patch("conch.kernels.quantization.gemm.torch.tensor",
+                            side_effect=lambda data, **kw: real_tensor([[0]] if data == [[]] else data, **kw)):
+                scaled_gemm_launcher(c, a, b, sa, sb, md)
+            out[f"sc_c_{odt_name}_{cname}"] = bits(c)
+    np.savez_compressed(OUT / "gemm_modes.npz", **out)
+
+
+GENERATORS = {"dyn": gen_dynamic, "modes": gen_modes}
 
 if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference checkout is only available in the authoring container"

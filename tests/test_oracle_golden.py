@@ -165,3 +165,75 @@ def test_dynamic_quant_rows_equal_reference_static_oracle(golden, dname, tokens,
         q8, s8 = oracle.dynamic_scaled_fp8_quant_ref(x, name)
         np.testing.assert_array_equal(to_bits(q8), g[f"q{flav}_{key}"])
         np.testing.assert_array_equal(s8.reshape(-1).numpy().view(np.uint32), g[f"s{flav}_{key}"].view(np.uint32))
+
+
+# ---------------------------------------------------------------------------------------------
+# kernel modes conch.ops never selects: golden = the reference's OWN Triton kernel under the CPU
+# interpreter (tests/golden/make_golden_r2.py gen_modes), fp16
+# ---------------------------------------------------------------------------------------------
+MODE_TAGS = [(2, 2), (4, 8), (4, 0), (8, 128), (8, 0)]
+MODE_CASES = {
+    "none": (oracle.GROUP_NONE, oracle.CHANNEL_NONE, "ws", None),
+    "shift": (oracle.GROUP_SHIFT, oracle.CHANNEL_NONE, "ws", "zi"),
+    "shift_scalar": (oracle.GROUP_SHIFT, oracle.CHANNEL_NONE, "ws", "scalar"),
+    "sym": (oracle.GROUP_SYMMETRIC_NO_SHIFT, oracle.CHANNEL_NONE, "ws", None),
+    "symshift": (oracle.GROUP_SYMMETRIC_WITH_SHIFT, oracle.CHANNEL_NONE, "ws", "zi"),
+    "symshift_scalar": (oracle.GROUP_SYMMETRIC_WITH_SHIFT, oracle.CHANNEL_NONE, "ws", "scalar"),
+    "asym": (oracle.GROUP_ASYMMETRIC, oracle.CHANNEL_NONE, "ws", "zf"),
+    "none_wonly": (oracle.GROUP_NONE, oracle.CHANNEL_WEIGHT_ONLY, "cs", None),
+    "shift_wonly": (oracle.GROUP_SHIFT, oracle.CHANNEL_WEIGHT_ONLY, "cs", "zi"),
+}
+
+
+def mode_inputs(g, nbits, bias, case):
+    tag = f"b{nbits}_bias{bias}"
+    gmode, cmode, sname, zname = MODE_CASES[case]
+    packed = torch.from_numpy(g[f"packed_{tag}"].copy())
+    ws = from_bits(g[f"ws_{tag}"], torch.float16)
+    cs = from_bits(g[f"cs_{tag}"], torch.float16)
+    zeros = None
+    if zname == "zi":
+        zeros = torch.from_numpy(g[f"zi_{tag}"].copy())
+    elif zname == "zf":
+        zeros = from_bits(g[f"zf_{tag}"], torch.float16)
+    elif zname == "scalar":
+        zeros = torch.tensor([3], dtype=torch.int32)
+    return tag, gmode, cmode, packed, ws, cs, zeros
+
+
+@pytest.mark.parametrize("case", list(MODE_CASES))
+@pytest.mark.parametrize(("nbits", "bias"), MODE_TAGS)
+def test_kernel_modes_match_reference_triton_kernel(golden, nbits, bias, case):
+    g = golden("gemm_modes")
+    tag, gmode, cmode, packed, ws, cs, zeros = mode_inputs(g, nbits, bias, case)
+    w = oracle.dequantize_modes_ref(packed, ws, zeros, nbits, bias, 64, gmode, torch.float16)
+    # identity activations: the kernel's output IS its dequantised weight matrix (times the channel scale) -> bit for bit
+    eye = torch.eye(128, dtype=torch.float16)
+    got = oracle.mixed_precision_gemm_modes_ref(eye, w, cs, cmode, torch.float16)
+    np.testing.assert_array_equal(to_bits(got), g[f"c_{tag}_{case}_eye"])
+    # random activations: fp32 accumulation order of the interpreter's dot vs torch's matmul -> one output ulp
+    x = from_bits(g["x_rand"], torch.float16)
+    got = oracle.mixed_precision_gemm_modes_ref(x, w, cs, cmode, torch.float16).float()
+    want = from_bits(g[f"c_{tag}_{case}_rand"], torch.float16).float()
+    assert (got - want).abs().max().item() <= 2.0**-10 * max(want.abs().max().item(), 1.0)
+
+
+@pytest.mark.parametrize("oname", ["f16"])
+@pytest.mark.parametrize("cname", ["none", "wonly", "aonly", "wa"])
+def test_scaled_channel_modes_match_reference_triton_kernel(golden, oname, cname):
+    g = golden("gemm_modes")
+    a = torch.from_numpy(g["sc_a"].copy())
+    b = torch.from_numpy(g["sc_bt"].copy()).T
+    sa, sb = torch.from_numpy(g["sc_sa"].copy()), torch.from_numpy(g["sc_sb"].copy())
+    cmode = {"none": oracle.CHANNEL_NONE, "wonly": oracle.CHANNEL_WEIGHT_ONLY, "aonly": oracle.CHANNEL_ACTIVATION_ONLY,
+             "wa": oracle.CHANNEL_WEIGHT_AND_ACTIVATION}[cname]
+    got = oracle.scaled_gemm_modes_ref(a, b, sa, sb, DT[oname], cmode)
+    want = from_bits(g[f"sc_c_{oname}_{cname}"], DT[oname])
+    if cname == "wa":
+        # the Triton kernel multiplies (sa * sb) first (gemm.py:440), the PyTorch oracle sb * (sa * acc)
+        # (reference/quantization/scaled_gemm.py:21-22): one output ulp apart on a few elements
+        diff = (got.float() - want.float()).abs()
+        eps = 2.0**-10 if oname == "f16" else 2.0**-7
+        assert (diff <= eps * want.float().abs()).all() and (diff > 0).float().mean().item() < 0.01
+    else:
+        np.testing.assert_array_equal(to_bits(got), to_bits(want))
