@@ -112,13 +112,12 @@ int check_scaled(const ScaledGemmArgs& p) {
     return CONCH_ERR_UNSUPPORTED;
   }
   if (p.m == 0 || p.n == 0) return CONCH_OK;
-  CONCH_CHECK_ARG(p.c && p.scale_a && p.scale_b, "scaled_gemm: NULL pointer (c=%p scale_a=%p scale_b=%p)",
-                  p.c, (const void*)p.scale_a, (const void*)p.scale_b);
+  CONCH_CHECK_ARG(p.c, "scaled_gemm: NULL pointer (c=%p)", p.c);
   CONCH_CHECK_ARG(p.k == 0 || (p.a && p.b), "scaled_gemm: NULL operand (a=%p b=%p)", p.a, p.b);
-  CONCH_CHECK_ARG(p.scale_a_numel == 1 || p.scale_a_numel == p.m,
+  CONCH_CHECK_ARG(!p.scale_a || p.scale_a_numel == 1 || p.scale_a_numel == p.m,
                   "scaled_gemm: scale_a has %lld elements, want 1 or M=%lld", (long long)p.scale_a_numel,
                   (long long)p.m);
-  CONCH_CHECK_ARG(p.scale_b_numel == 1 || p.scale_b_numel == p.n,
+  CONCH_CHECK_ARG(!p.scale_b || p.scale_b_numel == 1 || p.scale_b_numel == p.n,
                   "scaled_gemm: scale_b has %lld elements, want 1 or N=%lld", (long long)p.scale_b_numel,
                   (long long)p.n);
   return CONCH_OK;
@@ -166,9 +165,35 @@ int run_scaled_fast(const ScaledGemmArgs& p, int variant, hipStream_t stream) {
   return launch_scaled_gemm_mfma(p, (variant == 2 || variant == 3) ? variant : 5, stream);
 }
 
-int run_scaled(const ScaledGemmArgs& p, hipStream_t stream) {
+// One fp32 1.0 per device, for "no scale on this side" (NULL scale pointer): every kernel then runs unchanged.
+int unit_scale(const float** out) {
+  static std::mutex mu;
+  static float* ones[64] = {};
+  int dev = 0;
+  CONCH_HIP(hipGetDevice(&dev));
+  CONCH_CHECK_ARG(dev >= 0 && dev < 64, "device id %d out of range", dev);
+  std::lock_guard<std::mutex> lock(mu);
+  if (!ones[dev]) {
+    const float one = 1.0f;
+    float* ptr = nullptr;
+    CONCH_HIP(hipMalloc((void**)&ptr, 256));
+    CONCH_HIP(hipMemcpy(ptr, &one, sizeof(one), hipMemcpyHostToDevice));
+    ones[dev] = ptr;
+  }
+  *out = ones[dev];
+  return CONCH_OK;
+}
+
+int run_scaled(const ScaledGemmArgs& p_in, hipStream_t stream) {
+  ScaledGemmArgs p = p_in;
   if (int rc = check_scaled(p)) return rc;
   if (p.m == 0 || p.n == 0) return CONCH_OK;
+  if (!p.scale_a || !p.scale_b) {  // channel-scale modes NONE / WEIGHT_ONLY / ACTIVATION_ONLY
+    const float* one = nullptr;
+    if (int rc = unit_scale(&one)) return rc;
+    if (!p.scale_a) { p.scale_a = one; p.scale_a_numel = 1; }
+    if (!p.scale_b) { p.scale_b = one; p.scale_b_numel = 1; }
+  }
   const int variant = tuning(CONCH_TUNE_GEMM_VARIANT);
   if (variant != 1 && scaled_gemm_mfma_supported(p)) return run_scaled_fast(p, variant, stream);
   if (variant >= 2 && variant <= 6) {
@@ -272,6 +297,42 @@ int run_mixed(const MixedGemmArgs& p, hipStream_t stream) {
   return launch_mixed_gemm_mfma(p, stream);
 }
 
+int run_mixed_modes(const MixedGemmArgs& p, const void* scales, const void* zeros, int64_t zeros_stride_g, int group_mode, int zeros_kind,
+                    int channel_mode, const void* channel_scales, hipStream_t stream) {
+  CONCH_CHECK_ARG(group_mode >= CONCH_GROUP_NONE && group_mode <= CONCH_GROUP_ASYMMETRIC, "mixed_precision_gemm: bad group mode %d", group_mode);
+  CONCH_CHECK_ARG(zeros_kind >= CONCH_ZEROS_NONE && zeros_kind <= CONCH_ZEROS_TENSOR_FLOAT, "mixed_precision_gemm: bad zeros kind %d", zeros_kind);
+  if (channel_mode != CONCH_CHANNEL_NONE && channel_mode != CONCH_CHANNEL_WEIGHT_ONLY) {
+    set_error("mixed_precision_gemm: channel-scale mode %d needs activation scales, which the mixed-precision launcher never passes", channel_mode);
+    return CONCH_ERR_UNSUPPORTED;
+  }
+  MixedGemmArgs chk = p;
+  chk.w_s = p.w_s ? p.w_s : (const void*)p.w_q;  // NONE / SHIFT carry no group scales: any non-NULL pointer passes the shared checks
+  chk.zp_mode = CONCH_ZP_NONE;
+  if (int rc = check_mixed(chk)) return rc;
+  if (p.m == 0 || p.n == 0) return CONCH_OK;
+  const bool needs_zeros = group_mode == CONCH_GROUP_SHIFT || group_mode == CONCH_GROUP_SYMMETRIC_WITH_SHIFT || group_mode == CONCH_GROUP_ASYMMETRIC;
+  const bool needs_scales = group_mode >= CONCH_GROUP_SYMMETRIC_NO_SHIFT;
+  CONCH_CHECK_ARG(!needs_zeros || (zeros && zeros_kind != CONCH_ZEROS_NONE), "mixed_precision_gemm: group mode %d needs zero points", group_mode);
+  CONCH_CHECK_ARG(!needs_scales || scales, "mixed_precision_gemm: group mode %d needs group scales", group_mode);
+  CONCH_CHECK_ARG(channel_mode == CONCH_CHANNEL_NONE || channel_scales, "mixed_precision_gemm: WEIGHT_ONLY needs channel scales");
+  CONCH_CHECK_ARG(p.bits <= 16, "mixed_precision_gemm: %d-bit weights do not fit a 16-bit activation dtype", p.bits);
+  // the two modes conch.ops produces, on the widths its fused kernels take: the fused path (bit-identical arithmetic)
+  const bool int_zeros = zeros_kind == CONCH_ZEROS_SCALAR_INT32 || zeros_kind == CONCH_ZEROS_TENSOR_INT32;
+  if (channel_mode == CONCH_CHANNEL_NONE && (p.bits == 4 || p.bits == 8) &&
+      (group_mode == CONCH_GROUP_SYMMETRIC_NO_SHIFT || (group_mode == CONCH_GROUP_SYMMETRIC_WITH_SHIFT && int_zeros))) {
+    MixedGemmArgs q = p;
+    q.w_s = scales;
+    q.w_zp = group_mode == CONCH_GROUP_SYMMETRIC_NO_SHIFT ? nullptr : (const int32_t*)zeros;
+    q.wzp_stride_g = zeros_stride_g;
+    q.zp_mode = group_mode == CONCH_GROUP_SYMMETRIC_NO_SHIFT ? CONCH_ZP_NONE
+                : zeros_kind == CONCH_ZEROS_SCALAR_INT32    ? CONCH_ZP_SCALAR
+                                                            : CONCH_ZP_TENSOR;
+    return run_mixed(q, stream);
+  }
+  return launch_mixed_gemm_modes(p, scales, zeros, zeros_stride_g, group_mode, zeros_kind,
+                                 channel_mode == CONCH_CHANNEL_WEIGHT_ONLY ? channel_scales : nullptr, stream);
+}
+
 // mixed_precision_gemm_silu_and_mul: `p` describes the OUTPUT (n columns); Wq / w_s / w_zp have 2n columns [gate | up].
 int run_mixed_silu(const MixedGemmArgs& p, hipStream_t stream) {
   MixedGemmArgs wide = p;
@@ -291,7 +352,7 @@ int run_mixed_silu(const MixedGemmArgs& p, hipStream_t stream) {
     q.fuse_silu = 1;
     return launch_mixed_gemm_skinny(q, stream);
   }
-  if (variant != 1 && variant != 2 && mixed_gemm_mfma_supported(p)) return launch_mixed_gemm_mfma(p, stream);
+  if (variant != 1 && variant != 2 && mixed_gemm_silu_fused_supported(p)) return launch_mixed_gemm_mfma(p, stream);
   void* tmp = nullptr;
   if (int rc = get_scratch(stream, kScratchWide, (size_t)p.m * (size_t)wide.n * 2, &tmp)) return rc;
   wide.c = tmp;
@@ -424,6 +485,16 @@ extern "C" int conch_mixed_precision_gemm(void* c, const void* x, const int32_t*
                         wzp_stride_g, c_stride_m, weight_bits, weight_bias, group_size, zp_mode, x_dtype,
                         out_dtype};
   return run_mixed(p, (hipStream_t)stream);
+}
+
+extern "C" int conch_mixed_precision_gemm_modes(void* c, const void* x, const int32_t* w_q_packed, const void* scales, const void* zeros,
+                                                const void* channel_scales, int64_t m, int64_t n, int64_t k, int64_t x_stride_m,
+                                                int64_t wq_stride_k, int64_t scales_stride_g, int64_t zeros_stride_g,
+                                                int64_t c_stride_m, int weight_bits, int weight_bias, int group_size, int group_mode,
+                                                int zeros_kind, int channel_mode, int x_dtype, int out_dtype, void* stream) {
+  const MixedGemmArgs p{c, x, w_q_packed, scales, nullptr, m, n, k, x_stride_m, wq_stride_k, scales_stride_g, zeros_stride_g,
+                        c_stride_m, weight_bits, weight_bias, group_size, CONCH_ZP_NONE, x_dtype, out_dtype};
+  return run_mixed_modes(p, scales, zeros, zeros_stride_g, group_mode, zeros_kind, channel_mode, channel_scales, (hipStream_t)stream);
 }
 
 extern "C" int conch_mixed_precision_gemm_silu_and_mul(void* c, const void* x, const int32_t* w_q_packed, const void* w_s,

@@ -90,6 +90,10 @@ __device__ __forceinline__ void probe_stamp(unsigned long long* slot) {
   do {                                                                                             \
     if (threadIdx.x == 0 && blockIdx.x < kProbeBlocks) probe_stamp(&(buf)[blockIdx.x * 8 + 2 * (which)]); \
   } while (0)
+#define CONCH_PROBE_AT(buf, which, idx)                                                           \
+  do {                                                                                             \
+    if (threadIdx.x == 0 && (idx) < kProbeBlocks) probe_stamp(&(buf)[(idx) * 8 + 2 * (which)]);    \
+  } while (0)
 #define CONCH_PROBE_READER(fn, buf)                                                                \
   extern "C" int fn(unsigned long long* out, int n_blocks) {                                       \
     if (n_blocks > conch::kProbeBlocks) n_blocks = conch::kProbeBlocks;                            \
@@ -97,6 +101,7 @@ __device__ __forceinline__ void probe_stamp(unsigned long long* slot) {
   }
 #else
 #define CONCH_PROBE(buf, which) do { } while (0)
+#define CONCH_PROBE_AT(buf, which, idx) do { } while (0)
 #endif
 
 // ---------------------------------------------------------------------------------------------

@@ -63,10 +63,15 @@ bool scaled_gemm_skinny_fused_supported(const ScaledGemmArgs& wide);  // silu_an
 int repack_for_mfma(const ScaledGemmArgs& p, ScaledGemmArgs* q, void** scratch, hipStream_t stream);
 int expand_fnuz_to_bf16(const ScaledGemmArgs& p, ScaledGemmArgs* q, hipStream_t stream);
 int launch_scaled_gemm_mfma_bf16(const ScaledGemmArgs& p, hipStream_t stream);
+int launch_scaled_gemm_mfma_16bit(const ScaledGemmArgs& p, hipStream_t stream);  // p.in_dtype = FP16 | BF16, byte units
+// gemm_modes.hip -- weight-group / channel-scale modes beyond the two conch.ops produces (dequantise first, then 16-bit MFMA)
+int launch_mixed_gemm_modes(const MixedGemmArgs& p, const void* scales, const void* zeros, int64_t zeros_stride_g, int group_mode,
+                            int zeros_kind, const void* channel_scales, hipStream_t stream);
 // quant.hip -- elementwise silu(x[:, :n]) * x[:, n:] on a 16-bit [m][2n] matrix (the unfused tail of the FFN pair)
 int launch_silu_and_mul(void* out, const void* x, int64_t m, int64_t n, int64_t x_stride_m, int64_t out_stride_m, int dtype,
                         hipStream_t stream);
 bool mixed_gemm_mfma_supported(const MixedGemmArgs& p);
+bool mixed_gemm_silu_fused_supported(const MixedGemmArgs& p);
 int launch_mixed_gemm_mfma(const MixedGemmArgs& p, hipStream_t stream);
 // gemm_mixed_skinny.hip -- decode batches (M <= 64, K % 1024 == 0): weights straight to MFMA registers, split-K (variant 4)
 bool mixed_gemm_skinny_supported(const MixedGemmArgs& p);

@@ -68,7 +68,9 @@ __global__ __launch_bounds__(256) void mixed_gemm_generic_kernel(MixedGemmArgs p
     const float s = bits16_to_float<X_DT>(((const uint16_t*)p.w_s)[g * p.ws_stride_g + n]);
     // (q exact) * s: the fp32 product is exact, so rounding it to X_DT is the single rounding of
     // the reference's fp16/bf16 multiply (kernels/quantization/gemm.py:201-210).
-    const float w = bits16_to_float<X_DT>(float_to_bits16<X_DT>((float)q * s));
+    // the difference is formed in the meta dtype (:205-210): bf16 rounds |q| > 256 (8-bit weights with a bias and a zero point)
+    const float qd = bits16_to_float<X_DT>(float_to_bits16<X_DT>((float)q));
+    const float w = bits16_to_float<X_DT>(float_to_bits16<X_DT>(qd * s));
     acc = fmaf(bits16_to_float<X_DT>(x[k]), w, acc);
   }
   ((uint16_t*)p.c)[m * p.c_stride_m + n] = float_to_bits16<OUT_DT>(acc);

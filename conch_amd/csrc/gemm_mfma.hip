@@ -23,6 +23,8 @@
 //     across the raw s_barriers.  Variant 5 (default) uses two phases per K step (16 MFMAs per cluster),
 //     variant 3 four (8 MFMAs per cluster, the form described phase by phase below).
 //   * workgroup ids are remapped XCD-aware (8 XCDs, private L2s) on top of a GROUP_M raster.
+#include <algorithm>
+
 #include "common.hpp"
 #include "gemm.hpp"
 #include "mfma_tile.hpp"
@@ -111,7 +113,7 @@ __device__ __forceinline__ EpiPrefetch epilogue_prefetch(const ScaledGemmArgs& p
   const int idx = is_b ? col : min(bm0 + tt, (int)p.m - 1);
   const float* base = is_b ? p.scale_b : p.scale_a;
   const bool vec = (is_b ? p.scale_b_numel : p.scale_a_numel) != 1;
-  e.v0 = base[vec ? idx : 0];
+  e.v0 = base ? base[vec ? idx : 0] : 1.0f;  // NULL scale pointer = 1 (the 16-bit operand path of gemm_modes.hip)
   uint32_t bits = 0;
   if (p.bias) bits = ((const uint16_t*)p.bias)[col];
   e.bias_bits = bits;
@@ -130,11 +132,11 @@ __device__ __forceinline__ void epilogue_park(char* lds, const EpiPrefetch& e) {
 
 template <int MMA, int OUT_DT, int NT = 4>
 __device__ __forceinline__ void epilogue(const typename AccT<MMA>::type (&acc)[8][4], const ScaledGemmArgs& p, const char* lds,
-                                         int bm0, int bn0, int wr, int wc, int lane) {
+                                         int bm0, int bn0, int wr, int wc, int lane, int epi_off = kEpiOff) {
   const int g = lane >> 4, jm = lane & 15;
   const bool vec_store = (p.c_stride_m % 8 == 0) && (((uintptr_t)p.c & 15) == 0);
   const bool has_bias = p.bias != nullptr;
-  const float* lsa = (const float*)(lds + kEpiOff);
+  const float* lsa = (const float*)(lds + epi_off);
   const float* lsb = lsa + 256;
   const float* lbias = lsa + 512;
   if constexpr (NT == 3) {
@@ -207,6 +209,72 @@ __device__ __forceinline__ void epilogue(const typename AccT<MMA>::type (&acc)[8
           for (int e = 0; e < 8; ++e)
             if (n0 + e < p.n) dst[e] = (uint16_t)((uint32_t)pk[e >> 1] >> (16 * (e & 1)));
         }
+      }
+    }
+  }
+}
+
+// Row-major epilogue through LDS (256-column tiles of the ping-pong kernels, whose last barrier guarantees that no wave still
+// reads operand LDS).  The accumulator layout gives a lane 8 consecutive columns of ONE row, so a 16-lane quarter of a direct
+// store instruction touches 16 different 128-byte lines -- measured 4.0-4.2 us per 128 KiB tile and CU, ~16 B/clk, a tenth of
+// the tile's time (profiles/r02/probe_boundary.txt).  Here every wave parks its 128 x 64 sub-tile (already scaled, cast and
+// biased: the same arithmetic, bit for bit) in its own 16 KiB of the dead operand buffers with conflict-free ds_write_b128
+// (16-byte chunk index XOR row & 7), reads it back row-wise with conflict-free ds_read_b128 and stores 8 rows x 128 bytes per
+// instruction: whole lines, two per quarter-wave.  No barrier: a wave only touches its own region.
+template <int MMA, int OUT_DT>
+__device__ __forceinline__ void epilogue_rows(const typename AccT<MMA>::type (&acc)[8][4], const ScaledGemmArgs& p, char* lds,
+                                              int bm0, int bn0, int wr, int wc, int lane, int wave, int epi_off = kEpiOff) {
+  asm volatile("" : "+v"(lane));  // lane-constant addresses are formed HERE, not hoisted above the K loop (and spilled across it)
+  const int g = lane >> 4, jm = lane & 15;
+  const bool vec_store = (p.c_stride_m % 8 == 0) && (((uintptr_t)p.c & 15) == 0);
+  const bool has_bias = p.bias != nullptr;
+  const float* lsa = (const float*)(lds + epi_off);
+  const float* lsb = lsa + 256;
+  const float* lbias = lsa + 512;
+  char* region = lds + wave * 16384;
+#pragma unroll
+  for (int nh = 0; nh < 2; ++nh) {
+    const int nl = wc * 64 + nh * 32 + 8 * g;
+    const f32x4 sb_lo = *(const f32x4*)(lsb + nl), sb_hi = *(const f32x4*)(lsb + nl + 4);
+    const f32x4 bs_lo = *(const f32x4*)(lbias + nl), bs_hi = *(const f32x4*)(lbias + nl + 4);
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+      const int row = mt * 16 + jm;  // row of the wave's sub-tile
+      const float sa = lsa[wr * 128 + row];
+      i32x4 pk;
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2) {
+        const int e = 2 * e2;
+        const f32x2 a2 = {(float)acc[mt][nh * 2 + (e >> 2)][e & 3], (float)acc[mt][nh * 2 + (e >> 2)][(e & 3) + 1]};
+        const f32x2 sb2 = e < 4 ? f32x2{sb_lo[e & 3], sb_lo[(e & 3) + 1]} : f32x2{sb_hi[e & 3], sb_hi[(e & 3) + 1]};
+        f32x2 v = f32x2{sa, sa} * a2;  // scaled_gemm.py:21
+        v = pin_f32x2(sb2 * v);        // :22
+        uint32_t h = pack2_bits16<OUT_DT>(v);  // :23
+        if (has_bias) {                // :24-25
+          const f32x2 b2 = e < 4 ? f32x2{bs_lo[e & 3], bs_lo[(e & 3) + 1]} : f32x2{bs_hi[e & 3], bs_hi[(e & 3) + 1]};
+          h = pack2_bits16<OUT_DT>(pin_f32x2(unpack2_bits16<OUT_DT>(h) + b2));
+        }
+        pk[e2] = (int)h;
+      }
+      *(i32x4*)(region + row * 128 + (((nh * 4 + g) ^ (row & 7)) * 16)) = pk;
+    }
+  }
+  // read back row-wise: instruction i covers rows 8 i .. 8 i + 7, lane = (row 8 i + lane / 8, 16-byte chunk lane & 7)
+  const int rr = lane >> 3, ch = lane & 7;
+  const int n0 = bn0 + wc * 64 + ch * 8;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = i * 8 + rr;
+    const i32x4 v = *(const i32x4*)(region + row * 128 + ((ch ^ rr) * 16));
+    const int m = bm0 + wr * 128 + row;
+    if (m < p.m) {
+      uint16_t* dst = (uint16_t*)p.c + (int64_t)m * p.c_stride_m + n0;
+      if (vec_store && n0 + 8 <= p.n) {
+        *(i32x4*)dst = v;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (n0 + e < p.n) dst[e] = (uint16_t)((uint32_t)v[e >> 1] >> (16 * (e & 1)));
       }
     }
   }
@@ -295,11 +363,16 @@ struct BlockSetup {
   Srcs src;
 };
 
-__device__ __forceinline__ BlockSetup setup_block(const ScaledGemmArgs& p, const TileSchedule* ts = nullptr) {
+// `tid`: the thread id to derive lane constants from.  The persistent kernel passes a value made opaque to the optimiser
+// at every tile boundary: hipcc otherwise hoists the lane-constant parts of this function out of the tile loop and spills
+// them across the K loop, and the reloads' compiler-inserted vmcnt(0) would drain the hand-counted LDS-DMA / store queue.
+__device__ __forceinline__ BlockSetup setup_block(const ScaledGemmArgs& p, const TileSchedule* ts = nullptr, int bid = -1, int tid = -1) {
   BlockSetup s;
   s.narrow = 0;
-  s.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  s.lane = threadIdx.x & 63;
+  if (bid < 0) bid = blockIdx.x;
+  if (tid < 0) tid = threadIdx.x;
+  s.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  s.lane = tid & 63;
   s.wr = s.wave >> 2;
   s.wc = s.wave & 3;
   // fused gate/up form: a tile is 256 rows x 128 OUTPUT columns (128 gate + 128 up columns of B)
@@ -307,12 +380,12 @@ __device__ __forceinline__ BlockSetup setup_block(const ScaledGemmArgs& p, const
   const int tiles_m = ((int)p.m + kTileM - 1) / kTileM;
   const int tiles_n = ((int)p.n + tile_n - 1) / tile_n;
   if (ts) {
-    const TilePlace tp = place_tile(blockIdx.x, *ts);
+    const TilePlace tp = place_tile(bid, *ts);
     s.bm0 = tp.tm * kTileM;
     s.bn0 = tp.n0;
     s.narrow = tp.narrow;
   } else {
-    const TileCoord tc = map_tile(blockIdx.x, tiles_m, tiles_n);
+    const TileCoord tc = map_tile(bid, tiles_m, tiles_n);
     s.bm0 = tc.tm * kTileM;
     s.bn0 = tc.tn * tile_n;
   }
@@ -517,7 +590,7 @@ __device__ __forceinline__ void pp2_step(WaveTile<MMA>& w, char* lds, const Bloc
 
 // K loop + epilogue of one tile; NT = 4 (256 columns) or 3 (192 columns: 24 instead of 32 MFMAs per wave and K step, the same
 // staging stream and waits)
-template <int MMA, int OUT_DT, bool SILU, int NT>
+template <int MMA, int OUT_DT, bool SILU, int NT, bool ROWS = false>
 __device__ __forceinline__ void pp2_tile(const ScaledGemmArgs& p, char* lds, const BlockSetup& s, WaveTile<MMA>& w, int steps) {
   CONCH_PROBE(g_probe_scaled, 0);
   int t = 0;
@@ -528,10 +601,12 @@ __device__ __forceinline__ void pp2_tile(const ScaledGemmArgs& p, char* lds, con
   if (s.wr == 0) __builtin_amdgcn_s_barrier();  // re-balance the barrier count
 
   if constexpr (SILU) epilogue_silu<MMA, OUT_DT>(w.acc, p, lds, s.bm0, s.bn0, s.wr, s.wc, s.lane);
+  else if constexpr (NT == 4 && ROWS) epilogue_rows<MMA, OUT_DT>(w.acc, p, lds, s.bm0, s.bn0, s.wr, s.wc, s.lane, s.wave);
   else epilogue<MMA, OUT_DT, NT>(w.acc, p, lds, s.bm0, s.bn0, s.wr, s.wc, s.lane);
 }
 
-template <int MMA, int OUT_DT, bool SILU>
+// ROWS: the row-major epilogue through LDS (epilogue_rows) instead of the direct accumulator-layout stores
+template <int MMA, int OUT_DT, bool SILU, bool ROWS = false>
 __global__ __launch_bounds__(kThreads, 2) void scaled_gemm_pp2_kernel(ScaledGemmArgs p, TileSchedule ts) {
   __shared__ __attribute__((aligned(1024))) char lds[kLdsTotal];
   CONCH_PROBE(g_probe_scaled, 2);
@@ -559,8 +634,110 @@ __global__ __launch_bounds__(kThreads, 2) void scaled_gemm_pp2_kernel(ScaledGemm
       return;
     }
   }
-  pp2_tile<MMA, OUT_DT, SILU, 4>(p, lds, s, w, steps);
+  pp2_tile<MMA, OUT_DT, SILU, 4, ROWS>(p, lds, s, w, steps);
   CONCH_PROBE(g_probe_scaled, 3);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Persistent form of the two-phase ping-pong kernel: one workgroup per CU walks its tiles (virtual block ids b, b + grid,
+// b + 2 grid ...: the same tile -> XCD map as the plain launch).  What it buys is the tile BOUNDARY (in-kernel stamps,
+// profiles/r02/probe_sched.txt: 4.2 us from the last MFMA to the last store issued -- the CU's store path moves ~16 B/clk --
+// + 0.7 us until the next workgroup enters + 1.9 us from entry to its first MFMA, against a 36.5 us K loop):
+//   * after a tile's last barrier, BEFORE its epilogue, the next tile's first TWO K steps (8 units = the whole LDS ring) and
+//     its scale vectors are put in flight by LDS-DMA; the epilogue's stores are issued behind them.  vmcnt retires in issue
+//     order, so the loads are never queued behind the stores: `vmcnt(16)` after the epilogue = "everything but my 16 stores";
+//   * the next K loop starts at once and runs its first two steps from LDS without waiting for any new load, so the stores
+//     drain under ~2.2 us of MFMAs; from phase B of step 1 on the steady-state counted waits apply unchanged (whatever they
+//     wait for is younger than the stores);
+//   * no launch gap, no first-load latency between tiles.
+// An earlier persistent attempt (round 1) issued the stores first and lost: the first counted wait of the next tile then
+// waited for them.  Contract on top of the tile kernel's: K >= 512 bytes, no bias (its load would need a VGPR destination:
+// hipcc drains the whole queue for those while LDS-DMA is in flight), uniform 256-column tiles.  Edge tiles (ragged M / N or
+// unaligned C rows: a store count that is not 16 per wave) drain fully instead of counting.
+// ---------------------------------------------------------------------------------------------
+constexpr int kEpiBytes = 3 * 1024;
+constexpr int kLdsTotalPersistent = kLdsBytes + 2 * kEpiBytes;  // two sets of parked scales
+
+// scale_a / scale_b of a tile -> LDS by LDS-DMA (4 bytes per lane; waves 0-3: the 256 row scales, waves 4-7: the column scales)
+__device__ __forceinline__ void stage_scales(char* lds, int epi_off, const ScaledGemmArgs& p, int wave, int tid, int bm0, int bn0) {
+  const int tt = tid & 255;
+  char* dst = lds + epi_off + wave * 256;
+  if (wave < 4) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)p.scale_a, 0, (uint32_t)(p.scale_a_numel * 4), 0x00020000);
+    const int idx = p.scale_a_numel != 1 ? min(bm0 + tt, (int)p.m - 1) : 0;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_t*)dst, 4, idx * 4, 0, 0, 0);
+  } else {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)p.scale_b, 0, (uint32_t)(p.scale_b_numel * 4), 0x00020000);
+    const int idx = p.scale_b_numel != 1 ? min(bn0 + tt, (int)p.n - 1) : 0;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_t*)dst, 4, idx * 4, 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ void stage_two_steps(char* lds, const BlockSetup& s) {
+  stage_unit<kU1>(lds, s.src, s.so, s.wave, 0);
+  stage_unit<kV1>(lds, s.src, s.so, s.wave, 0);
+  stage_unit<kV2>(lds, s.src, s.so, s.wave, 0);
+  stage_unit<kU2>(lds, s.src, s.so, s.wave, 0);
+  stage_unit<kU1>(lds, s.src, s.so, s.wave, 1);
+  stage_unit<kV1>(lds, s.src, s.so, s.wave, 1);
+  stage_unit<kV2>(lds, s.src, s.so, s.wave, 1);
+  stage_unit<kU2>(lds, s.src, s.so, s.wave, 1);
+}
+
+template <int MMA, int OUT_DT>
+__global__ __launch_bounds__(kThreads, 2) void scaled_gemm_pp2_persistent_kernel(ScaledGemmArgs p, TileSchedule ts, int total_tiles) {
+  __shared__ __attribute__((aligned(1024))) char lds[kLdsTotalPersistent];
+  const int steps = (int)(p.k / kStepBytes);  // >= 4 (dispatcher)
+  int vb = blockIdx.x;
+  int eb = 0;  // which set of parked scales the CURRENT tile uses
+  BlockSetup s = setup_block(p, &ts, vb);
+  stage_scales(lds, kLdsBytes, p, s.wave, threadIdx.x, s.bm0, s.bn0);
+  stage_two_steps(lds, s);
+  CONCH_VMCNT(0);
+  __builtin_amdgcn_s_barrier();
+  const bool vec_rows = (p.c_stride_m % 8 == 0) && (((uintptr_t)p.c & 15) == 0);
+  WaveTile<MMA> w;
+  for (;;) {
+    zero_acc<MMA>(w);
+    if (s.wr == 1) __builtin_amdgcn_s_barrier();  // stagger the second wave of every SIMD
+    CONCH_PROBE_AT(g_probe_scaled, 0, vb);
+    pp2_step<MMA, 4, 0, 1, -1, -1>(w, lds, s, 0);  // V2 / U2 of step 1 are already in flight or landed
+    pp2_step<MMA, 4, 1, 1, -1, 6>(w, lds, s, 1);
+    int t = 2;
+    for (; t + 2 < steps; ++t) pp2_step<MMA, 4, 1, 1, 8, 6>(w, lds, s, t);
+    pp2_step<MMA, 4, 1, 0, 8, 2>(w, lds, s, t);
+    pp2_step<MMA, 4, 0, 0, 0, -1>(w, lds, s, t + 1);
+    CONCH_PROBE_AT(g_probe_scaled, 1, vb);
+    if (s.wr == 0) __builtin_amdgcn_s_barrier();  // re-balance: every wave is past its last LDS read of this tile
+    CONCH_PROBE_AT(g_probe_scaled, 2, vb);  // (slot 2 = boundary start here, not kernel entry)
+
+    const int bm0 = s.bm0, bn0 = s.bn0;
+    const int next = vb + (int)gridDim.x;
+    const bool more = next < total_tiles;  // workgroup-uniform
+    if (more) {
+      // the next tile's staging offsets live only until its loads are issued (they are recomputed behind the epilogue:
+      // eight more registers across the epilogue would spill, and scratch traffic would break the counted waits)
+      int tid = threadIdx.x;
+      asm volatile("" : "+v"(tid));  // see setup_block
+      const BlockSetup sn = setup_block(p, &ts, next, tid);
+      stage_scales(lds, kLdsBytes + (eb ^ 1) * kEpiBytes, p, sn.wave, tid, sn.bm0, sn.bn0);
+      stage_two_steps(lds, sn);
+      __builtin_amdgcn_sched_barrier(0);  // the loads go out before the first store
+    }
+    epilogue<MMA, OUT_DT, 4>(w.acc, p, lds, bm0, bn0, s.wr, s.wc, s.lane, kLdsBytes + eb * kEpiBytes);
+    CONCH_PROBE_AT(g_probe_scaled, 3, vb);
+    if (!more) return;
+    __builtin_amdgcn_sched_barrier(0);
+    // a full tile with 16-byte stores issues exactly 16 stores per wave; anything else drains
+    if (vec_rows && bm0 + kTileM <= (int)p.m && bn0 + kTileN <= (int)p.n) CONCH_VMCNT(16);
+    else CONCH_VMCNT(0);
+    __builtin_amdgcn_s_barrier();
+    int next_opaque = next, tid2 = threadIdx.x;
+    asm volatile("" : "+s"(next_opaque), "+v"(tid2));  // keep hipcc from carrying the first computation across the epilogue
+    s = setup_block(p, &ts, next_opaque, tid2);
+    vb = next;
+    eb ^= 1;
+  }
 }
 
 }  // namespace
@@ -602,18 +779,21 @@ static double schedule_makespan(int64_t t4, int64_t t3, int cus, double e) {
   return end;
 }
 
-// CONCH_TUNE_TILE_SCHEDULE: 0 = auto, 1 = uniform 256-column tiles, 2 = force the best two-width schedule
+// CONCH_TUNE_TILE_SCHEDULE: 0 = auto, 1 = uniform 256-column tiles, 2 = the best two-width schedule, wide tiles first on
+// every XCD, 3 = the same with odd XCDs walking their narrow tiles first.
+// auto = uniform: measured on MI355X (profiles/r02/tile_schedule_ab.txt) the two-width schedule does not shorten C3 although
+// it removes the idle last round -- the chip is power-limited, the idle CUs of a last round hand their power to the busy ones.
 static TileSchedule choose_tile_schedule(const ScaledGemmArgs& p) {
   const int tiles_m = (int)((p.m + kTileM - 1) / kTileM);
   const int tiles_n = (int)((p.n + kTileN - 1) / kTileN);
-  TileSchedule uni{tiles_m, tiles_n, 0};
+  TileSchedule uni{tiles_m, tiles_n, 0, 0};
   const int mode = tuning(CONCH_TUNE_TILE_SCHEDULE);
-  if (mode == 1 || p.fuse_silu) return uni;
+  if (mode <= 1 || p.fuse_silu) return uni;
   const int cus = device_cu_count();
   // per-tile fixed cost: ~6 us (C-store burst, re-entry, first LDS-DMA landing) against 36.8 us of K loop at K = 4096
   const double e = 0.163 * 4096.0 / (double)p.k;
   const double t_uni = (double)(((int64_t)tiles_m * tiles_n + cus - 1) / cus) * (1.0 + e);
-  double best = t_uni * (mode == 2 ? 10.0 : 0.98);  // auto: only for a gain above 2 %
+  double best = t_uni * 10.0;  // forced: the best two-width schedule whatever the model says
   TileSchedule pick = uni;
   const int a_max = (int)(p.n / kTileN);
   for (int a = a_max; a >= 0; --a) {
@@ -623,7 +803,7 @@ static TileSchedule choose_tile_schedule(const ScaledGemmArgs& p) {
     const double t = schedule_makespan((int64_t)tiles_m * a, (int64_t)tiles_m * b, cus, e);
     if (t < best - 1e-9) {
       best = t;
-      pick = TileSchedule{tiles_m, a, b};
+      pick = TileSchedule{tiles_m, a, b, mode == 3 ? 1 : 0};
     }
   }
   return pick;
@@ -635,17 +815,32 @@ int launch_scaled_gemm_mfma(const ScaledGemmArgs& p, int variant, hipStream_t st
   const int tiles_n = (int)((p.n + tile_n - 1) / tile_n);
   if (p.fuse_silu) variant = 5;
   dim3 grid((unsigned)(tiles_m * tiles_n));
-  TileSchedule ts{tiles_m, tiles_n, 0};
+  TileSchedule ts{tiles_m, tiles_n, 0, 0};
   if (!p.fuse_silu && variant != 2 && variant != 3 && p.k >= 2 * kStepBytes) {
     ts = choose_tile_schedule(p);
     grid = dim3((unsigned)(ts.tiles_m * (ts.big_cols + ts.narrow_cols)));
   }
+  // CONCH_TUNE_PERSISTENT: 0 = auto, 1 = plain launch, 2 = persistent workgroups (one per CU) whenever the contract holds,
+  // n > 2 = persistent with n workgroups (test hook: many tiles per workgroup on small problems)
+  // CONCH_TUNE_EPILOGUE: 0 = auto, 1 = direct stores from the accumulator layout, 2 = row-major through LDS
+  const int epi_mode = tuning(CONCH_TUNE_EPILOGUE);
+  const bool rows_epilogue = epi_mode == 2;  // auto = direct: the LDS route measured 0-2 % slower (profiles/r02/epilogue_ab.txt)
+  const int persist_mode = tuning(CONCH_TUNE_PERSISTENT);
+  const int cus = device_cu_count();
+  const int total_tiles = (int)grid.x;
+  const bool contract = !p.fuse_silu && (variant == 0 || variant == 5) && ts.narrow_cols == 0 && !p.bias && p.k >= 4 * kStepBytes;
+  const bool persistent = contract && persist_mode >= 2;  // auto = plain launch: profiles/r02/probe_boundary.txt
+  if (persistent) grid = dim3((unsigned)std::min(total_tiles, persist_mode > 2 ? persist_mode : cus));
 #define CONCH_LAUNCH(MMA, OUT)                                                                           \
   do {                                                                                                   \
-    if (variant == 2)                                                                                    \
+    if (persistent)                                                                                      \
+      hipLaunchKernelGGL((scaled_gemm_pp2_persistent_kernel<MMA, OUT>), grid, dim3(kThreads), 0, stream, p, ts, total_tiles); \
+    else if (variant == 2)                                                                               \
       hipLaunchKernelGGL((scaled_gemm_simple_kernel<MMA, OUT>), grid, dim3(kThreads), 0, stream, p);     \
     else if (p.fuse_silu)                                                                                \
       hipLaunchKernelGGL((scaled_gemm_pp2_kernel<MMA, OUT, true>), grid, dim3(kThreads), 0, stream, p, ts);  \
+    else if (variant != 3 && p.k >= 2 * kStepBytes && rows_epilogue)                                     \
+      hipLaunchKernelGGL((scaled_gemm_pp2_kernel<MMA, OUT, false, true>), grid, dim3(kThreads), 0, stream, p, ts); \
     else if (variant != 3 && p.k >= 2 * kStepBytes)                                                      \
       hipLaunchKernelGGL((scaled_gemm_pp2_kernel<MMA, OUT, false>), grid, dim3(kThreads), 0, stream, p, ts); \
     else                                                                                                 \
@@ -662,17 +857,30 @@ int launch_scaled_gemm_mfma(const ScaledGemmArgs& p, int variant, hipStream_t st
 #undef CONCH_LAUNCH
 }
 
-// e4m3fnuz compat path: operands already expanded to bf16 (exact) by repack.hip; `p` is in BYTE units
-// (k = 2 * K elements, strides in bytes) and satisfies the tile contract by construction.
-int launch_scaled_gemm_mfma_bf16(const ScaledGemmArgs& p, hipStream_t stream) {
+// 16-bit operands (bf16: the e4m3fnuz compat path, operands expanded exactly by repack.hip; fp16 / bf16: the dequantise-first
+// path of gemm_modes.hip).  `p` is in BYTE units (k = 2 * K elements, strides in bytes) and satisfies the tile contract by
+// construction; p.in_dtype says which 16-bit MFMA runs.
+int launch_scaled_gemm_mfma_16bit(const ScaledGemmArgs& p, hipStream_t stream) {
   const int tiles_m = (int)((p.m + kTileM - 1) / kTileM);
   const int tiles_n = (int)((p.n + kTileN - 1) / kTileN);
   const dim3 grid((unsigned)(tiles_m * tiles_n));
-  if (p.out_dtype == CONCH_DT_BF16)
+  if (p.in_dtype == CONCH_DT_FP16) {
+    if (p.out_dtype == CONCH_DT_BF16)
+      hipLaunchKernelGGL((scaled_gemm_pingpong_kernel<kMmaF16, CONCH_DT_BF16>), grid, dim3(kThreads), 0, stream, p);
+    else
+      hipLaunchKernelGGL((scaled_gemm_pingpong_kernel<kMmaF16, CONCH_DT_FP16>), grid, dim3(kThreads), 0, stream, p);
+  } else if (p.out_dtype == CONCH_DT_BF16) {
     hipLaunchKernelGGL((scaled_gemm_pingpong_kernel<kMmaBf16, CONCH_DT_BF16>), grid, dim3(kThreads), 0, stream, p);
-  else
+  } else {
     hipLaunchKernelGGL((scaled_gemm_pingpong_kernel<kMmaBf16, CONCH_DT_FP16>), grid, dim3(kThreads), 0, stream, p);
-  return check_launch("scaled_gemm_mfma_bf16");
+  }
+  return check_launch("scaled_gemm_mfma_16bit");
+}
+
+int launch_scaled_gemm_mfma_bf16(const ScaledGemmArgs& p, hipStream_t stream) {
+  ScaledGemmArgs q = p;
+  q.in_dtype = CONCH_DT_BF16;
+  return launch_scaled_gemm_mfma_16bit(q, stream);
 }
 
 // mixed-precision MFMA kernels live in gemm_mixed.hip

@@ -40,6 +40,10 @@ namespace {
 using namespace tile;
 using mixed::ChunkDequant;
 
+// see ChunkDequant: bf16 x 8-bit weights with a zero point round the difference first
+template <int X_DT, int BITS, int ZP>
+using Dequant = ChunkDequant<X_DT, BITS, (X_DT == CONCH_DT_BF16 && BITS == 8 && ZP != CONCH_ZP_NONE)>;
+
 constexpr int kStepK = 64;  // k elements per step (128 bytes of 16-bit)
 
 struct MixedTile {
@@ -210,7 +214,7 @@ template <int X_DT, int BITS, int ZP, int NT, int MODE, int ISSUE, bool DEFER>
 __device__ __forceinline__ void mixed_step(MixedTile& w, WeightRegs<BITS, NT>& regs, char* lds, const LoopCtx& c, WeightCursor& cur, int t) {
   constexpr int N1 = NT - 2;
   constexpr int kWpc = WeightRegs<BITS, NT>::kWpc;
-  constexpr int kSlices = ChunkDequant<X_DT, BITS>::kSlices;
+  constexpr int kSlices = Dequant<X_DT, BITS, ZP>::kSlices;
   static_assert(kSlices <= 16, "more slices per chunk than MFMA slots per chunk");
   // everything this wave staged for step t (LDS-DMA, ds_write) and loaded for step t+1 is complete ...
 #ifdef CONCH_CLOCK_PROBE
@@ -240,7 +244,7 @@ __device__ __forceinline__ void mixed_step(MixedTile& w, WeightRegs<BITS, NT>& r
   };
   WeightRegs<BITS, NT> next;
 
-  ChunkDequant<X_DT, BITS> cv[NT];
+  Dequant<X_DT, BITS, ZP> cv[NT];
   int slot = 0;  // a constant in every unrolled copy
   auto tail = [&](int sl) {
     // the step's VMEM work from slot ISSUE on: one per slot the four LDS-DMA pieces of X of step t+1, then the
@@ -451,9 +455,9 @@ __global__ __launch_bounds__(kThreads, 2) void mixed_gemm_kernel(MixedGemmArgs p
   advance(cur, c.ws);
 #pragma unroll
   for (int it = 0; it < NT; ++it) {
-    ChunkDequant<X_DT, BITS> cv;
+    Dequant<X_DT, BITS, ZP> cv;
 #pragma unroll
-    for (int sl = 0; sl < ChunkDequant<X_DT, BITS>::kSlices; ++sl)
+    for (int sl = 0; sl < Dequant<X_DT, BITS, ZP>::kSlices; ++sl)
       cv.slice(sl, regs.w[it][0], regs.w[it][kWpc - 1], c.off_base + regs.zp[it < 2 ? 0 : 1], regs.scale[it < 2 ? 0 : 1], lds + kXBytes + c.ln.lds[it], c.and_mask, c.or_magic);
   }
   if (steps > 1) {
@@ -490,9 +494,9 @@ int launch_zp(const MixedGemmArgs& p, hipStream_t stream) {
         case CONCH_ZP_SCALAR:
           hipLaunchKernelGGL((mixed_gemm_kernel<X_DT, OUT_DT, BITS, CONCH_ZP_SCALAR, 4, true>), grid, dim3(kThreads), 0, stream, p);
           break;
-        default:
-          hipLaunchKernelGGL((mixed_gemm_kernel<X_DT, OUT_DT, BITS, CONCH_ZP_TENSOR, 4, true>), grid, dim3(kThreads), 0, stream, p);
-          break;
+        default:  // per-group zero points at this width do not fit the register file (mixed_gemm_silu_fused_supported)
+          set_error("mixed_precision_gemm_silu_and_mul: no fused kernel for per-group zero points");
+          return CONCH_ERR_UNSUPPORTED;
       }
       return check_launch("mixed_gemm_mfma_silu");
     }
@@ -507,7 +511,14 @@ int launch_zp(const MixedGemmArgs& p, hipStream_t stream) {
       hipLaunchKernelGGL((mixed_gemm_kernel<X_DT, OUT_DT, BITS, CONCH_ZP_SCALAR, NT>), grid, dim3(kThreads), 0, stream, p);
       break;
     default:
-      hipLaunchKernelGGL((mixed_gemm_kernel<X_DT, OUT_DT, BITS, CONCH_ZP_TENSOR, NT>), grid, dim3(kThreads), 0, stream, p);
+      // per-group zero points: 192 columns at most -- at 256 the zero-point registers on top of the 128 accumulators spilled
+      // (4 to 7 dwords of scratch in the K loop, whose traffic also counts against the loop's vmcnt waits)
+      if constexpr (NT == 4) {
+        set_error("mixed_precision_gemm: 256-column tiles are not built for per-group zero points");
+        return CONCH_ERR_UNSUPPORTED;
+      } else {
+        hipLaunchKernelGGL((mixed_gemm_kernel<X_DT, OUT_DT, BITS, CONCH_ZP_TENSOR, NT>), grid, dim3(kThreads), 0, stream, p);
+      }
       break;
   }
   return check_launch("mixed_gemm_mfma");
@@ -548,6 +559,9 @@ int launch_bits(const MixedGemmArgs& p, int nt, hipStream_t stream) {
 
 }  // namespace
 
+// the fused gate/up epilogue runs on the 256-column tile only, which is not built for per-group zero points
+bool mixed_gemm_silu_fused_supported(const MixedGemmArgs& p) { return p.zp_mode != CONCH_ZP_TENSOR && mixed_gemm_mfma_supported(p); }
+
 bool mixed_gemm_mfma_supported(const MixedGemmArgs& p) {
   if (p.bits != 4 && p.bits != 8) return false;
   if (p.x_dtype != CONCH_DT_FP16 && p.x_dtype != CONCH_DT_BF16) return false;
@@ -570,7 +584,8 @@ bool mixed_gemm_mfma_supported(const MixedGemmArgs& p) {
 int launch_mixed_gemm_mfma(const MixedGemmArgs& p, hipStream_t stream) {
   const int num_cus = device_cu_count();
   const int forced = tuning(1);  // CONCH_TUNE_MIXED_TILE_NT: 0 = auto, 2..4 = force
-  const int nt = p.fuse_silu ? 4 : (forced >= 2 && forced <= 4) ? forced : pick_nt(p, num_cus);
+  int nt = p.fuse_silu ? 4 : (forced >= 2 && forced <= 4) ? forced : pick_nt(p, num_cus);
+  if (p.zp_mode == CONCH_ZP_TENSOR && nt == 4 && !p.fuse_silu) nt = 3;
   if (p.x_dtype == CONCH_DT_FP16) {
     return p.out_dtype == CONCH_DT_FP16 ? launch_bits<CONCH_DT_FP16, CONCH_DT_FP16>(p, nt, stream)
                                         : launch_bits<CONCH_DT_FP16, CONCH_DT_BF16>(p, nt, stream);

@@ -30,9 +30,9 @@ constexpr int kMsStepK = 64;              // k elements per step (128 bytes of f
 constexpr int kMsSteps = 16;              // steps per slice
 constexpr int kMsSliceK = kMsSteps * kMsStepK;
 
-template <int X_DT, int BITS>
+template <int X_DT, int BITS, int ZP>
 __device__ __forceinline__ i32x4 dequant8(uint32_t w0, uint32_t w1, int off, uint32_t scale_bits, uint32_t mask, uint32_t magic) {
-  ChunkDequant<X_DT, BITS> cv;
+  ChunkDequant<X_DT, BITS, (X_DT == CONCH_DT_BF16 && BITS == 8 && ZP != CONCH_ZP_NONE)> cv;
 #pragma unroll
   for (int s = 0; s + 1 < ChunkDequant<X_DT, BITS>::kSlices; ++s) cv.slice(s, w0, w1, off, scale_bits, nullptr, mask, magic);
   return cv.out;
@@ -109,8 +109,8 @@ __global__ __launch_bounds__(kMsThreads) void mixed_skinny_kernel(MixedGemmArgs 
 #pragma unroll
   for (int s = 0; s < kMsSteps; ++s) {
     // the lane's 8 + 8 weights of this step: k = 8g..8g+7 (first half step) and 32 + 8g.. (second), column n
-    const i32x4 w_lo = dequant8<X_DT, BITS>(wq[s][0][0], wq[s][0][kWpc - 1], off_base + zp[s], sc[s], and_mask, or_magic);
-    const i32x4 w_hi = dequant8<X_DT, BITS>(wq[s][1][0], wq[s][1][kWpc - 1], off_base + zp[s], sc[s], and_mask, or_magic);
+    const i32x4 w_lo = dequant8<X_DT, BITS, ZP>(wq[s][0][0], wq[s][0][kWpc - 1], off_base + zp[s], sc[s], and_mask, or_magic);
+    const i32x4 w_hi = dequant8<X_DT, BITS, ZP>(wq[s][1][0], wq[s][1][kWpc - 1], off_base + zp[s], sc[s], and_mask, or_magic);
 #pragma unroll
     for (int i = 0; i < ROWS / 16; ++i) {
       const Frag fx = read_frag(lds, s * kUnit + lane_off + i * 2048);

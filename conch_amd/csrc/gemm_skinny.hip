@@ -321,9 +321,19 @@ __global__ __launch_bounds__(256) void skinny_reduce_kernel(ScaledGemmArgs p, co
   const int64_t quads_per_row = p.n / 4;
   if (quad >= p.m * quads_per_row) return;
   const int m = (int)(quad / quads_per_row), n = (int)(quad % quads_per_row) * 4;
-  typename AccT<MMA>::type sum = __builtin_bit_cast(typename AccT<MMA>::type, *(const i32x4*)(slabs + (int64_t)m * p.n + n));
-  for (int s = 1; s < slices; ++s)
-    sum += __builtin_bit_cast(typename AccT<MMA>::type, *(const i32x4*)(slabs + ((int64_t)s * p.m + m) * p.n + n));
+  // four slices of loads in flight at a time (a plain `for s` loop is one dependent L2 round trip per slice), added in
+  // slice order: exact for int32, deterministic for fp32
+  typename AccT<MMA>::type sum;
+  for (int sb = 0; sb < slices; sb += 4) {
+    i32x4 part[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) part[j] = *(const i32x4*)(slabs + ((int64_t)min(sb + j, slices - 1) * p.m + m) * p.n + n);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const typename AccT<MMA>::type v = __builtin_bit_cast(typename AccT<MMA>::type, part[j]);
+      sum = (sb + j == 0) ? v : (sb + j < slices) ? sum + v : sum;
+    }
+  }
   const float sa = p.scale_a[p.scale_a_numel != 1 ? m : 0];
   uint16_t o[4];
 #pragma unroll
@@ -429,7 +439,14 @@ template <int MMA, int OUT_DT>
 int launch_splitk(const ScaledGemmArgs& p, int slices, hipStream_t stream) {
   int mode = tuning(CONCH_TUNE_SKINNY_MODE);
   int rows = p.m <= 32 ? 32 : p.m <= 64 ? 64 : 128;
-  if (mode == 0) mode = 2;
+  if (mode == 0) {
+    // measured (profiles/r02/splitk_modes.txt): the one-launch form wins when its workgroups -- 2048-byte slices, <= 64-row
+    // blocks -- fit one round of the chip (C2: 13.0 against 13.5 us) and for <= 32-row batches up to two rounds; with
+    // 1024-byte slices the last arriver's serial pass over four or more slabs costs more than the second launch
+    const int64_t wgs = ((p.n + kSpN - 1) / kSpN) * (p.k / (2 * kSpSliceK)) * ((p.m + 63) / 64);
+    const int cus = device_cu_count();
+    mode = (p.k % (2 * kSpSliceK) == 0 && (wgs <= cus || (p.m <= 32 && wgs <= 2 * cus))) ? 3 : 1;
+  }
   int steps = kSpSteps;
   if (mode == 3 && p.k % (2 * kSpSliceK) == 0) {
     steps = 2 * kSpSteps;

@@ -67,6 +67,8 @@ struct TileSchedule {
   int tiles_m;
   int big_cols;
   int narrow_cols;
+  int alternate;  // 1 = XCDs with an odd label walk their narrow tiles FIRST: the two halves of the chip then reach their
+                  // tile boundaries (C-store bursts) a quarter of a tile apart instead of all at once
 };
 
 struct TilePlace {
@@ -91,13 +93,19 @@ __device__ __forceinline__ TilePlace place_tile(int bid, const TileSchedule& ts)
   const int w0 = xcd * q + min(xcd, r);            // tiles of any width given to XCDs below this one
   const int b0 = (xcd * t4) >> 3;                  // wide tiles given to XCDs below this one
   const int b1 = ((xcd + 1) * t4) >> 3;
-  if (idx < b1 - b0) {
-    const TileCoord c = raster_tile(b0 + idx, ts.tiles_m, ts.big_cols);
+  const int nbig = b1 - b0;
+  const int nnarrow = (q + (xcd < r ? 1 : 0)) - nbig;
+  const bool narrow_first = ts.alternate && (xcd & 1);
+  const bool is_big = narrow_first ? idx >= nnarrow : idx < nbig;
+  const int big_idx = narrow_first ? idx - nnarrow : idx;
+  const int narrow_idx = narrow_first ? idx : idx - nbig;
+  if (is_big) {
+    const TileCoord c = raster_tile(b0 + big_idx, ts.tiles_m, ts.big_cols);
     t.tm = c.tm;
     t.n0 = c.tn * kTileN;
     t.narrow = 0;
   } else {
-    const TileCoord c = raster_tile((w0 - b0) + idx - (b1 - b0), ts.tiles_m, ts.narrow_cols);
+    const TileCoord c = raster_tile((w0 - b0) + narrow_idx, ts.tiles_m, ts.narrow_cols);
     t.tm = c.tm;
     t.n0 = ts.big_cols * kTileN + c.tn * (kTileN * 3 / 4);
     t.narrow = 1;
@@ -211,7 +219,7 @@ __device__ __forceinline__ void wait_vmcnt_n() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-enum { kMmaFp8 = 0, kMmaInt8 = 1, kMmaBf16 = 2 };
+enum { kMmaFp8 = 0, kMmaInt8 = 1, kMmaBf16 = 2, kMmaF16 = 3 };
 
 template <int MMA> struct AccT { typedef f32x4 type; };
 template <> struct AccT<kMmaInt8> { typedef i32x4 type; };
@@ -232,6 +240,9 @@ __device__ __forceinline__ void mma_step(typename AccT<MMA>::type& acc, const Fr
     // 128-byte K step = 64 bf16: chunk g holds k = 8g..8g+7, chunk g+4 holds k = 32+8g.. (e4m3fnuz compat path)
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa.lo), __builtin_bit_cast(bf16x8, fb.lo), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa.hi), __builtin_bit_cast(bf16x8, fb.hi), acc, 0, 0, 0);
+  } else if constexpr (MMA == kMmaF16) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fa.lo), __builtin_bit_cast(f16x8, fb.lo), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fa.hi), __builtin_bit_cast(f16x8, fb.hi), acc, 0, 0, 0);
   } else {
     acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa.lo, fb.lo, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa.hi, fb.hi, acc, 0, 0, 0);

@@ -13,7 +13,10 @@
 namespace conch {
 namespace mixed {
 
-template <int X_DT, int BITS>
+// ROUND_DIFF: round (q - bias - zp) to bf16 before the scale multiply.  The reference forms the difference IN the meta dtype
+// (kernels/quantization/gemm.py:205-210; w_ref likewise casts the integer difference first, quant_utils.py:74): with 8-bit
+// weights, a bias and a zero point it can reach 383 in magnitude, which bf16 (8 significant bits) rounds -- fp16 never has to.
+template <int X_DT, int BITS, bool ROUND_DIFF = false>
 struct ChunkDequant {
   static constexpr bool kHalf = X_DT == CONCH_DT_FP16;
   static constexpr int kSlices = 10;  // the last one is the ds_write_b128
@@ -35,6 +38,10 @@ struct ChunkDequant {
     const f16x2 hx = __builtin_bit_cast(f16x2, x), hy = __builtin_bit_cast(f16x2, y);
     lo = f32x2{(float)hx[0], (float)hy[0]};
     hi = f32x2{(float)hx[1], (float)hy[1]};
+    if constexpr (ROUND_DIFF) {
+      lo = unpack2_bits16<CONCH_DT_BF16>(pack2_bits16<CONCH_DT_BF16>(lo));
+      hi = unpack2_bits16<CONCH_DT_BF16>(pack2_bits16<CONCH_DT_BF16>(hi));
+    }
   }
   // output dword j of the chunk is the pair (k 2j, k 2j+1)
   static constexpr int kOutLoP = 0, kOutHiP = BITS == 4 ? 2 : 1, kOutLoQ = BITS == 4 ? 1 : 2, kOutHiQ = 3;

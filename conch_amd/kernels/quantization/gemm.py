@@ -119,6 +119,13 @@ def _scaled_gemm_call(
         raise ValueError(f"output shape {tuple(output.shape)} does not match metadata")
     sa = _as_fp32_vector(scale_a, "scale_a")
     sb = _as_fp32_vector(scale_b, "scale_b")
+    # channel-scale modes of the launcher (kernels/quantization/gemm.py:408-440): a side that is not applied is passed as
+    # NULL, which the C ABI reads as the constant 1.  conch.ops always builds WEIGHT_AND_ACTIVATION (ops gemm.py:228).
+    mode = metadata.channel_scale_mode
+    if mode in (ChannelScaleMode.NONE, ChannelScaleMode.WEIGHT_ONLY):
+        sa = None
+    if mode in (ChannelScaleMode.NONE, ChannelScaleMode.ACTIVATION_ONLY):
+        sb = None
     if bias is not None:
         if bias.dtype != output.dtype:
             bias = bias.to(output.dtype)
@@ -129,7 +136,7 @@ def _scaled_gemm_call(
         _C.ptr(output), _C.ptr(a), _C.ptr(b), _C.ptr(sa), _C.ptr(sb), _C.ptr(bias),
         metadata.m_dim, metadata.n_dim if n_out is None else n_out, metadata.k_dim,
         a.stride(0), a.stride(1), b.stride(0), b.stride(1), output.stride(0), output.stride(1),
-        sa.numel(), sb.numel(), _C.dtype_id(a.dtype), _C.dtype_id(output.dtype),
+        1 if sa is None else sa.numel(), 1 if sb is None else sb.numel(), _C.dtype_id(a.dtype), _C.dtype_id(output.dtype),
         _C.current_stream_handle(a.device), *extra,
     )
     with _C.on_device_of(output, a, b, sa, sb, bias):
@@ -199,8 +206,6 @@ def _mixed_gemm_call(
         raise NotImplementedError("mixed_precision_gemm accumulates in float32 only")
     if metadata.meta_dtype != x.dtype or scales.dtype != x.dtype:
         raise NotImplementedError("mixed_precision_gemm: scales / meta dtype must equal the activation dtype")
-    if metadata.channel_scale_mode != ChannelScaleMode.NONE:
-        raise NotImplementedError("mixed_precision_gemm: channel scaling is not reachable from conch.ops")
     if w_q_packed.dtype not in (torch.int32, getattr(torch, "uint32", torch.int32)):
         raise ValueError(f"Invalid datatype for packed weights: {w_q_packed.dtype}")
     if x.stride(1) != 1:
@@ -215,11 +220,21 @@ def _mixed_gemm_call(
                          f"({metadata.m_dim}, {metadata.k_dim}, {metadata.n_dim})")
     if tuple(output.shape) != (metadata.m_dim, metadata.n_dim if n_out is None else n_out):
         raise ValueError(f"output shape {tuple(output.shape)} does not match metadata")
-    if zeros is None or metadata.weight_group_mode == WeightGroupMode.SYMMETRIC_NO_SHIFT:
+    gmode, cmode = metadata.weight_group_mode, metadata.channel_scale_mode
+    fused = (cmode == ChannelScaleMode.NONE and metadata.weight_size_bits in (4, 8)
+             and (gmode == WeightGroupMode.SYMMETRIC_NO_SHIFT
+                  or (gmode == WeightGroupMode.SYMMETRIC_WITH_SHIFT and zeros is not None and not zeros.dtype.is_floating_point)))
+    if not fused:
+        # a mode conch.ops never produces: the explicit-modes entry point
+        if fn_name != "conch_mixed_precision_gemm":
+            raise NotImplementedError(f"{fn_name}: only the weight-group modes conch.ops produces (SYMMETRIC_NO_SHIFT / "
+                                      "SYMMETRIC_WITH_SHIFT on 4- / 8-bit weights, no channel scale)")
+        return _mixed_gemm_modes_call(output, x, w_q_packed, scales, zeros, metadata)
+    if gmode == WeightGroupMode.SYMMETRIC_NO_SHIFT:
         zp_mode, zeros_t, zp_stride = _C.ZP_NONE, None, 0
     else:
-        if zeros.dtype.is_floating_point or zeros.dtype == torch.bool:
-            raise ValueError(f"zero points must be integers (got {zeros.dtype}): they are subtracted before the scale")
+        if zeros.dtype == torch.bool:
+            raise ValueError("zero points must be integers")
         if zeros.dtype != torch.int32:
             zeros = zeros.to(torch.int32)  # exact: every integer dtype torch has fits the packed weights' range
         if metadata.zero_is_scalar:
@@ -236,6 +251,53 @@ def _mixed_gemm_call(
     )
     with _C.on_device_of(output, x, w_q_packed, scales, zeros_t):
         return getattr(lib or _C.load(), fn_name)(*args)
+
+
+_ZEROS_NONE, _ZEROS_SCALAR_INT32, _ZEROS_TENSOR_INT32, _ZEROS_SCALAR_FLOAT, _ZEROS_TENSOR_FLOAT = range(5)
+
+
+def _mixed_gemm_modes_call(output, x, w_q_packed, scales, zeros, metadata: MixedPrecisionMatmulMetadata) -> int:
+    """conch_mixed_precision_gemm_modes: any WeightGroupMode, ChannelScaleMode NONE / WEIGHT_ONLY, 1- to 16-bit weights.
+
+    Mirrors what the reference launcher feeds `_gemm_kernel` (kernels/quantization/gemm.py:482-545): `scales` is the group
+    scale tensor [K/G, N] for the SYMMETRIC / ASYMMETRIC modes and, under WEIGHT_ONLY, ALSO the per-column scale the kernel
+    reads at `scales_ptr + n` (:409) -- i.e. its first row.  `zeros` of any dtype is converted to the meta dtype on load
+    (:363-371): integers go over as int32, floating tensors as the activation dtype.
+    """
+    gmode, cmode = metadata.weight_group_mode, metadata.channel_scale_mode
+    if cmode not in (ChannelScaleMode.NONE, ChannelScaleMode.WEIGHT_ONLY):
+        raise NotImplementedError(f"mixed_precision_gemm: {cmode} needs activation scales, which this launcher never passes "
+                                  "(kernels/quantization/gemm.py:507 scales_a_ptr=None)")
+    needs_zeros = gmode in (WeightGroupMode.SHIFT, WeightGroupMode.SYMMETRIC_WITH_SHIFT, WeightGroupMode.ASYMMETRIC)
+    needs_scales = gmode in (WeightGroupMode.SYMMETRIC_NO_SHIFT, WeightGroupMode.SYMMETRIC_WITH_SHIFT, WeightGroupMode.ASYMMETRIC)
+    if needs_zeros and zeros is None:
+        raise ValueError(f"{gmode} needs zero points")
+    zeros_t, zkind, zstride = None, _ZEROS_NONE, 0
+    if needs_zeros:
+        scalar = zeros.numel() == 1
+        if zeros.dtype.is_floating_point:
+            zeros_t = zeros.to(x.dtype)
+            zkind = _ZEROS_SCALAR_FLOAT if scalar else _ZEROS_TENSOR_FLOAT
+        else:
+            zeros_t = zeros.to(torch.int32)
+            zkind = _ZEROS_SCALAR_INT32 if scalar else _ZEROS_TENSOR_INT32
+        zeros_t = zeros_t.reshape(-1) if scalar else (zeros_t if zeros_t.stride(-1) == 1 else zeros_t.contiguous())
+        zstride = 0 if scalar else zeros_t.stride(0)
+    channel = None
+    if cmode == ChannelScaleMode.WEIGHT_ONLY:
+        channel = scales.reshape(-1)[: metadata.n_dim].to(x.dtype).contiguous()
+        if channel.numel() != metadata.n_dim:
+            raise ValueError(f"WEIGHT_ONLY needs {metadata.n_dim} channel scales, got {channel.numel()}")
+    group_scales = scales if needs_scales else None
+    args = (
+        _C.ptr(output), _C.ptr(x), _C.ptr(w_q_packed), _C.ptr(group_scales), _C.ptr(zeros_t), _C.ptr(channel),
+        metadata.m_dim, metadata.n_dim, metadata.k_dim,
+        x.stride(0), w_q_packed.stride(0), (scales.stride(0) if scales.dim() == 2 else metadata.n_dim) if needs_scales else 0, zstride,
+        output.stride(0), metadata.weight_size_bits, metadata.weight_bias, metadata.group_size, gmode.value, zkind, cmode.value,
+        _C.dtype_id(x.dtype), _C.dtype_id(output.dtype), _C.current_stream_handle(x.device),
+    )
+    with _C.on_device_of(output, x, w_q_packed, scales, zeros_t):
+        return _C.load().conch_mixed_precision_gemm_modes(*args)
 
 
 def mixed_precision_gemm_launcher(

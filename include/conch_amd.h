@@ -73,6 +73,34 @@ typedef enum conch_zp_mode {
   CONCH_ZP_TENSOR = 2  /* int32 [K/group_size, N] */
 } conch_zp_mode_t;
 
+/* Weight-group and channel-scale modes of the reference kernel (conch/kernels/quantization/gemm.py:34-41, :68-74; same
+ * values).  conch.ops only ever selects SYMMETRIC_NO_SHIFT / SYMMETRIC_WITH_SHIFT with CHANNEL_NONE (mixed) and
+ * WEIGHT_AND_ACTIVATION (scaled); the others are reachable through the launchers with hand-built metadata. */
+typedef enum conch_group_mode {
+  CONCH_GROUP_NONE = 0,                 /* W = q - bias */
+  CONCH_GROUP_SHIFT = 1,                /* W = (q - bias) - zeros */
+  CONCH_GROUP_SYMMETRIC_NO_SHIFT = 2,   /* W = (q - bias) * scales */
+  CONCH_GROUP_SYMMETRIC_WITH_SHIFT = 3, /* W = ((q - bias) - zeros) * scales */
+  CONCH_GROUP_ASYMMETRIC = 4            /* W = fma(q - bias, scales, zeros) */
+} conch_group_mode_t;
+
+typedef enum conch_channel_mode {
+  CONCH_CHANNEL_NONE = 0,
+  CONCH_CHANNEL_WEIGHT_ONLY = 1,
+  CONCH_CHANNEL_ACTIVATION_ONLY = 2,
+  CONCH_CHANNEL_WEIGHT_AND_ACTIVATION = 3
+} conch_channel_mode_t;
+
+/* What `zeros` points to in conch_mixed_precision_gemm_modes (the reference converts whatever it loads to the meta dtype,
+ * kernels/quantization/gemm.py:363-371). */
+typedef enum conch_zeros_kind {
+  CONCH_ZEROS_NONE = 0,
+  CONCH_ZEROS_SCALAR_INT32 = 1,
+  CONCH_ZEROS_TENSOR_INT32 = 2, /* int32 [K/G][N] */
+  CONCH_ZEROS_SCALAR_FLOAT = 3, /* one element of x_dtype */
+  CONCH_ZEROS_TENSOR_FLOAT = 4  /* x_dtype [K/G][N] */
+} conch_zeros_kind_t;
+
 /* Kernel-selection knobs for tests and benchmarks (process-global, not part of the data path). */
 typedef enum conch_tuning_key {
   CONCH_TUNE_GEMM_VARIANT = 0 /* 0 = auto, 1 = generic (any shape/stride), 2 = LDS-tiled MFMA with a plain
@@ -90,8 +118,17 @@ typedef enum conch_tuning_key {
                                 kernel), 2 = ONE launch (the last-arriving slice of a tile reduces it), 1024-byte K slices,
                                 3 = one launch, 2048-byte slices and <= 64-row blocks */
   ,
-  CONCH_TUNE_TILE_SCHEDULE = 4 /* 256x256-tile scaled GEMM: 0 = auto, 1 = uniform 256-column tiles (round-1 form),
-                                 2 = N-balanced strips (256-column tiles plus one narrower tail tile per strip) */
+  CONCH_TUNE_TILE_SCHEDULE = 4 /* 256x256-tile scaled GEMM: 0 = auto (= 1), 1 = uniform 256-column tiles, 2 = two tile
+                                 widths (256-column tiles, then 192-column tiles: no idle last round), wide first on
+                                 every XCD, 3 = the same with odd XCDs walking their narrow tiles first */
+  ,
+  CONCH_TUNE_PERSISTENT = 5 /* 256x256-tile scaled GEMM: 0 = auto (= 1), 1 = one workgroup per tile, 2 = persistent
+                               workgroups (one per CU) that prefetch the next tile's first K steps under the epilogue,
+                               n > 2 = persistent with n workgroups (test hook) */
+  ,
+  CONCH_TUNE_EPILOGUE = 6 /* 256x256-tile scaled GEMM (two-phase ping-pong): 0 = auto, 1 = direct 16-byte stores from the
+                             accumulator layout (16 lines per quarter-wave), 2 = sub-tile parked in LDS and stored as whole
+                             128-byte rows */
 } conch_tuning_key_t;
 
 int conch_abi_version(void);
@@ -153,6 +190,8 @@ int conch_dynamic_scaled_fp8_quant(uint8_t* out, float* scale_out, const void* x
  * (FP16 | BF16); scale_a: fp32, scale_a_numel = 1 or M (element stride 1); scale_b likewise with N;
  * bias: NULL or [N] of out_dtype, added in out_dtype after the cast exactly as the reference does.
  * int8 accumulates exactly in int32; fp8 accumulates in fp32.
+ * scale_a == NULL / scale_b == NULL mean "no scale on that side" (a constant 1): the launcher's channel-scale modes
+ * ACTIVATION_ONLY (scale_b NULL), WEIGHT_ONLY (scale_a NULL) and NONE (both NULL), kernels/quantization/gemm.py:408-440.
  */
 int conch_scaled_gemm(void* c, const void* a, const void* b, const float* scale_a,
                       const float* scale_b, const void* bias, int64_t m, int64_t n, int64_t k,
@@ -195,6 +234,22 @@ int conch_mixed_precision_gemm(void* c, const void* x, const int32_t* w_q_packed
                                int64_t wzp_stride_g, int64_t c_stride_m, int weight_bits,
                                int weight_bias, int group_size, int zp_mode, int x_dtype,
                                int out_dtype, void* stream);
+
+/*
+ * mixed_precision_gemm with an explicit weight-group mode, zero-point kind and channel-scale mode (what
+ * mixed_precision_gemm_launcher, kernels/quantization/gemm.py:482-545, does when its metadata carries a mode conch.ops never
+ * sets).  Every step of the dequantisation is rounded to x_dtype in the kernel's order (kernels/quantization/gemm.py:192-216):
+ *   b = x_dtype(q) - weight_bias;  NONE: W = b;  SHIFT: W = b - z;  SYMMETRIC_NO_SHIFT: W = b * s;
+ *   SYMMETRIC_WITH_SHIFT: W = (b - z) * s;  ASYMMETRIC: W = fma(b, s, z)
+ * weight_bits in {1, 2, 4, 8, 16}; scales: x_dtype [K/G][N] (unused by NONE / SHIFT); zeros per zeros_kind;
+ * channel_mode NONE, or WEIGHT_ONLY with channel_scales = x_dtype [N]:  C = out_dtype( x_dtype(acc) * channel_scales[n] )
+ * (:408-416).  ACTIVATION_ONLY / WEIGHT_AND_ACTIVATION need activation scales the mixed launcher never passes: UNSUPPORTED.
+ */
+int conch_mixed_precision_gemm_modes(void* c, const void* x, const int32_t* w_q_packed, const void* scales, const void* zeros,
+                                     const void* channel_scales, int64_t m, int64_t n, int64_t k, int64_t x_stride_m,
+                                     int64_t wq_stride_k, int64_t scales_stride_g, int64_t zeros_stride_g, int64_t c_stride_m,
+                                     int weight_bits, int weight_bias, int group_size, int group_mode, int zeros_kind,
+                                     int channel_mode, int x_dtype, int out_dtype, void* stream);
 
 /*
  * mixed_precision_gemm_silu_and_mul  (SURVEY.md 8(f) N3 for the int4 / int8-weight FFN: the reference's pair

@@ -331,7 +331,7 @@ def dequantize_modes_ref(
       SHIFT             b -= zeros                                                                     :197-198
       SYMMETRIC_NO_SHIFT    b = b * scales                                                             :201-202
       SYMMETRIC_WITH_SHIFT  b = (b - zeros) * scales                                                   :205-210
-      ASYMMETRIC        b = fma(b, scales, zeros)   -- ONE rounding: evaluated in float64, rounded to meta    :213-214
+      ASYMMETRIC        b = fma(b, scales, zeros)   -- fused: product and sum in float64, then float32, then meta   :213-214
 
     `zeros`: None | one element | [K/G, N], any dtype, converted to meta on load (:363-371); `scales`: [K/G, N] meta.
     Returns [K, N] in meta_dtype (the kernel then casts to the activation dtype, which is the same here).
@@ -353,7 +353,7 @@ def dequantize_modes_ref(
     if group_mode == GROUP_SYMMETRIC_WITH_SHIFT:
         return (b - per_row(zeros)) * per_row(scales)
     if group_mode == GROUP_ASYMMETRIC:
-        return (b.double() * per_row(scales).double() + per_row(zeros).double()).to(meta_dtype)
+        return (b.double() * per_row(scales).double() + per_row(zeros).double()).float().to(meta_dtype)
     raise ValueError(f"unknown weight group mode {group_mode}")
 
 

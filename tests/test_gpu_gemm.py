@@ -145,6 +145,8 @@ def _reset_tuning():
     yield
     _C.set_tuning(_C.TUNE_TILE_SCHEDULE, 0)
     _C.set_tuning(_C.TUNE_SKINNY_MODE, 0)
+    _C.set_tuning(_C.TUNE_PERSISTENT, 0)
+    _C.set_tuning(_C.TUNE_EPILOGUE, 0)
 
 
 @pytest.mark.parametrize("iname", ["int8", "fn"])
@@ -160,6 +162,44 @@ def test_two_width_tile_schedule_is_bit_identical_and_correct(_reset_tuning, ina
     np.testing.assert_array_equal(to_bits(balanced), to_bits(uniform))
     ref = oracle.scaled_gemm_ref(a, b, sa, sb, torch.bfloat16, bias)
     check_scaled(balanced, ref, IN_T[iname], torch.bfloat16, (a, b, sa, sb, bias))
+
+
+@pytest.mark.parametrize("oname", ["f16", "bf16"])
+@pytest.mark.parametrize("iname", ["int8", "fn"])
+@pytest.mark.parametrize(("m", "k", "n", "use_bias"), [(4096, 512, 11008, False), (1000, 640, 1500, True), (300, 384, 520, True),
+                                                        (257, 256, 8, False), (2304, 512, 4672, True), (512, 256, 1004, False)])
+def test_row_major_epilogue_is_bit_identical(_reset_tuning, oname, iname, m, k, n, use_bias):
+    """Epilogue through LDS (whole 128-byte rows per store) against the direct accumulator-layout stores: the same values,
+    another route to memory -- full tiles, ragged M / N edges, rows that are not 16-byte aligned (N = 1004, 8)."""
+    a, b, sa, sb, bias = make_scaled_inputs(m, k, n, IN_T[iname], DT[oname], False, False, use_bias)
+    _C.set_gemm_variant(_C.VARIANT_MFMA_PINGPONG2)
+    _C.set_tuning(_C.TUNE_EPILOGUE, 1)
+    direct = run_scaled(a, b, sa, sb, DT[oname], bias)
+    _C.set_tuning(_C.TUNE_EPILOGUE, 2)
+    rows = run_scaled(a, b, sa, sb, DT[oname], bias)
+    np.testing.assert_array_equal(to_bits(rows), to_bits(direct))
+    ref = oracle.scaled_gemm_ref(a, b, sa, sb, DT[oname], bias)
+    check_scaled(rows, ref, IN_T[iname], DT[oname], (a, b, sa, sb, bias))
+
+
+@pytest.mark.parametrize("workgroups", [2, 7, 16, 256])
+@pytest.mark.parametrize("iname", ["int8", "fn"])
+@pytest.mark.parametrize(("m", "k", "n"), [(4096, 512, 11008), (1024, 512, 2048), (1000, 640, 1500), (2304, 1024, 4672), (512, 4096, 768),
+                                            (8192, 512, 3584)])
+def test_persistent_tile_walk_is_bit_identical_and_correct(_reset_tuning, workgroups, iname, m, k, n):
+    """Persistent workgroups (next tile's first two K steps and scales prefetched under the epilogue, counted waits across the
+    tile boundary) against one workgroup per tile: the same per-element accumulation order, so the same bits -- for full tiles
+    (counted wait behind exactly 16 stores) and for ragged ones (drained), with 1 to hundreds of tiles per workgroup."""
+    a, b, sa, sb, _ = make_scaled_inputs(m, k, n, IN_T[iname], torch.bfloat16, False, False, False)
+    _C.set_gemm_variant(_C.VARIANT_MFMA_PINGPONG2)
+    _C.set_tuning(_C.TUNE_PERSISTENT, 1)
+    plain = run_scaled(a, b, sa, sb, torch.bfloat16, None)
+    _C.set_tuning(_C.TUNE_PERSISTENT, workgroups)
+    for _ in range(2):
+        walk = run_scaled(a, b, sa, sb, torch.bfloat16, None)
+        np.testing.assert_array_equal(to_bits(walk), to_bits(plain))
+    ref = oracle.scaled_gemm_ref(a, b, sa, sb, torch.bfloat16, None)
+    check_scaled(walk, ref, IN_T[iname], torch.bfloat16, (a, b, sa, sb, None))
 
 
 @pytest.mark.parametrize("mode", [2, 3])
@@ -717,3 +757,131 @@ def test_mixed_precision_decode_dequant_is_bit_exact():
                 got = mixed_precision_gemm(x.cuda(), packed.cuda(), w_s.cuda(), None if w_zp is None else w_zp.cuda(),
                                            wt.size_bits, wt.bias, 128)
                 np.testing.assert_array_equal(to_bits(got), to_bits(w_ref[rows]), err_msg=f"{dname} {wname} zp={use_zp}")
+
+
+# ---------------------------------------------------------------------------------------------
+# kernel modes conch.ops never selects, through the launchers with hand-set metadata
+# ---------------------------------------------------------------------------------------------
+import dataclasses  # noqa: E402
+
+from conch_amd.kernels.quantization.gemm import (  # noqa: E402
+    ChannelScaleMode,
+    WeightGroupMode,
+    mixed_precision_gemm_launcher,
+    scaled_gemm_launcher,
+)
+from conch_amd.ops.quantization.gemm import create_mixed_precision_metadata, create_scaled_metadata  # noqa: E402
+from tests.test_oracle_golden import MODE_CASES, MODE_TAGS, mode_inputs  # noqa: E402
+
+GMODE = {oracle.GROUP_NONE: WeightGroupMode.NONE, oracle.GROUP_SHIFT: WeightGroupMode.SHIFT,
+         oracle.GROUP_SYMMETRIC_NO_SHIFT: WeightGroupMode.SYMMETRIC_NO_SHIFT,
+         oracle.GROUP_SYMMETRIC_WITH_SHIFT: WeightGroupMode.SYMMETRIC_WITH_SHIFT, oracle.GROUP_ASYMMETRIC: WeightGroupMode.ASYMMETRIC}
+CMODE = {oracle.CHANNEL_NONE: ChannelScaleMode.NONE, oracle.CHANNEL_WEIGHT_ONLY: ChannelScaleMode.WEIGHT_ONLY,
+         oracle.CHANNEL_ACTIVATION_ONLY: ChannelScaleMode.ACTIVATION_ONLY,
+         oracle.CHANNEL_WEIGHT_AND_ACTIVATION: ChannelScaleMode.WEIGHT_AND_ACTIVATION}
+
+
+def run_mixed_mode(x, packed, scales, zeros, nbits, bias, group, gmode, cmode, out_dtype=None):
+    dev = lambda t: None if t is None else t.cuda()  # noqa: E731
+    xd, pd, sd, zd = dev(x), dev(packed), dev(scales), dev(zeros)
+    md = create_mixed_precision_metadata(xd, pd, sd, zd, nbits, bias, group, output_dtype=out_dtype)
+    md = dataclasses.replace(md, weight_group_mode=GMODE[gmode], channel_scale_mode=CMODE[cmode],
+                             zero_is_scalar=zeros is not None and zeros.numel() == 1)
+    out = torch.empty((x.shape[0], packed.shape[1]), dtype=md.output_dtype, device="cuda")
+    mixed_precision_gemm_launcher(out, xd, pd, sd, zd, md)
+    return out.cpu()
+
+
+@pytest.mark.parametrize("case", list(MODE_CASES))
+@pytest.mark.parametrize(("nbits", "bias"), MODE_TAGS)
+def test_kernel_modes_match_reference_triton_kernel_golden(golden, nbits, bias, case):
+    """Golden = the reference's own Triton kernel (CPU interpreter).  Identity activations: bit for bit."""
+    g = golden("gemm_modes")
+    tag, gmode, cmode, packed, ws, cs, zeros = mode_inputs(g, nbits, bias, case)
+    scales = cs if cmode == oracle.CHANNEL_WEIGHT_ONLY else ws
+    got = run_mixed_mode(torch.eye(128, dtype=torch.float16), packed, scales, zeros, nbits, bias, 64, gmode, cmode)
+    np.testing.assert_array_equal(to_bits(got), g[f"c_{tag}_{case}_eye"])
+    x = from_bits(g["x_rand"], torch.float16)
+    got = run_mixed_mode(x, packed, scales, zeros, nbits, bias, 64, gmode, cmode).float()
+    want = from_bits(g[f"c_{tag}_{case}_rand"], torch.float16).float()
+    assert (got - want).abs().max().item() <= 2.0**-10 * max(want.abs().max().item(), 1.0)
+
+
+@pytest.mark.parametrize("dname", ["f16", "bf16"])
+@pytest.mark.parametrize("case", list(MODE_CASES))
+@pytest.mark.parametrize(("nbits", "bias"), [(2, 2), (4, 8), (8, 128), (8, 0), (1, 0), (16, 0)])
+def test_kernel_modes_tiled_path_dequantises_bit_exactly(dname, nbits, bias, case):
+    """The dequantise-first + 16-bit MFMA path (K % 64 == 0, large enough) against the oracle's restatement, both dtypes:
+    identity activations expose the dequantised weights (x channel scale) bit for bit; random activations to accumulation
+    order.  1- and 16-bit weights exercise the widths the reference's docstring promises (gemm.py:4)."""
+    dt = DT[dname]
+    gmode, cmode, _, zname = MODE_CASES[case]
+    k, n, group = 512, 320, 128
+    seed_everything(nbits * 100 + bias)
+    hi = 2**nbits
+    # 16-bit weights: small values, so that neither the weights (65535 -> inf in fp16) nor the K = 512 sums overflow fp16
+    wq = torch.randint(0, min(hi, 64), (k, n), dtype=torch.int64).to(torch.int32) if nbits == 16 else \
+        torch.randint(0, hi, (k, n), dtype=torch.int64).to(torch.int32)
+    packed = torch.from_numpy(oracle.pack_rows_ref(wq.numpy(), nbits))
+    ws = (torch.rand(k // group, n) * 0.37 + 0.01).to(dt)
+    cs = (torch.rand(1, n) * 1.5 + 0.25).to(dt)
+    zeros = {None: None, "zi": torch.randint(0, min(hi, 256), (k // group, n), dtype=torch.int32),
+             "zf": (torch.rand(k // group, n) * 5 - 2.5).to(dt), "scalar": torch.tensor([3], dtype=torch.int32)}[zname]
+    w = oracle.dequantize_modes_ref(packed, ws, zeros, nbits, bias, group, gmode, dt)
+    scales = cs if cmode == oracle.CHANNEL_WEIGHT_ONLY else ws
+    eye = torch.eye(k, dtype=dt)
+    got = run_mixed_mode(eye, packed, scales, zeros, nbits, bias, group, gmode, cmode)
+    want = oracle.mixed_precision_gemm_modes_ref(eye, w, cs, cmode, dt)
+    np.testing.assert_array_equal(to_bits(got), to_bits(want))
+    x = (2 * torch.rand(300, k) - 1).to(dt)
+    got = run_mixed_mode(x, packed, scales, zeros, nbits, bias, group, gmode, cmode).float()
+    want = oracle.mixed_precision_gemm_modes_ref(x, w, cs, cmode, dt).float()
+    tol = 2.0 * EPS[dt] * max(want.abs().max().item(), 1e-6)
+    assert (got - want).abs().max().item() <= tol
+
+
+@pytest.mark.parametrize("oname", ["f16", "bf16"])
+@pytest.mark.parametrize("cname", ["none", "wonly", "aonly", "wa"])
+@pytest.mark.parametrize(("m", "k", "n"), [(128, 128, 64), (512, 1024, 768), (100, 1024, 260)])
+def test_scaled_launcher_channel_modes(oname, cname, m, k, n):
+    """ChannelScaleMode set by hand on the scaled launcher's metadata (kernels/quantization/gemm.py:408-440): int8, bit-exact."""
+    cmode = {"none": oracle.CHANNEL_NONE, "wonly": oracle.CHANNEL_WEIGHT_ONLY, "aonly": oracle.CHANNEL_ACTIVATION_ONLY,
+             "wa": oracle.CHANNEL_WEIGHT_AND_ACTIVATION}[cname]
+    a, b, sa, sb, _ = make_scaled_inputs(m, k, n, torch.int8, DT[oname], False, False, False)
+    ad, bd, sad, sbd = a.cuda(), b.T.contiguous().cuda().T, sa.cuda(), sb.cuda()
+    md = dataclasses.replace(create_scaled_metadata(ad, bd, sad, sbd, DT[oname]), channel_scale_mode=CMODE[cmode])
+    out = torch.empty((m, n), dtype=DT[oname], device="cuda")
+    scaled_gemm_launcher(out, ad, bd, sad, sbd, md)
+    want = oracle.scaled_gemm_modes_ref(a, b, sa, sb, DT[oname], cmode)
+    np.testing.assert_array_equal(to_bits(out), to_bits(want))
+
+
+def test_scaled_launcher_channel_modes_golden(golden):
+    """The same against the reference's Triton kernel (fp16 outputs; NONE / WEIGHT_ONLY / ACTIVATION_ONLY bit for bit)."""
+    g = golden("gemm_modes")
+    a = torch.from_numpy(g["sc_a"].copy()).cuda()
+    b = torch.from_numpy(g["sc_bt"].copy()).cuda().T
+    sa, sb = torch.from_numpy(g["sc_sa"].copy()).cuda(), torch.from_numpy(g["sc_sb"].copy()).cuda()
+    for cname, cmode in (("none", ChannelScaleMode.NONE), ("wonly", ChannelScaleMode.WEIGHT_ONLY), ("aonly", ChannelScaleMode.ACTIVATION_ONLY)):
+        md = dataclasses.replace(create_scaled_metadata(a, b, sa, sb, torch.float16), channel_scale_mode=cmode)
+        out = torch.empty((128, 64), dtype=torch.float16, device="cuda")
+        scaled_gemm_launcher(out, a, b, sa, sb, md)
+        np.testing.assert_array_equal(to_bits(out), g[f"sc_c_f16_{cname}"])
+
+
+def test_nsharded_gemm_world1_equals_scaled_gemm():
+    """conch_amd.distributed on the GPU with one rank: the GEMM writes the row-major result directly (no gather, no copy) and
+    must equal the plain op bit for bit; gathered_blocks() is a view of the same buffer."""
+    from conch_amd.distributed import NShardedScaledGemm
+
+    m, k, n = 2048, 1024, 3584
+    a, b, sa, sb, bias = make_scaled_inputs(m, k, n, torch.float8_e4m3fn, torch.bfloat16, False, False, True)
+    ad, bd, sad, sbd, biasd = a.cuda(), b.T.contiguous().cuda().T, sa.cuda(), sb.cuda(), bias.cuda()
+    want = scaled_gemm(ad, bd, sad, sbd, torch.bfloat16, biasd)
+    for panels in (1, 2, 4):
+        op = NShardedScaledGemm(m, n, torch.bfloat16, torch.device("cuda"), panels=panels)
+        got = op(ad, bd, sad, sbd, biasd)
+        np.testing.assert_array_equal(to_bits(got), to_bits(want))
+        blocks = op.gathered_blocks(ad, bd, sad, sbd, biasd)
+        assert blocks.shape == (panels, 1, m // panels, n)
+        np.testing.assert_array_equal(to_bits(blocks[panels - 1, 0]), to_bits(want[m - m // panels:]))

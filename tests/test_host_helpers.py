@@ -60,6 +60,10 @@ def test_c_abi_validation_without_gpu():
     assert lib.conch_static_scaled_int8_quant(None, None, None, 2, 16, 16, 16, _C.DT_FP16, None) == 1
     rc = lib.conch_mixed_precision_gemm(None, None, None, None, None, 4, 4, 8, 8, 4, 4, 4, 4, 3, 0, 8, 0, _C.DT_FP16, _C.DT_FP16, None)
     assert rc == 1 and b"weight_bits" in lib.conch_last_error()
+    # the modes entry point: ACTIVATION_ONLY needs scales the mixed launcher never passes
+    rc = lib.conch_mixed_precision_gemm_modes(None, None, None, None, None, None, 4, 4, 8, 8, 4, 4, 4, 4, 4, 0, 8, 0, 0, 2,
+                                              _C.DT_FP16, _C.DT_FP16, None)
+    assert rc == 2 and b"activation scales" in lib.conch_last_error()
     with pytest.raises(ValueError):
         _C.check(1, "x")
     with pytest.raises(NotImplementedError):
@@ -79,6 +83,10 @@ def test_fused_ffn_ops_validation_without_gpu():
     assert lib.conch_scaled_gemm_silu_and_mul(None, None, None, None, None, None, 0, 4, 4, 4, 1, 1, 4, 4, 1, 1, 1, _C.DT_INT8, _C.DT_BF16, None) == 0
     rc = lib.conch_mixed_precision_gemm_silu_and_mul(None, None, None, None, None, 4, 4, 8, 8, 4, 4, 4, 4, 3, 0, 8, 0, _C.DT_FP16, _C.DT_FP16, None)
     assert rc == 1 and b"weight_bits" in lib.conch_last_error()
+    # the modes entry point: ACTIVATION_ONLY needs scales the mixed launcher never passes
+    rc = lib.conch_mixed_precision_gemm_modes(None, None, None, None, None, None, 4, 4, 8, 8, 4, 4, 4, 4, 4, 0, 8, 0, 0, 2,
+                                              _C.DT_FP16, _C.DT_FP16, None)
+    assert rc == 2 and b"activation scales" in lib.conch_last_error()
     # host side: B / the packed weights need an even number of columns [gate | up]; host tensors are refused
     s = torch.tensor([1.0])
     a = torch.zeros(4, 128, dtype=torch.int8)

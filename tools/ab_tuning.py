@@ -17,7 +17,7 @@ from conch_amd import _C  # noqa: E402
 from conch_amd.kernels.quantization import gemm as kg  # noqa: E402
 from conch_amd.ops.quantization.gemm import create_scaled_metadata  # noqa: E402
 
-KEYS = {"variant": 0, "nt": 1, "nosplitk": 2, "skinny": 3, "sched": 4}
+KEYS = {"variant": 0, "nt": 1, "nosplitk": 2, "skinny": 3, "sched": 4, "persist": 5, "epi": 6}
 SHAPES = {"c3": (4096, 4096, 11008, "fp8"), "c3i8": (4096, 4096, 11008, "int8"), "c2": (128, 4096, 4096, "int8"),
           "c2fp8": (128, 4096, 4096, "fp8"), "c5shard": (8192, 8192, 3584, "fp8"), "sq8k": (8192, 8192, 8192, "fp8")}
 

@@ -46,6 +46,31 @@ def read_probe(fn_name: str, blocks: int):
             clocks.append((t1 - t0) / (r1 - r0) * 0.1)  # GHz
             loops.append((r1 - r0) * 0.01)  # us
             spans.append((r0, r1, r_in, r_out))
+    if "--persist" in sys.argv:
+        # tile b + 256 follows tile b on the same workgroup (persistent) or roughly the same CU slot (plain launch)
+        raw = {b: tuple(buf[8 * b + i] for i in (1, 3, 5, 7)) for b in range(blocks) if buf[8 * b + 3] > buf[8 * b + 1]}
+        gaps = sorted((raw[b + N_CU][0] - raw[b][1]) * 0.01 for b in raw if b + N_CU in raw)
+        tails = sorted((raw[b + N_CU][0] - raw[b][3]) * 0.01 for b in raw if b + N_CU in raw and raw[b][3] > raw[b][1])
+        if gaps:
+            print(f"    K loop end of tile b -> K loop start of tile b+{N_CU}: median {statistics.median(gaps):.2f} us  p10 {gaps[len(gaps) // 10]:.2f}  p90 {gaps[len(gaps) * 9 // 10]:.2f}")
+        if tails:
+            print(f"    last store issued of tile b -> K loop start of tile b+{N_CU}: median {statistics.median(tails):.2f} us")
+        first_steps = None
+    if "--classes" in sys.argv and loops:
+        # two-width tile schedules: the K loops fall into a short (192-column) and a long (256-column) class
+        ls = sorted(loops)
+        cut = (ls[0] + ls[-1]) / 2
+        short, long_ = [v for v in ls if v < cut], [v for v in ls if v >= cut]
+        for name, grp in (("short", short), ("long", long_)):
+            if grp:
+                print(f"    K loops, {name} class: n={len(grp)}  median {statistics.median(grp):.2f} us  min {grp[0]:.2f}  max {grp[-1]:.2f}")
+        epi = sorted((sp[3] - sp[1]) * 0.01 for sp in spans if sp[3] > sp[1])
+        pro = sorted((sp[0] - sp[2]) * 0.01 for sp in spans if sp[0] > sp[2]) or [0.0]
+        if epi:
+            print(f"    K loop end -> stores issued: median {statistics.median(epi):.2f} us  p10 {epi[len(epi) // 10]:.2f}  p90 {epi[len(epi) * 9 // 10]:.2f};  "
+                  f"entry -> K loop: median {statistics.median(pro):.2f} us")
+        first, last = min(sp[2] for sp in spans), max(sp[3] for sp in spans)
+        print(f"    first entry -> last exit {(last - first) * 0.01:.1f} us; sum of K loops / CU {sum(loops) / N_CU:.1f} us")
     if "--timeline" in sys.argv and spans:
         # K-loop start / end of the workgroups of the LAST launch, in start order, relative to the first start
         spans.sort()
@@ -97,7 +122,7 @@ def scaled_case(m, k, n, dtype, flops_per_clk_cu, zeros=False):
     md = create_scaled_metadata(a, b, sa, sb, out.dtype)
     us = sustained(lambda: kg.scaled_gemm_launcher(out, a, b, sa, sb, md), SECONDS)
     tiles = -(-m // 256) * -(-n // 256)
-    ghz, loop_us, loop_max = read_probe("conch_debug_probe_scaled", tiles)
+    ghz, loop_us, loop_max = read_probe("conch_debug_probe_scaled", -(-m // 256) * -(-n // 192) if "--sched" in sys.argv else tiles)
     rounds = -(-tiles // N_CU)
     # per-workgroup occupancy of its CU's matrix pipes during its own K loop
     occ = (2.0 * 256 * 256 * k) / (flops_per_clk_cu * ghz * 1e9 * loop_us * 1e-6)
@@ -137,6 +162,18 @@ def mixed_case(m, k, n, dtype, bits):
 
 
 if __name__ == "__main__":
+    if "--persist" in sys.argv:  # tile-boundary study: plain launch against persistent workgroups
+        for mode in (1, 2):
+            _C.set_tuning(5, mode)
+            print(f"-- CONCH_TUNE_PERSISTENT = {mode}")
+            scaled_case(4096, 4096, 11008, torch.float8_e4m3fn, 8138.0)
+        sys.exit(0)
+    if "--sched" in sys.argv:  # tile-schedule study of the headline shape only
+        for sched in (int(v) for v in sys.argv[sys.argv.index("--sched") + 1].split(",")):
+            _C.set_tuning(4, sched)
+            print(f"-- CONCH_TUNE_TILE_SCHEDULE = {sched}")
+            scaled_case(4096, 4096, 11008, torch.float8_e4m3fn, 8138.0)
+        sys.exit(0)
     # dense peak per CU per clock: 5e15 / 256 / 2.4e9 (fp8, int8), half that for fp16 / bf16
     scaled_case(4096, 4096, 11008, torch.float8_e4m3fn, 8138.0)
     if "--zeros" in sys.argv:
