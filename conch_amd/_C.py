@@ -87,6 +87,9 @@ _SIGNATURES = {
         c_int,
         [c_void_p] * 5 + [_I64] * 8 + [c_int] * 6 + [c_void_p],
     ),
+    "conch_bnb_quantize_blockwise": (c_int, [c_void_p] * 4 + [_I64, c_int, c_int, c_int, c_int, c_void_p]),
+    "conch_bnb_dequantize_blockwise": (c_int, [c_void_p] * 4 + [_I64, c_int, c_int, c_int, c_int, c_void_p]),
+    "conch_bnb_gemm_4bit": (c_int, [c_void_p] * 4 + [_I64] * 5 + [c_int] * 5 + [c_void_p]),
     "conch_mixed_precision_gemm_modes": (
         c_int,
         [c_void_p] * 6 + [_I64] * 8 + [c_int] * 8 + [c_void_p],

@@ -1,0 +1,377 @@
+// bitsandbytes-style blockwise quantisation: NF4 / FP4 (two codes per byte, high nibble first) and the
+// general 8-bit form with a 256-entry code book, per-block absmax scaling.
+//
+// Replaces the Triton kernels of conch/kernels/quantization/bitsandbytes/{quantize,dequantize}_blockwise.py (one program per
+// block walking its elements ONE AT A TIME -- the reference's slowest kernels, README.md:66-67); arithmetic = the reference's
+// PyTorch implementation (conch/reference/quantization/bitsandbytes/*.py; oracle/bnb.py pins it):
+//   quantise    absmax[b] = max |x| over the block (exact, stored in the absmax tensor's dtype);  v = float(x) * (1.0f / float(absmax));
+//               code = position of v among the format's decision thresholds (strict >), fp4 on |v| with the sign in bit 3;
+//               8-bit: seven bisection steps over the code book from pivot 127, then the nearer neighbour
+//   dequantise  out = out_dtype( absmax_dtype( value[code] * float(absmax[b]) ) )
+// gfx950 design: 16-byte loads (8 fp16 / bf16 elements per lane), a block = a group of blocksize/8 lanes of one wave (up to
+// 512 elements; larger blocks take 2 / 4 / 8 register-resident passes of the wave), segmented wave reduction by xor shuffles,
+// one dword (4-bit) or two dwords (8-bit) stored per lane: one pass over HBM.  The code book sits in LDS.
+#include "common.hpp"
+#include "gemm.hpp"
+
+namespace conch {
+namespace {
+
+enum { kQtNf4 = 0, kQtFp4 = 1, kQt8bit = 2 };
+
+__device__ const float kNf4Values[16] = {-1.0f, -0.6961928009986877f, -0.5250730514526367f, -0.39491748809814453f,
+                                         -0.28444138169288635f, -0.18477343022823334f, -0.09105003625154495f, 0.0f,
+                                         0.07958029955625534f, 0.16093020141124725f, 0.24611230194568634f, 0.33791524171829224f,
+                                         0.44070982933044434f, 0.5626170039176941f, 0.7229568362236023f, 1.0f};
+__device__ const float kFp4Values[16] = {0.0f, 0.0052083333f, 0.6666666f, 1.0f, 0.333333f, 0.5f, 0.166666f, 0.25f,
+                                         -0.0f, -0.0052083333f, -0.666666f, -1.0f, -0.333333f, -0.5f, -0.166666f, -0.25f};
+
+__device__ __forceinline__ uint32_t nf4_code(float v) {
+  // reference/.../quantize_blockwise.py:38-74: a binary search with strict > over these ascending thresholds
+  uint32_t c = 0;
+  c += v > -0.8480964004993439f;
+  c += v > -0.6106329262256622f;
+  c += v > -0.4599952697753906f;
+  c += v > -0.33967943489551544f;
+  c += v > -0.23460740596055984f;
+  c += v > -0.13791173323988914f;
+  c += v > -0.045525018125772476f;
+  c += v > 0.03979014977812767f;
+  c += v > 0.1202552504837513f;
+  c += v > 0.2035212516784668f;
+  c += v > 0.2920137718319893f;
+  c += v > 0.3893125355243683f;
+  c += v > 0.5016634166240692f;
+  c += v > 0.6427869200706482f;
+  c += v > 0.8614784181118011f;
+  return c;
+}
+
+__device__ __forceinline__ uint32_t fp4_code(float v) {
+  // :12-35: sign in bit 3, the magnitude's rank among seven thresholds mapped through the format's code order
+  const float a = fabsf(v);
+  uint32_t r = 0;
+  r += a > 0.00260417f;
+  r += a > 0.0859375f;
+  r += a > 0.208333334f;
+  r += a > 0.29166667f;
+  r += a > 0.4166667f;
+  r += a > 0.5833334f;
+  r += a > 0.83333334f;
+  const uint32_t by_rank = 0x32547610u;  // rank r -> code: 0,1,6,7,4,5,2,3 (nibble r)
+  return ((by_rank >> (4 * r)) & 0xfu) + (v < 0.0f ? 8u : 0u);
+}
+
+__device__ __forceinline__ uint32_t code8(float x, const float* code) {
+  // :77-119
+  int pivot = 127, upper_pivot = 255, lower_pivot = 0;
+  float lower = -1.0f, upper = 1.0f;
+  float val = code[pivot];
+#pragma unroll
+  for (int step = 64; step >= 1; step >>= 1) {
+    if (x > val) {
+      lower_pivot = pivot;
+      lower = val;
+      pivot += step;
+    } else {
+      upper_pivot = pivot;
+      upper = val;
+      pivot -= step;
+    }
+    val = code[pivot];
+  }
+  if (upper_pivot == 255) upper = code[upper_pivot];
+  if (lower_pivot == 0) lower = code[lower_pivot];
+  if (x > val) {
+    const float mid = pin_f32(upper + val) * 0.5f;
+    return (uint32_t)(x > mid ? upper_pivot : pivot);
+  }
+  const float mid = pin_f32(lower + val) * 0.5f;
+  return (uint32_t)(x < mid ? lower_pivot : pivot);
+}
+
+template <int DT>
+__device__ __forceinline__ void store_scalar(void* p, int64_t i, float v) {
+  if constexpr (DT == CONCH_DT_FP32) ((float*)p)[i] = v;
+  else ((uint16_t*)p)[i] = float_to_bits16<DT>(v);
+}
+
+// 8 consecutive elements starting at `e0` (a multiple of 8); elements at or beyond `end` read as absent (valid = false)
+template <int XDT>
+__device__ __forceinline__ void load8(const void* x, int64_t e0, int64_t end, float (&f)[8]) {
+  if (e0 + 8 <= end) {
+    if constexpr (XDT == CONCH_DT_FP32) {
+      const f32x4 a = *(const f32x4*)((const float*)x + e0), b = *(const f32x4*)((const float*)x + e0 + 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f[i] = a[i];
+        f[4 + i] = b[i];
+      }
+    } else {
+      const u16x8 v = *(const u16x8*)((const uint16_t*)x + e0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[i] = bits16_to_float<XDT>(v[i]);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = e0 + i < end ? load_as_float<XDT>(x, e0 + i) : 0.0f;
+  }
+}
+
+constexpr int kBnbThreads = 256;
+
+// PASSES x 512 = elements a wave covers per block sweep.  blocksize <= 512: PASSES = 1 and a wave holds 512 / blocksize blocks
+// side by side (lane group = blocksize / 8 lanes); larger blocks: PASSES = blocksize / 512, one block per wave.
+template <int XDT, int ADT, int QT, int PASSES>
+__global__ __launch_bounds__(kBnbThreads) void bnb_quantize_kernel(uint8_t* __restrict__ out, void* __restrict__ absmax,
+                                                                    const void* __restrict__ x, const float* __restrict__ code,
+                                                                    int64_t n, int blocksize) {
+  __shared__ float lcode[256];
+  if constexpr (QT == kQt8bit) {
+    lcode[threadIdx.x] = code[threadIdx.x];
+    __syncthreads();
+  }
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (kBnbThreads / 64) + (threadIdx.x >> 6);
+  const int64_t span = (int64_t)PASSES * 512;           // elements per wave
+  const int64_t w0 = wave * span;                       // first element of this wave
+  if (w0 >= n) return;
+  float f[PASSES][8];
+  float amax = 0.0f;
+#pragma unroll
+  for (int ps = 0; ps < PASSES; ++ps) {
+    const int64_t e0 = w0 + ps * 512 + lane * 8;
+    // the block this lane's elements belong to ends at blk_end: elements of the NEXT block never enter this one's maximum
+    const int64_t blk = e0 / blocksize;
+    const int64_t blk_end = min((blk + 1) * (int64_t)blocksize, n);
+    load8<XDT>(x, e0, blk_end, f[ps]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(f[ps][i]));
+  }
+  // reduce over the lane group that shares a block (all 64 lanes when the block is >= 512 elements)
+  const int group = PASSES > 1 ? 64 : blocksize / 8;
+  for (int off = 1; off < group; off <<= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+  const int64_t e_first = w0 + lane * 8;
+  const int64_t blk = e_first / blocksize;
+  if (e_first < n && (lane & (group - 1)) == 0) {
+    if constexpr (ADT == CONCH_DT_FP32) ((float*)absmax)[blk] = amax;
+    else ((uint16_t*)absmax)[blk] = float_to_bits16<ADT>(amax);  // exact: amax is a value of the input dtype
+  }
+  const float inv = 1.0f / amax;  // IEEE division, like torch; an all-zero block gives inf and v = NaN (every comparison false)
+#pragma unroll
+  for (int ps = 0; ps < PASSES; ++ps) {
+    const int64_t e0 = w0 + ps * 512 + lane * 8;
+    if (e0 >= n) continue;
+    const int64_t b = e0 / blocksize;
+    const int64_t blk_end = min((b + 1) * (int64_t)blocksize, n);
+    const int64_t valid = blk_end - e0;  // elements of this lane that exist (> 0)
+    uint32_t c[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float v = f[ps][i] * inv;
+      if constexpr (QT == kQtNf4) c[i] = nf4_code(v);
+      else if constexpr (QT == kQtFp4) c[i] = fp4_code(v);
+      else c[i] = code8(v, lcode);
+    }
+    if constexpr (QT == kQt8bit) {
+      uint8_t* dst = out + e0;
+      if (valid >= 8) {
+        i32x2 pk;
+        pk[0] = (int)(c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24));
+        pk[1] = (int)(c[4] | (c[5] << 8) | (c[6] << 16) | (c[7] << 24));
+        *(i32x2*)dst = pk;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (i < valid) dst[i] = (uint8_t)c[i];
+      }
+    } else {
+      // pair j of a block = elements 2j, 2j+1 -> one byte, first element in the high nibble; a block of odd length drops its
+      // last element (quantize_blockwise.py:162); output byte of element e of block b: b * blocksize/2 + (e - b*blocksize)/2
+      uint8_t* dst = out + b * (blocksize / 2) + (e0 - b * blocksize) / 2;
+      const uint32_t word = ((c[0] << 4) | c[1]) | (((c[2] << 4) | c[3]) << 8) | (((c[4] << 4) | c[5]) << 16) | (((c[6] << 4) | c[7]) << 24);
+      if (valid >= 8) {
+        *(uint32_t*)dst = word;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (2 * j + 1 < valid) dst[j] = (uint8_t)(word >> (8 * j));
+      }
+    }
+  }
+}
+
+// one thread = 8 consecutive output elements (4 packed bytes, or 8 code bytes)
+template <int ODT, int ADT, int QT>
+__global__ __launch_bounds__(kBnbThreads) void bnb_dequantize_kernel(void* __restrict__ out, const uint8_t* __restrict__ xq,
+                                                                      const void* __restrict__ absmax, const float* __restrict__ code,
+                                                                      int64_t n, int blocksize, int64_t out_stride_row, int64_t row_len) {
+  __shared__ float lut[256];
+  if constexpr (QT == kQt8bit) lut[threadIdx.x] = code[threadIdx.x];
+  else if (threadIdx.x < 16) lut[threadIdx.x] = QT == kQtNf4 ? kNf4Values[threadIdx.x] : kFp4Values[threadIdx.x];
+  __syncthreads();
+  const int64_t e0 = ((int64_t)blockIdx.x * kBnbThreads + threadIdx.x) * 8;
+  if (e0 >= n) return;
+  const int64_t b = e0 / blocksize;  // 8 | blocksize: the eight elements share a block
+  float am;
+  if constexpr (ADT == CONCH_DT_FP32) am = ((const float*)absmax)[b];
+  else am = bits16_to_float<ADT>(((const uint16_t*)absmax)[b]);
+  // 4-bit inputs only ever hold an even number of elements (dequantize_blockwise.py: output_size even)
+  const int64_t valid = min((int64_t)8, n - e0);
+  uint32_t c[8];
+  if constexpr (QT == kQt8bit) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) c[i] = i < valid ? xq[e0 + i] : 0u;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t byte = 2 * j < valid ? xq[e0 / 2 + j] : 0u;
+      c[2 * j] = byte >> 4;
+      c[2 * j + 1] = byte & 0xfu;
+    }
+  }
+  // row-strided output (the GEMM's W^T scratch has the same rows): element e -> row e / row_len, column e % row_len
+  const int64_t row = e0 / row_len, col = e0 - row * row_len;
+  const int64_t o0 = row * out_stride_row + col;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (i >= valid) break;
+    float r = pin_f32(lut[c[i]] * am);
+    if constexpr (ADT != CONCH_DT_FP32) r = bits16_to_float<ADT>(float_to_bits16<ADT>(r));  // the product lives in absmax's dtype
+    store_scalar<ODT>(out, o0 + i, r);
+  }
+}
+
+template <int XDT, int ADT, int QT>
+int launch_quantize(uint8_t* out, void* absmax, const void* x, const float* code, int64_t n, int blocksize, hipStream_t stream) {
+  const int passes = blocksize <= 512 ? 1 : blocksize / 512;
+  const int64_t waves = (n + (int64_t)passes * 512 - 1) / ((int64_t)passes * 512);
+  const dim3 grid((unsigned)((waves + 3) / 4)), block(kBnbThreads);
+  switch (passes) {
+    case 1: hipLaunchKernelGGL((bnb_quantize_kernel<XDT, ADT, QT, 1>), grid, block, 0, stream, out, absmax, x, code, n, blocksize); break;
+    case 2: hipLaunchKernelGGL((bnb_quantize_kernel<XDT, ADT, QT, 2>), grid, block, 0, stream, out, absmax, x, code, n, blocksize); break;
+    case 4: hipLaunchKernelGGL((bnb_quantize_kernel<XDT, ADT, QT, 4>), grid, block, 0, stream, out, absmax, x, code, n, blocksize); break;
+    default: hipLaunchKernelGGL((bnb_quantize_kernel<XDT, ADT, QT, 8>), grid, block, 0, stream, out, absmax, x, code, n, blocksize); break;
+  }
+  return check_launch("bnb_quantize_blockwise");
+}
+
+template <int XDT, int ADT>
+int quantize_qt(uint8_t* out, void* absmax, const void* x, const float* code, int64_t n, int blocksize, int qt, hipStream_t stream) {
+  if (qt == kQtNf4) return launch_quantize<XDT, ADT, kQtNf4>(out, absmax, x, code, n, blocksize, stream);
+  if (qt == kQtFp4) return launch_quantize<XDT, ADT, kQtFp4>(out, absmax, x, code, n, blocksize, stream);
+  return launch_quantize<XDT, ADT, kQt8bit>(out, absmax, x, code, n, blocksize, stream);
+}
+
+template <int XDT>
+int quantize_adt(uint8_t* out, void* absmax, const void* x, const float* code, int64_t n, int blocksize, int qt, int adt, hipStream_t stream) {
+  if (adt == CONCH_DT_FP32) return quantize_qt<XDT, CONCH_DT_FP32>(out, absmax, x, code, n, blocksize, qt, stream);
+  if (adt == CONCH_DT_FP16) return quantize_qt<XDT, CONCH_DT_FP16>(out, absmax, x, code, n, blocksize, qt, stream);
+  return quantize_qt<XDT, CONCH_DT_BF16>(out, absmax, x, code, n, blocksize, qt, stream);
+}
+
+template <int ODT, int ADT>
+int dequantize_qt(void* out, const uint8_t* xq, const void* absmax, const float* code, int64_t n, int blocksize, int qt,
+                  int64_t out_stride_row, int64_t row_len, hipStream_t stream) {
+  const dim3 grid((unsigned)((n + 8 * kBnbThreads - 1) / (8 * kBnbThreads))), block(kBnbThreads);
+  if (qt == kQtNf4) hipLaunchKernelGGL((bnb_dequantize_kernel<ODT, ADT, kQtNf4>), grid, block, 0, stream, out, xq, absmax, code, n, blocksize, out_stride_row, row_len);
+  else if (qt == kQtFp4) hipLaunchKernelGGL((bnb_dequantize_kernel<ODT, ADT, kQtFp4>), grid, block, 0, stream, out, xq, absmax, code, n, blocksize, out_stride_row, row_len);
+  else hipLaunchKernelGGL((bnb_dequantize_kernel<ODT, ADT, kQt8bit>), grid, block, 0, stream, out, xq, absmax, code, n, blocksize, out_stride_row, row_len);
+  return check_launch("bnb_dequantize_blockwise");
+}
+
+template <int ODT>
+int dequantize_adt(void* out, const uint8_t* xq, const void* absmax, const float* code, int64_t n, int blocksize, int qt, int adt,
+                   int64_t out_stride_row, int64_t row_len, hipStream_t stream) {
+  if (adt == CONCH_DT_FP32) return dequantize_qt<ODT, CONCH_DT_FP32>(out, xq, absmax, code, n, blocksize, qt, out_stride_row, row_len, stream);
+  if (adt == CONCH_DT_FP16) return dequantize_qt<ODT, CONCH_DT_FP16>(out, xq, absmax, code, n, blocksize, qt, out_stride_row, row_len, stream);
+  return dequantize_qt<ODT, CONCH_DT_BF16>(out, xq, absmax, code, n, blocksize, qt, out_stride_row, row_len, stream);
+}
+
+bool float_dt(int dt) { return dt == CONCH_DT_FP32 || dt == CONCH_DT_FP16 || dt == CONCH_DT_BF16; }
+
+int check_common(int64_t n, int blocksize, int qt, int adt, const void* code, const char* what) {
+  CONCH_CHECK_ARG(n >= 0, "%s: negative size", what);
+  CONCH_CHECK_ARG(blocksize >= 64 && blocksize <= 4096 && (blocksize & (blocksize - 1)) == 0,
+                  "%s: blocksize %d (want a power of two in 64..4096)", what, blocksize);
+  CONCH_CHECK_ARG(qt >= kQtNf4 && qt <= kQt8bit, "%s: quant type %d (0 = nf4, 1 = fp4, 2 = 8-bit code book)", what, qt);
+  CONCH_CHECK_ARG(float_dt(adt), "%s: absmax dtype %d (want FP32 / FP16 / BF16)", what, adt);
+  CONCH_CHECK_ARG(qt != kQt8bit || code, "%s: the 8-bit form needs its 256-entry code book", what);
+  return CONCH_OK;
+}
+
+int dequantize_any(void* out, const uint8_t* xq, const void* absmax, const float* code, int64_t n, int blocksize, int qt, int adt, int odt,
+                   int64_t out_stride_row, int64_t row_len, hipStream_t stream) {
+  if (odt == CONCH_DT_FP32) return dequantize_adt<CONCH_DT_FP32>(out, xq, absmax, code, n, blocksize, qt, adt, out_stride_row, row_len, stream);
+  if (odt == CONCH_DT_FP16) return dequantize_adt<CONCH_DT_FP16>(out, xq, absmax, code, n, blocksize, qt, adt, out_stride_row, row_len, stream);
+  return dequantize_adt<CONCH_DT_BF16>(out, xq, absmax, code, n, blocksize, qt, adt, out_stride_row, row_len, stream);
+}
+
+}  // namespace
+}  // namespace conch
+
+using namespace conch;
+
+extern "C" int conch_bnb_quantize_blockwise(uint8_t* out, void* absmax, const void* x, const float* code, int64_t n, int blocksize,
+                                            int quant_type, int x_dtype, int absmax_dtype, void* stream) {
+  if (int rc = check_common(n, blocksize, quant_type, absmax_dtype, code, "bnb_quantize_blockwise")) return rc;
+  CONCH_CHECK_ARG(float_dt(x_dtype), "bnb_quantize_blockwise: input dtype %d (want FP32 / FP16 / BF16)", x_dtype);
+  if (n == 0) return CONCH_OK;
+  CONCH_CHECK_ARG(out && absmax && x, "bnb_quantize_blockwise: NULL pointer");
+  CONCH_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 7) == 0, "bnb_quantize_blockwise: x must be 16-byte and out 8-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  if (x_dtype == CONCH_DT_FP32) return quantize_adt<CONCH_DT_FP32>(out, absmax, x, code, n, blocksize, quant_type, absmax_dtype, s);
+  if (x_dtype == CONCH_DT_FP16) return quantize_adt<CONCH_DT_FP16>(out, absmax, x, code, n, blocksize, quant_type, absmax_dtype, s);
+  return quantize_adt<CONCH_DT_BF16>(out, absmax, x, code, n, blocksize, quant_type, absmax_dtype, s);
+}
+
+extern "C" int conch_bnb_dequantize_blockwise(void* out, const uint8_t* xq, const void* absmax, const float* code, int64_t n, int blocksize,
+                                              int quant_type, int out_dtype, int absmax_dtype, void* stream) {
+  if (int rc = check_common(n, blocksize, quant_type, absmax_dtype, code, "bnb_dequantize_blockwise")) return rc;
+  CONCH_CHECK_ARG(float_dt(out_dtype), "bnb_dequantize_blockwise: output dtype %d (want FP32 / FP16 / BF16)", out_dtype);
+  CONCH_CHECK_ARG(quant_type == kQt8bit || n % 2 == 0, "bnb_dequantize_blockwise: 4-bit outputs have an even number of elements");
+  if (n == 0) return CONCH_OK;
+  CONCH_CHECK_ARG(out && absmax && xq, "bnb_dequantize_blockwise: NULL pointer");
+  return dequantize_any(out, xq, absmax, code, n, blocksize, quant_type, absmax_dtype, out_dtype, n, n, (hipStream_t)stream);
+}
+
+// y = x @ dequantise(W)^T for a bitsandbytes-style 4-bit weight W [N][K] (flattened, blocks of `blocksize` along the flat index,
+// two codes per byte): W is dequantised into library scratch in x's dtype -- its rows ARE the K-contiguous B^T the tile kernel
+// wants -- and multiplied on the 16-bit MFMA tile kernel of gemm_mfma.hip (fp32 accumulation).
+extern "C" int conch_bnb_gemm_4bit(void* c, const void* x, const uint8_t* w_packed, const void* absmax, int64_t m, int64_t n, int64_t k,
+                                   int64_t x_stride_m, int64_t c_stride_m, int blocksize, int quant_type, int absmax_dtype, int x_dtype,
+                                   int out_dtype, void* stream) {
+  if (int rc = check_common(n * k, blocksize, quant_type, absmax_dtype, nullptr, "bnb_gemm_4bit")) return rc;
+  CONCH_CHECK_ARG(m >= 0 && n >= 0 && k >= 0, "bnb_gemm_4bit: negative shape");
+  if (quant_type == kQt8bit || (x_dtype != CONCH_DT_FP16 && x_dtype != CONCH_DT_BF16) || (out_dtype != CONCH_DT_FP16 && out_dtype != CONCH_DT_BF16)) {
+    set_error("bnb_gemm_4bit: nf4 / fp4 weights with fp16 / bf16 activations and outputs only");
+    return CONCH_ERR_UNSUPPORTED;
+  }
+  if (m == 0 || n == 0) return CONCH_OK;
+  CONCH_CHECK_ARG(c && x && w_packed && absmax, "bnb_gemm_4bit: NULL pointer");
+  const int64_t lim = (int64_t)1 << 31;
+  if (k % 64 || k < 128 || (x_stride_m * 2) % 16 || ((uintptr_t)x & 15) || m * x_stride_m * 2 >= lim || n * k * 2 >= lim || m >= (1 << 24) || n >= (1 << 24)) {
+    set_error("bnb_gemm_4bit: needs K %% 64 == 0, K >= 128, 16-byte aligned activation rows and operands below 2 GiB");
+    return CONCH_ERR_UNSUPPORTED;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  void* wt = nullptr;
+  if (int rc = get_scratch(s, kScratchRepack, (size_t)n * k * 2, &wt)) return rc;
+  if (int rc = dequantize_any(wt, w_packed, absmax, nullptr, n * k, blocksize, quant_type, absmax_dtype, x_dtype, k, k, s)) return rc;
+  ScaledGemmArgs g{};
+  g.c = c;
+  g.a = x;
+  g.b = wt;
+  g.m = m;
+  g.n = n;
+  g.k = k * 2;
+  g.a_stride_m = x_stride_m * 2;
+  g.b_stride_n = k * 2;
+  g.a_stride_k = g.b_stride_k = 1;
+  g.c_stride_m = c_stride_m;
+  g.c_stride_n = 1;
+  g.scale_a_numel = g.scale_b_numel = 1;
+  g.in_dtype = x_dtype;
+  g.out_dtype = out_dtype;
+  return launch_scaled_gemm_mfma_16bit(g, s);
+}

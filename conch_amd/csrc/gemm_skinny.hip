@@ -440,12 +440,12 @@ int launch_splitk(const ScaledGemmArgs& p, int slices, hipStream_t stream) {
   int mode = tuning(CONCH_TUNE_SKINNY_MODE);
   int rows = p.m <= 32 ? 32 : p.m <= 64 ? 64 : 128;
   if (mode == 0) {
-    // measured (profiles/r02/splitk_modes.txt): the one-launch form wins when its workgroups -- 2048-byte slices, <= 64-row
-    // blocks -- fit one round of the chip (C2: 13.0 against 13.5 us) and for <= 32-row batches up to two rounds; with
-    // 1024-byte slices the last arriver's serial pass over four or more slabs costs more than the second launch
+    // measured (profiles/r02/splitk_modes.txt, 14 decode shapes x {1, 3}): the one-launch form wins only where its workgroups --
+    // 2048-byte slices, two 64-row blocks -- fill exactly one round of the chip (C2: 13.0 against 13.5 us); for <= 64 rows its
+    // sixteen steps in flight per workgroup lose to the 8-step slices, and with 1024-byte slices (mode 2) the last arriver's
+    // serial pass over four or more slabs costs more than the second launch it saves (16.0 against 13.5 us on C2)
     const int64_t wgs = ((p.n + kSpN - 1) / kSpN) * (p.k / (2 * kSpSliceK)) * ((p.m + 63) / 64);
-    const int cus = device_cu_count();
-    mode = (p.k % (2 * kSpSliceK) == 0 && (wgs <= cus || (p.m <= 32 && wgs <= 2 * cus))) ? 3 : 1;
+    mode = (p.m > 64 && p.m <= 128 && p.k % (2 * kSpSliceK) == 0 && wgs <= device_cu_count()) ? 3 : 1;
   }
   int steps = kSpSteps;
   if (mode == 3 && p.k % (2 * kSpSliceK) == 0) {

@@ -265,6 +265,25 @@ int conch_mixed_precision_gemm_silu_and_mul(void* c, const void* x, const int32_
                                int out_dtype, void* stream);
 
 /*
+ * bitsandbytes-style blockwise quantisation (replaces quantize_blockwise_launcher /
+ * dequantize_blockwise_launcher of conch/kernels/quantization/bitsandbytes/*.py; semantics = the reference's PyTorch
+ * implementation, conch/reference/quantization/bitsandbytes/*.py).  quant_type: 0 = nf4, 1 = fp4 (two codes per byte, the
+ * first element in the high nibble), 2 = 8-bit with a 256-entry fp32 code book `code` (NULL otherwise).  blocksize: a power
+ * of two in 64..4096; block b covers elements [b * blocksize, (b+1) * blocksize) of the flat tensor of `n` elements.
+ *   quantise:    absmax[b] = max |x| (stored in absmax_dtype);  code(x * (1 / absmax[b]))
+ *   dequantise:  out[e] = out_dtype( absmax_dtype( value[code] * absmax[e / blocksize] ) )
+ */
+int conch_bnb_quantize_blockwise(uint8_t* out, void* absmax, const void* x, const float* code, int64_t n, int blocksize,
+                                 int quant_type, int x_dtype, int absmax_dtype, void* stream);
+int conch_bnb_dequantize_blockwise(void* out, const uint8_t* xq, const void* absmax, const float* code, int64_t n, int blocksize,
+                                   int quant_type, int out_dtype, int absmax_dtype, void* stream);
+/* C[M][N] = X[M][K] @ dequantise(W)^T for a 4-bit (nf4 / fp4) weight W[N][K]: dequantised into library scratch in x_dtype, then
+ * the 16-bit MFMA tile kernel (fp32 accumulation).  K % 64 == 0. */
+int conch_bnb_gemm_4bit(void* c, const void* x, const uint8_t* w_packed, const void* absmax, int64_t m, int64_t n, int64_t k,
+                        int64_t x_stride_m, int64_t c_stride_m, int blocksize, int quant_type, int absmax_dtype, int x_dtype,
+                        int out_dtype, void* stream);
+
+/*
  * Timing helper used by bench.py: launches `iters` back-to-back scaled_gemm calls on `stream`
  * bracketed by HIP events recorded ON THAT STREAM and returns the average milliseconds per call
  * in *avg_ms (synchronises the stream; not for use inside graph capture).

@@ -46,3 +46,9 @@ from oracle.reference import (  # noqa: F401
     silu_and_mul_ref,
     unpack_rows_ref,
 )
+
+from oracle.bnb import (  # noqa: E402,F401
+    create_dynamic_map_ref,
+    dequantize_blockwise_ref,
+    quantize_blockwise_ref,
+)

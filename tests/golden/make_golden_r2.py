@@ -192,7 +192,70 @@ def gen_modes() -> None:
     np.savez_compressed(OUT / "gemm_modes.npz", **out)
 
 
-GENERATORS = {"dyn": gen_dynamic, "modes": gen_modes}
+def gen_bnb() -> None:
+    """bitsandbytes-style blockwise NF4 / FP4 / FP8: the reference's PyTorch implementations
+    (conch/reference/quantization/bitsandbytes/{quantize,dequantize}_blockwise.py) on the recipes of its tests
+    (tests/quantize_blockwise_test.py:150-170, tests/dequantize_blockwise_test.py:126-140), plus the dynamic 8-bit map
+    (conch/ops/quantization/bitsandbytes/functional.py:30-84) and edge inputs (an all-zero block, values on the decision
+    thresholds, an odd tail)."""
+    from conch.ops.quantization.bitsandbytes.functional import _create_dynamic_map
+    from conch.reference.quantization.bitsandbytes.dequantize_blockwise import dequantize_blockwise_launcher as ref_dequant
+    from conch.reference.quantization.bitsandbytes.quantize_blockwise import quantize_blockwise_launcher as ref_quant
+
+    out: dict[str, np.ndarray] = {}
+    code = _create_dynamic_map()
+    out["dynamic_map"] = code.numpy().copy()
+    for qt in ("nf4", "fp4", "fp8"):
+        for blocksize in (64, 1024):
+            for mult in (2.5, 6):
+                for dname, dtype in DT.items():
+                    key = f"{qt}_b{blocksize}_m{mult}_{dname}"
+                    n = int(blocksize * mult)
+                    nblocks = -(-n // blocksize)
+                    # quantize: tests/quantize_blockwise_test.py:150-170 (seed 2)
+                    seed_everything(2)
+                    x = torch.randn((n,), dtype=dtype)
+                    if qt == "fp4":
+                        x = x.uniform_(-1.0, 1.0)
+                    absmax = torch.empty((nblocks,), dtype=dtype)
+                    q = torch.zeros((n,) if qt == "fp8" else ((n + 1) // 2, 1), dtype=torch.uint8)
+                    ref_quant(x, absmax, q.view(-1), code if qt == "fp8" else None, blocksize, n, qt)
+                    out[f"qx_{key}"] = bits(x)
+                    out[f"qabsmax_{key}"] = bits(absmax)
+                    out[f"qout_{key}"] = q.view(-1).numpy().copy()
+                    # dequantize: tests/dequantize_blockwise_test.py:126-140 (seed 0)
+                    seed_everything(0)
+                    nin = n if qt == "fp8" else n // 2
+                    xq = torch.randint(0, 255, (nin,), dtype=torch.uint8)
+                    am = torch.randn((nblocks,), dtype=dtype)
+                    d = torch.empty((n,), dtype=dtype)
+                    ref_dequant(xq, am, d, code if qt == "fp8" else None, blocksize, n, qt)
+                    out[f"dx_{key}"] = xq.numpy().copy()
+                    out[f"dabsmax_{key}"] = bits(am)
+                    out[f"dout_{key}"] = bits(d)
+    # edges: fp32 input, blocksize 64: block 0 all zero, block 1 = the decision thresholds and their fp32 neighbours,
+    # block 2 short and odd (the last element is dropped by the 4-bit packing)
+    nf4_t = [-0.8480964004993439, -0.6106329262256622, -0.4599952697753906, -0.33967943489551544, -0.23460740596055984,
+             -0.13791173323988914, -0.045525018125772476, 0.03979014977812767, 0.1202552504837513, 0.2035212516784668,
+             0.2920137718319893, 0.3893125355243683, 0.5016634166240692, 0.6427869200706482, 0.8614784181118011]
+    fp4_t = [0.00260417, 0.0859375, 0.208333334, 0.29166667, 0.4166667, 0.5833334, 0.83333334]
+    for qt, ts in (("nf4", nf4_t), ("fp4", fp4_t + [-t for t in fp4_t])):
+        t32 = np.array(ts, dtype=np.float32)
+        probe = np.concatenate([t32, np.nextafter(t32, np.float32(2)), np.nextafter(t32, np.float32(-2)), [1.0, -1.0, 0.0, -0.0]]).astype(np.float32)
+        probe = np.resize(probe, 64).astype(np.float32)
+        probe[0] = 1.0  # the block's absmax: the other values are then quantised as they stand
+        x = torch.from_numpy(np.concatenate([np.zeros(64, np.float32), probe, np.linspace(-0.9, 0.7, 11, dtype=np.float32)]))
+        n = x.numel()
+        absmax = torch.empty((3,), dtype=torch.float32)
+        q = torch.zeros(((n + 1) // 2,), dtype=torch.uint8)
+        ref_quant(x, absmax, q, None, 64, n, qt)
+        out[f"edge_x_{qt}"] = x.numpy().copy()
+        out[f"edge_absmax_{qt}"] = absmax.numpy().copy()
+        out[f"edge_q_{qt}"] = q.numpy().copy()
+    np.savez_compressed(OUT / "bnb_blockwise.npz", **out)
+
+
+GENERATORS = {"dyn": gen_dynamic, "modes": gen_modes, "bnb": gen_bnb}
 
 if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference checkout is only available in the authoring container"

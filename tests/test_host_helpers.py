@@ -230,3 +230,26 @@ def test_mixed_metadata_and_strict_errors():
         create_mixed_precision_metadata(x, wq, ws, zp[:1], 4, 8, 128, strict=True)
     with pytest.raises(NotImplementedError):
         create_mixed_precision_metadata(x, wq, ws, None, 4, 8, 128, scaled_activations=True, strict=True)
+
+
+def test_bnb_dynamic_map_and_shapes(golden):
+    """Host side of the bitsandbytes API: the dynamic 8-bit map equals the reference's bit for bit; shape
+    helpers follow functional.py:107-123; unsupported arguments raise like the reference's."""
+    from conch_amd.ops.quantization.bitsandbytes import functional as F
+
+    np.testing.assert_array_equal(F._create_dynamic_map().numpy().view(np.uint32), golden("bnb_blockwise")["dynamic_map"].view(np.uint32))
+    assert F.get_absmax_shape(160, 64) == (3,)
+    assert F.get_quantized_output_shape(161, "nf4") == (81, 1) and F.get_quantized_output_shape(161, "fp8") == (161,)
+    assert F.get_quantized_output_shape(256, "fp4", torch.bfloat16) == (64, 1)
+    with pytest.raises(NotImplementedError):
+        F.quantize_blockwise(torch.zeros(64), quant_type="int4")
+    with pytest.raises(NotImplementedError):
+        F.quantize_blockwise(torch.zeros(64), blocksize=96)
+    with pytest.raises(ValueError):
+        F.dequantize_blockwise(torch.zeros(32, dtype=torch.uint8))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        F.quantize_4bit(torch.zeros(128))
+    lib = _C.load()
+    assert lib.conch_bnb_quantize_blockwise(None, None, None, None, 128, 96, 0, _C.DT_FP16, _C.DT_FP32, None) == 1
+    assert lib.conch_bnb_dequantize_blockwise(None, None, None, None, 128, 64, 2, _C.DT_FP16, _C.DT_FP32, None) == 1  # no code book
+    assert lib.conch_bnb_dequantize_blockwise(None, None, None, None, 0, 64, 0, _C.DT_FP16, _C.DT_FP32, None) == 0
