@@ -19,31 +19,34 @@ namespace {
 
 enum { kQtNf4 = 0, kQtFp4 = 1, kQt8bit = 2 };
 
-__device__ const float kNf4Values[16] = {-1.0f, -0.6961928009986877f, -0.5250730514526367f, -0.39491748809814453f,
-                                         -0.28444138169288635f, -0.18477343022823334f, -0.09105003625154495f, 0.0f,
-                                         0.07958029955625534f, 0.16093020141124725f, 0.24611230194568634f, 0.33791524171829224f,
-                                         0.44070982933044434f, 0.5626170039176941f, 0.7229568362236023f, 1.0f};
-__device__ const float kFp4Values[16] = {0.0f, 0.0052083333f, 0.6666666f, 1.0f, 0.333333f, 0.5f, 0.166666f, 0.25f,
-                                         -0.0f, -0.0052083333f, -0.666666f, -1.0f, -0.333333f, -0.5f, -0.166666f, -0.25f};
+__device__ const float kNf4Values[16] = {(float)-1.0, (float)-0.6961928009986877, (float)-0.5250730514526367, (float)-0.39491748809814453,
+                                         (float)-0.28444138169288635, (float)-0.18477343022823334, (float)-0.09105003625154495, (float)0.0,
+                                         (float)0.07958029955625534, (float)0.16093020141124725, (float)0.24611230194568634, (float)0.33791524171829224,
+                                         (float)0.44070982933044434, (float)0.5626170039176941, (float)0.7229568362236023, (float)1.0};
+__device__ const float kFp4Values[16] = {(float)0.0, (float)0.0052083333, (float)0.6666666, (float)1.0, (float)0.333333, (float)0.5, (float)0.166666, (float)0.25,
+                                         (float)-0.0, (float)-0.0052083333, (float)-0.666666, (float)-1.0, (float)-0.333333, (float)-0.5, (float)-0.166666, (float)-0.25};
 
+// Constants are written as DOUBLE literals cast to float: the reference's Python floats reach fp32 through a double (several
+// thresholds are exact midpoints of two fp32 NF4 values, i.e. fp32 rounding ties: a decimal -> float literal rounds some of
+// them the other way, caught by the golden edge vectors)
 __device__ __forceinline__ uint32_t nf4_code(float v) {
   // reference/.../quantize_blockwise.py:38-74: a binary search with strict > over these ascending thresholds
   uint32_t c = 0;
-  c += v > -0.8480964004993439f;
-  c += v > -0.6106329262256622f;
-  c += v > -0.4599952697753906f;
-  c += v > -0.33967943489551544f;
-  c += v > -0.23460740596055984f;
-  c += v > -0.13791173323988914f;
-  c += v > -0.045525018125772476f;
-  c += v > 0.03979014977812767f;
-  c += v > 0.1202552504837513f;
-  c += v > 0.2035212516784668f;
-  c += v > 0.2920137718319893f;
-  c += v > 0.3893125355243683f;
-  c += v > 0.5016634166240692f;
-  c += v > 0.6427869200706482f;
-  c += v > 0.8614784181118011f;
+  c += v > (float)-0.8480964004993439;
+  c += v > (float)-0.6106329262256622;
+  c += v > (float)-0.4599952697753906;
+  c += v > (float)-0.33967943489551544;
+  c += v > (float)-0.23460740596055984;
+  c += v > (float)-0.13791173323988914;
+  c += v > (float)-0.045525018125772476;
+  c += v > (float)0.03979014977812767;
+  c += v > (float)0.1202552504837513;
+  c += v > (float)0.2035212516784668;
+  c += v > (float)0.2920137718319893;
+  c += v > (float)0.3893125355243683;
+  c += v > (float)0.5016634166240692;
+  c += v > (float)0.6427869200706482;
+  c += v > (float)0.8614784181118011;
   return c;
 }
 
@@ -51,13 +54,13 @@ __device__ __forceinline__ uint32_t fp4_code(float v) {
   // :12-35: sign in bit 3, the magnitude's rank among seven thresholds mapped through the format's code order
   const float a = fabsf(v);
   uint32_t r = 0;
-  r += a > 0.00260417f;
-  r += a > 0.0859375f;
-  r += a > 0.208333334f;
-  r += a > 0.29166667f;
-  r += a > 0.4166667f;
-  r += a > 0.5833334f;
-  r += a > 0.83333334f;
+  r += a > (float)0.00260417;
+  r += a > (float)0.0859375;
+  r += a > (float)0.208333334;
+  r += a > (float)0.29166667;
+  r += a > (float)0.4166667;
+  r += a > (float)0.5833334;
+  r += a > (float)0.83333334;
   const uint32_t by_rank = 0x32547610u;  // rank r -> code: 0,1,6,7,4,5,2,3 (nibble r)
   return ((by_rank >> (4 * r)) & 0xfu) + (v < 0.0f ? 8u : 0u);
 }
