@@ -75,6 +75,14 @@ _SIGNATURES = {
         c_int,
         [c_void_p] * 6 + [_I64] * 11 + [c_int, c_int, c_void_p],
     ),
+    "conch_scaled_gemm_gelu_tanh_and_mul": (
+        c_int,
+        [c_void_p] * 6 + [_I64] * 11 + [c_int, c_int, c_void_p],
+    ),
+    "conch_mixed_precision_gemm_gelu_tanh_and_mul": (
+        c_int,
+        [c_void_p] * 5 + [_I64] * 8 + [c_int] * 6 + [c_void_p],
+    ),
     "conch_time_scaled_gemm_silu_and_mul": (
         c_int,
         [c_void_p] * 6 + [_I64] * 11 + [c_int, c_int, c_void_p, c_int, ctypes.POINTER(c_float)],

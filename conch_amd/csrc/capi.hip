@@ -230,7 +230,7 @@ int run_scaled_silu(const ScaledGemmArgs& p, hipStream_t stream) {
     const ScaledKernel pick = choose_scaled_kernel(wide);
     if (pick == kKernelSkinny && scaled_gemm_skinny_fused_supported(wide)) {
       ScaledGemmArgs q = wide;  // n = 2d for the partial sums; c / c_stride_m describe the d-column result
-      q.fuse_silu = 1;
+      q.fuse_silu = p.fuse_silu;
       return launch_scaled_gemm_skinny(q, stream);
     }
     // few 256-row tiles: the 128x128-tile kernel on the wide problem plus the elementwise pass beats the fused 256-row tile
@@ -244,7 +244,7 @@ int run_scaled_silu(const ScaledGemmArgs& p, hipStream_t stream) {
   wide.c_stride_m = wide.n;
   wide.c_stride_n = 1;
   if (int rc = run_scaled(wide, stream)) return rc;
-  return launch_silu_and_mul(p.c, tmp, p.m, p.n, wide.n, p.c_stride_m, p.out_dtype, stream);
+  return launch_silu_and_mul(p.c, tmp, p.m, p.n, wide.n, p.c_stride_m, p.out_dtype, p.fuse_silu, stream);
 }
 
 int check_mixed(const MixedGemmArgs& p) {
@@ -349,7 +349,7 @@ int run_mixed_silu(const MixedGemmArgs& p, hipStream_t stream) {
                       (p.m <= 32 || (double)wide.n * (double)p.k < 9.0e7);
   if (decode) {
     MixedGemmArgs q = wide;  // n = 2d for the partial sums; c / c_stride_m describe the d-column result
-    q.fuse_silu = 1;
+    q.fuse_silu = p.fuse_silu;
     return launch_mixed_gemm_skinny(q, stream);
   }
   if (variant != 1 && variant != 2 && mixed_gemm_silu_fused_supported(p)) return launch_mixed_gemm_mfma(p, stream);
@@ -358,7 +358,7 @@ int run_mixed_silu(const MixedGemmArgs& p, hipStream_t stream) {
   wide.c = tmp;
   wide.c_stride_m = wide.n;
   if (int rc = run_mixed(wide, stream)) return rc;
-  return launch_silu_and_mul(p.c, tmp, p.m, p.n, wide.n, p.c_stride_m, p.out_dtype, stream);
+  return launch_silu_and_mul(p.c, tmp, p.m, p.n, wide.n, p.c_stride_m, p.out_dtype, p.fuse_silu, stream);
 }
 
 template <class F>
@@ -450,6 +450,18 @@ extern "C" int conch_scaled_gemm_silu_and_mul(void* c, const void* a, const void
   return run_scaled_silu(p, (hipStream_t)stream);
 }
 
+extern "C" int conch_scaled_gemm_gelu_tanh_and_mul(void* c, const void* a, const void* b, const float* scale_a,
+                                                   const float* scale_b, const void* bias, int64_t m, int64_t n_out, int64_t k,
+                                                   int64_t a_stride_m, int64_t a_stride_k, int64_t b_stride_k,
+                                                   int64_t b_stride_n, int64_t c_stride_m, int64_t c_stride_n,
+                                                   int64_t scale_a_numel, int64_t scale_b_numel, int in_dtype, int out_dtype,
+                                                   void* stream) {
+  ScaledGemmArgs p{c, a, b, scale_a, scale_b, bias, m, n_out, k, a_stride_m, a_stride_k, b_stride_k,
+                   b_stride_n, c_stride_m, c_stride_n, scale_a_numel, scale_b_numel, in_dtype, out_dtype};
+  p.fuse_silu = 2;  // gelu-tanh gate
+  return run_scaled_silu(p, (hipStream_t)stream);
+}
+
 extern "C" int conch_time_scaled_gemm_silu_and_mul(void* c, const void* a, const void* b, const float* scale_a,
                                                    const float* scale_b, const void* bias, int64_t m, int64_t n_out,
                                                    int64_t k, int64_t a_stride_m, int64_t a_stride_k, int64_t b_stride_k,
@@ -506,6 +518,18 @@ extern "C" int conch_mixed_precision_gemm_silu_and_mul(void* c, const void* x, c
   MixedGemmArgs p{c, x, w_q_packed, w_s, w_zp, m, n_out, k, x_stride_m, wq_stride_k, ws_stride_g,
                   wzp_stride_g, c_stride_m, weight_bits, weight_bias, group_size, zp_mode, x_dtype, out_dtype};
   p.fuse_silu = 1;
+  return run_mixed_silu(p, (hipStream_t)stream);
+}
+
+extern "C" int conch_mixed_precision_gemm_gelu_tanh_and_mul(void* c, const void* x, const int32_t* w_q_packed, const void* w_s,
+                                                            const int32_t* w_zp, int64_t m, int64_t n_out, int64_t k,
+                                                            int64_t x_stride_m, int64_t wq_stride_k, int64_t ws_stride_g,
+                                                            int64_t wzp_stride_g, int64_t c_stride_m, int weight_bits,
+                                                            int weight_bias, int group_size, int zp_mode, int x_dtype,
+                                                            int out_dtype, void* stream) {
+  MixedGemmArgs p{c, x, w_q_packed, w_s, w_zp, m, n_out, k, x_stride_m, wq_stride_k, ws_stride_g,
+                  wzp_stride_g, c_stride_m, weight_bits, weight_bias, group_size, zp_mode, x_dtype, out_dtype};
+  p.fuse_silu = 2;  // gelu-tanh gate
   return run_mixed_silu(p, (hipStream_t)stream);
 }
 

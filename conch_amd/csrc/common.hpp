@@ -159,6 +159,19 @@ __device__ __forceinline__ float silu_f32(float g) {
   return (g * __builtin_amdgcn_rcpf((1.0f + e) * 0x1p-32f)) * 0x1p-32f;
 }
 
+// gelu(g, approximate="tanh") = 0.5 g (1 + tanh(z)), z = sqrt(2/pi) (g + 0.044715 g^3)
+// (conch/kernels/activation/gelu_tanh_and_mul.py:66-68; reference/activation/gelu_tanh_and_mul.py:13-16 = F.gelu).
+// 0.5 (1 + tanh z) is sigmoid(2z), so this is g * sigmoid(2z) and shares silu's form -- and its care for the denominator.
+__device__ __forceinline__ float gelu_tanh_f32(float g) {
+  const float z = 0.7978845608028654f * (g + 0.044715f * (g * g * g));
+  const float e = __builtin_amdgcn_exp2f(z * -2.88539008177792681472f);  // exp(-2z)
+  return (g * __builtin_amdgcn_rcpf((1.0f + e) * 0x1p-32f)) * 0x1p-32f;
+}
+
+// gate activation of the fused FFN epilogues: the value of the args' `fuse_silu` field (1 = silu, 2 = gelu-tanh)
+enum { kActSilu = 1, kActGeluTanh = 2 };
+__device__ __forceinline__ float act_f32(float g, int act) { return act == kActGeluTanh ? gelu_tanh_f32(g) : silu_f32(g); }
+
 template <int DT>
 __device__ __forceinline__ float load_as_float(const void* p, int64_t idx) {
   if constexpr (DT == CONCH_DT_FP32) {

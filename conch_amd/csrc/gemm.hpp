@@ -20,7 +20,7 @@ struct ScaledGemmArgs {
   int64_t c_stride_m, c_stride_n;
   int64_t scale_a_numel, scale_b_numel;
   int in_dtype, out_dtype;
-  // 1 = fused gate/up FFN form (conch_scaled_gemm_silu_and_mul): B, scale_b and bias have 2n columns [gate | up], C has
+  // != 0 = fused gate/up FFN form; the value is the gate activation (1 = silu, 2 = gelu-tanh) (conch_scaled_gemm_silu_and_mul): B, scale_b and bias have 2n columns [gate | up], C has
   // n columns, C[i][j] = silu(gemm[i][j]) * gemm[i][n + j] with the reference's roundings (oracle: scaled_gemm_silu_and_mul_ref)
   int fuse_silu = 0;
 };
@@ -68,7 +68,7 @@ int launch_scaled_gemm_mfma_16bit(const ScaledGemmArgs& p, hipStream_t stream); 
 int launch_mixed_gemm_modes(const MixedGemmArgs& p, const void* scales, const void* zeros, int64_t zeros_stride_g, int group_mode,
                             int zeros_kind, const void* channel_scales, hipStream_t stream);
 // quant.hip -- elementwise silu(x[:, :n]) * x[:, n:] on a 16-bit [m][2n] matrix (the unfused tail of the FFN pair)
-int launch_silu_and_mul(void* out, const void* x, int64_t m, int64_t n, int64_t x_stride_m, int64_t out_stride_m, int dtype,
+int launch_silu_and_mul(void* out, const void* x, int64_t m, int64_t n, int64_t x_stride_m, int64_t out_stride_m, int dtype, int act,
                         hipStream_t stream);
 bool mixed_gemm_mfma_supported(const MixedGemmArgs& p);
 bool mixed_gemm_silu_fused_supported(const MixedGemmArgs& p);

@@ -118,27 +118,27 @@ int launch_mixed_gemm_generic(const MixedGemmArgs& p, hipStream_t stream) {
 // ---------------------------------------------------------------------------------------------
 namespace {
 template <int DT>
-__global__ void silu_and_mul_kernel(uint16_t* out, const uint16_t* x, int64_t m, int64_t n, int64_t x_stride_m, int64_t out_stride_m) {
+__global__ void silu_and_mul_kernel(uint16_t* out, const uint16_t* x, int64_t m, int64_t n, int64_t x_stride_m, int64_t out_stride_m, int act) {
   const int64_t total = m * n;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = i / n, col = i - r * n;
     const float g = bits16_to_float<DT>(x[r * x_stride_m + col]);
     const float u = bits16_to_float<DT>(x[r * x_stride_m + n + col]);
-    const float s = bits16_to_float<DT>(float_to_bits16<DT>(pin_f32(silu_f32(g))));
+    const float s = bits16_to_float<DT>(float_to_bits16<DT>(pin_f32(act_f32(g, act))));
     out[r * out_stride_m + col] = float_to_bits16<DT>(pin_f32(s * u));
   }
 }
 }  // namespace
 
-int launch_silu_and_mul(void* out, const void* x, int64_t m, int64_t n, int64_t x_stride_m, int64_t out_stride_m, int dtype,
+int launch_silu_and_mul(void* out, const void* x, int64_t m, int64_t n, int64_t x_stride_m, int64_t out_stride_m, int dtype, int act,
                         hipStream_t stream) {
   if (m == 0 || n == 0) return CONCH_OK;
   const int64_t total = m * n;
   const unsigned blocks = (unsigned)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
   if (dtype == CONCH_DT_FP16)
-    hipLaunchKernelGGL((silu_and_mul_kernel<CONCH_DT_FP16>), dim3(blocks), dim3(256), 0, stream, (uint16_t*)out, (const uint16_t*)x, m, n, x_stride_m, out_stride_m);
+    hipLaunchKernelGGL((silu_and_mul_kernel<CONCH_DT_FP16>), dim3(blocks), dim3(256), 0, stream, (uint16_t*)out, (const uint16_t*)x, m, n, x_stride_m, out_stride_m, act);
   else
-    hipLaunchKernelGGL((silu_and_mul_kernel<CONCH_DT_BF16>), dim3(blocks), dim3(256), 0, stream, (uint16_t*)out, (const uint16_t*)x, m, n, x_stride_m, out_stride_m);
+    hipLaunchKernelGGL((silu_and_mul_kernel<CONCH_DT_BF16>), dim3(blocks), dim3(256), 0, stream, (uint16_t*)out, (const uint16_t*)x, m, n, x_stride_m, out_stride_m, act);
   return check_launch("silu_and_mul");
 }
 

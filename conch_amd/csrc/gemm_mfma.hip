@@ -288,11 +288,11 @@ __device__ __forceinline__ void epilogue_rows(const typename AccT<MMA>::type (&a
 // reciprocal are the hardware's v_exp_f32 / v_rcp_f32 (1 ulp each, in fp32): the result can differ from the CPU oracle by
 // one output ulp on a few elements in 10^4 (bound asserted in tests/test_gpu_gemm.py).
 template <int OUT_DT>
-__device__ __forceinline__ uint32_t silu_mul2(uint32_t g_bits, uint32_t u_bits) {
+__device__ __forceinline__ uint32_t silu_mul2(uint32_t g_bits, uint32_t u_bits, int act) {
   const f32x2 g = unpack2_bits16<OUT_DT>(g_bits);
   f32x2 s;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) s[i] = silu_f32(g[i]);
+  for (int i = 0; i < 2; ++i) s[i] = act_f32(g[i], act);
   const f32x2 sr = unpack2_bits16<OUT_DT>(pack2_bits16<OUT_DT>(pin_f32x2(s)));
   return pack2_bits16<OUT_DT>(pin_f32x2(sr * unpack2_bits16<OUT_DT>(u_bits)));
 }
@@ -339,7 +339,7 @@ __device__ __forceinline__ void epilogue_silu(const typename AccT<MMA>::type (&a
         }
         gu[h] = hb;
       }
-      pk[e2] = (int)silu_mul2<OUT_DT>(gu[0], gu[1]);
+      pk[e2] = (int)silu_mul2<OUT_DT>(gu[0], gu[1], p.fuse_silu);
     }
     if (m < p.m) {
       uint16_t* dst = (uint16_t*)p.c + (int64_t)m * p.c_stride_m + n0;

@@ -108,7 +108,7 @@ __device__ __forceinline__ void mixed_epilogue_silu(const MixedTile& w, const Mi
       const f32x4& au = w.acc[mt][2 + (e >> 2)];
       const f32x2 gv = unpack2_bits16<OUT_DT>(pack2_bits16<OUT_DT>(f32x2{ag[e & 3], ag[(e & 3) + 1]}));
       const uint32_t ub = pack2_bits16<OUT_DT>(f32x2{au[e & 3], au[(e & 3) + 1]});
-      const f32x2 sv = unpack2_bits16<OUT_DT>(pack2_bits16<OUT_DT>(pin_f32x2(f32x2{silu_f32(gv[0]), silu_f32(gv[1])})));
+      const f32x2 sv = unpack2_bits16<OUT_DT>(pack2_bits16<OUT_DT>(pin_f32x2(f32x2{act_f32(gv[0], p.fuse_silu), act_f32(gv[1], p.fuse_silu)})));
       pk[e2] = (int)pack2_bits16<OUT_DT>(pin_f32x2(sv * unpack2_bits16<OUT_DT>(ub)));
     }
     uint16_t* dst = (uint16_t*)p.c + (int64_t)m * p.c_stride_m + n0;

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void mixed_skinny_reduce_silu_kernel(MixedGemm
   for (int e = 0; e < 4; ++e) {
     const float gr = bits16_to_float<OUT_DT>(float_to_bits16<OUT_DT>(g[e]));
     const float ur = bits16_to_float<OUT_DT>(float_to_bits16<OUT_DT>(u[e]));
-    const float sr = bits16_to_float<OUT_DT>(float_to_bits16<OUT_DT>(pin_f32(silu_f32(gr))));
+    const float sr = bits16_to_float<OUT_DT>(float_to_bits16<OUT_DT>(pin_f32(act_f32(gr, p.fuse_silu))));
     dst[e] = float_to_bits16<OUT_DT>(pin_f32(sr * ur));
   }
 }

@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256) void skinny_reduce_silu_kernel(ScaledGemmArgs 
   uint16_t* dst = (uint16_t*)p.c + (int64_t)m * p.c_stride_m + j0;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const float s = bits16_to_float<OUT_DT>(float_to_bits16<OUT_DT>(pin_f32(silu_f32(bits16_to_float<OUT_DT>(gu[0][e])))));
+    const float s = bits16_to_float<OUT_DT>(float_to_bits16<OUT_DT>(pin_f32(act_f32(bits16_to_float<OUT_DT>(gu[0][e]), p.fuse_silu))));
     dst[e] = float_to_bits16<OUT_DT>(pin_f32(s * bits16_to_float<OUT_DT>(gu[1][e])));
   }
 }

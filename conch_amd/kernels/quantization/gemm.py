@@ -162,6 +162,17 @@ def scaled_gemm_launcher(
     _C.check(status, "scaled_gemm")
 
 
+def _scaled_gemm_act_and_mul(fn_name: str, what: str, output, a, b, scale_a, scale_b, metadata: ScaledMatmulMetadata, bias) -> None:
+    if metadata.n_dim % 2:
+        raise ValueError(f"{what}: B needs an even number of columns [gate | up], got {metadata.n_dim}")
+    if output.shape != (metadata.m_dim, metadata.n_dim // 2):
+        raise ValueError(f"output shape {tuple(output.shape)} != ({metadata.m_dim}, {metadata.n_dim // 2})")
+    if output.stride(1) != 1:
+        raise ValueError(f"{what}: output needs unit column stride")
+    status = _scaled_gemm_call(fn_name, output, a, b, scale_a, scale_b, metadata, bias, n_out=metadata.n_dim // 2)
+    _C.check(status, what)
+
+
 def scaled_gemm_silu_and_mul_launcher(
     output: torch.Tensor,
     a: torch.Tensor,
@@ -177,15 +188,23 @@ def scaled_gemm_silu_and_mul_launcher(
     kernels/quantization/gemm.py:564-627, then silu_and_mul_launcher, ops/activation/silu_and_mul.py:11-29) with the
     same roundings.  `metadata` describes the GEMM (n_dim = 2 x output columns).
     """
-    if metadata.n_dim % 2:
-        raise ValueError(f"scaled_gemm_silu_and_mul: B needs an even number of columns [gate | up], got {metadata.n_dim}")
-    if output.shape != (metadata.m_dim, metadata.n_dim // 2):
-        raise ValueError(f"output shape {tuple(output.shape)} != ({metadata.m_dim}, {metadata.n_dim // 2})")
-    if output.stride(1) != 1:
-        raise ValueError("scaled_gemm_silu_and_mul: output needs unit column stride")
-    status = _scaled_gemm_call("conch_scaled_gemm_silu_and_mul", output, a, b, scale_a, scale_b, metadata, bias,
-                               n_out=metadata.n_dim // 2)
-    _C.check(status, "scaled_gemm_silu_and_mul")
+    _scaled_gemm_act_and_mul("conch_scaled_gemm_silu_and_mul", "scaled_gemm_silu_and_mul", output, a, b, scale_a, scale_b, metadata, bias)
+
+
+def scaled_gemm_gelu_tanh_and_mul_launcher(
+    output: torch.Tensor,
+    a: torch.Tensor,
+    b: torch.Tensor,
+    scale_a: torch.Tensor,
+    scale_b: torch.Tensor,
+    metadata: ScaledMatmulMetadata,
+    bias: torch.Tensor | None = None,
+) -> None:
+    """output[:, j] = gelu_tanh(G[:, j]) * G[:, N/2 + j] with G = scaled_gemm(a, b, ...), in one launch: the GeGLU pair
+    `gelu_tanh_and_mul(scaled_gemm(...))` (conch/ops/activation/gelu_tanh_and_mul.py; kernel
+    conch/kernels/activation/gelu_tanh_and_mul.py:60-70) with the reference's roundings."""
+    _scaled_gemm_act_and_mul("conch_scaled_gemm_gelu_tanh_and_mul", "scaled_gemm_gelu_tanh_and_mul", output, a, b, scale_a, scale_b,
+                             metadata, bias)
 
 
 def _mixed_gemm_call(
@@ -226,7 +245,7 @@ def _mixed_gemm_call(
                   or (gmode == WeightGroupMode.SYMMETRIC_WITH_SHIFT and zeros is not None and not zeros.dtype.is_floating_point)))
     if not fused:
         # a mode conch.ops never produces: the explicit-modes entry point
-        if fn_name != "conch_mixed_precision_gemm":
+        if fn_name not in ("conch_mixed_precision_gemm", "conch_time_mixed_precision_gemm"):
             raise NotImplementedError(f"{fn_name}: only the weight-group modes conch.ops produces (SYMMETRIC_NO_SHIFT / "
                                       "SYMMETRIC_WITH_SHIFT on 4- / 8-bit weights, no channel scale)")
         return _mixed_gemm_modes_call(output, x, w_q_packed, scales, zeros, metadata)
@@ -315,6 +334,15 @@ def mixed_precision_gemm_launcher(
     _C.check(status, "mixed_precision_gemm")
 
 
+def _mixed_gemm_act_and_mul(fn_name: str, what: str, output, x, w_q_packed, scales, zeros, metadata: MixedPrecisionMatmulMetadata) -> None:
+    if metadata.n_dim % 2:
+        raise ValueError(f"{what}: the weights need an even number of columns [gate | up], got {metadata.n_dim}")
+    if output.shape != (metadata.m_dim, metadata.n_dim // 2) or output.stride(1) != 1:
+        raise ValueError(f"output must be a ({metadata.m_dim}, {metadata.n_dim // 2}) tensor with unit column stride")
+    status = _mixed_gemm_call(fn_name, output, x, w_q_packed, scales, zeros, metadata, n_out=metadata.n_dim // 2)
+    _C.check(status, what)
+
+
 def mixed_precision_gemm_silu_and_mul_launcher(
     output: torch.Tensor,
     x: torch.Tensor,
@@ -329,10 +357,18 @@ def mixed_precision_gemm_silu_and_mul_launcher(
     kernels/quantization/gemm.py:482-545, then silu_and_mul_launcher, ops/activation/silu_and_mul.py:11-29) with the same
     roundings.  `metadata` describes the GEMM (n_dim = 2 x output columns).
     """
-    if metadata.n_dim % 2:
-        raise ValueError(f"mixed_precision_gemm_silu_and_mul: the weights need an even number of columns [gate | up], got {metadata.n_dim}")
-    if output.shape != (metadata.m_dim, metadata.n_dim // 2) or output.stride(1) != 1:
-        raise ValueError(f"output must be a ({metadata.m_dim}, {metadata.n_dim // 2}) tensor with unit column stride")
-    status = _mixed_gemm_call("conch_mixed_precision_gemm_silu_and_mul", output, x, w_q_packed, scales, zeros, metadata,
-                              n_out=metadata.n_dim // 2)
-    _C.check(status, "mixed_precision_gemm_silu_and_mul")
+    _mixed_gemm_act_and_mul("conch_mixed_precision_gemm_silu_and_mul", "mixed_precision_gemm_silu_and_mul", output, x, w_q_packed,
+                            scales, zeros, metadata)
+
+
+def mixed_precision_gemm_gelu_tanh_and_mul_launcher(
+    output: torch.Tensor,
+    x: torch.Tensor,
+    w_q_packed: torch.Tensor,
+    scales: torch.Tensor,
+    zeros: torch.Tensor | None,
+    metadata: MixedPrecisionMatmulMetadata,
+) -> None:
+    """The same pair with the gelu-tanh gate (conch/ops/activation/gelu_tanh_and_mul.py after mixed_precision_gemm)."""
+    _mixed_gemm_act_and_mul("conch_mixed_precision_gemm_gelu_tanh_and_mul", "mixed_precision_gemm_gelu_tanh_and_mul", output, x,
+                            w_q_packed, scales, zeros, metadata)

@@ -10,15 +10,18 @@ from __future__ import annotations
 import torch
 
 from conch_amd.kernels.quantization.gemm import (
+    mixed_precision_gemm_gelu_tanh_and_mul_launcher,
     mixed_precision_gemm_launcher,
     mixed_precision_gemm_silu_and_mul_launcher,
+    scaled_gemm_gelu_tanh_and_mul_launcher,
     scaled_gemm_launcher,
     scaled_gemm_silu_and_mul_launcher,
 )
 from conch_amd.ops.quantization._metadata import create_mixed_precision_metadata, create_scaled_metadata
 
 __all__ = ["create_mixed_precision_metadata", "create_scaled_metadata", "mixed_precision_gemm", "scaled_gemm",
-           "scaled_gemm_silu_and_mul", "mixed_precision_gemm_silu_and_mul"]
+           "scaled_gemm_silu_and_mul", "mixed_precision_gemm_silu_and_mul", "scaled_gemm_gelu_tanh_and_mul",
+           "mixed_precision_gemm_gelu_tanh_and_mul"]
 
 
 def mixed_precision_gemm(x: torch.Tensor, w_q_packed: torch.Tensor, w_s: torch.Tensor, w_zp: torch.Tensor | None,
@@ -71,4 +74,27 @@ def mixed_precision_gemm_silu_and_mul(x: torch.Tensor, w_q_packed: torch.Tensor,
                                            output_dtype=output_dtype, strict=strict)
     out = x.new_empty((meta.m_dim, meta.n_dim // 2), dtype=meta.output_dtype)
     mixed_precision_gemm_silu_and_mul_launcher(out, x, w_q_packed, w_s, w_zp, meta)
+    return out
+
+
+def scaled_gemm_gelu_tanh_and_mul(a: torch.Tensor, b: torch.Tensor, scale_a: torch.Tensor, scale_b: torch.Tensor,
+                                  output_dtype: torch.dtype, bias: torch.Tensor | None = None, strict: bool = False) -> torch.Tensor:
+    """gelu_tanh_and_mul(scaled_gemm(a, b, scale_a, scale_b, output_dtype, bias)) in one launch (the GeGLU FFN pair; SURVEY.md
+    8(f) N3).  `b` is (K, 2d) = [gate | up]; the result is (M, d): gelu(G[:, :d], approximate="tanh") * G[:, d:].  The
+    reference runs conch.ops.quantization.gemm.scaled_gemm and conch.ops.activation.gelu_tanh_and_mul back to back."""
+    meta = create_scaled_metadata(a, b, scale_a, scale_b, output_dtype, strict=strict)
+    out = a.new_empty((meta.m_dim, meta.n_dim // 2), dtype=output_dtype)
+    scaled_gemm_gelu_tanh_and_mul_launcher(out, a, b, scale_a, scale_b, meta, bias=bias)
+    return out
+
+
+def mixed_precision_gemm_gelu_tanh_and_mul(x: torch.Tensor, w_q_packed: torch.Tensor, w_s: torch.Tensor, w_zp: torch.Tensor | None,
+                                           weight_size_bits: int, weight_bias: int, group_size: int, *,
+                                           output_dtype: torch.dtype | None = None, strict: bool = False) -> torch.Tensor:
+    """gelu_tanh_and_mul(mixed_precision_gemm(x, w_q_packed, ...)) in one launch; packed weights, scales and zero points have 2d
+    columns [gate | up], the result is (M, d)."""
+    meta = create_mixed_precision_metadata(x, w_q_packed, w_s, w_zp, weight_size_bits, weight_bias, group_size,
+                                           output_dtype=output_dtype, strict=strict)
+    out = x.new_empty((meta.m_dim, meta.n_dim // 2), dtype=meta.output_dtype)
+    mixed_precision_gemm_gelu_tanh_and_mul_launcher(out, x, w_q_packed, w_s, w_zp, meta)
     return out

@@ -218,6 +218,19 @@ int conch_scaled_gemm_silu_and_mul(void* c, const void* a, const void* b, const 
                                    void* stream);
 
 /*
+ * scaled_gemm_gelu_tanh_and_mul  (second activation: the GeGLU pair
+ * `gelu_tanh_and_mul(scaled_gemm(a, b, ...))`, conch/ops/activation/gelu_tanh_and_mul.py after scaled_gemm; semantics =
+ * reference/activation/gelu_tanh_and_mul.py:13-16, F.gelu(gate, approximate="tanh") * up, every intermediate rounded to out_dtype).
+ * Arguments exactly as conch_scaled_gemm_silu_and_mul.
+ */
+int conch_scaled_gemm_gelu_tanh_and_mul(void* c, const void* a, const void* b, const float* scale_a,
+                                        const float* scale_b, const void* bias, int64_t m, int64_t n_out, int64_t k,
+                                        int64_t a_stride_m, int64_t a_stride_k, int64_t b_stride_k,
+                                        int64_t b_stride_n, int64_t c_stride_m, int64_t c_stride_n,
+                                        int64_t scale_a_numel, int64_t scale_b_numel, int in_dtype, int out_dtype,
+                                        void* stream);
+
+/*
  * mixed_precision_gemm  (replaces kernels/quantization/gemm.py:482-545;
  * dequantisation semantics = kernels/quantization/gemm.py:176-216, bit-identical to the w_ref of
  * third_party/vllm/quant_utils.py:74)
@@ -258,6 +271,14 @@ int conch_mixed_precision_gemm_modes(void* c, const void* x, const int32_t* w_q_
  *   C[m][j] = out_dtype( out_dtype( silu((float) G[m][j]) ) * (float) G[m][n_out + j] ),  G = conch_mixed_precision_gemm(...)
  */
 int conch_mixed_precision_gemm_silu_and_mul(void* c, const void* x, const int32_t* w_q_packed, const void* w_s,
+                               const int32_t* w_zp, int64_t m, int64_t n_out, int64_t k,
+                               int64_t x_stride_m, int64_t wq_stride_k, int64_t ws_stride_g,
+                               int64_t wzp_stride_g, int64_t c_stride_m, int weight_bits,
+                               int weight_bias, int group_size, int zp_mode, int x_dtype,
+                               int out_dtype, void* stream);
+
+/* The same pair with the gelu-tanh gate (arguments exactly as conch_mixed_precision_gemm_silu_and_mul). */
+int conch_mixed_precision_gemm_gelu_tanh_and_mul(void* c, const void* x, const int32_t* w_q_packed, const void* w_s,
                                const int32_t* w_zp, int64_t m, int64_t n_out, int64_t k,
                                int64_t x_stride_m, int64_t wq_stride_k, int64_t ws_stride_g,
                                int64_t wzp_stride_g, int64_t c_stride_m, int weight_bits,

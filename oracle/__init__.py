@@ -33,12 +33,15 @@ from oracle.reference import (  # noqa: F401
     dynamic_scaled_fp8_quant_ref,
     dynamic_scaled_int8_quant_ref,
     encode_fp8,
+    gelu_tanh_and_mul_ref,
+    mixed_precision_gemm_gelu_tanh_and_mul_ref,
     mixed_precision_gemm_modes_ref,
     mixed_precision_gemm_ref,
     mixed_precision_gemm_silu_and_mul_ref,
     pack_rows_ref,
     quantize_weights_ref,
     scaled_fp8_quant_ref,
+    scaled_gemm_gelu_tanh_and_mul_ref,
     scaled_gemm_modes_ref,
     scaled_gemm_ref,
     scaled_gemm_silu_and_mul_ref,

@@ -173,6 +173,23 @@ def silu_and_mul_ref(x: torch.Tensor) -> torch.Tensor:
     return torch.nn.functional.silu(x[..., :d]) * x[..., d:]
 
 
+def gelu_tanh_and_mul_ref(x: torch.Tensor) -> torch.Tensor:
+    """conch/reference/activation/gelu_tanh_and_mul.py:13-16: F.gelu(x[..., :d], approximate="tanh") * x[..., d:] -- torch
+    evaluates the gelu in fp32 and rounds it to x's dtype, then the product is rounded again."""
+    d = x.shape[-1] // 2
+    return torch.nn.functional.gelu(x[..., :d], approximate="tanh") * x[..., d:]
+
+
+def scaled_gemm_gelu_tanh_and_mul_ref(a, b, scale_a, scale_b, out_dtype, bias=None) -> torch.Tensor:
+    """The reference's two PyTorch references back to back: scaled_gemm (reference/quantization/scaled_gemm.py:12-27), then
+    gelu_tanh_and_mul."""
+    return gelu_tanh_and_mul_ref(scaled_gemm_ref(a, b, scale_a, scale_b, out_dtype, bias))
+
+
+def mixed_precision_gemm_gelu_tanh_and_mul_ref(a: torch.Tensor, w_ref: torch.Tensor) -> torch.Tensor:
+    return gelu_tanh_and_mul_ref(mixed_precision_gemm_ref(a, w_ref))
+
+
 def scaled_gemm_silu_and_mul_ref(
     a: torch.Tensor,
     b: torch.Tensor,

@@ -255,7 +255,25 @@ def gen_bnb() -> None:
     np.savez_compressed(OUT / "bnb_blockwise.npz", **out)
 
 
-GENERATORS = {"dyn": gen_dynamic, "modes": gen_modes, "bnb": gen_bnb}
+def gen_gelu() -> None:
+    """SURVEY.md 8(f) N3, second activation: conch.reference.activation.gelu_tanh_and_mul applied to the reference's GEMM outputs
+    already stored in scaled_gemm.npz / mixed_gemm.npz (c_<key>); only the new outputs are stored (y_<key>)."""
+    from conch.reference.activation.gelu_tanh_and_mul import gelu_tanh_and_mul as ref_gelu
+
+    for src, dst in (("scaled_gemm.npz", "scaled_gemm_gelu.npz"), ("mixed_gemm.npz", "mixed_gemm_gelu.npz")):
+        gz = np.load(OUT / src)
+        out: dict[str, np.ndarray] = {}
+        for name in gz.files:
+            if not name.startswith("c_"):
+                continue
+            key = name[2:]
+            odt = torch.float16 if ("_f16_" in key or key.endswith("_f16")) else torch.bfloat16
+            c = torch.from_numpy(gz[name].view(np.int16).copy()).view(odt)
+            out[f"y_{key}"] = bits(ref_gelu(c))
+        np.savez_compressed(OUT / dst, **out)
+
+
+GENERATORS = {"dyn": gen_dynamic, "modes": gen_modes, "bnb": gen_bnb, "gelu": gen_gelu}
 
 if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference checkout is only available in the authoring container"

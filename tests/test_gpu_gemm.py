@@ -19,8 +19,10 @@ import oracle
 from conch_amd import _C
 from conch_amd.ops.quantization.gemm import (
     mixed_precision_gemm,
+    mixed_precision_gemm_gelu_tanh_and_mul,
     mixed_precision_gemm_silu_and_mul,
     scaled_gemm,
+    scaled_gemm_gelu_tanh_and_mul,
     scaled_gemm_silu_and_mul,
 )
 from conch_amd.third_party.vllm.quant_utils import pack_rows, quantize_weights
@@ -527,6 +529,12 @@ def check_mixed(got, a, w_ref, k):
     eps = EPS[got.dtype]
     assert (g - exact).abs().max().item() <= 1.0 * eps * scale
     assert (g - ref).abs().max().item() <= 3.0 * eps * scale
+    # per element (an error confined to small-magnitude outputs cannot hide under max|C|): one output rounding of the exact
+    # value plus the worst-case fp32 accumulation-order error of ITS products
+    s_abs = (a.double().abs() @ w_ref.double().abs()).float()
+    bound = eps * exact.abs() + (k * 2.0**-24) * s_abs + 1e-30
+    excess = ((g - exact).abs() - bound).max().item()
+    assert excess <= 0, f"per-element bound exceeded by {excess:.4g}"
     atol = min(5e-2 * math.sqrt(k), 1)
     torch.testing.assert_close(g, ref, rtol=1e-1, atol=atol)  # the reference's own bar
 
@@ -578,6 +586,35 @@ def test_mixed_precision_c4_config_properties():
         lo, hi = rank * shard, (rank + 1) * shard
         part = mixed_precision_gemm(a_d, p_d[:, lo:hi].contiguous(), s_d[:, lo:hi].contiguous(), None, wt.size_bits, wt.bias, 128)
         assert torch.equal(part, got[:, lo:hi]), f"rank {rank}"
+
+
+@pytest.mark.parametrize(("wname", "use_zp", "dname"), [("uint4", True, "bf16"), ("uint8b128", False, "f16"), ("uint8", True, "bf16"),
+                                                         ("uint4b8", False, "bf16"), ("uint4", True, "f16")])
+def test_mixed_precision_c4_size_other_weight_types(wname, use_zp, dname):
+    """The C4 shape (1024 x 4096 x 11008) with zero points, 8-bit weights and bf16 -- the instantiations BASELINE's own
+    configuration does not touch: bands of rows against the oracle, the whole product against the generic device kernel."""
+    m, k, n = 1024, 4096, 11008
+    wt = WTYPES[wname]
+    a, w_ref, packed, w_s, w_zp = make_mixed_inputs(m, k, n, wt, use_zp, DT[dname])
+    args = (a.cuda(), packed.cuda(), w_s.cuda(), None if w_zp is None else w_zp.cuda(), wt.size_bits, wt.bias, 128)
+    got = mixed_precision_gemm(*args)
+    rows = torch.cat([torch.arange(0, 32), torch.arange(500, 532), torch.arange(992, 1024)])
+    check_mixed(got[rows.cuda()], a[rows], w_ref, k)
+    _C.set_gemm_variant(_C.VARIANT_GENERIC)
+    slow = mixed_precision_gemm(*args)
+    _C.set_gemm_variant(_C.VARIANT_AUTO)
+    assert (got.float() - slow.float()).abs().max().item() <= 2.0 * EPS[DT[dname]] * slow.float().abs().max().item()
+
+
+def test_scaled_gemm_c3_size_e4m3fnuz():
+    """The dtype the REFERENCE hands an AMD user (conch/ops/quantization/fp8.py:27) at the headline shape: exact expansion to
+    bf16 + the bf16 MFMA tile kernel.  Bands of rows against the oracle, per element."""
+    m, k, n = 4096, 4096, 11008
+    a, b, sa, sb, _ = make_scaled_inputs(m, k, n, torch.float8_e4m3fnuz, torch.bfloat16, False, False, False)
+    got = scaled_gemm(a.cuda(), b.T.contiguous().cuda().T, sa.cuda(), sb.cuda(), torch.bfloat16)
+    rows = torch.cat([torch.arange(0, 48), torch.arange(2040, 2072), torch.arange(4080, 4096)])
+    ref = oracle.scaled_gemm_ref(a[rows], b, sa[rows], sb, torch.bfloat16, None)
+    check_scaled(got[rows.cuda()], ref, torch.float8_e4m3fnuz, torch.bfloat16, (a[rows], b, sa[rows], sb, None))
 
 
 @pytest.mark.parametrize("wname", list(WTYPES))
@@ -885,3 +922,73 @@ def test_nsharded_gemm_world1_equals_scaled_gemm():
         blocks = op.gathered_blocks(ad, bd, sad, sbd, biasd)
         assert blocks.shape == (panels, 1, m // panels, n)
         np.testing.assert_array_equal(to_bits(blocks[panels - 1, 0]), to_bits(want[m - m // panels:]))
+
+
+# ---------------------------------------------------------------------------------------------
+# the GeGLU pairs (second activation): gelu_tanh_and_mul fused behind both GEMMs
+# ---------------------------------------------------------------------------------------------
+def run_gelu(a, b, sa, sb, out_dtype, bias):
+    dev = lambda t: None if t is None else t.cuda()  # noqa: E731
+    b_dev = b.T.contiguous().cuda().T if b.stride(0) == 1 else b.cuda()
+    return scaled_gemm_gelu_tanh_and_mul(dev(a), b_dev, dev(sa), dev(sb), out_dtype, dev(bias))
+
+
+@pytest.mark.parametrize("iname", list(IN_T))
+@pytest.mark.parametrize("oname", ["f16", "bf16"])
+@pytest.mark.parametrize("key_tail", ["sa1_sb1_b1", "sa0_sb0_b1", "sa0_sb0_b0", "sa1_sb0_b0"])
+def test_scaled_gemm_gelu_golden_from_reference(golden, iname, oname, key_tail):
+    """Expected = the reference's gelu_tanh_and_mul of the reference's scaled_gemm (tests/golden/scaled_gemm_gelu.npz); same
+    bars as the silu pair (hardware exp / rcp against torch's tanh: two output ulps, <= 0.2 % of the elements off)."""
+    g, y = golden("scaled_gemm"), golden("scaled_gemm_gelu")
+    key = f"{iname}_{oname}_{key_tail}"
+    a = from_bits(g[f"a_{key}"], IN_T[iname])
+    b = from_bits(g[f"bt_{key}"], IN_T[iname]).T
+    sa, sb = torch.from_numpy(g[f"sa_{key}"]), torch.from_numpy(g[f"sb_{key}"])
+    bias = from_bits(g[f"bias_{key}"], DT[oname]) if key_tail.endswith("b1") else None
+    got = run_gelu(a, b, sa, sb, DT[oname], bias)
+    assert got.shape == (128, 64) and got.dtype == DT[oname]
+    check_silu(got, from_bits(y[f"y_{key}"], DT[oname]), DT[oname], exact_gemm=iname == "int8")
+
+
+@pytest.mark.parametrize("iname", ["int8", "fn"])
+@pytest.mark.parametrize(("m", "k", "d"), [(1024, 1024, 512), (300, 384, 260), (257, 256, 8), (64, 2048, 96), (16, 1024, 1376)])
+def test_scaled_gemm_gelu_shapes_fused_equals_unfused(iname, m, k, d):
+    a, b, sa, sb, bias = make_scaled_inputs(m, k, 2 * d, IN_T[iname], torch.bfloat16, False, False, True)
+    ref = oracle.scaled_gemm_gelu_tanh_and_mul_ref(a, b, sa, sb, torch.bfloat16, bias)
+    got = run_gelu(a, b, sa, sb, torch.bfloat16, bias)
+    check_silu(got, ref, torch.bfloat16, exact_gemm=iname == "int8")
+    _C.set_gemm_variant(_C.VARIANT_MFMA_SIMPLE)
+    unfused = run_gelu(a, b, sa, sb, torch.bfloat16, bias)
+    _C.set_gemm_variant(_C.VARIANT_AUTO)
+    if m <= 64 and k % 1024 == 0 and iname != "int8":
+        tol = 4.0 * EPS[torch.bfloat16] * unfused.float().abs().max().item()
+        assert (got.float() - unfused.float()).abs().max().item() <= tol
+    else:
+        assert torch.equal(got, unfused)
+    # and it is not the silu pair
+    assert not torch.equal(got, run_silu(a, b, sa, sb, torch.bfloat16, bias))
+
+
+@pytest.mark.parametrize(("m", "k", "d"), [(300, 256, 260), (1024, 512, 688), (16, 1024, 260)])
+@pytest.mark.parametrize(("wname", "use_zp", "dname"), [("uint4b8", False, "f16"), ("uint4", True, "bf16"), ("uint8", False, "bf16")])
+def test_mixed_precision_gelu_fused(m, k, d, wname, use_zp, dname):
+    """int4 / int8-weight GeGLU pair: against the exact pair in fp64 (6 eps of max|y|: the GEMM's accumulation-order tolerance
+    through the gate) and bit for bit against the library's own unfused pair."""
+    wt = WTYPES[wname]
+    a, w_ref, packed, w_s, w_zp = make_mixed_inputs(m, k, 2 * d, wt, use_zp, DT[dname], 128)
+    a = (a.float() * 0.02).to(DT[dname])
+    args = (a.cuda(), packed.cuda(), w_s.cuda(), None if w_zp is None else w_zp.cuda(), wt.size_bits, wt.bias, 128)
+    got = mixed_precision_gemm_gelu_tanh_and_mul(*args)
+    exact_g = a.double() @ w_ref.double()
+    exact = (torch.nn.functional.gelu(exact_g[:, :d], approximate="tanh") * exact_g[:, d:]).float()
+    ok = exact.abs() < 3.0e4
+    assert (got.float().cpu()[ok] - exact[ok]).abs().max().item() <= 6.0 * EPS[DT[dname]] * exact[ok].abs().max().item()
+    _C.set_gemm_variant(_C.VARIANT_MFMA_SIMPLE)
+    try:
+        unfused = mixed_precision_gemm_gelu_tanh_and_mul(*args)
+    finally:
+        _C.set_gemm_variant(_C.VARIANT_AUTO)
+    if m <= 64 and k % 1024 == 0:
+        assert (got.float() - unfused.float()).abs().max().item() <= 4.0 * EPS[DT[dname]] * unfused.float().abs().max().item()
+    else:
+        assert torch.equal(got, unfused)

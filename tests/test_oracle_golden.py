@@ -114,6 +114,9 @@ def test_scaled_gemm_silu_and_mul(golden, iname, oname, sa_s, sb_s, use_bias):
     got = oracle.scaled_gemm_silu_and_mul_ref(a, b, sa, sb, DT[oname], bias)
     assert got.shape == (a.shape[0], b.shape[1] // 2)
     np.testing.assert_array_equal(to_bits(got), y[f"y_{key}"])
+    # the GeGLU pair (scaled_gemm -> the reference's gelu_tanh_and_mul)
+    got = oracle.scaled_gemm_gelu_tanh_and_mul_ref(a, b, sa, sb, DT[oname], bias)
+    np.testing.assert_array_equal(to_bits(got), golden("scaled_gemm_gelu")[f"y_{key}"])
 
 
 MIXED_KEYS = [(w, z, d) for w in ("uint4b8", "uint8b128", "uint4", "uint8") for z in (1, 0) for d in ("f16", "bf16")]
@@ -146,6 +149,8 @@ def test_quantize_pack_dequant_mixed(golden, wname, zp, dname):
     # the FFN pair (mixed GEMM -> the reference's silu_and_mul)
     y = oracle.mixed_precision_gemm_silu_and_mul_ref(a, w_ref)
     np.testing.assert_array_equal(to_bits(y), golden("mixed_gemm_silu")[f"y_{key}"])
+    y = oracle.mixed_precision_gemm_gelu_tanh_and_mul_ref(a, w_ref)
+    np.testing.assert_array_equal(to_bits(y), golden("mixed_gemm_gelu")[f"y_{key}"])
 
 
 DYN_CASES = [(d, t, h) for d in DT for t, h in ((1, 16), (7, 67), (5, 768), (3, 2064), (2, 8200))]
