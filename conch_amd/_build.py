@@ -69,4 +69,9 @@ def build(force: bool = False, verbose: bool = False, probe: bool = False) -> Pa
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, probe="--probe" in sys.argv))
+    # both libraries by default: the diagnostic twin must export the same C ABI as the product library (bench.py opens it
+    # through the same ctypes declarations); --probe / --product build one of them only
+    if "--product" not in sys.argv:
+        print(build(force="--force" in sys.argv, verbose=True, probe=True))
+    if "--probe" not in sys.argv:
+        print(build(force="--force" in sys.argv, verbose=True, probe=False))

@@ -236,12 +236,28 @@ __global__ __launch_bounds__(kBnbThreads) void bnb_dequantize_kernel(void* __res
   // row-strided output (the GEMM's W^T scratch has the same rows): element e -> row e / row_len, column e % row_len
   const int64_t row = e0 / row_len, col = e0 - row * row_len;
   const int64_t o0 = row * out_stride_row + col;
+  float r[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    if (i >= valid) break;
-    float r = pin_f32(lut[c[i]] * am);
-    if constexpr (ADT != CONCH_DT_FP32) r = bits16_to_float<ADT>(float_to_bits16<ADT>(r));  // the product lives in absmax's dtype
-    store_scalar<ODT>(out, o0 + i, r);
+    r[i] = pin_f32(lut[c[i]] * am);
+    if constexpr (ADT != CONCH_DT_FP32) r[i] = bits16_to_float<ADT>(float_to_bits16<ADT>(r[i]));  // the product lives in absmax's dtype
+  }
+  constexpr int kEltBytes = ODT == CONCH_DT_FP32 ? 4 : 2;
+  char* dst = (char*)out + o0 * kEltBytes;
+  if (valid == 8 && ((uintptr_t)dst & 15) == 0) {  // whole group, aligned: 16-byte stores
+    if constexpr (ODT == CONCH_DT_FP32) {
+      ((f32x4*)dst)[0] = f32x4{r[0], r[1], r[2], r[3]};
+      ((f32x4*)dst)[1] = f32x4{r[4], r[5], r[6], r[7]};
+    } else {
+      i32x4 pk;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pk[j] = (int)pack2_bits16<ODT>(f32x2{r[2 * j], r[2 * j + 1]});
+      *(i32x4*)dst = pk;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < valid) store_scalar<ODT>(out, o0 + i, r[i]);
   }
 }
 

@@ -927,6 +927,34 @@ def test_nsharded_gemm_world1_equals_scaled_gemm():
 # ---------------------------------------------------------------------------------------------
 # the GeGLU pairs (second activation): gelu_tanh_and_mul fused behind both GEMMs
 # ---------------------------------------------------------------------------------------------
+def check_gelu(got, ref, gemm_out, out_dtype, exact_gemm):
+    """gelu_tanh_and_mul against the oracle (torch's F.gelu(approximate="tanh")).
+
+    torch evaluates 0.5 x (1 + tanh z) in fp32: for gates below about -3 the sum 1 + tanh z cancels and its result is a
+    multiple of 2^-24 -- the gate value carries an ABSOLUTE error of up to |x| 2^-24, far more than an fp16 / bf16 ulp of the
+    tiny result.  The device evaluates the same function as x sigmoid(2z) (no cancellation), so on those elements the two
+    differ by torch's own evaluation error, amplified by |up|.  Bound per element, with g, u = gate, up of the (exact) GEMM:
+        |dy| <= |u| (|g| 2^-22 + 2 ulp(gelu(g))) + 2 ulp(y);   elsewhere the silu pair's bar (two output ulps)."""
+    if not exact_gemm:
+        check_silu(got, ref, out_dtype, exact_gemm=False)
+        return
+    gv, r = got.float().cpu(), ref.float()
+    d = gemm_out.shape[1] // 2
+    gate, up = gemm_out[:, :d].float(), gemm_out[:, d:].float()
+    fin = torch.isfinite(r) & torch.isfinite(gate) & torch.isfinite(up)
+    assert torch.equal(torch.isnan(gv), torch.isnan(r))
+
+    def ulp(t):
+        return torch.maximum(torch.ldexp(torch.ones_like(t), torch.frexp(t)[1] - 1 - MANT[out_dtype]), torch.full_like(t, 2.0**-24))
+
+    s = torch.nn.functional.gelu(gate, approximate="tanh")
+    bound = up.abs() * (gate.abs() * 2.0**-22 + 2 * ulp(s)) + 2 * ulp(r)
+    assert ((gv - r).abs()[fin] <= bound[fin]).all(), f"worst excess {((gv - r).abs() - bound)[fin].max().item():.3g}"
+    # gates between about -6 and -2 sit in torch's cancellation regime: its value there is off by up to 2^-12 relative, which
+    # moves a bf16 rounding a few per cent of the time (measured 5.4 % of ALL elements on the reference's own recipe)
+    assert (gv[fin] != r[fin]).float().mean().item() <= 1e-1
+
+
 def run_gelu(a, b, sa, sb, out_dtype, bias):
     dev = lambda t: None if t is None else t.cuda()  # noqa: E731
     b_dev = b.T.contiguous().cuda().T if b.stride(0) == 1 else b.cuda()
@@ -947,7 +975,8 @@ def test_scaled_gemm_gelu_golden_from_reference(golden, iname, oname, key_tail):
     bias = from_bits(g[f"bias_{key}"], DT[oname]) if key_tail.endswith("b1") else None
     got = run_gelu(a, b, sa, sb, DT[oname], bias)
     assert got.shape == (128, 64) and got.dtype == DT[oname]
-    check_silu(got, from_bits(y[f"y_{key}"], DT[oname]), DT[oname], exact_gemm=iname == "int8")
+    check_gelu(got, from_bits(y[f"y_{key}"], DT[oname]), from_bits(g[f"c_{key}"], DT[oname]).reshape(128, 128), DT[oname],
+               exact_gemm=iname == "int8")
 
 
 @pytest.mark.parametrize("iname", ["int8", "fn"])
@@ -956,7 +985,7 @@ def test_scaled_gemm_gelu_shapes_fused_equals_unfused(iname, m, k, d):
     a, b, sa, sb, bias = make_scaled_inputs(m, k, 2 * d, IN_T[iname], torch.bfloat16, False, False, True)
     ref = oracle.scaled_gemm_gelu_tanh_and_mul_ref(a, b, sa, sb, torch.bfloat16, bias)
     got = run_gelu(a, b, sa, sb, torch.bfloat16, bias)
-    check_silu(got, ref, torch.bfloat16, exact_gemm=iname == "int8")
+    check_gelu(got, ref, oracle.scaled_gemm_ref(a, b, sa, sb, torch.bfloat16, bias), torch.bfloat16, exact_gemm=iname == "int8")
     _C.set_gemm_variant(_C.VARIANT_MFMA_SIMPLE)
     unfused = run_gelu(a, b, sa, sb, torch.bfloat16, bias)
     _C.set_gemm_variant(_C.VARIANT_AUTO)
