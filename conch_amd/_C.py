@@ -95,6 +95,15 @@ _SIGNATURES = {
         c_int,
         [c_void_p] * 5 + [_I64] * 8 + [c_int] * 6 + [c_void_p],
     ),
+    "conch_prepacked_mixed_weights_bytes": (_I64, [_I64, _I64, c_int, c_int]),
+    "conch_mixed_gemm_tile_nt": (c_int, [_I64, _I64, _I64, c_int, c_int]),
+    "conch_prepack_mixed_weights": (c_int, [c_void_p, c_void_p, _I64, _I64, _I64, c_int, c_int, c_void_p]),
+    "conch_unpack_mixed_weights": (c_int, [c_void_p, c_void_p, _I64, _I64, _I64, c_int, c_int, c_void_p]),
+    "conch_mixed_precision_gemm_prepacked": (c_int, [c_void_p] * 5 + [_I64] * 7 + [c_int] * 7 + [c_void_p]),
+    "conch_time_mixed_precision_gemm_prepacked": (
+        c_int,
+        [c_void_p] * 5 + [_I64] * 7 + [c_int] * 7 + [c_void_p, c_int, ctypes.POINTER(c_float)],
+    ),
     "conch_bnb_quantize_blockwise": (c_int, [c_void_p] * 4 + [_I64, c_int, c_int, c_int, c_int, c_void_p]),
     "conch_bnb_dequantize_blockwise": (c_int, [c_void_p] * 4 + [_I64, c_int, c_int, c_int, c_int, c_void_p]),
     "conch_bnb_gemm_4bit": (c_int, [c_void_p] * 4 + [_I64] * 5 + [c_int] * 5 + [c_void_p]),

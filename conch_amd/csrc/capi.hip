@@ -499,6 +499,82 @@ extern "C" int conch_mixed_precision_gemm(void* c, const void* x, const int32_t*
   return run_mixed(p, (hipStream_t)stream);
 }
 
+// ---- weight pre-pack ----
+static int check_prepack(int64_t k, int64_t n, int bits, int nt, const char* what) {
+  CONCH_CHECK_ARG(bits == 4 || bits == 8, "%s: %d-bit weights (the tile kernel takes 4 and 8)", what, bits);
+  CONCH_CHECK_ARG(nt >= 2 && nt <= 4, "%s: tile width %d x 64 columns (want 2, 3 or 4)", what, nt);
+  CONCH_CHECK_ARG(k >= 64 && k % 64 == 0 && n >= 1, "%s: K=%lld must be a multiple of 64, N=%lld positive", what, (long long)k, (long long)n);
+  CONCH_CHECK_ARG(prepacked_weight_words(k, n, bits, nt) * 4 < ((int64_t)1 << 31), "%s: image of 2 GiB or more", what);
+  return CONCH_OK;
+}
+
+extern "C" int64_t conch_prepacked_mixed_weights_bytes(int64_t k, int64_t n, int weight_bits, int tile_nt) {
+  if (check_prepack(k, n, weight_bits, tile_nt, "prepacked_mixed_weights_bytes")) return -1;
+  return prepacked_weight_words(k, n, weight_bits, tile_nt) * 4;
+}
+
+extern "C" int conch_mixed_gemm_tile_nt(int64_t m, int64_t n, int64_t k, int weight_bits, int zp_mode) {
+  MixedGemmArgs p{};
+  p.m = m;
+  p.n = n;
+  p.k = k;
+  p.bits = weight_bits;
+  p.zp_mode = zp_mode;
+  return mixed_gemm_tile_nt(p);
+}
+
+extern "C" int conch_prepack_mixed_weights(int32_t* image, const int32_t* w_q_packed, int64_t k, int64_t n, int64_t wq_stride_k,
+                                           int weight_bits, int tile_nt, void* stream) {
+  if (int rc = check_prepack(k, n, weight_bits, tile_nt, "prepack_mixed_weights")) return rc;
+  CONCH_CHECK_ARG(image && w_q_packed && wq_stride_k >= n, "prepack_mixed_weights: NULL pointer or row stride below N");
+  return prepack_mixed_weights((uint32_t*)image, (uint32_t*)w_q_packed, k, n, wq_stride_k, weight_bits, tile_nt, false, (hipStream_t)stream);
+}
+
+extern "C" int conch_unpack_mixed_weights(int32_t* w_q_packed, const int32_t* image, int64_t k, int64_t n, int64_t wq_stride_k,
+                                          int weight_bits, int tile_nt, void* stream) {
+  if (int rc = check_prepack(k, n, weight_bits, tile_nt, "unpack_mixed_weights")) return rc;
+  CONCH_CHECK_ARG(image && w_q_packed && wq_stride_k >= n, "unpack_mixed_weights: NULL pointer or row stride below N");
+  return prepack_mixed_weights((uint32_t*)image, (uint32_t*)w_q_packed, k, n, wq_stride_k, weight_bits, tile_nt, true, (hipStream_t)stream);
+}
+
+static int run_mixed_prepacked(MixedGemmArgs p, int tile_nt, hipStream_t stream) {
+  if (int rc = check_prepack(p.k, p.n > 0 ? p.n : 1, p.bits, tile_nt, "mixed_precision_gemm_prepacked")) return rc;
+  p.wq_stride_k = p.n;  // unused by the kernel; keeps the shared checks meaningful
+  if (int rc = check_mixed(p)) return rc;
+  if (p.m == 0 || p.n == 0) return CONCH_OK;
+  p.prepacked = tile_nt;
+  if (p.zp_mode == CONCH_ZP_TENSOR && tile_nt == 4) {
+    set_error("mixed_precision_gemm_prepacked: per-group zero points run on tiles of at most 192 columns (tile_nt <= 3)");
+    return CONCH_ERR_UNSUPPORTED;
+  }
+  if (!mixed_gemm_mfma_supported(p) || p.x_dtype != p.out_dtype) {
+    set_error("mixed_precision_gemm_prepacked: outside the tile kernel's contract (K %% 64 == 0, group_size %% 64 == 0, 16-byte "
+              "aligned activation rows, output dtype = activation dtype)");
+    return CONCH_ERR_UNSUPPORTED;
+  }
+  return launch_mixed_gemm_mfma(p, stream);
+}
+
+extern "C" int conch_mixed_precision_gemm_prepacked(void* c, const void* x, const int32_t* image, const void* w_s, const int32_t* w_zp,
+                                                    int64_t m, int64_t n, int64_t k, int64_t x_stride_m, int64_t ws_stride_g,
+                                                    int64_t wzp_stride_g, int64_t c_stride_m, int weight_bits, int weight_bias,
+                                                    int group_size, int zp_mode, int tile_nt, int x_dtype, int out_dtype, void* stream) {
+  const MixedGemmArgs p{c, x, image, w_s, w_zp, m, n, k, x_stride_m, n, ws_stride_g, wzp_stride_g, c_stride_m, weight_bits, weight_bias,
+                        group_size, zp_mode, x_dtype, out_dtype};
+  return run_mixed_prepacked(p, tile_nt, (hipStream_t)stream);
+}
+
+extern "C" int conch_time_mixed_precision_gemm_prepacked(void* c, const void* x, const int32_t* image, const void* w_s,
+                                                         const int32_t* w_zp, int64_t m, int64_t n, int64_t k, int64_t x_stride_m,
+                                                         int64_t ws_stride_g, int64_t wzp_stride_g, int64_t c_stride_m, int weight_bits,
+                                                         int weight_bias, int group_size, int zp_mode, int tile_nt, int x_dtype,
+                                                         int out_dtype, void* stream, int iters, float* avg_ms) {
+  const MixedGemmArgs p{c, x, image, w_s, w_zp, m, n, k, x_stride_m, n, ws_stride_g, wzp_stride_g, c_stride_m, weight_bits, weight_bias,
+                        group_size, zp_mode, x_dtype, out_dtype};
+  hipStream_t s = (hipStream_t)stream;
+  return time_loop([&] { return run_mixed_prepacked(p, tile_nt, s); }, s, iters, avg_ms);
+}
+
 extern "C" int conch_mixed_precision_gemm_modes(void* c, const void* x, const int32_t* w_q_packed, const void* scales, const void* zeros,
                                                 const void* channel_scales, int64_t m, int64_t n, int64_t k, int64_t x_stride_m,
                                                 int64_t wq_stride_k, int64_t scales_stride_g, int64_t zeros_stride_g,

@@ -43,6 +43,8 @@ struct MixedGemmArgs {
   // 1 = fused gate/up FFN form (conch_mixed_precision_gemm_silu_and_mul): Wq / w_s / w_zp have 2n columns [gate | up],
   // C has n columns, C[i][j] = silu(G[i][j]) * G[i][n + j] with G = the plain product rounded to out_dtype
   int fuse_silu = 0;
+  // != 0: w_q is the image conch_prepack_mixed_weights made for tiles of 64 x `prepacked` columns (2, 3 or 4)
+  int prepacked = 0;
 };
 
 // gemm_generic.hip
@@ -72,6 +74,11 @@ int launch_silu_and_mul(void* out, const void* x, int64_t m, int64_t n, int64_t 
                         hipStream_t stream);
 bool mixed_gemm_mfma_supported(const MixedGemmArgs& p);
 bool mixed_gemm_silu_fused_supported(const MixedGemmArgs& p);
+// weight pre-pack for the tile kernel (gemm_mixed.hip): image size in 32-bit words, pack / unpack, the width auto would pick
+int64_t prepacked_weight_words(int64_t k, int64_t n, int bits, int nt);
+int prepack_mixed_weights(uint32_t* image, uint32_t* plain, int64_t k, int64_t n, int64_t plain_stride, int bits, int nt, bool unpack,
+                          hipStream_t stream);
+int mixed_gemm_tile_nt(const MixedGemmArgs& p);
 int launch_mixed_gemm_mfma(const MixedGemmArgs& p, hipStream_t stream);
 // gemm_mixed_skinny.hip -- decode batches (M <= 64, K % 1024 == 0): weights straight to MFMA registers, split-K (variant 4)
 bool mixed_gemm_skinny_supported(const MixedGemmArgs& p);

@@ -41,8 +41,8 @@ using namespace tile;
 using mixed::ChunkDequant;
 
 // see ChunkDequant: bf16 x 8-bit weights with a zero point round the difference first
-template <int X_DT, int BITS, int ZP>
-using Dequant = ChunkDequant<X_DT, BITS, (X_DT == CONCH_DT_BF16 && BITS == 8 && ZP != CONCH_ZP_NONE)>;
+template <int X_DT, int BITS, int ZP, bool PRE = false>
+using Dequant = ChunkDequant<X_DT, BITS, (X_DT == CONCH_DT_BF16 && BITS == 8 && ZP != CONCH_ZP_NONE), PRE>;
 
 constexpr int kStepK = 64;  // k elements per step (128 bytes of 16-bit)
 
@@ -159,13 +159,36 @@ __device__ __forceinline__ void advance(WeightCursor& c, const WeightSrc& u) {
   c.z += wrap ? u.z_group : 0;
 }
 
-template <int BITS, int ZP, int NT>
+// PRE: the words come from the image conch_prepack_mixed_weights laid out -- the NT x kWpc words of a thread and K step are
+// contiguous (ONE 8 / 12 / 16-byte load per thread instead of NT 4-byte ones, 1 KiB contiguous per wave-instruction); ln.vq[0]
+// is the thread's byte offset inside a (tile column, K step) record, c.q the record's offset.
+template <int BITS, int ZP, int NT, bool PRE = false>
 __device__ __forceinline__ void load_weights(WeightRegs<BITS, NT>& r, const WeightLane& ln, const WeightSrc& u, const WeightCursor& c) {
   constexpr int kWpc = WeightRegs<BITS, NT>::kWpc;
+  if constexpr (PRE) {
+#pragma unroll
+    for (int i = 0; i < kWpc; ++i) {  // half i of the thread's record: words [it][i] for it = 0 .. NT-1
+      const int soff = c.q + i * NT * 4;
+      if constexpr (NT == 4) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(u.q, ln.vq[0], soff, 0);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) r.w[it][i] = v[it];
+      } else if constexpr (NT == 3) {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b96(u.q, ln.vq[0], soff, 0);
+#pragma unroll
+        for (int it = 0; it < 3; ++it) r.w[it][i] = v[it];
+      } else {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b64(u.q, ln.vq[0], soff, 0);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) r.w[it][i] = v[it];
+      }
+    }
+  } else {
 #pragma unroll
   for (int it = 0; it < NT; ++it)
 #pragma unroll
     for (int i = 0; i < kWpc; ++i) r.w[it][i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(u.q, ln.vq[it], c.q + i * u.q_row, 0);
+  }
 #pragma unroll
   for (int un = 0; un < (NT > 2 ? 2 : 1); ++un) {
     r.scale[un] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(u.s, ln.vs[un], c.s, 0);
@@ -210,11 +233,11 @@ struct LoopCtx {
 
 // One K step.  MODE 0: steps t+1 and t+2 exist; 1: t+1 exists; 2: last step.  ISSUE = the slot at which this
 // wave starts issuing the step's VMEM work.
-template <int X_DT, int BITS, int ZP, int NT, int MODE, int ISSUE, bool DEFER>
+template <int X_DT, int BITS, int ZP, int NT, int MODE, int ISSUE, bool DEFER, bool PRE = false>
 __device__ __forceinline__ void mixed_step(MixedTile& w, WeightRegs<BITS, NT>& regs, char* lds, const LoopCtx& c, WeightCursor& cur, int t) {
   constexpr int N1 = NT - 2;
   constexpr int kWpc = WeightRegs<BITS, NT>::kWpc;
-  constexpr int kSlices = Dequant<X_DT, BITS, ZP>::kSlices;
+  constexpr int kSlices = Dequant<X_DT, BITS, ZP, PRE>::kSlices;
   static_assert(kSlices <= 16, "more slices per chunk than MFMA slots per chunk");
   // everything this wave staged for step t (LDS-DMA, ds_write) and loaded for step t+1 is complete ...
 #ifdef CONCH_CLOCK_PROBE
@@ -244,7 +267,7 @@ __device__ __forceinline__ void mixed_step(MixedTile& w, WeightRegs<BITS, NT>& r
   };
   WeightRegs<BITS, NT> next;
 
-  Dequant<X_DT, BITS, ZP> cv[NT];
+  Dequant<X_DT, BITS, ZP, PRE> cv[NT];
   int slot = 0;  // a constant in every unrolled copy
   auto tail = [&](int sl) {
     // the step's VMEM work from slot ISSUE on: one per slot the four LDS-DMA pieces of X of step t+1, then the
@@ -257,7 +280,7 @@ __device__ __forceinline__ void mixed_step(MixedTile& w, WeightRegs<BITS, NT>& r
     }
     if constexpr (MODE == 0) {
       if (sl == ISSUE + 4) {
-        load_weights<BITS, ZP, NT>(next, c.ln, c.ws, cur);
+        load_weights<BITS, ZP, NT, PRE>(next, c.ln, c.ws, cur);
         advance(cur, c.ws);
       }
     }
@@ -335,7 +358,7 @@ __device__ __forceinline__ void mixed_step(MixedTile& w, WeightRegs<BITS, NT>& r
   if constexpr (MODE == 0) regs = next;
 }
 
-template <int X_DT, int BITS, int ZP, int NT, int ISSUE, bool DEFER>
+template <int X_DT, int BITS, int ZP, int NT, int ISSUE, bool DEFER, bool PRE = false>
 __device__ __forceinline__ void mixed_mainloop(MixedTile& w, WeightRegs<BITS, NT>& regs, char* lds, const LoopCtx& c, WeightCursor& cur, int steps) {
   if constexpr (DEFER) {
 #pragma unroll
@@ -344,12 +367,12 @@ __device__ __forceinline__ void mixed_mainloop(MixedTile& w, WeightRegs<BITS, NT
     for (int tt = 0; tt < 2; ++tt) w.fn[0][tt] = Frag{i32x4{0, 0, 0, 0}, i32x4{0, 0, 0, 0}};
   }
   int t = 0;
-  for (; t + 2 < steps; ++t) mixed_step<X_DT, BITS, ZP, NT, 0, ISSUE, DEFER>(w, regs, lds, c, cur, t);
+  for (; t + 2 < steps; ++t) mixed_step<X_DT, BITS, ZP, NT, 0, ISSUE, DEFER, PRE>(w, regs, lds, c, cur, t);
   if (steps > 1) {
-    mixed_step<X_DT, BITS, ZP, NT, 1, ISSUE, DEFER>(w, regs, lds, c, cur, t);
+    mixed_step<X_DT, BITS, ZP, NT, 1, ISSUE, DEFER, PRE>(w, regs, lds, c, cur, t);
     ++t;
   }
-  mixed_step<X_DT, BITS, ZP, NT, 2, ISSUE, DEFER>(w, regs, lds, c, cur, t);
+  mixed_step<X_DT, BITS, ZP, NT, 2, ISSUE, DEFER, PRE>(w, regs, lds, c, cur, t);
   if constexpr (DEFER) {  // the last step's phase 3
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -364,8 +387,9 @@ __device__ __forceinline__ void mixed_mainloop(MixedTile& w, WeightRegs<BITS, NT
 __device__ unsigned long long g_probe_mixed[kProbeBlocks * 8];
 #endif
 
-template <int X_DT, int OUT_DT, int BITS, int ZP, int NT, bool SILU = false>
+template <int X_DT, int OUT_DT, int BITS, int ZP, int NT, bool SILU = false, bool PRE = false>
 __global__ __launch_bounds__(kThreads, 2) void mixed_gemm_kernel(MixedGemmArgs p) {
+  static_assert(!(SILU && PRE), "the fused gate/up form reads the plain [K/pf][N] layout");
   static_assert(!SILU || NT == 4, "the fused gate/up form pairs the V1 and V2 units of a full-width tile");
   // SILU (conch_mixed_precision_gemm_silu_and_mul): a tile is 256 rows x 128 OUTPUT columns; a wave-column owns 32 of
   // them, V1 holds their gate columns and V2 the up columns p.n further right, so accumulator tiles 0,1 / 2,3 of a lane
@@ -421,10 +445,17 @@ __global__ __launch_bounds__(kThreads, 2) void mixed_gemm_kernel(MixedGemmArgs p
     c.ws.z = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_zp, 0, (uint32_t)(((groups - 1) * p.wzp_stride_g + w_cols) * 4), 0x00020000);
   c.ws.q_row = (int)p.wq_stride_k * 4;
   c.ws.q_step = kWordRowsPerStep * c.ws.q_row;
+  if constexpr (PRE) {  // records of 512 threads x NT x kWpc words per (tile column, K step): mixed_prepack.hpp
+    constexpr int kRecord = 512 * NT * kWpc * 4;
+    const int64_t image_bytes = (int64_t)tiles_n * (p.k / kStepK) * kRecord;
+    c.ws.q = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_q, 0, (uint32_t)image_bytes, 0x00020000);
+    c.ws.q_step = kRecord;
+    c.ln.vq[0] = (int)threadIdx.x * NT * kWpc * 4;
+  }
   c.ws.s_group = (int)p.ws_stride_g * 2;
   c.ws.z_group = (int)p.wzp_stride_g * 4;
   c.ws.steps_per_group = p.group_size / kStepK;
-  WeightCursor cur = {cp * kWpc * c.ws.q_row, 0, 0, c.ws.steps_per_group};
+  WeightCursor cur = {PRE ? tc.tn * (int)(p.k / kStepK) * c.ws.q_step : cp * kWpc * c.ws.q_row, 0, 0, c.ws.steps_per_group};
   c.off_base = p.weight_bias + (ZP == CONCH_ZP_SCALAR ? p.w_zp[0] : 0);
 
   // fragment read offsets
@@ -451,24 +482,24 @@ __global__ __launch_bounds__(kThreads, 2) void mixed_gemm_kernel(MixedGemmArgs p
   stage_x_piece<0, 1>(lds, c.src, c.so, c.wave, 0);
   stage_x_piece<1, 0>(lds, c.src, c.so, c.wave, 0);
   stage_x_piece<1, 1>(lds, c.src, c.so, c.wave, 0);
-  load_weights<BITS, ZP, NT>(regs, c.ln, c.ws, cur);
+  load_weights<BITS, ZP, NT, PRE>(regs, c.ln, c.ws, cur);
   advance(cur, c.ws);
 #pragma unroll
   for (int it = 0; it < NT; ++it) {
-    Dequant<X_DT, BITS, ZP> cv;
+    Dequant<X_DT, BITS, ZP, PRE> cv;
 #pragma unroll
-    for (int sl = 0; sl < Dequant<X_DT, BITS, ZP>::kSlices; ++sl)
+    for (int sl = 0; sl < Dequant<X_DT, BITS, ZP, PRE>::kSlices; ++sl)
       cv.slice(sl, regs.w[it][0], regs.w[it][kWpc - 1], c.off_base + regs.zp[it < 2 ? 0 : 1], regs.scale[it < 2 ? 0 : 1], lds + kXBytes + c.ln.lds[it], c.and_mask, c.or_magic);
   }
   if (steps > 1) {
-    load_weights<BITS, ZP, NT>(regs, c.ln, c.ws, cur);
+    load_weights<BITS, ZP, NT, PRE>(regs, c.ln, c.ws, cur);
     advance(cur, c.ws);
   }
 
   // The two waves of a SIMD (w and w + 4) issue their VMEM work at different places of the step.
   CONCH_PROBE(g_probe_mixed, 0);
-  if (wr == 0) mixed_mainloop<X_DT, BITS, ZP, NT, 0, false>(w, regs, lds, c, cur, steps);
-  else mixed_mainloop<X_DT, BITS, ZP, NT, 16, true>(w, regs, lds, c, cur, steps);
+  if (wr == 0) mixed_mainloop<X_DT, BITS, ZP, NT, 0, false, PRE>(w, regs, lds, c, cur, steps);
+  else mixed_mainloop<X_DT, BITS, ZP, NT, 16, true, PRE>(w, regs, lds, c, cur, steps);
   CONCH_PROBE(g_probe_mixed, 1);
 #ifdef CONCH_CLOCK_PROBE
   if (threadIdx.x == 0 && blockIdx.x < kProbeBlocks) {  // slots 4..7 of the block: cycles at the step-top wait / barrier (wave 0)
@@ -503,6 +534,30 @@ int launch_zp(const MixedGemmArgs& p, hipStream_t stream) {
   }
   const int tiles_n = (int)((p.n + 64 * NT - 1) / (64 * NT));
   const dim3 grid((unsigned)(tiles_m * tiles_n));
+  if (p.prepacked) {  // weights in the image of conch_prepack_mixed_weights for THIS tile width; instantiated for OUT_DT == X_DT
+    if constexpr (X_DT == OUT_DT) {
+      switch (p.zp_mode) {
+        case CONCH_ZP_NONE:
+          hipLaunchKernelGGL((mixed_gemm_kernel<X_DT, OUT_DT, BITS, CONCH_ZP_NONE, NT, false, true>), grid, dim3(kThreads), 0, stream, p);
+          break;
+        case CONCH_ZP_SCALAR:
+          hipLaunchKernelGGL((mixed_gemm_kernel<X_DT, OUT_DT, BITS, CONCH_ZP_SCALAR, NT, false, true>), grid, dim3(kThreads), 0, stream, p);
+          break;
+        default:
+          if constexpr (NT == 4) {
+            set_error("mixed_precision_gemm: 256-column tiles are not built for per-group zero points");
+            return CONCH_ERR_UNSUPPORTED;
+          } else {
+            hipLaunchKernelGGL((mixed_gemm_kernel<X_DT, OUT_DT, BITS, CONCH_ZP_TENSOR, NT, false, true>), grid, dim3(kThreads), 0, stream, p);
+          }
+          break;
+      }
+      return check_launch("mixed_gemm_mfma_prepacked");
+    } else {
+      set_error("mixed_precision_gemm (prepacked): output dtype must equal the activation dtype");
+      return CONCH_ERR_UNSUPPORTED;
+    }
+  }
   switch (p.zp_mode) {
     case CONCH_ZP_NONE:
       hipLaunchKernelGGL((mixed_gemm_kernel<X_DT, OUT_DT, BITS, CONCH_ZP_NONE, NT>), grid, dim3(kThreads), 0, stream, p);
@@ -557,7 +612,103 @@ int launch_bits(const MixedGemmArgs& p, int nt, hipStream_t stream) {
   return p.bits == 4 ? launch_nt<X_DT, OUT_DT, 4>(p, nt, stream) : launch_nt<X_DT, OUT_DT, 8>(p, nt, stream);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Weight pre-pack (the reference's comparator does the same for its kernel:
+// benchmarks/mixed_precision_gemm_benchmark.py:59-75, machete_prepack_B).  The [K/pf][N] tensor is rewritten ONCE, offline,
+// into the order the K loop consumes it: for every (tile column of 64 NT output columns, K step of 64) one record of
+// 512 threads x (kWpc halves x NT words) -- exactly the registers mixed_gemm_kernel's threads hold for that step -- with the
+// nibbles of every word re-ordered so that the in-register dequantisation needs no permute (ChunkDequant, PRE).
+// The item <-> (column, 8-k chunk) map below is THE map of the kernel's prologue; pack and unpack share it.
+// ---------------------------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ void weight_item(int tid, int it, int bn0, int n_max, int& chunk, int& ncol) {
+  const int rho = tid & 127, cp = tid >> 7;
+  const int r5 = rho & 31, r = r5 & 15, tq = r5 >> 4;
+  const int wcol = (rho >> 5) * 16 * NT;
+  const int pair = 8 * (r >> 2) + (r & 3) + 4 * tq;
+  const int n1 = min(bn0 + wcol + pair, n_max);
+  const int n2 = min(bn0 + wcol + 32 + (NT == 4 ? pair : r), n_max);
+  const int dchunk = it == 0 ? 0 : it == 1 ? 4 : it == 2 ? (NT == 4 ? 0 : 4 * tq) : 4;
+  chunk = cp + dchunk;
+  ncol = it < 2 ? n1 : n2;
+}
+
+template <int BITS>
+__device__ __forceinline__ uint32_t reorder_word(uint32_t w, bool inverse) {
+  if constexpr (BITS == 4) {
+    // plain: nibble j = k j.  packed: nibble j = k 2j, nibble j + 4 = k 2j + 1
+    uint32_t out = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int pj = (j & 1) * 4 + (j >> 1);  // packed position of k j
+      out |= inverse ? ((w >> (4 * pj)) & 0xfu) << (4 * j) : ((w >> (4 * j)) & 0xfu) << (4 * pj);
+    }
+    return out;
+  } else {
+    // bytes k0 k1 k2 k3 <-> k0 k2 k1 k3 (its own inverse)
+    return (w & 0xff0000ffu) | ((w & 0x0000ff00u) << 8) | ((w & 0x00ff0000u) >> 8);
+  }
+}
+
+template <int BITS, int NT, bool UNPACK>
+__global__ __launch_bounds__(kThreads) void prepack_kernel(uint32_t* __restrict__ image, uint32_t* __restrict__ plain, int64_t n, int64_t plain_stride,
+                                                           int steps) {
+  constexpr int kWpc = BITS == 4 ? 1 : 2;
+  constexpr int kWordRowsPerStep = kStepK * BITS / 32;
+  const int tn = blockIdx.x / steps, t = blockIdx.x - tn * steps;
+  const int tid = threadIdx.x;
+  uint32_t* rec = image + ((int64_t)blockIdx.x * kThreads + tid) * (NT * kWpc);
+#pragma unroll
+  for (int it = 0; it < NT; ++it) {
+    int chunk, ncol;
+    weight_item<NT>(tid, it, tn * 64 * NT, (int)n - 1, chunk, ncol);
+#pragma unroll
+    for (int i = 0; i < kWpc; ++i) {
+      uint32_t* src = plain + ((int64_t)t * kWordRowsPerStep + chunk * kWpc + i) * plain_stride + ncol;
+      if constexpr (UNPACK) *src = reorder_word<BITS>(rec[i * NT + it], true);  // clamped duplicates write equal words
+      else rec[i * NT + it] = reorder_word<BITS>(*src, false);
+    }
+  }
+}
+
+template <bool UNPACK>
+int launch_prepack(uint32_t* image, uint32_t* plain, int64_t k, int64_t n, int64_t plain_stride, int bits, int nt, hipStream_t stream) {
+  const int steps = (int)(k / kStepK);
+  const int tiles_n = (int)((n + 64 * nt - 1) / (64 * nt));
+  const dim3 grid((unsigned)(tiles_n * steps)), block(kThreads);
+#define CONCH_LAUNCH(B, N) hipLaunchKernelGGL((prepack_kernel<B, N, UNPACK>), grid, block, 0, stream, image, plain, n, plain_stride, steps)
+  if (bits == 4) {
+    if (nt == 4) CONCH_LAUNCH(4, 4);
+    else if (nt == 3) CONCH_LAUNCH(4, 3);
+    else CONCH_LAUNCH(4, 2);
+  } else {
+    if (nt == 4) CONCH_LAUNCH(8, 4);
+    else if (nt == 3) CONCH_LAUNCH(8, 3);
+    else CONCH_LAUNCH(8, 2);
+  }
+#undef CONCH_LAUNCH
+  return check_launch(UNPACK ? "unpack_mixed_weights" : "prepack_mixed_weights");
+}
+
 }  // namespace
+
+int64_t prepacked_weight_words(int64_t k, int64_t n, int bits, int nt) {
+  const int64_t steps = k / kStepK, tiles_n = (n + 64 * nt - 1) / (64 * nt);
+  return tiles_n * steps * kThreads * nt * (bits == 4 ? 1 : 2);
+}
+
+int prepack_mixed_weights(uint32_t* image, uint32_t* plain, int64_t k, int64_t n, int64_t plain_stride, int bits, int nt, bool unpack,
+                          hipStream_t stream) {
+  return unpack ? launch_prepack<true>(image, plain, k, n, plain_stride, bits, nt, stream)
+                : launch_prepack<false>(image, plain, k, n, plain_stride, bits, nt, stream);
+}
+
+// the tile width the dispatcher would pick for this problem (so that a caller can pre-pack for it)
+int mixed_gemm_tile_nt(const MixedGemmArgs& p) {
+  int nt = pick_nt(p, device_cu_count());
+  if (p.zp_mode == CONCH_ZP_TENSOR && nt == 4) nt = 3;
+  return nt;
+}
 
 // the fused gate/up epilogue runs on the 256-column tile only, which is not built for per-group zero points
 bool mixed_gemm_silu_fused_supported(const MixedGemmArgs& p) { return p.zp_mode != CONCH_ZP_TENSOR && mixed_gemm_mfma_supported(p); }
@@ -576,7 +727,12 @@ bool mixed_gemm_mfma_supported(const MixedGemmArgs& p) {
   // the weight arrays are addressed through 32-bit buffer offsets
   const int64_t lim32 = (int64_t)1 << 32;
   const int64_t w_cols = p.fuse_silu ? 2 * p.n : p.n;
-  if (((p.k * p.bits / 32) * p.wq_stride_k + w_cols) * 4 >= lim32 || ((p.k / p.group_size) * p.ws_stride_g + w_cols) * 2 >= lim32) return false;
+  if (p.prepacked) {
+    if (p.prepacked < 2 || p.prepacked > 4 || p.fuse_silu || prepacked_weight_words(p.k, p.n, p.bits, p.prepacked) * 4 >= ((int64_t)1 << 31)) return false;
+  } else if (((p.k * p.bits / 32) * p.wq_stride_k + w_cols) * 4 >= lim32) {
+    return false;
+  }
+  if (((p.k / p.group_size) * p.ws_stride_g + w_cols) * 2 >= lim32) return false;
   if (p.zp_mode == CONCH_ZP_TENSOR && ((p.k / p.group_size) * p.wzp_stride_g + w_cols) * 4 >= lim32) return false;
   return true;
 }
@@ -586,6 +742,7 @@ int launch_mixed_gemm_mfma(const MixedGemmArgs& p, hipStream_t stream) {
   const int forced = tuning(1);  // CONCH_TUNE_MIXED_TILE_NT: 0 = auto, 2..4 = force
   int nt = p.fuse_silu ? 4 : (forced >= 2 && forced <= 4) ? forced : pick_nt(p, num_cus);
   if (p.zp_mode == CONCH_ZP_TENSOR && nt == 4 && !p.fuse_silu) nt = 3;
+  if (p.prepacked) nt = p.prepacked;  // the image was laid out for this width
   if (p.x_dtype == CONCH_DT_FP16) {
     return p.out_dtype == CONCH_DT_FP16 ? launch_bits<CONCH_DT_FP16, CONCH_DT_FP16>(p, nt, stream)
                                         : launch_bits<CONCH_DT_FP16, CONCH_DT_BF16>(p, nt, stream);

@@ -16,7 +16,10 @@ namespace mixed {
 // ROUND_DIFF: round (q - bias - zp) to bf16 before the scale multiply.  The reference forms the difference IN the meta dtype
 // (kernels/quantization/gemm.py:205-210; w_ref likewise casts the integer difference first, quant_utils.py:74): with 8-bit
 // weights, a bias and a zero point it can reach 383 in magnitude, which bf16 (8 significant bits) rounds -- fp16 never has to.
-template <int X_DT, int BITS, bool ROUND_DIFF = false>
+// PRE: the chunk comes from a tensor laid out by conch_prepack_mixed_weights -- int4: nibble j holds k 2j and nibble j + 4 holds
+// k 2j + 1 (int8: bytes k0, k2, k1, k3), so that ((w >> 4j) & mask) | magic IS output dword j = (k 2j, k 2j + 1): the four
+// v_perm_b32 of the fp16 path and the cross pairing of the bf16 path disappear (19 -> 15 VALU per eight int4 weights).
+template <int X_DT, int BITS, bool ROUND_DIFF = false, bool PRE = false>
 struct ChunkDequant {
   static constexpr bool kHalf = X_DT == CONCH_DT_FP16;
   static constexpr int kSlices = 10;  // the last one is the ds_write_b128
@@ -43,8 +46,14 @@ struct ChunkDequant {
       hi = unpack2_bits16<CONCH_DT_BF16>(pack2_bits16<CONCH_DT_BF16>(hi));
     }
   }
+  static __device__ __forceinline__ f32x2 widen1(uint32_t x) {
+    const f16x2 hx = __builtin_bit_cast(f16x2, x);
+    f32x2 v = f32x2{(float)hx[0], (float)hx[1]};
+    if constexpr (ROUND_DIFF) v = unpack2_bits16<CONCH_DT_BF16>(pack2_bits16<CONCH_DT_BF16>(v));
+    return v;
+  }
   // output dword j of the chunk is the pair (k 2j, k 2j+1)
-  static constexpr int kOutLoP = 0, kOutHiP = BITS == 4 ? 2 : 1, kOutLoQ = BITS == 4 ? 1 : 2, kOutHiQ = 3;
+  static constexpr int kOutLoP = 0, kOutHiP = PRE ? 1 : (BITS == 4 ? 2 : 1), kOutLoQ = PRE ? 2 : (BITS == 4 ? 1 : 2), kOutHiQ = 3;
 
   // `mask` (a VGPR) and `magic` (an SGPR) hold 0x000f000f / 0x00ff00ff and 0x64006400 as VALUES the compiler cannot see:
   // with literals it emits v_and_b32 + v_or_b32 (a VOP3 instruction cannot carry a 32-bit literal on gfx9); with
@@ -80,19 +89,39 @@ struct ChunkDequant {
         c = pk_mul(c, sc);
         d = pk_mul(d, sc);
       } else if (s == 7) {
-        out[kOutLoP] = (int)__builtin_amdgcn_perm(b, a, kLowHalves);
-        out[kOutHiP] = (int)__builtin_amdgcn_perm(b, a, kHighHalves);
+        if constexpr (PRE) {
+          out[0] = (int)a;
+          out[1] = (int)b;
+        } else {
+          out[kOutLoP] = (int)__builtin_amdgcn_perm(b, a, kLowHalves);
+          out[kOutHiP] = (int)__builtin_amdgcn_perm(b, a, kHighHalves);
+        }
       } else if (s == 8) {
-        out[kOutLoQ] = (int)__builtin_amdgcn_perm(d, c, kLowHalves);
-        out[kOutHiQ] = (int)__builtin_amdgcn_perm(d, c, kHighHalves);
+        if constexpr (PRE) {
+          out[2] = (int)c;
+          out[3] = (int)d;
+        } else {
+          out[kOutLoQ] = (int)__builtin_amdgcn_perm(d, c, kLowHalves);
+          out[kOutHiQ] = (int)__builtin_amdgcn_perm(d, c, kHighHalves);
+        }
       } else if (s == 9) {
         *(i32x4*)dst = out;
       }
     } else {
       if (s == 5) {
-        widen(a, b, p_lo, p_hi);
+        if constexpr (PRE) {
+          p_lo = widen1(a);  // -> output dword 0
+          p_hi = widen1(b);  // -> 1
+        } else {
+          widen(a, b, p_lo, p_hi);
+        }
       } else if (s == 6) {
-        widen(c, d, q_lo, q_hi);
+        if constexpr (PRE) {
+          q_lo = widen1(c);  // -> 2
+          q_hi = widen1(d);  // -> 3
+        } else {
+          widen(c, d, q_lo, q_hi);
+        }
       } else if (s == 7) {
         out[kOutLoP] = (int)pack2_bits16<CONCH_DT_BF16>(p_lo * f32x2{fs, fs});
         out[kOutHiP] = (int)pack2_bits16<CONCH_DT_BF16>(p_hi * f32x2{fs, fs});

@@ -265,6 +265,29 @@ int conch_mixed_precision_gemm_modes(void* c, const void* x, const int32_t* w_q_
                                      int channel_mode, int x_dtype, int out_dtype, void* stream);
 
 /*
+ * Weight pre-pack for the tile kernel (the reference's comparator pre-packs for ITS kernel,
+ * benchmarks/mixed_precision_gemm_benchmark.py:59-75).  conch_prepack_mixed_weights rewrites the [K*bits/32][N] packed tensor
+ * (kernels/quantization/gemm.py:320-326) ONCE, offline, into the order the K loop consumes it for tiles of 64 * tile_nt output
+ * columns: per (tile column, K step of 64) one contiguous record of 512 threads x tile_nt x (bits/4) words, nibbles re-ordered so
+ * that the in-register dequantisation needs no permute.  Same number of bytes as the source (rounded up to whole tiles).
+ *   conch_mixed_gemm_tile_nt               the tile width (2, 3 or 4) the dispatcher picks for (M, N, K): pre-pack for it
+ *   conch_prepacked_mixed_weights_bytes    size of the image (-1 on bad arguments)
+ *   conch_unpack_mixed_weights             the inverse (round trip: unpack(prepack(w)) == w)
+ *   conch_mixed_precision_gemm_prepacked   conch_mixed_precision_gemm on an image; bit-identical results; weight_bits 4 | 8,
+ *                                          out_dtype == x_dtype, per-group zero points need tile_nt <= 3
+ */
+int64_t conch_prepacked_mixed_weights_bytes(int64_t k, int64_t n, int weight_bits, int tile_nt);
+int conch_mixed_gemm_tile_nt(int64_t m, int64_t n, int64_t k, int weight_bits, int zp_mode);
+int conch_prepack_mixed_weights(int32_t* image, const int32_t* w_q_packed, int64_t k, int64_t n, int64_t wq_stride_k,
+                                int weight_bits, int tile_nt, void* stream);
+int conch_unpack_mixed_weights(int32_t* w_q_packed, const int32_t* image, int64_t k, int64_t n, int64_t wq_stride_k,
+                               int weight_bits, int tile_nt, void* stream);
+int conch_mixed_precision_gemm_prepacked(void* c, const void* x, const int32_t* image, const void* w_s, const int32_t* w_zp,
+                                         int64_t m, int64_t n, int64_t k, int64_t x_stride_m, int64_t ws_stride_g,
+                                         int64_t wzp_stride_g, int64_t c_stride_m, int weight_bits, int weight_bias,
+                                         int group_size, int zp_mode, int tile_nt, int x_dtype, int out_dtype, void* stream);
+
+/*
  * mixed_precision_gemm_silu_and_mul  (SURVEY.md 8(f) N3 for the int4 / int8-weight FFN: the reference's pair
  * mixed_precision_gemm (kernels/quantization/gemm.py:482-545) + silu_and_mul (ops/activation/silu_and_mul.py:11-29)
  * in one launch).  w_q_packed / w_s / w_zp have 2 n_out columns [gate | up]; C: [M][n_out]:
@@ -322,6 +345,11 @@ int conch_time_scaled_gemm_silu_and_mul(void* c, const void* a, const void* b, c
                            int64_t scale_a_numel, int64_t scale_b_numel, int in_dtype,
                            int out_dtype, void* stream, int iters, float* avg_ms);
 
+int conch_time_mixed_precision_gemm_prepacked(void* c, const void* x, const int32_t* image, const void* w_s,
+                                              const int32_t* w_zp, int64_t m, int64_t n, int64_t k, int64_t x_stride_m,
+                                              int64_t ws_stride_g, int64_t wzp_stride_g, int64_t c_stride_m, int weight_bits,
+                                              int weight_bias, int group_size, int zp_mode, int tile_nt, int x_dtype,
+                                              int out_dtype, void* stream, int iters, float* avg_ms);
 int conch_time_mixed_precision_gemm(void* c, const void* x, const int32_t* w_q_packed,
                                     const void* w_s, const int32_t* w_zp, int64_t m, int64_t n,
                                     int64_t k, int64_t x_stride_m, int64_t wq_stride_k,

@@ -1021,3 +1021,51 @@ def test_mixed_precision_gelu_fused(m, k, d, wname, use_zp, dname):
         assert (got.float() - unfused.float()).abs().max().item() <= 4.0 * EPS[DT[dname]] * unfused.float().abs().max().item()
     else:
         assert torch.equal(got, unfused)
+
+
+# ---------------------------------------------------------------------------------------------
+# weight pre-pack
+# ---------------------------------------------------------------------------------------------
+from conch_amd.ops.quantization.prepack import (  # noqa: E402
+    mixed_precision_gemm_prepacked,
+    prepack_mixed_weights,
+    unpack_mixed_weights,
+)
+
+
+@pytest.mark.parametrize("bits", [4, 8])
+@pytest.mark.parametrize("tile_nt", [2, 3, 4])
+@pytest.mark.parametrize(("k", "n"), [(64, 64), (256, 1376), (512, 200), (4096, 11008), (128, 1)])
+def test_prepack_round_trip(bits, tile_nt, k, n):
+    """unpack(prepack(w)) == w for every width / tile width, ragged N included (clamped columns of the last tile)."""
+    w = torch.randint(-2**31, 2**31 - 1, (k * bits // 32, n), dtype=torch.int32, device="cuda")
+    pre = prepack_mixed_weights(w, bits, tile_nt=tile_nt)
+    assert pre.image.numel() == -(-n // (64 * tile_nt)) * (k // 64) * 512 * tile_nt * (1 if bits == 4 else 2)
+    assert torch.equal(unpack_mixed_weights(pre), w)
+    assert not torch.equal(pre.image[: w.numel()].view_as(w), w) or k * n <= 64  # it IS a different layout
+
+
+@pytest.mark.parametrize(("wname", "use_zp", "dname"), [("uint4b8", False, "f16"), ("uint4", True, "bf16"), ("uint8b128", False, "bf16"),
+                                                         ("uint8", True, "f16"), ("uint4b8", False, "bf16")])
+@pytest.mark.parametrize(("m", "k", "n"), [(1024, 512, 1376), (300, 256, 520), (2048, 1024, 4096), (257, 128, 200)])
+@pytest.mark.parametrize("tile_nt", [None, 2, 3])
+def test_prepacked_gemm_is_bit_identical(wname, use_zp, dname, m, k, n, tile_nt):
+    wt = WTYPES[wname]
+    a, w_ref, packed, w_s, w_zp = make_mixed_inputs(m, k, n, wt, use_zp, DT[dname])
+    dev = lambda t: None if t is None else t.cuda()  # noqa: E731
+    plain = mixed_precision_gemm(dev(a), dev(packed), dev(w_s), dev(w_zp), wt.size_bits, wt.bias, 128)
+    pre = prepack_mixed_weights(dev(packed), wt.size_bits, m_hint=m, per_group_zero_points=use_zp, tile_nt=tile_nt)
+    got = mixed_precision_gemm_prepacked(dev(a), pre, dev(w_s), dev(w_zp), wt.bias, 128)
+    assert torch.equal(got, plain)
+    check_mixed(got, a, w_ref, k)
+
+
+def test_prepacked_gemm_c4_config():
+    """BASELINE config C4 on a pre-packed weight: the same bits as the plain op at full size."""
+    m, k, n = 1024, 4096, 11008
+    wt = scalar_types.uint4b8
+    a, w_ref, packed, w_s, _ = make_mixed_inputs(m, k, n, wt, False, torch.float16)
+    plain = mixed_precision_gemm(a.cuda(), packed.cuda(), w_s.cuda(), None, wt.size_bits, wt.bias, 128)
+    pre = prepack_mixed_weights(packed.cuda(), wt.size_bits, m_hint=m)
+    assert pre.tile_nt == 3  # 232 tiles of 192 columns: one round of the chip
+    assert torch.equal(mixed_precision_gemm_prepacked(a.cuda(), pre, w_s.cuda(), None, wt.bias, 128), plain)
