@@ -17,6 +17,7 @@ ROOT = Path(__file__).resolve().parent.parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
+from conch_amd import envs  # noqa: E402
 from conch_amd.platforms import current_platform  # noqa: E402
 from conch_amd.utils.benchmark import BenchmarkMetadata, benchmark_it  # noqa: E402
 
@@ -46,8 +47,19 @@ def report_match(ok: bool, detail: str = "") -> None:
 
 
 def run_pair(name: str, ours, baseline, params: dict, iteration_time_ms: int, warmup_time_ms: int, csv: bool,
-             flops: float | None = None, nbytes: float | None = None) -> None:
+             flops: float | None = None, nbytes: float | None = None, extra: dict | None = None) -> None:
+    """`extra`: further comparators {tag: callable}, timed only under CONCH_BENCH_ENABLE_ALL_REF=1 (the reference gates its
+    vLLM / bitsandbytes legs the same way, benchmarks/scaled_gemm_benchmark.py:196-214)."""
     md = BenchmarkMetadata(platform=current_platform.name(), params=params)
+    extras = []
+    if extra and envs.CONCH_BENCH_ENABLE_ALL_REF:
+        for tag, fn in extra.items():
+            try:
+                fn()
+            except Exception as exc:  # noqa: BLE001 -- a vendor path this build lacks is reported, not fatal
+                print(f"{tag}: unavailable ({str(exc)[:100]})", file=sys.stderr)
+                continue
+            extras.append(benchmark_it(fn, tag=tag, metadata=md, iteration_time_ms=iteration_time_ms, warmup_time_ms=warmup_time_ms))
     base = benchmark_it(baseline, tag="Baseline (PyTorch on GPU)", metadata=md, iteration_time_ms=iteration_time_ms,
                         warmup_time_ms=warmup_time_ms)
     mine = benchmark_it(ours, tag="conch_amd (HIP)", metadata=md, iteration_time_ms=iteration_time_ms,
@@ -55,6 +67,8 @@ def run_pair(name: str, ours, baseline, params: dict, iteration_time_ms: int, wa
     mine.print_parameters(csv=csv)
     mine.print_results(csv=csv)
     base.print_results(csv=csv)
+    for r in extras:
+        r.print_results(csv=csv)
     if not csv:
         if flops:
             print(f"{name}: {flops / (mine.median_ * 1e-3) / 1e12:.1f} TFLOP/s (median)")

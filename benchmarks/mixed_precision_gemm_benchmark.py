@@ -23,12 +23,14 @@ WEIGHT_TYPES = {"uint4b8": scalar_types.uint4b8, "uint8b128": scalar_types.uint8
 @click.option("--weight-dtype", default="uint4b8", type=click.Choice(sorted(WEIGHT_TYPES)))
 @click.option("--zero-points", is_flag=True)
 @click.option("--group-size", default=128, type=int)
+@click.option("--prepack", is_flag=True, help="pre-pack the weights for the tile kernel first (one-off, not timed), as the "
+              "reference does for its comparator (benchmarks/mixed_precision_gemm_benchmark.py:59-75)")
 @click.option("--iteration-time-ms", default=2000, type=int)
 @click.option("--warmup-time-ms", default=500, type=int)
 @click.option("--verbose", is_flag=True)
 @click.option("--gpu", default="cuda:0")
 @click.option("--csv", is_flag=True)
-def main(m_dim, k_dim, n_dim, input_dtype, weight_dtype, zero_points, group_size, iteration_time_ms, warmup_time_ms,
+def main(m_dim, k_dim, n_dim, input_dtype, weight_dtype, zero_points, group_size, prepack, iteration_time_ms, warmup_time_ms,
          verbose, gpu, csv):
     seed_everything(0)
     device = torch.device(gpu)
@@ -41,7 +43,15 @@ def main(m_dim, k_dim, n_dim, input_dtype, weight_dtype, zero_points, group_size
     a, w_ref, packed, w_s = a.to(device), w_ref.to(device), packed.to(device), w_s.to(device)
     w_zp = None if w_zp is None else w_zp.to(device)
 
+    pre = None
+    if prepack:
+        from conch_amd.ops.quantization.prepack import mixed_precision_gemm_prepacked, prepack_mixed_weights
+
+        pre = prepack_mixed_weights(packed, wt.size_bits, m_hint=m_dim, per_group_zero_points=w_zp is not None and w_zp.numel() > 1)
+
     def ours():
+        if pre is not None:
+            return mixed_precision_gemm_prepacked(a, pre, w_s, w_zp, wt.bias, group_size)
         return mixed_precision_gemm(a, packed, w_s, w_zp, wt.size_bits, wt.bias, group_size)
 
     ref = torch.matmul(a, w_ref)
@@ -51,7 +61,7 @@ def main(m_dim, k_dim, n_dim, input_dtype, weight_dtype, zero_points, group_size
     if verbose:
         print(out)
     params = {"m_dim": m_dim, "k_dim": k_dim, "n_dim": n_dim, "input_dtype": input_dtype, "weight_dtype": weight_dtype,
-              "zero_points": zero_points, "group_size": group_size}
+              "zero_points": zero_points, "group_size": group_size, "prepack": prepack}
     run_pair("mixed_precision_gemm", ours, lambda: torch.matmul(a, w_ref), params, iteration_time_ms, warmup_time_ms,
              csv, flops=2.0 * m_dim * n_dim * k_dim)
 

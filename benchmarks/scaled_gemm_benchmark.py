@@ -48,9 +48,14 @@ def main(m_dim, k_dim, n_dim, input_dtype, output_dtype, use_scalar_scale_a, use
         print(out)
     params = {"m_dim": m_dim, "k_dim": k_dim, "n_dim": n_dim, "input_dtype": input_dtype, "output_dtype": output_dtype,
               "scalar_scale_a": use_scalar_scale_a, "scalar_scale_b": use_scalar_scale_b, "bias": use_bias}
+    extra = None
+    if input_dtype == "fp8" and not use_scalar_scale_a and not use_scalar_scale_b:
+        # the vendor library's row-wise fp8 GEMM (hipBLASLt) -- this platform's counterpart of the reference's vLLM CUTLASS leg
+        sb_row = scale_b.T.contiguous()
+        extra = {"hipBLASLt (torch._scaled_mm)": lambda: torch._scaled_mm(a, b, scale_a=scale_a, scale_b=sb_row, bias=bias, out_dtype=out_dtype)}
     run_pair("scaled_gemm", lambda: scaled_gemm(a, b, scale_a, scale_b, out_dtype, bias),
              lambda: torch_scaled_gemm(a, b, scale_a, scale_b, out_dtype, bias), params, iteration_time_ms,
-             warmup_time_ms, csv, flops=2.0 * m_dim * n_dim * k_dim)
+             warmup_time_ms, csv, flops=2.0 * m_dim * n_dim * k_dim, extra=extra)
 
 
 if __name__ == "__main__":

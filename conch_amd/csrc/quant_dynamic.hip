@@ -1,7 +1,7 @@
 // Dynamic per-token quantisation feeders: fp16/bf16/fp32 [tokens][hidden] -> int8 / fp8 e4m3 + one fp32 scale per token.
 //
 // SURVEY.md 8(f) N1.  The reference stops at `scale is None -> NotImplementedError`
-// (conch/ops/quantization/int8.py:41-44, fp8.py:46-48); the per-row scale this op returns is exactly the (M, 1) `scale_a`
+// (conch/ops/quantization/int8.py:42-44, fp8.py:46-48); the per-row scale this op returns is exactly the (M, 1) `scale_a`
 // that scaled_gemm already takes (conch/ops/quantization/gemm.py:199-206).  Definition (oracle:
 // oracle/reference.py dynamic_scaled_{int8,fp8}_quant_ref): the STATIC op's arithmetic with a per-row scale,
 //   absmax[t] = max_h |float(x[t][h])|

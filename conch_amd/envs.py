@@ -1,8 +1,9 @@
 """Environment flags, evaluated lazily on attribute access (mirrors conch/envs.py:16-39).
 
-The optional third-party baselines the reference gates behind these flags (vLLM, bitsandbytes,
-its CUDA extension, torchvision) do not exist on the MI355X path, so every flag defaults to false
-and only switches harness behaviour.
+CONCH_BENCH_ENABLE_ALL_REF switches the extra comparator legs of benchmarks/*.py on (benchmarks/_common.py: the vendor
+library's GEMM where the reference times vLLM's).  The other names exist so that code written against the reference's
+module still imports; the third-party baselines they gate (vLLM, bitsandbytes, the CUDA extension, torchvision) do not
+exist on the MI355X path and nothing here reads them.
 """
 
 import os

@@ -128,6 +128,8 @@ def _scaled_gemm_call(
         sb = None
     if bias is not None:
         if bias.dtype != output.dtype:
+            # only the fused gate/up forms get here (no reference to match: the bias is added before the activation, in
+            # fp32, after this one rounding of the bias itself to the output dtype)
             bias = bias.to(output.dtype)
         bias = bias.reshape(-1).contiguous()
         if bias.numel() != metadata.n_dim:
@@ -158,8 +160,16 @@ def scaled_gemm_launcher(
     `bias` is an extension: the reference adds it with a second kernel
     (ops/quantization/gemm.py:249-250), here the epilogue fuses it with identical rounding.
     """
-    status = _scaled_gemm_call("conch_scaled_gemm", output, a, b, scale_a, scale_b, metadata, bias)
+    # The fused add reads the bias in the OUTPUT dtype.  A bias of another dtype (the reference's `output.add_(bias)`
+    # computes out + bias in the promoted type, e.g. fp32, and rounds once) is therefore added the reference's way, by a
+    # second pass -- casting it first would round the bias itself.
+    late_bias = bias if bias is not None and bias.dtype != output.dtype else None
+    status = _scaled_gemm_call("conch_scaled_gemm", output, a, b, scale_a, scale_b, metadata, None if late_bias is not None else bias)
     _C.check(status, "scaled_gemm")
+    if late_bias is not None:
+        if late_bias.numel() != metadata.n_dim:
+            raise ValueError(f"bias has {late_bias.numel()} elements, want N={metadata.n_dim}")
+        output.add_(late_bias.reshape(-1))
 
 
 def _scaled_gemm_act_and_mul(fn_name: str, what: str, output, a, b, scale_a, scale_b, metadata: ScaledMatmulMetadata, bias) -> None:

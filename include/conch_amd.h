@@ -169,7 +169,7 @@ int conch_static_scaled_fp8_quant(uint8_t* out, const void* x, const float* scal
 
 /*
  * Dynamic per-token quantisation.  The reference's wrappers stop at
- * `scale is None -> NotImplementedError` (conch/ops/quantization/int8.py:41-44, fp8.py:46-48); these entry points are
+ * `scale is None -> NotImplementedError` (conch/ops/quantization/int8.py:42-44, fp8.py:46-48); these entry points are
  * what a launcher behind that branch would bind.  Per token row t:
  *   scale_out[t] = max_h |x[t][h]| / QMAX  (fp32; QMAX = 127 | 448 e4m3fn | 240 e4m3fnuz; 1.0 for an all-zero row)
  *   out[t][h]    = the static op above applied with scale_out[t]

@@ -128,6 +128,20 @@ def test_scaled_gemm_large_shape_fnuz(oname, sa_scalar, sb_scalar, use_bias):
     check_scaled(run_scaled(a, b, sa, sb, DT[oname], bias), ref, IN_T["fnuz"], DT[oname], (a, b, sa, sb, bias))
 
 
+@pytest.mark.parametrize("oname", ["bf16", "f16"])
+def test_scaled_gemm_fp32_bias_is_added_like_the_reference(oname):
+    """A bias that is not in the output dtype: the reference's `output.add_(bias)` (ops/quantization/gemm.py:249-250) adds in
+    fp32 and rounds once; casting the bias first would round twice."""
+    m, k, n = 256, 512, 384
+    a, b, sa, sb, _ = make_scaled_inputs(m, k, n, torch.int8, DT[oname], False, False, False)
+    bias = torch.rand((n,), dtype=torch.float32)
+    nobias = oracle.scaled_gemm_ref(a, b, sa, sb, DT[oname], None)
+    want = (nobias.float() + bias).to(DT[oname])
+    got = run_scaled(a, b, sa, sb, DT[oname], bias).cpu()
+    assert got.dtype == DT[oname]
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+
+
 def test_scaled_gemm_small_scale_rows_and_columns():
     """Rows / columns whose scales are 1e-6 of the rest: a kernel that is wrong only there passes any max|C| bound."""
     m, k, n = 512, 1024, 768
