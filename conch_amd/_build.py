@@ -36,17 +36,23 @@ def _stale(target: Path, deps: list[Path]) -> bool:
 PROBE_LIB = PKG / "libconch_amd_probe.so"
 
 
-def build(force: bool = False, verbose: bool = False, probe: bool = False) -> Path:
+def build(force: bool = False, verbose: bool = False, probe: bool = False, variant: str | None = None, defines: tuple[str, ...] = ()) -> Path:
     """Compile every HIP source for gfx950 and link the shared library.  Returns its path.
 
     `probe=True` builds the DIAGNOSTIC twin libconch_amd_probe.so (-DCONCH_CLOCK_PROBE: in-kernel clock stamps
     around the GEMM K loops, read by tools/clock_probe.py); the product library never contains them.
+    `variant="x", defines=("-DFOO",)` builds libconch_amd_x.so with extra macros, for interleaved A/B runs of an experiment
+    against the product library in one process (tools/ab_lib.py); never loaded by the package itself.
     """
     headers = sorted(CSRC.glob("*.hpp")) + [ROOT / "include" / "conch_amd.h", Path(__file__)]
     objdir = PKG / ("build_probe" if probe else "build")
-    objdir.mkdir(exist_ok=True)
     flags = [*FLAGS, "-DCONCH_CLOCK_PROBE"] if probe else FLAGS
     lib = PROBE_LIB if probe else LIB
+    if variant:
+        objdir = PKG / f"build_{variant}"
+        flags = [*FLAGS, *defines]
+        lib = PKG / f"libconch_amd_{variant}.so"
+    objdir.mkdir(exist_ok=True)
 
     def compile_one(src: str) -> Path:
         s = CSRC / src
@@ -69,6 +75,10 @@ def build(force: bool = False, verbose: bool = False, probe: bool = False) -> Pa
 
 
 if __name__ == "__main__":
+    if "--variant" in sys.argv:  # python -m conch_amd._build --variant NAME -DMACRO ...
+        name = sys.argv[sys.argv.index("--variant") + 1]
+        print(build(force="--force" in sys.argv, verbose=True, variant=name, defines=tuple(a for a in sys.argv if a.startswith("-D"))))
+        sys.exit(0)
     # both libraries by default: the diagnostic twin must export the same C ABI as the product library (bench.py opens it
     # through the same ctypes declarations); --probe / --product build one of them only
     if "--product" not in sys.argv:

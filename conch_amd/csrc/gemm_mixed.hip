@@ -41,10 +41,15 @@ using namespace tile;
 using mixed::ChunkDequant;
 
 // see ChunkDequant: bf16 x 8-bit weights with a zero point round the difference first
-template <int X_DT, int BITS, int ZP, bool PRE = false>
-using Dequant = ChunkDequant<X_DT, BITS, (X_DT == CONCH_DT_BF16 && BITS == 8 && ZP != CONCH_ZP_NONE), PRE>;
+template <int X_DT, int BITS, int ZP, bool PRE = false, bool SILU = false>
+#ifdef CONCH_EXP_NO_SHIFTLESS  // A/B variant (tools/ab_lib.py): the int4 upper pairs shifted down as before
+using Dequant = ChunkDequant<X_DT, BITS, (X_DT == CONCH_DT_BF16 && BITS == 8 && ZP != CONCH_ZP_NONE), PRE, false>;
+#else
+using Dequant = ChunkDequant<X_DT, BITS, (X_DT == CONCH_DT_BF16 && BITS == 8 && ZP != CONCH_ZP_NONE), PRE, !SILU>;
+#endif
 
 constexpr int kStepK = 64;  // k elements per step (128 bytes of 16-bit)
+constexpr int kMixedTall = 5;  // tile code of the 512 x 128 tile (2..4 = 256 x 64 NT)
 
 struct MixedTile {
   f32x4 acc[8][4];
@@ -211,6 +216,15 @@ __device__ __forceinline__ void mma1(f32x4& acc, const Frag& fa, const Frag& fb,
 constexpr int kXBytes = 2 * kUnitBytes;
 constexpr int kStageBytes = 2 * kXBytes;
 constexpr int kMixedLdsBytes = 2 * kStageBytes;  // 128 KiB
+// TALL form: a tile of 512 rows x 128 columns (wave-rows 0..3 of 128 rows, wave-columns 0..1 of 64 columns -- a wave still owns
+// 128 x 64, so the MFMA phases are those of the 256-column tile).  Per K step the same 64 MFMAs per wave but HALF the weights to
+// dequantise (the loop's limiter is the vector issue port) against twice the X bytes to stage.  A stage is X (512 rows x 128 B,
+// row r of the block at byte 128 r: wave-row wr at 16 KiB wr) followed by ONE weight unit laid out like the 128-column
+// tile's (NT = 2: 32 columns per unit-row quarter, pairs of MFMA tiles interleaved); two stages = all 160 KiB of the CU.
+constexpr int kTallRows = 512;
+constexpr int kTallXBytes = kTallRows * kStepBytes;              // 64 KiB
+constexpr int kTallStageBytes = kTallXBytes + kUnitBytes;        // 80 KiB
+constexpr int kTallLdsBytes = 2 * kTallStageBytes;               // 160 KiB
 
 template <int UNIT2, int J>
 __device__ __forceinline__ void stage_x_piece(char* lds, const Srcs& src, const StageOffsets& so, int wave, int tile) {
@@ -218,9 +232,20 @@ __device__ __forceinline__ void stage_x_piece(char* lds, const Srcs& src, const 
   __builtin_amdgcn_raw_ptr_buffer_load_lds(src.a, (lds_void_t*)dst, 16, so.off[UNIT2 ? kU2 : kU1][J], tile * kStepBytes, 0, 0);
 }
 
+// TALL: piece J (0..7) of the 8 KiB of X rows [64 wave, 64 wave + 64) this wave stages per step; so.off[J >> 1][J & 1] is the
+// lane's source offset
+template <int J>
+__device__ __forceinline__ void stage_x_piece_tall(char* lds, const Srcs& src, const StageOffsets& so, int wave, int tile) {
+  char* dst = lds + (tile & 1) * kTallStageBytes + wave * 8192 + J * 1024;
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(src.a, (lds_void_t*)dst, 16, so.off[J >> 1][J & 1], tile * kStepBytes, 0, 0);
+}
+
 struct LoopCtx {
-#ifdef CONCH_CLOCK_PROBE
-  mutable unsigned long long wait_cycles = 0, barrier_cycles = 0;  // diagnostic build: time at the step-top wait / barrier
+#ifdef CONCH_CLOCK_PROBE_STEPS
+  // -DCONCH_CLOCK_PROBE_STEPS (on top of the diagnostic twin's -DCONCH_CLOCK_PROBE): time at the step-top wait / barrier.  Off
+  // by default: s_memtime is a scalar-memory operation, and with one outstanding the compiler must open every step's fragment
+  // waits with lgkmcnt(0) -- the stamps change the loop they measure.
+  mutable unsigned long long wait_cycles = 0, barrier_cycles = 0;
 #endif
   Srcs src;
   StageOffsets so;
@@ -228,19 +253,32 @@ struct LoopCtx {
   WeightSrc ws;
   int wave, m_base, n_base, off_base;
   int m_base_hi, n_base_hi;        // the same fragment offsets with the 16-byte chunk index + 4 (byte offset ^ 64)
-  uint32_t and_mask, or_magic;     // ChunkDequant::slice's constants, opaque to the compiler
+  uint32_t and_mask, or_magic, and_mask_hi;  // ChunkDequant::slice's constants, opaque to the compiler
 };
 
 // One K step.  MODE 0: steps t+1 and t+2 exist; 1: t+1 exists; 2: last step.  ISSUE = the slot at which this
 // wave starts issuing the step's VMEM work.
-template <int X_DT, int BITS, int ZP, int NT, int MODE, int ISSUE, bool DEFER, bool PRE = false>
+// DIAG (diagnostic twin only, timing experiments with WRONG results): 1 = no MFMAs (fragments still read), 2 = no fragment reads,
+// 3 = no dequantisation (no VALU slices, no ds_write), 4 = no LDS-DMA of X, 5 = no weight loads.
+template <int X_DT, int BITS, int ZP, int NT, int MODE, int ISSUE, bool DEFER, bool PRE = false, bool TALL = false, int DIAG = 0, bool SILU = false>
 __device__ __forceinline__ void mixed_step(MixedTile& w, WeightRegs<BITS, NT>& regs, char* lds, const LoopCtx& c, WeightCursor& cur, int t) {
-  constexpr int N1 = NT - 2;
+  static_assert(!TALL || NT == 2, "the tall tile dequantises two items per thread (the 128-column weight unit)");
+  constexpr int N1 = TALL ? 2 : NT - 2;  // MFMA n tiles of a wave beyond the first two
+  constexpr int kStage = TALL ? kTallStageBytes : kStageBytes;
+  constexpr int kXB = TALL ? kTallXBytes : kXBytes;
+  constexpr int kHalfM = TALL ? 4 * 2048 : kUnitBytes;  // from m tile i to m tile 4 + i of the wave
+  constexpr int kHalfN = TALL ? 2 * 2048 : kUnitBytes;  // from n tile tt to n tile 2 + tt
+  constexpr int kXPieces = TALL ? 8 : 4;
+#ifdef CONCH_EXP_HORDER
+  constexpr bool kHOrder = true;   // experiment: the two K halves of one accumulator NOT back to back (h outside tt)
+#else
+  constexpr bool kHOrder = false;
+#endif
   constexpr int kWpc = WeightRegs<BITS, NT>::kWpc;
-  constexpr int kSlices = Dequant<X_DT, BITS, ZP, PRE>::kSlices;
+  constexpr int kSlices = Dequant<X_DT, BITS, ZP, PRE, SILU>::kSlices;
   static_assert(kSlices <= 16, "more slices per chunk than MFMA slots per chunk");
   // everything this wave staged for step t (LDS-DMA, ds_write) and loaded for step t+1 is complete ...
-#ifdef CONCH_CLOCK_PROBE
+#ifdef CONCH_CLOCK_PROBE_STEPS
   const unsigned long long probe_a = __builtin_amdgcn_s_memtime();
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   const unsigned long long probe_b = __builtin_amdgcn_s_memtime();
@@ -249,11 +287,15 @@ __device__ __forceinline__ void mixed_step(MixedTile& w, WeightRegs<BITS, NT>& r
   c.wait_cycles += probe_b - probe_a;
   c.barrier_cycles += probe_c - probe_b;
 #else
+  // (Inline asm, so the compiler's counter model does not know the counters are zero here: it re-waits for the previous step's
+  // weight loads after the barrier and opens the first wave's fragment waits with lgkmcnt(0).  The same wait as
+  // __builtin_amdgcn_s_waitcnt, which the model does see, gives counted waits throughout -- and measures within +-0.4 % on the
+  // 192- and 256-column tiles, 4-6 % SLOWER on the 128-column one: profiles/r02/mixed_loop_ab.txt.)
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // ... and every wave is done reading the other stage
 #endif
-  const int ubuf = (t & 1) * kStageBytes, vbuf = ubuf + kXBytes;
-  const int vnext = ((t + 1) & 1) * kStageBytes + kXBytes;
+  const int ubuf = (t & 1) * kStage, vbuf = ubuf + kXB;
+  const int vnext = ((t + 1) & 1) * kStage + kXB;
   // four per-step base addresses (X / weights, chunk g / g + 4); every fragment read is base + an immediate offset
   const char* ulo = lds + ubuf + c.m_base;
   const char* uhi = lds + ubuf + c.m_base_hi;
@@ -265,30 +307,44 @@ __device__ __forceinline__ void mixed_step(MixedTile& w, WeightRegs<BITS, NT>& r
     f.hi = *(const i32x4*)(hi + off);
     return f;
   };
+  auto mma = [](f32x4& acc, const Frag& fa, const Frag& fb, int h) {
+    if constexpr (DIAG == 1) asm volatile("" ::"v"(fa.lo), "v"(fa.hi), "v"(fb.lo), "v"(fb.hi));  // keep the reads alive
+    else mma1<X_DT>(acc, fa, fb, h);
+  };
   WeightRegs<BITS, NT> next;
 
-  Dequant<X_DT, BITS, ZP, PRE> cv[NT];
+  Dequant<X_DT, BITS, ZP, PRE, SILU> cv[NT];
   int slot = 0;  // a constant in every unrolled copy
   auto tail = [&](int sl) {
     // the step's VMEM work from slot ISSUE on: one per slot the four LDS-DMA pieces of X of step t+1, then the
     // packed words / scales / zero points of step t+2
-    if constexpr (MODE <= 1) {
+    if constexpr (MODE <= 1 && !TALL && DIAG != 4) {
       if (sl == ISSUE + 0) stage_x_piece<0, 0>(lds, c.src, c.so, c.wave, t + 1);
       if (sl == ISSUE + 1) stage_x_piece<0, 1>(lds, c.src, c.so, c.wave, t + 1);
       if (sl == ISSUE + 2) stage_x_piece<1, 0>(lds, c.src, c.so, c.wave, t + 1);
       if (sl == ISSUE + 3) stage_x_piece<1, 1>(lds, c.src, c.so, c.wave, t + 1);
     }
-    if constexpr (MODE == 0) {
-      if (sl == ISSUE + 4) {
+    if constexpr (MODE <= 1 && TALL && DIAG != 4) {
+      if (sl == ISSUE + 0) stage_x_piece_tall<0>(lds, c.src, c.so, c.wave, t + 1);
+      if (sl == ISSUE + 1) stage_x_piece_tall<1>(lds, c.src, c.so, c.wave, t + 1);
+      if (sl == ISSUE + 2) stage_x_piece_tall<2>(lds, c.src, c.so, c.wave, t + 1);
+      if (sl == ISSUE + 3) stage_x_piece_tall<3>(lds, c.src, c.so, c.wave, t + 1);
+      if (sl == ISSUE + 4) stage_x_piece_tall<4>(lds, c.src, c.so, c.wave, t + 1);
+      if (sl == ISSUE + 5) stage_x_piece_tall<5>(lds, c.src, c.so, c.wave, t + 1);
+      if (sl == ISSUE + 6) stage_x_piece_tall<6>(lds, c.src, c.so, c.wave, t + 1);
+      if (sl == ISSUE + 7) stage_x_piece_tall<7>(lds, c.src, c.so, c.wave, t + 1);
+    }
+    if constexpr (MODE == 0 && DIAG != 5) {
+      if (sl == ISSUE + kXPieces) {
         load_weights<BITS, ZP, NT, PRE>(next, c.ln, c.ws, cur);
         advance(cur, c.ws);
       }
     }
-    if constexpr (MODE <= 1) {
+    if constexpr (MODE <= 1 && DIAG != 3) {
       const int it = sl / kSlices, sub = sl % kSlices;
       if (it < NT) {
         const int un = it < 2 ? 0 : 1;
-        cv[it].slice(sub, regs.w[it][0], regs.w[it][kWpc - 1], c.off_base + regs.zp[un], regs.scale[un], lds + vnext + c.ln.lds[it], c.and_mask, c.or_magic);
+        cv[it].slice(sub, regs.w[it][0], regs.w[it][kWpc - 1], c.off_base + regs.zp[un], regs.scale[un], lds + vnext + c.ln.lds[it], c.and_mask, c.or_magic, c.and_mask_hi);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -298,12 +354,11 @@ __device__ __forceinline__ void mixed_step(MixedTile& w, WeightRegs<BITS, NT>& r
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          mma1<X_DT>(w.acc[4 + i][tt], w.fn[0][tt], w.fm[i], h);
-          tail(slot++);
-        }
+      for (int q = 0; q < 4; ++q) {
+        const int tt = kHOrder ? q % 2 : q / 2, h = kHOrder ? q / 2 : q % 2;
+        mma(w.acc[4 + i][tt], w.fn[0][tt], w.fm[i], h);
+        tail(slot++);
+      }
   };
   // DEFER (waves 4-7, the second wave of every SIMD): the previous step's phase 3 runs here, after the barrier,
   // and needs no LDS access, so the matrix pipe has work while the other wave of the SIMD waits for its first
@@ -312,24 +367,23 @@ __device__ __forceinline__ void mixed_step(MixedTile& w, WeightRegs<BITS, NT>& r
   if constexpr (DEFER) phase3();
   // phase-0 fragment reads, ahead of the slots that hide their latency
 #pragma unroll
-  for (int tt = 0; tt < 2; ++tt) w.fn[0][tt] = frag(vlo, vhi, tt * 2048);
+  for (int tt = 0; tt < 2; ++tt) if constexpr (DIAG != 2) w.fn[0][tt] = frag(vlo, vhi, tt * 2048);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) w.fm[i] = frag(ulo, uhi, i * 2048);
+  for (int i = 0; i < 4; ++i) if constexpr (DIAG != 2) w.fm[i] = frag(ulo, uhi, i * 2048);
   __builtin_amdgcn_sched_barrier(0);
   // phase 0: (m rows 0-63 of the wave) x (n tiles 0,1); the V2 fragments of phase 1 -- or, for the narrowest
   // tile, the U2 fragments -- are fetched underneath
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        mma1<X_DT>(w.acc[i][tt], w.fn[0][tt], w.fm[i], h);
-        const int idx = (i * 2 + tt) * 2 + h;
+    for (int q = 0; q < 4; ++q) {
+        const int tt = kHOrder ? q % 2 : q / 2, h = kHOrder ? q / 2 : q % 2;
+        mma(w.acc[i][tt], w.fn[0][tt], w.fm[i], h);
+        const int idx = i * 4 + q;
         if constexpr (N1 > 0) {
-          if (idx >= 2 && idx < 2 + N1) w.fn[1][idx - 2] = frag(vlo, vhi, kUnitBytes + (idx - 2) * 2048);
+          if (idx >= 2 && idx < 2 + N1) if constexpr (DIAG != 2) w.fn[1][idx - 2] = frag(vlo, vhi, kHalfN + (idx - 2) * 2048);
         } else {
-          if (idx % 4 == 3) w.fm[i] = frag(ulo, uhi, kUnitBytes + i * 2048);
+          if (idx % 4 == 3) if constexpr (DIAG != 2) w.fm[i] = frag(ulo, uhi, kHalfM + i * 2048);
         }
         tail(slot++);
       }
@@ -337,42 +391,44 @@ __device__ __forceinline__ void mixed_step(MixedTile& w, WeightRegs<BITS, NT>& r
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int tt = 0; tt < N1; ++tt)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        mma1<X_DT>(w.acc[i][2 + tt], w.fn[1][tt], w.fm[i], h);
-        if (tt == N1 - 1 && h == 1) w.fm[i] = frag(ulo, uhi, kUnitBytes + i * 2048);
+    for (int q = 0; q < 2 * N1; ++q) {
+        const int tt = kHOrder ? q % N1 : q / 2, h = kHOrder ? q / N1 : q % 2;
+        mma(w.acc[i][2 + tt], w.fn[1][tt], w.fm[i], h);
+        if (q == 2 * N1 - 1) if constexpr (DIAG != 2) w.fm[i] = frag(ulo, uhi, kHalfM + i * 2048);
         tail(slot++);
       }
   // phase 2: m rows 64-127 x n tiles 2..
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int tt = 0; tt < N1; ++tt)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        mma1<X_DT>(w.acc[4 + i][2 + tt], w.fn[1][tt], w.fm[i], h);
+    for (int q = 0; q < 2 * N1; ++q) {
+        const int tt = kHOrder ? q % N1 : q / 2, h = kHOrder ? q / N1 : q % 2;
+        mma(w.acc[4 + i][2 + tt], w.fn[1][tt], w.fm[i], h);
         tail(slot++);
       }
   if constexpr (!DEFER) phase3();
-  if constexpr (MODE == 0) regs = next;
+  if constexpr (MODE == 0 && DIAG != 5) regs = next;
 }
 
-template <int X_DT, int BITS, int ZP, int NT, int ISSUE, bool DEFER, bool PRE = false>
+template <int X_DT, int BITS, int ZP, int NT, int ISSUE, bool DEFER, bool PRE = false, bool TALL = false, int DIAG = 0, bool SILU = false>
 __device__ __forceinline__ void mixed_mainloop(MixedTile& w, WeightRegs<BITS, NT>& regs, char* lds, const LoopCtx& c, WeightCursor& cur, int steps) {
-  if constexpr (DEFER) {
+  if constexpr (DEFER || DIAG == 2) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) w.fm[i] = Frag{i32x4{0, 0, 0, 0}, i32x4{0, 0, 0, 0}};
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) w.fn[0][tt] = Frag{i32x4{0, 0, 0, 0}, i32x4{0, 0, 0, 0}};
+    if constexpr (DIAG == 2) {
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) w.fn[1][tt] = Frag{i32x4{0, 0, 0, 0}, i32x4{0, 0, 0, 0}};
+    }
   }
   int t = 0;
-  for (; t + 2 < steps; ++t) mixed_step<X_DT, BITS, ZP, NT, 0, ISSUE, DEFER, PRE>(w, regs, lds, c, cur, t);
+  for (; t + 2 < steps; ++t) mixed_step<X_DT, BITS, ZP, NT, 0, ISSUE, DEFER, PRE, TALL, DIAG, SILU>(w, regs, lds, c, cur, t);
   if (steps > 1) {
-    mixed_step<X_DT, BITS, ZP, NT, 1, ISSUE, DEFER, PRE>(w, regs, lds, c, cur, t);
+    mixed_step<X_DT, BITS, ZP, NT, 1, ISSUE, DEFER, PRE, TALL, DIAG, SILU>(w, regs, lds, c, cur, t);
     ++t;
   }
-  mixed_step<X_DT, BITS, ZP, NT, 2, ISSUE, DEFER, PRE>(w, regs, lds, c, cur, t);
+  mixed_step<X_DT, BITS, ZP, NT, 2, ISSUE, DEFER, PRE, TALL, DIAG, SILU>(w, regs, lds, c, cur, t);
   if constexpr (DEFER) {  // the last step's phase 3
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -387,28 +443,39 @@ __device__ __forceinline__ void mixed_mainloop(MixedTile& w, WeightRegs<BITS, NT
 __device__ unsigned long long g_probe_mixed[kProbeBlocks * 8];
 #endif
 
-template <int X_DT, int OUT_DT, int BITS, int ZP, int NT, bool SILU = false, bool PRE = false>
+template <int X_DT, int OUT_DT, int BITS, int ZP, int NT, bool SILU = false, bool PRE = false, bool TALL = false, int DIAG = 0>
 __global__ __launch_bounds__(kThreads, 2) void mixed_gemm_kernel(MixedGemmArgs p) {
   static_assert(!(SILU && PRE), "the fused gate/up form reads the plain [K/pf][N] layout");
   static_assert(!SILU || NT == 4, "the fused gate/up form pairs the V1 and V2 units of a full-width tile");
+  static_assert(!TALL || (NT == 2 && !SILU), "the tall tile is 512 rows x 128 columns");
+  constexpr int kRows = TALL ? kTallRows : kTileM;
   // SILU (conch_mixed_precision_gemm_silu_and_mul): a tile is 256 rows x 128 OUTPUT columns; a wave-column owns 32 of
   // them, V1 holds their gate columns and V2 the up columns p.n further right, so accumulator tiles 0,1 / 2,3 of a lane
   // are gate / up of the same eight outputs (same construction as gemm_mfma.hip's fused epilogue).
   constexpr int kTileW = SILU ? 128 : 64 * NT;
   constexpr int kWpc = WeightRegs<BITS, NT>::kWpc;
   constexpr int kWordRowsPerStep = kStepK * BITS / 32;
-  __shared__ __attribute__((aligned(1024))) char lds[kMixedLdsBytes];
+  __shared__ __attribute__((aligned(1024))) char lds[TALL ? kTallLdsBytes : kMixedLdsBytes];
   LoopCtx c;
   c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  const int wr = c.wave >> 2, wc = c.wave & 3;
-  const int tiles_m = ((int)p.m + kTileM - 1) / kTileM;
+  const int wr = TALL ? c.wave >> 1 : c.wave >> 2, wc = TALL ? c.wave & 1 : c.wave & 3;
+  const int tiles_m = ((int)p.m + kRows - 1) / kRows;
   const int tiles_n = ((int)p.n + kTileW - 1) / kTileW;
   const TileCoord tc = map_tile(blockIdx.x, tiles_m, tiles_n);
-  const int bm0 = tc.tm * kTileM, bn0 = tc.tn * kTileW;
+  const int bm0 = tc.tm * kRows, bn0 = tc.tn * kTileW;
 
   // activations: LDS-DMA units (byte strides: 2 bytes per element)
-  c.so = make_stage_offsets(c.wave, lane, bm0, bn0, (int)p.m - 1, 0, (int)p.x_stride_m * 2, 0);
+  if constexpr (TALL) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int row = 64 * c.wave + 8 * j + (lane >> 3);
+      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+      c.so.off[j >> 1][j & 1] = min(bm0 + row, (int)p.m - 1) * ((int)p.x_stride_m * 2) + chunk * 16;
+    }
+  } else {
+    c.so = make_stage_offsets(c.wave, lane, bm0, bn0, (int)p.m - 1, 0, (int)p.x_stride_m * 2, 0);
+  }
   c.src.a = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (uint32_t)(((p.m - 1) * p.x_stride_m + p.k) * 2), 0x00020000);
   c.src.b = c.src.a;
 
@@ -461,13 +528,14 @@ __global__ __launch_bounds__(kThreads, 2) void mixed_gemm_kernel(MixedGemmArgs p
   // fragment read offsets
   const int fr = lane & 15, fg = lane >> 4;
   const int lane_off = (fr >> 3) * 1024 + (fr & 7) * 128 + ((fg ^ ((fr >> 1) & 7)) * 16);
-  c.m_base = (wr * 8) * 1024 + lane_off;
-  c.n_base = (wc * 4) * 1024 + lane_off;
+  c.m_base = (TALL ? wr * 16 : wr * 8) * 1024 + lane_off;
+  c.n_base = (TALL ? wc * 8 : wc * 4) * 1024 + lane_off;
   c.m_base_hi = c.m_base ^ 64;
   c.n_base_hi = c.n_base ^ 64;
   c.and_mask = BITS == 4 ? 0x000f000fu : 0x00ff00ffu;
   c.or_magic = 0x64006400u;
-  asm volatile("" : "+v"(c.and_mask), "+s"(c.or_magic));
+  c.and_mask_hi = c.and_mask << 4;
+  asm volatile("" : "+v"(c.and_mask), "+s"(c.or_magic), "+v"(c.and_mask_hi));
 
   MixedTile w;
 #pragma unroll
@@ -478,18 +546,30 @@ __global__ __launch_bounds__(kThreads, 2) void mixed_gemm_kernel(MixedGemmArgs p
   const int steps = (int)(p.k / kStepK);
   WeightRegs<BITS, NT> regs;
   // prologue: X and weights of step 0 (converted at once), weights of step 1 to registers
-  stage_x_piece<0, 0>(lds, c.src, c.so, c.wave, 0);
-  stage_x_piece<0, 1>(lds, c.src, c.so, c.wave, 0);
-  stage_x_piece<1, 0>(lds, c.src, c.so, c.wave, 0);
-  stage_x_piece<1, 1>(lds, c.src, c.so, c.wave, 0);
+  if constexpr (TALL) {
+    stage_x_piece_tall<0>(lds, c.src, c.so, c.wave, 0);
+    stage_x_piece_tall<1>(lds, c.src, c.so, c.wave, 0);
+    stage_x_piece_tall<2>(lds, c.src, c.so, c.wave, 0);
+    stage_x_piece_tall<3>(lds, c.src, c.so, c.wave, 0);
+    stage_x_piece_tall<4>(lds, c.src, c.so, c.wave, 0);
+    stage_x_piece_tall<5>(lds, c.src, c.so, c.wave, 0);
+    stage_x_piece_tall<6>(lds, c.src, c.so, c.wave, 0);
+    stage_x_piece_tall<7>(lds, c.src, c.so, c.wave, 0);
+  } else {
+    stage_x_piece<0, 0>(lds, c.src, c.so, c.wave, 0);
+    stage_x_piece<0, 1>(lds, c.src, c.so, c.wave, 0);
+    stage_x_piece<1, 0>(lds, c.src, c.so, c.wave, 0);
+    stage_x_piece<1, 1>(lds, c.src, c.so, c.wave, 0);
+  }
   load_weights<BITS, ZP, NT, PRE>(regs, c.ln, c.ws, cur);
   advance(cur, c.ws);
 #pragma unroll
   for (int it = 0; it < NT; ++it) {
-    Dequant<X_DT, BITS, ZP, PRE> cv;
+    Dequant<X_DT, BITS, ZP, PRE, SILU> cv;
 #pragma unroll
-    for (int sl = 0; sl < Dequant<X_DT, BITS, ZP, PRE>::kSlices; ++sl)
-      cv.slice(sl, regs.w[it][0], regs.w[it][kWpc - 1], c.off_base + regs.zp[it < 2 ? 0 : 1], regs.scale[it < 2 ? 0 : 1], lds + kXBytes + c.ln.lds[it], c.and_mask, c.or_magic);
+    for (int sl = 0; sl < Dequant<X_DT, BITS, ZP, PRE, SILU>::kSlices; ++sl)
+      cv.slice(sl, regs.w[it][0], regs.w[it][kWpc - 1], c.off_base + regs.zp[it < 2 ? 0 : 1], regs.scale[it < 2 ? 0 : 1],
+               lds + (TALL ? kTallXBytes : kXBytes) + c.ln.lds[it], c.and_mask, c.or_magic, c.and_mask_hi);
   }
   if (steps > 1) {
     load_weights<BITS, ZP, NT, PRE>(regs, c.ln, c.ws, cur);
@@ -498,18 +578,25 @@ __global__ __launch_bounds__(kThreads, 2) void mixed_gemm_kernel(MixedGemmArgs p
 
   // The two waves of a SIMD (w and w + 4) issue their VMEM work at different places of the step.
   CONCH_PROBE(g_probe_mixed, 0);
-  if (wr == 0) mixed_mainloop<X_DT, BITS, ZP, NT, 0, false, PRE>(w, regs, lds, c, cur, steps);
-  else mixed_mainloop<X_DT, BITS, ZP, NT, 16, true, PRE>(w, regs, lds, c, cur, steps);
+#ifdef CONCH_EXP_SETPRIO
+  if ((c.wave >> 2) != 0) __builtin_amdgcn_s_setprio(CONCH_EXP_SETPRIO);
+#endif
+  if ((c.wave >> 2) == 0) mixed_mainloop<X_DT, BITS, ZP, NT, 0, false, PRE, TALL, DIAG, SILU>(w, regs, lds, c, cur, steps);
+  else mixed_mainloop<X_DT, BITS, ZP, NT, 16, true, PRE, TALL, DIAG, SILU>(w, regs, lds, c, cur, steps);
   CONCH_PROBE(g_probe_mixed, 1);
-#ifdef CONCH_CLOCK_PROBE
+#ifdef CONCH_CLOCK_PROBE_STEPS
   if (threadIdx.x == 0 && blockIdx.x < kProbeBlocks) {  // slots 4..7 of the block: cycles at the step-top wait / barrier (wave 0)
     g_probe_mixed[blockIdx.x * 8 + 4] = c.wait_cycles;
     g_probe_mixed[blockIdx.x * 8 + 5] = c.barrier_cycles;
   }
+  if (threadIdx.x == 256 && blockIdx.x < kProbeBlocks) {  // slots 6, 7: the same for wave 4 (second wave of SIMD 0, late VMEM issue)
+    g_probe_mixed[blockIdx.x * 8 + 6] = c.wait_cycles;
+    g_probe_mixed[blockIdx.x * 8 + 7] = c.barrier_cycles;
+  }
 #endif
 
   if constexpr (SILU) mixed_epilogue_silu<OUT_DT>(w, p, bm0, bn0, wr, wc, lane);
-  else mixed_epilogue<X_DT, OUT_DT, NT>(w, p, bm0, bn0, wr, wc, lane);
+  else mixed_epilogue<X_DT, OUT_DT, TALL ? 4 : NT>(w, p, bm0, bn0, wr, wc, lane);
 }
 
 template <int X_DT, int OUT_DT, int BITS, int NT>
@@ -558,6 +645,21 @@ int launch_zp(const MixedGemmArgs& p, hipStream_t stream) {
       return CONCH_ERR_UNSUPPORTED;
     }
   }
+#ifdef CONCH_CLOCK_PROBE
+  if constexpr (X_DT == CONCH_DT_FP16 && OUT_DT == CONCH_DT_FP16 && BITS == 4 && NT == 4) {
+    const int diag = tuning(7);  // diagnostic twin: timing experiments of the K loop (see mixed_step)
+    if (diag >= 1 && diag <= 5 && p.zp_mode == CONCH_ZP_NONE) {
+#define CONCH_DIAG(D) hipLaunchKernelGGL((mixed_gemm_kernel<X_DT, OUT_DT, BITS, CONCH_ZP_NONE, NT, false, false, false, D>), grid, dim3(kThreads), 0, stream, p)
+      if (diag == 1) CONCH_DIAG(1);
+      else if (diag == 2) CONCH_DIAG(2);
+      else if (diag == 3) CONCH_DIAG(3);
+      else if (diag == 4) CONCH_DIAG(4);
+      else CONCH_DIAG(5);
+#undef CONCH_DIAG
+      return check_launch("mixed_gemm_mfma_diag");
+    }
+  }
+#endif
   switch (p.zp_mode) {
     case CONCH_ZP_NONE:
       hipLaunchKernelGGL((mixed_gemm_kernel<X_DT, OUT_DT, BITS, CONCH_ZP_NONE, NT>), grid, dim3(kThreads), 0, stream, p);
@@ -579,14 +681,42 @@ int launch_zp(const MixedGemmArgs& p, hipStream_t stream) {
   return check_launch("mixed_gemm_mfma");
 }
 
-// Tile width 64*NT, NT in {4, 3, 2}: the width that needs the least (rounds of workgroups) x (work per
-// workgroup).  C4 (1024 x 11008): 256-wide = 172 tiles (67 % of 256 CUs busy), 192-wide = 232 tiles in
-// ONE round at 3/4 of the work each.
+// The 512 x 128 tile (kMixedTall): plain or pre-packed (the NT = 2 image) weights, every zero-point mode.
+template <int X_DT, int OUT_DT, int BITS>
+int launch_tall(const MixedGemmArgs& p, hipStream_t stream) {
+  const int tiles_m = (int)((p.m + kTallRows - 1) / kTallRows), tiles_n = (int)((p.n + 127) / 128);
+  const dim3 grid((unsigned)(tiles_m * tiles_n));
+#define CONCH_TALL(ZP, PRE) hipLaunchKernelGGL((mixed_gemm_kernel<X_DT, OUT_DT, BITS, ZP, 2, false, PRE, true>), grid, dim3(kThreads), 0, stream, p)
+  if (p.prepacked) {
+    if constexpr (X_DT == OUT_DT) {
+      if (p.zp_mode == CONCH_ZP_NONE) CONCH_TALL(CONCH_ZP_NONE, true);
+      else if (p.zp_mode == CONCH_ZP_SCALAR) CONCH_TALL(CONCH_ZP_SCALAR, true);
+      else CONCH_TALL(CONCH_ZP_TENSOR, true);
+    } else {
+      set_error("mixed_precision_gemm (prepacked): output dtype must equal the activation dtype");
+      return CONCH_ERR_UNSUPPORTED;
+    }
+  } else {
+    if (p.zp_mode == CONCH_ZP_NONE) CONCH_TALL(CONCH_ZP_NONE, false);
+    else if (p.zp_mode == CONCH_ZP_SCALAR) CONCH_TALL(CONCH_ZP_SCALAR, false);
+    else CONCH_TALL(CONCH_ZP_TENSOR, false);
+  }
+#undef CONCH_TALL
+  return check_launch("mixed_gemm_mfma_tall");
+}
+
+// Tile shape: 256 rows x 64 NT columns, NT in {4, 3, 2}, or 512 x 128 (kMixedTall) -- the one that needs the least
+// (rounds of workgroups) x (time per workgroup).  C4 (1024 x 11008): 256-wide = 172 tiles (67 % of 256 CUs busy), 192-wide = 232
+// tiles in ONE round at 3/4 of the work each.  The 512 x 128 tile does the MFMA work of a 256 x 256 tile in 1.03-1.04 of its time
+// (profiles/r02/mixed_tall_ab.txt) and exists for the problems the 256-column tile cannot take: per-group zero points (whose
+// registers do not fit at 256 columns) at M >= 2048 -- 4096 x 8192 x 4096 with zero points: 352 tiles of 192 columns = two rounds,
+// 299 us; 256 tall tiles = one round, 217 us.
 int pick_nt(const MixedGemmArgs& p, int num_cus) {
   const int64_t tiles_m = (p.m + kTileM - 1) / kTileM;
   int best = 4;
   double best_cost = 1e30;
   for (int nt = 4; nt >= 2; --nt) {
+    if (nt == 4 && p.zp_mode == CONCH_ZP_TENSOR && !p.fuse_silu) continue;  // not built (see launch_zp)
     const int64_t tiles = tiles_m * ((p.n + 64 * nt - 1) / (64 * nt));
     const int64_t rounds = (tiles + num_cus - 1) / num_cus;
     // + fixed per-tile cost (X staging, prologue, epilogue, issue-port share): measured 85 us at 192 columns against
@@ -597,11 +727,17 @@ int pick_nt(const MixedGemmArgs& p, int num_cus) {
       best = nt;
     }
   }
+  if (!p.fuse_silu) {
+    const int64_t tiles = ((p.m + kTallRows - 1) / kTallRows) * ((p.n + 127) / 128);
+    const double cost = (double)((tiles + num_cus - 1) / num_cus) * 5.4;
+    if (cost < best_cost - 1e-9) best = kMixedTall;
+  }
   return best;
 }
 
 template <int X_DT, int OUT_DT, int BITS>
 int launch_nt(const MixedGemmArgs& p, int nt, hipStream_t stream) {
+  if (nt == kMixedTall) return launch_tall<X_DT, OUT_DT, BITS>(p, stream);
   if (nt == 3) return launch_zp<X_DT, OUT_DT, BITS, 3>(p, stream);
   if (nt == 2) return launch_zp<X_DT, OUT_DT, BITS, 2>(p, stream);
   return launch_zp<X_DT, OUT_DT, BITS, 4>(p, stream);
@@ -705,9 +841,8 @@ int prepack_mixed_weights(uint32_t* image, uint32_t* plain, int64_t k, int64_t n
 
 // the tile width the dispatcher would pick for this problem (so that a caller can pre-pack for it)
 int mixed_gemm_tile_nt(const MixedGemmArgs& p) {
-  int nt = pick_nt(p, device_cu_count());
-  if (p.zp_mode == CONCH_ZP_TENSOR && nt == 4) nt = 3;
-  return nt;
+  const int nt = pick_nt(p, device_cu_count());
+  return nt == kMixedTall ? 2 : nt;  // the 512 x 128 tile reads the 128-column image
 }
 
 // the fused gate/up epilogue runs on the 256-column tile only, which is not built for per-group zero points
@@ -739,10 +874,11 @@ bool mixed_gemm_mfma_supported(const MixedGemmArgs& p) {
 
 int launch_mixed_gemm_mfma(const MixedGemmArgs& p, hipStream_t stream) {
   const int num_cus = device_cu_count();
-  const int forced = tuning(1);  // CONCH_TUNE_MIXED_TILE_NT: 0 = auto, 2..4 = force
-  int nt = p.fuse_silu ? 4 : (forced >= 2 && forced <= 4) ? forced : pick_nt(p, num_cus);
-  if (p.zp_mode == CONCH_ZP_TENSOR && nt == 4 && !p.fuse_silu) nt = 3;
-  if (p.prepacked) nt = p.prepacked;  // the image was laid out for this width
+  const int forced = tuning(1);  // CONCH_TUNE_MIXED_TILE_NT: 0 = auto, 2..4 = force 64 NT columns, 5 = force the 512 x 128 tile
+  int nt = p.fuse_silu ? 4 : (forced >= 2 && forced <= kMixedTall) ? forced : pick_nt(p, num_cus);
+  if (p.zp_mode == CONCH_ZP_TENSOR && nt == 4 && !p.fuse_silu) nt = 3;  // a forced 4
+  // a pre-packed image was laid out for one tile width; the 128-column image serves both the 256 x 128 and the 512 x 128 tile
+  if (p.prepacked) nt = (p.prepacked == 2 && nt == kMixedTall) ? kMixedTall : p.prepacked;
   if (p.x_dtype == CONCH_DT_FP16) {
     return p.out_dtype == CONCH_DT_FP16 ? launch_bits<CONCH_DT_FP16, CONCH_DT_FP16>(p, nt, stream)
                                         : launch_bits<CONCH_DT_FP16, CONCH_DT_BF16>(p, nt, stream);

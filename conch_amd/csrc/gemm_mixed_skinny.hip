@@ -31,10 +31,10 @@ constexpr int kMsSteps = 16;              // steps per slice
 constexpr int kMsSliceK = kMsSteps * kMsStepK;
 
 template <int X_DT, int BITS, int ZP>
-__device__ __forceinline__ i32x4 dequant8(uint32_t w0, uint32_t w1, int off, uint32_t scale_bits, uint32_t mask, uint32_t magic) {
+__device__ __forceinline__ i32x4 dequant8(uint32_t w0, uint32_t w1, int off, uint32_t scale_bits, uint32_t mask, uint32_t magic, uint32_t mask_hi) {
   ChunkDequant<X_DT, BITS, (X_DT == CONCH_DT_BF16 && BITS == 8 && ZP != CONCH_ZP_NONE)> cv;
 #pragma unroll
-  for (int s = 0; s + 1 < ChunkDequant<X_DT, BITS>::kSlices; ++s) cv.slice(s, w0, w1, off, scale_bits, nullptr, mask, magic);
+  for (int s = 0; s + 1 < ChunkDequant<X_DT, BITS>::kSlices; ++s) cv.slice(s, w0, w1, off, scale_bits, nullptr, mask, magic, mask_hi);
   return cv.out;
 }
 
@@ -96,7 +96,8 @@ __global__ __launch_bounds__(kMsThreads) void mixed_skinny_kernel(MixedGemmArgs 
   }
   const int off_base = p.weight_bias + (ZP == CONCH_ZP_SCALAR ? p.w_zp[0] : 0);
   uint32_t and_mask = BITS == 4 ? 0x000f000fu : 0x00ff00ffu, or_magic = 0x64006400u;
-  asm volatile("" : "+v"(and_mask), "+s"(or_magic));
+  uint32_t and_mask_hi = and_mask << 4;  // int4: the pairs four bits up, taken without a shift (ChunkDequant)
+  asm volatile("" : "+v"(and_mask), "+s"(or_magic), "+v"(and_mask_hi));
 
   f32x4 acc[ROWS / 16];
 #pragma unroll
@@ -109,8 +110,8 @@ __global__ __launch_bounds__(kMsThreads) void mixed_skinny_kernel(MixedGemmArgs 
 #pragma unroll
   for (int s = 0; s < kMsSteps; ++s) {
     // the lane's 8 + 8 weights of this step: k = 8g..8g+7 (first half step) and 32 + 8g.. (second), column n
-    const i32x4 w_lo = dequant8<X_DT, BITS, ZP>(wq[s][0][0], wq[s][0][kWpc - 1], off_base + zp[s], sc[s], and_mask, or_magic);
-    const i32x4 w_hi = dequant8<X_DT, BITS, ZP>(wq[s][1][0], wq[s][1][kWpc - 1], off_base + zp[s], sc[s], and_mask, or_magic);
+    const i32x4 w_lo = dequant8<X_DT, BITS, ZP>(wq[s][0][0], wq[s][0][kWpc - 1], off_base + zp[s], sc[s], and_mask, or_magic, and_mask_hi);
+    const i32x4 w_hi = dequant8<X_DT, BITS, ZP>(wq[s][1][0], wq[s][1][kWpc - 1], off_base + zp[s], sc[s], and_mask, or_magic, and_mask_hi);
 #pragma unroll
     for (int i = 0; i < ROWS / 16; ++i) {
       const Frag fx = read_frag(lds, s * kUnit + lane_off + i * 2048);

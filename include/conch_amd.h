@@ -110,7 +110,7 @@ typedef enum conch_tuning_key {
                                  256x256 tiles).  mixed_precision_gemm has one LDS-tiled MFMA
                                  kernel: 1 = generic, any other value = that kernel */
   ,
-  CONCH_TUNE_MIXED_TILE_NT = 1 /* mixed_precision_gemm tile width in 64-column units: 0 = auto, 2..4 = force */
+  CONCH_TUNE_MIXED_TILE_NT = 1 /* mixed_precision_gemm tile shape: 0 = auto, 2..4 = force 256 rows x 64 NT columns, 5 = force 512 x 128 */
   ,
   CONCH_TUNE_SKINNY_NO_SPLITK = 2 /* 1 = keep the skinny-M scaled GEMM's K split inside the workgroup */
   ,
@@ -310,8 +310,8 @@ int conch_mixed_precision_gemm_gelu_tanh_and_mul(void* c, const void* x, const i
 
 /*
  * bitsandbytes-style blockwise quantisation (replaces quantize_blockwise_launcher /
- * dequantize_blockwise_launcher of conch/kernels/quantization/bitsandbytes/*.py; semantics = the reference's PyTorch
- * implementation, conch/reference/quantization/bitsandbytes/*.py).  quant_type: 0 = nf4, 1 = fp4 (two codes per byte, the
+ * dequantize_blockwise_launcher of conch/kernels/quantization/bitsandbytes/{quantize,dequantize}_blockwise.py; semantics = the reference's PyTorch
+ * implementation, conch/reference/quantization/bitsandbytes/).  quant_type: 0 = nf4, 1 = fp4 (two codes per byte, the
  * first element in the high nibble), 2 = 8-bit with a 256-entry fp32 code book `code` (NULL otherwise).  blocksize: a power
  * of two in 64..4096; block b covers elements [b * blocksize, (b+1) * blocksize) of the flat tensor of `n` elements.
  *   quantise:    absmax[b] = max |x| (stored in absmax_dtype);  code(x * (1 / absmax[b]))

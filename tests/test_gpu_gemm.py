@@ -649,13 +649,13 @@ def test_mixed_precision_gemm_golden_from_reference(golden, wname, zp, dname):
 
 
 @pytest.mark.parametrize("variant", ["auto"])
-@pytest.mark.parametrize("nt", [2, 3, 4])
-@pytest.mark.parametrize(("m", "k", "n"), [(300, 256, 520), (1024, 512, 1376), (64, 128, 200), (512, 64, 256)])
+@pytest.mark.parametrize("nt", [2, 3, 4, 5])
+@pytest.mark.parametrize(("m", "k", "n"), [(300, 256, 520), (1024, 512, 1376), (64, 128, 200), (512, 64, 256), (1100, 384, 300)])
 @pytest.mark.parametrize(("wname", "use_zp", "dname"), [("uint4b8", False, "f16"), ("uint4", True, "bf16"),
                                                          ("uint8b128", True, "f16"), ("uint8", False, "bf16")])
 def test_mixed_precision_every_tile_width(variant, nt, m, k, n, wname, use_zp, dname):
-    """The MFMA kernel at each tile width (64*nt columns),
-    ragged M / N and the shortest K (one and two K steps) included."""
+    """The MFMA kernel at each tile shape (256 rows x 64*nt columns; nt = 5: the 512 x 128 tile),
+    ragged M / N and the shortest K (one to three K steps) included."""
     wt = WTYPES[wname]
     group = 64 if k < 128 else 128
     a, w_ref, packed, w_s, w_zp = make_mixed_inputs(m, k, n, wt, use_zp, DT[dname], group)
@@ -1072,6 +1072,29 @@ def test_prepacked_gemm_is_bit_identical(wname, use_zp, dname, m, k, n, tile_nt)
     got = mixed_precision_gemm_prepacked(dev(a), pre, dev(w_s), dev(w_zp), wt.bias, 128)
     assert torch.equal(got, plain)
     check_mixed(got, a, w_ref, k)
+
+
+@pytest.mark.parametrize(("wname", "use_zp", "dname"), [("uint4b8", False, "f16"), ("uint4", True, "bf16"), ("uint8b128", False, "bf16"),
+                                                         ("uint8", True, "f16")])
+@pytest.mark.parametrize(("m", "k", "n"), [(2048, 1024, 4096), (1300, 256, 520), (512, 128, 128)])
+def test_tall_tile_is_bit_identical(wname, use_zp, dname, m, k, n):
+    """The 512 x 128 tile (half the dequantisation per MFMA) against the dispatcher's choice: the tile shape moves work, not the
+    order in which an output accumulates its K products.  Plain weights and the 128-column pre-packed image."""
+    wt = WTYPES[wname]
+    a, w_ref, packed, w_s, w_zp = make_mixed_inputs(m, k, n, wt, use_zp, DT[dname])
+    dev = lambda t: None if t is None else t.cuda()  # noqa: E731
+    _C.set_tuning(_C.TUNE_MIXED_TILE_NT, 4 if not use_zp else 3)
+    try:
+        base = mixed_precision_gemm(dev(a), dev(packed), dev(w_s), dev(w_zp), wt.size_bits, wt.bias, 128)
+        _C.set_tuning(_C.TUNE_MIXED_TILE_NT, 5)
+        tall = mixed_precision_gemm(dev(a), dev(packed), dev(w_s), dev(w_zp), wt.size_bits, wt.bias, 128)
+        pre = prepack_mixed_weights(dev(packed), wt.size_bits, tile_nt=2)
+        tall_pre = mixed_precision_gemm_prepacked(dev(a), pre, dev(w_s), dev(w_zp), wt.bias, 128)
+    finally:
+        _C.set_tuning(_C.TUNE_MIXED_TILE_NT, 0)
+    assert torch.equal(tall, base)
+    assert torch.equal(tall_pre, base)
+    check_mixed(tall, a, w_ref, k)
 
 
 def test_prepacked_gemm_c4_config():

@@ -139,10 +139,14 @@ def mixed_stalls(blocks=256):
     fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
     buf = (ctypes.c_ulonglong * (8 * blocks))()
     assert fn(buf, blocks) == 0
-    rows = [(buf[8 * b + 2] - buf[8 * b], buf[8 * b + 4], buf[8 * b + 5]) for b in range(blocks) if buf[8 * b + 2] > buf[8 * b]]
+    rows = [(buf[8 * b + 2] - buf[8 * b], buf[8 * b + 4], buf[8 * b + 5], buf[8 * b + 6], buf[8 * b + 7]) for b in range(blocks)
+            if buf[8 * b + 2] > buf[8 * b]]
     tot = statistics.median(r[0] for r in rows)
+    if not any(r[1] for r in rows):  # the twin was built without -DCONCH_CLOCK_PROBE_STEPS (the default: the stamps perturb the loop)
+        return
     print(f"    wave 0 of a workgroup: K loop {tot:.0f} cycles, of which {statistics.median(r[1] for r in rows) / tot * 100:.1f} % at the "
-          f"step-top s_waitcnt and {statistics.median(r[2] for r in rows) / tot * 100:.1f} % at the barrier")
+          f"step-top s_waitcnt and {statistics.median(r[2] for r in rows) / tot * 100:.1f} % at the barrier; wave 4 (late VMEM issue): "
+          f"{statistics.median(r[3] for r in rows) / tot * 100:.1f} % / {statistics.median(r[4] for r in rows) / tot * 100:.1f} %")
 
 
 def mixed_case(m, k, n, dtype, bits):
@@ -162,6 +166,22 @@ def mixed_case(m, k, n, dtype, bits):
 
 
 if __name__ == "__main__":
+    if "--mixed-diag" in sys.argv:  # timing experiments of the mixed K loop (WRONG results): tuning key 7, see gemm_mixed.hip mixed_step
+        names = {0: "full loop", 1: "no MFMAs", 2: "no fragment reads", 3: "no dequantisation (VALU + ds_write)", 4: "no LDS-DMA of X", 5: "no weight loads"}
+        _C.set_tuning(1, 4)
+        for diag in range(6):
+            _C.set_tuning(7, diag)
+            print(f"-- {names[diag]}")
+            mixed_case(4096, 8192, 4096, torch.float16, 4)
+        _C.set_tuning(7, 0)
+        sys.exit(0)
+    if "--mixed" in sys.argv:  # mixed kernel only, tile shapes given as a comma list (tuning key 1: 0 auto, 2..4, 5 = 512 x 128)
+        for nt in (int(v) for v in sys.argv[sys.argv.index("--mixed") + 1].split(",")):
+            _C.set_tuning(1, nt)
+            print(f"-- CONCH_TUNE_MIXED_TILE_NT = {nt}")
+            mixed_case(4096, 8192, 4096, torch.float16, 4)
+            mixed_case(1024, 4096, 11008, torch.float16, 4)
+        sys.exit(0)
     if "--persist" in sys.argv:  # tile-boundary study: plain launch against persistent workgroups
         for mode in (1, 2):
             _C.set_tuning(5, mode)
