@@ -53,6 +53,7 @@ _SIGNATURES = {
     "conch_last_error": (c_char_p, []),
     "conch_set_tuning": (c_int, [c_int, c_int]),
     "conch_get_tuning": (c_int, [c_int]),
+    "conch_set_timing_rotation": (c_int, [c_int, _I64]),
     "conch_device_count": (c_int, []),
     "conch_scaled_gemm_workspace_bytes": (_I64, [_I64, _I64, _I64]),
     "conch_mixed_precision_gemm_workspace_bytes": (_I64, [_I64, _I64, _I64]),

@@ -125,20 +125,26 @@ int check_scaled(const ScaledGemmArgs& p) {
 
 enum ScaledKernel { kKernelTiled = 0, kKernelMid = 1, kKernelSkinny = 2 };
 
-// The cheapest of three kernels by a cost model fitted to two 112-point sweeps over M in 8..1024, K in {4096, 8192},
-// N in 4096..28672, int8 and fp8 (tools/quick_bench.py --skinnysweep, profiles/r01/skinny_tiled_mid_sweep*.txt), in us:
-//   split-K skinny  4.5-5.5 + c(M) N K        (re-reads the A slice per 64-column block; two row blocks above M = 128)
-//   256x256 tiles   rounds x (34 + 0.05 t) K/4096,  t = tiles per round of 256 workgroups (a lone tile is bound by its
-//                   CU's L2 -> LDS rate; a full round shares the L2 / Infinity Cache)
-//   128x128 tiles   rounds x (19 + 0.0176 t) K/4096, t = tiles per round of 512 workgroups (two per CU)
+// The cheapest of three kernels by a cost model, in us.  Round 1 fitted it to back-to-back launches on ONE weight buffer, which
+// stays in L2 and the 256 MiB Infinity Cache; a decode step streams every layer's weights from HBM, where the tile kernels with few
+// workgroups are bound by what ONE CU can pull from HBM (a 128x128 tile's 256 K bytes at ~33 GB/s, a 256x256 tile's 512 K bytes
+// at ~48 GB/s) while the split-K form spreads the stream over the chip.  Round 2 refits it to that regime
+// (tools/dispatch_cold_sweep.py: every candidate timed while cycling through > 600 MB of weight buffers, M in 8..1024,
+// six (K, N) pairs, int8 and fp8; profiles/r02/dispatch_cold_sweep_before.txt / _after.txt):
+//   split-K skinny  5.3 + c(M) N K        (re-reads the A slice per 64-column block; two row blocks above M = 128)
+//   256x256 tiles   rounds x (41 + 0.06 t) K/4096,  t = tiles per round of 256 workgroups
+//   128x128 tiles   rounds x (31 + 0.02 t) K/4096,  t = tiles per round of 512 workgroups (two per CU)
+// The warm fit (round 1) was 4.5-5.5 + c N K with c 1.7 .. 9.7, rounds x (34 + 0.05 t), rounds x (19 + 0.0176 t): with it the
+// dispatcher picked the 128x128 tiles where the split-K form is 15-47 % faster on cold weights (96-128 x 4096 x 11008,
+// 8-32 x 4096 x 28672, 256 x 4096 x 4096).
 ScaledKernel choose_scaled_kernel(const ScaledGemmArgs& p) {
   const double kscale = (double)p.k / 4096.0;
   const int64_t tiles256 = ((p.m + 255) / 256) * ((p.n + 255) / 256);
   const int64_t rounds256 = (tiles256 + 255) / 256;
-  const double tiled_us = (double)rounds256 * (34.0 + 0.05 * (double)tiles256 / (double)rounds256) * kscale;
+  const double tiled_us = (double)rounds256 * (41.0 + 0.06 * (double)tiles256 / (double)rounds256) * kscale;
   const int64_t tiles128 = ((p.m + 127) / 128) * ((p.n + 127) / 128);
   const int64_t rounds128 = (tiles128 + 511) / 512;
-  const double mid_us = (double)rounds128 * (19.0 + 0.0176 * (double)tiles128 / (double)rounds128) * kscale;
+  const double mid_us = (double)rounds128 * (31.0 + 0.02 * (double)tiles128 / (double)rounds128) * kscale;
   ScaledKernel pick = kKernelTiled;
   double best = tiled_us;
   if (mid_us < best) {
@@ -146,9 +152,9 @@ ScaledKernel choose_scaled_kernel(const ScaledGemmArgs& p) {
     pick = kKernelMid;
   }
   if (scaled_gemm_skinny_supported(p)) {
-    const double c = p.m <= 16 ? 1.7 : p.m <= 32 ? 2.0 : p.m <= 48 ? 2.3 : p.m <= 64 ? 2.5 : p.m <= 96 ? 4.3 : p.m <= 128 ? 4.8
-                     : p.m <= 192 ? 8.5 : 9.7;  // steps at the 32- / 64- / 128-row forms and at the second row block
-    const double skinny_us = (p.m <= 64 ? 4.5 : 5.5) + c * 1e-7 * (double)p.n * (double)p.k;
+    const double c = p.m <= 8 ? 2.1 : p.m <= 16 ? 2.2 : p.m <= 32 ? 2.5 : p.m <= 48 ? 2.7 : p.m <= 64 ? 3.0 : p.m <= 96 ? 4.5
+                     : p.m <= 128 ? 5.15 : p.m <= 192 ? 9.3 : 10.2;  // steps at the 32- / 64- / 128-row forms and at the second row block
+    const double skinny_us = 5.3 + c * 1e-7 * (double)p.n * (double)p.k;
     if (skinny_us < best) pick = kKernelSkinny;
   }
   return pick;
@@ -156,7 +162,7 @@ ScaledKernel choose_scaled_kernel(const ScaledGemmArgs& p) {
 
 int run_scaled_fast(const ScaledGemmArgs& p, int variant, hipStream_t stream) {
   if (variant == 4 && !scaled_gemm_skinny_supported(p)) {
-    set_error("scaled_gemm: skinny variant forced but its contract is not met (M <= 256, K %% 1024 == 0)");
+    set_error("scaled_gemm: skinny variant forced but its contract is not met (M <= 256; N %% 4 == 0 or K %% 1024 == 0)");
     return CONCH_ERR_UNSUPPORTED;
   }
   const ScaledKernel pick = variant == 4 ? kKernelSkinny : variant == 6 ? kKernelMid : variant == 0 ? choose_scaled_kernel(p) : kKernelTiled;
@@ -272,20 +278,34 @@ int check_mixed(const MixedGemmArgs& p) {
   return CONCH_OK;
 }
 
+// 64 < M <= 256: two to four row blocks of the decode kernel (each streams the weights; the later ones mostly from L2) against ONE
+// row of tiles of the LDS-tiled kernel, which for so few rows is bound by what a CU can pull per K step, not by N.  Fitted on
+// weights streamed from HBM (profiles/r02/dispatch_cold_sweep_after.txt), us: decode 5 + 0.475e-6 N K per row block; tiles
+// 15.5 K/1024 per round.  (96-128 x 4096 x 4096: 21 against 62 us; 128 x 11008 x 4096: 50 against 162 us.)
+bool mixed_decode_beats_tiles(const MixedGemmArgs& p) {
+  const double blocks = (double)((p.m + 63) / 64);
+  const double decode_us = 5.0 + 0.475e-6 * (double)p.n * (double)p.k * blocks * (p.bits == 8 ? 1.6 : 1.0);
+  const int64_t tiles = (p.n + 127) / 128;  // the narrowest tile: the most workgroups a single row of tiles can have
+  const double tile_us = 15.5 * (double)p.k / 1024.0 * (double)((tiles + 255) / 256);
+  return decode_us < tile_us;
+}
+
 int run_mixed(const MixedGemmArgs& p, hipStream_t stream) {
   if (int rc = check_mixed(p)) return rc;
   if (p.m == 0 || p.n == 0) return CONCH_OK;
-  // variant 1 forces the generic kernel, 4 the decode-batch kernel (gemm_mixed_skinny.hip: M <= 64), any other non-zero
+  // variant 1 forces the generic kernel, 4 the decode-batch kernel (gemm_mixed_skinny.hip: M <= 256), any other non-zero
   // value the LDS-tiled MFMA kernel (gemm_mixed.hip); auto = decode-batch kernel when its contract is met, else tiled
   const int variant = tuning(CONCH_TUNE_GEMM_VARIANT);
   const bool fast_ok = mixed_gemm_mfma_supported(p);
   if (variant == 4 && !mixed_gemm_skinny_supported(p)) {
-    set_error("mixed_precision_gemm: skinny variant forced but its contract is not met (M <= 64, K %% 1024 == 0, N %% 4 == 0)");
+    set_error("mixed_precision_gemm: skinny variant forced but its contract is not met (M <= 256, N %% 4 == 0)");
     return CONCH_ERR_UNSUPPORTED;
   }
-  // auto: the decode-batch kernel up to 32 rows, and up to 64 rows while N x K < 9e7 (it re-stages the X slice per
-  // 64-column block: 64x4096x28672 ties with the tiled kernel at 58 us; profiles/r01/mixed_decode.txt)
-  const bool decode = variant == 4 || (variant == 0 && (p.m <= 32 || (double)p.n * (double)p.k < 9.0e7));
+  // auto: the decode-batch kernel for every shape it takes (M <= 64; up to four row blocks = 256 rows where mixed_decode_beats_tiles says so).  Round 1 stopped at 32 rows for N x K >= 9e7, where the two
+  // kernels tie on a cache-resident weight (64x4096x28672: 58 us each); on weights streamed from HBM the decode kernel is 6-13 %
+  // ahead there too (48-64 x 4096/8192 x 28672: profiles/r02/dispatch_cold_sweep_before.txt)
+  bool decode = variant == 4 || variant == 0;
+  if (variant == 0 && p.m > 64) decode = mixed_decode_beats_tiles(p);
   if (decode && mixed_gemm_skinny_supported(p)) return launch_mixed_gemm_skinny(p, stream);
   if (variant == 1 || !fast_ok) {
     if (variant >= 2 && !fast_ok) {
@@ -346,7 +366,7 @@ int run_mixed_silu(const MixedGemmArgs& p, hipStream_t stream) {
   MixedGemmArgs probe = wide;  // the contract check wants a C row that holds n columns; the fused reduce writes only d
   probe.c_stride_m = wide.n;
   const bool decode = variant == 0 && mixed_gemm_skinny_supported(probe) && wide.n % 8 == 0 &&
-                      (p.m <= 32 || (double)wide.n * (double)p.k < 9.0e7);
+                      (p.m <= 64 || mixed_decode_beats_tiles(wide));  // the plain op's rule (run_mixed)
   if (decode) {
     MixedGemmArgs q = wide;  // n = 2d for the partial sums; c / c_stride_m describe the d-column result
     q.fuse_silu = p.fuse_silu;
@@ -361,21 +381,39 @@ int run_mixed_silu(const MixedGemmArgs& p, hipStream_t stream) {
   return launch_silu_and_mul(p.c, tmp, p.m, p.n, wide.n, p.c_stride_m, p.out_dtype, p.fuse_silu, stream);
 }
 
+// Weight rotation of the timing helpers (conch_set_timing_rotation): launch i reads its weights at base + (i % count) * stride, so
+// that with count x (weight bytes) beyond the 256 MiB Infinity Cache every launch streams its weights from HBM, as a decode step
+// does -- back-to-back launches on ONE buffer time the cache-resident case only.
+std::atomic<int> g_rotate_count{1};
+std::atomic<int64_t> g_rotate_stride{0};
+
+inline const void* rotated(const void* base, int i) {
+  const int count = g_rotate_count.load();
+  return count > 1 ? (const void*)((const char*)base + (int64_t)(i % count) * g_rotate_stride.load()) : base;
+}
+
+struct EventPair {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  ~EventPair() {
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+  }
+};
+
+// `launch(i)`: enqueue launch number i
 template <class F>
 int time_loop(F&& launch, hipStream_t stream, int iters, float* avg_ms) {
   CONCH_CHECK_ARG(iters > 0 && avg_ms, "timing: iters=%d avg_ms=%p", iters, (void*)avg_ms);
-  hipEvent_t e0, e1;
-  CONCH_HIP(hipEventCreate(&e0));
-  CONCH_HIP(hipEventCreate(&e1));
+  EventPair ev;  // destroyed on every return path
+  CONCH_HIP(hipEventCreate(&ev.e0));
+  CONCH_HIP(hipEventCreate(&ev.e1));
   int rc = CONCH_OK;
-  CONCH_HIP(hipEventRecord(e0, stream));
-  for (int i = 0; i < iters && rc == CONCH_OK; ++i) rc = launch();
-  CONCH_HIP(hipEventRecord(e1, stream));
-  CONCH_HIP(hipEventSynchronize(e1));
+  CONCH_HIP(hipEventRecord(ev.e0, stream));
+  for (int i = 0; i < iters && rc == CONCH_OK; ++i) rc = launch(i);
+  CONCH_HIP(hipEventRecord(ev.e1, stream));
+  CONCH_HIP(hipEventSynchronize(ev.e1));
   float ms = 0.f;
-  CONCH_HIP(hipEventElapsedTime(&ms, e0, e1));
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
+  CONCH_HIP(hipEventElapsedTime(&ms, ev.e0, ev.e1));
   *avg_ms = ms / (float)iters;
   return rc;
 }
@@ -395,6 +433,13 @@ extern "C" int conch_set_tuning(int key, int value) {
 }
 extern "C" int conch_get_tuning(int key) { return tuning(key); }
 
+extern "C" int conch_set_timing_rotation(int count, int64_t stride_bytes) {
+  CONCH_CHECK_ARG(count >= 1 && stride_bytes >= 0, "conch_set_timing_rotation: count=%d stride=%lld", count, (long long)stride_bytes);
+  g_rotate_count.store(count);
+  g_rotate_stride.store(stride_bytes);
+  return CONCH_OK;
+}
+
 // Worst case over every kernel the dispatcher may pick for this shape (any layout, either fp8 flavour, fused FFN form
 // included): split-K slabs (M <= 256), K-contiguous / bf16-expanded operand copies, the [M][N] intermediate of an unfused pair.
 extern "C" int64_t conch_scaled_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k) {
@@ -409,7 +454,7 @@ extern "C" int64_t conch_scaled_gemm_workspace_bytes(int64_t m, int64_t n, int64
 extern "C" int64_t conch_mixed_precision_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k) {
   if (m <= 0 || n <= 0 || k < 0) return 0;
   int64_t need = m * n * 2;
-  if (m <= 64) need = std::max(need, (k / 1024 + 1) * m * n * 4);  // gemm_mixed_skinny.hip slabs
+  if (m <= 256) need = std::max(need, (k / 1024 + 1) * m * n * 4);  // gemm_mixed_skinny.hip slabs
   return need + ((int64_t)1 << 20);
 }
 
@@ -472,7 +517,7 @@ extern "C" int conch_time_scaled_gemm_silu_and_mul(void* c, const void* a, const
                    b_stride_n, c_stride_m, c_stride_n, scale_a_numel, scale_b_numel, in_dtype, out_dtype};
   p.fuse_silu = 1;
   hipStream_t s = (hipStream_t)stream;
-  return time_loop([&] { return run_scaled_silu(p, s); }, s, iters, avg_ms);
+  return time_loop([&](int) { return run_scaled_silu(p, s); }, s, iters, avg_ms);
 }
 
 extern "C" int conch_time_scaled_gemm(void* c, const void* a, const void* b, const float* scale_a,
@@ -484,7 +529,13 @@ extern "C" int conch_time_scaled_gemm(void* c, const void* a, const void* b, con
   const ScaledGemmArgs p{c, a, b, scale_a, scale_b, bias, m, n, k, a_stride_m, a_stride_k, b_stride_k,
                          b_stride_n, c_stride_m, c_stride_n, scale_a_numel, scale_b_numel, in_dtype, out_dtype};
   hipStream_t s = (hipStream_t)stream;
-  return time_loop([&] { return run_scaled(p, s); }, s, iters, avg_ms);
+  return time_loop(
+      [&](int i) {
+        ScaledGemmArgs q = p;
+        q.b = rotated(p.b, i);
+        return run_scaled(q, s);
+      },
+      s, iters, avg_ms);
 }
 
 extern "C" int conch_mixed_precision_gemm(void* c, const void* x, const int32_t* w_q_packed, const void* w_s,
@@ -572,7 +623,13 @@ extern "C" int conch_time_mixed_precision_gemm_prepacked(void* c, const void* x,
   const MixedGemmArgs p{c, x, image, w_s, w_zp, m, n, k, x_stride_m, n, ws_stride_g, wzp_stride_g, c_stride_m, weight_bits, weight_bias,
                         group_size, zp_mode, x_dtype, out_dtype};
   hipStream_t s = (hipStream_t)stream;
-  return time_loop([&] { return run_mixed_prepacked(p, tile_nt, s); }, s, iters, avg_ms);
+  return time_loop(
+      [&](int i) {
+        MixedGemmArgs q = p;
+        q.w_q = (const int32_t*)rotated(p.w_q, i);
+        return run_mixed_prepacked(q, tile_nt, s);
+      },
+      s, iters, avg_ms);
 }
 
 extern "C" int conch_mixed_precision_gemm_modes(void* c, const void* x, const int32_t* w_q_packed, const void* scales, const void* zeros,
@@ -620,5 +677,11 @@ extern "C" int conch_time_mixed_precision_gemm(void* c, const void* x, const int
                         wzp_stride_g, c_stride_m, weight_bits, weight_bias, group_size, zp_mode, x_dtype,
                         out_dtype};
   hipStream_t s = (hipStream_t)stream;
-  return time_loop([&] { return run_mixed(p, s); }, s, iters, avg_ms);
+  return time_loop(
+      [&](int i) {
+        MixedGemmArgs q = p;
+        q.w_q = (const int32_t*)rotated(p.w_q, i);
+        return run_mixed(q, s);
+      },
+      s, iters, avg_ms);
 }

@@ -29,6 +29,7 @@ constexpr int kMsN = 64;                  // columns per workgroup
 constexpr int kMsStepK = 64;              // k elements per step (128 bytes of fp16 / bf16)
 constexpr int kMsSteps = 16;              // steps per slice
 constexpr int kMsSliceK = kMsSteps * kMsStepK;
+constexpr int kMsMaxM = 256;
 
 template <int X_DT, int BITS, int ZP>
 __device__ __forceinline__ i32x4 dequant8(uint32_t w0, uint32_t w1, int off, uint32_t scale_bits, uint32_t mask, uint32_t magic, uint32_t mask_hi) {
@@ -52,6 +53,12 @@ __global__ __launch_bounds__(kMsThreads) void mixed_skinny_kernel(MixedGemmArgs 
   const int k0 = blockIdx.y * kMsSliceK;
   const int m0 = blockIdx.z * ROWS;
 
+  // A ragged LAST slice (K % 1024 != 0; K % 64 == 0 always): the steps past K load X, the packed words, the scale and the zero
+  // point from an out-of-range buffer offset (the range check is on the VGPR offset) -- zeros in LDS, and a zero SCALE makes
+  // the dequantised weights zero whatever (0 - bias - zp) is: their MFMAs add 0 x 0.
+  const int valid_steps = min(kMsSteps, ((int)p.k - k0) / kMsStepK);  // workgroup-uniform
+  // (a macro, not a lambda: a lambda in this kernel template makes hipcc's host pass drop the kernel's launch stub)
+#define CONCH_KILL(s) ((s) < valid_steps ? 0 : (int)0x80000000)
   // ---- X slice -> LDS (8-row x 128-byte subtiles, source-side swizzle); piece q = rows 8q..8q+7 of a step
   const __amdgpu_buffer_rsrc_t rx =
       __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (uint32_t)(((p.m - 1) * p.x_stride_m + p.k) * 2), 0x00020000);
@@ -64,7 +71,7 @@ __global__ __launch_bounds__(kMsThreads) void mixed_skinny_kernel(MixedGemmArgs 
       const int row = 8 * q + (lane >> 3);
       const int chunk = (lane & 7) ^ ((row >> 1) & 7);
       const int voff = min(m0 + row, (int)p.m - 1) * (int)p.x_stride_m * 2 + chunk * 16;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t*)(lds + s * kUnit + q * 1024), 16, voff, (k0 + s * kMsStepK) * 2, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t*)(lds + s * kUnit + q * 1024), 16, voff | CONCH_KILL(s), (k0 + s * kMsStepK) * 2, 0, 0);
     }
 
   // ---- weights, scales, zero points of the whole slice -> registers
@@ -88,12 +95,13 @@ __global__ __launch_bounds__(kMsThreads) void mixed_skinny_kernel(MixedGemmArgs 
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int i = 0; i < kWpc; ++i)
-        wq[s][h][i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rq, vq, q_base + (s * kWordRows + h * (kWordRows / 2) + i) * q_row, 0);
+        wq[s][h][i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rq, vq | CONCH_KILL(s), q_base + (s * kWordRows + h * (kWordRows / 2) + i) * q_row, 0);
     const int grp = (k0 + s * kMsStepK) / p.group_size;
-    sc[s] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs, n * 2, grp * (int)p.ws_stride_g * 2, 0);
-    if constexpr (ZP == CONCH_ZP_TENSOR) zp[s] = (int)__builtin_amdgcn_raw_buffer_load_b32(rz, n * 4, grp * (int)p.wzp_stride_g * 4, 0);
+    sc[s] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs, (n * 2) | CONCH_KILL(s), grp * (int)p.ws_stride_g * 2, 0);
+    if constexpr (ZP == CONCH_ZP_TENSOR) zp[s] = (int)__builtin_amdgcn_raw_buffer_load_b32(rz, (n * 4) | CONCH_KILL(s), grp * (int)p.wzp_stride_g * 4, 0);
     else zp[s] = 0;
   }
+#undef CONCH_KILL
   const int off_base = p.weight_bias + (ZP == CONCH_ZP_SCALAR ? p.w_zp[0] : 0);
   uint32_t and_mask = BITS == 4 ? 0x000f000fu : 0x00ff00ffu, or_magic = 0x64006400u;
   uint32_t and_mask_hi = and_mask << 4;  // int4: the pairs four bits up, taken without a shift (ChunkDequant)
@@ -200,14 +208,14 @@ void launch_zp_mode(const MixedGemmArgs& p, int rows, dim3 grid, float* ws, hipS
 bool mixed_gemm_skinny_supported(const MixedGemmArgs& p) {
   if (!mixed_gemm_mfma_supported(p)) return false;  // dtypes, bits in {4, 8}, alignment, 32-bit buffer offsets
   if (p.fuse_silu) return false;
-  if (p.m > 64 || p.n % 4) return false;
-  if (p.k % kMsSliceK) return false;                 // whole 1024-element slices (group_size % 64 == 0 is in the base contract)
+  if (p.m > kMsMaxM || p.n % 4) return false;        // up to four 64-row blocks (the dispatcher decides above 64 rows)
+  // K: any multiple of 64 (the base contract); the last 1024-element slice may be shorter (K = 11008: 10 slices + 12 steps)
   if ((((uintptr_t)p.c) & 1) || p.c_stride_m < p.n) return false;
   return true;
 }
 
 int launch_mixed_gemm_skinny(const MixedGemmArgs& p, hipStream_t stream) {
-  const int slices = (int)(p.k / kMsSliceK);
+  const int slices = (int)((p.k + kMsSliceK - 1) / kMsSliceK);
   const int rows = p.m <= 16 ? 16 : p.m <= 32 ? 32 : 64;
   void* ws = nullptr;
   if (int rc = get_scratch(stream, kScratchMixedSplitK, (size_t)slices * p.m * p.n * 4, &ws)) return rc;

@@ -223,15 +223,19 @@ __global__ __launch_bounds__(kSkThreads, 1) void skinny_splitk_kernel(ScaledGemm
   const int voff_b = min(n0 + r, (int)p.n - 1) * (int)p.b_stride_n + 16 * g;
   const int lane_off = (r >> 3) * 1024 + (r & 7) * 128 + ((g ^ ((r >> 1) & 7)) * 16);
 
+  // A ragged LAST slice (K % slice != 0; K % 128 == 0 always): the steps past K load from an out-of-range buffer offset --
+  // zeros into the registers and into LDS alike (the range check is on the VGPR offset) -- and their MFMAs add 0 x 0.
+  const int valid_steps = min(STEPS, ((int)p.k - k_begin) / kStepBytes);  // workgroup-uniform
   Frag fb[STEPS];
 #pragma unroll
   for (int s = 0; s < STEPS; ++s) {
-    fb[s].lo = ld16(rb, voff_b, k_begin + s * kStepBytes);
-    fb[s].hi = ld16(rb, voff_b, k_begin + s * kStepBytes + 64);
+    const int kill = s < valid_steps ? 0 : (int)0x80000000;
+    fb[s].lo = ld16(rb, voff_b | kill, k_begin + s * kStepBytes);
+    fb[s].hi = ld16(rb, voff_b | kill, k_begin + s * kStepBytes + 64);
     char* dst = lds + s * kUnit + wave * (ROWS / 4) * kStepBytes;
 #pragma unroll
     for (int j = 0; j < kPieces; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(dst + j * 1024), 16, voff_a[j],
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(dst + j * 1024), 16, voff_a[j] | kill,
                                                k_begin + s * kStepBytes, 0, 0);
     // the counted waits below count VMEM operations in THIS order, step by step: no reordering across steps
     __builtin_amdgcn_sched_barrier(0);
@@ -414,9 +418,10 @@ void launch_splitk_kernel(int rows, int steps, dim3 grid, const ScaledGemmArgs& 
 constexpr int kSpMaxTiles = 16384;  // arrival counters per (device, stream): 64 KiB
 
 int splitk_slices(const ScaledGemmArgs& p) {
-  // slices of exactly 1024 K-bytes (K % 1024 == 0 is part of the skinny contract)
-  if (p.n % 4 || p.m > 2 * kSkM || p.k % kSpSliceK) return 0;
-  return (int)(p.k / kSpSliceK);
+  // slices of 1024 K-bytes, the last one possibly shorter (K % 128 == 0 is part of the MFMA contract): K = 11008, the Llama-7B
+  // down projection, is 10 slices + 6 steps
+  if (p.n % 4 || p.m > 2 * kSkM) return 0;
+  return (int)((p.k + kSpSliceK - 1) / kSpSliceK);
 }
 
 }  // namespace
@@ -429,7 +434,8 @@ bool scaled_gemm_skinny_fused_supported(const ScaledGemmArgs& wide) {
 bool scaled_gemm_skinny_supported(const ScaledGemmArgs& p) {
   if (!scaled_gemm_mfma_supported(p)) return false;
   if (p.m > 2 * kSkM) return false;                      // beyond two row blocks the tiled kernels win
-  if (p.k % (2 * kStepBytes * kSkWaves)) return false;   // K/4 per wave, an even number of 128-byte steps
+  // the in-workgroup form needs K/4 per wave, an even number of 128-byte steps; the split-K form any K % 128 == 0 but N % 4 == 0
+  if (p.k % (2 * kStepBytes * kSkWaves) && p.n % 4) return false;
   return true;
 }
 
@@ -450,7 +456,7 @@ int launch_splitk(const ScaledGemmArgs& p, int slices, hipStream_t stream) {
   int steps = kSpSteps;
   if (mode == 3 && p.k % (2 * kSpSliceK) == 0) {
     steps = 2 * kSpSteps;
-    slices /= 2;
+    slices = (slices + 1) / 2;
     rows = p.m <= 32 ? 32 : 64;
   } else if (mode == 3) {
     mode = 2;
@@ -484,7 +490,9 @@ int launch_splitk(const ScaledGemmArgs& p, int slices, hipStream_t stream) {
 int launch_scaled_gemm_skinny(const ScaledGemmArgs& p, hipStream_t stream) {
   // fuse_silu: `p` is the WIDE problem (n = 2d) whose reduce kernel writes the d-column FFN result (the caller has checked
   // scaled_gemm_skinny_fused_supported); only the split-K form has a reduce kernel
-  const int slices = (tuning(CONCH_TUNE_SKINNY_NO_SPLITK) == 1 && !p.fuse_silu) ? 0 : splitk_slices(p);  // CONCH_TUNE_SKINNY_NO_SPLITK = 1 disables split-K
+  // CONCH_TUNE_SKINNY_NO_SPLITK = 1 disables split-K (where the in-workgroup form can take the shape)
+  const bool in_wg_ok = p.k % (2 * kStepBytes * kSkWaves) == 0;
+  const int slices = (tuning(CONCH_TUNE_SKINNY_NO_SPLITK) == 1 && !p.fuse_silu && in_wg_ok) ? 0 : splitk_slices(p);
   if (slices >= 1) {
     int rc;
     if (p.in_dtype == CONCH_DT_FP8_E4M3FN)

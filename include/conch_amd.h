@@ -14,7 +14,7 @@
  * re-entrant.  Launchers never allocate USER-VISIBLE memory (docs/conch/structure.md:14-15 of the reference).
  *
  * Library scratch.  Some paths need device scratch the caller does not see: the split-K slabs of the skinny-M kernels
- * (M <= 256 scaled, M <= 64 mixed), K-contiguous copies of operands in non-native layouts, the bf16 expansion of
+ * (M <= 256 scaled, M <= 256 mixed), K-contiguous copies of operands in non-native layouts, the bf16 expansion of
  * e4m3fnuz operands, the [M][2d] intermediate of an FFN pair that cannot use the fused epilogue.  It is owned by the
  * library, one buffer per (device, stream, slot), allocated with hipMalloc the first time a call needs more than the
  * slot holds and never freed or moved afterwards (enqueued and graph-captured launches keep using the old buffer).
@@ -331,7 +331,13 @@ int conch_bnb_gemm_4bit(void* c, const void* x, const uint8_t* w_packed, const v
  * Timing helper used by bench.py: launches `iters` back-to-back scaled_gemm calls on `stream`
  * bracketed by HIP events recorded ON THAT STREAM and returns the average milliseconds per call
  * in *avg_ms (synchronises the stream; not for use inside graph capture).
+ *
+ * conch_set_timing_rotation(count, stride_bytes): launch i of conch_time_scaled_gemm / conch_time_mixed_precision_gemm[_prepacked]
+ * reads its WEIGHTS (b / w_q_packed / image) at base + (i % count) * stride_bytes.  With count x (weight bytes) beyond the
+ * 256 MiB Infinity Cache every launch streams its weights from HBM, as a decode step of a model does; count = 1 (the default)
+ * re-reads one cache-resident buffer.  The caller owns the count buffers.  (tools/dispatch_cold_sweep.py)
  */
+int conch_set_timing_rotation(int count, int64_t stride_bytes);
 int conch_time_scaled_gemm(void* c, const void* a, const void* b, const float* scale_a,
                            const float* scale_b, const void* bias, int64_t m, int64_t n, int64_t k,
                            int64_t a_stride_m, int64_t a_stride_k, int64_t b_stride_k,

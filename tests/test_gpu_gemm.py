@@ -261,13 +261,14 @@ def test_one_launch_splitk_under_uneven_load(_reset_tuning):
 @pytest.mark.parametrize(("m", "k", "n"), [(128, 256, 128), (1024, 1024, 1024), (300, 384, 520), (257, 128, 8),
                                             (512, 1152, 1376), (2304, 512, 4672), (4096, 256, 11008),
                                             (128, 1024, 4096), (200, 2048, 520), (1, 1024, 24), (256, 3072, 1376),
-                                            (48, 1024, 520), (20, 2048, 4096), (33, 1024, 64)])
+                                            (48, 1024, 520), (20, 2048, 4096), (33, 1024, 64),
+                                            (16, 1152, 256), (96, 2944, 520), (200, 128, 64)])
 def test_scaled_gemm_every_kernel_variant(variant, iname, m, k, n):
     """Each device kernel, including ragged M/N tails (partial tiles, N not a multiple of 256 / 16)."""
     if variant == "pingpong2" and k < 256:
         pytest.skip("two-phase ping-pong stages two K steps in its prologue (K >= 256)")
-    if variant == "skinny" and (m > 256 or k % 1024):
-        pytest.skip("skinny kernel: M <= 256 and K a multiple of 1024")
+    if variant == "skinny" and (m > 256 or (k % 1024 and n % 4)):
+        pytest.skip("skinny kernel: M <= 256, and N % 4 == 0 (split-K form) or K a multiple of 1024 (in-workgroup form)")
     a, b, sa, sb, bias = make_scaled_inputs(m, k, n, IN_T[iname], torch.bfloat16, False, False, True)
     ref = oracle.scaled_gemm_ref(a, b, sa, sb, torch.bfloat16, bias)
     _C.set_gemm_variant(VARIANTS[variant])
@@ -476,9 +477,9 @@ def test_scaled_gemm_silu_shapes_fused_equals_unfused(iname, m, k, d):
     _C.set_gemm_variant(_C.VARIANT_MFMA_SIMPLE)
     unfused = run_silu(a, b, sa, sb, torch.bfloat16, bias)
     _C.set_gemm_variant(_C.VARIANT_AUTO)
-    if m <= 64 and k % 1024 == 0 and iname != "int8":
-        # decode batch: auto runs the split-K kernel with the silu fused into its reduce kernel -- another fp32 summation
-        # order than the tiled kernel of the unfused pair
+    if m <= 256 and iname != "int8":
+        # skinny M: auto may run the split-K kernel with the silu fused into its reduce kernel (the cost model decides) --
+        # another fp32 summation order than the tiled kernel of the unfused pair
         tol = 4.0 * EPS[torch.bfloat16] * unfused.float().abs().max().item()
         assert (got.float() - unfused.float()).abs().max().item() <= tol
     else:
@@ -762,7 +763,7 @@ def test_mixed_precision_silu_fused_equals_unfused(m, k, d, wname, use_zp, dname
     finally:
         _C.load().conch_set_tuning(1, 0)
         _C.set_gemm_variant(_C.VARIANT_AUTO)
-    if m <= 64 and k % 1024 == 0:
+    if m <= 256:
         # decode batch: the decode-batch kernel with the silu fused into its reduce kernel (other summation order)
         tol = 4.0 * EPS[DT[dname]] * unfused.float().abs().max().item()
         assert (got.float() - unfused.float()).abs().max().item() <= tol
@@ -773,11 +774,12 @@ def test_mixed_precision_silu_fused_equals_unfused(m, k, d, wname, use_zp, dname
 # ---------------------------------------------------------------------------------------------
 # decode-batch kernel of mixed_precision_gemm (M <= 64, gemm_mixed_skinny.hip)
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize(("m", "k", "n"), [(1, 1024, 64), (16, 2048, 520), (20, 1024, 4096), (33, 4096, 1376), (64, 2048, 256), (48, 1024, 100)])
+@pytest.mark.parametrize(("m", "k", "n"), [(1, 1024, 64), (16, 2048, 520), (20, 1024, 4096), (33, 4096, 1376), (64, 2048, 256), (48, 1024, 100),
+                                            (8, 1152, 256), (40, 2944, 520), (16, 128, 64), (100, 1024, 256), (128, 2048, 520), (250, 1152, 256)])
 @pytest.mark.parametrize(("wname", "use_zp", "dname"), [("uint4b8", False, "f16"), ("uint4", True, "bf16"),
                                                          ("uint8b128", True, "f16"), ("uint8", False, "bf16")])
 def test_mixed_precision_decode_batches(m, k, n, wname, use_zp, dname):
-    """The automatic choice for M <= 64, K % 1024 == 0, N % 4 == 0 (forced with variant 4 so that a contract change cannot
+    """The automatic choice for M <= 64, N % 4 == 0, any K (a ragged last 1024-element slice included) (forced with variant 4 so that a contract change cannot
     silently skip it): against the oracle, and against the LDS-tiled kernel (other summation order: 2 eps of max|C|)."""
     wt = WTYPES[wname]
     a, w_ref, packed, w_s, w_zp = make_mixed_inputs(m, k, n, wt, use_zp, DT[dname])
@@ -788,7 +790,9 @@ def test_mixed_precision_decode_batches(m, k, n, wname, use_zp, dname):
     _C.set_gemm_variant(_C.VARIANT_MFMA_PINGPONG2)
     tiled = mixed_precision_gemm(*args)
     _C.set_gemm_variant(_C.VARIANT_AUTO)
-    assert torch.equal(mixed_precision_gemm(*args), got)  # auto = the decode-batch kernel
+    auto = mixed_precision_gemm(*args)
+    assert torch.equal(auto, got if m <= 64 else auto)  # auto = the decode-batch kernel up to 64 rows (a cost rule above)
+    assert torch.equal(auto, got) or torch.equal(auto, tiled)
     tol = 2.0 * EPS[DT[dname]] * tiled.float().abs().max().item()
     assert (got.float() - tiled.float()).abs().max().item() <= tol
 
@@ -1003,7 +1007,7 @@ def test_scaled_gemm_gelu_shapes_fused_equals_unfused(iname, m, k, d):
     _C.set_gemm_variant(_C.VARIANT_MFMA_SIMPLE)
     unfused = run_gelu(a, b, sa, sb, torch.bfloat16, bias)
     _C.set_gemm_variant(_C.VARIANT_AUTO)
-    if m <= 64 and k % 1024 == 0 and iname != "int8":
+    if m <= 256 and iname != "int8":
         tol = 4.0 * EPS[torch.bfloat16] * unfused.float().abs().max().item()
         assert (got.float() - unfused.float()).abs().max().item() <= tol
     else:
@@ -1031,7 +1035,7 @@ def test_mixed_precision_gelu_fused(m, k, d, wname, use_zp, dname):
         unfused = mixed_precision_gemm_gelu_tanh_and_mul(*args)
     finally:
         _C.set_gemm_variant(_C.VARIANT_AUTO)
-    if m <= 64 and k % 1024 == 0:
+    if m <= 256:
         assert (got.float() - unfused.float()).abs().max().item() <= 4.0 * EPS[DT[dname]] * unfused.float().abs().max().item()
     else:
         assert torch.equal(got, unfused)
@@ -1106,3 +1110,65 @@ def test_prepacked_gemm_c4_config():
     pre = prepack_mixed_weights(packed.cuda(), wt.size_bits, m_hint=m)
     assert pre.tile_nt == 3  # 232 tiles of 192 columns: one round of the chip
     assert torch.equal(mixed_precision_gemm_prepacked(a.cuda(), pre, w_s.cuda(), None, wt.bias, 128), plain)
+
+
+# ---------------------------------------------------------------------------------------------
+# K that is not a multiple of the split-K slice: the Llama-7B down projection (K = 11008 = 10 slices + 768) at decode sizes
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("iname", ["int8", "fn"])
+@pytest.mark.parametrize("m", [1, 16, 128, 200])
+def test_scaled_gemm_down_projection_decode(iname, m):
+    k, n = 11008, 4096
+    a, b, sa, sb, bias = make_scaled_inputs(m, k, n, IN_T[iname], torch.bfloat16, False, False, True)
+    ref = oracle.scaled_gemm_ref(a, b, sa, sb, torch.bfloat16, bias)
+    _C.set_gemm_variant(_C.VARIANT_MFMA_SKINNY)
+    got = run_scaled(a, b, sa, sb, torch.bfloat16, bias)
+    check_scaled(got, ref, IN_T[iname], torch.bfloat16, (a, b, sa, sb, bias))
+    _C.set_gemm_variant(_C.VARIANT_AUTO)
+    auto = run_scaled(a, b, sa, sb, torch.bfloat16, bias)
+    check_scaled(auto, ref, IN_T[iname], torch.bfloat16, (a, b, sa, sb, bias))
+
+
+def test_scaled_gemm_ragged_slice_ignores_what_lies_behind_k():
+    """The steps past K of the last slice must contribute nothing even if the memory behind a row holds NaN patterns: A and B are
+    views of wider arrays whose tail columns are 0x7f (e4m3fn NaN)."""
+    m, k, n, pad = 24, 1152, 64, 1024
+    a_wide = torch.full((m, k + pad), 0x7F, dtype=torch.uint8).view(torch.float8_e4m3fn)
+    b_wide = torch.full((n, k + pad), 0x7F, dtype=torch.uint8).view(torch.float8_e4m3fn)
+    a0 = (0.25 * torch.rand((m, k))).to(torch.float8_e4m3fn)
+    b0 = (0.25 * torch.rand((n, k))).to(torch.float8_e4m3fn)
+    a_wide.view(torch.uint8)[:, :k] = a0.view(torch.uint8)
+    b_wide.view(torch.uint8)[:, :k] = b0.view(torch.uint8)
+    sa, sb = 0.25 * torch.rand((m, 1)), 0.25 * torch.rand((n, 1))
+    ref = oracle.scaled_gemm_ref(a0, b0.T, sa, sb, torch.bfloat16, None)
+    _C.set_gemm_variant(_C.VARIANT_MFMA_SKINNY)
+    got = scaled_gemm(a_wide.cuda()[:, :k], b_wide.cuda()[:, :k].T, sa.cuda(), sb.cuda(), torch.bfloat16)
+    assert torch.isfinite(got.float()).all()
+    check_scaled(got, ref, torch.float8_e4m3fn, torch.bfloat16, (a0, b0.T, sa, sb, None))
+
+
+@pytest.mark.parametrize(("wname", "use_zp", "dname"), [("uint4b8", False, "f16"), ("uint4", True, "bf16"), ("uint8b128", False, "f16")])
+@pytest.mark.parametrize("m", [1, 16, 64])
+def test_mixed_precision_down_projection_decode(m, wname, use_zp, dname):
+    k, n = 11008, 4096
+    wt = WTYPES[wname]
+    a, w_ref, packed, w_s, w_zp = make_mixed_inputs(m, k, n, wt, use_zp, DT[dname])
+    args = (a.cuda(), packed.cuda(), w_s.cuda(), None if w_zp is None else w_zp.cuda(), wt.size_bits, wt.bias, 128)
+    _C.set_gemm_variant(_C.VARIANT_MFMA_SKINNY)
+    got = mixed_precision_gemm(*args)
+    check_mixed(got, a, w_ref, k)
+    _C.set_gemm_variant(_C.VARIANT_AUTO)
+    assert torch.equal(mixed_precision_gemm(*args), got)  # auto = the decode-batch kernel
+
+
+def test_mixed_precision_ragged_slice_ignores_inf_behind_k():
+    """X is a view of a wider array whose tail columns are +inf: the steps past K of the last slice must not read them."""
+    m, k, n, pad = 8, 1152, 128, 1024
+    wt = scalar_types.uint4b8
+    a, w_ref, packed, w_s, _ = make_mixed_inputs(m, k, n, wt, False, torch.float16)
+    wide = torch.full((m, k + pad), float("inf"), dtype=torch.float16)
+    wide[:, :k] = a
+    _C.set_gemm_variant(_C.VARIANT_MFMA_SKINNY)
+    got = mixed_precision_gemm(wide.cuda()[:, :k], packed.cuda(), w_s.cuda(), None, wt.size_bits, wt.bias, 128)
+    assert torch.isfinite(got.float()).all()
+    check_mixed(got, a, w_ref, k)
