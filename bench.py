@@ -403,6 +403,8 @@ def main() -> None:
     ap.add_argument("--quick", action="store_true", help="skip the sustained / cold / clock legs (PMC profiling passes)")
     ap.add_argument("--no-cold", action="store_true", help="skip the cache-flushed op-level leg")
     ap.add_argument("--no-probe", action="store_true", help="skip the diagnostic-twin clock probe (kernel-trace profiling: its kernels share names)")
+    ap.add_argument("--c5-base", action="store_true",
+                    help="N = 1, workload c3: add the one-GPU figure of BASELINE config C5 (the strong-scaling base of --gpus N > 1) as a side field")
     ap.add_argument("--dp", action="store_true",
                     help="with --gpus N > 1: make the weak-scaling data-parallel C3 run the headline instead of N-sharded C5")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
@@ -528,6 +530,17 @@ def main() -> None:
         },
         "roofline": roofline,
     }
+    if world == 1 and args.workload == "c3" and args.c5_base:
+        # opt-in (it launches the headline's kernel symbol on another shape, which would skew a rocprofv3 per-kernel average of
+        # this command) -- the strong-scaling base of the multi-GPU lines: `--gpus N` (N > 1) reports BASELINE config C5 (a different metric than
+        # this line's C3), so its one-GPU figure rides along here for whoever computes N-GPU efficiency from the N = 1 run
+        try:
+            r5 = nshard_c5(1, 0, device, 10, 3)
+            result["c5_one_gpu"] = {"metric": "effective TFLOP/s, scaled-GEMM fp8xbf16 8192x8192x28672 on ONE GPU (strong-scaling base of --gpus N > 1)",
+                                    "value": r5["tflops_gemm_plus_allgather_rowmajor"], "unit": "TFLOP/s",
+                                    "ms_per_step": r5["ms_gemm_plus_allgather_rowmajor"], "steps": 10, "warmup": 3}
+        except Exception as exc:  # noqa: BLE001 -- a side field must not take the headline down
+            result["c5_one_gpu"] = {"error": repr(exc)}
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         if kind.startswith("scaled"):
             result["cpu_baseline"] = cpu_baseline_scaled(kind, m, k, n)
