@@ -15,7 +15,7 @@
 namespace conch {
 
 static thread_local char g_error[512] = "";
-static std::atomic<int> g_tuning[8] = {};
+static std::atomic<int> g_tuning[10] = {};
 
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -24,7 +24,7 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-int tuning(int key) { return (key >= 0 && key < 8) ? g_tuning[key].load() : 0; }
+int tuning(int key) { return (key >= 0 && key < 10) ? g_tuning[key].load() : 0; }
 
 int device_cu_count() {
   static std::atomic<int> cache[64] = {};
@@ -133,7 +133,8 @@ enum ScaledKernel { kKernelTiled = 0, kKernelMid = 1, kKernelSkinny = 2 };
 // six (K, N) pairs, int8 and fp8; profiles/r02/dispatch_cold_sweep_before.txt / _after.txt):
 //   split-K skinny  5.3 + c(M) N K        (re-reads the A slice per 64-column block; two row blocks above M = 128)
 //   256x256 tiles   rounds x (41 + 0.06 t) K/4096,  t = tiles per round of 256 workgroups
-//   128x128 tiles   rounds x (31 + 0.02 t) K/4096,  t = tiles per round of 512 workgroups (two per CU)
+//   128x128 tiles   rounds x (31 + 0.02 t) K/4096,  t = tiles per round of 512 workgroups (two per CU); with at most one tile
+//                   per CU (the 4-stage ring): (23 + 0.04 max(0, t - 128)) K/4096
 // The warm fit (round 1) was 4.5-5.5 + c N K with c 1.7 .. 9.7, rounds x (34 + 0.05 t), rounds x (19 + 0.0176 t): with it the
 // dispatcher picked the 128x128 tiles where the split-K form is 15-47 % faster on cold weights (96-128 x 4096 x 11008,
 // 8-32 x 4096 x 28672, 256 x 4096 x 4096).
@@ -144,7 +145,9 @@ ScaledKernel choose_scaled_kernel(const ScaledGemmArgs& p) {
   const double tiled_us = (double)rounds256 * (41.0 + 0.06 * (double)tiles256 / (double)rounds256) * kscale;
   const int64_t tiles128 = ((p.m + 127) / 128) * ((p.n + 127) / 128);
   const int64_t rounds128 = (tiles128 + 511) / 512;
-  const double mid_us = (double)rounds128 * (31.0 + 0.02 * (double)tiles128 / (double)rounds128) * kscale;
+  // at most one tile per CU: the 4-stage ring (gemm_mid.hip), three K steps in flight per CU instead of one
+  const double mid_us = tiles128 <= device_cu_count() ? (23.0 + 0.04 * (double)std::max<int64_t>(0, tiles128 - 128)) * kscale
+                                                      : (double)rounds128 * (31.0 + 0.02 * (double)tiles128 / (double)rounds128) * kscale;
   ScaledKernel pick = kKernelTiled;
   double best = tiled_us;
   if (mid_us < best) {
@@ -427,7 +430,7 @@ extern "C" int conch_abi_version(void) { return CONCH_AMD_ABI_VERSION; }
 extern "C" const char* conch_last_error(void) { return g_error; }
 
 extern "C" int conch_set_tuning(int key, int value) {
-  CONCH_CHECK_ARG(key >= 0 && key < 8, "conch_set_tuning: unknown key %d", key);
+  CONCH_CHECK_ARG(key >= 0 && key < 10, "conch_set_tuning: unknown key %d", key);
   g_tuning[key].store(value);
   return CONCH_OK;
 }

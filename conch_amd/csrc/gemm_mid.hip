@@ -19,15 +19,20 @@ using namespace tile;
 constexpr int kMidThreads = 256;
 constexpr int kMidTile = 128;
 constexpr int kMidBuf = 2 * kUnitBytes;                 // U (128 rows of A) + V (128 rows of B^T)
-constexpr int kMidEpi = 2 * kMidBuf;                    // float sa[128] | sb[128] | bias[128]
-constexpr int kMidLds = kMidEpi + 3 * 128 * 4;          // 64 KiB + 1.5 KiB
+// STAGES buffers, then float sa[128] | sb[128] | bias[128].  STAGES = 2 (64 KiB + 1.5 KiB): two workgroups per CU, one K step in
+// flight each.  STAGES = 4 (128 KiB + 1.5 KiB): ONE workgroup per CU with three K steps (96 KiB) in flight, for problems of at
+// most one tile per CU -- there a CU holds a single 2-stage workgroup anyway, its one step in flight is issued after the barrier
+// and waited for before the next (32 KiB per memory latency: 1 MiB of operands in 31 us at K = 4096 on weights streamed from HBM,
+// whatever N and M are; profiles/r02/dispatch_cold_sweep_before.txt).
 
 struct MidOffsets {
   int u[4], v[4];  // byte offset of this lane's 16-byte source chunk for the wave's four pieces of a unit
 };
 
-template <int MMA, int OUT_DT>
+template <int MMA, int OUT_DT, int STAGES>
 __global__ __launch_bounds__(kMidThreads, 2) void scaled_gemm_mid_kernel(ScaledGemmArgs p) {
+  constexpr int kMidEpi = STAGES * kMidBuf;
+  constexpr int kMidLds = kMidEpi + 3 * 128 * 4;
   __shared__ __attribute__((aligned(1024))) char lds[kMidLds];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -52,7 +57,7 @@ __global__ __launch_bounds__(kMidThreads, 2) void scaled_gemm_mid_kernel(ScaledG
     so.v[j] = min(bn0 + nrow, (int)p.n - 1) * (int)p.b_stride_n + chunk * 16;
   }
   auto stage = [&](int step) {
-    char* dst = lds + (step & 1) * kMidBuf + wave * 4096;
+    char* dst = lds + (step % STAGES) * kMidBuf + wave * 4096;
     const int koff = step * kStepBytes;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -71,7 +76,10 @@ __global__ __launch_bounds__(kMidThreads, 2) void scaled_gemm_mid_kernel(ScaledG
     const float v0 = base[vec ? idx : 0];
     uint32_t bits = 0;
     if (p.bias) bits = ((const uint16_t*)p.bias)[min(bn0 + tt, (int)p.n - 1)];
-    stage(0);
+    const int steps0 = (int)(p.k / kStepBytes);
+#pragma unroll
+    for (int s0 = 0; s0 < STAGES - 1; ++s0)
+      if (s0 < steps0) stage(s0);
     float* f = (float*)(lds + kMidEpi);
     f[t] = v0;
     if (is_b) f[t + 128] = bits16_to_float<OUT_DT>((uint16_t)bits);
@@ -90,10 +98,17 @@ __global__ __launch_bounds__(kMidThreads, 2) void scaled_gemm_mid_kernel(ScaledG
 
   const int steps = (int)(p.k / kStepBytes);
   for (int t = 0; t < steps; ++t) {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this wave's pieces of step t have landed ...
-    __builtin_amdgcn_s_barrier();                                // ... and every wave is done with the other buffer
-    if (t + 1 < steps) stage(t + 1);
-    const int buf = (t & 1) * kMidBuf;
+    // this wave's pieces of step t have landed (the steps behind it -- up to STAGES - 2, eight LDS-DMA instructions each, the
+    // only vector-memory work in the loop -- may still be in flight; the last steps simply drain) ...
+    if (STAGES > 2 && steps - 1 - t >= STAGES - 2) {
+      wait_vmcnt_n<8 * (STAGES - 2)>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                                // ... and every wave is done with the buffer of step t - 1
+    if (t + STAGES - 1 < steps) stage(t + STAGES - 1);
+    const int buf = (t % STAGES) * kMidBuf;
     Frag fn[4], fm[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) fn[q] = read_frag(lds, buf + n_base + q * 2048);
@@ -158,9 +173,13 @@ int launch_scaled_gemm_mid(const ScaledGemmArgs& p, hipStream_t stream) {
   const int tiles_m = (int)((p.m + kMidTile - 1) / kMidTile);
   const int tiles_n = (int)((p.n + kMidTile - 1) / kMidTile);
   const dim3 grid((unsigned)(tiles_m * tiles_n));
+  // at most one tile per CU: the deep ring (one workgroup per CU either way); CONCH_TUNE_MID_STAGES forces 2 or 4
+  const int forced = tuning(CONCH_TUNE_MID_STAGES);
+  const bool deep = forced == 4 || (forced != 2 && (int64_t)tiles_m * tiles_n <= device_cu_count());
 #define CONCH_LAUNCH_MID(MMA, OUT)                                                                         \
   do {                                                                                                     \
-    hipLaunchKernelGGL((scaled_gemm_mid_kernel<MMA, OUT>), grid, dim3(kMidThreads), 0, stream, p);          \
+    if (deep) hipLaunchKernelGGL((scaled_gemm_mid_kernel<MMA, OUT, 4>), grid, dim3(kMidThreads), 0, stream, p); \
+    else hipLaunchKernelGGL((scaled_gemm_mid_kernel<MMA, OUT, 2>), grid, dim3(kMidThreads), 0, stream, p);  \
     return check_launch("scaled_gemm_mid");                                                                \
   } while (0)
   if (p.in_dtype == CONCH_DT_FP8_E4M3FN) {

@@ -647,7 +647,7 @@ int launch_zp(const MixedGemmArgs& p, hipStream_t stream) {
   }
 #ifdef CONCH_CLOCK_PROBE
   if constexpr (X_DT == CONCH_DT_FP16 && OUT_DT == CONCH_DT_FP16 && BITS == 4 && NT == 4) {
-    const int diag = tuning(7);  // diagnostic twin: timing experiments of the K loop (see mixed_step)
+    const int diag = tuning(CONCH_TUNE_DIAG);  // diagnostic twin: timing experiments of the K loop (see mixed_step)
     if (diag >= 1 && diag <= 5 && p.zp_mode == CONCH_ZP_NONE) {
 #define CONCH_DIAG(D) hipLaunchKernelGGL((mixed_gemm_kernel<X_DT, OUT_DT, BITS, CONCH_ZP_NONE, NT, false, false, false, D>), grid, dim3(kThreads), 0, stream, p)
       if (diag == 1) CONCH_DIAG(1);

@@ -129,6 +129,12 @@ typedef enum conch_tuning_key {
   CONCH_TUNE_EPILOGUE = 6 /* 256x256-tile scaled GEMM (two-phase ping-pong): 0 = auto, 1 = direct 16-byte stores from the
                              accumulator layout (16 lines per quarter-wave), 2 = sub-tile parked in LDS and stored as whole
                              128-byte rows */
+  ,
+  CONCH_TUNE_DIAG = 7 /* diagnostic twin of the library only (-DCONCH_CLOCK_PROBE): timing experiments of the mixed K loop with
+                         parts removed (wrong results); ignored by the product library */
+  ,
+  CONCH_TUNE_MID_STAGES = 8 /* 128x128-tile scaled GEMM: 0 = auto (the 4-stage ring, one workgroup per CU, when there is at
+                               most one tile per CU; else the 2-stage loop, two workgroups per CU), 2 / 4 = force */
 } conch_tuning_key_t;
 
 int conch_abi_version(void);

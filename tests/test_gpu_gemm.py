@@ -163,6 +163,7 @@ def _reset_tuning():
     _C.set_tuning(_C.TUNE_SKINNY_MODE, 0)
     _C.set_tuning(_C.TUNE_PERSISTENT, 0)
     _C.set_tuning(_C.TUNE_EPILOGUE, 0)
+    _C.set_tuning(_C.TUNE_MID_STAGES, 0)
 
 
 @pytest.mark.parametrize("iname", ["int8", "fn"])
@@ -216,6 +217,24 @@ def test_persistent_tile_walk_is_bit_identical_and_correct(_reset_tuning, workgr
         np.testing.assert_array_equal(to_bits(walk), to_bits(plain))
     ref = oracle.scaled_gemm_ref(a, b, sa, sb, torch.bfloat16, None)
     check_scaled(walk, ref, IN_T[iname], torch.bfloat16, (a, b, sa, sb, None))
+
+
+@pytest.mark.parametrize("iname", ["int8", "fn"])
+@pytest.mark.parametrize(("m", "k", "n"), [(512, 4096, 1024), (300, 128, 520), (257, 256, 8), (128, 384, 136), (1024, 512, 4096), (200, 1152, 64)])
+def test_mid_kernel_ring_depths_are_bit_identical(_reset_tuning, iname, m, k, n):
+    """The 128x128-tile kernel with the 2-stage loop (two workgroups per CU) and the 4-stage ring (one per CU, three K steps in
+    flight; K of one to three steps included): the ring depth moves loads, not the accumulation order."""
+    a, b, sa, sb, bias = make_scaled_inputs(m, k, n, IN_T[iname], torch.bfloat16, False, False, True)
+    ref = oracle.scaled_gemm_ref(a, b, sa, sb, torch.bfloat16, bias)
+    _C.set_gemm_variant(_C.VARIANT_MFMA_MID)
+    _C.set_tuning(_C.TUNE_MID_STAGES, 2)
+    two = run_scaled(a, b, sa, sb, torch.bfloat16, bias)
+    _C.set_tuning(_C.TUNE_MID_STAGES, 4)
+    four = run_scaled(a, b, sa, sb, torch.bfloat16, bias)
+    assert torch.equal(two, four)
+    check_scaled(four, ref, IN_T[iname], torch.bfloat16, (a, b, sa, sb, bias))
+    for _ in range(3):  # back to back: the ring of one launch must not depend on what the previous one left in LDS
+        assert torch.equal(run_scaled(a, b, sa, sb, torch.bfloat16, bias), four)
 
 
 @pytest.mark.parametrize("mode", [2, 3])

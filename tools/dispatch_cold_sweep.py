@@ -53,17 +53,19 @@ def scaled_case(m, k, n, dtype):
     res = {}
     for regime, rot in (("warm", 1), ("cold", count)):
         LIB.conch_set_timing_rotation(rot, n * k)
-        for name, variant in (("auto", 0), ("skinny", 4), ("mid128", 6), ("tile256", 5)):
+        for name, variant in (("auto", 0), ("skinny", 4), ("mid128", 6), ("mid128x2", 6), ("tile256", 5)):
             if variant == 4 and m > 256:
                 continue
             _C.set_gemm_variant(variant)
+            _C.set_tuning(_C.TUNE_MID_STAGES, 2 if name == "mid128x2" else 0)  # mid128x2 = the 2-stage loop forced
             try:
                 res[(regime, name)] = timed(run, 30.0)
             except Exception:  # noqa: BLE001 -- a forced variant whose contract the shape does not meet
                 pass
     _C.set_gemm_variant(0)
     LIB.conch_set_timing_rotation(1, 0)
-    report(f"scaled {str(dtype)[6:]:13s} {m:5d}x{k}x{n}", res, ("skinny", "mid128", "tile256"))
+    _C.set_tuning(_C.TUNE_MID_STAGES, 0)
+    report(f"scaled {str(dtype)[6:]:13s} {m:5d}x{k}x{n}", res, ("skinny", "mid128", "mid128x2", "tile256"))
 
 
 def mixed_case(m, k, n, dtype=torch.float16, bits=4):

@@ -1,6 +1,5 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out
-timeout 900 tools/gpu_profile.sh r02i_c3 --workload c3 > /dev/null 2>&1
-head -3 gpurun_out/prof_r02i_c3/summary.txt
-tail -c 1200 gpurun_out/prof_r02i_c3/trace.log | grep -o '"kernel_sustained_ms": [0-9.]*'
+timeout 1200 python tools/dispatch_cold_sweep.py "$@" 2>&1 | grep -v amdgpu.ids > gpurun_out/dispatch_cold_sweep.txt
+grep -c "pick costs" gpurun_out/dispatch_cold_sweep.txt; grep "pick costs" gpurun_out/dispatch_cold_sweep.txt | cut -c1-330 | head -30
