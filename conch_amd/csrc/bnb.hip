@@ -13,6 +13,7 @@
 // one dword (4-bit) or two dwords (8-bit) stored per lane: one pass over HBM.  The code book sits in LDS.
 #include "common.hpp"
 #include "gemm.hpp"
+#include "mfma_tile.hpp"
 
 namespace conch {
 namespace {
@@ -307,6 +308,190 @@ int dequantize_adt(void* out, const uint8_t* xq, const void* absmax, const float
   return dequantize_qt<ODT, CONCH_DT_BF16>(out, xq, absmax, code, n, blocksize, qt, out_stride_row, row_len, stream);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Decode-batch GEMM on the 4-bit weight (M <= 128): y = x @ dequantise(W)^T without materialising W.
+// Same construction as gemm_mixed_skinny.hip: a workgroup owns (64 columns, one 1024-element K slice, a block of 16 / 32 / 64
+// rows); the X slice is staged once by LDS-DMA; a lane of the MFMA's weight operand is (column n, 8-element k-group), and those
+// eight codes are exactly ONE 32-bit word of row n of the packed tensor (byte j = code 2j << 4 | code 2j+1).  A code becomes a
+// number through a table in LDS (256 entries: packed byte -> its two fp32 numbers) and the block's absmax, with the roundings of bnb_dequantize_kernel -- absmax dtype, then the activation dtype -- so the
+// weights multiplied here are bit for bit the ones the dequantise-first path multiplies.  fp32 partial sums go to slabs; the
+// fp32-slab reduce of gemm_mixed_skinny.hip adds the slices in slice order and casts.
+// ---------------------------------------------------------------------------------------------
+struct BnbGemmArgs {
+  void* c;
+  const void* x;
+  const uint8_t* w;
+  const void* absmax;
+  int64_t m, n, k, x_stride_m, c_stride_m;
+  int blocksize;
+};
+
+constexpr int kBgThreads = 256;
+constexpr int kBgN = 64;        // columns per workgroup
+constexpr int kBgStepK = 64;    // k elements per step (128 bytes of fp16 / bf16)
+constexpr int kBgSteps = 16;    // steps per slice
+constexpr int kBgSliceK = kBgSteps * kBgStepK;
+
+template <int X_DT, int ADT, int QT, int ROWS>
+__global__ __launch_bounds__(kBgThreads) void bnb_decode_gemm_kernel(BnbGemmArgs p, float* __restrict__ slabs) {
+  using namespace tile;
+  constexpr int kUnit = ROWS * 128;  // one K step of X
+  __shared__ __attribute__((aligned(1024))) char lds[kBgSteps * kUnit + 2048];
+  // byte -> its two numbers (code byte >> 4 first): ONE 8-byte LDS read per packed byte instead of two 4-byte reads and twice the
+  // address arithmetic (the loop is bound by vector instructions, not by the LDS)
+  f32x2* lut = (f32x2*)(lds + kBgSteps * kUnit);
+  {
+    const float* t16 = QT == kQtNf4 ? kNf4Values : kFp4Values;
+    lut[threadIdx.x] = f32x2{t16[threadIdx.x >> 4], t16[threadIdx.x & 15]};
+  }
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 15, g = lane >> 4;
+  const int nw = blockIdx.x * kBgN + wave * 16;
+  const int n = min(nw + r, (int)p.n - 1);  // this lane's weight row
+  const int k0 = blockIdx.y * kBgSliceK;
+  const int m0 = blockIdx.z * ROWS;
+  // a ragged last slice: the steps past K load from an out-of-range VGPR offset (zeros for X in LDS; absmax 0 -> weights 0)
+  const int valid_steps = min(kBgSteps, ((int)p.k - k0) / kBgStepK);
+#define CONCH_KILL(s) ((s) < valid_steps ? 0 : (int)0x80000000)
+
+  const __amdgpu_buffer_rsrc_t rx =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (uint32_t)(((p.m - 1) * p.x_stride_m + p.k) * 2), 0x00020000);
+  constexpr int kPieces = ROWS / 8;
+#pragma unroll
+  for (int s = 0; s < kBgSteps; ++s)
+#pragma unroll
+    for (int q = 0; q < kPieces; ++q) {
+      if ((q & 3) != wave) continue;  // wave-uniform
+      const int row = 8 * q + (lane >> 3);
+      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+      const int voff = min(m0 + row, (int)p.m - 1) * (int)p.x_stride_m * 2 + chunk * 16;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t*)(lds + s * kUnit + q * 1024), 16, voff | CONCH_KILL(s), (k0 + s * kBgStepK) * 2, 0, 0);
+    }
+
+  // packed words and absmax of the whole slice -> registers
+  constexpr int kAbsBytes = ADT == CONCH_DT_FP32 ? 4 : 2;
+  const int64_t blocks = p.n * p.k / p.blocksize;
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (uint32_t)(p.n * p.k / 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.absmax, 0, (uint32_t)(blocks * kAbsBytes), 0x00020000);
+  const int bs_shift = __builtin_ctz((unsigned)p.blocksize);  // a power of two (check_common)
+  const int vw = n * (int)(p.k / 2) + 4 * g;                         // byte offset of the lane's k-group inside a half step
+  const int va = n * (int)(p.k >> bs_shift) * kAbsBytes;           // ... of the row's first block
+  uint32_t wq[kBgSteps][2];
+  float am[kBgSteps];
+#pragma unroll
+  for (int s = 0; s < kBgSteps; ++s) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      wq[s][h] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rw, vw | CONCH_KILL(s), (k0 + s * kBgStepK + 32 * h) / 2, 0);
+    const int blk = (k0 + s * kBgStepK) >> bs_shift;
+    if constexpr (ADT == CONCH_DT_FP32)
+      am[s] = __builtin_bit_cast(float, (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(ra, va | CONCH_KILL(s), blk * 4, 0));
+    else
+      am[s] = bits16_to_float<ADT>((uint16_t)__builtin_amdgcn_raw_buffer_load_b16(ra, va | CONCH_KILL(s), blk * 2, 0));
+  }
+#undef CONCH_KILL
+
+  f32x4 acc[ROWS / 16];
+#pragma unroll
+  for (int i = 0; i < ROWS / 16; ++i) acc[i] = f32x4{0, 0, 0, 0};
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();  // the X pieces of every wave and the table have landed
+
+  // eight codes of one word -> eight numbers of the activation dtype: output dword j = (k 2j, k 2j + 1) = (high, low nibble of byte j)
+  // (no pin_f32 here: a volatile asm between the lookups would make the scheduler finish one LDS round trip before it starts the
+  // next -- the table reads of a step must all be in flight together; -ffp-contract=off keeps multiply and convert apart)
+  auto lookup = [&](uint32_t w, f32x2 (&t)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t addr = j == 0 ? (w << 3) & 0x7f8u : (w >> (8 * j - 3)) & 0x7f8u;  // byte j x 8
+      t[j] = *(const f32x2*)((const char*)lut + addr);
+    }
+  };
+  auto scale8 = [&](const f32x2 (&t)[4], float a) {
+    i32x4 out;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v0 = t[j][0] * a, v1 = t[j][1] * a;
+      if constexpr (ADT != CONCH_DT_FP32) {  // the product lives in absmax's dtype (bnb_dequantize_kernel)
+        v0 = bits16_to_float<ADT>(float_to_bits16<ADT>(v0));
+        v1 = bits16_to_float<ADT>(float_to_bits16<ADT>(v1));
+      }
+      out[j] = (int)pack2_bits16<X_DT>(f32x2{v0, v1});
+    }
+    return out;
+  };
+
+  const int lane_off = (r >> 3) * 1024 + (r & 7) * 128 + ((g ^ ((r >> 1) & 7)) * 16);
+#pragma unroll
+  for (int s = 0; s < kBgSteps; ++s) {
+    f32x2 t_lo[4], t_hi[4];
+    lookup(wq[s][0], t_lo);
+    lookup(wq[s][1], t_hi);
+    const i32x4 w_lo = scale8(t_lo, am[s]);
+    const i32x4 w_hi = scale8(t_hi, am[s]);
+#pragma unroll
+    for (int i = 0; i < ROWS / 16; ++i) {
+      const Frag fx = read_frag(lds, s * kUnit + lane_off + i * 2048);
+      if constexpr (X_DT == CONCH_DT_FP16) {
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w_lo), __builtin_bit_cast(f16x8, fx.lo), acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w_hi), __builtin_bit_cast(f16x8, fx.hi), acc[i], 0, 0, 0);
+      } else {
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w_lo), __builtin_bit_cast(bf16x8, fx.lo), acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w_hi), __builtin_bit_cast(bf16x8, fx.hi), acc[i], 0, 0, 0);
+      }
+    }
+  }
+
+  // D rows = n (4g + e), D columns = m (lane % 16): four consecutive n of one row per lane
+  float* slab = slabs + (int64_t)blockIdx.y * p.m * p.n;
+#pragma unroll
+  for (int i = 0; i < ROWS / 16; ++i) {
+    const int m = m0 + i * 16 + r;
+    const int nn = nw + 4 * g;
+    if (m < p.m && nn + 4 <= p.n) *(f32x4*)(slab + (int64_t)m * p.n + nn) = acc[i];
+  }
+}
+
+template <int X_DT, int ADT, int QT>
+void launch_decode_rows(const BnbGemmArgs& p, int rows, dim3 grid, float* ws, hipStream_t stream) {
+  const dim3 block(kBgThreads);
+  if (rows == 16) hipLaunchKernelGGL((bnb_decode_gemm_kernel<X_DT, ADT, QT, 16>), grid, block, 0, stream, p, ws);
+  else if (rows == 32) hipLaunchKernelGGL((bnb_decode_gemm_kernel<X_DT, ADT, QT, 32>), grid, block, 0, stream, p, ws);
+  else hipLaunchKernelGGL((bnb_decode_gemm_kernel<X_DT, ADT, QT, 64>), grid, block, 0, stream, p, ws);
+}
+
+template <int X_DT, int ADT>
+void launch_decode_qt(const BnbGemmArgs& p, int qt, int rows, dim3 grid, float* ws, hipStream_t stream) {
+  if (qt == kQtNf4) launch_decode_rows<X_DT, ADT, kQtNf4>(p, rows, grid, ws, stream);
+  else launch_decode_rows<X_DT, ADT, kQtFp4>(p, rows, grid, ws, stream);
+}
+
+template <int X_DT>
+void launch_decode_adt(const BnbGemmArgs& p, int qt, int adt, int rows, dim3 grid, float* ws, hipStream_t stream) {
+  if (adt == CONCH_DT_FP32) launch_decode_qt<X_DT, CONCH_DT_FP32>(p, qt, rows, grid, ws, stream);
+  else if (adt == CONCH_DT_FP16) launch_decode_qt<X_DT, CONCH_DT_FP16>(p, qt, rows, grid, ws, stream);
+  else launch_decode_qt<X_DT, CONCH_DT_BF16>(p, qt, rows, grid, ws, stream);
+}
+
+// decode batches: up to two 64-row blocks, rows of four columns, whole blocks inside a row
+bool bnb_decode_supported(int64_t m, int64_t n, int64_t k, int blocksize) {
+  return m <= 128 && n % 4 == 0 && k % blocksize == 0 && n * k / 2 < ((int64_t)1 << 31);
+}
+
+int launch_bnb_decode_gemm(const BnbGemmArgs& p, int qt, int adt, int x_dtype, int out_dtype, hipStream_t stream) {
+  const int slices = (int)((p.k + kBgSliceK - 1) / kBgSliceK);
+  const int rows = p.m <= 16 ? 16 : p.m <= 32 ? 32 : 64;
+  void* ws = nullptr;
+  if (int rc = get_scratch(stream, kScratchMixedSplitK, (size_t)slices * p.m * p.n * 4, &ws)) return rc;
+  const dim3 grid((unsigned)((p.n + kBgN - 1) / kBgN), (unsigned)slices, (unsigned)((p.m + rows - 1) / rows));
+  if (x_dtype == CONCH_DT_FP16) launch_decode_adt<CONCH_DT_FP16>(p, qt, adt, rows, grid, (float*)ws, stream);
+  else launch_decode_adt<CONCH_DT_BF16>(p, qt, adt, rows, grid, (float*)ws, stream);
+  if (int rc = check_launch("bnb_decode_gemm")) return rc;
+  return launch_f32_slab_reduce(p.c, (const float*)ws, slices, p.m, p.n, p.c_stride_m, out_dtype, stream);
+}
+
 bool float_dt(int dt) { return dt == CONCH_DT_FP32 || dt == CONCH_DT_FP16 || dt == CONCH_DT_BF16; }
 
 int check_common(int64_t n, int blocksize, int qt, int adt, const void* code, const char* what) {
@@ -356,7 +541,8 @@ extern "C" int conch_bnb_dequantize_blockwise(void* out, const uint8_t* xq, cons
 
 // y = x @ dequantise(W)^T for a bitsandbytes-style 4-bit weight W [N][K] (flattened, blocks of `blocksize` along the flat index,
 // two codes per byte): W is dequantised into library scratch in x's dtype -- its rows ARE the K-contiguous B^T the tile kernel
-// wants -- and multiplied on the 16-bit MFMA tile kernel of gemm_mfma.hip (fp32 accumulation).
+// wants -- and multiplied on the 16-bit MFMA tile kernel of gemm_mfma.hip (fp32 accumulation).  Decode batches (M <= 128) skip
+// the materialised weight: bnb_decode_gemm_kernel.
 extern "C" int conch_bnb_gemm_4bit(void* c, const void* x, const uint8_t* w_packed, const void* absmax, int64_t m, int64_t n, int64_t k,
                                    int64_t x_stride_m, int64_t c_stride_m, int blocksize, int quant_type, int absmax_dtype, int x_dtype,
                                    int out_dtype, void* stream) {
@@ -374,6 +560,17 @@ extern "C" int conch_bnb_gemm_4bit(void* c, const void* x, const uint8_t* w_pack
     return CONCH_ERR_UNSUPPORTED;
   }
   hipStream_t s = (hipStream_t)stream;
+  // decode batches: the weights go from the packed tensor straight into MFMA operand registers (CONCH_TUNE_GEMM_VARIANT = 2
+  // forces the dequantise-first path, 4 the decode kernel)
+  const int variant = tuning(CONCH_TUNE_GEMM_VARIANT);
+  if (variant != 2 && bnb_decode_supported(m, n, k, blocksize) && (((uintptr_t)c & 1) == 0) && c_stride_m >= n) {
+    const BnbGemmArgs d{c, x, w_packed, absmax, m, n, k, x_stride_m, c_stride_m, blocksize};
+    return launch_bnb_decode_gemm(d, quant_type, absmax_dtype, x_dtype, out_dtype, s);
+  }
+  if (variant == 4) {
+    set_error("bnb_gemm_4bit: decode kernel forced but its contract is not met (M <= 128, N %% 4 == 0, K %% blocksize == 0)");
+    return CONCH_ERR_UNSUPPORTED;
+  }
   void* wt = nullptr;
   if (int rc = get_scratch(s, kScratchRepack, (size_t)n * k * 2, &wt)) return rc;
   if (int rc = dequantize_any(wt, w_packed, absmax, nullptr, n * k, blocksize, quant_type, absmax_dtype, x_dtype, k, k, s)) return rc;

@@ -83,5 +83,6 @@ int launch_mixed_gemm_mfma(const MixedGemmArgs& p, hipStream_t stream);
 // gemm_mixed_skinny.hip -- decode batches (M <= 64, K % 1024 == 0): weights straight to MFMA registers, split-K (variant 4)
 bool mixed_gemm_skinny_supported(const MixedGemmArgs& p);
 int launch_mixed_gemm_skinny(const MixedGemmArgs& p, hipStream_t stream);
+int launch_f32_slab_reduce(void* c, const float* slabs, int slices, int64_t m, int64_t n, int64_t c_stride_m, int out_dtype, hipStream_t stream);
 
 }  // namespace conch

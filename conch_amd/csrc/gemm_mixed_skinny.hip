@@ -205,6 +205,21 @@ void launch_zp_mode(const MixedGemmArgs& p, int rows, dim3 grid, float* ws, hipS
 
 }  // namespace
 
+// out[m][n] = cast( sum over slices, in slice order ) of fp32 slabs [slice][M][N] (also the reduce of bnb.hip's 4-bit decode GEMM)
+int launch_f32_slab_reduce(void* c, const float* slabs, int slices, int64_t m, int64_t n, int64_t c_stride_m, int out_dtype, hipStream_t stream) {
+  MixedGemmArgs p{};
+  p.c = c;
+  p.m = m;
+  p.n = n;
+  p.c_stride_m = c_stride_m;
+  const int64_t quads = m * (n / 4);
+  if (out_dtype == CONCH_DT_FP16)
+    hipLaunchKernelGGL((mixed_skinny_reduce_kernel<CONCH_DT_FP16>), dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, p, slabs, slices);
+  else
+    hipLaunchKernelGGL((mixed_skinny_reduce_kernel<CONCH_DT_BF16>), dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, p, slabs, slices);
+  return check_launch("f32_slab_reduce");
+}
+
 bool mixed_gemm_skinny_supported(const MixedGemmArgs& p) {
   if (!mixed_gemm_mfma_supported(p)) return false;  // dtypes, bits in {4, 8}, alignment, 32-bit buffer offsets
   if (p.fuse_silu) return false;

@@ -1,5 +1,6 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out
-timeout 1200 python tools/dispatch_cold_sweep.py "$@" 2>&1 | grep -v amdgpu.ids > gpurun_out/dispatch_cold_sweep.txt
-grep -c "pick costs" gpurun_out/dispatch_cold_sweep.txt; grep "pick costs" gpurun_out/dispatch_cold_sweep.txt | cut -c1-330 | head -30
+timeout 1800 python -m pytest tests/test_gpu_bnb.py -x -q -m gpu 2>&1 | tail -5 > gpurun_out/bnb_tests.txt
+cat gpurun_out/bnb_tests.txt
+timeout 600 python tools/time_variants.py 2>&1 | grep -i "bnb" | tee gpurun_out/bnb_times.txt

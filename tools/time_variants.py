@@ -99,7 +99,7 @@ def bnb():
         for m in (16, 1024):
             x = torch.randn(m, 4096, device="cuda", dtype=torch.float16)
             t = sustained(torch_timer(lambda: matmul_4bit(x, q, st)), 0.3)
-            print(f"bnb matmul_4bit {qt} M={m} K=4096 N=11008 (dequantise + 16-bit MFMA GEMM): {t * 1e3:7.1f} us  {2.0 * m * 4096 * 11008 / t / 1e9:7.0f} TFLOP/s", flush=True)
+            print(f"bnb matmul_4bit {qt} M={m} K=4096 N=11008 ({'decode kernel: codes -> MFMA operands' if m <= 128 else 'dequantise + 16-bit MFMA GEMM'}): {t * 1e3:7.1f} us  {2.0 * m * 4096 * 11008 / t / 1e9:7.0f} TFLOP/s", flush=True)
 
 
 if __name__ == "__main__":
