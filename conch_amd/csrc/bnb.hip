@@ -400,8 +400,8 @@ __global__ __launch_bounds__(kBgThreads) void bnb_decode_gemm_kernel(BnbGemmArgs
   __syncthreads();  // the X pieces of every wave and the table have landed
 
   // eight codes of one word -> eight numbers of the activation dtype: output dword j = (k 2j, k 2j + 1) = (high, low nibble of byte j)
-  // (no pin_f32 here: a volatile asm between the lookups would make the scheduler finish one LDS round trip before it starts the
-  // next -- the table reads of a step must all be in flight together; -ffp-contract=off keeps multiply and convert apart)
+  // the table reads of a step are all in flight together (lookup), then the arithmetic (scale8); pin_f32 keeps the fp32 product
+  // and the conversion two roundings
   auto lookup = [&](uint32_t w, f32x2 (&t)[4]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(kBgThreads) void bnb_decode_gemm_kernel(BnbGemmArgs
     i32x4 out;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float v0 = t[j][0] * a, v1 = t[j][1] * a;
+      float v0 = pin_f32(t[j][0] * a), v1 = pin_f32(t[j][1] * a);
       if constexpr (ADT != CONCH_DT_FP32) {  // the product lives in absmax's dtype (bnb_dequantize_kernel)
         v0 = bits16_to_float<ADT>(float_to_bits16<ADT>(v0));
         v1 = bits16_to_float<ADT>(float_to_bits16<ADT>(v1));

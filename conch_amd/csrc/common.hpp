@@ -127,15 +127,22 @@ __device__ __forceinline__ uint16_t float_to_bf16_bits(float f) {
 // Make an fp32 value opaque to the optimiser.  hipcc otherwise folds `(_Float16)(a * b)` into
 // v_fma_mixlo_f16, which rounds the exact product ONCE to fp16; the reference rounds to fp32 first
 // and then to fp16 (torch), and the two differ in rare double-rounding cases.
+// NOT volatile: the value must be opaque, the statement need not be ordered -- a volatile asm is a barrier for every load and
+// store around it (bnb.hip's table lookups completed one LDS round trip at a time behind one).
+#ifdef CONCH_EXP_VOLATILE_PIN  // A/B variant (tools/ab_lib.py): the ordered form the tree had before
+#define CONCH_PIN_ASM asm volatile
+#else
+#define CONCH_PIN_ASM asm
+#endif
 __device__ __forceinline__ float pin_f32(float v) {
-  asm volatile("" : "+v"(v));
+  CONCH_PIN_ASM("" : "+v"(v));
   return v;
 }
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f32x2 pin_f32x2(f32x2 v) {
-  asm volatile("" : "+v"(v));
+  CONCH_PIN_ASM("" : "+v"(v));
   return v;
 }
 

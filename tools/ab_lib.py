@@ -14,7 +14,7 @@ from conch_amd.ops.quantization.gemm import create_mixed_precision_metadata  # n
 from conch_amd.ops.quantization.prepack import _prepacked_args, prepack_mixed_weights  # noqa: E402
 
 VARIANT = sys.argv[1]
-ROUNDS = int(sys.argv[2]) if len(sys.argv) > 2 else 7
+ROUNDS = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 7
 BASE = _C.load()
 EXP = _C.load_library(Path(_C.LIB_PATH).with_name(f"libconch_amd_{VARIANT}.so"))
 
@@ -60,7 +60,47 @@ def case(m, k, n, dtype, bits, zp, nt=0):
           f"{med[VARIANT] / med['base']:.3f}, +pre {med[VARIANT + '+pre'] / med['base+pre']:.3f}  bits {'equal' if same else 'DIFFER'}", flush=True)
 
 
+def scaled(m, k, n, dtype, silu=False):
+    from conch_amd.ops.quantization.gemm import create_scaled_metadata
+
+    torch.manual_seed(0)
+    if dtype == torch.int8:
+        a = torch.randint(-32, 32, (m, k), dtype=torch.int8, device="cuda")
+        bt = torch.randint(-32, 32, (n, k), dtype=torch.int8, device="cuda")
+    else:
+        a = (0.25 * torch.rand((m, k), device="cuda")).to(dtype)
+        bt = (0.25 * torch.rand((n, k), device="cuda")).to(dtype)
+    sa, sb = 0.25 * torch.rand((m, 1), device="cuda"), 0.25 * torch.rand((n, 1), device="cuda")
+    bias = torch.rand((n,), device="cuda").to(torch.bfloat16)
+    outs = [torch.empty((m, n), dtype=torch.bfloat16, device="cuda") for _ in range(2)]
+    md = create_scaled_metadata(a, bt.T, sa, sb, torch.bfloat16)
+    ms = ctypes.c_float()
+
+    def run(lib, out, iters):
+        _C.check(kg._scaled_gemm_call("conch_time_scaled_gemm", out, a, bt.T, sa, sb, md, bias, (iters, ctypes.byref(ms)), lib=lib), "time")
+        return ms.value
+
+    iters = int(min(3000, max(30, 30.0 / max(run(BASE, outs[0], 20), 1e-4))))
+    for _ in range(3):
+        run(BASE, outs[0], iters), run(EXP, outs[1], iters)
+    same = torch.equal(outs[0], outs[1])
+    res = {"base": [], VARIANT: []}
+    for _ in range(ROUNDS):
+        res["base"].append(run(BASE, outs[0], iters))
+        res[VARIANT].append(run(EXP, outs[1], iters))
+    med = {k_: statistics.median(v) for k_, v in res.items()}
+    print(f"scaled {str(dtype)[6:]:13s} {m}x{k}x{n} (+bias): base {med['base'] * 1e3:7.1f} us  {VARIANT} {med[VARIANT] * 1e3:7.1f} us   {VARIANT}/base = "
+          f"{med[VARIANT] / med['base']:.3f}  bits {'equal' if same else 'DIFFER'}", flush=True)
+
+
 if __name__ == "__main__":
+    if "--scaled" in sys.argv:
+        scaled(4096, 4096, 11008, torch.float8_e4m3fn)
+        scaled(4096, 4096, 11008, torch.int8)
+        scaled(8192, 8192, 8192, torch.float8_e4m3fn)
+        scaled(128, 4096, 4096, torch.int8)
+        scaled(512, 4096, 4096, torch.float8_e4m3fn)
+        scaled(16, 4096, 11008, torch.int8)
     case(1024, 4096, 11008, torch.float16, 4, False)
     case(4096, 8192, 4096, torch.float16, 4, False)
     case(1024, 4096, 11008, torch.bfloat16, 4, False)

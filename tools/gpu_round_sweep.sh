@@ -1,6 +1,4 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out
-timeout 1800 python -m pytest tests/test_gpu_bnb.py -x -q -m gpu 2>&1 | tail -5 > gpurun_out/bnb_tests.txt
-cat gpurun_out/bnb_tests.txt
-timeout 600 python tools/time_variants.py 2>&1 | grep -i "bnb" | tee gpurun_out/bnb_times.txt
+timeout 900 python tools/ab_lib.py vpin 5 --scaled 2>&1 | grep -v amdgpu.ids | tee gpurun_out/ab_vpin.txt

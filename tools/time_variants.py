@@ -57,8 +57,12 @@ def mixed(m, k, n, dtype, bits, zp):
 
 def scaled(m, k, n, dtype):
     torch.manual_seed(0)
-    a = (0.25 * torch.rand((m, k), device="cuda")).to(dtype)
-    bt = (0.25 * torch.rand((n, k), device="cuda")).to(dtype)
+    if dtype == torch.int8:  # the reference tests' distribution (tests/scaled_gemm_test.py); NOT (0.25 * rand).to(int8), which is all zeros
+        a = torch.randint(-32, 32, (m, k), dtype=torch.int8, device="cuda")
+        bt = torch.randint(-32, 32, (n, k), dtype=torch.int8, device="cuda")
+    else:
+        a = (0.25 * torch.rand((m, k), device="cuda")).to(dtype)
+        bt = (0.25 * torch.rand((n, k), device="cuda")).to(dtype)
     sa, sb = 0.25 * torch.rand((m, 1), device="cuda"), 0.25 * torch.rand((n, 1), device="cuda")
     out = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
     md = create_scaled_metadata(a, bt.T, sa, sb, torch.bfloat16)
@@ -68,7 +72,7 @@ def scaled(m, k, n, dtype):
         _C.check(kg._scaled_gemm_call("conch_time_scaled_gemm", out, a, bt.T, sa, sb, md, None, (iters, ctypes.byref(ms))), "time")
         return ms.value
     t = sustained(run)
-    peak = 5000 if dtype == torch.float8_e4m3fn else 2500
+    peak = 2500 if dtype == torch.float8_e4m3fnuz else 5000  # fp8 / int8 dense MFMA peak; the fnuz path multiplies in bf16
     print(f"scaled {m}x{k}x{n} {str(dtype)[6:]:16s}: {t * 1e3:8.1f} us  {2.0 * m * n * k / t / 1e9:7.0f} TFLOP/s ({2.0 * m * n * k / t / 1e9 / peak:.3f} of "
           f"{peak / 1000} PF){'  [expansion to bf16 + bf16 MFMA: two extra passes + half-rate MFMA]' if dtype == torch.float8_e4m3fnuz else ''}", flush=True)
 
