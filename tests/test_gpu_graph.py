@@ -1,0 +1,96 @@
+"""HIP-graph capture of a decode step (include/conch_amd.h, "Library scratch"): after conch_reserve_scratch on the capture
+stream every entry point is allocation-free and synchronisation-free, so a serving stack can capture its decode step once and
+replay it; without the reservation a call that must grow a scratch slot inside a capture fails cleanly instead of breaking it."""
+
+from __future__ import annotations
+
+import pytest
+import torch
+
+from conch_amd import _C
+from conch_amd.ops.quantization.gemm import mixed_precision_gemm, scaled_gemm
+from conch_amd.ops.quantization.int8 import scaled_int8_quant
+from conch_amd.third_party.vllm.quant_utils import pack_rows
+from conch_amd.third_party.vllm.utils import seed_everything
+
+pytestmark = pytest.mark.gpu
+
+
+def _int4_weights(k, n, group=128):
+    q = torch.randint(0, 16, (k, n), dtype=torch.int32)
+    packed = pack_rows(q, 4, k, n)
+    scales = (0.01 + 0.05 * torch.rand((k // group, n))).to(torch.float16)
+    return packed.cuda(), scales.cuda()
+
+
+def _decode_step(x, scale_x, sa, w1t, sb1, w2, s2):
+    """quantise the activations, an int8 projection at decode batch size (split-K kernel: library scratch), an int4 GEMV-like
+    projection (decode kernel: library scratch)."""
+    q, _ = scaled_int8_quant(x, scale_x)
+    y1 = scaled_gemm(q, w1t.T, sa, sb1, torch.bfloat16)
+    y2 = mixed_precision_gemm(x, w2, s2, None, 4, 8, 128)
+    return q, y1, y2
+
+
+@pytest.mark.parametrize("m", [8, 128])
+def test_decode_step_replays_from_a_hip_graph(m):
+    seed_everything(11)
+    k, n = 4096, 4096
+    dev = torch.device("cuda")
+    x = (torch.rand((m, k), device=dev) - 0.5).to(torch.float16)
+    scale_x = torch.tensor([0.004], dtype=torch.float32, device=dev)
+    sa = torch.full((m, 1), 0.004, dtype=torch.float32, device=dev)
+    w1t = torch.randint(-32, 32, (n, k), dtype=torch.int8, device=dev)
+    sb1 = 0.25 * torch.rand((n, 1), device=dev)
+    w2, s2 = _int4_weights(k, n)
+    stream = torch.cuda.Stream()
+    lib = _C.load()
+    need = max(lib.conch_scaled_gemm_workspace_bytes(m, n, k), lib.conch_mixed_precision_gemm_workspace_bytes(m, n, k))
+    with torch.cuda.stream(stream):
+        _C.reserve_scratch(need)  # keyed by (device, stream): the capture stream
+        _decode_step(x, scale_x, sa, w1t, sb1, w2, s2)  # eager warm-up on that stream
+    stream.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=stream):
+        outs = _decode_step(x, scale_x, sa, w1t, sb1, w2, s2)
+    for trial in range(3):
+        x.copy_((torch.rand((m, k), device=dev) - 0.5).to(torch.float16))
+        graph.replay()
+        torch.cuda.synchronize()
+        got = [t.clone() for t in outs]
+        want = _decode_step(x, scale_x, sa, w1t, sb1, w2, s2)
+        torch.cuda.synchronize()
+        for g, w in zip(got, want):
+            assert torch.equal(g.view(torch.uint8), w.view(torch.uint8)), f"trial {trial}: replayed step differs from the eager one"
+
+
+def test_scratch_growth_inside_a_capture_is_refused_not_fatal():
+    """A fresh stream has no scratch: the split-K path must fail with the documented error (-> ValueError) and leave the capture
+    usable; after the reservation the same call captures."""
+    seed_everything(12)
+    m, k, n = 16, 2048, 1024
+    dev = torch.device("cuda")
+    a = torch.randint(-32, 32, (m, k), dtype=torch.int8, device=dev)
+    bt = torch.randint(-32, 32, (n, k), dtype=torch.int8, device=dev)
+    sa, sb = 0.25 * torch.rand((m, 1), device=dev), 0.25 * torch.rand((n, 1), device=dev)
+    want = scaled_gemm(a, bt.T, sa, sb, torch.bfloat16)
+    stream = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(stream):
+        graph.capture_begin()
+        try:
+            with pytest.raises(ValueError, match="reserve"):
+                scaled_gemm(a, bt.T, sa, sb, torch.bfloat16)
+        finally:
+            graph.capture_end()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(stream):
+        _C.reserve_scratch(_C.load().conch_scaled_gemm_workspace_bytes(m, n, k))
+    stream.synchronize()
+    graph2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph2, stream=stream):
+        out = scaled_gemm(a, bt.T, sa, sb, torch.bfloat16)
+    graph2.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)

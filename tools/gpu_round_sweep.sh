@@ -1,4 +1,5 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out
-timeout 900 python tools/ab_lib.py vpin 5 --scaled 2>&1 | grep -v amdgpu.ids | tee gpurun_out/ab_vpin.txt
+timeout 600 python -m pytest tests/test_gpu_graph.py -x -q -m gpu 2>&1 | tail -25 > gpurun_out/graph_tests.txt
+cat gpurun_out/graph_tests.txt
