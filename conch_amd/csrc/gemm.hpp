@@ -45,6 +45,10 @@ struct MixedGemmArgs {
   int fuse_silu = 0;
   // != 0: w_q is the image conch_prepack_mixed_weights made for tiles of 64 x `prepacked` columns (2, 3 or 4)
   int prepacked = 0;
+  // split-K form of the LDS-tiled kernel (few tiles, M > 256): blockIdx.y = K slice of `split_steps` 64-element steps (a
+  // multiple of group_size / 64), fp32 partial sums to slabs [slice][M][N] instead of the cast-and-store epilogue
+  int split_steps = 0;
+  float* slabs = nullptr;
 };
 
 // gemm_generic.hip

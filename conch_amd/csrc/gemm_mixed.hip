@@ -29,6 +29,8 @@
 // Tried and dropped (profiles/README.md): a ping-pong K loop with the dequantisation in the load segments, a
 // three-stage X ring (LDS-DMA two steps ahead, 160 KiB of LDS), a sched_group_barrier pattern over the whole
 // step instead of the hand-made slots.
+#include <algorithm>
+
 #include "common.hpp"
 #include "gemm.hpp"
 #include "mfma_tile.hpp"
@@ -90,6 +92,29 @@ __device__ __forceinline__ void mixed_epilogue(const MixedTile& w, const MixedGe
         for (int e = 0; e < 8; ++e)
           if (e < width && n0 + e < p.n) dst[e] = (uint16_t)((uint32_t)pk[e >> 1] >> (16 * (e & 1)));
       }
+    }
+  }
+}
+
+// Split-K form: the raw fp32 accumulators to this slice's slab [M][N] (N % 4 == 0: 16-byte stores), same lane -> (m, n) map as
+// mixed_epilogue; the fp32-slab reduce of gemm_mixed_skinny.hip adds the slices in slice order and casts.
+template <int NT>
+__device__ __forceinline__ void mixed_epilogue_slab(const MixedTile& w, const MixedGemmArgs& p, int bm0, int bn0, int wr, int wc, int lane,
+                                                    float* __restrict__ slab) {
+  const int g = lane >> 4, jm = lane & 15;
+#pragma unroll
+  for (int nh = 0; nh < 2; ++nh) {
+    if (nh == 1 && NT == 2) continue;
+    const bool pair_h = nh == 0 || NT == 4;
+    const int width = pair_h ? 8 : 4;
+    const int n0 = bn0 + wc * 16 * NT + nh * 32 + width * g;
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+      const int m = bm0 + wr * 128 + mt * 16 + jm;
+      if (m >= p.m) continue;
+      float* dst = slab + (int64_t)m * p.n + n0;
+      if (n0 + 4 <= p.n) *(f32x4*)dst = w.acc[mt][nh * 2];
+      if (pair_h && n0 + 8 <= p.n) *(f32x4*)(dst + 4) = w.acc[mt][nh * 2 + 1];
     }
   }
 }
@@ -392,7 +417,7 @@ __device__ __forceinline__ void mixed_step(MixedTile& w, WeightRegs<BITS, NT>& r
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int q = 0; q < 2 * N1; ++q) {
-        const int tt = kHOrder ? q % N1 : q / 2, h = kHOrder ? q / N1 : q % 2;
+        const int tt = kHOrder ? q % (N1 > 0 ? N1 : 1) : q / 2, h = kHOrder ? q / (N1 > 0 ? N1 : 1) : q % 2;
         mma(w.acc[i][2 + tt], w.fn[1][tt], w.fm[i], h);
         if (q == 2 * N1 - 1) if constexpr (DIAG != 2) w.fm[i] = frag(ulo, uhi, kHalfM + i * 2048);
         tail(slot++);
@@ -402,7 +427,7 @@ __device__ __forceinline__ void mixed_step(MixedTile& w, WeightRegs<BITS, NT>& r
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int q = 0; q < 2 * N1; ++q) {
-        const int tt = kHOrder ? q % N1 : q / 2, h = kHOrder ? q / N1 : q % 2;
+        const int tt = kHOrder ? q % (N1 > 0 ? N1 : 1) : q / 2, h = kHOrder ? q / (N1 > 0 ? N1 : 1) : q % 2;
         mma(w.acc[4 + i][2 + tt], w.fn[1][tt], w.fm[i], h);
         tail(slot++);
       }
@@ -465,6 +490,10 @@ __global__ __launch_bounds__(kThreads, 2) void mixed_gemm_kernel(MixedGemmArgs p
   const TileCoord tc = map_tile(blockIdx.x, tiles_m, tiles_n);
   const int bm0 = tc.tm * kRows, bn0 = tc.tn * kTileW;
 
+  // split-K form: this workgroup's K range starts at step0 (0 in the plain form); the X buffer is rebased there, the weight
+  // cursor starts there, the loop below counts its own steps from 0
+  const int total_steps = (int)(p.k / kStepK);
+  const int step0 = p.split_steps ? (int)blockIdx.y * p.split_steps : 0;
   // activations: LDS-DMA units (byte strides: 2 bytes per element)
   if constexpr (TALL) {
 #pragma unroll
@@ -476,7 +505,8 @@ __global__ __launch_bounds__(kThreads, 2) void mixed_gemm_kernel(MixedGemmArgs p
   } else {
     c.so = make_stage_offsets(c.wave, lane, bm0, bn0, (int)p.m - 1, 0, (int)p.x_stride_m * 2, 0);
   }
-  c.src.a = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (uint32_t)(((p.m - 1) * p.x_stride_m + p.k) * 2), 0x00020000);
+  c.src.a = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.x + (int64_t)step0 * kStepBytes), 0,
+                                              (uint32_t)(((p.m - 1) * p.x_stride_m + p.k) * 2 - step0 * kStepBytes), 0x00020000);
   c.src.b = c.src.a;
 
   // weight work items of this thread: unit row rho of V1, chunks cp and cp + 4; V2: see the file header.
@@ -522,7 +552,9 @@ __global__ __launch_bounds__(kThreads, 2) void mixed_gemm_kernel(MixedGemmArgs p
   c.ws.s_group = (int)p.ws_stride_g * 2;
   c.ws.z_group = (int)p.wzp_stride_g * 4;
   c.ws.steps_per_group = p.group_size / kStepK;
-  WeightCursor cur = {PRE ? tc.tn * (int)(p.k / kStepK) * c.ws.q_step : cp * kWpc * c.ws.q_row, 0, 0, c.ws.steps_per_group};
+  const int group0 = step0 / c.ws.steps_per_group;  // split_steps is a multiple of steps_per_group
+  WeightCursor cur = {(PRE ? tc.tn * total_steps * c.ws.q_step : cp * kWpc * c.ws.q_row) + step0 * c.ws.q_step, group0 * c.ws.s_group,
+                      group0 * c.ws.z_group, c.ws.steps_per_group};
   c.off_base = p.weight_bias + (ZP == CONCH_ZP_SCALAR ? p.w_zp[0] : 0);
 
   // fragment read offsets
@@ -543,7 +575,7 @@ __global__ __launch_bounds__(kThreads, 2) void mixed_gemm_kernel(MixedGemmArgs p
 #pragma unroll
     for (int j = 0; j < 4; ++j) w.acc[i][j] = f32x4{0, 0, 0, 0};
 
-  const int steps = (int)(p.k / kStepK);
+  const int steps = p.split_steps ? min(p.split_steps, total_steps - step0) : total_steps;
   WeightRegs<BITS, NT> regs;
   // prologue: X and weights of step 0 (converted at once), weights of step 1 to registers
   if constexpr (TALL) {
@@ -595,8 +627,16 @@ __global__ __launch_bounds__(kThreads, 2) void mixed_gemm_kernel(MixedGemmArgs p
   }
 #endif
 
-  if constexpr (SILU) mixed_epilogue_silu<OUT_DT>(w, p, bm0, bn0, wr, wc, lane);
-  else mixed_epilogue<X_DT, OUT_DT, TALL ? 4 : NT>(w, p, bm0, bn0, wr, wc, lane);
+  if constexpr (SILU) {
+    mixed_epilogue_silu<OUT_DT>(w, p, bm0, bn0, wr, wc, lane);
+  } else {
+    if (p.slabs) mixed_epilogue_slab<TALL ? 4 : NT>(w, p, bm0, bn0, wr, wc, lane, p.slabs + (int64_t)blockIdx.y * p.m * p.n);
+    else mixed_epilogue<X_DT, OUT_DT, TALL ? 4 : NT>(w, p, bm0, bn0, wr, wc, lane);
+  }
+}
+
+inline int split_slices(const MixedGemmArgs& p) {
+  return p.split_steps ? (int)((p.k / kStepK + p.split_steps - 1) / p.split_steps) : 1;
 }
 
 template <int X_DT, int OUT_DT, int BITS, int NT>
@@ -620,7 +660,7 @@ int launch_zp(const MixedGemmArgs& p, hipStream_t stream) {
     }
   }
   const int tiles_n = (int)((p.n + 64 * NT - 1) / (64 * NT));
-  const dim3 grid((unsigned)(tiles_m * tiles_n));
+  const dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)split_slices(p));
   if (p.prepacked) {  // weights in the image of conch_prepack_mixed_weights for THIS tile width; instantiated for OUT_DT == X_DT
     if constexpr (X_DT == OUT_DT) {
       switch (p.zp_mode) {
@@ -685,7 +725,7 @@ int launch_zp(const MixedGemmArgs& p, hipStream_t stream) {
 template <int X_DT, int OUT_DT, int BITS>
 int launch_tall(const MixedGemmArgs& p, hipStream_t stream) {
   const int tiles_m = (int)((p.m + kTallRows - 1) / kTallRows), tiles_n = (int)((p.n + 127) / 128);
-  const dim3 grid((unsigned)(tiles_m * tiles_n));
+  const dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)split_slices(p));
 #define CONCH_TALL(ZP, PRE) hipLaunchKernelGGL((mixed_gemm_kernel<X_DT, OUT_DT, BITS, ZP, 2, false, PRE, true>), grid, dim3(kThreads), 0, stream, p)
   if (p.prepacked) {
     if constexpr (X_DT == OUT_DT) {
@@ -872,19 +912,64 @@ bool mixed_gemm_mfma_supported(const MixedGemmArgs& p) {
   return true;
 }
 
-int launch_mixed_gemm_mfma(const MixedGemmArgs& p, hipStream_t stream) {
+// Split-K for problems whose tiles leave most of the chip idle (M of a few hundred rows x N of a few thousand columns: 512 x 4096 x
+// 4096 is 64 tiles): S slices of the K range per tile, fp32 partial sums to slabs, the fp32-slab reduce.  Worth it while the tile
+// kernel's time (~ steps per workgroup) drops by more than the slabs cost (S x M x N x 4 bytes written and read again).
+int pick_split(const MixedGemmArgs& p, int nt, int num_cus) {
+  if (p.fuse_silu || p.n % 4 || p.m <= 256) return 1;
+  const int rows = nt == kMixedTall ? kTallRows : kTileM, cols = nt == kMixedTall ? 128 : 64 * nt;
+  const int64_t tiles = ((p.m + rows - 1) / rows) * ((p.n + cols - 1) / cols);
+  const int steps = (int)(p.k / kStepK), spg = p.group_size / kStepK;
+  int best = 1;
+  double best_us = 1e30;
+  for (int s = 1; s <= 8; s *= 2) {
+    if (s > 1 && (tiles * s > num_cus || steps / s < 16)) break;
+    const int per = ((steps + s - 1) / s + spg - 1) / spg * spg;  // steps per slice, whole groups
+    // ~0.97 us per step on a sparsely filled chip (profiles/r02/dispatch_cold_sweep_after.txt: one row of tiles, 15.5 us per 1024 of
+    // K) + the slabs: written once, read once, ~4 TB/s, plus the reduce launch
+    const double us = 0.97 * per + (s > 1 ? 3.0 + 2.0 * (double)s * (double)p.m * (double)p.n * 4.0 / 4.0e6 : 0.0);
+    if (us < best_us - 1e-9) {
+      best_us = us;
+      best = s;
+    }
+  }
+  return best;
+}
+
+int launch_mixed_gemm_mfma(const MixedGemmArgs& p_in, hipStream_t stream) {
+  MixedGemmArgs p = p_in;
   const int num_cus = device_cu_count();
   const int forced = tuning(1);  // CONCH_TUNE_MIXED_TILE_NT: 0 = auto, 2..4 = force 64 NT columns, 5 = force the 512 x 128 tile
   int nt = p.fuse_silu ? 4 : (forced >= 2 && forced <= kMixedTall) ? forced : pick_nt(p, num_cus);
   if (p.zp_mode == CONCH_ZP_TENSOR && nt == 4 && !p.fuse_silu) nt = 3;  // a forced 4
   // a pre-packed image was laid out for one tile width; the 128-column image serves both the 256 x 128 and the 512 x 128 tile
   if (p.prepacked) nt = (p.prepacked == 2 && nt == kMixedTall) ? kMixedTall : p.prepacked;
-  if (p.x_dtype == CONCH_DT_FP16) {
-    return p.out_dtype == CONCH_DT_FP16 ? launch_bits<CONCH_DT_FP16, CONCH_DT_FP16>(p, nt, stream)
-                                        : launch_bits<CONCH_DT_FP16, CONCH_DT_BF16>(p, nt, stream);
+  // CONCH_TUNE_MIXED_SPLITK: 0 = auto, 1 = never, 2 / 4 / 8 = force that many K slices (where the shape allows)
+  const int forced_split = tuning(CONCH_TUNE_MIXED_SPLITK);
+  int split = forced_split == 0 ? pick_split(p, nt, num_cus) : forced_split;
+  const int steps = (int)(p.k / kStepK), spg = p.group_size / kStepK;
+  if (p.fuse_silu || p.n % 4 || steps / std::max(split, 1) < 2) split = 1;
+  if (split > 1) {
+    p.split_steps = ((steps + split - 1) / split + spg - 1) / spg * spg;
+    const int slices = split_slices(p);
+    void* ws = nullptr;
+    if (int rc = get_scratch(stream, kScratchMixedSplitK, (size_t)slices * p.m * p.n * 4, &ws)) return rc;
+    p.slabs = (float*)ws;
+    if (slices == 1) {  // the rounding to whole groups left one slice: the plain form
+      p.split_steps = 0;
+      p.slabs = nullptr;
+    }
   }
-  return p.out_dtype == CONCH_DT_BF16 ? launch_bits<CONCH_DT_BF16, CONCH_DT_BF16>(p, nt, stream)
+  int rc;
+  if (p.x_dtype == CONCH_DT_FP16) {
+    rc = p.out_dtype == CONCH_DT_FP16 ? launch_bits<CONCH_DT_FP16, CONCH_DT_FP16>(p, nt, stream)
+                                      : launch_bits<CONCH_DT_FP16, CONCH_DT_BF16>(p, nt, stream);
+  } else {
+    rc = p.out_dtype == CONCH_DT_BF16 ? launch_bits<CONCH_DT_BF16, CONCH_DT_BF16>(p, nt, stream)
                                       : launch_bits<CONCH_DT_BF16, CONCH_DT_FP16>(p, nt, stream);
+  }
+  if (rc || !p.slabs) return rc;
+  return launch_f32_slab_reduce(p.c, p.slabs, split_slices(p), p.m, p.n, p.c_stride_m, p.out_dtype, stream);
 }
 
 }  // namespace conch

@@ -135,6 +135,9 @@ typedef enum conch_tuning_key {
   ,
   CONCH_TUNE_MID_STAGES = 8 /* 128x128-tile scaled GEMM: 0 = auto (the 4-stage ring, one workgroup per CU, when there is at
                                most one tile per CU; else the 2-stage loop, two workgroups per CU), 2 / 4 = force */
+  ,
+  CONCH_TUNE_MIXED_SPLITK = 9 /* LDS-tiled mixed_precision_gemm: K slices per tile (fp32 slabs + reduce kernel) when the tiles
+                                 leave most of the chip idle: 0 = auto, 1 = never, 2 / 4 / 8 = force */
 } conch_tuning_key_t;
 
 int conch_abi_version(void);

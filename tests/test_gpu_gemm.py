@@ -164,6 +164,7 @@ def _reset_tuning():
     _C.set_tuning(_C.TUNE_PERSISTENT, 0)
     _C.set_tuning(_C.TUNE_EPILOGUE, 0)
     _C.set_tuning(_C.TUNE_MID_STAGES, 0)
+    _C.set_tuning(_C.TUNE_MIXED_SPLITK, 0)
 
 
 @pytest.mark.parametrize("iname", ["int8", "fn"])
@@ -1191,3 +1192,34 @@ def test_mixed_precision_ragged_slice_ignores_inf_behind_k():
     got = mixed_precision_gemm(wide.cuda()[:, :k], packed.cuda(), w_s.cuda(), None, wt.size_bits, wt.bias, 128)
     assert torch.isfinite(got.float()).all()
     check_mixed(got, a, w_ref, k)
+
+
+# ---------------------------------------------------------------------------------------------
+# split-K form of the LDS-tiled mixed kernel (few tiles: M of a few hundred rows, N of a few thousand columns)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("split", [2, 4, 8])
+@pytest.mark.parametrize(("m", "k", "n"), [(512, 4096, 1024), (300, 2048, 520), (1024, 1152, 256), (700, 4096, 4096)])
+@pytest.mark.parametrize(("wname", "use_zp", "dname"), [("uint4b8", False, "f16"), ("uint4", True, "bf16"), ("uint8b128", False, "bf16")])
+def test_mixed_precision_split_k(_reset_tuning, split, m, k, n, wname, use_zp, dname):
+    """K slices per tile, fp32 slabs, reduce in slice order: against the oracle, against the unsplit kernel (another summation
+    order: 2 eps of max|C|), plain and pre-packed weights; K whose slices are not equal (1152 = 18 steps) included."""
+    wt = WTYPES[wname]
+    a, w_ref, packed, w_s, w_zp = make_mixed_inputs(m, k, n, wt, use_zp, DT[dname])
+    dev = lambda t: None if t is None else t.cuda()  # noqa: E731
+    args = (dev(a), dev(packed), dev(w_s), dev(w_zp), wt.size_bits, wt.bias, 128)
+    _C.set_gemm_variant(_C.VARIANT_MFMA_PINGPONG2)  # the LDS-tiled kernel, not the decode kernel
+    try:
+        _C.set_tuning(_C.TUNE_MIXED_SPLITK, 1)
+        whole = mixed_precision_gemm(*args)
+        _C.set_tuning(_C.TUNE_MIXED_SPLITK, split)
+        got = mixed_precision_gemm(*args)
+        pre = prepack_mixed_weights(dev(packed), wt.size_bits, m_hint=m, per_group_zero_points=use_zp)
+        got_pre = mixed_precision_gemm_prepacked(dev(a), pre, dev(w_s), dev(w_zp), wt.bias, 128)
+        again = mixed_precision_gemm(*args)
+    finally:
+        _C.set_tuning(_C.TUNE_MIXED_SPLITK, 0)
+        _C.set_gemm_variant(_C.VARIANT_AUTO)
+    check_mixed(got, a, w_ref, k)
+    tol = 2.0 * EPS[DT[dname]] * whole.float().abs().max().item()
+    assert (got.float() - whole.float()).abs().max().item() <= tol
+    assert torch.equal(got_pre, got) and torch.equal(again, got)  # same slices, same order: deterministic

@@ -84,17 +84,21 @@ def mixed_case(m, k, n, dtype=torch.float16, bits=4):
     res = {}
     for regime, rot in (("warm", 1), ("cold", count)):
         LIB.conch_set_timing_rotation(rot, words * n * 4)
-        for name, variant in (("auto", 0), ("decode", 4), ("tile", 5)):
+        for name, variant in (("auto", 0), ("decode", 4), ("tile", 5), ("tile/2", 5), ("tile/4", 5), ("tile/8", 5)):
             if variant == 4 and m > 256:
                 continue
+            if "/" in name and m <= 256:
+                continue
             _C.set_gemm_variant(variant)
+            _C.set_tuning(_C.TUNE_MIXED_SPLITK, int(name.split("/")[1]) if "/" in name else (1 if name == "tile" else 0))
             try:
                 res[(regime, name)] = timed(run, 30.0)
             except Exception:  # noqa: BLE001
                 pass
     _C.set_gemm_variant(0)
     LIB.conch_set_timing_rotation(1, 0)
-    report(f"mixed  int{bits} x {str(dtype)[6:]:8s} {m:5d}x{k}x{n}", res, ("decode", "tile"))
+    _C.set_tuning(_C.TUNE_MIXED_SPLITK, 0)
+    report(f"mixed  int{bits} x {str(dtype)[6:]:8s} {m:5d}x{k}x{n}", res, ("decode", "tile", "tile/2", "tile/4", "tile/8"))
 
 
 def report(label, res, names):
@@ -111,15 +115,19 @@ def report(label, res, names):
     print(f"{label}: warm auto {auto_w:6.1f} us (best {wn} {wt:6.1f})   cold auto {auto_c:6.1f} us (best {cn} {ct:6.1f}; {cold}){flag}", flush=True)
 
 
+MIXED_MS = [384, 512, 768, 1024, 2048] if "--mixed-mid" in sys.argv else [1, 8, 16, 32, 48, 64, 96, 128, 192, 256, 384, 512, 1024]
+
+
 if __name__ == "__main__":
     ms_ = [8, 32, 64, 128, 256, 512] if QUICK else [8, 16, 32, 48, 64, 96, 128, 192, 256, 384, 512, 768, 1024]
     shapes = [(4096, 4096), (4096, 11008)] if QUICK else [(4096, 4096), (4096, 11008), (8192, 8192), (4096, 28672), (8192, 28672), (11008, 4096)]
+    if "--mixed-mid" not in sys.argv:
+        for k, n in shapes:
+            for m in ms_:
+                scaled_case(m, k, n, torch.int8)
+        for k, n in shapes[:3]:
+            for m in ms_:
+                scaled_case(m, k, n, torch.float8_e4m3fn)
     for k, n in shapes:
-        for m in ms_:
-            scaled_case(m, k, n, torch.int8)
-    for k, n in shapes[:3]:
-        for m in ms_:
-            scaled_case(m, k, n, torch.float8_e4m3fn)
-    for k, n in shapes:
-        for m in [1, 8, 16, 32, 48, 64, 96, 128, 192, 256, 384]:
+        for m in MIXED_MS:
             mixed_case(m, k, n)
