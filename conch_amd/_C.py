@@ -89,6 +89,10 @@ _SIGNATURES = {
         c_int,
         [c_void_p] * 6 + [_I64] * 11 + [c_int, c_int, c_void_p, c_int, ctypes.POINTER(c_float)],
     ),
+    "conch_static_quant_scaled_gemm": (
+        c_int,
+        [c_void_p] * 6 + [_I64] * 10 + [c_int, c_int, c_int, c_void_p],
+    ),
     "conch_time_scaled_gemm": (
         c_int,
         [c_void_p] * 6 + [_I64] * 11 + [c_int, c_int, c_void_p, c_int, ctypes.POINTER(c_float)],

@@ -223,6 +223,47 @@ int run_scaled(const ScaledGemmArgs& p_in, hipStream_t stream) {
   return launch_scaled_gemm_generic(p, stream);
 }
 
+// scaled_gemm on 16-bit activations with a static per-tensor activation scale: c = scaled_gemm(static_quant(x, scale_x), b, scale_x,
+// scale_b) in one launch where the skinny-M split-K kernel runs the shape (it quantises A on its way into LDS, bit-identically
+// to quant.hip), else the unfused pair through library scratch.  p.a = x, p.a_src_dtype = its dtype, p.a_stride_m in elements.
+
+int run_static_quant_scaled(const ScaledGemmArgs& p, hipStream_t stream) {
+  CONCH_CHECK_ARG(p.a_src_dtype == CONCH_DT_FP16 || p.a_src_dtype == CONCH_DT_BF16,
+                  "static_quant_scaled_gemm: activations must be FP16 or BF16 (got dtype %d)", p.a_src_dtype);
+  CONCH_CHECK_ARG(p.in_dtype == CONCH_DT_INT8 || p.in_dtype == CONCH_DT_FP8_E4M3FN,
+                  "static_quant_scaled_gemm: quantised dtype %d (want INT8 or FP8_E4M3FN)", p.in_dtype);
+  CONCH_CHECK_ARG(p.scale_a && p.scale_a_numel == 1, "static_quant_scaled_gemm: one per-tensor activation scale");
+  ScaledGemmArgs q = p;  // the problem as the GEMM kernels see it: A = m x k quantised bytes
+  q.a_src_dtype = 0;
+  if (int rc = check_scaled(q)) return rc;
+  if (p.m == 0 || p.n == 0) return CONCH_OK;
+  CONCH_CHECK_ARG(p.scale_b, "static_quant_scaled_gemm: NULL scale_b");
+  const int variant = tuning(CONCH_TUNE_GEMM_VARIANT);
+  ScaledGemmArgs probe = q;      // layout contract of the fused path: 16-byte aligned activation rows, K-contiguous
+  probe.a_stride_m = p.a_stride_m * 2;
+  // Every (64-column block, K slice) workgroup quantises its own A slice again, N / 64 times over: worth it while that work
+  // (measured ~11 elements per ns and CU, profiles/r02/fused_quant_times.txt) stays under the ~8 us a separate quantiser launch
+  // costs at these sizes.
+  const int rows = p.m <= 32 ? 32 : p.m <= 64 ? 64 : 128;
+  const int64_t wgs = ((p.n + 63) / 64) * ((p.k + 1023) / 1024) * ((p.m + rows - 1) / rows);
+  const double requant_us = (double)((wgs + device_cu_count() - 1) / device_cu_count()) * (double)rows * 1024.0 / 11.0e3;
+  const bool fused_ok = p.a_stride_k == 1 && p.n % 4 == 0 && scaled_gemm_skinny_supported(probe) &&
+                        (variant == 4 || (variant == 0 && choose_scaled_kernel(probe) == kKernelSkinny && requant_us < 8.0));
+  if (fused_ok) return launch_scaled_gemm_skinny(p, stream);
+  // the unfused pair: quantise into scratch (row stride K), then the ordinary op
+  void* aq = nullptr;
+  if (int rc = get_scratch(stream, kScratchWide, (size_t)p.m * (size_t)p.k, &aq)) return rc;
+  CONCH_CHECK_ARG(p.a_stride_k == 1, "static_quant_scaled_gemm: activations must be K-contiguous");
+  const int rc = p.in_dtype == CONCH_DT_INT8
+                     ? conch_static_scaled_int8_quant((int8_t*)aq, p.a, p.scale_a, p.m, p.k, p.a_stride_m, p.k, p.a_src_dtype, stream)
+                     : conch_static_scaled_fp8_quant((uint8_t*)aq, p.a, p.scale_a, p.m, p.k, p.a_stride_m, p.k, p.a_src_dtype, CONCH_DT_FP8_E4M3FN, stream);
+  if (rc) return rc;
+  q.a = aq;
+  q.a_stride_m = p.k;
+  return run_scaled(q, stream);
+}
+
+
 // scaled_gemm_silu_and_mul: `p` describes the OUTPUT (n columns); B / scale_b / bias have 2n columns [gate | up].
 int run_scaled_silu(const ScaledGemmArgs& p, hipStream_t stream) {
   ScaledGemmArgs wide = p;  // the plain GEMM the fused op contains: checks and the unfused fallback run on it
@@ -485,6 +526,17 @@ extern "C" int conch_scaled_gemm(void* c, const void* a, const void* b, const fl
   const ScaledGemmArgs p{c, a, b, scale_a, scale_b, bias, m, n, k, a_stride_m, a_stride_k, b_stride_k,
                          b_stride_n, c_stride_m, c_stride_n, scale_a_numel, scale_b_numel, in_dtype, out_dtype};
   return run_scaled(p, (hipStream_t)stream);
+}
+
+extern "C" int conch_static_quant_scaled_gemm(void* c, const void* x, const void* b, const float* scale_x, const float* scale_b,
+                                              const void* bias, int64_t m, int64_t n, int64_t k, int64_t x_stride_m,
+                                              int64_t x_stride_k, int64_t b_stride_k, int64_t b_stride_n, int64_t c_stride_m,
+                                              int64_t c_stride_n, int64_t scale_b_numel, int x_dtype, int quant_dtype, int out_dtype,
+                                              void* stream) {
+  ScaledGemmArgs p{c, x, b, scale_x, scale_b, bias, m, n, k, x_stride_m, x_stride_k, b_stride_k, b_stride_n, c_stride_m, c_stride_n,
+                   1, scale_b_numel, quant_dtype, out_dtype};
+  p.a_src_dtype = x_dtype;
+  return run_static_quant_scaled(p, (hipStream_t)stream);
 }
 
 extern "C" int conch_scaled_gemm_silu_and_mul(void* c, const void* a, const void* b, const float* scale_a,

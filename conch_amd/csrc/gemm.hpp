@@ -23,6 +23,10 @@ struct ScaledGemmArgs {
   // != 0 = fused gate/up FFN form; the value is the gate activation (1 = silu, 2 = gelu-tanh) (conch_scaled_gemm_silu_and_mul): B, scale_b and bias have 2n columns [gate | up], C has
   // n columns, C[i][j] = silu(gemm[i][j]) * gemm[i][n + j] with the reference's roundings (oracle: scaled_gemm_silu_and_mul_ref)
   int fuse_silu = 0;
+  // != 0 (CONCH_DT_FP16 / CONCH_DT_BF16): `a` holds 16-bit ACTIVATIONS (a_stride_m in elements) that the kernel quantises to
+  // in_dtype on the fly with the static per-tensor scale scale_a[0] (scale_a_numel == 1), exactly as
+  // static_scaled_{int8,fp8}_quant would -- conch_static_quant_scaled_gemm, skinny-M split-K kernel only
+  int a_src_dtype = 0;
 };
 
 // mixed_precision_gemm: C = out( X @ dequant(Wq) ).  Strides in ELEMENTS of the respective array.

@@ -13,6 +13,7 @@
 #include "common.hpp"
 #include "gemm.hpp"
 #include "mfma_tile.hpp"
+#include "quant_common.hpp"
 
 namespace conch {
 namespace {
@@ -193,9 +194,16 @@ __device__ __forceinline__ i32x2 sp_epilogue4(const ScaledGemmArgs& p, const ACC
 // registers, bit-identical to what it stored -- then runs the fused epilogue and puts the counter back to zero.
 // Placement-independent: nothing here depends on which XCD or CU a slice runs on.  The LDS request is kept above half
 // of the CU's 160 KiB so that one workgroup runs per CU (the regime the hand-off was measured in).
-template <int MMA, int OUT_DT, int ROWS, int STEPS, bool FUSED>
+// A_SRC != 0 (CONCH_DT_FP16 / BF16; two-launch form only): A arrives as 16-bit activations and is quantised on the way into
+// LDS with the static per-tensor scale scale_a[0] -- the arithmetic of quant.hip (x * (1 / scale), clamp, convert), so the bytes
+// in LDS are the ones static_scaled_{int8,fp8}_quant would have written to HBM and the product is bit-identical to the unfused
+// pair.  The B^T fragments are put in flight first; the A slice (ROWS x STEPS x 128 elements) then passes through registers:
+// 16 elements per thread and item, laid down where the LDS-DMA would have put them (unit row rho, 16-byte position pos holds
+// source chunk pos ^ ((rho >> 1) & 7)).  At decode sizes the separate quantiser is a launch of the GEMM's own order.
+template <int MMA, int OUT_DT, int ROWS, int STEPS, bool FUSED, int A_SRC = 0>
 __global__ __launch_bounds__(kSkThreads, 1) void skinny_splitk_kernel(ScaledGemmArgs p, int* __restrict__ slabs,
                                                                        unsigned* __restrict__ counters) {
+  static_assert(A_SRC == 0 || !FUSED, "the quantising prologue is built for the two-launch form");
   constexpr int kUnit = ROWS * kStepBytes;  // one K step of A
   constexpr int kPieces = ROWS / 32;        // 8-row x 128-byte subtiles a wave feeds per step
   constexpr int kLds = (FUSED && STEPS * kUnit < 84 * 1024) ? 84 * 1024 : STEPS * kUnit;
@@ -207,7 +215,7 @@ __global__ __launch_bounds__(kSkThreads, 1) void skinny_splitk_kernel(ScaledGemm
   const int slice = blockIdx.y;
   const int k_begin = slice * (STEPS * kStepBytes);
 
-  const uint32_t a_bytes = (uint32_t)((p.m - 1) * p.a_stride_m + p.k);
+  const uint32_t a_bytes = (uint32_t)(((p.m - 1) * p.a_stride_m + p.k) * (A_SRC ? 2 : 1));
   const uint32_t b_bytes = (uint32_t)((p.n - 1) * p.b_stride_n + p.k);
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.b, 0, b_bytes, 0x00020000);
@@ -232,13 +240,44 @@ __global__ __launch_bounds__(kSkThreads, 1) void skinny_splitk_kernel(ScaledGemm
     const int kill = s < valid_steps ? 0 : (int)0x80000000;
     fb[s].lo = ld16(rb, voff_b | kill, k_begin + s * kStepBytes);
     fb[s].hi = ld16(rb, voff_b | kill, k_begin + s * kStepBytes + 64);
-    char* dst = lds + s * kUnit + wave * (ROWS / 4) * kStepBytes;
+    if constexpr (A_SRC == 0) {
+      char* dst = lds + s * kUnit + wave * (ROWS / 4) * kStepBytes;
 #pragma unroll
-    for (int j = 0; j < kPieces; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(dst + j * 1024), 16, voff_a[j] | kill,
-                                               k_begin + s * kStepBytes, 0, 0);
+      for (int j = 0; j < kPieces; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(dst + j * 1024), 16, voff_a[j] | kill,
+                                                 k_begin + s * kStepBytes, 0, 0);
+    }
     // the counted waits below count VMEM operations in THIS order, step by step: no reordering across steps
     __builtin_amdgcn_sched_barrier(0);
+  }
+  if constexpr (A_SRC != 0) {
+    constexpr int kKind = MMA == kMmaInt8 ? quant::kInt8 : quant::kFp8Fn;
+    const float inv = 1.0f / p.scale_a[0];
+    constexpr int kItems = STEPS * ROWS * 8;  // (step, unit row, 16-byte position)
+#pragma unroll 4
+    for (int it = threadIdx.x; it < kItems; it += kSkThreads) {
+      const int s = it / (ROWS * 8), rem = it - s * (ROWS * 8);
+      const int rho = rem >> 3, pos = rem & 7;
+      const int chunk = pos ^ ((rho >> 1) & 7);
+      const int kill = s < valid_steps ? 0 : (int)0x80000000;
+      const int voff = (min(m0 + rho, (int)p.m - 1) * (int)p.a_stride_m + chunk * 16) * 2;
+      const int soff = (k_begin + s * kStepBytes) * 2;
+      const i32x4 lo = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, voff | kill, soff, 0));
+      const i32x4 hi = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, (voff + 16) | kill, soff, 0));
+      float f[16];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f[2 * j] = bits16_to_float<A_SRC>((uint16_t)((uint32_t)lo[j] & 0xffffu));
+        f[2 * j + 1] = bits16_to_float<A_SRC>((uint16_t)((uint32_t)lo[j] >> 16));
+        f[8 + 2 * j] = bits16_to_float<A_SRC>((uint16_t)((uint32_t)hi[j] & 0xffffu));
+        f[8 + 2 * j + 1] = bits16_to_float<A_SRC>((uint16_t)((uint32_t)hi[j] >> 16));
+      }
+      i32x4 q;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) q[j] = (int)quant::quant_four<kKind>(f[4 * j], f[4 * j + 1], f[4 * j + 2], f[4 * j + 3], inv);
+      *(i32x4*)(lds + s * kUnit + rho * kStepBytes + pos * 16) = q;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // B^T fragments and this thread's ds_writes are complete
   }
 
   typename AccT<MMA>::type acc[ROWS / 16];
@@ -410,6 +449,22 @@ void launch_splitk_kernel(int rows, int steps, dim3 grid, const ScaledGemmArgs& 
       return;
     }
   }
+  if constexpr (!FUSED) {
+    if (p.a_src_dtype) {  // quantise A on the way in (conch_static_quant_scaled_gemm)
+#define CONCH_QA(R)                                                                                                              \
+  do {                                                                                                                           \
+    if (p.a_src_dtype == CONCH_DT_FP16)                                                                                          \
+      hipLaunchKernelGGL((skinny_splitk_kernel<MMA, OUT_DT, R, kSpSteps, false, CONCH_DT_FP16>), grid, block, 0, stream, p, ws, counters); \
+    else                                                                                                                         \
+      hipLaunchKernelGGL((skinny_splitk_kernel<MMA, OUT_DT, R, kSpSteps, false, CONCH_DT_BF16>), grid, block, 0, stream, p, ws, counters); \
+  } while (0)
+      if (rows == 32) CONCH_QA(32);
+      else if (rows == 64) CONCH_QA(64);
+      else CONCH_QA(128);
+#undef CONCH_QA
+      return;
+    }
+  }
   if (rows == 32) hipLaunchKernelGGL((skinny_splitk_kernel<MMA, OUT_DT, 32, kSpSteps, FUSED>), grid, block, 0, stream, p, ws, counters);
   else if (rows == 64) hipLaunchKernelGGL((skinny_splitk_kernel<MMA, OUT_DT, 64, kSpSteps, FUSED>), grid, block, 0, stream, p, ws, counters);
   else hipLaunchKernelGGL((skinny_splitk_kernel<MMA, OUT_DT, 128, kSpSteps, FUSED>), grid, block, 0, stream, p, ws, counters);
@@ -453,6 +508,7 @@ int launch_splitk(const ScaledGemmArgs& p, int slices, hipStream_t stream) {
     const int64_t wgs = ((p.n + kSpN - 1) / kSpN) * (p.k / (2 * kSpSliceK)) * ((p.m + 63) / 64);
     mode = (p.m > 64 && p.m <= 128 && p.k % (2 * kSpSliceK) == 0 && wgs <= device_cu_count()) ? 3 : 1;
   }
+  if (p.a_src_dtype) mode = 1;  // the quantising prologue lives in the two-launch form
   int steps = kSpSteps;
   if (mode == 3 && p.k % (2 * kSpSliceK) == 0) {
     steps = 2 * kSpSteps;
@@ -465,7 +521,7 @@ int launch_splitk(const ScaledGemmArgs& p, int slices, hipStream_t stream) {
   const size_t bytes = (size_t)slices * p.m * p.n * 4;
   // the in-launch reduce addresses all slabs through one 32-bit buffer descriptor and needs one counter per tile; the
   // gate/up fusion combines two tiles per output and keeps its reduce kernel
-  if (p.fuse_silu || bytes >= ((size_t)1 << 31) || (size_t)grid.x * grid.z > (size_t)kSpMaxTiles) mode = 1;
+  if (p.fuse_silu || p.a_src_dtype || bytes >= ((size_t)1 << 31) || (size_t)grid.x * grid.z > (size_t)kSpMaxTiles) mode = 1;
   void* ws = nullptr;
   if (int rc = get_scratch(stream, kScratchSplitK, bytes, &ws)) return rc;
   if (mode != 1) {
@@ -492,7 +548,7 @@ int launch_scaled_gemm_skinny(const ScaledGemmArgs& p, hipStream_t stream) {
   // scaled_gemm_skinny_fused_supported); only the split-K form has a reduce kernel
   // CONCH_TUNE_SKINNY_NO_SPLITK = 1 disables split-K (where the in-workgroup form can take the shape)
   const bool in_wg_ok = p.k % (2 * kStepBytes * kSkWaves) == 0;
-  const int slices = (tuning(CONCH_TUNE_SKINNY_NO_SPLITK) == 1 && !p.fuse_silu && in_wg_ok) ? 0 : splitk_slices(p);
+  const int slices = (tuning(CONCH_TUNE_SKINNY_NO_SPLITK) == 1 && !p.fuse_silu && !p.a_src_dtype && in_wg_ok) ? 0 : splitk_slices(p);
   if (slices >= 1) {
     int rc;
     if (p.in_dtype == CONCH_DT_FP8_E4M3FN)

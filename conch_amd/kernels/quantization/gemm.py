@@ -172,6 +172,46 @@ def scaled_gemm_launcher(
         output.add_(late_bias.reshape(-1))
 
 
+def static_quant_scaled_gemm_launcher(
+    output: torch.Tensor,
+    x: torch.Tensor,
+    b: torch.Tensor,
+    scale_x: torch.Tensor,
+    scale_b: torch.Tensor,
+    bias: torch.Tensor | None = None,
+) -> None:
+    """output = scaled_gemm(static_scaled_{int8,fp8}_quant(x, scale_x), b, scale_x, scale_b) [+ bias], bit for bit, without the
+    quantised copy of x where the skinny-M kernel runs the shape (the quantiser fused into the GEMM prologue).
+
+    Replaces the pair static_scaled_int8_quant_launcher / static_scaled_fp8_quant_launcher (kernels/quantization/int8.py:63-97,
+    fp8.py:65-97) + scaled_gemm_launcher (kernels/quantization/gemm.py:564-627).  `b` fixes the quantised dtype."""
+    _C.require_device(output, x, b, scale_x, scale_b, bias)
+    if x.dtype not in (torch.float16, torch.bfloat16):
+        raise ValueError(f"x must be float16 or bfloat16 (got {x.dtype})")
+    if x.dim() != 2 or b.dim() != 2 or x.shape[1] != b.shape[0]:
+        raise ValueError(f"x {tuple(x.shape)} does not multiply b {tuple(b.shape)}")
+    m, k = x.shape
+    n = b.shape[1]
+    if tuple(output.shape) != (m, n):
+        raise ValueError(f"output shape {tuple(output.shape)} != {(m, n)}")
+    if scale_x.numel() != 1 or scale_x.dtype != torch.float32:
+        raise ValueError("scale_x must be one float32 (static per-tensor activation scale)")
+    sb = _as_fp32_vector(scale_b, "scale_b")
+    if bias is not None:
+        if bias.dtype != output.dtype:
+            raise ValueError("bias must have the output dtype")
+        bias = bias.reshape(-1).contiguous()
+        if bias.numel() != n:
+            raise ValueError(f"bias has {bias.numel()} elements, want N={n}")
+    with _C.on_device_of(output, x, b, scale_x, sb, bias):
+        status = _C.load().conch_static_quant_scaled_gemm(
+            _C.ptr(output), _C.ptr(x), _C.ptr(b), _C.ptr(scale_x), _C.ptr(sb), _C.ptr(bias), m, n, k,
+            x.stride(0), x.stride(1), b.stride(0), b.stride(1), output.stride(0), output.stride(1), sb.numel(),
+            _C.dtype_id(x.dtype), _C.dtype_id(b.dtype), _C.dtype_id(output.dtype), _C.current_stream_handle(x.device),
+        )
+    _C.check(status, "static_quant_scaled_gemm")
+
+
 def _scaled_gemm_act_and_mul(fn_name: str, what: str, output, a, b, scale_a, scale_b, metadata: ScaledMatmulMetadata, bias) -> None:
     if metadata.n_dim % 2:
         raise ValueError(f"{what}: B needs an even number of columns [gate | up], got {metadata.n_dim}")

@@ -16,12 +16,13 @@ from conch_amd.kernels.quantization.gemm import (
     scaled_gemm_gelu_tanh_and_mul_launcher,
     scaled_gemm_launcher,
     scaled_gemm_silu_and_mul_launcher,
+    static_quant_scaled_gemm_launcher,
 )
 from conch_amd.ops.quantization._metadata import create_mixed_precision_metadata, create_scaled_metadata
 
 __all__ = ["create_mixed_precision_metadata", "create_scaled_metadata", "mixed_precision_gemm", "scaled_gemm",
            "scaled_gemm_silu_and_mul", "mixed_precision_gemm_silu_and_mul", "scaled_gemm_gelu_tanh_and_mul",
-           "mixed_precision_gemm_gelu_tanh_and_mul"]
+           "mixed_precision_gemm_gelu_tanh_and_mul", "static_quant_scaled_gemm"]
 
 
 def mixed_precision_gemm(x: torch.Tensor, w_q_packed: torch.Tensor, w_s: torch.Tensor, w_zp: torch.Tensor | None,
@@ -97,4 +98,15 @@ def mixed_precision_gemm_gelu_tanh_and_mul(x: torch.Tensor, w_q_packed: torch.Te
                                            output_dtype=output_dtype, strict=strict)
     out = x.new_empty((meta.m_dim, meta.n_dim // 2), dtype=meta.output_dtype)
     mixed_precision_gemm_gelu_tanh_and_mul_launcher(out, x, w_q_packed, w_s, w_zp, meta)
+    return out
+
+
+def static_quant_scaled_gemm(x: torch.Tensor, b: torch.Tensor, scale_x: torch.Tensor, scale_b: torch.Tensor,
+                             output_dtype: torch.dtype, bias: torch.Tensor | None = None) -> torch.Tensor:
+    """scaled_gemm(scaled_{int8,fp8}_quant(x, scale_x)[0], b, scale_x, scale_b, output_dtype, bias) in one call, bit for bit
+    (the activation quantiser fused into the GEMM).  `x`: fp16 / bf16 activations [M, K]; `b`: int8 / fp8
+    weights [K, N] (its dtype is the one x is quantised to); `scale_x`: the static per-tensor activation scale (one float32).
+    At decode batch sizes the quantisation happens on the way into the GEMM kernel's LDS; larger M runs the two kernels."""
+    out = torch.empty((x.shape[0], b.shape[1]), dtype=output_dtype, device=x.device)
+    static_quant_scaled_gemm_launcher(out, x, b, scale_x, scale_b, bias)
     return out

@@ -337,6 +337,20 @@ int conch_bnb_gemm_4bit(void* c, const void* x, const uint8_t* w_packed, const v
                         int out_dtype, void* stream);
 
 /*
+ * scaled_gemm on 16-bit ACTIVATIONS with a static per-tensor activation scale (second half):
+ *   c = conch_scaled_gemm( static_scaled_{int8,fp8}_quant(x, scale_x), b, scale_a = scale_x, scale_b, bias )
+ * bit for bit.  Where the skinny-M split-K kernel runs the shape (decode batches: M <= 256, N % 4 == 0, 16-byte aligned
+ * K-contiguous rows) the quantisation happens on A's way into LDS -- no quantised copy of A in HBM, no second launch; other
+ * shapes run the unfused pair through library scratch.  Replaces the pair of reference launchers
+ * static_scaled_{int8,fp8}_quant_launcher (conch/kernels/quantization/int8.py:63-97, fp8.py:65-97) + scaled_gemm_launcher
+ * (conch/kernels/quantization/gemm.py:564-627).  x_dtype: FP16 / BF16; quant_dtype: INT8 / FP8_E4M3FN (= b's dtype).
+ */
+int conch_static_quant_scaled_gemm(void* c, const void* x, const void* b, const float* scale_x, const float* scale_b, const void* bias,
+                                   int64_t m, int64_t n, int64_t k, int64_t x_stride_m, int64_t x_stride_k, int64_t b_stride_k,
+                                   int64_t b_stride_n, int64_t c_stride_m, int64_t c_stride_n, int64_t scale_b_numel, int x_dtype,
+                                   int quant_dtype, int out_dtype, void* stream);
+
+/*
  * Timing helper used by bench.py: launches `iters` back-to-back scaled_gemm calls on `stream`
  * bracketed by HIP events recorded ON THAT STREAM and returns the average milliseconds per call
  * in *avg_ms (synchronises the stream; not for use inside graph capture).

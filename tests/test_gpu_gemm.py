@@ -1223,3 +1223,56 @@ def test_mixed_precision_split_k(_reset_tuning, split, m, k, n, wname, use_zp, d
     tol = 2.0 * EPS[DT[dname]] * whole.float().abs().max().item()
     assert (got.float() - whole.float()).abs().max().item() <= tol
     assert torch.equal(got_pre, got) and torch.equal(again, got)  # same slices, same order: deterministic
+
+
+# ---------------------------------------------------------------------------------------------
+# static activation quantiser fused into the GEMM (second half)
+# ---------------------------------------------------------------------------------------------
+from conch_amd.ops.quantization.fp8 import scaled_fp8_quant  # noqa: E402
+from conch_amd.ops.quantization.gemm import static_quant_scaled_gemm  # noqa: E402
+from conch_amd.ops.quantization.int8 import scaled_int8_quant  # noqa: E402
+
+
+@pytest.mark.parametrize("iname", ["int8", "fn"])
+@pytest.mark.parametrize("xname", ["f16", "bf16"])
+@pytest.mark.parametrize(("m", "k", "n"), [(1, 1024, 64), (16, 4096, 520), (33, 1152, 1376), (64, 2048, 256), (100, 11008, 512), (128, 4096, 4096),
+                                            (200, 1024, 260), (256, 384, 128), (512, 1024, 768), (24, 1000, 72), (48, 1024, 66)])
+def test_static_quant_scaled_gemm_equals_the_pair(_reset_tuning, iname, xname, m, k, n):
+    """One call == static quantiser + scaled_gemm with scale_a = the quantiser's scale, bit for bit: decode sizes (the split-K
+    kernel quantises A on its way into LDS; ragged K slices, ragged M / N), sizes the tile kernels take (unfused pair inside),
+    and layouts the fused path cannot take (K not a multiple of 128, N not a multiple of 4)."""
+    seed_everything(21)
+    in_dt = IN_T[iname]
+    x = (4.0 * (torch.rand((m, k)) - 0.5)).to(DT[xname])
+    x[0, 0] = 1000.0  # saturates both formats
+    if in_dt == torch.int8:
+        bt = torch.randint(-32, 32, (n, k), dtype=torch.int8)
+        sx = torch.tensor([0.02], dtype=torch.float32)
+        quant = scaled_int8_quant
+    else:
+        bt = (0.25 * torch.rand((n, k))).to(in_dt)
+        sx = torch.tensor([0.01], dtype=torch.float32)
+        quant = scaled_fp8_quant
+    sb = 0.25 * torch.rand((n, 1))
+    bias = torch.rand((n,)).to(torch.bfloat16)
+    xd, bd, sxd, sbd, biasd = x.cuda(), bt.cuda().T, sx.cuda(), sb.cuda(), bias.cuda()
+    got = static_quant_scaled_gemm(xd, bd, sxd, sbd, torch.bfloat16, biasd)
+    xq, _ = quant(xd, sxd)
+    # the pair on the kernel the fused call used: split-K two-launch form where it can run, the dispatcher's choice elsewhere
+    fused_layout = m <= 256 and n % 4 == 0 and k % 128 == 0
+    if fused_layout and in_dt != torch.int8:
+        _C.set_tuning(_C.TUNE_SKINNY_MODE, 1)
+    pair = scaled_gemm(xq, bd, sxd.reshape(1, 1), sbd, torch.bfloat16, biasd)
+    if in_dt == torch.int8 or not fused_layout:
+        assert torch.equal(got, pair)
+    else:
+        # the dispatcher may have run either side on another kernel (fp32 summation order): equal when both took the split-K form
+        _C.set_gemm_variant(_C.VARIANT_MFMA_SKINNY)
+        forced_pair = scaled_gemm(xq, bd, sxd.reshape(1, 1), sbd, torch.bfloat16, biasd)
+        forced = static_quant_scaled_gemm(xd, bd, sxd, sbd, torch.bfloat16, biasd)
+        _C.set_gemm_variant(_C.VARIANT_AUTO)
+        assert torch.equal(forced, forced_pair)
+        tol = 4.0 * EPS[torch.bfloat16] * pair.float().abs().max().item()
+        assert (got.float() - pair.float()).abs().max().item() <= tol
+    ref = oracle.scaled_gemm_ref(xq.cpu(), bt.T, sx.reshape(1, 1), sb, torch.bfloat16, bias)
+    check_scaled(got, ref, in_dt, torch.bfloat16)

@@ -1,4 +1,4 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out
-timeout 900 python tools/vendor_compare.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/vendor_compare.txt
+timeout 600 python tools/time_fused_quant.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/fused_quant_times.txt
