@@ -230,7 +230,15 @@ def ptr(t: torch.Tensor | None) -> int | None:
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def current_stream_handle(device: torch.device) -> int:
+    """The hipStream_t of torch's current stream on `device` (the raw-handle query when this torch build has it: the Stream
+    object `torch.cuda.current_stream` builds costs ~4 us per op call, a fifth of a decode-size call's host time)."""
+    if _raw_stream is not None:
+        idx = device.index
+        return _raw_stream(torch.cuda.current_device() if idx is None else idx)
     return torch.cuda.current_stream(device).cuda_stream
 
 
