@@ -30,6 +30,7 @@ constexpr int kMsStepK = 64;              // k elements per step (128 bytes of f
 constexpr int kMsSteps = 16;              // steps per slice
 constexpr int kMsSliceK = kMsSteps * kMsStepK;
 constexpr int kMsMaxM = 256;
+constexpr int kMsMaxTiles = 16384;  // arrival counters per (device, stream): the 64 KiB slot gemm_skinny.hip uses too
 
 template <int X_DT, int BITS, int ZP>
 __device__ __forceinline__ i32x4 dequant8(uint32_t w0, uint32_t w1, int off, uint32_t scale_bits, uint32_t mask, uint32_t magic, uint32_t mask_hi) {
@@ -39,8 +40,14 @@ __device__ __forceinline__ i32x4 dequant8(uint32_t w0, uint32_t w1, int off, uin
   return cv.out;
 }
 
-template <int X_DT, int BITS, int ZP, int ROWS>
-__global__ __launch_bounds__(kMsThreads) void mixed_skinny_kernel(MixedGemmArgs p, float* __restrict__ slabs) {
+// FUSED = the reduce of the slices runs in the same launch (same hand-off as gemm_skinny.hip's one-launch form, the first row of
+// MI355X_MICROARCH.md's table of measured hand-offs): every wave stores its partial tile write-through (sc1) and drains its own
+// stores, workgroup barrier, one lane draws a ticket from the tile's agent-scope counter; the workgroup that draws the last
+// ticket re-reads all slices with sc1 loads, adds them IN SLICE ORDER -- the order of the reduce kernel: bit-identical results --
+// casts, stores C and puts the counter back to zero.  At GEMV sizes the slab tile of a workgroup is 4 KiB: the second launch
+// costs more than the last arriver's pass over the slices.
+template <int X_DT, int BITS, int ZP, int ROWS, bool FUSED = false, int OUT_DT = CONCH_DT_FP16>
+__global__ __launch_bounds__(kMsThreads) void mixed_skinny_kernel(MixedGemmArgs p, float* __restrict__ slabs, unsigned* __restrict__ counters) {
   constexpr int kUnit = ROWS * 128;            // one K step of X
   constexpr int kWpc = BITS == 4 ? 1 : 2;      // 32-bit words per 8-k chunk
   constexpr int kWordRows = kMsStepK * BITS / 32;  // word rows per K step (8 / 16)
@@ -134,12 +141,70 @@ __global__ __launch_bounds__(kMsThreads) void mixed_skinny_kernel(MixedGemmArgs 
   }
 
   // D rows = n (4g + e), D columns = m (lane % 16): four consecutive n of one row per lane
-  float* slab = slabs + (int64_t)blockIdx.y * p.m * p.n;
+  const int nn = nw + 4 * g;
+  if constexpr (!FUSED) {
+    float* slab = slabs + (int64_t)blockIdx.y * p.m * p.n;
 #pragma unroll
-  for (int i = 0; i < ROWS / 16; ++i) {
-    const int m = m0 + i * 16 + r;
-    const int nn = nw + 4 * g;
-    if (m < p.m && nn + 4 <= p.n) *(f32x4*)(slab + (int64_t)m * p.n + nn) = acc[i];
+    for (int i = 0; i < ROWS / 16; ++i) {
+      const int m = m0 + i * 16 + r;
+      if (m < p.m && nn + 4 <= p.n) *(f32x4*)(slab + (int64_t)m * p.n + nn) = acc[i];
+    }
+  } else {
+    const int slices = (int)gridDim.y;
+    const uint32_t slab_bytes = (uint32_t)(p.m * p.n * 4);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)slabs, 0, slab_bytes * (uint32_t)slices, 0x00020000);
+    int voff_s[ROWS / 16];
+#pragma unroll
+    for (int i = 0; i < ROWS / 16; ++i) voff_s[i] = (min(m0 + i * 16 + r, (int)p.m - 1) * (int)p.n + min(nn, (int)p.n - 4)) * 4;
+#pragma unroll
+    for (int i = 0; i < ROWS / 16; ++i) {
+      const int m = m0 + i * 16 + r;
+      if (m < p.m && nn + 4 <= p.n)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i]), rs, voff_s[i], (int)blockIdx.y * (int)slab_bytes, 16);  // sc1
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its own write-through stores
+    __syncthreads();
+    unsigned* flag = (unsigned*)lds;  // the X slice is dead: every wave's last ds_read fed an MFMA before the barrier
+    unsigned* cnt = counters + (blockIdx.z * gridDim.x + blockIdx.x);
+    if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (*flag != (unsigned)(slices - 1)) return;  // workgroup-uniform
+    f32x4 sum[ROWS / 16];
+    for (int sb = 0; sb < slices; sb += 4) {
+      u32x4 part[4][ROWS / 16];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int soff = min(sb + j, slices - 1) * (int)slab_bytes;
+#pragma unroll
+        for (int i = 0; i < ROWS / 16; ++i) part[j][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_s[i], soff, 16);  // sc1
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool first = sb + j == 0, live = sb + j < slices;
+#pragma unroll
+        for (int i = 0; i < ROWS / 16; ++i) {
+          const f32x4 v = __builtin_bit_cast(f32x4, part[j][i]);
+          sum[i] = first ? v : live ? sum[i] + v : sum[i];
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < ROWS / 16; ++i) {
+      const int m = m0 + i * 16 + r;
+      if (m < p.m && nn + 4 <= p.n) {
+        i32x2 pk;
+        pk[0] = (int)pack2_bits16<OUT_DT>(f32x2{sum[i][0], sum[i][1]});
+        pk[1] = (int)pack2_bits16<OUT_DT>(f32x2{sum[i][2], sum[i][3]});
+        uint16_t* dst = (uint16_t*)p.c + (int64_t)m * p.c_stride_m + nn;
+        if ((((uintptr_t)dst) & 7) == 0) {
+          *(i32x2*)dst = pk;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dst[e] = (uint16_t)((uint32_t)pk[e >> 1] >> (16 * (e & 1)));
+        }
+      }
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
   }
 }
 
@@ -189,18 +254,31 @@ __global__ __launch_bounds__(256) void mixed_skinny_reduce_silu_kernel(MixedGemm
 }
 
 template <int X_DT, int BITS, int ZP>
-void launch_rows(const MixedGemmArgs& p, int rows, dim3 grid, float* ws, hipStream_t stream) {
+void launch_rows(const MixedGemmArgs& p, int rows, dim3 grid, float* ws, unsigned* counters, hipStream_t stream) {
   const dim3 block(kMsThreads);
-  if (rows == 16) hipLaunchKernelGGL((mixed_skinny_kernel<X_DT, BITS, ZP, 16>), grid, block, 0, stream, p, ws);
-  else if (rows == 32) hipLaunchKernelGGL((mixed_skinny_kernel<X_DT, BITS, ZP, 32>), grid, block, 0, stream, p, ws);
-  else hipLaunchKernelGGL((mixed_skinny_kernel<X_DT, BITS, ZP, 64>), grid, block, 0, stream, p, ws);
+  if (counters) {  // one launch (rows <= 32 only: the GEMV sizes it is for); output dtype = the activation dtype or the other one
+#define CONCH_ONE(R)                                                                                                                 \
+  do {                                                                                                                               \
+    if (p.out_dtype == CONCH_DT_FP16)                                                                                                \
+      hipLaunchKernelGGL((mixed_skinny_kernel<X_DT, BITS, ZP, R, true, CONCH_DT_FP16>), grid, block, 0, stream, p, ws, counters);     \
+    else                                                                                                                             \
+      hipLaunchKernelGGL((mixed_skinny_kernel<X_DT, BITS, ZP, R, true, CONCH_DT_BF16>), grid, block, 0, stream, p, ws, counters);     \
+  } while (0)
+    if (rows == 16) CONCH_ONE(16);
+    else CONCH_ONE(32);
+#undef CONCH_ONE
+    return;
+  }
+  if (rows == 16) hipLaunchKernelGGL((mixed_skinny_kernel<X_DT, BITS, ZP, 16>), grid, block, 0, stream, p, ws, counters);
+  else if (rows == 32) hipLaunchKernelGGL((mixed_skinny_kernel<X_DT, BITS, ZP, 32>), grid, block, 0, stream, p, ws, counters);
+  else hipLaunchKernelGGL((mixed_skinny_kernel<X_DT, BITS, ZP, 64>), grid, block, 0, stream, p, ws, counters);
 }
 
 template <int X_DT, int BITS>
-void launch_zp_mode(const MixedGemmArgs& p, int rows, dim3 grid, float* ws, hipStream_t stream) {
-  if (p.zp_mode == CONCH_ZP_NONE) launch_rows<X_DT, BITS, CONCH_ZP_NONE>(p, rows, grid, ws, stream);
-  else if (p.zp_mode == CONCH_ZP_SCALAR) launch_rows<X_DT, BITS, CONCH_ZP_SCALAR>(p, rows, grid, ws, stream);
-  else launch_rows<X_DT, BITS, CONCH_ZP_TENSOR>(p, rows, grid, ws, stream);
+void launch_zp_mode(const MixedGemmArgs& p, int rows, dim3 grid, float* ws, unsigned* counters, hipStream_t stream) {
+  if (p.zp_mode == CONCH_ZP_NONE) launch_rows<X_DT, BITS, CONCH_ZP_NONE>(p, rows, grid, ws, counters, stream);
+  else if (p.zp_mode == CONCH_ZP_SCALAR) launch_rows<X_DT, BITS, CONCH_ZP_SCALAR>(p, rows, grid, ws, counters, stream);
+  else launch_rows<X_DT, BITS, CONCH_ZP_TENSOR>(p, rows, grid, ws, counters, stream);
 }
 
 }  // namespace
@@ -233,15 +311,29 @@ int launch_mixed_gemm_skinny(const MixedGemmArgs& p, hipStream_t stream) {
   const int slices = (int)((p.k + kMsSliceK - 1) / kMsSliceK);
   const int rows = p.m <= 16 ? 16 : p.m <= 32 ? 32 : 64;
   void* ws = nullptr;
-  if (int rc = get_scratch(stream, kScratchMixedSplitK, (size_t)slices * p.m * p.n * 4, &ws)) return rc;
+  const size_t bytes = (size_t)slices * p.m * p.n * 4;
+  if (int rc = get_scratch(stream, kScratchMixedSplitK, bytes, &ws)) return rc;
   const dim3 grid((unsigned)((p.n + kMsN - 1) / kMsN), (unsigned)slices, (unsigned)((p.m + rows - 1) / rows));
-  if (p.x_dtype == CONCH_DT_FP16) {
-    if (p.bits == 4) launch_zp_mode<CONCH_DT_FP16, 4>(p, rows, grid, (float*)ws, stream);
-    else launch_zp_mode<CONCH_DT_FP16, 8>(p, rows, grid, (float*)ws, stream);
-  } else {
-    if (p.bits == 4) launch_zp_mode<CONCH_DT_BF16, 4>(p, rows, grid, (float*)ws, stream);
-    else launch_zp_mode<CONCH_DT_BF16, 8>(p, rows, grid, (float*)ws, stream);
+  // CONCH_TUNE_SKINNY_MODE (shared with the scaled split-K kernel): 0 = auto, 1 = two launches, 2 / 3 = one launch.  Auto: one
+  // launch for up to 32 rows (GEMV sizes: the slab tile of a workgroup is 2-8 KiB, the last arriver's pass over the slices is
+  // cheaper than a second launch: profiles/r02/mixed_decode_one_launch.txt)
+  const int mode = tuning(CONCH_TUNE_SKINNY_MODE);
+  const bool one_launch = !p.fuse_silu && rows <= 32 && slices >= 2 && mode != 1 && bytes < ((size_t)1 << 31) &&
+                          (size_t)grid.x * grid.z <= (size_t)kMsMaxTiles;
+  unsigned* counters = nullptr;
+  if (one_launch) {
+    void* cbuf = nullptr;
+    if (int rc = get_scratch(stream, kScratchCounters, (size_t)kMsMaxTiles * 4, &cbuf, /*zero_on_alloc=*/true)) return rc;
+    counters = (unsigned*)cbuf;
   }
+  if (p.x_dtype == CONCH_DT_FP16) {
+    if (p.bits == 4) launch_zp_mode<CONCH_DT_FP16, 4>(p, rows, grid, (float*)ws, counters, stream);
+    else launch_zp_mode<CONCH_DT_FP16, 8>(p, rows, grid, (float*)ws, counters, stream);
+  } else {
+    if (p.bits == 4) launch_zp_mode<CONCH_DT_BF16, 4>(p, rows, grid, (float*)ws, counters, stream);
+    else launch_zp_mode<CONCH_DT_BF16, 8>(p, rows, grid, (float*)ws, counters, stream);
+  }
+  if (one_launch) return check_launch("mixed_gemm_skinny_one_launch");
   if (p.fuse_silu) {  // p.n = 2d columns [gate | up], C has d (caller: mixed_gemm_skinny_supported(wide) && d % 4 == 0)
     const int64_t oquads = p.m * (p.n / 8);
     if (p.out_dtype == CONCH_DT_FP16)

@@ -1286,3 +1286,22 @@ def test_static_quant_scaled_gemm_equals_the_pair(_reset_tuning, iname, xname, m
         assert (got.float() - pair.float()).abs().max().item() <= tol
     ref = oracle.scaled_gemm_ref(xq.cpu(), bt.T, sx.reshape(1, 1), sb, torch.bfloat16, bias)
     check_scaled(got, ref, in_dt, torch.bfloat16)
+
+
+@pytest.mark.parametrize(("m", "k", "n"), [(1, 4096, 4096), (8, 1024, 64), (16, 2048, 520), (20, 11008, 512), (32, 1152, 256), (3, 8192, 1376)])
+@pytest.mark.parametrize(("wname", "use_zp", "dname"), [("uint4b8", False, "f16"), ("uint4", True, "bf16"), ("uint8b128", False, "bf16")])
+def test_mixed_decode_one_launch_is_bit_identical_to_two_launches(_reset_tuning, m, k, n, wname, use_zp, dname):
+    """GEMV sizes: the reduce of the K slices inside the decode kernel (last-arriving workgroup of a tile, slice order) against
+    the separate reduce kernel; repeated launches (the counters reset themselves)."""
+    wt = WTYPES[wname]
+    a, w_ref, packed, w_s, w_zp = make_mixed_inputs(m, k, n, wt, use_zp, DT[dname])
+    dev = lambda t: None if t is None else t.cuda()  # noqa: E731
+    args = (dev(a), dev(packed), dev(w_s), dev(w_zp), wt.size_bits, wt.bias, 128)
+    _C.set_tuning(_C.TUNE_SKINNY_MODE, 1)
+    two = mixed_precision_gemm(*args)
+    _C.set_tuning(_C.TUNE_SKINNY_MODE, 2)
+    for _ in range(4):
+        assert torch.equal(mixed_precision_gemm(*args), two)
+    _C.set_tuning(_C.TUNE_SKINNY_MODE, 0)
+    assert torch.equal(mixed_precision_gemm(*args), two)
+    check_mixed(two, a, w_ref, k)
