@@ -1305,3 +1305,28 @@ def test_mixed_decode_one_launch_is_bit_identical_to_two_launches(_reset_tuning,
     _C.set_tuning(_C.TUNE_SKINNY_MODE, 0)
     assert torch.equal(mixed_precision_gemm(*args), two)
     check_mixed(two, a, w_ref, k)
+
+
+@pytest.mark.parametrize(("m", "k", "n"), [(16, 4096, 11008), (32, 8192, 8192), (8, 4096, 28672)])
+def test_mixed_decode_one_launch_with_several_workgroups_per_cu(_reset_tuning, m, k, n):
+    """688 / 1024 / 1792 workgroups of the one-launch decode kernel on 256 CUs (two to four resident per CU, several rounds):
+    the write-through / ticket / sc1-load hand-off must not depend on one workgroup per CU.  40 launches, a second stream
+    keeping some CUs busy with an unrelated GEMM half of the time, every result against the two-launch form bit for bit."""
+    wt = scalar_types.uint4b8
+    a, w_ref, packed, w_s, _ = make_mixed_inputs(m, k, n, wt, False, torch.float16)
+    args = (a.cuda(), packed.cuda(), w_s.cuda(), None, wt.size_bits, wt.bias, 128)
+    _C.set_tuning(_C.TUNE_SKINNY_MODE, 1)
+    two = mixed_precision_gemm(*args)
+    _C.set_tuning(_C.TUNE_SKINNY_MODE, 2)
+    side = torch.cuda.Stream()
+    big = torch.randn((2048, 2048), device="cuda", dtype=torch.float16)
+    outs = []
+    for i in range(40):
+        if i % 2:
+            with torch.cuda.stream(side):
+                torch.matmul(big, big)
+        outs.append(mixed_precision_gemm(*args))
+    torch.cuda.synchronize()
+    for i, o in enumerate(outs):
+        assert torch.equal(o, two), f"launch {i}"
+    check_mixed(two, a, w_ref, k)
