@@ -206,7 +206,11 @@ __global__ __launch_bounds__(kSkThreads, 1) void skinny_splitk_kernel(ScaledGemm
   static_assert(A_SRC == 0 || !FUSED, "the quantising prologue is built for the two-launch form");
   constexpr int kUnit = ROWS * kStepBytes;  // one K step of A
   constexpr int kPieces = ROWS / 32;        // 8-row x 128-byte subtiles a wave feeds per step
-  constexpr int kLds = (FUSED && STEPS * kUnit < 84 * 1024) ? 84 * 1024 : STEPS * kUnit;
+  // (Round 2 first padded the one-launch form's LDS request above half a CU, to stay in the one-workgroup-per-CU regime the
+  // guide's hand-off table was measured in.  The hand-off does not need it -- sc1 stores are at L2 once drained, sc1 loads come
+  // from L2 whatever else the CU runs; stress tests with two to four workgroups per CU -- and the padding cost up to 20 % at
+  // decode sizes: profiles/r02/splitk_one_launch_nopad.txt.)
+  constexpr int kLds = STEPS * kUnit;
   __shared__ __attribute__((aligned(1024))) char lds[kLds];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -506,7 +510,8 @@ int launch_splitk(const ScaledGemmArgs& p, int slices, hipStream_t stream) {
     // sixteen steps in flight per workgroup lose to the 8-step slices, and with 1024-byte slices (mode 2) the last arriver's
     // serial pass over four or more slabs costs more than the second launch it saves (16.0 against 13.5 us on C2)
     const int64_t wgs = ((p.n + kSpN - 1) / kSpN) * (p.k / (2 * kSpSliceK)) * ((p.m + 63) / 64);
-    mode = (p.m > 64 && p.m <= 128 && p.k % (2 * kSpSliceK) == 0 && wgs <= device_cu_count()) ? 3 : 1;
+    if (p.m <= 32) mode = (p.k >= 8192 && p.k % (2 * kSpSliceK) == 0) ? 3 : 2;  // GEMV sizes: the slab tile is 2-8 KiB, one launch wins 4-10 %
+    else mode = (p.m > 64 && p.m <= 128 && p.k % (2 * kSpSliceK) == 0 && wgs <= device_cu_count()) ? 3 : 1;
   }
   if (p.a_src_dtype) mode = 1;  // the quantising prologue lives in the two-launch form
   int steps = kSpSteps;

@@ -256,14 +256,17 @@ def test_one_launch_splitk_is_bit_identical_to_two_launches(_reset_tuning, mode,
     check_scaled(one, ref, IN_T[iname], torch.bfloat16, (a, b, sa, sb, bias))
 
 
-def test_one_launch_splitk_under_uneven_load(_reset_tuning):
-    """The hand-off must not depend on timing or placement: run it while another stream keeps the chip unevenly busy, many
-    times, against the two-launch result."""
-    a, b, sa, sb, bias = make_scaled_inputs(128, 4096, 4096, torch.int8, torch.bfloat16, False, False, False)
+@pytest.mark.parametrize(("m", "k", "n", "mode", "iname"), [(128, 4096, 4096, 2, "int8"), (16, 4096, 11008, 2, "fn"), (32, 8192, 8192, 3, "int8"),
+                                                            (8, 4096, 28672, 2, "fn")])
+def test_one_launch_splitk_under_uneven_load(_reset_tuning, m, k, n, mode, iname):
+    """The hand-off must not depend on timing, placement or on one workgroup per CU (the last three shapes run 688 - 1792
+    workgroups of 32 KiB of LDS: up to four per CU): run it while another stream keeps the chip unevenly busy, many times,
+    against the two-launch result."""
+    a, b, sa, sb, bias = make_scaled_inputs(m, k, n, IN_T[iname], torch.bfloat16, False, False, False)
     _C.set_gemm_variant(_C.VARIANT_MFMA_SKINNY)
     _C.set_tuning(_C.TUNE_SKINNY_MODE, 1)
     want = to_bits(run_scaled(a, b, sa, sb, torch.bfloat16, bias))
-    _C.set_tuning(_C.TUNE_SKINNY_MODE, 2)
+    _C.set_tuning(_C.TUNE_SKINNY_MODE, mode)
     ad, bd, sad, sbd = a.cuda(), b.T.contiguous().cuda().T, sa.cuda(), sb.cuda()
     noise_a = torch.randn(3000, 3000, device="cuda")
     side = torch.cuda.Stream()
