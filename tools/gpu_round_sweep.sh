@@ -1,4 +1,5 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out
-timeout 1800 python -m pytest tests/test_gpu_gemm.py tests/test_gpu_graph.py -x -q -m gpu -k "one_launch or splitk or every_kernel_variant or decode or graph or down_projection or static_quant or c2_config or fused" 2>&1 | tail -5 | tee gpurun_out/ol_tests.txt
+timeout 1500 python tools/dispatch_cold_sweep.py 2>&1 | grep -v amdgpu.ids > gpurun_out/dispatch_cold_sweep.txt
+grep -c "pick costs" gpurun_out/dispatch_cold_sweep.txt; grep "pick costs" gpurun_out/dispatch_cold_sweep.txt | cut -c1-300 | head -20; wc -l gpurun_out/dispatch_cold_sweep.txt
