@@ -88,7 +88,7 @@ int prepack_mixed_weights(uint32_t* image, uint32_t* plain, int64_t k, int64_t n
                           hipStream_t stream);
 int mixed_gemm_tile_nt(const MixedGemmArgs& p);
 int launch_mixed_gemm_mfma(const MixedGemmArgs& p, hipStream_t stream);
-// gemm_mixed_skinny.hip -- decode batches (M <= 64, K % 1024 == 0): weights straight to MFMA registers, split-K (variant 4)
+// gemm_mixed_skinny.hip -- decode batches (M <= 256 by a cost rule, N % 4 == 0, any K % 64 == 0): weights straight to MFMA registers, split-K (variant 4)
 bool mixed_gemm_skinny_supported(const MixedGemmArgs& p);
 int launch_mixed_gemm_skinny(const MixedGemmArgs& p, hipStream_t stream);
 int launch_f32_slab_reduce(void* c, const float* slabs, int slices, int64_t m, int64_t n, int64_t c_stride_m, int out_dtype, hipStream_t stream);
