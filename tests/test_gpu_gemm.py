@@ -1333,3 +1333,33 @@ def test_mixed_decode_one_launch_with_several_workgroups_per_cu(_reset_tuning, m
     for i, o in enumerate(outs):
         assert torch.equal(o, two), f"launch {i}"
     check_mixed(two, a, w_ref, k)
+
+
+@pytest.mark.parametrize("nt", [2, 3, 4, 5])
+@pytest.mark.parametrize(("wname", "use_zp", "dname", "group"), [("uint4b8", False, "f16", 128), ("uint4", True, "bf16", 64)])
+def test_mixed_precision_split_k_on_every_tile_shape(_reset_tuning, nt, wname, use_zp, dname, group):
+    """The split-K form on each tile shape (the 512 x 128 tile included) and with 64-element weight groups (one step per group)."""
+    if nt == 4 and use_zp:
+        pytest.skip("256-column tiles are not built for per-group zero points")
+    m, k, n = 600, 1536, 520
+    wt = WTYPES[wname]
+    a, w_ref, packed, w_s, w_zp = make_mixed_inputs(m, k, n, wt, use_zp, DT[dname], group)
+    dev = lambda t: None if t is None else t.cuda()  # noqa: E731
+    args = (dev(a), dev(packed), dev(w_s), dev(w_zp), wt.size_bits, wt.bias, group)
+    _C.set_gemm_variant(_C.VARIANT_MFMA_PINGPONG2)
+    _C.set_tuning(_C.TUNE_MIXED_TILE_NT, nt)
+    try:
+        _C.set_tuning(_C.TUNE_MIXED_SPLITK, 1)
+        whole = mixed_precision_gemm(*args)
+        outs = []
+        for split in (2, 4, 8):
+            _C.set_tuning(_C.TUNE_MIXED_SPLITK, split)
+            outs.append(mixed_precision_gemm(*args))
+    finally:
+        _C.set_tuning(_C.TUNE_MIXED_SPLITK, 0)
+        _C.set_tuning(_C.TUNE_MIXED_TILE_NT, 0)
+        _C.set_gemm_variant(_C.VARIANT_AUTO)
+    tol = 2.0 * EPS[DT[dname]] * whole.float().abs().max().item()
+    for got in outs:
+        check_mixed(got, a, w_ref, k)
+        assert (got.float() - whole.float()).abs().max().item() <= tol

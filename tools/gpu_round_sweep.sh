@@ -1,5 +1,4 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out
-timeout 1500 python tools/dispatch_cold_sweep.py 2>&1 | grep -v amdgpu.ids > gpurun_out/dispatch_cold_sweep.txt
-grep -c "pick costs" gpurun_out/dispatch_cold_sweep.txt; grep "pick costs" gpurun_out/dispatch_cold_sweep.txt | cut -c1-300 | head -20; wc -l gpurun_out/dispatch_cold_sweep.txt
+timeout 1800 python -m pytest tests/test_gpu_gemm.py -x -q -m gpu -k "split_k_on_every" 2>&1 | tail -12 | tee gpurun_out/sk_tests.txt
