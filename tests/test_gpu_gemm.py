@@ -1098,7 +1098,7 @@ def test_prepack_round_trip(bits, tile_nt, k, n):
 
 @pytest.mark.parametrize(("wname", "use_zp", "dname"), [("uint4b8", False, "f16"), ("uint4", True, "bf16"), ("uint8b128", False, "bf16"),
                                                          ("uint8", True, "f16"), ("uint4b8", False, "bf16")])
-@pytest.mark.parametrize(("m", "k", "n"), [(1024, 512, 1376), (300, 256, 520), (2048, 1024, 4096), (257, 128, 200)])
+@pytest.mark.parametrize(("m", "k", "n"), [(1024, 512, 1376), (300, 256, 520), (1100, 512, 1024), (257, 128, 200)])
 @pytest.mark.parametrize("tile_nt", [None, 2, 3])
 def test_prepacked_gemm_is_bit_identical(wname, use_zp, dname, m, k, n, tile_nt):
     wt = WTYPES[wname]
@@ -1113,7 +1113,7 @@ def test_prepacked_gemm_is_bit_identical(wname, use_zp, dname, m, k, n, tile_nt)
 
 @pytest.mark.parametrize(("wname", "use_zp", "dname"), [("uint4b8", False, "f16"), ("uint4", True, "bf16"), ("uint8b128", False, "bf16"),
                                                          ("uint8", True, "f16")])
-@pytest.mark.parametrize(("m", "k", "n"), [(2048, 1024, 4096), (1300, 256, 520), (512, 128, 128)])
+@pytest.mark.parametrize(("m", "k", "n"), [(1100, 512, 1024), (1300, 256, 520), (512, 128, 128)])
 def test_tall_tile_is_bit_identical(wname, use_zp, dname, m, k, n):
     """The 512 x 128 tile (half the dequantisation per MFMA) against the dispatcher's choice: the tile shape moves work, not the
     order in which an output accumulates its K products.  Plain weights and the 128-column pre-packed image."""
@@ -1211,7 +1211,7 @@ def test_mixed_precision_ragged_slice_ignores_inf_behind_k():
 # split-K form of the LDS-tiled mixed kernel (few tiles: M of a few hundred rows, N of a few thousand columns)
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("split", [2, 4, 8])
-@pytest.mark.parametrize(("m", "k", "n"), [(512, 4096, 1024), (300, 2048, 520), (1024, 1152, 256), (700, 4096, 4096)])
+@pytest.mark.parametrize(("m", "k", "n"), [(512, 2048, 1024), (300, 2048, 520), (1024, 1152, 256), (700, 2048, 1024)])
 @pytest.mark.parametrize(("wname", "use_zp", "dname"), [("uint4b8", False, "f16"), ("uint4", True, "bf16"), ("uint8b128", False, "bf16")])
 def test_mixed_precision_split_k(_reset_tuning, split, m, k, n, wname, use_zp, dname):
     """K slices per tile, fp32 slabs, reduce in slice order: against the oracle, against the unsplit kernel (another summation
