@@ -14,15 +14,17 @@
  * re-entrant.  Launchers never allocate USER-VISIBLE memory (docs/conch/structure.md:14-15 of the reference).
  *
  * Library scratch.  Some paths need device scratch the caller does not see: the split-K slabs of the skinny-M kernels
- * (M <= 256 scaled, M <= 256 mixed), K-contiguous copies of operands in non-native layouts, the bf16 expansion of
- * e4m3fnuz operands, the [M][2d] intermediate of an FFN pair that cannot use the fused epilogue.  It is owned by the
+ * (M <= 256 scaled, M <= 256 mixed, M <= 128 4-bit blockwise) and of the split-K form of the LDS-tiled mixed kernel (M > 256 with
+ * few tiles), K-contiguous copies of operands in non-native layouts, the bf16 expansion of e4m3fnuz operands, the dequantised
+ * weight of the dequantise-first paths (kernel modes, 4-bit matmul above 128 rows), the quantised activations and the [M][2d]
+ * intermediate of a pair that cannot use its fused form.  It is owned by the
  * library, one buffer per (device, stream, slot), allocated with hipMalloc the first time a call needs more than the
  * slot holds and never freed or moved afterwards (enqueued and graph-captured launches keep using the old buffer).
  * Consequences: (1) a call that must grow a slot does a hipMalloc -- no stream or device synchronisation -- and so is
  * NOT legal inside hipStreamBeginCapture; it fails with CONCH_ERR_INVALID_ARGUMENT there instead of breaking the
  * capture; (2) after conch_reserve_scratch(stream, bytes) with bytes >= conch_*_workspace_bytes() of every shape that
  * will be used, every entry point is allocation-free, synchronisation-free and graph-capture safe on that stream.
- * The tiled MFMA kernels on native layouts (K-contiguous A and B^T, K % 128 == 0, M > 256) never use scratch.
+ * The tiled scaled-GEMM MFMA kernels on native layouts (K-contiguous A and B^T, K % 128 == 0, M > 256) never use scratch.
  * The device a call runs on is the CURRENT device (hipSetDevice), which must be the one the pointers live on.
  *
  * Return value: CONCH_OK (0) or a conch_status_t error; conch_last_error() returns a
