@@ -58,6 +58,7 @@ _SIGNATURES = {
     "conch_device_count": (c_int, []),
     "conch_scaled_gemm_workspace_bytes": (_I64, [_I64, _I64, _I64]),
     "conch_mixed_precision_gemm_workspace_bytes": (_I64, [_I64, _I64, _I64]),
+    "conch_bnb_gemm_4bit_workspace_bytes": (_I64, [_I64, _I64, _I64]),
     "conch_reserve_scratch": (c_int, [c_void_p, _I64]),
     "conch_static_scaled_int8_quant": (c_int, [c_void_p, c_void_p, c_void_p, _I64, _I64, _I64, _I64, c_int, c_void_p]),
     "conch_static_scaled_fp8_quant": (

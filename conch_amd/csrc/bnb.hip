@@ -11,6 +11,8 @@
 // gfx950 design: 16-byte loads (8 fp16 / bf16 elements per lane), a block = a group of blocksize/8 lanes of one wave (up to
 // 512 elements; larger blocks take 2 / 4 / 8 register-resident passes of the wave), segmented wave reduction by xor shuffles,
 // one dword (4-bit) or two dwords (8-bit) stored per lane: one pass over HBM.  The code book sits in LDS.
+#include <algorithm>
+
 #include "common.hpp"
 #include "gemm.hpp"
 #include "mfma_tile.hpp"
@@ -531,6 +533,15 @@ extern "C" int conch_bnb_dequantize_blockwise(void* out, const uint8_t* xq, cons
   if (n == 0) return CONCH_OK;
   CONCH_CHECK_ARG(out && absmax && xq, "bnb_dequantize_blockwise: NULL pointer");
   return dequantize_any(out, xq, absmax, code, n, blocksize, quant_type, absmax_dtype, out_dtype, n, n, (hipStream_t)stream);
+}
+
+// Upper bound of the library scratch conch_bnb_gemm_4bit may need for this shape (see "Library scratch" in conch_amd.h): the
+// fp32 slabs of the decode kernel (M <= 128) or the dequantised weight of the dequantise-first path.
+extern "C" int64_t conch_bnb_gemm_4bit_workspace_bytes(int64_t m, int64_t n, int64_t k) {
+  if (m <= 0 || n <= 0 || k <= 0) return 0;
+  int64_t need = n * k * 2;
+  if (m <= 128) need = std::max(need, (k / kBgSliceK + 1) * m * n * 4);
+  return need + ((int64_t)1 << 20);
 }
 
 // y = x @ dequantise(W)^T for a bitsandbytes-style 4-bit weight W [N][K] (flattened, blocks of `blocksize` along the flat index,

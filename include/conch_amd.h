@@ -335,6 +335,7 @@ int conch_bnb_dequantize_blockwise(void* out, const uint8_t* xq, const void* abs
                                    int quant_type, int out_dtype, int absmax_dtype, void* stream);
 /* C[M][N] = X[M][K] @ dequantise(W)^T for a 4-bit (nf4 / fp4) weight W[N][K]: dequantised into library scratch in x_dtype, then
  * the 16-bit MFMA tile kernel (fp32 accumulation).  K % 64 == 0. */
+int64_t conch_bnb_gemm_4bit_workspace_bytes(int64_t m, int64_t n, int64_t k); /* library-scratch upper bound (conch_reserve_scratch) */
 int conch_bnb_gemm_4bit(void* c, const void* x, const uint8_t* w_packed, const void* absmax, int64_t m, int64_t n, int64_t k,
                         int64_t x_stride_m, int64_t c_stride_m, int blocksize, int quant_type, int absmax_dtype, int x_dtype,
                         int out_dtype, void* stream);
