@@ -1,8 +1,14 @@
 """Soak test of the one-launch split-K hand-offs (scaled M <= 32 / C2, mixed decode <= 32 rows): N launches of eleven shapes in random
 order, a second stream keeping the chip unevenly busy, every result compared bit for bit with the two-launch form.
 usage: python tools/soak_one_launch.py [launches]"""
-import random, sys, torch
-from conch_amd import _C
+import random
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from conch_amd import _C  # noqa: E402
 from conch_amd.ops.quantization.gemm import scaled_gemm, mixed_precision_gemm
 torch.manual_seed(0); random.seed(0)
 cases = []
