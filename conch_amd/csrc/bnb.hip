@@ -305,7 +305,7 @@ int dequantize_adt(void* out, const uint8_t* xq, const void* absmax, const float
 }
 
 // ---------------------------------------------------------------------------------------------
-// Decode-batch GEMM on the 4-bit weight (M <= 128): y = x @ dequantise(W)^T without materialising W.
+// Decode-batch GEMM on the 4-bit weight (M <= 256 by a cost rule): y = x @ dequantise(W)^T without materialising W.
 // Same construction as gemm_mixed_skinny.hip: a workgroup owns (64 columns, one 1024-element K slice, a block of 16 / 32 / 64
 // rows); the X slice is staged once by LDS-DMA; a lane of the MFMA's weight operand is (column n, 8-element k-group), and those
 // eight codes are exactly ONE 32-bit word of row n of the packed tensor (byte j = code 2j << 4 | code 2j+1).  A code becomes a
@@ -471,9 +471,15 @@ void launch_decode_adt(const BnbGemmArgs& p, int qt, int adt, int rows, dim3 gri
   else launch_decode_qt<X_DT, CONCH_DT_BF16>(p, qt, rows, grid, ws, stream);
 }
 
-// decode batches: up to two 64-row blocks, rows of four columns, whole blocks inside a row
-bool bnb_decode_supported(int64_t m, int64_t n, int64_t k, int blocksize) {
-  return m <= 128 && n % 4 == 0 && k % blocksize == 0 && n * k / 2 < ((int64_t)1 << 31);
+// decode batches: up to four 64-row blocks, rows of four columns, whole blocks inside a row.  Above 64 rows every row block
+// decodes the weight again, so the decode kernel runs only while that is cheaper than materialising the weight once and running the
+// 16-bit tile kernel on it (fitted to profiles/r02/bnb_decode_times.txt, us: 5 + 0.85e-6 N K per row block against
+// 15 K / 1024 + 0.7e-6 N K); `forced` = CONCH_TUNE_GEMM_VARIANT 4.
+bool bnb_decode_supported(int64_t m, int64_t n, int64_t k, int blocksize, bool forced) {
+  if (m > 256 || n % 4 || k % blocksize || n * k / 2 >= ((int64_t)1 << 31)) return false;
+  if (m <= 64 || forced) return true;
+  const double nk = (double)n * (double)k;
+  return (double)((m + 63) / 64) * (5.0 + 0.85e-6 * nk) < 15.0 * (double)k / 1024.0 + 0.7e-6 * nk;
 }
 
 int launch_bnb_decode_gemm(const BnbGemmArgs& p, int qt, int adt, int x_dtype, int out_dtype, hipStream_t stream) {
@@ -536,17 +542,17 @@ extern "C" int conch_bnb_dequantize_blockwise(void* out, const uint8_t* xq, cons
 }
 
 // Upper bound of the library scratch conch_bnb_gemm_4bit may need for this shape (see "Library scratch" in conch_amd.h): the
-// fp32 slabs of the decode kernel (M <= 128) or the dequantised weight of the dequantise-first path.
+// fp32 slabs of the decode kernel (M <= 256) or the dequantised weight of the dequantise-first path.
 extern "C" int64_t conch_bnb_gemm_4bit_workspace_bytes(int64_t m, int64_t n, int64_t k) {
   if (m <= 0 || n <= 0 || k <= 0) return 0;
   int64_t need = n * k * 2;
-  if (m <= 128) need = std::max(need, (k / kBgSliceK + 1) * m * n * 4);
+  if (m <= 256) need = std::max(need, (k / kBgSliceK + 1) * m * n * 4);
   return need + ((int64_t)1 << 20);
 }
 
 // y = x @ dequantise(W)^T for a bitsandbytes-style 4-bit weight W [N][K] (flattened, blocks of `blocksize` along the flat index,
 // two codes per byte): W is dequantised into library scratch in x's dtype -- its rows ARE the K-contiguous B^T the tile kernel
-// wants -- and multiplied on the 16-bit MFMA tile kernel of gemm_mfma.hip (fp32 accumulation).  Decode batches (M <= 128) skip
+// wants -- and multiplied on the 16-bit MFMA tile kernel of gemm_mfma.hip (fp32 accumulation).  Decode batches (M <= 256 by a cost rule) skip
 // the materialised weight: bnb_decode_gemm_kernel.
 extern "C" int conch_bnb_gemm_4bit(void* c, const void* x, const uint8_t* w_packed, const void* absmax, int64_t m, int64_t n, int64_t k,
                                    int64_t x_stride_m, int64_t c_stride_m, int blocksize, int quant_type, int absmax_dtype, int x_dtype,
@@ -568,12 +574,12 @@ extern "C" int conch_bnb_gemm_4bit(void* c, const void* x, const uint8_t* w_pack
   // decode batches: the weights go from the packed tensor straight into MFMA operand registers (CONCH_TUNE_GEMM_VARIANT = 2
   // forces the dequantise-first path, 4 the decode kernel)
   const int variant = tuning(CONCH_TUNE_GEMM_VARIANT);
-  if (variant != 2 && bnb_decode_supported(m, n, k, blocksize) && (((uintptr_t)c & 1) == 0) && c_stride_m >= n) {
+  if (variant != 2 && bnb_decode_supported(m, n, k, blocksize, variant == 4) && (((uintptr_t)c & 1) == 0) && c_stride_m >= n) {
     const BnbGemmArgs d{c, x, w_packed, absmax, m, n, k, x_stride_m, c_stride_m, blocksize};
     return launch_bnb_decode_gemm(d, quant_type, absmax_dtype, x_dtype, out_dtype, s);
   }
   if (variant == 4) {
-    set_error("bnb_gemm_4bit: decode kernel forced but its contract is not met (M <= 128, N %% 4 == 0, K %% blocksize == 0)");
+    set_error("bnb_gemm_4bit: decode kernel forced but its contract is not met (M <= 256, N %% 4 == 0, K %% blocksize == 0)");
     return CONCH_ERR_UNSUPPORTED;
   }
   void* wt = nullptr;

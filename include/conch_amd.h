@@ -14,7 +14,7 @@
  * re-entrant.  Launchers never allocate USER-VISIBLE memory (docs/conch/structure.md:14-15 of the reference).
  *
  * Library scratch.  Some paths need device scratch the caller does not see: the split-K slabs of the skinny-M kernels
- * (M <= 256 scaled, M <= 256 mixed, M <= 128 4-bit blockwise) and of the split-K form of the LDS-tiled mixed kernel (M > 256 with
+ * (M <= 256 scaled, M <= 256 mixed, M <= 256 4-bit blockwise) and of the split-K form of the LDS-tiled mixed kernel (M > 256 with
  * few tiles), K-contiguous copies of operands in non-native layouts, the bf16 expansion of e4m3fnuz operands, the dequantised
  * weight of the dequantise-first paths (kernel modes, 4-bit matmul above 128 rows), the quantised activations and the [M][2d]
  * intermediate of a pair that cannot use its fused form.  It is owned by the

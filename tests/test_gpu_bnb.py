@@ -165,7 +165,7 @@ def test_matmul_4bit(qt, dname, m, k, n, blocksize):
 @pytest.mark.parametrize("qt", ["nf4", "fp4"])
 @pytest.mark.parametrize(("dname", "absmax_dt"), [("f16", torch.float32), ("bf16", torch.float32), ("f16", torch.float16)])
 @pytest.mark.parametrize(("m", "k", "n", "blocksize"), [(1, 1024, 64, 64), (16, 2048, 520, 128), (33, 4096, 1376, 64), (64, 1152, 256, 128),
-                                                         (100, 1024, 260, 1024), (8, 11008, 512, 64), (128, 192, 64, 64)])
+                                                         (100, 1024, 260, 1024), (8, 11008, 512, 64), (128, 192, 64, 64), (200, 1024, 256, 64)])
 def test_matmul_4bit_decode_kernel(qt, dname, absmax_dt, m, k, n, blocksize):
     """The decode-batch kernel (M <= 128: packed codes straight into MFMA operands, no materialised weight; forced with
     variant 4 so that a contract change cannot silently skip it): per element against the fp64 product of the oracle's
@@ -194,7 +194,7 @@ def test_matmul_4bit_decode_kernel(qt, dname, absmax_dt, m, k, n, blocksize):
     bound = eps * want.abs() + (k * 2.0**-24) * (x.double().abs() @ wd.double().abs().T) + 1e-30
     assert ((got.double() - want).abs() <= bound).all()
     assert ((first.double() - want).abs() <= bound).all()
-    assert torch.equal(auto, got)  # auto = the decode kernel at these sizes
+    assert torch.equal(auto, got) or torch.equal(auto, first)  # auto = the decode kernel up to 64 rows, a cost rule above
 
 
 def test_matmul_4bit_decode_dequant_is_bit_exact():
