@@ -308,7 +308,7 @@ def nshard_c5(world: int, rank: int, device: torch.device, steps: int, warmup: i
         got = c[:band, r * n_loc : r * n_loc + 64]
         mismatches += int((want.view(torch.int16) != got.view(torch.int16)).sum().item())
     t_gemm = timed_region(lambda: op.local_gemm(a, bt_loc.T, sa, sb_loc), steps, warmup, world, device)
-    t_blocks = timed_region(lambda: op.gathered_blocks(a, bt_loc.T, sa, sb_loc), steps, warmup, world, device)
+    t_blocks = timed_region(lambda: op.gathered_panels(a, bt_loc.T, sa, sb_loc), steps, warmup, world, device)
     t_full = timed_region(lambda: op(a, bt_loc.T, sa, sb_loc), steps, warmup, world, device)
     flops = 2.0 * m * n * k
     return {

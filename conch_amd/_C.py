@@ -60,6 +60,7 @@ _SIGNATURES = {
     "conch_mixed_precision_gemm_workspace_bytes": (_I64, [_I64, _I64, _I64]),
     "conch_bnb_gemm_4bit_workspace_bytes": (_I64, [_I64, _I64, _I64]),
     "conch_reserve_scratch": (c_int, [c_void_p, _I64]),
+    "conch_reset_scratch": (c_int, [c_void_p]),
     "conch_static_scaled_int8_quant": (c_int, [c_void_p, c_void_p, c_void_p, _I64, _I64, _I64, _I64, c_int, c_void_p]),
     "conch_static_scaled_fp8_quant": (
         c_int,
@@ -225,6 +226,13 @@ def reserve_scratch(nbytes: int, device: torch.device | None = None) -> None:
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
     with torch.cuda.device(device):
         check(load().conch_reserve_scratch(current_stream_handle(device), int(nbytes)), "conch_reserve_scratch")
+
+
+def reset_scratch(device: torch.device | None = None) -> None:
+    """Zero the split-K arrival counters of torch's current stream (recovery after a launch that did not complete)."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    with torch.cuda.device(device):
+        check(load().conch_reset_scratch(current_stream_handle(device)), "conch_reset_scratch")
 
 
 def ptr(t: torch.Tensor | None) -> int | None:

@@ -96,10 +96,12 @@ __device__ __forceinline__ void store_scalar(void* p, int64_t i, float v) {
   else ((uint16_t*)p)[i] = float_to_bits16<DT>(v);
 }
 
-// 8 consecutive elements starting at `e0` (a multiple of 8); elements at or beyond `end` read as absent (valid = false)
+// 8 consecutive elements starting at `e0` (a multiple of 8); elements at or beyond `end` read as absent (valid = false).
+// `wide`: the base pointer is 16-byte aligned (grid-uniform), so the 8-element group is too; a slice such as t[1:] of a
+// contiguous tensor is not, and takes the per-element path like the ragged tail (the reference accepts any pointer)
 template <int XDT>
-__device__ __forceinline__ void load8(const void* x, int64_t e0, int64_t end, float (&f)[8]) {
-  if (e0 + 8 <= end) {
+__device__ __forceinline__ void load8(const void* x, int64_t e0, int64_t end, bool wide, float (&f)[8]) {
+  if (wide && e0 + 8 <= end) {
     if constexpr (XDT == CONCH_DT_FP32) {
       const f32x4 a = *(const f32x4*)((const float*)x + e0), b = *(const f32x4*)((const float*)x + e0 + 4);
 #pragma unroll
@@ -136,6 +138,7 @@ __global__ __launch_bounds__(kBnbThreads) void bnb_quantize_kernel(uint8_t* __re
   const int64_t span = (int64_t)PASSES * 512;           // elements per wave
   const int64_t w0 = wave * span;                       // first element of this wave
   if (w0 >= n) return;
+  const bool wide = ((uintptr_t)x & 15) == 0;
   float f[PASSES][8];
   float amax = 0.0f;
 #pragma unroll
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(kBnbThreads) void bnb_quantize_kernel(uint8_t* __re
     // the block this lane's elements belong to ends at blk_end: elements of the NEXT block never enter this one's maximum
     const int64_t blk = e0 / blocksize;
     const int64_t blk_end = min((blk + 1) * (int64_t)blocksize, n);
-    load8<XDT>(x, e0, blk_end, f[ps]);
+    load8<XDT>(x, e0, blk_end, wide, f[ps]);
 #pragma unroll
     for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(f[ps][i]));
   }
@@ -524,7 +527,7 @@ extern "C" int conch_bnb_quantize_blockwise(uint8_t* out, void* absmax, const vo
   CONCH_CHECK_ARG(float_dt(x_dtype), "bnb_quantize_blockwise: input dtype %d (want FP32 / FP16 / BF16)", x_dtype);
   if (n == 0) return CONCH_OK;
   CONCH_CHECK_ARG(out && absmax && x, "bnb_quantize_blockwise: NULL pointer");
-  CONCH_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 7) == 0, "bnb_quantize_blockwise: x must be 16-byte and out 8-byte aligned");
+  CONCH_CHECK_ARG(((uintptr_t)out & 7) == 0, "bnb_quantize_blockwise: out must be 8-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   if (x_dtype == CONCH_DT_FP32) return quantize_adt<CONCH_DT_FP32>(out, absmax, x, code, n, blocksize, quant_type, absmax_dtype, s);
   if (x_dtype == CONCH_DT_FP16) return quantize_adt<CONCH_DT_FP16>(out, absmax, x, code, n, blocksize, quant_type, absmax_dtype, s);

@@ -511,6 +511,27 @@ extern "C" int conch_reserve_scratch(void* stream, int64_t bytes) {
   return get_scratch((hipStream_t)stream, kScratchCounters, (size_t)64 * 1024, &ignored, /*zero_on_alloc=*/true);
 }
 
+// The one-launch split-K forms (gemm_skinny.hip, gemm_mixed_skinny.hip, bnb.hip) count arrivals in the 64 KiB counter slot of
+// (device, stream): zero at allocation, put back to zero by the last arriver of every tile.  A launch that did not run to
+// completion (a fault, a reset) can leave them non-zero, and every later one-launch call on that stream would then reduce a
+// tile too early or never.  This puts them back: a memset enqueued ON `stream`, behind whatever is already there.
+extern "C" int conch_reset_scratch(void* stream) {
+  int device = 0;
+  CONCH_HIP(hipGetDevice(&device));
+  void* ptr = nullptr;
+  size_t size = 0;
+  {
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    auto it = g_scratch.find(ScratchKey{device, (hipStream_t)stream, kScratchCounters});
+    if (it != g_scratch.end()) {
+      ptr = it->second.ptr;
+      size = it->second.size;
+    }
+  }
+  if (ptr) CONCH_HIP(hipMemsetAsync(ptr, 0, size, (hipStream_t)stream));
+  return CONCH_OK;
+}
+
 extern "C" int conch_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;

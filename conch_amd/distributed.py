@@ -16,7 +16,8 @@ Data movement, designed for xGMI (point-to-point links: the gather, not the GEMM
   nothing is copied before it.
 * The all-gather of panel p runs on a side stream while the GEMM of panel p+1 runs on the compute stream.
 * An all-gather concatenates along dim 0, so a gathered panel is [G, h, N/G] ("column-block major").
-  `gathered_blocks()` hands that layout out as is, for consumers that are themselves column-parallel.  `__call__`
+  `gathered_panels()` hands that layout out as is ([panels, G, h, N/G]), for consumers that are themselves
+  column-parallel; `gathered_blocks()` is the un-panelised [G, M, N/G] form (one GEMM, one gather).  `__call__`
   returns the row-major [M, N] tensor: each gathered panel is unpacked into it ([G, h, N/G] -> rows) on the side
   stream, behind its own gather and under the next panel's gather -- the one whole-matrix permuting copy of round 1
   is gone.  With world_size == 1 the GEMM writes the row-major result directly (column offset + row stride N) and
@@ -55,7 +56,8 @@ def default_panels(m: int, n_local: int, tile: int = 256, cus: int = 256) -> int
     tiles_m = -(-m // tile)
     best = 1
     for p in range(2, 9):
-        if tiles_m % p == 0 and (tiles_m // p) * tiles_n >= 0.85 * cus:
+        # a panel is a whole number of rows AND of tile rows: M = 1001 or 515 rows stay one panel
+        if m % p == 0 and (m // p) % tile == 0 and tiles_m % p == 0 and (tiles_m // p) * tiles_n >= 0.85 * cus:
             best = p
     return best
 
@@ -87,11 +89,16 @@ class NShardedScaledGemm:
         self.output_dtype = output_dtype
         self.device = torch.device(device)
         self.gemm_fn = gemm_fn
-        self.panels = panels if panels is not None else default_panels(m, self.n_local)
+        # row panels exist to overlap the gather of one panel with the GEMM of the next: with one rank there is no gather,
+        # the heuristic is not consulted and an explicit `panels` only shapes gathered_panels()' view
+        if panels is None:
+            panels = default_panels(m, self.n_local) if self.world_size > 1 else 1
+        self.panels = panels
         if self.panels < 1 or m % self.panels:
             raise ValueError(f"M={m} is not divisible into {self.panels} panels")
         self.h = m // self.panels
         g = self.world_size
+        self._blocks = None  # [G, M, N/G] staging of gathered_blocks(), allocated on first use
         self._c = torch.empty((m, n), dtype=output_dtype, device=self.device)  # row-major result
         # gather staging, one [G, h, N/G] buffer per panel (unused when world_size == 1)
         self._stage = torch.empty((self.panels, g, self.h, self.n_local), dtype=output_dtype, device=self.device) if g > 1 else None
@@ -145,14 +152,28 @@ class NShardedScaledGemm:
             rows = self._c[p * self.h : (p + 1) * self.h]
             rows.view(self.h, g, self.n_local).copy_(self._stage[p].permute(1, 0, 2))
 
-    def gathered_blocks(self, a, b_shard, scale_a, scale_b_shard, bias_shard=None) -> torch.Tensor:
+    def gathered_panels(self, a, b_shard, scale_a, scale_b_shard, bias_shard=None) -> torch.Tensor:
         """[panels, G, M/panels, N/G]: [p, g] holds rows of panel p, columns [g*N/G, (g+1)*N/G) of C -- the layout the
-        all-gather produces, with no copy at all (for column-parallel consumers)."""
+        panelised all-gathers produce, with no copy at all and every gather but the last under the next panel's GEMM
+        (for column-parallel consumers that can walk row panels)."""
         if self.world_size == 1:
             c = self.local_gemm(a, b_shard, scale_a, scale_b_shard, bias_shard)
             return c.view(self.panels, self.h, 1, self.n_local).permute(0, 2, 1, 3)
         self._run(a, b_shard, scale_a, scale_b_shard, bias_shard, unpack=False)
         return self._stage
+
+    def gathered_blocks(self, a, b_shard, scale_a, scale_b_shard, bias_shard=None) -> torch.Tensor:
+        """[G, M, N/G], whatever `panels` is: blocks[g] is rank g's [M, N/G] column block of C (columns
+        [g*N/G, (g+1)*N/G)) -- ONE GEMM into this rank's slot and ONE in-place all-gather, no copy.  The panelised,
+        overlapped form of the same data is gathered_panels()."""
+        if self.world_size == 1:
+            return self.local_gemm(a, b_shard, scale_a, scale_b_shard, bias_shard).view(1, self.m, self.n_local)
+        if self._blocks is None:
+            self._blocks = torch.empty((self.world_size, self.m, self.n_local), dtype=self.output_dtype, device=self.device)
+        slot = self._blocks[self.rank]
+        self._gemm_into(slot, a, b_shard, scale_a, scale_b_shard, bias_shard)
+        dist.all_gather_into_tensor(self._blocks.view(self.world_size * self.m, self.n_local), slot, group=self.group)
+        return self._blocks
 
     def __call__(self, a, b_shard, scale_a, scale_b_shard, bias_shard=None) -> torch.Tensor:
         """Row-major [M, N] C, identical on every rank."""

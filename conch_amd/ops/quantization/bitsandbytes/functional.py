@@ -186,9 +186,22 @@ def matmul_4bit(x: torch.Tensor, w_packed: torch.Tensor, quant_state: QuantState
         raise NotImplementedError("matmul_4bit: nf4 / fp4 weights only")
     if len(quant_state.shape) != 2 or x.dim() != 2 or x.shape[1] != quant_state.shape[1]:
         raise ValueError(f"x {tuple(x.shape)} does not multiply a weight of shape {tuple(quant_state.shape)}")
-    _C.require_device(x, w_packed, quant_state.absmax)
     n, k = quant_state.shape
     m = x.shape[0]
+    # the C entry takes no buffer sizes and the dequantise-first kernels read through raw pointers: a state that does
+    # not describe `w_packed` must fail HERE, not read device memory out of bounds
+    if quant_state.blocksize not in SUPPORTED_BLOCKSIZES:
+        raise NotImplementedError(f"Unsupported blocksize: {quant_state.blocksize} ({SUPPORTED_BLOCKSIZES = })")
+    want_bytes = (n * k + 1) // 2
+    have_bytes = w_packed.numel() * w_packed.element_size()
+    if have_bytes != want_bytes:
+        raise ValueError(f"w_packed holds {have_bytes} bytes; a 4-bit weight of shape {(n, k)} needs {want_bytes}")
+    want_blocks = -(-(n * k) // quant_state.blocksize)
+    if quant_state.absmax.numel() != want_blocks:  # nested statistics: one 8-bit code per block, the same count
+        raise ValueError(
+            f"absmax has {quant_state.absmax.numel()} entries; {n * k} elements in blocks of {quant_state.blocksize} need {want_blocks}"
+        )
+    _C.require_device(x, w_packed, quant_state.absmax)
     absmax = _resolve_absmax(quant_state).contiguous()
     if x.stride(1) != 1:
         x = x.contiguous()

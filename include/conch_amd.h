@@ -24,6 +24,12 @@
  * NOT legal inside hipStreamBeginCapture; it fails with CONCH_ERR_INVALID_ARGUMENT there instead of breaking the
  * capture; (2) after conch_reserve_scratch(stream, bytes) with bytes >= conch_*_workspace_bytes() of every shape that
  * will be used, every entry point is allocation-free, synchronisation-free and graph-capture safe on that stream.
+ * (3) Scratch belongs to the STREAM the call was made on, and that includes the arrival counters and partial-sum slabs of
+ * the one-launch split-K forms, whose addresses are baked into a captured graph.  Replay a captured graph on its CAPTURE
+ * stream (or make sure no other conch call of that stream's is in flight while it replays elsewhere): two launches that
+ * share counters and slabs and are not ordered by a stream race.  The counters are zero between launches by construction
+ * (the last arriver of a tile puts its counter back); after a launch that did not complete (device fault / reset) call
+ * conch_reset_scratch(stream) before using that stream's one-launch forms again.
  * The tiled scaled-GEMM MFMA kernels on native layouts (K-contiguous A and B^T, K % 128 == 0, M > 256) never use scratch.
  * The device a call runs on is the CURRENT device (hipSetDevice), which must be the one the pointers live on.
  *
@@ -157,6 +163,9 @@ int64_t conch_scaled_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k);
 int64_t conch_mixed_precision_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k);
 /* Grow every scratch slot of (current device, stream) to at least `bytes` now (hipMalloc; not inside capture). */
 int conch_reserve_scratch(void* stream, int64_t bytes);
+/* Zero the split-K arrival counters of (current device, stream) with a memset enqueued on `stream` (recovery after an
+ * incomplete launch; see "Library scratch" (3)).  A stream that never used a one-launch form has none: CONCH_OK. */
+int conch_reset_scratch(void* stream);
 
 /*
  * static_scaled_int8_quant  (replaces kernels/quantization/int8.py:63-97;

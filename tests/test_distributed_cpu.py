@@ -48,13 +48,20 @@ def _worker(rank: int, world: int, port: int, in_dtype_name: str) -> None:
                 got = op(a, b[:, lo:hi], sa, sb[lo:hi], bias[lo:hi])
                 assert got.shape == (m, n)
                 assert torch.equal(got.view(torch.int16), full.view(torch.int16)), f"rank {rank}: gathered C differs"
-            blocks = op.gathered_blocks(a, b[:, lo:hi], sa, sb[lo:hi], bias[lo:hi])
-            assert blocks.shape == (panels, world, m // panels, n // world)
+            pan = op.gathered_panels(a, b[:, lo:hi], sa, sb[lo:hi], bias[lo:hi])
+            assert pan.shape == (panels, world, m // panels, n // world)
             for p in range(panels):
                 rows = slice(p * (m // panels), (p + 1) * (m // panels))
                 for g in range(world):
                     glo, ghi = shard_bounds(n, world, g)
-                    assert torch.equal(blocks[p, g].view(torch.int16), full[rows, glo:ghi].contiguous().view(torch.int16))
+                    assert torch.equal(pan[p, g].view(torch.int16), full[rows, glo:ghi].contiguous().view(torch.int16))
+            # the un-panelised contract: blocks[g] is rank g's [M, N/G] block whatever `panels` is
+            for _ in range(2):
+                blocks = op.gathered_blocks(a, b[:, lo:hi], sa, sb[lo:hi], bias[lo:hi])
+                assert blocks.shape == (world, m, n // world)
+                for g in range(world):
+                    glo, ghi = shard_bounds(n, world, g)
+                    assert torch.equal(blocks[g].view(torch.int16), full[:, glo:ghi].contiguous().view(torch.int16))
         # scalar scale_a is not sliced per panel
         op = NShardedScaledGemm(m, n, torch.bfloat16, torch.device("cpu"), gemm_fn=oracle.scaled_gemm_ref, panels=2)
         s1 = torch.tensor([[0.5]])
@@ -89,8 +96,48 @@ def test_world1_writes_row_major_result_directly():
     op = NShardedScaledGemm(m, n, torch.bfloat16, torch.device("cpu"), gemm_fn=oracle.scaled_gemm_ref, panels=2)
     got = op(a, b, sa, sb)
     assert torch.equal(got.view(torch.int16), full.view(torch.int16))
+    pan = op.gathered_panels(a, b, sa, sb)
+    assert pan.shape == (2, 1, 16, 48) and torch.equal(pan[1, 0].view(torch.int16), full[16:].view(torch.int16))
     blocks = op.gathered_blocks(a, b, sa, sb)
-    assert blocks.shape == (2, 1, 16, 48) and torch.equal(blocks[1, 0].view(torch.int16), full[16:].view(torch.int16))
+    assert blocks.shape == (1, m, n) and torch.equal(blocks[0].view(torch.int16), full.view(torch.int16))
     # C5 on 8 GPUs: 32 x 14 tiles per rank -> two panels of 224 tiles; C3 on one GPU: no split
     assert default_panels(8192, 3584) == 2
     assert default_panels(256, 3584) == 1
+
+
+def test_default_panels_only_returns_divisors_of_m():
+    """the heuristic counted tile rows (ceil(M / 256)) and could return a panel count M is not divisible by."""
+    from conch_amd.distributed import default_panels
+
+    assert default_panels(515, 65536) == 1     # 3 tile rows, 515 % 3 != 0
+    assert default_panels(1001, 28672) == 1
+    assert default_panels(768, 65536) == 3     # whole tile rows per panel
+    for m in (1, 255, 257, 1001, 4096, 8192, 12288, 999999):
+        for n_local in (64, 3584, 28672, 65536):
+            p = default_panels(m, n_local)
+            assert p >= 1 and m % p == 0
+    # default arguments must construct for any M (one rank: no panels are used at all)
+    for m, n in ((1001, 28672), (515, 65536), (7, 8)):
+        op = NShardedScaledGemm(m, n, torch.bfloat16, torch.device("cpu"), gemm_fn=oracle.scaled_gemm_ref)
+        assert op.panels == 1
+
+
+def _odd_m_worker(rank: int, world: int, port: int) -> None:
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(1)
+        m, k, n = 77, 64, 8192  # odd M, wide N: default panels must fall back to 1, not raise
+        a = torch.randint(-32, 32, (m, k), dtype=torch.int8)
+        b = torch.randint(-32, 32, (n, k), dtype=torch.int8).T
+        sa, sb = 0.25 * torch.rand(m, 1), 0.25 * torch.rand(n, 1)
+        full = oracle.scaled_gemm_ref(a, b, sa, sb, torch.bfloat16, None)
+        op = NShardedScaledGemm(m, n, torch.bfloat16, torch.device("cpu"), gemm_fn=oracle.scaled_gemm_ref)
+        lo, hi = op.lo, op.hi
+        assert torch.equal(op(a, b[:, lo:hi], sa, sb[lo:hi]).view(torch.int16), full.view(torch.int16))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_nsharded_gemm_world2_odd_m_default_panels():
+    mp.spawn(_odd_m_worker, args=(2, _free_port()), nprocs=2, join=True)

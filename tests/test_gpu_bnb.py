@@ -222,3 +222,24 @@ def test_matmul_4bit_decode_dequant_is_bit_exact():
             want = wd[:, cols].T.contiguous()
             want = torch.where(want == 0, torch.zeros_like(want), want)  # fp4 has a -0 code; a sum of products returns +0
             np.testing.assert_array_equal(to_bits(got), to_bits(want), err_msg=f"{qt} {dname} {absmax_dt}")
+
+
+@pytest.mark.parametrize("dname", list(DT))
+@pytest.mark.parametrize("qt", QTYPES)
+@pytest.mark.parametrize("shift", [1, 3])
+def test_quantize_blockwise_takes_a_misaligned_slice(dname, qt, shift):
+    """t[shift:] of a contiguous tensor is contiguous but not 16-byte aligned; the reference takes any pointer.
+    The kernel falls back to per-element loads for such a base and must produce the same codes and absmax."""
+    seed_everything(5)
+    blocksize, n = 64, 64 * 37 + 10
+    base = torch.randn((n + shift,), dtype=DT[dname])
+    if qt == "fp4":
+        base = base.uniform_(-1.0, 1.0)
+    x = base[shift:]
+    code = _create_dynamic_map() if qt == "fp8" else None
+    want_q, want_absmax = oracle.quantize_blockwise_ref(x.clone(), blocksize, qt, code)
+    xd = base.cuda()[shift:]
+    assert xd.data_ptr() % 16 != 0 and xd.is_contiguous()
+    got_q, state = quantize_blockwise(xd, blocksize=blocksize, quant_type=qt, code=None if code is None else code.cuda())
+    np.testing.assert_array_equal(to_bits(state.absmax), to_bits(want_absmax.to(state.absmax.dtype)))
+    np.testing.assert_array_equal(got_q.cpu().numpy().reshape(-1), want_q.numpy().reshape(-1))

@@ -970,9 +970,12 @@ def test_nsharded_gemm_world1_equals_scaled_gemm():
         op = NShardedScaledGemm(m, n, torch.bfloat16, torch.device("cuda"), panels=panels)
         got = op(ad, bd, sad, sbd, biasd)
         np.testing.assert_array_equal(to_bits(got), to_bits(want))
+        pan = op.gathered_panels(ad, bd, sad, sbd, biasd)
+        assert pan.shape == (panels, 1, m // panels, n)
+        np.testing.assert_array_equal(to_bits(pan[panels - 1, 0]), to_bits(want[m - m // panels:]))
         blocks = op.gathered_blocks(ad, bd, sad, sbd, biasd)
-        assert blocks.shape == (panels, 1, m // panels, n)
-        np.testing.assert_array_equal(to_bits(blocks[panels - 1, 0]), to_bits(want[m - m // panels:]))
+        assert blocks.shape == (1, m, n)
+        np.testing.assert_array_equal(to_bits(blocks[0]), to_bits(want))
 
 
 # ---------------------------------------------------------------------------------------------

@@ -94,3 +94,25 @@ def test_scratch_growth_inside_a_capture_is_refused_not_fatal():
     graph2.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, want)
+
+
+def test_reset_scratch_is_harmless_between_one_launch_calls():
+    """conch_reset_scratch zeroes the arrival counters of the current stream with a memset ordered ON that stream: between two
+    one-launch split-K calls it changes nothing (the counters are zero there by construction); on a stream that never used a
+    one-launch form it is a no-op."""
+    seed_everything(13)
+    m, k, n = 16, 4096, 4096  # M <= 32: the one-launch split-K form
+    dev = torch.device("cuda")
+    a = torch.randint(-32, 32, (m, k), dtype=torch.int8, device=dev)
+    bt = torch.randint(-32, 32, (n, k), dtype=torch.int8, device=dev)
+    sa, sb = 0.25 * torch.rand((m, 1), device=dev), 0.25 * torch.rand((n, 1), device=dev)
+    want = scaled_gemm(a, bt.T, sa, sb, torch.bfloat16)
+    for _ in range(3):
+        _C.reset_scratch()
+        got = scaled_gemm(a, bt.T, sa, sb, torch.bfloat16)
+        assert torch.equal(got, want)
+    fresh = torch.cuda.Stream()
+    with torch.cuda.stream(fresh):
+        _C.reset_scratch()
+        _C.reset_scratch()
+    fresh.synchronize()

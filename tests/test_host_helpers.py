@@ -253,3 +253,35 @@ def test_bnb_dynamic_map_and_shapes(golden):
     assert lib.conch_bnb_quantize_blockwise(None, None, None, None, 128, 96, 0, _C.DT_FP16, _C.DT_FP32, None) == 1
     assert lib.conch_bnb_dequantize_blockwise(None, None, None, None, 128, 64, 2, _C.DT_FP16, _C.DT_FP32, None) == 1  # no code book
     assert lib.conch_bnb_dequantize_blockwise(None, None, None, None, 0, 64, 0, _C.DT_FP16, _C.DT_FP32, None) == 0
+
+
+def test_matmul_4bit_rejects_states_that_do_not_describe_the_weight():
+    """the C entry takes no buffer sizes, so a packed tensor / absmax vector / blocksize that does not match
+    quant_state.shape must be refused in Python, before any device pointer is formed (runs without a GPU)."""
+    from conch_amd.ops.quantization.bitsandbytes.functional import QuantState, matmul_4bit
+
+    n, k, bs = 64, 128, 64
+    x = torch.zeros((4, k), dtype=torch.float16)
+    wq = torch.zeros((n * k // 2,), dtype=torch.uint8)
+    absmax = torch.ones((n * k // bs,), dtype=torch.float32)
+
+    def state(**kw):
+        base = {"absmax": absmax, "shape": torch.Size((n, k)), "dtype": torch.float16, "blocksize": bs, "quant_type": "nf4", "code": None}
+        base.update(kw)
+        return QuantState(**base)
+
+    with pytest.raises(ValueError, match="w_packed holds"):
+        matmul_4bit(x, wq[:-1], state())
+    with pytest.raises(ValueError, match="w_packed holds"):
+        matmul_4bit(x, torch.zeros((n * k,), dtype=torch.uint8), state())
+    with pytest.raises(ValueError, match="absmax has"):
+        matmul_4bit(x, wq, state(absmax=absmax[:-1]))
+    with pytest.raises(ValueError, match="absmax has"):
+        matmul_4bit(x, wq, state(blocksize=128))  # absmax sized for blocks of 64
+    with pytest.raises(NotImplementedError, match="blocksize"):
+        matmul_4bit(x, wq, state(blocksize=96))
+    with pytest.raises(ValueError, match="does not multiply"):
+        matmul_4bit(x[:, :-1], wq, state())
+    # a consistent state gets past the size checks and is refused only for living on the CPU
+    with pytest.raises((RuntimeError, ValueError), match="(?i)device|cuda|rocm|gpu"):
+        matmul_4bit(x, wq, state())
