@@ -36,13 +36,16 @@ def _stale(target: Path, deps: list[Path]) -> bool:
 PROBE_LIB = PKG / "libconch_amd_probe.so"
 
 
-def build(force: bool = False, verbose: bool = False, probe: bool = False, variant: str | None = None, defines: tuple[str, ...] = ()) -> Path:
+def build(force: bool = False, verbose: bool = False, probe: bool = False, variant: str | None = None, defines: tuple[str, ...] = (),
+          only: tuple[str, ...] = ()) -> Path:
     """Compile every HIP source for gfx950 and link the shared library.  Returns its path.
 
     `probe=True` builds the DIAGNOSTIC twin libconch_amd_probe.so (-DCONCH_CLOCK_PROBE: in-kernel clock stamps
     around the GEMM K loops, read by tools/clock_probe.py); the product library never contains them.
     `variant="x", defines=("-DFOO",)` builds libconch_amd_x.so with extra macros, for interleaved A/B runs of an experiment
-    against the product library in one process (tools/ab_lib.py); never loaded by the package itself.
+    against the product library in one process (tools/ab_lib.py); never loaded by the package itself.  `only=("gemm_mfma.hip",)`
+    recompiles just those sources with the macros and links the product build's objects for the rest (the macros of an
+    experiment live in one or two files; a full rebuild per variant costs minutes).
     """
     headers = sorted(CSRC.glob("*.hpp")) + [ROOT / "include" / "conch_amd.h", Path(__file__)]
     objdir = PKG / ("build_probe" if probe else "build")
@@ -56,6 +59,8 @@ def build(force: bool = False, verbose: bool = False, probe: bool = False, varia
 
     def compile_one(src: str) -> Path:
         s = CSRC / src
+        if variant and only and src not in only:
+            return PKG / "build" / (s.stem + ".o")  # the product build's object (built below if missing)
         o = objdir / (s.stem + ".o")
         if force or _stale(o, [s, *headers]):
             cmd = [HIPCC, *flags, "-c", str(s), "-o", str(o)]
@@ -64,6 +69,8 @@ def build(force: bool = False, verbose: bool = False, probe: bool = False, varia
             subprocess.run(cmd, check=True)
         return o
 
+    if variant and only:
+        build(verbose=verbose)  # the objects the variant borrows
     with ThreadPoolExecutor(max_workers=min(4, len(SOURCES))) as pool:
         objs = list(pool.map(compile_one, SOURCES))
     if force or _stale(lib, objs):
@@ -77,7 +84,8 @@ def build(force: bool = False, verbose: bool = False, probe: bool = False, varia
 if __name__ == "__main__":
     if "--variant" in sys.argv:  # python -m conch_amd._build --variant NAME -DMACRO ...
         name = sys.argv[sys.argv.index("--variant") + 1]
-        print(build(force="--force" in sys.argv, verbose=True, variant=name, defines=tuple(a for a in sys.argv if a.startswith("-D"))))
+        only = tuple(sys.argv[sys.argv.index("--only") + 1].split(",")) if "--only" in sys.argv else ()
+        print(build(force="--force" in sys.argv, verbose=True, variant=name, defines=tuple(a for a in sys.argv if a.startswith("-D")), only=only))
         sys.exit(0)
     # both libraries by default: the diagnostic twin must export the same C ABI as the product library (bench.py opens it
     # through the same ctypes declarations); --probe / --product build one of them only

@@ -130,6 +130,20 @@ __device__ __forceinline__ void epilogue_park(char* lds, const EpiPrefetch& e) {
   if (t >= 256) f[t + 256] = bits16_to_float<OUT_DT>((uint16_t)bits);
 }
 
+// 16-byte C store.  Experiment builds (python -m conch_amd._build --variant X -DCONCH_EXP_C_STORE=n) pick the cache policy:
+// 1 = sc1 (write-through, the line is dropped from the XCD's L2), 2 = nt, 3 = sc0 sc1; the product build stores plainly.
+__device__ __forceinline__ void store_c16(uint16_t* dst, const i32x4& pk) {
+#if defined(CONCH_EXP_C_STORE) && CONCH_EXP_C_STORE == 1
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(pk) : "memory");
+#elif defined(CONCH_EXP_C_STORE) && CONCH_EXP_C_STORE == 2
+  asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(pk) : "memory");
+#elif defined(CONCH_EXP_C_STORE) && CONCH_EXP_C_STORE == 3
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(pk) : "memory");
+#else
+  *(i32x4*)dst = pk;
+#endif
+}
+
 template <int MMA, int OUT_DT, int NT = 4>
 __device__ __forceinline__ void epilogue(const typename AccT<MMA>::type (&acc)[8][4], const ScaledGemmArgs& p, const char* lds,
                                          int bm0, int bn0, int wr, int wc, int lane, int epi_off = kEpiOff) {
@@ -203,7 +217,7 @@ __device__ __forceinline__ void epilogue(const typename AccT<MMA>::type (&acc)[8
       if (m < p.m) {
         uint16_t* dst = (uint16_t*)p.c + (int64_t)m * p.c_stride_m + n0;
         if (vec_store && n0 + 8 <= p.n) {
-          *(i32x4*)dst = pk;
+          store_c16(dst, pk);
         } else {
 #pragma unroll
           for (int e = 0; e < 8; ++e)
@@ -214,70 +228,122 @@ __device__ __forceinline__ void epilogue(const typename AccT<MMA>::type (&acc)[8
   }
 }
 
-// Row-major epilogue through LDS (256-column tiles of the ping-pong kernels, whose last barrier guarantees that no wave still
-// reads operand LDS).  The accumulator layout gives a lane 8 consecutive columns of ONE row, so a 16-lane quarter of a direct
-// store instruction touches 16 different 128-byte lines -- measured 4.0-4.2 us per 128 KiB tile and CU, ~16 B/clk, a tenth of
-// the tile's time (profiles/r02/probe_boundary.txt).  Here every wave parks its 128 x 64 sub-tile (already scaled, cast and
-// biased: the same arithmetic, bit for bit) in its own 16 KiB of the dead operand buffers with conflict-free ds_write_b128
-// (16-byte chunk index XOR row & 7), reads it back row-wise with conflict-free ds_read_b128 and stores 8 rows x 128 bytes per
-// instruction: whole lines, two per quarter-wave.  No barrier: a wave only touches its own region.
-template <int MMA, int OUT_DT>
-__device__ __forceinline__ void epilogue_rows(const typename AccT<MMA>::type (&acc)[8][4], const ScaledGemmArgs& p, char* lds,
-                                              int bm0, int bn0, int wr, int wc, int lane, int wave, int epi_off = kEpiOff) {
+// Row-major epilogue through LDS (256-column tiles of the ping-pong kernels).  The accumulator layout gives a lane 8 consecutive
+// columns of ONE row, so a 16-lane quarter of a direct store instruction touches 16 different 128-byte lines, and that access
+// shape -- not the chip, not the XCD -- is what bounds the direct epilogue: tools/micro/store_rate.hip
+// (profiles/r03/store_rate.txt) stores one 128 KiB tile per CU in 4.0 us (13.6 B/clk/CU) whether 1 or 256 CUs do it, while
+// 8 rows x 128 bytes per instruction (whole lines, two per quarter-wave) take 1.0 us on a lone CU and 2.4 us when all 256 CUs
+// burst together.  Here a wave passes its 128 x 64 sub-tile (already scaled, cast and biased: the same arithmetic, bit for bit)
+// through ONE 2 KiB LDS buffer of its own, sixteen rows at a time: conflict-free ds_write_b128 in accumulator order (16-byte
+// chunk index XOR row & 7), conflict-free ds_read_b128 row-wise, `buffer_store_dwordx4` of whole lines.  A wave's LDS
+// instructions execute in issue order, so one buffer is enough (block b is written behind the read of block b - 1) and no
+// barrier is needed; the loop is a software pipeline -- read back block b - 1, convert and park block b, store block b - 1 --
+// so the store queue fills from the second block on.  Stores are write-through (`sc1`): C is never re-read by this kernel,
+// and lines that do not stay in the XCD's L2 leave it to the operand panels (C3: K loop 36.5 -> 35.2 us, held clock 2.07 ->
+// 2.14 GHz; profiles/r03/probe_epilogue.txt).  The per-store address is one VGPR offset, fixed per lane, plus a scalar.
+// `stage_off`: byte offset of 16 KiB of LDS nobody else touches during the epilogue (plain launch: the dead operand buffers,
+// behind the kernel's last barrier; persistent walk: the spare LDS behind the parked scales, the operand ring being refilled).
+// Tiles that are not whole (ragged M / N), unaligned C rows and C buffers beyond 4 GiB take the direct epilogue.
+#ifdef CONCH_EXP_C_AUX  // experiment builds: another cache policy for the whole-line C stores
+constexpr int kCStoreAux = CONCH_EXP_C_AUX;
+#else
+constexpr int kCStoreAux = 16;  // cache-policy bits of the C stores: 16 = sc1 (write-through), 0 = default, 2 = nt
+#endif
+
+__device__ __forceinline__ bool tile_stores_whole_lines(const ScaledGemmArgs& p, int bm0, int bn0) {
+  return (p.c_stride_m % 8 == 0) && (((uintptr_t)p.c & 15) == 0) && bm0 + kTileM <= (int)p.m && bn0 + kTileN <= (int)p.n &&
+         ((p.m - 1) * p.c_stride_m + p.n) * 2 < ((int64_t)1 << 32);
+}
+
+template <int MMA, int OUT_DT, bool BIAS>
+__device__ __forceinline__ void epilogue_rows_body(const typename AccT<MMA>::type (&acc)[8][4], const ScaledGemmArgs& p, char* lds,
+                                                   int stage_off, int bm0, int bn0, int wr, int wc, int lane, int wave, int epi_off) {
   asm volatile("" : "+v"(lane));  // lane-constant addresses are formed HERE, not hoisted above the K loop (and spilled across it)
   const int g = lane >> 4, jm = lane & 15;
-  const bool vec_store = (p.c_stride_m % 8 == 0) && (((uintptr_t)p.c & 15) == 0);
-  const bool has_bias = p.bias != nullptr;
-  const float* lsa = (const float*)(lds + epi_off);
-  const float* lsb = lsa + 256;
-  const float* lbias = lsa + 512;
-  char* region = lds + wave * 16384;
+  const int rr = lane >> 3, ch = lane & 7;
+  const float* lsa = (const float*)(lds + epi_off) + wr * 128 + jm;
+  const float* lsb = (const float*)(lds + epi_off) + 256;
+  const float* lbias = lsb + 256;
+  const int region = stage_off + wave * 2048;                  // byte offsets from the 1024-aligned LDS base
+  const int woff = region + jm * 128 + ((g ^ (jm & 7)) * 16);  // column half 0; half 1 is chunk + 4 = this offset ^ 64
+  const int roff = region + rr * 128 + ((ch ^ rr) * 16);       // rows rr (and rr + 8: + 1024), logical chunk ch
+  f32x4 sbv[2][2], bsv[2][2];  // [column half nh][low / high four columns]
 #pragma unroll
   for (int nh = 0; nh < 2; ++nh) {
     const int nl = wc * 64 + nh * 32 + 8 * g;
-    const f32x4 sb_lo = *(const f32x4*)(lsb + nl), sb_hi = *(const f32x4*)(lsb + nl + 4);
-    const f32x4 bs_lo = *(const f32x4*)(lbias + nl), bs_hi = *(const f32x4*)(lbias + nl + 4);
+    sbv[nh][0] = *(const f32x4*)(lsb + nl);
+    sbv[nh][1] = *(const f32x4*)(lsb + nl + 4);
+    if constexpr (BIAS) {
+      bsv[nh][0] = *(const f32x4*)(lbias + nl);
+      bsv[nh][1] = *(const f32x4*)(lbias + nl + 4);
+    }
+  }
+  const int stride_b = (int)p.c_stride_m * 2;
+  const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.c, 0, (uint32_t)(((p.m - 1) * p.c_stride_m + p.n) * 2), 0x00020000);
+  const int voff = (bm0 + wr * 128 + rr) * stride_b + (bn0 + wc * 64 + ch * 8) * 2;
+  const int step8 = 8 * stride_b;  // scalar: eight rows further down
+  i32x4 rd0, rd1;
 #pragma unroll
-    for (int mt = 0; mt < 8; ++mt) {
-      const int row = mt * 16 + jm;  // row of the wave's sub-tile
-      const float sa = lsa[wr * 128 + row];
-      i32x4 pk;
+  for (int b = 0; b < 9; ++b) {
+    if (b >= 1) {  // block b - 1 back, row-wise: lands under the conversion below
+      rd0 = *(const i32x4*)(lds + roff);
+      rd1 = *(const i32x4*)(lds + roff + 1024);
+    }
+    if (b < 8) {   // convert block b and park it (behind the read above in LDS order: same buffer)
+      const float sa = lsa[b * 16];
+      i32x4 pk[2];
+      // the eight column pairs are independent chains of {multiply, multiply, convert}: one straight-line block, so that
+      // hipcc interleaves them instead of padding every dependent pair with s_nop
+      f32x2 v[2][4];
 #pragma unroll
-      for (int e2 = 0; e2 < 4; ++e2) {
-        const int e = 2 * e2;
-        const f32x2 a2 = {(float)acc[mt][nh * 2 + (e >> 2)][e & 3], (float)acc[mt][nh * 2 + (e >> 2)][(e & 3) + 1]};
-        const f32x2 sb2 = e < 4 ? f32x2{sb_lo[e & 3], sb_lo[(e & 3) + 1]} : f32x2{sb_hi[e & 3], sb_hi[(e & 3) + 1]};
-        f32x2 v = f32x2{sa, sa} * a2;  // scaled_gemm.py:21
-        v = pin_f32x2(sb2 * v);        // :22
-        uint32_t h = pack2_bits16<OUT_DT>(v);  // :23
-        if (has_bias) {                // :24-25
-          const f32x2 b2 = e < 4 ? f32x2{bs_lo[e & 3], bs_lo[(e & 3) + 1]} : f32x2{bs_hi[e & 3], bs_hi[(e & 3) + 1]};
-          h = pack2_bits16<OUT_DT>(pin_f32x2(unpack2_bits16<OUT_DT>(h) + b2));
+      for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+          const int e = 2 * e2;
+          const f32x2 a2 = {(float)acc[b][nh * 2 + (e >> 2)][e & 3], (float)acc[b][nh * 2 + (e >> 2)][(e & 3) + 1]};
+          v[nh][e2] = f32x2{sa, sa} * a2;  // scaled_gemm.py:21
         }
-        pk[e2] = (int)h;
-      }
-      *(i32x4*)(region + row * 128 + (((nh * 4 + g) ^ (row & 7)) * 16)) = pk;
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+          const int e = 2 * e2;
+          const f32x2 sb2 = {sbv[nh][e >> 2][e & 3], sbv[nh][e >> 2][(e & 3) + 1]};
+          v[nh][e2] = pin_f32x2(sb2 * v[nh][e2]);  // :22 (rounded to fp32 before the cast, like torch)
+        }
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+          const int e = 2 * e2;
+          uint32_t h = pack2_bits16<OUT_DT>(v[nh][e2]);  // :23
+          if constexpr (BIAS) {                          // :24-25, added in the output dtype
+            const f32x2 b2 = {bsv[nh][e >> 2][e & 3], bsv[nh][e >> 2][(e & 3) + 1]};
+            h = pack2_bits16<OUT_DT>(pin_f32x2(unpack2_bits16<OUT_DT>(h) + b2));
+          }
+          pk[nh][e2] = (int)h;
+        }
+      *(i32x4*)(lds + woff) = pk[0];
+      *(i32x4*)(lds + (woff ^ 64)) = pk[1];
+    }
+    if (b >= 1) {
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rd0), rc, voff, (2 * b - 2) * step8, kCStoreAux);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rd1), rc, voff, (2 * b - 1) * step8, kCStoreAux);
     }
   }
-  // read back row-wise: instruction i covers rows 8 i .. 8 i + 7, lane = (row 8 i + lane / 8, 16-byte chunk lane & 7)
-  const int rr = lane >> 3, ch = lane & 7;
-  const int n0 = bn0 + wc * 64 + ch * 8;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int row = i * 8 + rr;
-    const i32x4 v = *(const i32x4*)(region + row * 128 + ((ch ^ rr) * 16));
-    const int m = bm0 + wr * 128 + row;
-    if (m < p.m) {
-      uint16_t* dst = (uint16_t*)p.c + (int64_t)m * p.c_stride_m + n0;
-      if (vec_store && n0 + 8 <= p.n) {
-        *(i32x4*)dst = v;
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (n0 + e < p.n) dst[e] = (uint16_t)((uint32_t)v[e >> 1] >> (16 * (e & 1)));
-      }
-    }
-  }
+}
+
+template <int MMA, int OUT_DT>
+__device__ __forceinline__ void epilogue_rows(const typename AccT<MMA>::type (&acc)[8][4], const ScaledGemmArgs& p, char* lds,
+                                              int stage_off, int bm0, int bn0, int wr, int wc, int lane, int wave,
+                                              int epi_off = kEpiOff) {
+  if (!tile_stores_whole_lines(p, bm0, bn0))  // workgroup-uniform
+    epilogue<MMA, OUT_DT, 4>(acc, p, lds, bm0, bn0, wr, wc, lane, epi_off);
+  else if (p.bias)
+    epilogue_rows_body<MMA, OUT_DT, true>(acc, p, lds, stage_off, bm0, bn0, wr, wc, lane, wave, epi_off);
+  else
+    epilogue_rows_body<MMA, OUT_DT, false>(acc, p, lds, stage_off, bm0, bn0, wr, wc, lane, wave, epi_off);
 }
 
 // Fused gate/up epilogue (scaled_gemm_silu_and_mul): the lane's accumulator tiles 0,1 are the gate values and tiles 2,3
@@ -390,9 +456,21 @@ __device__ __forceinline__ BlockSetup setup_block(const ScaledGemmArgs& p, const
     s.bn0 = tc.tn * tile_n;
   }
   const int lda = (int)p.a_stride_m, ldb = (int)p.b_stride_n;
-  if (s.narrow) s.so = make_stage_offsets(s.wave, s.lane, s.bm0, s.bn0, (int)p.m - 1, (int)p.n - 1, lda, ldb, 48, 32);
-  else if (p.fuse_silu) s.so = make_stage_offsets(s.wave, s.lane, s.bm0, s.bn0, (int)p.m - 1, (int)p.n - 1, lda, ldb, 32, (int)p.n);
-  else s.so = make_stage_offsets(s.wave, s.lane, s.bm0, s.bn0, (int)p.m - 1, (int)p.n - 1, lda, ldb);
+  // timing experiments (wrong results by construction; never in the product build): every tile stages the operand panels
+  // of tile (0, 0) [1], of its own row and column 0 [2], or of the first tile of its 4 x 8 block [3] -- an upper bound on
+  // what serving the operand stream from L2 instead of the Infinity Cache is worth
+#if defined(CONCH_EXP_SAME_PANELS) && CONCH_EXP_SAME_PANELS == 1
+  const int sbm0 = 0, sbn0 = 0;
+#elif defined(CONCH_EXP_SAME_PANELS) && CONCH_EXP_SAME_PANELS == 2
+  const int sbm0 = s.bm0, sbn0 = 0;
+#elif defined(CONCH_EXP_SAME_PANELS) && CONCH_EXP_SAME_PANELS == 3
+  const int sbm0 = s.bm0 & ~1023, sbn0 = s.bn0 & ~2047;
+#else
+  const int sbm0 = s.bm0, sbn0 = s.bn0;
+#endif
+  if (s.narrow) s.so = make_stage_offsets(s.wave, s.lane, sbm0, sbn0, (int)p.m - 1, (int)p.n - 1, lda, ldb, 48, 32);
+  else if (p.fuse_silu) s.so = make_stage_offsets(s.wave, s.lane, sbm0, sbn0, (int)p.m - 1, (int)p.n - 1, lda, ldb, 32, (int)p.n);
+  else s.so = make_stage_offsets(s.wave, s.lane, sbm0, sbn0, (int)p.m - 1, (int)p.n - 1, lda, ldb);
   const int64_t b_cols = p.fuse_silu ? 2 * p.n : p.n;
   const uint32_t a_bytes = (uint32_t)((p.m - 1) * p.a_stride_m + p.k);
   const uint32_t b_bytes = (uint32_t)((b_cols - 1) * p.b_stride_n + p.k);
@@ -569,22 +647,31 @@ __device__ __forceinline__ void pp2_cluster(WaveTile<MMA>& w, int which) {
 template <int MMA, int NT, int ISSUE_A, int ISSUE_B, int VM_A, int VM_B>
 __device__ __forceinline__ void pp2_step(WaveTile<MMA>& w, char* lds, const BlockSetup& s, int t) {
   const int buf = (t & 1) * kBufBytes;
+  // Timing experiments (wrong results; experiment builds only): CONCH_EXP_SKIP_READS drops the phase-B fragment reads (a third
+  // of the LDS read bytes; the MFMAs reuse phase A's registers), CONCH_EXP_SKIP_DMA issues one unit per phase instead of two
+  // (half the L2 -> LDS stream; the counted waits then wait for less, never for more).
   // ---- phase A ----
   phase_reads<MMA, 0, true>(w, lds, buf, s.m_base, s.n_base);
   phase_reads<MMA, 1, true, NT>(w, lds, buf, s.m_base, s.n_base);
   if constexpr (ISSUE_A) {
     stage_unit<kV2>(lds, s.src, s.so, s.wave, t + 1);
+#ifndef CONCH_EXP_SKIP_DMA
     stage_unit<kU2>(lds, s.src, s.so, s.wave, t + 1);
+#endif
   }
-  wait_vmcnt<VM_A>();
+  wait_vm<VM_A>();
   pp2_cluster<MMA, NT>(w, 0);
   // ---- phase B ----
+#ifndef CONCH_EXP_SKIP_READS
   phase_reads<MMA, 2, true>(w, lds, buf, s.m_base, s.n_base);
+#endif
   if constexpr (ISSUE_B) {
     stage_unit<kU1>(lds, s.src, s.so, s.wave, t + 2);
+#ifndef CONCH_EXP_SKIP_DMA
     stage_unit<kV1>(lds, s.src, s.so, s.wave, t + 2);
+#endif
   }
-  wait_vmcnt<VM_B>();
+  wait_vm<VM_B>();
   pp2_cluster<MMA, NT>(w, 1);
 }
 
@@ -601,7 +688,7 @@ __device__ __forceinline__ void pp2_tile(const ScaledGemmArgs& p, char* lds, con
   if (s.wr == 0) __builtin_amdgcn_s_barrier();  // re-balance the barrier count
 
   if constexpr (SILU) epilogue_silu<MMA, OUT_DT>(w.acc, p, lds, s.bm0, s.bn0, s.wr, s.wc, s.lane);
-  else if constexpr (NT == 4 && ROWS) epilogue_rows<MMA, OUT_DT>(w.acc, p, lds, s.bm0, s.bn0, s.wr, s.wc, s.lane, s.wave);
+  else if constexpr (NT == 4 && ROWS) epilogue_rows<MMA, OUT_DT>(w.acc, p, lds, 0, s.bm0, s.bn0, s.wr, s.wc, s.lane, s.wave);
   else epilogue<MMA, OUT_DT, NT>(w.acc, p, lds, s.bm0, s.bn0, s.wr, s.wc, s.lane);
 }
 
@@ -656,7 +743,8 @@ __global__ __launch_bounds__(kThreads, 2) void scaled_gemm_pp2_kernel(ScaledGemm
 // unaligned C rows: a store count that is not 16 per wave) drain fully instead of counting.
 // ---------------------------------------------------------------------------------------------
 constexpr int kEpiBytes = 3 * 1024;
-constexpr int kLdsTotalPersistent = kLdsBytes + 2 * kEpiBytes;  // two sets of parked scales
+constexpr int kStageOffPersistent = kLdsBytes + 2 * kEpiBytes;          // 2 KiB per wave for the row-major epilogue
+constexpr int kLdsTotalPersistent = kStageOffPersistent + 8 * 2048;     // operand ring + two sets of parked scales + staging
 
 // scale_a / scale_b of a tile -> LDS by LDS-DMA (4 bytes per lane; waves 0-3: the 256 row scales, waves 4-7: the column scales)
 __device__ __forceinline__ void stage_scales(char* lds, int epi_off, const ScaledGemmArgs& p, int wave, int tid, int bm0, int bn0) {
@@ -695,14 +783,18 @@ __global__ __launch_bounds__(kThreads, 2) void scaled_gemm_pp2_persistent_kernel
   stage_two_steps(lds, s);
   CONCH_VMCNT(0);
   __builtin_amdgcn_s_barrier();
-  const bool vec_rows = (p.c_stride_m % 8 == 0) && (((uintptr_t)p.c & 15) == 0);
   WaveTile<MMA> w;
   for (;;) {
     zero_acc<MMA>(w);
     if (s.wr == 1) __builtin_amdgcn_s_barrier();  // stagger the second wave of every SIMD
     CONCH_PROBE_AT(g_probe_scaled, 0, vb);
-    pp2_step<MMA, 4, 0, 1, -1, -1>(w, lds, s, 0);  // V2 / U2 of step 1 are already in flight or landed
-    pp2_step<MMA, 4, 1, 1, -1, 6>(w, lds, s, 1);
+    // The whole ring (units 0-7 = K steps 0 and 1) was put in flight before the previous tile's 16 stores; the boundary
+    // waited for units 0-2 only.  vmcnt retires in issue order, so a count of [loads allowed in flight] + 16 stores waits
+    // for exactly the loads the plain kernel's counts wait for: A(0) units <= U2(0), B(0) <= V2(1), A(1) <= U2(1); the
+    // stores may stay in flight until B(1), whose wait (6) is for a load issued behind them.  (First tile, edge tiles:
+    // everything has drained and the counts are trivially met.)
+    pp2_step<MMA, 4, 0, 1, 24, 22>(w, lds, s, 0);  // V2 / U2 of step 1 are already in flight or landed
+    pp2_step<MMA, 4, 1, 1, 24, 6>(w, lds, s, 1);
     int t = 2;
     for (; t + 2 < steps; ++t) pp2_step<MMA, 4, 1, 1, 8, 6>(w, lds, s, t);
     pp2_step<MMA, 4, 1, 0, 8, 2>(w, lds, s, t);
@@ -724,12 +816,14 @@ __global__ __launch_bounds__(kThreads, 2) void scaled_gemm_pp2_persistent_kernel
       stage_two_steps(lds, sn);
       __builtin_amdgcn_sched_barrier(0);  // the loads go out before the first store
     }
-    epilogue<MMA, OUT_DT, 4>(w.acc, p, lds, bm0, bn0, s.wr, s.wc, s.lane, kLdsBytes + eb * kEpiBytes);
+    // whole tiles: row-major through the spare LDS (the operand ring is being refilled), 16 whole-line stores per wave
+    epilogue_rows<MMA, OUT_DT>(w.acc, p, lds, kStageOffPersistent, bm0, bn0, s.wr, s.wc, s.lane, s.wave, kLdsBytes + eb * kEpiBytes);
     CONCH_PROBE_AT(g_probe_scaled, 3, vb);
     if (!more) return;
     __builtin_amdgcn_sched_barrier(0);
-    // a full tile with 16-byte stores issues exactly 16 stores per wave; anything else drains
-    if (vec_rows && bm0 + kTileM <= (int)p.m && bn0 + kTileN <= (int)p.n) CONCH_VMCNT(16);
+    // a whole tile issues exactly 16 stores per wave: 16 + the 10 youngest LDS-DMA pieces may stay in flight = units 0-2
+    // of the next tile have landed (the plain kernel's prologue wait); anything else (masked stores) drains
+    if (tile_stores_whole_lines(p, bm0, bn0)) wait_vmcnt_n<26>();
     else CONCH_VMCNT(0);
     __builtin_amdgcn_s_barrier();
     int next_opaque = next, tid2 = threadIdx.x;
@@ -824,7 +918,9 @@ int launch_scaled_gemm_mfma(const ScaledGemmArgs& p, int variant, hipStream_t st
   // n > 2 = persistent with n workgroups (test hook: many tiles per workgroup on small problems)
   // CONCH_TUNE_EPILOGUE: 0 = auto, 1 = direct stores from the accumulator layout, 2 = row-major through LDS
   const int epi_mode = tuning(CONCH_TUNE_EPILOGUE);
-  const bool rows_epilogue = epi_mode == 2;  // auto = direct: the LDS route measured 0-2 % slower (profiles/r02/epilogue_ab.txt)
+  // auto = row-major (round 3: the pipelined single-buffer form with write-through whole-line stores, C3 -3.5 %, 8192^3 / the
+  // C5 shard -1 %, int8 -3 %: profiles/r03/epilogue_ab.txt; round 2's unpipelined form had measured 0-2 % slower)
+  const bool rows_epilogue = epi_mode != 1;
   const int persist_mode = tuning(CONCH_TUNE_PERSISTENT);
   const int cus = device_cu_count();
   const int total_tiles = (int)grid.x;

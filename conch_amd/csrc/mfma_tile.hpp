@@ -219,6 +219,12 @@ __device__ __forceinline__ void wait_vmcnt_n() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// the same, N < 0 = no wait
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  if constexpr (N >= 0) wait_vmcnt_n<N>();
+}
+
 enum { kMmaFp8 = 0, kMmaInt8 = 1, kMmaBf16 = 2, kMmaF16 = 3 };
 
 template <int MMA> struct AccT { typedef f32x4 type; };

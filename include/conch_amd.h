@@ -135,9 +135,9 @@ typedef enum conch_tuning_key {
                                workgroups (one per CU) that prefetch the next tile's first K steps under the epilogue,
                                n > 2 = persistent with n workgroups (test hook) */
   ,
-  CONCH_TUNE_EPILOGUE = 6 /* 256x256-tile scaled GEMM (two-phase ping-pong): 0 = auto, 1 = direct 16-byte stores from the
-                             accumulator layout (16 lines per quarter-wave), 2 = sub-tile parked in LDS and stored as whole
-                             128-byte rows */
+  CONCH_TUNE_EPILOGUE = 6 /* 256x256-tile scaled GEMM (two-phase ping-pong): 0 = auto (= 2), 1 = direct 16-byte stores from the
+                             accumulator layout (16 lines per quarter-wave), 2 = sub-tile passed through LDS sixteen rows at a
+                             time and stored as whole 128-byte rows, write-through (whole tiles; others store directly) */
   ,
   CONCH_TUNE_DIAG = 7 /* diagnostic twin of the library only (-DCONCH_CLOCK_PROBE): timing experiments of the mixed K loop with
                          parts removed (wrong results); ignored by the product library */

@@ -27,6 +27,8 @@ def main():
     key, vals = sys.argv[2].split("=")
     vals = [int(v) for v in vals.split(",")]
     rounds = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3].isdigit() else 9
+    if "--tune-epi2" in sys.argv:  # the row-major epilogue on every leg
+        _C.set_tuning(6, 2)
     if "--variant" in sys.argv:
         _C.set_gemm_variant(int(sys.argv[sys.argv.index("--variant") + 1]))
     if wl in SHAPES:

@@ -22,7 +22,10 @@ sys.path.insert(0, str(ROOT))
 
 from conch_amd import _C, _build  # noqa: E402
 
-_C.LIB_PATH = _build.PROBE_LIB
+import os  # noqa: E402
+
+# CONCH_PROBE_LIB=<path>: another diagnostic build (python -m conch_amd._build --variant X -DCONCH_CLOCK_PROBE -D...)
+_C.LIB_PATH = Path(os.environ["CONCH_PROBE_LIB"]) if os.environ.get("CONCH_PROBE_LIB") else _build.PROBE_LIB
 from conch_amd.kernels.quantization import gemm as kg  # noqa: E402
 from conch_amd.ops.quantization.gemm import create_mixed_precision_metadata, create_scaled_metadata  # noqa: E402
 
@@ -188,6 +191,8 @@ if __name__ == "__main__":
             print(f"-- CONCH_TUNE_PERSISTENT = {mode}")
             scaled_case(4096, 4096, 11008, torch.float8_e4m3fn, 8138.0)
         sys.exit(0)
+    if "--epi" in sys.argv:  # CONCH_TUNE_EPILOGUE for every case below (1 = direct stores, 2 = row-major through LDS)
+        _C.set_tuning(6, int(sys.argv[sys.argv.index("--epi") + 1]))
     if "--sched" in sys.argv:  # tile-schedule study of the headline shape only
         for sched in (int(v) for v in sys.argv[sys.argv.index("--sched") + 1].split(",")):
             _C.set_tuning(4, sched)
