@@ -53,6 +53,9 @@ struct MixedGemmArgs {
   // multiple of group_size / 64), fp32 partial sums to slabs [slice][M][N] instead of the cast-and-store epilogue
   int split_steps = 0;
   float* slabs = nullptr;
+  // whole tiles of the LDS-tiled kernel: 1 = row-major epilogue through LDS (whole-line write-through stores), 0 = direct stores
+  // from the accumulator layout (set by the launcher from CONCH_TUNE_EPILOGUE)
+  int rows_epilogue = 1;
 };
 
 // gemm_generic.hip

@@ -134,11 +134,11 @@ __device__ __forceinline__ void epilogue_park(char* lds, const EpiPrefetch& e) {
 // 1 = sc1 (write-through, the line is dropped from the XCD's L2), 2 = nt, 3 = sc0 sc1; the product build stores plainly.
 __device__ __forceinline__ void store_c16(uint16_t* dst, const i32x4& pk) {
 #if defined(CONCH_EXP_C_STORE) && CONCH_EXP_C_STORE == 1
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(pk) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(pk) : "memory");
 #elif defined(CONCH_EXP_C_STORE) && CONCH_EXP_C_STORE == 2
-  asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(pk) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(dst), "v"(pk) : "memory");
 #elif defined(CONCH_EXP_C_STORE) && CONCH_EXP_C_STORE == 3
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(pk) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(pk) : "memory");
 #else
   *(i32x4*)dst = pk;
 #endif
@@ -328,8 +328,12 @@ __device__ __forceinline__ void epilogue_rows_body(const typename AccT<MMA>::typ
       *(i32x4*)(lds + (woff ^ 64)) = pk[1];
     }
     if (b >= 1) {
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rd0), rc, voff, (2 * b - 2) * step8, kCStoreAux);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rd1), rc, voff, (2 * b - 1) * step8, kCStoreAux);
+      // the row-group offset goes into the VGPR offset, soffset stays the constant 0: with a REGISTER soffset hipcc (ROCm 7.2)
+      // assumes there is no write-after-read hazard on the data registers of a 16-byte buffer store and may overwrite
+      // them with its next VALU instruction before the store has read them -- observed on gfx950 as a wrong first dword in
+      // a few lanes of some launches (gemm_mixed.hip's row-major epilogue, round 3)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rd0), rc, voff + (2 * b - 2) * step8, 0, kCStoreAux);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rd1), rc, voff + (2 * b - 1) * step8, 0, kCStoreAux);
     }
   }
 }
@@ -874,7 +878,8 @@ static double schedule_makespan(int64_t t4, int64_t t3, int cus, double e) {
 }
 
 // CONCH_TUNE_TILE_SCHEDULE: 0 = auto, 1 = uniform 256-column tiles, 2 = the best two-width schedule, wide tiles first on
-// every XCD, 3 = the same with odd XCDs walking their narrow tiles first.
+// every XCD, 3 = the same with odd XCDs walking their narrow tiles first, 4 = wide and narrow tiles dealt to alternate slots of
+// every XCD's first round.
 // auto = uniform: measured on MI355X (profiles/r02/tile_schedule_ab.txt) the two-width schedule does not shorten C3 although
 // it removes the idle last round -- the chip is power-limited, the idle CUs of a last round hand their power to the busy ones.
 static TileSchedule choose_tile_schedule(const ScaledGemmArgs& p) {
@@ -897,7 +902,7 @@ static TileSchedule choose_tile_schedule(const ScaledGemmArgs& p) {
     const double t = schedule_makespan((int64_t)tiles_m * a, (int64_t)tiles_m * b, cus, e);
     if (t < best - 1e-9) {
       best = t;
-      pick = TileSchedule{tiles_m, a, b, mode == 3 ? 1 : 0};
+      pick = TileSchedule{tiles_m, a, b, mode == 3 ? 1 : mode == 4 ? 2 : 0};
     }
   }
   return pick;

@@ -96,6 +96,82 @@ __device__ __forceinline__ void mixed_epilogue(const MixedTile& w, const MixedGe
   }
 }
 
+// Row-major epilogue through LDS for whole tiles (round 3; the scaled kernels' finding, profiles/r03/store_rate.txt: the
+// accumulator-layout stores above put 16 different 128-byte lines into every quarter of a store instruction and run at
+// 13.6 B/clk/CU whatever else the chip does -- 8-byte stores of a lone third tile at half that -- while whole lines run at
+// up to four times the rate).  A wave owns 16 WT columns = 96 bytes of a row at the 192-column tile (C4), not a line, so the
+// image is built by the workgroup: every wave parks its cast sub-tile in a [tile rows][tile columns] bf16 / fp16 image in
+// the dead operand buffers (16-byte chunk index XOR row & 7 inside each 128-byte line: conflict-free ds_write_b128),
+// barrier, and every wave stores its share of the image as whole lines with write-through buffer stores -- 4 rows x 256
+// bytes per instruction where a row is a multiple of 256 bytes (a 16-lane group reads one row's 16 chunks: 16 banks
+// slots), 8 rows x 128 bytes at the 384-byte rows of the 192-column tile.  Same values as mixed_epilogue, bit for bit.
+template <int OUT_DT, int NT, bool TALL>
+__device__ __forceinline__ bool mixed_tile_is_whole(const MixedGemmArgs& p, int bm0, int bn0) {
+  constexpr int kRows = TALL ? 512 : 256, kCols = TALL ? 128 : 64 * NT;
+  return (p.c_stride_m % 8 == 0) && (((uintptr_t)p.c & 15) == 0) && bm0 + kRows <= (int)p.m && bn0 + kCols <= (int)p.n &&
+         ((p.m - 1) * p.c_stride_m + p.n) * 2 < ((int64_t)1 << 32);
+}
+
+template <int OUT_DT, int NT, bool TALL>
+__device__ __forceinline__ void mixed_epilogue_rows(const MixedTile& w, const MixedGemmArgs& p, char* lds, int bm0, int bn0, int wr,
+                                                    int wc, int lane, int wave) {
+  constexpr int kRows = TALL ? 512 : 256, kCols = TALL ? 128 : 64 * NT;
+  constexpr int kPitch = kCols * 2;          // bytes per image row: 256, 384 or 512
+  constexpr int WT = TALL ? 4 : NT;          // 16-column MFMA tiles per wave
+  constexpr int kWaveChunks = 2 * WT;        // 16-byte chunks per wave and row
+  const int g = lane >> 4, jm = lane & 15;
+  __syncthreads();  // every wave is past its last operand read: the buffers are dead (a fence too: the raw s_barrier
+                    // builtin does not order the stores below for the compiler)
+  // ---- park: same lane -> (row, columns) map and the same casts as mixed_epilogue ----
+#pragma unroll
+  for (int nh = 0; nh < 2; ++nh) {
+    if (nh == 1 && WT == 2) continue;
+    const bool pair_h = nh == 0 || WT == 4;
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+      const int row = wr * 128 + mt * 16 + jm;  // row & 7 == jm & 7
+      i32x4 pk;
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2) {
+        const int e = 2 * e2;
+        const f32x4& a = w.acc[mt][nh * 2 + (pair_h ? (e >> 2) : 0)];
+        pk[e2] = (int)pack2_bits16<OUT_DT>(f32x2{a[e & 3], a[(e & 3) + 1]});
+      }
+      if (pair_h) {
+        const int chunk = wc * kWaveChunks + nh * 4 + g;
+        *(i32x4*)(lds + row * kPitch + (((chunk & ~7) | ((chunk & 7) ^ (jm & 7))) * 16)) = pk;
+      } else {  // lone third tile: four columns = 8 bytes per lane, two lanes per chunk
+        const int chunk = wc * kWaveChunks + 4 + (g >> 1);
+        *(i32x2*)(lds + row * kPitch + (((chunk & ~7) | ((chunk & 7) ^ (jm & 7))) * 16) + (g & 1) * 8) = i32x2{pk[0], pk[1]};
+      }
+    }
+  }
+  __syncthreads();
+  // ---- store whole lines ----
+  const int stride_b = (int)p.c_stride_m * 2;
+  const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.c, 0, (uint32_t)(((p.m - 1) * p.c_stride_m + p.n) * 2), 0x00020000);
+  constexpr bool kWide = kPitch % 256 == 0;          // 4 rows x 256 bytes per instruction, else 8 rows x 128 bytes
+  constexpr int kPieceRows = kWide ? 4 : 8;
+  constexpr int kPieceCols = kPitch / (kWide ? 256 : 128);   // pieces side by side in a row group
+  constexpr int kPerWave = (kRows / kPieceRows) * kPieceCols / 8;
+  const int lr = kWide ? lane >> 4 : lane >> 3;     // row of the piece
+  const int lc = kWide ? lane & 15 : lane & 7;      // 16-byte chunk of the piece
+  const int voff = (bm0 + lr) * stride_b + bn0 * 2 + lc * 16;
+#pragma unroll
+  for (int i = 0; i < kPerWave; ++i) {
+    const int q = wave * kPerWave + i;               // wave-uniform
+    const int rg = q / kPieceCols, pc = q % kPieceCols;
+    const int row = rg * kPieceRows + lr;
+    const int chunk = pc * (kWide ? 16 : 8) + lc;
+    const i32x4 v = *(const i32x4*)(lds + row * kPitch + (((chunk & ~7) | ((chunk & 7) ^ (row & 7))) * 16));
+    // offset in the VGPR, soffset the constant 0: with a register soffset hipcc does not guard the data registers of a
+    // 16-byte buffer store against its next VALU write (gemm_mfma.hip, epilogue_rows_body)
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rc,
+                                           voff + rg * kPieceRows * stride_b + pc * (kWide ? 256 : 128), 0, 16);  // sc1
+  }
+}
+
 // Split-K form: the raw fp32 accumulators to this slice's slab [M][N] (N % 4 == 0: 16-byte stores), same lane -> (m, n) map as
 // mixed_epilogue; the fp32-slab reduce of gemm_mixed_skinny.hip adds the slices in slice order and casts.
 template <int NT>
@@ -631,6 +707,8 @@ __global__ __launch_bounds__(kThreads, 2) void mixed_gemm_kernel(MixedGemmArgs p
     mixed_epilogue_silu<OUT_DT>(w, p, bm0, bn0, wr, wc, lane);
   } else {
     if (p.slabs) mixed_epilogue_slab<TALL ? 4 : NT>(w, p, bm0, bn0, wr, wc, lane, p.slabs + (int64_t)blockIdx.y * p.m * p.n);
+    else if (p.rows_epilogue && mixed_tile_is_whole<OUT_DT, NT, TALL>(p, bm0, bn0))  // workgroup-uniform
+      mixed_epilogue_rows<OUT_DT, NT, TALL>(w, p, lds, bm0, bn0, wr, wc, lane, c.wave);
     else mixed_epilogue<X_DT, OUT_DT, TALL ? 4 : NT>(w, p, bm0, bn0, wr, wc, lane);
   }
 }
@@ -938,6 +1016,7 @@ int pick_split(const MixedGemmArgs& p, int nt, int num_cus) {
 
 int launch_mixed_gemm_mfma(const MixedGemmArgs& p_in, hipStream_t stream) {
   MixedGemmArgs p = p_in;
+  p.rows_epilogue = tuning(CONCH_TUNE_EPILOGUE) != 1;  // auto = row-major (profiles/r03/mixed_epilogue_ab.txt)
   const int num_cus = device_cu_count();
   const int forced = tuning(1);  // CONCH_TUNE_MIXED_TILE_NT: 0 = auto, 2..4 = force 64 NT columns, 5 = force the 512 x 128 tile
   int nt = p.fuse_silu ? 4 : (forced >= 2 && forced <= kMixedTall) ? forced : pick_nt(p, num_cus);

@@ -312,7 +312,7 @@ __global__ __launch_bounds__(kSkThreads, 1) void skinny_splitk_kernel(ScaledGemm
     for (int i = 0; i < ROWS / 16; ++i) {
       const int m = m0 + i * 16 + r;
       if (m < p.m && n + 4 <= p.n)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i]), rs, voff_s[i], slice * (int)slab_bytes, 16);  // sc1
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i]), rs, voff_s[i] + slice * (int)slab_bytes, 0, 16);  // sc1; constant soffset: see gemm_mfma.hip epilogue_rows_body
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its own write-through stores
     __syncthreads();

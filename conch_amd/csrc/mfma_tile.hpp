@@ -68,7 +68,8 @@ struct TileSchedule {
   int big_cols;
   int narrow_cols;
   int alternate;  // 1 = XCDs with an odd label walk their narrow tiles FIRST: the two halves of the chip then reach their
-                  // tile boundaries (C-store bursts) a quarter of a tile apart instead of all at once
+                  // tile boundaries (C-store bursts) a quarter of a tile apart instead of all at once;
+                  // 2 = the same offset between the two halves of EVERY XCD's CUs (see place_tile)
 };
 
 struct TilePlace {
@@ -95,10 +96,28 @@ __device__ __forceinline__ TilePlace place_tile(int bid, const TileSchedule& ts)
   const int b1 = ((xcd + 1) * t4) >> 3;
   const int nbig = b1 - b0;
   const int nnarrow = (q + (xcd < r ? 1 : 0)) - nbig;
-  const bool narrow_first = ts.alternate && (xcd & 1);
-  const bool is_big = narrow_first ? idx >= nnarrow : idx < nbig;
-  const int big_idx = narrow_first ? idx - nnarrow : idx;
-  const int narrow_idx = narrow_first ? idx : idx - nbig;
+  bool is_big;
+  int big_idx, narrow_idx;
+  if (ts.alternate == 2) {
+    // within every XCD the first round deals wide and narrow tiles to alternate workgroup slots (16 + 16 on 32 CUs): the two
+    // halves of the XCD's CUs then reach every later tile boundary -- the C-store burst into the XCD's L2 -- about a sixth
+    // of a tile apart; then the remaining wide tiles, then the remaining narrow ones
+    const int pairs = min(16, min(nbig, nnarrow));
+    if (idx < 2 * pairs) {
+      is_big = !(idx & 1);
+      big_idx = narrow_idx = idx >> 1;
+    } else {
+      const int rest = idx - 2 * pairs;
+      is_big = rest < nbig - pairs;
+      big_idx = pairs + rest;
+      narrow_idx = pairs + rest - (nbig - pairs);
+    }
+  } else {
+    const bool narrow_first = ts.alternate && (xcd & 1);
+    is_big = narrow_first ? idx >= nnarrow : idx < nbig;
+    big_idx = narrow_first ? idx - nnarrow : idx;
+    narrow_idx = narrow_first ? idx : idx - nbig;
+  }
   if (is_big) {
     const TileCoord c = raster_tile(b0 + big_idx, ts.tiles_m, ts.big_cols);
     t.tm = c.tm;

@@ -175,9 +175,10 @@ def test_two_width_tile_schedule_is_bit_identical_and_correct(_reset_tuning, ina
     _C.set_gemm_variant(_C.VARIANT_MFMA_PINGPONG2)
     _C.set_tuning(_C.TUNE_TILE_SCHEDULE, 1)
     uniform = run_scaled(a, b, sa, sb, torch.bfloat16, bias)
-    _C.set_tuning(_C.TUNE_TILE_SCHEDULE, 2)
-    balanced = run_scaled(a, b, sa, sb, torch.bfloat16, bias)
-    np.testing.assert_array_equal(to_bits(balanced), to_bits(uniform))
+    for mode in (3, 4, 2):  # odd XCDs narrow-first; wide / narrow on alternate slots of every XCD; wide first everywhere
+        _C.set_tuning(_C.TUNE_TILE_SCHEDULE, mode)
+        balanced = run_scaled(a, b, sa, sb, torch.bfloat16, bias)
+        np.testing.assert_array_equal(to_bits(balanced), to_bits(uniform))
     ref = oracle.scaled_gemm_ref(a, b, sa, sb, torch.bfloat16, bias)
     check_scaled(balanced, ref, IN_T[iname], torch.bfloat16, (a, b, sa, sb, bias))
 
@@ -680,6 +681,30 @@ def test_mixed_precision_gemm_golden_from_reference(golden, wname, zp, dname):
     got = mixed_precision_gemm(a.cuda(), packed.cuda(), w_s.cuda(), None if w_zp is None else w_zp.cuda(), bits, bias,
                                group)
     check_mixed(got, a, from_bits(g[f"wref_{key}"], dtype), a.shape[1])
+
+
+@pytest.mark.parametrize("nt", [2, 3, 4, 5])
+@pytest.mark.parametrize(("m", "k", "n"), [(1024, 256, 1536), (1100, 128, 1000), (512, 384, 768), (2048, 128, 520)])
+@pytest.mark.parametrize(("wname", "use_zp", "dname"), [("uint4b8", False, "f16"), ("uint4", True, "bf16"), ("uint8b128", False, "bf16")])
+def test_mixed_row_major_epilogue_is_bit_identical(_reset_tuning, nt, m, k, n, wname, use_zp, dname):
+    """Whole tiles of the LDS-tiled mixed kernel leave through an LDS image and whole-line write-through stores (round 3); ragged
+    tiles and the direct route (CONCH_TUNE_EPILOGUE = 1) store from the accumulator layout.  Same casts, same bits -- at every
+    tile shape (a wave's share of a row is 64, 96 or 128 bytes: the image is built by the workgroup), with whole and ragged
+    tiles in one launch."""
+    wt = WTYPES[wname]
+    a, w_ref, packed, w_s, w_zp = make_mixed_inputs(m, k, n, wt, use_zp, DT[dname])
+    dev = lambda t: None if t is None else t.cuda()  # noqa: E731
+    _C.set_tuning(_C.TUNE_MIXED_TILE_NT, nt)
+    try:
+        _C.set_tuning(_C.TUNE_EPILOGUE, 1)
+        direct = mixed_precision_gemm(dev(a), dev(packed), dev(w_s), dev(w_zp), wt.size_bits, wt.bias, 128)
+        _C.set_tuning(_C.TUNE_EPILOGUE, 2)
+        rows = mixed_precision_gemm(dev(a), dev(packed), dev(w_s), dev(w_zp), wt.size_bits, wt.bias, 128)
+    finally:
+        _C.set_tuning(_C.TUNE_MIXED_TILE_NT, 0)
+        _C.set_tuning(_C.TUNE_EPILOGUE, 0)
+    np.testing.assert_array_equal(to_bits(rows), to_bits(direct))
+    check_mixed(rows, a, w_ref, k)
 
 
 @pytest.mark.parametrize("variant", ["auto"])
