@@ -27,6 +27,9 @@ struct ScaledGemmArgs {
   // in_dtype on the fly with the static per-tensor scale scale_a[0] (scale_a_numel == 1), exactly as
   // static_scaled_{int8,fp8}_quant would -- conch_static_quant_scaled_gemm, skinny-M split-K kernel only
   int a_src_dtype = 0;
+  // 128 x 128-tile kernel: 1 = whole tiles leave row-major through LDS (epilogue_rows.hpp), 0 = direct stores from the accumulator
+  // layout (set by the launcher from CONCH_TUNE_EPILOGUE; the 256 x 256-tile kernels pick by instantiation)
+  int rows_epilogue = 1;
 };
 
 // mixed_precision_gemm: C = out( X @ dequant(Wq) ).  Strides in ELEMENTS of the respective array.

@@ -10,6 +10,7 @@
 #include "common.hpp"
 #include "gemm.hpp"
 #include "mfma_tile.hpp"
+#include "epilogue_rows.hpp"
 
 namespace conch {
 namespace {
@@ -120,7 +121,15 @@ __global__ __launch_bounds__(kMidThreads, 2) void scaled_gemm_mid_kernel(ScaledG
       for (int q = 0; q < 4; ++q) mma_step<MMA>(acc[i][q], fn[q], fm[i]);  // D rows = n, D cols = m
   }
 
-  // epilogue: sb * (sa * acc), RNE cast, bias in the output dtype (reference/quantization/scaled_gemm.py:21-25)
+  // epilogue: sb * (sa * acc), RNE cast, bias in the output dtype (reference/quantization/scaled_gemm.py:21-25).
+  // Whole tiles: row-major through 2 KiB of LDS per wave, whole-line write-through stores (epilogue_rows.hpp; a wave's 64
+  // columns are one 128-byte line per row); CONCH_TUNE_EPILOGUE = 1 and ragged tiles store from the accumulator layout.
+  if (p.rows_epilogue && tile_stores_whole_lines(p, bm0, bn0, kMidTile, kMidTile)) {  // workgroup-uniform
+    __syncthreads();  // every wave is past its last operand read; nothing is in flight (the last steps drained)
+    if (p.bias) epilogue_rows_body<MMA, OUT_DT, true, 4, kMidTile>(acc, p, lds, 0, bm0, bn0, wr, wc, lane, wave, kMidEpi);
+    else epilogue_rows_body<MMA, OUT_DT, false, 4, kMidTile>(acc, p, lds, 0, bm0, bn0, wr, wc, lane, wave, kMidEpi);
+    return;
+  }
   const bool vec_store = (p.c_stride_m % 8 == 0) && (((uintptr_t)p.c & 15) == 0);
   const bool has_bias = p.bias != nullptr;
   const float* lsa = (const float*)(lds + kMidEpi);
@@ -169,7 +178,9 @@ __global__ __launch_bounds__(kMidThreads, 2) void scaled_gemm_mid_kernel(ScaledG
 }  // namespace
 
 // Same layout contract as the 256x256 kernels (scaled_gemm_mfma_supported).
-int launch_scaled_gemm_mid(const ScaledGemmArgs& p, hipStream_t stream) {
+int launch_scaled_gemm_mid(const ScaledGemmArgs& p_in, hipStream_t stream) {
+  ScaledGemmArgs p = p_in;
+  p.rows_epilogue = tuning(CONCH_TUNE_EPILOGUE) != 1;
   const int tiles_m = (int)((p.m + kMidTile - 1) / kMidTile);
   const int tiles_n = (int)((p.n + kMidTile - 1) / kMidTile);
   const dim3 grid((unsigned)(tiles_m * tiles_n));

@@ -1,10 +1,7 @@
 mkdir -p gpurun_out/r3a
-python -m pytest tests/test_gpu_gemm.py -q -m gpu -k "mixed_row_major" -n 2 2>&1 | tail -2
+timeout 1500 python -m pytest tests -x -q -m gpu -n 2 > gpurun_out/r3a/t_all2.log 2>&1; tail -3 gpurun_out/r3a/t_all2.log
 {
-python tools/ab_mixed_tuning.py c4 6=1,2 9
-python tools/ab_mixed_tuning.py readme 6=1,2 9
-python tools/ab_mixed_tuning.py sq8k 6=1,2 7
-python tools/ab_mixed_tuning.py 4096x4096x11008 6=1,2 7
-python tools/ab_mixed_tuning.py readme 6=1,2 7 --nt 5
-for w in c3 sq8k c5shard; do python tools/ab_tuning.py $w epi=1,2 7; done
-} 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r3a/ab8_mixed_epi.log
+for w in 256x4096x11008:int8 512x4096x4096:fp8 1024x4096x4096:fp8 128x4096x28672:int8; do
+  python tools/ab_tuning.py $w epi=1,2 7 --variant 6
+done
+} 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r3a/ab9_mid_epi.log
