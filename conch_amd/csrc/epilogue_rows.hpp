@@ -121,5 +121,47 @@ __device__ __forceinline__ void epilogue_rows_body(const typename AccT<MMA>::typ
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Workgroup-built image: for tiles whose waves own LESS than a 128-byte line of a row (the mixed GEMM's 192- and 128-column
+// tiles, the fused gate/up tiles: 64 or 96 bytes per wave and row).  Every wave parks its cast 16-byte chunks at
+// image_chunk_offset() in a [ROWS][PITCH bytes] image in dead operand LDS, the workgroup synchronises, and image_store_rows()
+// stores the image as whole lines, write-through: 4 rows x 256 bytes per instruction where PITCH is a multiple of 256 (a
+// 16-lane group reads one row's 16 chunks: 16 different bank slots), 8 rows x 128 bytes otherwise (384-byte rows).  The chunk
+// index is XORed with row & 7 inside its 128-byte line: conflict-free ds_write_b128 for 8 lanes on 8 consecutive rows of one
+// chunk column, conflict-free ds_read_b128 for either piece shape (derivation: gemm_mixed.hip, mixed_epilogue_rows).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int PITCH>
+__device__ __forceinline__ int image_chunk_offset(int row, int chunk) {
+  return row * PITCH + (((chunk & ~7) | ((chunk & 7) ^ (row & 7))) * 16);
+}
+
+// `n_cols`: columns of C (elements); c_stride_m in elements; the tile is whole (caller checked) and starts at (bm0, bn0).
+template <int ROWS, int PITCH>
+__device__ __forceinline__ void image_store_rows(const char* lds, void* c, int64_t m, int64_t n_cols, int64_t c_stride_m, int bm0, int bn0,
+                                                 int lane, int wave) {
+  const int stride_b = (int)c_stride_m * 2;
+  const __amdgpu_buffer_rsrc_t rc =
+      __builtin_amdgcn_make_buffer_rsrc(c, 0, (uint32_t)(((m - 1) * c_stride_m + n_cols) * 2), 0x00020000);
+  constexpr bool kWide = PITCH % 256 == 0;
+  constexpr int kPieceRows = kWide ? 4 : 8;
+  constexpr int kPieceCols = PITCH / (kWide ? 256 : 128);  // pieces side by side in a row group
+  constexpr int kPerWave = (ROWS / kPieceRows) * kPieceCols / 8;
+  static_assert((ROWS / kPieceRows) * kPieceCols % 8 == 0, "pieces divide over the eight waves");
+  const int lr = kWide ? lane >> 4 : lane >> 3;  // row of the piece
+  const int lc = kWide ? lane & 15 : lane & 7;   // 16-byte chunk of the piece
+  const int voff = (bm0 + lr) * stride_b + bn0 * 2 + lc * 16;
+#pragma unroll
+  for (int i = 0; i < kPerWave; ++i) {
+    const int q = wave * kPerWave + i;  // wave-uniform
+    const int rg = q / kPieceCols, pc = q % kPieceCols;
+    const int row = rg * kPieceRows + lr;
+    const int chunk = pc * (kWide ? 16 : 8) + lc;
+    const i32x4 v = *(const i32x4*)(lds + image_chunk_offset<PITCH>(row, chunk));
+    // offset in the VGPR, soffset the constant 0 (see epilogue_rows_body)
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rc, voff + rg * kPieceRows * stride_b + pc * (kWide ? 256 : 128), 0,
+                                           kCStoreAux);
+  }
+}
+
 }  // namespace tile
 }  // namespace conch

@@ -34,6 +34,7 @@
 #include "common.hpp"
 #include "gemm.hpp"
 #include "mfma_tile.hpp"
+#include "epilogue_rows.hpp"
 #include "mixed_dequant.hpp"
 
 namespace conch {
@@ -139,37 +140,15 @@ __device__ __forceinline__ void mixed_epilogue_rows(const MixedTile& w, const Mi
       }
       if (pair_h) {
         const int chunk = wc * kWaveChunks + nh * 4 + g;
-        *(i32x4*)(lds + row * kPitch + (((chunk & ~7) | ((chunk & 7) ^ (jm & 7))) * 16)) = pk;
+        *(i32x4*)(lds + image_chunk_offset<kPitch>(row, chunk)) = pk;
       } else {  // lone third tile: four columns = 8 bytes per lane, two lanes per chunk
         const int chunk = wc * kWaveChunks + 4 + (g >> 1);
-        *(i32x2*)(lds + row * kPitch + (((chunk & ~7) | ((chunk & 7) ^ (jm & 7))) * 16) + (g & 1) * 8) = i32x2{pk[0], pk[1]};
+        *(i32x2*)(lds + image_chunk_offset<kPitch>(row, chunk) + (g & 1) * 8) = i32x2{pk[0], pk[1]};
       }
     }
   }
   __syncthreads();
-  // ---- store whole lines ----
-  const int stride_b = (int)p.c_stride_m * 2;
-  const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)p.c, 0, (uint32_t)(((p.m - 1) * p.c_stride_m + p.n) * 2), 0x00020000);
-  constexpr bool kWide = kPitch % 256 == 0;          // 4 rows x 256 bytes per instruction, else 8 rows x 128 bytes
-  constexpr int kPieceRows = kWide ? 4 : 8;
-  constexpr int kPieceCols = kPitch / (kWide ? 256 : 128);   // pieces side by side in a row group
-  constexpr int kPerWave = (kRows / kPieceRows) * kPieceCols / 8;
-  const int lr = kWide ? lane >> 4 : lane >> 3;     // row of the piece
-  const int lc = kWide ? lane & 15 : lane & 7;      // 16-byte chunk of the piece
-  const int voff = (bm0 + lr) * stride_b + bn0 * 2 + lc * 16;
-#pragma unroll
-  for (int i = 0; i < kPerWave; ++i) {
-    const int q = wave * kPerWave + i;               // wave-uniform
-    const int rg = q / kPieceCols, pc = q % kPieceCols;
-    const int row = rg * kPieceRows + lr;
-    const int chunk = pc * (kWide ? 16 : 8) + lc;
-    const i32x4 v = *(const i32x4*)(lds + row * kPitch + (((chunk & ~7) | ((chunk & 7) ^ (row & 7))) * 16));
-    // offset in the VGPR, soffset the constant 0: with a register soffset hipcc does not guard the data registers of a
-    // 16-byte buffer store against its next VALU write (gemm_mfma.hip, epilogue_rows_body)
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rc,
-                                           voff + rg * kPieceRows * stride_b + pc * (kWide ? 256 : 128), 0, 16);  // sc1
-  }
+  image_store_rows<kRows, kPitch>(lds, p.c, p.m, p.n, p.c_stride_m, bm0, bn0, lane, wave);
 }
 
 // Split-K form: the raw fp32 accumulators to this slice's slab [M][N] (N % 4 == 0: 16-byte stores), same lane -> (m, n) map as

@@ -201,6 +201,40 @@ def test_row_major_epilogue_is_bit_identical(_reset_tuning, oname, iname, m, k, 
     check_scaled(rows, ref, IN_T[iname], DT[oname], (a, b, sa, sb, bias))
 
 
+def test_row_major_epilogues_repeat_bit_identically():
+    """The whole-line epilogues store with 16-byte buffer stores.  With a REGISTER soffset hipcc (ROCm 7.2) does not guard such a
+    store's data registers against its next VALU write, which showed on gfx950 as a wrong first dword in a few lanes of SOME
+    launches (round 3) -- so: many launches of each form, every one equal to the direct-store result."""
+    a, b, sa, sb, _ = make_scaled_inputs(1024, 512, 1536, IN_T["fn"], torch.bfloat16, False, False, False)
+    wt = WTYPES["uint4b8"]
+    x, _, packed, w_s, _ = make_mixed_inputs(1024, 256, 1536, wt, False, torch.float16)
+    xd, pd, wsd = x.cuda(), packed.cuda(), w_s.cuda()
+    try:
+        _C.set_tuning(_C.TUNE_EPILOGUE, 1)
+        want_s = {v: None for v in (_C.VARIANT_MFMA_PINGPONG2, _C.VARIANT_MFMA_MID)}
+        for v in want_s:
+            _C.set_gemm_variant(v)
+            want_s[v] = run_scaled(a, b, sa, sb, torch.bfloat16, None)
+        _C.set_gemm_variant(0)
+        want_m = {}
+        for nt in (2, 3, 4, 5):
+            _C.set_tuning(_C.TUNE_MIXED_TILE_NT, nt)
+            want_m[nt] = mixed_precision_gemm(xd, pd, wsd, None, wt.size_bits, wt.bias, 128)
+        _C.set_tuning(_C.TUNE_EPILOGUE, 2)
+        for _ in range(25):
+            for v, want in want_s.items():
+                _C.set_gemm_variant(v)
+                assert torch.equal(run_scaled(a, b, sa, sb, torch.bfloat16, None), want)
+            _C.set_gemm_variant(0)
+            for nt, want in want_m.items():
+                _C.set_tuning(_C.TUNE_MIXED_TILE_NT, nt)
+                assert torch.equal(mixed_precision_gemm(xd, pd, wsd, None, wt.size_bits, wt.bias, 128), want)
+    finally:
+        _C.set_gemm_variant(0)
+        _C.set_tuning(_C.TUNE_MIXED_TILE_NT, 0)
+        _C.set_tuning(_C.TUNE_EPILOGUE, 0)
+
+
 @pytest.mark.parametrize("workgroups", [2, 7, 16, 256])
 @pytest.mark.parametrize("iname", ["int8", "fn"])
 @pytest.mark.parametrize(("m", "k", "n"), [(4096, 512, 11008), (1024, 512, 2048), (1000, 640, 1500), (2304, 1024, 4672), (512, 4096, 768),
