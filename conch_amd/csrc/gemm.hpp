@@ -30,7 +30,27 @@ struct ScaledGemmArgs {
   // 128 x 128-tile kernel: 1 = whole tiles leave row-major through LDS (epilogue_rows.hpp), 0 = direct stores from the accumulator
   // layout (set by the launcher from CONCH_TUNE_EPILOGUE; the 256 x 256-tile kernels pick by instantiation)
   int rows_epilogue = 1;
+  // reciprocal of the tile raster's one runtime divisor (GROUP_M x tile columns), made by the launcher (set_raster_divisor):
+  // the tile kernels otherwise open with three integer divisions by runtime values, ~0.6 us of every workgroup's life
+  // (profiles/r03/probe_setup.txt).  raster_shift < 0: not set, the kernel divides.
+  uint32_t raster_magic = 0;
+  int raster_shift = -1;
 };
+
+// n / d for n < 2^31 as mulhi(n, magic) >> shift (d not a power of two: shift = ceil(log2 d) - 1, magic = ceil(2^(32 + shift) / d),
+// exact because n d < 2^(32 + shift + 1)), or n >> shift with magic = 0 (d = 2^shift).
+inline void set_raster_divisor(uint32_t d, uint32_t* magic, int* shift) {
+  int s = 0;
+  while ((1u << s) < d) ++s;
+  if ((1u << s) == d) {
+    *magic = 0;
+    *shift = s;
+  } else {
+    *shift = s - 1;
+    const uint64_t num = (uint64_t)1 << (32 + s - 1);
+    *magic = (uint32_t)((num + d - 1) / d);
+  }
+}
 
 // mixed_precision_gemm: C = out( X @ dequant(Wq) ).  Strides in ELEMENTS of the respective array.
 struct MixedGemmArgs {
@@ -59,6 +79,8 @@ struct MixedGemmArgs {
   // whole tiles of the LDS-tiled kernel: 1 = row-major epilogue through LDS (whole-line write-through stores), 0 = direct stores
   // from the accumulator layout (set by the launcher from CONCH_TUNE_EPILOGUE)
   int rows_epilogue = 1;
+  uint32_t raster_magic = 0;  // see ScaledGemmArgs
+  int raster_shift = -1;
 };
 
 // gemm_generic.hip

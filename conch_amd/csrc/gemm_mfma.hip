@@ -341,12 +341,12 @@ __device__ __forceinline__ BlockSetup setup_block(const ScaledGemmArgs& p, const
   const int tiles_m = ((int)p.m + kTileM - 1) / kTileM;
   const int tiles_n = ((int)p.n + tile_n - 1) / tile_n;
   if (ts) {
-    const TilePlace tp = place_tile(bid, *ts);
+    const TilePlace tp = place_tile(bid, *ts, p.raster_magic, p.raster_shift);
     s.bm0 = tp.tm * kTileM;
     s.bn0 = tp.n0;
     s.narrow = tp.narrow;
   } else {
-    const TileCoord tc = map_tile(bid, tiles_m, tiles_n);
+    const TileCoord tc = map_tile(bid, tiles_m, tiles_n, p.raster_magic, p.raster_shift);
     s.bm0 = tc.tm * kTileM;
     s.bn0 = tc.tn * tile_n;
   }
@@ -591,8 +591,14 @@ __device__ __forceinline__ void pp2_tile(const ScaledGemmArgs& p, char* lds, con
 template <int MMA, int OUT_DT, bool SILU, bool ROWS = false>
 __global__ __launch_bounds__(kThreads, 2) void scaled_gemm_pp2_kernel(ScaledGemmArgs p, TileSchedule ts) {
   __shared__ __attribute__((aligned(1024))) char lds[kLdsTotal];
+#ifndef CONCH_EXP_PROBE_AFTER_SETUP
   CONCH_PROBE(g_probe_scaled, 2);
+#endif
   const BlockSetup s = SILU ? setup_block(p) : setup_block(p, &ts);
+#ifdef CONCH_EXP_PROBE_AFTER_SETUP  // diagnostic: the "entry" stamp taken behind the tile / address arithmetic instead of before it
+  asm volatile("" ::"v"(s.so.off[0][0]), "v"(s.so.off[3][1]), "v"(s.m_base), "v"(s.n_base));
+  CONCH_PROBE(g_probe_scaled, 2);
+#endif
   WaveTile<MMA> w;
   zero_acc<MMA>(w);
   const int steps = (int)(p.k / kStepBytes);  // >= 2 (dispatcher)
@@ -799,7 +805,8 @@ static TileSchedule choose_tile_schedule(const ScaledGemmArgs& p) {
   return pick;
 }
 
-int launch_scaled_gemm_mfma(const ScaledGemmArgs& p, int variant, hipStream_t stream) {
+int launch_scaled_gemm_mfma(const ScaledGemmArgs& p_in, int variant, hipStream_t stream) {
+  ScaledGemmArgs p = p_in;
   const int tile_n = p.fuse_silu ? kTileN / 2 : kTileN;
   const int tiles_m = (int)((p.m + kTileM - 1) / kTileM);
   const int tiles_n = (int)((p.n + tile_n - 1) / tile_n);
@@ -817,6 +824,8 @@ int launch_scaled_gemm_mfma(const ScaledGemmArgs& p, int variant, hipStream_t st
   // auto = row-major (round 3: the pipelined single-buffer form with write-through whole-line stores, C3 -3.5 %, 8192^3 / the
   // C5 shard -1 %, int8 -3 %: profiles/r03/epilogue_ab.txt; round 2's unpipelined form had measured 0-2 % slower)
   const bool rows_epilogue = epi_mode != 1;
+  // the raster's runtime divisor as a host-made reciprocal (uniform schedules; the two-width ones divide in the kernel)
+  if (ts.narrow_cols == 0) set_raster_divisor((uint32_t)(kGroupM * ts.big_cols), &p.raster_magic, &p.raster_shift);
   const int persist_mode = tuning(CONCH_TUNE_PERSISTENT);
   const int cus = device_cu_count();
   const int total_tiles = (int)grid.x;
@@ -852,9 +861,11 @@ int launch_scaled_gemm_mfma(const ScaledGemmArgs& p, int variant, hipStream_t st
 // 16-bit operands (bf16: the e4m3fnuz compat path, operands expanded exactly by repack.hip; fp16 / bf16: the dequantise-first
 // path of gemm_modes.hip).  `p` is in BYTE units (k = 2 * K elements, strides in bytes) and satisfies the tile contract by
 // construction; p.in_dtype says which 16-bit MFMA runs.
-int launch_scaled_gemm_mfma_16bit(const ScaledGemmArgs& p, hipStream_t stream) {
+int launch_scaled_gemm_mfma_16bit(const ScaledGemmArgs& p_in, hipStream_t stream) {
+  ScaledGemmArgs p = p_in;
   const int tiles_m = (int)((p.m + kTileM - 1) / kTileM);
   const int tiles_n = (int)((p.n + kTileN - 1) / kTileN);
+  set_raster_divisor((uint32_t)(kGroupM * tiles_n), &p.raster_magic, &p.raster_shift);
   const dim3 grid((unsigned)(tiles_m * tiles_n));
   if (p.in_dtype == CONCH_DT_FP16) {
     if (p.out_dtype == CONCH_DT_BF16)

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(kMidThreads, 2) void scaled_gemm_mid_kernel(ScaledG
   const int wr = wave >> 1, wc = wave & 1;
   const int tiles_m = ((int)p.m + kMidTile - 1) / kMidTile;
   const int tiles_n = ((int)p.n + kMidTile - 1) / kMidTile;
-  const TileCoord tc = map_tile(blockIdx.x, tiles_m, tiles_n);
+  const TileCoord tc = map_tile(blockIdx.x, tiles_m, tiles_n, p.raster_magic, p.raster_shift);
   const int bm0 = tc.tm * kMidTile, bn0 = tc.tn * kMidTile;
 
   Srcs src;
@@ -181,6 +181,7 @@ __global__ __launch_bounds__(kMidThreads, 2) void scaled_gemm_mid_kernel(ScaledG
 int launch_scaled_gemm_mid(const ScaledGemmArgs& p_in, hipStream_t stream) {
   ScaledGemmArgs p = p_in;
   p.rows_epilogue = tuning(CONCH_TUNE_EPILOGUE) != 1;
+  set_raster_divisor((uint32_t)(kGroupM * ((p.n + kMidTile - 1) / kMidTile)), &p.raster_magic, &p.raster_shift);
   const int tiles_m = (int)((p.m + kMidTile - 1) / kMidTile);
   const int tiles_n = (int)((p.n + kMidTile - 1) / kMidTile);
   const dim3 grid((unsigned)(tiles_m * tiles_n));

@@ -542,7 +542,7 @@ __global__ __launch_bounds__(kThreads, 2) void mixed_gemm_kernel(MixedGemmArgs p
   const int wr = TALL ? c.wave >> 1 : c.wave >> 2, wc = TALL ? c.wave & 1 : c.wave & 3;
   const int tiles_m = ((int)p.m + kRows - 1) / kRows;
   const int tiles_n = ((int)p.n + kTileW - 1) / kTileW;
-  const TileCoord tc = map_tile(blockIdx.x, tiles_m, tiles_n);
+  const TileCoord tc = map_tile(blockIdx.x, tiles_m, tiles_n, p.raster_magic, p.raster_shift);
   const int bm0 = tc.tm * kRows, bn0 = tc.tn * kTileW;
 
   // split-K form: this workgroup's K range starts at step0 (0 in the plain form); the X buffer is rebased there, the weight
@@ -1017,6 +1017,10 @@ int launch_mixed_gemm_mfma(const MixedGemmArgs& p_in, hipStream_t stream) {
       p.split_steps = 0;
       p.slabs = nullptr;
     }
+  }
+  {  // the raster's runtime divisor (GROUP_M x tile columns of the tile shape picked) as a host-made reciprocal
+    const int tile_w = p.fuse_silu ? 128 : nt == kMixedTall ? 128 : 64 * nt;
+    set_raster_divisor((uint32_t)(kGroupM * ((p.n + tile_w - 1) / tile_w)), &p.raster_magic, &p.raster_shift);
   }
   int rc;
   if (p.x_dtype == CONCH_DT_FP16) {

@@ -37,24 +37,31 @@ struct TileCoord {
 // XCD-aware + GROUP_M rasterisation.  Workgroups are dealt round-robin over the 8 XCDs, so ids
 // b and b+8 share an L2: give each XCD a contiguous run of the GROUP_M-ordered tile list
 // (bijective for any grid size).  Pure speed; correctness does not depend on placement.
-__device__ __forceinline__ TileCoord raster_tile(int lin, int tiles_m, int tiles_n) {
+// `magic` / `shift`: host-made reciprocal of per_group = GROUP_M x tiles_n (gemm.hpp, set_raster_divisor; shift < 0 = not
+// given).  The group size is 1..4 (GROUP_M = 4), so the other two divisions are by a small constant each.
+__device__ __forceinline__ TileCoord raster_tile(int lin, int tiles_m, int tiles_n, uint32_t magic = 0, int shift = -1) {
   const int per_group = kGroupM * tiles_n;
-  const int group = lin / per_group;
+  const int group = shift < 0 ? lin / per_group : magic ? (int)(__umulhi((uint32_t)lin, magic) >> shift) : lin >> shift;
   const int first_m = group * kGroupM;
   const int gsz = min(tiles_m - first_m, kGroupM);
   const int in_group = lin - group * per_group;
+  int q;
+  if (gsz == 4) q = in_group >> 2;
+  else if (gsz == 3) q = (int)(__umulhi((uint32_t)in_group, 0xAAAAAAABu) >> 1);
+  else if (gsz == 2) q = in_group >> 1;
+  else q = in_group;
   TileCoord t;
-  t.tm = first_m + in_group % gsz;
-  t.tn = in_group / gsz;
+  t.tm = first_m + (in_group - q * gsz);
+  t.tn = q;
   return t;
 }
 
-__device__ __forceinline__ TileCoord map_tile(int bid, int tiles_m, int tiles_n) {
+__device__ __forceinline__ TileCoord map_tile(int bid, int tiles_m, int tiles_n, uint32_t magic = 0, int shift = -1) {
   const int nwg = tiles_m * tiles_n;
   const int xcd = bid & 7;
   const int q = nwg >> 3, r = nwg & 7;
   const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  return raster_tile(lin, tiles_m, tiles_n);
+  return raster_tile(lin, tiles_m, tiles_n, magic, shift);
 }
 
 // Two-width tile schedule of the 256-row scaled GEMM (gemm_mfma.hip): `big_cols` tile columns of 256 output columns,
@@ -78,10 +85,10 @@ struct TilePlace {
   int narrow;  // 1 = 192-column tile
 };
 
-__device__ __forceinline__ TilePlace place_tile(int bid, const TileSchedule& ts) {
+__device__ __forceinline__ TilePlace place_tile(int bid, const TileSchedule& ts, uint32_t magic = 0, int shift = -1) {
   TilePlace t;
   if (ts.narrow_cols == 0) {
-    const TileCoord c = map_tile(bid, ts.tiles_m, ts.big_cols);
+    const TileCoord c = map_tile(bid, ts.tiles_m, ts.big_cols, magic, shift);
     t.tm = c.tm;
     t.n0 = c.tn * kTileN;
     t.narrow = 0;

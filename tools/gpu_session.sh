@@ -1,3 +1,5 @@
-mkdir -p gpurun_out/r3a
-python -m pytest tests/test_gpu_gemm.py -q -m gpu -k "silu or gelu or mixed_row_major" -n 2 2>&1 | tail -3
-python tools/time_fused_ffn.py 7 2>&1 | grep -v amdgpu | tee gpurun_out/r3a/ab10_fused_ffn.log
+python -m pytest tests/test_gpu_gemm.py -q -m gpu -n 2 -x 2>&1 | tail -2
+{
+echo "### entry stamp BEFORE the setup arithmetic"; python tools/clock_probe.py 2 --sched 1 --classes
+echo "### entry stamp AFTER the setup arithmetic"; CONCH_PROBE_LIB=conch_amd/libconch_amd_probeas.so python tools/clock_probe.py 2 --sched 1 --classes
+} 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r3a/probe_setup2.log
