@@ -32,6 +32,23 @@ int tuning(int key);
     }                                                                                     \
   } while (0)
 
+// A buffer descriptor that hipcc can see is wave-uniform: the base pointer (two halves) and the byte count go through
+// v_readfirstlane first.  Without it a descriptor whose inputs hipcc computed on the vector ALU (SGPR pressure, a select, a value
+// carried in a struct with per-lane members) is kept in VGPRs and EVERY buffer instruction that uses it is wrapped in a
+// "waterfall" loop -- four v_readfirstlane, two v_cmp, s_and_saveexec, the instruction, a branch -- found around half of the
+// LDS-DMA instructions of the scaled GEMM's K loop in round 3 (cdna_hip_programming.md T20: `grep -c s_and_saveexec` next to
+// buffer ops in the .s; tools/isa_waterfalls.py).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_uniform_rsrc(const void* base, uint32_t bytes) {
+#ifdef CONCH_EXP_PLAIN_RSRC  // A/B variant: the descriptor as rounds 1-2 built it
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
+#endif
+  const uint64_t a = (uint64_t)base;
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+  const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)bytes);
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, n, 0x00020000);
+}
+
 // Library-owned device scratch, one buffer per (device, stream, slot), grown on demand and kept for the life of the
 // process (stream-ordered hipMallocAsync/hipFreeAsync per call measured ~10 us on ROCm 7.2).  A buffer is only ever used
 // by work enqueued on its own stream, so reuse is ordered by the stream; a grown slot never frees the old buffer (work

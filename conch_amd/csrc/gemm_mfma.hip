@@ -369,8 +369,8 @@ __device__ __forceinline__ BlockSetup setup_block(const ScaledGemmArgs& p, const
   const int64_t b_cols = p.fuse_silu ? 2 * p.n : p.n;
   const uint32_t a_bytes = (uint32_t)((p.m - 1) * p.a_stride_m + p.k);
   const uint32_t b_bytes = (uint32_t)((b_cols - 1) * p.b_stride_n + p.k);
-  s.src.a = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, a_bytes, 0x00020000);
-  s.src.b = __builtin_amdgcn_make_buffer_rsrc((void*)p.b, 0, b_bytes, 0x00020000);
+  s.src.a = make_uniform_rsrc(p.a, a_bytes);
+  s.src.b = make_uniform_rsrc(p.b, b_bytes);
   // fragment read offsets inside a unit (bytes): row r of a 16-row tile, k-group g
   const int r = s.lane & 15, g = s.lane >> 4;
   const int lane_off = (r >> 3) * 1024 + (r & 7) * 128 + ((g ^ ((r >> 1) & 7)) * 16);

@@ -61,8 +61,8 @@ __global__ __launch_bounds__(kSkThreads, 1) void scaled_gemm_skinny_kernel(Scale
 
   const uint32_t a_bytes = (uint32_t)((p.m - 1) * p.a_stride_m + p.k);
   const uint32_t b_bytes = (uint32_t)((p.n - 1) * p.b_stride_n + p.k);
-  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.b, 0, b_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ra = make_uniform_rsrc(p.a, a_bytes);
+  const __amdgpu_buffer_rsrc_t rb = make_uniform_rsrc(p.b, b_bytes);
   // lane (r, g) holds bytes [16g,16g+16) and [64+16g, ...) of row r of every fragment's 128-byte K step
   int voff_a[8];
 #pragma unroll
@@ -221,8 +221,8 @@ __global__ __launch_bounds__(kSkThreads, 1) void skinny_splitk_kernel(ScaledGemm
 
   const uint32_t a_bytes = (uint32_t)(((p.m - 1) * p.a_stride_m + p.k) * (A_SRC ? 2 : 1));
   const uint32_t b_bytes = (uint32_t)((p.n - 1) * p.b_stride_n + p.k);
-  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.b, 0, b_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ra = make_uniform_rsrc(p.a, a_bytes);
+  const __amdgpu_buffer_rsrc_t rb = make_uniform_rsrc(p.b, b_bytes);
 
   // A unit staging: wave w feeds unit rows [ROWS/4 * w, ROWS/4 * (w + 1)) = kPieces subtiles of 8 rows x 128 bytes
   int voff_a[4];  // the first kPieces are used (a dependent array bound here makes hipcc's host pass drop the kernel's stub)
