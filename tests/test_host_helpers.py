@@ -285,3 +285,17 @@ def test_matmul_4bit_rejects_states_that_do_not_describe_the_weight():
     # a consistent state gets past the size checks and is refused only for living on the CPU
     with pytest.raises((RuntimeError, ValueError), match="(?i)device|cuda|rocm|gpu"):
         matmul_4bit(x, wq, state())
+
+
+def test_headline_kernels_have_no_waterfalled_buffer_instructions():
+    """Round 3: hipcc had kept the B operand's buffer descriptor in VGPRs and wrapped half of the scaled GEMM's LDS-DMA
+    instructions in waterfall loops (4 % of C3).  The descriptor inputs now go through v_readfirstlane (common.hpp,
+    make_uniform_rsrc); this compiles the two scaled tile-kernel sources to assembly (no GPU needed, ~25 s) and checks that no
+    buffer instruction sits in such a loop.  tools/isa_waterfalls.py without arguments checks every source (minutes)."""
+    import subprocess
+    import sys
+
+    csrc = ROOT / "conch_amd" / "csrc"
+    res = subprocess.run([sys.executable, str(ROOT / "tools" / "isa_waterfalls.py"), str(csrc / "gemm_mfma.hip"), str(csrc / "gemm_mid.hip")],
+                         capture_output=True, text=True, check=False)
+    assert res.returncode == 0, res.stdout + res.stderr
