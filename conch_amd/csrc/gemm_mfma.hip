@@ -327,7 +327,10 @@ struct BlockSetup {
 // `tid`: the thread id to derive lane constants from.  The persistent kernel passes a value made opaque to the optimiser
 // at every tile boundary: hipcc otherwise hoists the lane-constant parts of this function out of the tile loop and spills
 // them across the K loop, and the reloads' compiler-inserted vmcnt(0) would drain the hand-counted LDS-DMA / store queue.
-__device__ __forceinline__ BlockSetup setup_block(const ScaledGemmArgs& p, const TileSchedule* ts = nullptr, int bid = -1, int tid = -1) {
+// `given_bm0` >= 0: the tile's first row / column are known (the persistent walk looks the next tile up once, before the epilogue,
+// and keeps the two scalars): the raster arithmetic -- most of this function's time -- is skipped.
+__device__ __forceinline__ BlockSetup setup_block(const ScaledGemmArgs& p, const TileSchedule* ts = nullptr, int bid = -1, int tid = -1,
+                                                  int given_bm0 = -1, int given_bn0 = 0) {
   BlockSetup s;
   s.narrow = 0;
   if (bid < 0) bid = blockIdx.x;
@@ -340,7 +343,10 @@ __device__ __forceinline__ BlockSetup setup_block(const ScaledGemmArgs& p, const
   const int tile_n = p.fuse_silu ? kTileN / 2 : kTileN;
   const int tiles_m = ((int)p.m + kTileM - 1) / kTileM;
   const int tiles_n = ((int)p.n + tile_n - 1) / tile_n;
-  if (ts) {
+  if (given_bm0 >= 0) {
+    s.bm0 = given_bm0;
+    s.bn0 = given_bn0;
+  } else if (ts) {
     const TilePlace tp = place_tile(bid, *ts, p.raster_magic, p.raster_shift);
     s.bm0 = tp.tm * kTileM;
     s.bn0 = tp.n0;
@@ -707,13 +713,19 @@ __global__ __launch_bounds__(kThreads, 2) void scaled_gemm_pp2_persistent_kernel
     const int bm0 = s.bm0, bn0 = s.bn0;
     const int next = vb + (int)gridDim.x;
     const bool more = next < total_tiles;  // workgroup-uniform
+    // The tile change looks the next tile up ONCE (the raster arithmetic is most of setup_block's 0.56 us,
+    // profiles/r03/probe_setup.txt) and keeps its two scalars; the per-lane parts are evaluated before the epilogue (to issue
+    // the loads) and again behind it, not carried across it: eight more live registers there would spill, and scratch traffic
+    // would break the counted waits.
+    int nbm0 = 0, nbn0 = 0;
     if (more) {
-      // the next tile's staging offsets live only until its loads are issued (they are recomputed behind the epilogue:
-      // eight more registers across the epilogue would spill, and scratch traffic would break the counted waits)
+      const TilePlace tp = place_tile(next, ts, p.raster_magic, p.raster_shift);
+      nbm0 = tp.tm * kTileM;
+      nbn0 = tp.n0;
       int tid = threadIdx.x;
       asm volatile("" : "+v"(tid));  // see setup_block
-      const BlockSetup sn = setup_block(p, &ts, next, tid);
-      stage_scales(lds, kLdsBytes + (eb ^ 1) * kEpiBytes, p, sn.wave, tid, sn.bm0, sn.bn0);
+      const BlockSetup sn = setup_block(p, &ts, next, tid, nbm0, nbn0);
+      stage_scales(lds, kLdsBytes + (eb ^ 1) * kEpiBytes, p, sn.wave, tid, nbm0, nbn0);
       stage_two_steps(lds, sn);
       __builtin_amdgcn_sched_barrier(0);  // the loads go out before the first store
     }
@@ -727,9 +739,9 @@ __global__ __launch_bounds__(kThreads, 2) void scaled_gemm_pp2_persistent_kernel
     if (tile_stores_whole_lines(p, bm0, bn0)) wait_vmcnt_n<26>();
     else CONCH_VMCNT(0);
     __builtin_amdgcn_s_barrier();
-    int next_opaque = next, tid2 = threadIdx.x;
-    asm volatile("" : "+s"(next_opaque), "+v"(tid2));  // keep hipcc from carrying the first computation across the epilogue
-    s = setup_block(p, &ts, next_opaque, tid2);
+    int tid2 = threadIdx.x;
+    asm volatile("" : "+s"(nbm0), "+s"(nbn0), "+v"(tid2));  // keep hipcc from carrying the first evaluation across the epilogue
+    s = setup_block(p, &ts, next, tid2, nbm0, nbn0);
     vb = next;
     eb ^= 1;
   }
