@@ -265,9 +265,11 @@ __global__ __launch_bounds__(kSkThreads, 1) void skinny_splitk_kernel(ScaledGemm
       const int chunk = pos ^ ((rho >> 1) & 7);
       const int kill = s < valid_steps ? 0 : (int)0x80000000;
       const int voff = (min(m0 + rho, (int)p.m - 1) * (int)p.a_stride_m + chunk * 16) * 2;
-      const int soff = (k_begin + s * kStepBytes) * 2;
-      const i32x4 lo = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, voff | kill, soff, 0));
-      const i32x4 hi = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, (voff + 16) | kill, soff, 0));
+      // the step's byte offset depends on the thread (s = it / ...): it belongs in the VGPR offset.  As an soffset hipcc wrapped
+      // both loads in a waterfall loop over its distinct values (up to eight trips per load; round 3, tools/isa_waterfalls.py)
+      const int koff = voff + (k_begin + s * kStepBytes) * 2;
+      const i32x4 lo = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, koff | kill, 0, 0));
+      const i32x4 hi = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, (koff + 16) | kill, 0, 0));
       float f[16];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {

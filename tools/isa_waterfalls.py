@@ -32,9 +32,12 @@ def waterfalls(src: Path) -> list[tuple[int, str]]:
         if not name.startswith("_Z"):
             continue
         lines = fn.split("\n")
-        # a waterfall: >= 2 v_readfirstlane just above the saveexec (the descriptor words), the buffer instruction just below
-        n = sum(1 for i, l in enumerate(lines) if "s_and_saveexec_b64" in l and any("buffer_" in x for x in lines[i + 1:i + 3])
-                and sum("v_readfirstlane_b32" in x for x in lines[max(0, i - 10):i]) >= 2)
+        # a waterfall: v_readfirstlane + v_cmp_eq just above the saveexec (the descriptor words, or a per-lane soffset), the buffer
+        # instruction just below, `s_xor_b64 exec, exec` just behind it
+        n = sum(1 for i, l in enumerate(lines) if "s_and_saveexec_b64" in l and any("buffer_" in x for x in lines[i + 1:i + 4])
+                and any("v_readfirstlane_b32" in x for x in lines[max(0, i - 10):i])
+                and any("v_cmp_eq" in x for x in lines[max(0, i - 6):i])
+                and any("s_xor_b64 exec, exec" in x for x in lines[i + 1:i + 8]))
         if n:
             rows.append((n, name))
     return rows
