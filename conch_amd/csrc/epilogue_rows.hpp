@@ -61,11 +61,12 @@ __device__ __forceinline__ void epilogue_rows_body(const typename AccT<MMA>::typ
       bsv[nh][1] = *(const f32x4*)(lbias + nl + 4);
     }
   }
-  const int stride_b = (int)p.c_stride_m * 2;
+  // byte offsets into C are unsigned 32-bit quantities (C is below 4 GiB here, not below 2 GiB)
+  const uint32_t stride_b = (uint32_t)p.c_stride_m * 2u;
   const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
       (void*)p.c, 0, (uint32_t)(((p.m - 1) * p.c_stride_m + p.n) * 2), 0x00020000);
-  const int voff = (bm0 + wr * (16 * MT) + rr) * stride_b + (bn0 + wc * 64 + ch * 8) * 2;
-  const int step8 = 8 * stride_b;  // scalar: eight rows further down
+  const uint32_t voff = (uint32_t)(bm0 + wr * (16 * MT) + rr) * stride_b + (uint32_t)(bn0 + wc * 64 + ch * 8) * 2u;
+  const uint32_t step8 = 8u * stride_b;  // scalar: eight rows further down
   i32x4 rd0, rd1;
 #pragma unroll
   for (int b = 0; b < MT + 1; ++b) {
@@ -115,8 +116,8 @@ __device__ __forceinline__ void epilogue_rows_body(const typename AccT<MMA>::typ
       // assumes there is no write-after-read hazard on the data registers of a 16-byte buffer store and may overwrite
       // them with its next VALU instruction before the store has read them -- observed on gfx950 as a wrong first dword in
       // a few lanes of some launches (gemm_mixed.hip's row-major epilogue, round 3)
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rd0), rc, voff + (2 * b - 2) * step8, 0, kCStoreAux);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rd1), rc, voff + (2 * b - 1) * step8, 0, kCStoreAux);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rd0), rc, (int)(voff + (uint32_t)(2 * b - 2) * step8), 0, kCStoreAux);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rd1), rc, (int)(voff + (uint32_t)(2 * b - 1) * step8), 0, kCStoreAux);
     }
   }
 }
@@ -139,7 +140,7 @@ __device__ __forceinline__ int image_chunk_offset(int row, int chunk) {
 template <int ROWS, int PITCH>
 __device__ __forceinline__ void image_store_rows(const char* lds, void* c, int64_t m, int64_t n_cols, int64_t c_stride_m, int bm0, int bn0,
                                                  int lane, int wave) {
-  const int stride_b = (int)c_stride_m * 2;
+  const uint32_t stride_b = (uint32_t)c_stride_m * 2u;  // unsigned byte offsets: C is below 4 GiB, not below 2 GiB
   const __amdgpu_buffer_rsrc_t rc =
       __builtin_amdgcn_make_buffer_rsrc(c, 0, (uint32_t)(((m - 1) * c_stride_m + n_cols) * 2), 0x00020000);
   constexpr bool kWide = PITCH % 256 == 0;
@@ -149,7 +150,7 @@ __device__ __forceinline__ void image_store_rows(const char* lds, void* c, int64
   static_assert((ROWS / kPieceRows) * kPieceCols % 8 == 0, "pieces divide over the eight waves");
   const int lr = kWide ? lane >> 4 : lane >> 3;  // row of the piece
   const int lc = kWide ? lane & 15 : lane & 7;   // 16-byte chunk of the piece
-  const int voff = (bm0 + lr) * stride_b + bn0 * 2 + lc * 16;
+  const uint32_t voff = (uint32_t)(bm0 + lr) * stride_b + (uint32_t)(bn0 * 2 + lc * 16);
 #pragma unroll
   for (int i = 0; i < kPerWave; ++i) {
     const int q = wave * kPerWave + i;  // wave-uniform
@@ -158,7 +159,7 @@ __device__ __forceinline__ void image_store_rows(const char* lds, void* c, int64
     const int chunk = pc * (kWide ? 16 : 8) + lc;
     const i32x4 v = *(const i32x4*)(lds + image_chunk_offset<PITCH>(row, chunk));
     // offset in the VGPR, soffset the constant 0 (see epilogue_rows_body)
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rc, voff + rg * kPieceRows * stride_b + pc * (kWide ? 256 : 128), 0,
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rc, (int)(voff + (uint32_t)(rg * kPieceRows) * stride_b + (uint32_t)(pc * (kWide ? 256 : 128))), 0,
                                            kCStoreAux);
   }
 }

@@ -201,6 +201,28 @@ def test_row_major_epilogue_is_bit_identical(_reset_tuning, oname, iname, m, k, 
     check_scaled(rows, ref, IN_T[iname], DT[oname], (a, b, sa, sb, bias))
 
 
+def test_row_major_epilogue_with_c_between_2_and_4_gib(_reset_tuning):
+    """The whole-line epilogue addresses C through one buffer descriptor with unsigned 32-bit byte offsets: a 2.7 GB output (rows
+    beyond the 2 GiB mark) must equal the direct stores'; C beyond 4 GiB falls back to them by itself."""
+    m, k, n = 65536, 256, 20480
+    torch.manual_seed(3)
+    a = (0.25 * torch.rand((m, k), device="cuda")).to(torch.float8_e4m3fn)
+    bt = (0.25 * torch.rand((n, k), device="cuda")).to(torch.float8_e4m3fn)
+    sa, sb = 0.25 * torch.rand((m, 1), device="cuda"), 0.25 * torch.rand((n, 1), device="cuda")
+    _C.set_gemm_variant(_C.VARIANT_MFMA_PINGPONG2)
+    _C.set_tuning(_C.TUNE_EPILOGUE, 1)
+    direct = scaled_gemm(a, bt.T, sa, sb, torch.bfloat16)
+    _C.set_tuning(_C.TUNE_EPILOGUE, 2)
+    rows = scaled_gemm(a, bt.T, sa, sb, torch.bfloat16)
+    _C.set_gemm_variant(0)
+    assert direct.numel() * 2 > 2**31
+    assert torch.equal(rows.view(torch.int16), direct.view(torch.int16))
+    # a band of rows beyond the 2 GiB mark against the oracle
+    r0 = m - 300
+    ref = oracle.scaled_gemm_ref(a[r0:].cpu(), bt.T.cpu(), sa[r0:].cpu(), sb.cpu(), torch.bfloat16, None)
+    check_scaled(rows[r0:].cpu(), ref, IN_T["fn"], torch.bfloat16)
+
+
 def test_row_major_epilogues_repeat_bit_identically():
     """The whole-line epilogues store with 16-byte buffer stores.  With a REGISTER soffset hipcc (ROCm 7.2) does not guard such a
     store's data registers against its next VALU write, which showed on gfx950 as a wrong first dword in a few lanes of SOME
