@@ -387,10 +387,30 @@ def run_quant_bench(args, tokens: int, hidden: int, device: torch.device, world:
         med = sorted(times)[2]
         result["cpu_baseline"] = {"value": round(bytes_alg / med / 1e9, 2), "unit": "GB/s", "cores": torch.get_num_threads(),
                                   "kind": "port", "sample": f"full tensor, median of 5 runs, {med * 1e3:.1f} ms each"}
+    emit(result, world, rank)
+
+
+def _flush_c_stdio() -> None:
+    """RCCL writes its version banner through C stdio, which is block-buffered on a pipe and would otherwise be flushed at process
+    exit -- BEHIND the JSON line.  Flush it now."""
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001, S110 -- cosmetic
+        pass
+
+
+def emit(result: dict, world: int, rank: int) -> None:
+    """The ONE JSON line, as the last thing any rank writes to stdout: every rank flushes what the libraries buffered, the ranks
+    meet, rank 0 prints, then the group is torn down."""
+    sys.stdout.flush()
+    _flush_c_stdio()
+    if world > 1:
+        torch.distributed.barrier()
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
+        _flush_c_stdio()
 
 
 def main() -> None:
@@ -443,10 +463,7 @@ def main() -> None:
                                        "workload": f"scaled_gemm fp8 {m}x{k}x{n} per rank, weights replicated, no collective"}
             except Exception as exc:  # noqa: BLE001
                 extra["dp_weak_c3"] = {"error": repr(exc)}
-        if rank == 0:
-            print(json.dumps(c5_headline(res, world, args.steps, args.warmup, extra)))
-        if world > 1:
-            torch.distributed.destroy_process_group()
+        emit(c5_headline(res, world, args.steps, args.warmup, extra), world, rank)
         return
 
     if kind == "quant_int8":
@@ -546,10 +563,7 @@ def main() -> None:
             result["cpu_baseline"] = cpu_baseline_scaled(kind, m, k, n)
         else:
             result["cpu_baseline"] = cpu_baseline_mixed(x, w_ref, m, k, n)
-    if rank == 0:
-        print(json.dumps(result))
-    if world > 1:
-        torch.distributed.destroy_process_group()
+    emit(result, world, rank)
 
 
 if __name__ == "__main__":

@@ -79,6 +79,7 @@ class NShardedScaledGemm:
         group: dist.ProcessGroup | None = None,
         gemm_fn: Callable | None = None,
         panels: int | None = None,
+        force_collective: bool = False,
     ) -> None:
         self.group = group
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -89,6 +90,9 @@ class NShardedScaledGemm:
         self.output_dtype = output_dtype
         self.device = torch.device(device)
         self.gemm_fn = gemm_fn
+        # one rank normally writes the row-major result directly; `force_collective` sends it through the staging buffers, the
+        # side stream and the all-gather anyway (a one-rank RCCL group: the GPU test of the exchange path on a one-GPU box)
+        self._exchange = self.world_size > 1 or force_collective
         # row panels exist to overlap the gather of one panel with the GEMM of the next: with one rank there is no gather,
         # the heuristic is not consulted and an explicit `panels` only shapes gathered_panels()' view
         if panels is None:
@@ -101,8 +105,8 @@ class NShardedScaledGemm:
         self._blocks = None  # [G, M, N/G] staging of gathered_blocks(), allocated on first use
         self._c = torch.empty((m, n), dtype=output_dtype, device=self.device)  # row-major result
         # gather staging, one [G, h, N/G] buffer per panel (unused when world_size == 1)
-        self._stage = torch.empty((self.panels, g, self.h, self.n_local), dtype=output_dtype, device=self.device) if g > 1 else None
-        self._side = torch.cuda.Stream(self.device) if self.device.type == "cuda" and g > 1 else None
+        self._stage = torch.empty((self.panels, g, self.h, self.n_local), dtype=output_dtype, device=self.device) if self._exchange else None
+        self._side = torch.cuda.Stream(self.device) if self.device.type == "cuda" and self._exchange else None
 
     # -- the local product -------------------------------------------------------------------------------------------
     def _gemm_into(self, out: torch.Tensor, a, b_shard, scale_a, scale_b_shard, bias_shard) -> None:
@@ -123,7 +127,7 @@ class NShardedScaledGemm:
 
     # -- the exchange ------------------------------------------------------------------------------------------------
     def _run(self, a, b_shard, scale_a, scale_b_shard, bias_shard, unpack: bool) -> None:
-        if self.world_size == 1:
+        if not self._exchange:
             self.local_gemm(a, b_shard, scale_a, scale_b_shard, bias_shard)
             return
         cuda = self._side is not None
@@ -156,7 +160,7 @@ class NShardedScaledGemm:
         """[panels, G, M/panels, N/G]: [p, g] holds rows of panel p, columns [g*N/G, (g+1)*N/G) of C -- the layout the
         panelised all-gathers produce, with no copy at all and every gather but the last under the next panel's GEMM
         (for column-parallel consumers that can walk row panels)."""
-        if self.world_size == 1:
+        if not self._exchange:
             c = self.local_gemm(a, b_shard, scale_a, scale_b_shard, bias_shard)
             return c.view(self.panels, self.h, 1, self.n_local).permute(0, 2, 1, 3)
         self._run(a, b_shard, scale_a, scale_b_shard, bias_shard, unpack=False)
@@ -166,7 +170,7 @@ class NShardedScaledGemm:
         """[G, M, N/G], whatever `panels` is: blocks[g] is rank g's [M, N/G] column block of C (columns
         [g*N/G, (g+1)*N/G)) -- ONE GEMM into this rank's slot and ONE in-place all-gather, no copy.  The panelised,
         overlapped form of the same data is gathered_panels()."""
-        if self.world_size == 1:
+        if not self._exchange:
             return self.local_gemm(a, b_shard, scale_a, scale_b_shard, bias_shard).view(1, self.m, self.n_local)
         if self._blocks is None:
             self._blocks = torch.empty((self.world_size, self.m, self.n_local), dtype=self.output_dtype, device=self.device)

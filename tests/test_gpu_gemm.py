@@ -1447,3 +1447,44 @@ def test_mixed_precision_split_k_on_every_tile_shape(_reset_tuning, nt, wname, u
     for got in outs:
         check_mixed(got, a, w_ref, k)
         assert (got.float() - whole.float()).abs().max().item() <= tol
+
+
+def test_nsharded_gemm_exchange_path_through_a_one_rank_rccl_group():
+    """The exchange path of conch_amd.distributed -- GEMM into the gather slot, all_gather_into_tensor on a side stream under the
+    next panel's GEMM, unpack to row-major -- on the real backend (RCCL), as far as a one-GPU box allows: a one-rank process
+    group.  The result must equal scaled_gemm bit for bit, in every layout the class hands out."""
+    import os
+    import socket
+
+    import torch.distributed as dist
+
+    from conch_amd.distributed import NShardedScaledGemm
+
+    if dist.is_initialized():
+        pytest.skip("a process group is already initialised in this process")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", torch.cuda.current_device()))
+    try:
+        m, k, n = 2048, 1024, 3584
+        a, b, sa, sb, bias = make_scaled_inputs(m, k, n, torch.float8_e4m3fn, torch.bfloat16, False, False, True)
+        ad, bd, sad, sbd, biasd = a.cuda(), b.T.contiguous().cuda().T, sa.cuda(), sb.cuda(), bias.cuda()
+        want = scaled_gemm(ad, bd, sad, sbd, torch.bfloat16, biasd)
+        for panels in (1, 2, 4):
+            op = NShardedScaledGemm(m, n, torch.bfloat16, torch.device("cuda"), panels=panels, force_collective=True)
+            for _ in range(3):  # buffers and the side stream are reused across calls
+                got = op(ad, bd, sad, sbd, biasd)
+                torch.cuda.synchronize()
+                np.testing.assert_array_equal(to_bits(got), to_bits(want))
+            pan = op.gathered_panels(ad, bd, sad, sbd, biasd)
+            torch.cuda.synchronize()
+            assert pan.shape == (panels, 1, m // panels, n)
+            np.testing.assert_array_equal(to_bits(pan[panels - 1, 0]), to_bits(want[m - m // panels:]))
+            blocks = op.gathered_blocks(ad, bd, sad, sbd, biasd)
+            torch.cuda.synchronize()
+            assert blocks.shape == (1, m, n)
+            np.testing.assert_array_equal(to_bits(blocks[0]), to_bits(want))
+    finally:
+        dist.destroy_process_group()
