@@ -1488,3 +1488,28 @@ def test_nsharded_gemm_exchange_path_through_a_one_rank_rccl_group():
             np.testing.assert_array_equal(to_bits(blocks[0]), to_bits(want))
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("col_off", [8, 64, 200])
+@pytest.mark.parametrize("variant_name", ["VARIANT_MFMA_PINGPONG2", "VARIANT_MFMA_MID", "VARIANT_MFMA_PINGPONG"])
+def test_whole_line_epilogue_into_a_strided_column_block(_reset_tuning, col_off, variant_name):
+    """An N-shard writes its column block into a wider row-major buffer: the output is a view with a column offset (16-byte but
+    not 128-byte aligned rows for offsets 8 and 200) and a row stride larger than N.  The whole-line epilogue addresses it
+    through a buffer descriptor over the view; it must write exactly the block and nothing around it."""
+    m, k, n, wide = 512, 256, 768, 1280
+    a, b, sa, sb, bias = make_scaled_inputs(m, k, n, IN_T["fn"], torch.bfloat16, False, False, True)
+    ad, bd, sad, sbd, biasd = a.cuda(), b.T.contiguous().cuda().T, sa.cuda(), sb.cuda(), bias.cuda()
+    md = create_scaled_metadata(ad, bd, sad, sbd, torch.bfloat16)
+    _C.set_gemm_variant(getattr(_C, variant_name))
+    try:
+        want = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
+        _C.set_tuning(_C.TUNE_EPILOGUE, 1)
+        scaled_gemm_launcher(want, ad, bd, sad, sbd, md, bias=biasd)
+        _C.set_tuning(_C.TUNE_EPILOGUE, 2)
+        buf = torch.full((m, wide), -7.0, dtype=torch.bfloat16, device="cuda")
+        scaled_gemm_launcher(buf[:, col_off:col_off + n], ad, bd, sad, sbd, md, bias=biasd)
+    finally:
+        _C.set_gemm_variant(0)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(to_bits(buf[:, col_off:col_off + n].contiguous()), to_bits(want))
+    assert bool((buf[:, :col_off] == -7.0).all()) and bool((buf[:, col_off + n:] == -7.0).all())
