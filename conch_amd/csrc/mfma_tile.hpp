@@ -15,7 +15,11 @@ constexpr int kStepBytes = 128;                     // K bytes per LDS row / per
 constexpr int kUnitBytes = 128 * kStepBytes;        // 16 KiB: 128 rows
 constexpr int kBufBytes = 4 * kUnitBytes;           // U1, V1, V2, U2
 constexpr int kLdsBytes = 2 * kBufBytes;            // double buffered: 128 KiB
+#ifdef CONCH_EXP_GROUP_M  // experiment builds: another raster group height
+constexpr int kGroupM = CONCH_EXP_GROUP_M;
+#else
 constexpr int kGroupM = 4;
+#endif
 
 // Stream order of the units of one K step.  U = rows of A (m), V = rows of B^T (n).
 // U1/U2 hold the first/second 64 rows of BOTH wave-rows' 128-row m ranges, V1/V2 the
@@ -49,7 +53,8 @@ __device__ __forceinline__ TileCoord raster_tile(int lin, int tiles_m, int tiles
   if (gsz == 4) q = in_group >> 2;
   else if (gsz == 3) q = (int)(__umulhi((uint32_t)in_group, 0xAAAAAAABu) >> 1);
   else if (gsz == 2) q = in_group >> 1;
-  else q = in_group;
+  else if (gsz == 1) q = in_group;
+  else q = in_group / gsz;  // only with an experimental GROUP_M above 4
   TileCoord t;
   t.tm = first_m + (in_group - q * gsz);
   t.tn = q;
