@@ -69,10 +69,30 @@ __device__ __forceinline__ void phase_mma(WaveTile<MMA>& w) {
   constexpr int MH = (PHASE >= 2) ? 1 : 0;                 // m sub-half
   constexpr int NH = (PHASE == 1 || PHASE == 2) ? 1 : 0;   // n sub-half
   constexpr int TN = NH == 1 ? NT - 2 : 2;                 // 16-row n tiles of this sub-half
+#ifdef CONCH_EXP_ROWWISE_MFMA
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int t = 0; t < TN; ++t) mma_step<MMA>(w.acc[MH * 4 + i][NH * 2 + t], w.fn[NH][t], w.fm[i]);
+#else
+  // boustrophedon over (m tile, n tile), the two-instruction operand types in two passes: see cluster_mma
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int tt = 0; tt < TN; ++tt) {
+      const int t = (i & 1) ? TN - 1 - tt : tt;
+      mma_part<MMA, 0>(w.acc[MH * 4 + i][NH * 2 + t], w.fn[NH][t], w.fm[i]);
+    }
+  if constexpr (MMA != kMmaFp8) {
+#pragma unroll
+    for (int i = 3; i >= 0; --i)
+#pragma unroll
+      for (int tt = 0; tt < TN; ++tt) {
+        const int t = (i & 1) ? tt : TN - 1 - tt;
+        mma_part<MMA, 1>(w.acc[MH * 4 + i][NH * 2 + t], w.fn[NH][t], w.fm[i]);
+      }
+  }
+#endif
 }
 
 // The MFMA half of a phase: the cluster at raised priority, then the closing barrier.
@@ -525,13 +545,14 @@ __global__ __launch_bounds__(kThreads, 2) void scaled_gemm_pingpong_kernel(Scale
 __device__ unsigned long long g_probe_scaled[kProbeBlocks * 8];
 #endif
 
+// The 16 (12 at the 192-column tile) MFMA pairs of a two-phase cluster: m tiles 4 * which .. + 3 against all n tiles.  Issued in
+// boustrophedon order over (m tile, n tile), so that consecutive MFMAs share an operand (round 3: on a part whose launches are
+// bound by energy the operand fetches count -- C3, 8192^3 and the C5 shard -1.1 ... -1.3 %, profiles/r03/mfma_order_ab.txt), and
+// for the two-instruction operand types as two passes (all chunk-g halves, then all chunk-g+4 halves).  Every accumulator still
+// sees its products in the same order: bit-identical.
 template <int MMA, int NT>
-__device__ __forceinline__ void pp2_cluster(WaveTile<MMA>& w, int which) {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this phase's fragment reads have left LDS
-  __builtin_amdgcn_sched_barrier(0);
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
-  __builtin_amdgcn_s_setprio(1);
+__device__ __forceinline__ void cluster_mma(WaveTile<MMA>& w, int which) {
+#ifdef CONCH_EXP_ROWWISE_MFMA  // A/B variant: rounds 1-2's order (n sub-half by n sub-half, m tile by m tile)
   if (which == 0) {
     phase_mma<MMA, 0, NT>(w);
     phase_mma<MMA, 1, NT>(w);
@@ -539,6 +560,35 @@ __device__ __forceinline__ void pp2_cluster(WaveTile<MMA>& w, int which) {
     phase_mma<MMA, 2, NT>(w);
     phase_mma<MMA, 3, NT>(w);
   }
+  return;
+#endif
+  const int mh = which == 0 ? 0 : 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int bb = 0; bb < NT; ++bb) {
+      const int b = (i & 1) ? NT - 1 - bb : bb;
+      mma_part<MMA, 0>(w.acc[mh + i][b], w.fn[b >> 1][b & 1], w.fm[i]);
+    }
+  if constexpr (MMA != kMmaFp8) {
+#pragma unroll
+    for (int i = 3; i >= 0; --i)
+#pragma unroll
+      for (int bb = 0; bb < NT; ++bb) {
+        const int b = (i & 1) ? bb : NT - 1 - bb;
+        mma_part<MMA, 1>(w.acc[mh + i][b], w.fn[b >> 1][b & 1], w.fm[i]);
+      }
+  }
+}
+
+template <int MMA, int NT>
+__device__ __forceinline__ void pp2_cluster(WaveTile<MMA>& w, int which) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this phase's fragment reads have left LDS
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_setprio(1);
+  cluster_mma<MMA, NT>(w, which);
   __builtin_amdgcn_s_setprio(0);
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_barrier();

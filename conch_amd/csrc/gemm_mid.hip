@@ -115,10 +115,24 @@ __global__ __launch_bounds__(kMidThreads, 2) void scaled_gemm_mid_kernel(ScaledG
     for (int q = 0; q < 4; ++q) fn[q] = read_frag(lds, buf + n_base + q * 2048);
 #pragma unroll
     for (int i = 0; i < 4; ++i) fm[i] = read_frag(lds, buf + m_base + i * 2048);
+    // D rows = n, D cols = m.  Boustrophedon over (m tile, n tile) so that consecutive MFMAs share an operand, the int8 form's two
+    // instructions per tile pair as two passes (gemm_mfma.hip, cluster_mma); every accumulator keeps its order of products
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) mma_step<MMA>(acc[i][q], fn[q], fm[i]);  // D rows = n, D cols = m
+      for (int qq = 0; qq < 4; ++qq) {
+        const int q = (i & 1) ? 3 - qq : qq;
+        mma_part<MMA, 0>(acc[i][q], fn[q], fm[i]);
+      }
+    if constexpr (MMA != kMmaFp8) {
+#pragma unroll
+      for (int i = 3; i >= 0; --i)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+          const int q = (i & 1) ? qq : 3 - qq;
+          mma_part<MMA, 1>(acc[i][q], fn[q], fm[i]);
+        }
+    }
   }
 
   // epilogue: sb * (sa * acc), RNE cast, bias in the output dtype (reference/quantization/scaled_gemm.py:21-25).

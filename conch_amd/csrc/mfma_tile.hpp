@@ -287,5 +287,22 @@ __device__ __forceinline__ void mma_step(typename AccT<MMA>::type& acc, const Fr
 }
 
 
+// One HALF of mma_step for the operand types that take two MFMAs per 128-byte K step (PART 0: the 16-byte chunks g, PART 1: the
+// chunks g + 4); the fp8 form is one instruction (PART 0; PART 1 is empty).  Lets a cluster issue all its PART-0 MFMAs, then all
+// its PART-1 MFMAs, each pass in an order in which consecutive instructions share an operand (cluster_mma in gemm_mfma.hip).
+template <int MMA, int PART>
+__device__ __forceinline__ void mma_part(typename AccT<MMA>::type& acc, const Frag& fa, const Frag& fb) {
+  if constexpr (MMA == kMmaFp8) {
+    if constexpr (PART == 0) mma_step<MMA>(acc, fa, fb);
+  } else if constexpr (MMA == kMmaBf16) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, PART ? fa.hi : fa.lo), __builtin_bit_cast(bf16x8, PART ? fb.hi : fb.lo), acc, 0, 0, 0);
+  } else if constexpr (MMA == kMmaF16) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, PART ? fa.hi : fa.lo), __builtin_bit_cast(f16x8, PART ? fb.hi : fb.lo), acc, 0, 0, 0);
+  } else {
+    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(PART ? fa.hi : fa.lo, PART ? fb.hi : fb.lo, acc, 0, 0, 0);
+  }
+}
+
+
 }  // namespace tile
 }  // namespace conch
