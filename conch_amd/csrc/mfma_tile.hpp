@@ -194,6 +194,17 @@ struct Srcs {
 };
 
 // Issue the two LDS-DMA wave-instructions this wave contributes to unit `KIND` of K step `tile`.
+#ifdef CONCH_EXP_DMA_AUX_A  // experiment builds: cache-policy bits of the operand LDS-DMA loads (1 = sc0, 2 = nt, 16 = sc1)
+constexpr int kDmaAuxA = CONCH_EXP_DMA_AUX_A;
+#else
+constexpr int kDmaAuxA = 0;
+#endif
+#ifdef CONCH_EXP_DMA_AUX_B
+constexpr int kDmaAuxB = CONCH_EXP_DMA_AUX_B;
+#else
+constexpr int kDmaAuxB = 0;
+#endif
+
 template <int KIND>
 __device__ __forceinline__ void stage_unit(char* lds, const Srcs& src, const StageOffsets& so, int wave,
                                            int tile) {
@@ -201,11 +212,11 @@ __device__ __forceinline__ void stage_unit(char* lds, const Srcs& src, const Sta
   const int koff = tile * kStepBytes;
   char* dst = lds + buf * kBufBytes + KIND * kUnitBytes + wave * 2048;
   if constexpr (KIND == kU1 || KIND == kU2) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(src.a, (lds_void_t*)dst, 16, so.off[KIND][0], koff, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(src.a, (lds_void_t*)(dst + 1024), 16, so.off[KIND][1], koff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(src.a, (lds_void_t*)dst, 16, so.off[KIND][0], koff, 0, kDmaAuxA);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(src.a, (lds_void_t*)(dst + 1024), 16, so.off[KIND][1], koff, 0, kDmaAuxA);
   } else {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(src.b, (lds_void_t*)dst, 16, so.off[KIND][0], koff, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(src.b, (lds_void_t*)(dst + 1024), 16, so.off[KIND][1], koff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(src.b, (lds_void_t*)dst, 16, so.off[KIND][0], koff, 0, kDmaAuxB);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(src.b, (lds_void_t*)(dst + 1024), 16, so.off[KIND][1], koff, 0, kDmaAuxB);
   }
 }
 
