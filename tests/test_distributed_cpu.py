@@ -141,3 +141,32 @@ def _odd_m_worker(rank: int, world: int, port: int) -> None:
 
 def test_nsharded_gemm_world2_odd_m_default_panels():
     mp.spawn(_odd_m_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
+def _one_rank_worker(rank: int, world: int, port: int) -> None:
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(2)
+        m, k, n = 64, 128, 96
+        a = torch.randint(-32, 32, (m, k), dtype=torch.int8)
+        b = torch.randint(-32, 32, (n, k), dtype=torch.int8).T
+        sa, sb = 0.25 * torch.rand(m, 1), 0.25 * torch.rand(n, 1)
+        full = oracle.scaled_gemm_ref(a, b, sa, sb, torch.bfloat16, None)
+        for panels in (1, 4):
+            op = NShardedScaledGemm(m, n, torch.bfloat16, torch.device("cpu"), gemm_fn=oracle.scaled_gemm_ref, panels=panels, force_collective=True)
+            assert op._stage is not None  # the exchange path, not the one-rank shortcut
+            for _ in range(2):
+                assert torch.equal(op(a, b, sa, sb).view(torch.int16), full.view(torch.int16))
+            assert torch.equal(op.gathered_blocks(a, b, sa, sb)[0].view(torch.int16), full.view(torch.int16))
+            pan = op.gathered_panels(a, b, sa, sb)
+            assert pan.shape == (panels, 1, m // panels, n)
+            assert torch.equal(pan[panels - 1, 0].view(torch.int16), full[m - m // panels:].view(torch.int16))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_force_collective_runs_the_exchange_path_with_one_rank():
+    """`force_collective=True` sends a one-rank group through the staging buffers and the all-gather (the GPU suite does the same
+    through a one-rank RCCL group: the exchange path on the real backend, as far as a one-GPU box allows)."""
+    mp.spawn(_one_rank_worker, args=(1, _free_port()), nprocs=1, join=True)
