@@ -13,6 +13,8 @@
 //   * partial sums go to fp32 slabs [slice][M][N] in library scratch; mixed_skinny_reduce_kernel adds the slices in a
 //     fixed order and casts (the reference's result type, kernels/quantization/gemm.py:482-545).
 // ROWS (16 / 32 / 64) = rows of X a workgroup stages and multiplies.
+#include <algorithm>
+
 #include "common.hpp"
 #include "gemm.hpp"
 #include "mfma_tile.hpp"
@@ -208,24 +210,44 @@ __global__ __launch_bounds__(kMsThreads) void mixed_skinny_kernel(MixedGemmArgs 
   }
 }
 
+// Grid of the slab reduce kernels: blockIdx.y walks the rows, blockIdx.x x 256 + thread the 4-column quads of a row.  (Round 3:
+// the kernels had taken a flat quad index and split it with a 64-bit division per thread -- ~200 instructions ahead of the first
+// load in a kernel that lives 3-4 us -- and the fp32 ones added their slices one dependent L2 round trip at a time.)
+inline dim3 reduce_grid(int64_t m, int64_t quads_per_row) {
+  return dim3((unsigned)((quads_per_row + 255) / 256), (unsigned)std::min<int64_t>(m, 65535));
+}
+
+// four slabs of loads in flight, added in slice order (deterministic)
+__device__ __forceinline__ f32x4 sum_slabs(const float* __restrict__ base, int64_t slab_stride, int slices) {
+  f32x4 sum = f32x4{0, 0, 0, 0};
+  for (int sb = 0; sb < slices; sb += 4) {
+    f32x4 part[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) part[j] = *(const f32x4*)(base + (int64_t)min(sb + j, slices - 1) * slab_stride);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sum = (sb + j == 0) ? part[j] : (sb + j < slices) ? sum + part[j] : sum;
+  }
+  return sum;
+}
+
 // out[m][n..n+3] = cast( sum over slices, in slice order )
 template <int OUT_DT>
 __global__ __launch_bounds__(256) void mixed_skinny_reduce_kernel(MixedGemmArgs p, const float* __restrict__ slabs, int slices) {
-  const int64_t quad = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t quads_per_row = p.n / 4;
-  if (quad >= p.m * quads_per_row) return;
-  const int m = (int)(quad / quads_per_row), n = (int)(quad % quads_per_row) * 4;
-  f32x4 sum = *(const f32x4*)(slabs + (int64_t)m * p.n + n);
-  for (int s = 1; s < slices; ++s) sum += *(const f32x4*)(slabs + ((int64_t)s * p.m + m) * p.n + n);
-  i32x2 pk;
-  pk[0] = (int)pack2_bits16<OUT_DT>(f32x2{sum[0], sum[1]});
-  pk[1] = (int)pack2_bits16<OUT_DT>(f32x2{sum[2], sum[3]});
-  uint16_t* dst = (uint16_t*)p.c + (int64_t)m * p.c_stride_m + n;
-  if ((((uintptr_t)dst) & 7) == 0) {
-    *(i32x2*)dst = pk;
-  } else {
+  const int q = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  if (q >= (int)(p.n / 4)) return;
+  const int n = q * 4;
+  for (int m = blockIdx.y; m < (int)p.m; m += gridDim.y) {
+    const f32x4 sum = sum_slabs(slabs + (int64_t)m * p.n + n, p.m * p.n, slices);
+    i32x2 pk;
+    pk[0] = (int)pack2_bits16<OUT_DT>(f32x2{sum[0], sum[1]});
+    pk[1] = (int)pack2_bits16<OUT_DT>(f32x2{sum[2], sum[3]});
+    uint16_t* dst = (uint16_t*)p.c + (int64_t)m * p.c_stride_m + n;
+    if ((((uintptr_t)dst) & 7) == 0) {
+      *(i32x2*)dst = pk;
+    } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) dst[e] = (uint16_t)((uint32_t)pk[e >> 1] >> (16 * (e & 1)));
+      for (int e = 0; e < 4; ++e) dst[e] = (uint16_t)((uint32_t)pk[e >> 1] >> (16 * (e & 1)));
+    }
   }
 }
 
@@ -234,22 +256,20 @@ __global__ __launch_bounds__(256) void mixed_skinny_reduce_kernel(MixedGemmArgs 
 template <int OUT_DT>
 __global__ __launch_bounds__(256) void mixed_skinny_reduce_silu_kernel(MixedGemmArgs p, const float* __restrict__ slabs, int slices) {
   const int64_t d = p.n / 2;
-  const int64_t quad = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t quads_per_row = d / 4;
-  if (quad >= p.m * quads_per_row) return;
-  const int m = (int)(quad / quads_per_row), j0 = (int)(quad % quads_per_row) * 4;
-  f32x4 g = *(const f32x4*)(slabs + (int64_t)m * p.n + j0), u = *(const f32x4*)(slabs + (int64_t)m * p.n + d + j0);
-  for (int s = 1; s < slices; ++s) {
-    g += *(const f32x4*)(slabs + ((int64_t)s * p.m + m) * p.n + j0);
-    u += *(const f32x4*)(slabs + ((int64_t)s * p.m + m) * p.n + d + j0);
-  }
-  uint16_t* dst = (uint16_t*)p.c + (int64_t)m * p.c_stride_m + j0;
+  const int q = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  if (q >= (int)(d / 4)) return;
+  const int j0 = q * 4;
+  for (int m = blockIdx.y; m < (int)p.m; m += gridDim.y) {
+    const f32x4 g = sum_slabs(slabs + (int64_t)m * p.n + j0, p.m * p.n, slices);
+    const f32x4 u = sum_slabs(slabs + (int64_t)m * p.n + d + j0, p.m * p.n, slices);
+    uint16_t* dst = (uint16_t*)p.c + (int64_t)m * p.c_stride_m + j0;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const float gr = bits16_to_float<OUT_DT>(float_to_bits16<OUT_DT>(g[e]));
-    const float ur = bits16_to_float<OUT_DT>(float_to_bits16<OUT_DT>(u[e]));
-    const float sr = bits16_to_float<OUT_DT>(float_to_bits16<OUT_DT>(pin_f32(act_f32(gr, p.fuse_silu))));
-    dst[e] = float_to_bits16<OUT_DT>(pin_f32(sr * ur));
+    for (int e = 0; e < 4; ++e) {
+      const float gr = bits16_to_float<OUT_DT>(float_to_bits16<OUT_DT>(g[e]));
+      const float ur = bits16_to_float<OUT_DT>(float_to_bits16<OUT_DT>(u[e]));
+      const float sr = bits16_to_float<OUT_DT>(float_to_bits16<OUT_DT>(pin_f32(act_f32(gr, p.fuse_silu))));
+      dst[e] = float_to_bits16<OUT_DT>(pin_f32(sr * ur));
+    }
   }
 }
 
@@ -290,11 +310,10 @@ int launch_f32_slab_reduce(void* c, const float* slabs, int slices, int64_t m, i
   p.m = m;
   p.n = n;
   p.c_stride_m = c_stride_m;
-  const int64_t quads = m * (n / 4);
   if (out_dtype == CONCH_DT_FP16)
-    hipLaunchKernelGGL((mixed_skinny_reduce_kernel<CONCH_DT_FP16>), dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, p, slabs, slices);
+    hipLaunchKernelGGL((mixed_skinny_reduce_kernel<CONCH_DT_FP16>), reduce_grid(m, n / 4), dim3(256), 0, stream, p, slabs, slices);
   else
-    hipLaunchKernelGGL((mixed_skinny_reduce_kernel<CONCH_DT_BF16>), dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, p, slabs, slices);
+    hipLaunchKernelGGL((mixed_skinny_reduce_kernel<CONCH_DT_BF16>), reduce_grid(m, n / 4), dim3(256), 0, stream, p, slabs, slices);
   return check_launch("f32_slab_reduce");
 }
 
@@ -335,18 +354,16 @@ int launch_mixed_gemm_skinny(const MixedGemmArgs& p, hipStream_t stream) {
   }
   if (one_launch) return check_launch("mixed_gemm_skinny_one_launch");
   if (p.fuse_silu) {  // p.n = 2d columns [gate | up], C has d (caller: mixed_gemm_skinny_supported(wide) && d % 4 == 0)
-    const int64_t oquads = p.m * (p.n / 8);
     if (p.out_dtype == CONCH_DT_FP16)
-      hipLaunchKernelGGL((mixed_skinny_reduce_silu_kernel<CONCH_DT_FP16>), dim3((unsigned)((oquads + 255) / 256)), dim3(256), 0, stream, p, (const float*)ws, slices);
+      hipLaunchKernelGGL((mixed_skinny_reduce_silu_kernel<CONCH_DT_FP16>), reduce_grid(p.m, p.n / 8), dim3(256), 0, stream, p, (const float*)ws, slices);
     else
-      hipLaunchKernelGGL((mixed_skinny_reduce_silu_kernel<CONCH_DT_BF16>), dim3((unsigned)((oquads + 255) / 256)), dim3(256), 0, stream, p, (const float*)ws, slices);
+      hipLaunchKernelGGL((mixed_skinny_reduce_silu_kernel<CONCH_DT_BF16>), reduce_grid(p.m, p.n / 8), dim3(256), 0, stream, p, (const float*)ws, slices);
     return check_launch("mixed_gemm_skinny_silu");
   }
-  const int64_t quads = p.m * (p.n / 4);
   if (p.out_dtype == CONCH_DT_FP16)
-    hipLaunchKernelGGL((mixed_skinny_reduce_kernel<CONCH_DT_FP16>), dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, p, (const float*)ws, slices);
+    hipLaunchKernelGGL((mixed_skinny_reduce_kernel<CONCH_DT_FP16>), reduce_grid(p.m, p.n / 4), dim3(256), 0, stream, p, (const float*)ws, slices);
   else
-    hipLaunchKernelGGL((mixed_skinny_reduce_kernel<CONCH_DT_BF16>), dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, p, (const float*)ws, slices);
+    hipLaunchKernelGGL((mixed_skinny_reduce_kernel<CONCH_DT_BF16>), reduce_grid(p.m, p.n / 4), dim3(256), 0, stream, p, (const float*)ws, slices);
   return check_launch("mixed_gemm_skinny");
 }
 

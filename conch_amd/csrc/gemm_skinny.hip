@@ -366,10 +366,11 @@ __global__ __launch_bounds__(kSkThreads, 1) void skinny_splitk_kernel(ScaledGemm
 // out[m][n..n+3] = epilogue( sum over slices, in slice order )
 template <int MMA, int OUT_DT>
 __global__ __launch_bounds__(256) void skinny_reduce_kernel(ScaledGemmArgs p, const int* __restrict__ slabs, int slices) {
-  const int64_t quad = (int64_t)blockIdx.x * 256 + threadIdx.x;  // 4 consecutive n
-  const int64_t quads_per_row = p.n / 4;
-  if (quad >= p.m * quads_per_row) return;
-  const int m = (int)(quad / quads_per_row), n = (int)(quad % quads_per_row) * 4;
+  // blockIdx.y = row, blockIdx.x x 256 + thread = the 4-column quad of the row (round 3: a flat index split by a 64-bit division
+  // per thread had put ~200 instructions ahead of the first load of a kernel that lives 3-4 us)
+  const int q = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  if (q >= (int)(p.n / 4)) return;
+  const int m = blockIdx.y, n = q * 4;
   // four slices of loads in flight at a time (a plain `for s` loop is one dependent L2 round trip per slice), added in
   // slice order: exact for int32, deterministic for fp32
   typename AccT<MMA>::type sum;
@@ -413,10 +414,9 @@ __global__ __launch_bounds__(256) void skinny_reduce_kernel(ScaledGemmArgs p, co
 template <int MMA, int OUT_DT>
 __global__ __launch_bounds__(256) void skinny_reduce_silu_kernel(ScaledGemmArgs p, const int* __restrict__ slabs, int slices) {
   const int64_t d = p.n / 2;
-  const int64_t quad = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t quads_per_row = d / 4;
-  if (quad >= p.m * quads_per_row) return;
-  const int m = (int)(quad / quads_per_row), j0 = (int)(quad % quads_per_row) * 4;
+  const int q = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  if (q >= (int)(d / 4)) return;
+  const int m = blockIdx.y, j0 = q * 4;
   const float sa = p.scale_a[p.scale_a_numel != 1 ? m : 0];
   uint16_t gu[2][4];
 #pragma unroll
@@ -538,14 +538,12 @@ int launch_splitk(const ScaledGemmArgs& p, int slices, hipStream_t stream) {
     return check_launch("scaled_gemm_skinny_splitk_fused");
   }
   launch_splitk_kernel<MMA, CONCH_DT_BF16, false>(rows, steps, grid, p, (int*)ws, nullptr, stream);
-  const int64_t quads = p.m * (p.n / 4);
   if (p.fuse_silu) {  // p.n = 2d columns [gate | up], C has d
-    const int64_t oquads = p.m * (p.n / 8);
-    hipLaunchKernelGGL((skinny_reduce_silu_kernel<MMA, OUT_DT>), dim3((unsigned)((oquads + 255) / 256)), dim3(256), 0, stream, p,
+    hipLaunchKernelGGL((skinny_reduce_silu_kernel<MMA, OUT_DT>), dim3((unsigned)((p.n / 8 + 255) / 256), (unsigned)p.m), dim3(256), 0, stream, p,
                        (const int*)ws, slices);
     return check_launch("scaled_gemm_skinny_splitk_silu");
   }
-  hipLaunchKernelGGL((skinny_reduce_kernel<MMA, OUT_DT>), dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, p,
+  hipLaunchKernelGGL((skinny_reduce_kernel<MMA, OUT_DT>), dim3((unsigned)((p.n / 4 + 255) / 256), (unsigned)p.m), dim3(256), 0, stream, p,
                      (const int*)ws, slices);
   return check_launch("scaled_gemm_skinny_splitk");
 }
