@@ -138,6 +138,8 @@ __global__ __launch_bounds__(kBnbThreads) void bnb_quantize_kernel(uint8_t* __re
   const int64_t span = (int64_t)PASSES * 512;           // elements per wave
   const int64_t w0 = wave * span;                       // first element of this wave
   if (w0 >= n) return;
+  const int bs_shift = __builtin_ctz((unsigned)blocksize);  // a power of two (check_common): the block of an element is a shift, not
+                                                            // a 64-bit division per lane and pass (round 3: ~100 instructions each)
   const bool wide = ((uintptr_t)x & 15) == 0;
   float f[PASSES][8];
   float amax = 0.0f;
@@ -145,8 +147,8 @@ __global__ __launch_bounds__(kBnbThreads) void bnb_quantize_kernel(uint8_t* __re
   for (int ps = 0; ps < PASSES; ++ps) {
     const int64_t e0 = w0 + ps * 512 + lane * 8;
     // the block this lane's elements belong to ends at blk_end: elements of the NEXT block never enter this one's maximum
-    const int64_t blk = e0 / blocksize;
-    const int64_t blk_end = min((blk + 1) * (int64_t)blocksize, n);
+    const int64_t blk = e0 >> bs_shift;
+    const int64_t blk_end = min((blk + 1) << bs_shift, n);
     load8<XDT>(x, e0, blk_end, wide, f[ps]);
 #pragma unroll
     for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(f[ps][i]));
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(kBnbThreads) void bnb_quantize_kernel(uint8_t* __re
   const int group = PASSES > 1 ? 64 : blocksize / 8;
   for (int off = 1; off < group; off <<= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
   const int64_t e_first = w0 + lane * 8;
-  const int64_t blk = e_first / blocksize;
+  const int64_t blk = e_first >> bs_shift;
   if (e_first < n && (lane & (group - 1)) == 0) {
     if constexpr (ADT == CONCH_DT_FP32) ((float*)absmax)[blk] = amax;
     else ((uint16_t*)absmax)[blk] = float_to_bits16<ADT>(amax);  // exact: amax is a value of the input dtype
@@ -165,8 +167,8 @@ __global__ __launch_bounds__(kBnbThreads) void bnb_quantize_kernel(uint8_t* __re
   for (int ps = 0; ps < PASSES; ++ps) {
     const int64_t e0 = w0 + ps * 512 + lane * 8;
     if (e0 >= n) continue;
-    const int64_t b = e0 / blocksize;
-    const int64_t blk_end = min((b + 1) * (int64_t)blocksize, n);
+    const int64_t b = e0 >> bs_shift;
+    const int64_t blk_end = min((b + 1) << bs_shift, n);
     const int64_t valid = blk_end - e0;  // elements of this lane that exist (> 0)
     uint32_t c[8];
 #pragma unroll
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(kBnbThreads) void bnb_quantize_kernel(uint8_t* __re
     } else {
       // pair j of a block = elements 2j, 2j+1 -> one byte, first element in the high nibble; a block of odd length drops its
       // last element (quantize_blockwise.py:162); output byte of element e of block b: b * blocksize/2 + (e - b*blocksize)/2
-      uint8_t* dst = out + b * (blocksize / 2) + (e0 - b * blocksize) / 2;
+      uint8_t* dst = out + (b << (bs_shift - 1)) + ((e0 - (b << bs_shift)) >> 1);
       const uint32_t word = ((c[0] << 4) | c[1]) | (((c[2] << 4) | c[3]) << 8) | (((c[4] << 4) | c[5]) << 16) | (((c[6] << 4) | c[7]) << 24);
       if (valid >= 8) {
         *(uint32_t*)dst = word;
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(kBnbThreads) void bnb_dequantize_kernel(void* __res
   __syncthreads();
   const int64_t e0 = ((int64_t)blockIdx.x * kBnbThreads + threadIdx.x) * 8;
   if (e0 >= n) return;
-  const int64_t b = e0 / blocksize;  // 8 | blocksize: the eight elements share a block
+  const int64_t b = e0 >> __builtin_ctz((unsigned)blocksize);  // a power of two; 8 | blocksize: the eight elements share a block
   float am;
   if constexpr (ADT == CONCH_DT_FP32) am = ((const float*)absmax)[b];
   else am = bits16_to_float<ADT>(((const uint16_t*)absmax)[b]);
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(kBnbThreads) void bnb_dequantize_kernel(void* __res
     }
   }
   // row-strided output (the GEMM's W^T scratch has the same rows): element e -> row e / row_len, column e % row_len
-  const int64_t row = e0 / row_len, col = e0 - row * row_len;
+  const int64_t row = row_len >= n ? 0 : e0 / row_len, col = e0 - row * row_len;  // flat output: one "row" (no division)
   const int64_t o0 = row * out_stride_row + col;
   float r[8];
 #pragma unroll
