@@ -15,7 +15,7 @@
 namespace conch {
 
 static thread_local char g_error[512] = "";
-static std::atomic<int> g_tuning[10] = {};
+static std::atomic<int> g_tuning[11] = {};
 
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -24,7 +24,7 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-int tuning(int key) { return (key >= 0 && key < 10) ? g_tuning[key].load() : 0; }
+int tuning(int key) { return (key >= 0 && key < 11) ? g_tuning[key].load() : 0; }
 
 int device_cu_count() {
   static std::atomic<int> cache[64] = {};
@@ -471,7 +471,7 @@ extern "C" int conch_abi_version(void) { return CONCH_AMD_ABI_VERSION; }
 extern "C" const char* conch_last_error(void) { return g_error; }
 
 extern "C" int conch_set_tuning(int key, int value) {
-  CONCH_CHECK_ARG(key >= 0 && key < 10, "conch_set_tuning: unknown key %d", key);
+  CONCH_CHECK_ARG(key >= 0 && key < 11, "conch_set_tuning: unknown key %d", key);
   g_tuning[key].store(value);
   return CONCH_OK;
 }

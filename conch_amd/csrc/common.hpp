@@ -111,6 +111,11 @@ __device__ __forceinline__ void probe_stamp(unsigned long long* slot) {
   do {                                                                                             \
     if (threadIdx.x == 0 && (idx) < kProbeBlocks) probe_stamp(&(buf)[(idx) * 8 + 2 * (which)]);    \
   } while (0)
+// eight 100 MHz stamps per workgroup (slot 0..7), workgroup index given by the kernel
+#define CONCH_STAMP(buf, slot, idx)                                                                \
+  do {                                                                                             \
+    if (threadIdx.x == 0 && (idx) < kProbeBlocks) (buf)[(idx) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
 #define CONCH_PROBE_READER(fn, buf)                                                                \
   extern "C" int fn(unsigned long long* out, int n_blocks) {                                       \
     if (n_blocks > conch::kProbeBlocks) n_blocks = conch::kProbeBlocks;                            \
@@ -119,6 +124,7 @@ __device__ __forceinline__ void probe_stamp(unsigned long long* slot) {
 #else
 #define CONCH_PROBE(buf, which) do { } while (0)
 #define CONCH_PROBE_AT(buf, which, idx) do { } while (0)
+#define CONCH_STAMP(buf, slot, idx) do { } while (0)
 #endif
 
 // ---------------------------------------------------------------------------------------------

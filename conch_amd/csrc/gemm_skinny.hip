@@ -141,38 +141,49 @@ __global__ __launch_bounds__(kSkThreads, 1) void scaled_gemm_skinny_kernel(Scale
 constexpr int kSpN = 64;          // columns per workgroup (16 per wave)
 constexpr int kSpSteps = 8;       // 128-byte K steps per slice: a slice is 1024 bytes of K
 constexpr int kSpSliceK = kSpSteps * kStepBytes;
+constexpr int kSpCountersPerTile = 4;  // one-launch form: one arrival counter per (tile, wave)
 
 // ROWS = rows of A a workgroup handles (32, 64 or 128): a decode batch of 32 rows stages, multiplies and writes a quarter
 // of what the 128-row form does.  Per step and wave: 2 register loads of B^T + ROWS/32 LDS-DMA pieces of A.
-template <int MMA, int ROWS, int STEPS, int S>
+// GATHER: the B^T fragments were fetched with lane L on (row L >> 2, 16-byte chunk L & 3) -- every quad of lanes inside one
+// 128-byte line, the access shape the texture path takes at full rate -- and lane (r, g) of the MFMA operand collects its
+// chunk from lane 4 r + g (`gather` = that lane's ds_bpermute address)
+template <int MMA, int ROWS, int STEPS, bool GATHER, int S>
 __device__ __forceinline__ void sp_consume(typename AccT<MMA>::type (&acc)[ROWS / 16], const Frag (&fb)[STEPS], const char* lds,
-                                           int lane_off) {
+                                           int lane_off, int gather) {
   constexpr int kOps = 2 + ROWS / 32;
   if constexpr (S < STEPS) {
     wait_vmcnt_n<kOps * (STEPS - 1 - S)>();  // step S of this wave has landed ...
+    Frag b = fb[S];
+    if constexpr (GATHER) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        b.lo[j] = __builtin_amdgcn_ds_bpermute(gather, fb[S].lo[j]);
+        b.hi[j] = __builtin_amdgcn_ds_bpermute(gather, fb[S].hi[j]);
+      }
+    }
     __builtin_amdgcn_s_barrier();            // ... and so has every other wave's quarter of unit S
 #pragma unroll
     for (int i = 0; i < ROWS / 16; ++i) {
       const Frag fa = read_frag(lds, S * (ROWS * kStepBytes) + lane_off + i * 2048);
-      mma_step<MMA>(acc[i], fb[S], fa);  // D rows = n, D cols = m
+      mma_step<MMA>(acc[i], b, fa);  // D rows = n, D cols = m
     }
-    sp_consume<MMA, ROWS, STEPS, S + 1>(acc, fb, lds, lane_off);
+    sp_consume<MMA, ROWS, STEPS, GATHER, S + 1>(acc, fb, lds, lane_off, gather);
   }
 }
 
-// scale / cast / bias of four consecutive columns of one row (scaled_gemm.py:21-25), packed as 2 dwords
+// scale / cast / bias of four consecutive columns of one row (scaled_gemm.py:21-25), packed as 2 dwords; the scales and the
+// bias bits are given (sp_epilogue4 loads them; the one-launch split-K kernel fetched them before its K slice)
 template <int OUT_DT, class ACC>
-__device__ __forceinline__ i32x2 sp_epilogue4(const ScaledGemmArgs& p, const ACC& sum, int m, int n) {
-  const float sa = p.scale_a[p.scale_a_numel != 1 ? m : 0];
+__device__ __forceinline__ i32x2 sp_epilogue4_vals(const ACC& sum, float sa, const float (&sb)[4], const uint32_t (&bias)[4], bool has_bias) {
   uint16_t o[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const float sb = p.scale_b[p.scale_b_numel != 1 ? n + e : 0];
     float v = sa * (float)sum[e];   // scaled_gemm.py:21
-    v = pin_f32(sb * v);            // :22
+    v = pin_f32(sb[e] * v);         // :22
     uint16_t h = float_to_bits16<OUT_DT>(v);  // :23
-    if (p.bias)                     // :24-25
-      h = float_to_bits16<OUT_DT>(pin_f32(bits16_to_float<OUT_DT>(h) + bits16_to_float<OUT_DT>(((const uint16_t*)p.bias)[n + e])));
+    if (has_bias)                   // :24-25
+      h = float_to_bits16<OUT_DT>(pin_f32(bits16_to_float<OUT_DT>(h) + bits16_to_float<OUT_DT>((uint16_t)bias[e])));
     o[e] = h;
   }
   i32x2 pk;
@@ -181,26 +192,72 @@ __device__ __forceinline__ i32x2 sp_epilogue4(const ScaledGemmArgs& p, const ACC
   return pk;
 }
 
+template <int OUT_DT, class ACC>
+__device__ __forceinline__ i32x2 sp_epilogue4(const ScaledGemmArgs& p, const ACC& sum, int m, int n) {
+  const float sa = p.scale_a[p.scale_a_numel != 1 ? m : 0];
+  float sb[4];
+  uint32_t bias[4] = {0, 0, 0, 0};  // one register each: packing two 16-bit loads into one makes hipcc wait for each in turn
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    sb[e] = p.scale_b[p.scale_b_numel != 1 ? n + e : 0];
+    if (p.bias) bias[e] = ((const uint16_t*)p.bias)[n + e];
+  }
+  return sp_epilogue4_vals<OUT_DT>(sum, sa, sb, bias, p.bias != nullptr);
+}
+
+// the last arriver's C stores: one branch on the bias for the whole sub-tile (a taken branch per output costs more than the
+// arithmetic it skips), one 8-byte store per row block at whatever alignment C has
+template <int OUT_DT, int ROWS, bool BIAS, class ACC>
+__device__ __forceinline__ void sp_finish(const ScaledGemmArgs& p, const ACC (&sum)[ROWS / 16], const float (&sa)[ROWS / 16],
+                                          const float (&sb)[4], const uint32_t (&bias)[4], const int (&coff)[ROWS / 16], int m_first,
+                                          bool live_n) {
+#pragma unroll
+  for (int i = 0; i < ROWS / 16; ++i) {
+    if (m_first + i * 16 < p.m && live_n) {
+      const i32x2 pk = sp_epilogue4_vals<OUT_DT>(sum[i], sa[i], sb, bias, BIAS);
+      __builtin_memcpy((uint16_t*)p.c + coff[i], &pk, 8);
+    }
+  }
+}
+
 // The whole slice is put in flight at once -- STEPS A units (ROWS x 128 bytes each, LDS-DMA) and STEPS B^T fragments
 // (8 VGPRs each) per wave -- so the slice costs one memory latency plus its transfer time instead of a
 // latency per K step; the steps are then consumed in issue order with counted vmcnt waits.
 //
 // FUSED = the reduce of the slices runs in the same launch (BASELINE config C2: one launch instead of two, no second
 // pass over the slabs by a second grid).  Protocol (MI355X_MICROARCH.md, inter-workgroup visibility, first row of the
-// table of measured hand-offs; cdna_hip_programming.md section 5, in-launch split-K reduction): every wave stores its
-// partial tile WRITE-THROUGH (sc1) and drains its own stores (s_waitcnt vmcnt(0)); workgroup barrier; ONE lane draws a
-// ticket from the tile's agent-scope counter; the workgroup that draws the last ticket re-reads the other slices' slabs
-// with sc1 loads (they bypass this CU's L1, so no acquire is needed) and adds them IN SLICE ORDER -- its own slice from
-// registers, bit-identical to what it stored -- then runs the fused epilogue and puts the counter back to zero.
-// Placement-independent: nothing here depends on which XCD or CU a slice runs on.  The LDS request is kept above half
-// of the CU's 160 KiB so that one workgroup runs per CU (the regime the hand-off was measured in).
+// table of measured hand-offs; cdna_hip_programming.md section 5, in-launch split-K reduction), per WAVE -- wave w of every
+// slice's workgroup owns the same 16 output columns, so no workgroup barrier is involved: the wave stores its partial
+// sub-tile WRITE-THROUGH (sc1) and drains its own stores (s_waitcnt vmcnt(0)); one lane draws a ticket from the (tile, wave)
+// agent-scope counter; the wave that draws the last ticket re-reads the slices' slabs with sc1 loads (they bypass this CU's
+// L1, so no acquire is needed) and adds them IN SLICE ORDER (two slices: the other one's slab only, its own partial sums from
+// registers, bit-identical to what it stored), then runs the fused epilogue -- scales and bias were fetched before the K
+// slice -- and puts the counter back to zero.  Placement-independent: nothing here depends on which XCD or CU a slice runs on.
+// Round 3 (profiles/r03/probe_skinny.txt, skinny_tail_ab.txt): scales ahead of the slice, the pair form and the per-wave
+// ticket took C2 from 12.5 to 10.4 us; the GATHER fetch order (sp_consume) to 9.3 us.
 // A_SRC != 0 (CONCH_DT_FP16 / BF16; two-launch form only): A arrives as 16-bit activations and is quantised on the way into
 // LDS with the static per-tensor scale scale_a[0] -- the arithmetic of quant.hip (x * (1 / scale), clamp, convert), so the bytes
 // in LDS are the ones static_scaled_{int8,fp8}_quant would have written to HBM and the product is bit-identical to the unfused
 // pair.  The B^T fragments are put in flight first; the A slice (ROWS x STEPS x 128 elements) then passes through registers:
 // 16 elements per thread and item, laid down where the LDS-DMA would have put them (unit row rho, 16-byte position pos holds
 // source chunk pos ^ ((rho >> 1) & 7)).  At decode sizes the separate quantiser is a launch of the GEMM's own order.
-template <int MMA, int OUT_DT, int ROWS, int STEPS, bool FUSED, int A_SRC = 0>
+#ifdef CONCH_CLOCK_PROBE
+__device__ unsigned long long g_probe_skinny[kProbeBlocks * 8];
+#define SK_STAMP(slot) CONCH_STAMP(g_probe_skinny, slot, (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)))
+#define SK_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// the shader clock (s_memtime) at entry (0) and when the slice is consumed (1): workgroup i < 2048 uses row i + 2048 of the buffer
+#define SK_CLOCK(which)                                                                                           \
+  do {                                                                                                            \
+    const int sk_idx = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));                     \
+    if (threadIdx.x == 0 && sk_idx < 2048) g_probe_skinny[(sk_idx + 2048) * 8 + (which)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define SK_CLOCK(which) do { } while (0)
+#define SK_STAMP(slot) do { } while (0)
+#define SK_DRAIN() do { } while (0)
+#endif
+
+template <int MMA, int OUT_DT, int ROWS, int STEPS, bool FUSED, int A_SRC = 0, bool GATHER = false>
 __global__ __launch_bounds__(kSkThreads, 1) void skinny_splitk_kernel(ScaledGemmArgs p, int* __restrict__ slabs,
                                                                        unsigned* __restrict__ counters) {
   static_assert(A_SRC == 0 || !FUSED, "the quantising prologue is built for the two-launch form");
@@ -212,6 +269,8 @@ __global__ __launch_bounds__(kSkThreads, 1) void skinny_splitk_kernel(ScaledGemm
   // decode sizes: profiles/r02/splitk_one_launch_nopad.txt.)
   constexpr int kLds = STEPS * kUnit;
   __shared__ __attribute__((aligned(1024))) char lds[kLds];
+  SK_STAMP(0);
+  SK_CLOCK(0);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int r = lane & 15, g = lane >> 4;
@@ -232,8 +291,36 @@ __global__ __launch_bounds__(kSkThreads, 1) void skinny_splitk_kernel(ScaledGemm
     const int chunk = (lane & 7) ^ ((rho >> 1) & 7);
     voff_a[j] = min(m0 + rho, (int)p.m - 1) * (int)p.a_stride_m + chunk * 16;
   }
-  const int voff_b = min(n0 + r, (int)p.n - 1) * (int)p.b_stride_n + 16 * g;
+  const int voff_b = GATHER ? min(n0 + (lane >> 2), (int)p.n - 1) * (int)p.b_stride_n + 16 * (lane & 3)
+                               : min(n0 + r, (int)p.n - 1) * (int)p.b_stride_n + 16 * g;
+  const int gather = (4 * r + g) * 4;
   const int lane_off = (r >> 3) * 1024 + (r & 7) * 128 + ((g ^ ((r >> 1) & 7)) * 16);
+
+  // One-launch form: the scales and the bias of this lane's outputs are requested BEFORE the K slice (they are older than
+  // every slice load, so the counted waits below are unchanged) -- the last arriver's epilogue then has no load of its own
+  // between the sum and the C stores (one L2 round trip off the launch's critical path; profiles/r03/probe_skinny.txt).
+  [[maybe_unused]] float pre_sa[ROWS / 16];
+  [[maybe_unused]] float pre_sb[4];
+  [[maybe_unused]] uint32_t pre_bias[4] = {0, 0, 0, 0};
+  [[maybe_unused]] int coff[ROWS / 16];  // element offset of this lane's four outputs in C (the launcher keeps C below 2^31 elements)
+  if constexpr (FUSED) {
+    const int nq = min(n0 + 4 * g, (int)p.n - 4);
+#pragma unroll
+    for (int i = 0; i < ROWS / 16; ++i) {
+      const int mq = min(m0 + i * 16 + r, (int)p.m - 1);
+      pre_sa[i] = p.scale_a[p.scale_a_numel != 1 ? mq : 0];
+      coff[i] = mq * (int)p.c_stride_m + nq;
+    }
+    // unconditional loads (without a bias: eight readable bytes of B^T, never used): a load under `if (p.bias)` is waited for
+    // at the end of its branch
+    const uint16_t* bias4 = p.bias ? (const uint16_t*)p.bias + nq : (const uint16_t*)p.b;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      pre_sb[e] = p.scale_b[p.scale_b_numel != 1 ? nq + e : 0];
+      pre_bias[e] = bias4[e];
+    }
+    asm volatile("" ::: "memory");
+  }
 
   // A ragged LAST slice (K % slice != 0; K % 128 == 0 always): the steps past K load from an out-of-range buffer offset --
   // zeros into the registers and into LDS alike (the range check is on the VGPR offset) -- and their MFMAs add 0 x 0.
@@ -286,11 +373,14 @@ __global__ __launch_bounds__(kSkThreads, 1) void skinny_splitk_kernel(ScaledGemm
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // B^T fragments and this thread's ds_writes are complete
   }
 
+  SK_STAMP(1);
   typename AccT<MMA>::type acc[ROWS / 16];
 #pragma unroll
   for (int i = 0; i < ROWS / 16; ++i) acc[i] = typename AccT<MMA>::type{0, 0, 0, 0};
 
-  sp_consume<MMA, ROWS, STEPS, 0>(acc, fb, lds, lane_off);
+  sp_consume<MMA, ROWS, STEPS, GATHER, 0>(acc, fb, lds, lane_off, gather);
+  SK_STAMP(2);
+  SK_CLOCK(1);
 
   // partial sums -> slab [slice][M][N] (4-byte elements); lane: m = m0 + 16 i + r, n = n0 + 4 g + e
   const int n = n0 + 4 * g;
@@ -317,49 +407,60 @@ __global__ __launch_bounds__(kSkThreads, 1) void skinny_splitk_kernel(ScaledGemm
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i]), rs, voff_s[i] + slice * (int)slab_bytes, 0, 16);  // sc1; constant soffset: see gemm_mfma.hip epilogue_rows_body
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its own write-through stores
-    __syncthreads();
-    unsigned* flag = (unsigned*)lds;  // the operand ring is dead: every wave's last ds_read fed an MFMA before the barrier
-    unsigned* cnt = counters + (blockIdx.z * gridDim.x + blockIdx.x);
-    if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    if (*flag != (unsigned)(slices - 1)) return;  // workgroup-uniform
-    // Last arriver: add the slices IN SLICE ORDER (exact for int32, deterministic for fp32), four slices of loads in
-    // flight at a time.  Every slice is loaded, this workgroup's own included (its stores are at L2 like the others'):
-    // a per-slice "registers or load" choice would make hipcc branch around, and drain, every load.
+    SK_STAMP(3);
+    // wave w of every slice's workgroup owns the same 16 output columns, so the hand-off is per WAVE -- one counter per (tile,
+    // wave), no workgroup barrier on the way
+    unsigned* cnt = counters + kSpCountersPerTile * (blockIdx.z * gridDim.x + blockIdx.x) + wave;
+    unsigned ticket = 0;
+    if (lane == 0) ticket = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket);
+    SK_STAMP(4);
+    if (ticket != (unsigned)(slices - 1)) return;  // wave-uniform
     typename AccT<MMA>::type sum[ROWS / 16];
-    for (int sb = 0; sb < slices; sb += 4) {
-      u32x4 part[4][ROWS / 16];
+    if (slices == 2) {
+      // two slices: the other slab only (a quarter of the general loop's loads); this slice's partial sums are still in
+      // registers, bit-identical to what was stored.  Operand order = slice order, as in the general loop.
+      u32x4 other[ROWS / 16];
+      const int soff = (1 - slice) * (int)slab_bytes;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int soff = min(sb + j, slices - 1) * (int)slab_bytes;
+      for (int i = 0; i < ROWS / 16; ++i) other[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_s[i], soff, 16);  // sc1
 #pragma unroll
-        for (int i = 0; i < ROWS / 16; ++i) part[j][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_s[i], soff, 16);  // sc1
+      for (int i = 0; i < ROWS / 16; ++i) {
+        const typename AccT<MMA>::type v = __builtin_bit_cast(typename AccT<MMA>::type, other[i]);
+        sum[i] = (slice == 0 ? acc[i] : v) + (slice == 0 ? v : acc[i]);
       }
+    } else {
+      // Last arriver: add the slices IN SLICE ORDER (exact for int32, deterministic for fp32), four slices of loads in
+      // flight at a time.  Every slice is loaded, this wave's own included (its stores are at L2 like the others'):
+      // a per-slice "registers or load" choice would make hipcc branch around, and drain, every load.
+      for (int sb = 0; sb < slices; sb += 4) {
+        u32x4 part[4][ROWS / 16];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const bool first = sb + j == 0, live = sb + j < slices;
+        for (int j = 0; j < 4; ++j) {
+          const int soff = min(sb + j, slices - 1) * (int)slab_bytes;
 #pragma unroll
-        for (int i = 0; i < ROWS / 16; ++i) {
-          const typename AccT<MMA>::type v = __builtin_bit_cast(typename AccT<MMA>::type, part[j][i]);
-          sum[i] = first ? v : live ? sum[i] + v : sum[i];
+          for (int i = 0; i < ROWS / 16; ++i) part[j][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_s[i], soff, 16);  // sc1
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool first = sb + j == 0, live = sb + j < slices;
+#pragma unroll
+          for (int i = 0; i < ROWS / 16; ++i) {
+            const typename AccT<MMA>::type v = __builtin_bit_cast(typename AccT<MMA>::type, part[j][i]);
+            sum[i] = first ? v : live ? sum[i] + v : sum[i];
+          }
         }
       }
     }
-#pragma unroll
-    for (int i = 0; i < ROWS / 16; ++i) {
-      const int m = m0 + i * 16 + r;
-      if (m < p.m && n + 4 <= p.n) {
-        const i32x2 pk = sp_epilogue4<OUT_DT>(p, sum[i], m, n);
-        uint16_t* dst = (uint16_t*)p.c + (int64_t)m * p.c_stride_m + n;
-        if ((((uintptr_t)dst) & 7) == 0) {
-          *(i32x2*)dst = pk;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) dst[e] = (uint16_t)((uint32_t)pk[e >> 1] >> (16 * (e & 1)));
-        }
-      }
-    }
-    if (threadIdx.x == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+    SK_DRAIN();
+    SK_STAMP(5);
+    const bool live_n = n + 4 <= p.n;
+    if (p.bias) sp_finish<OUT_DT, ROWS, true>(p, sum, pre_sa, pre_sb, pre_bias, coff, m0 + r, live_n);
+    else sp_finish<OUT_DT, ROWS, false>(p, sum, pre_sa, pre_sb, pre_bias, coff, m0 + r, live_n);
+    SK_STAMP(6);
+    SK_DRAIN();
+    SK_STAMP(7);
+    if (lane == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
   }
 }
 
@@ -444,14 +545,22 @@ __global__ __launch_bounds__(256) void skinny_reduce_silu_kernel(ScaledGemmArgs 
   }
 }
 
-// launches the split-K kernel for a runtime (row count, steps per slice) pair
+// launches the split-K kernel for a runtime (row count, steps per slice, B^T fetch order) triple
 template <int MMA, int OUT_DT, bool FUSED>
-void launch_splitk_kernel(int rows, int steps, dim3 grid, const ScaledGemmArgs& p, int* ws, unsigned* counters, hipStream_t stream) {
+void launch_splitk_kernel(int rows, int steps, bool gather, dim3 grid, const ScaledGemmArgs& p, int* ws, unsigned* counters,
+                          hipStream_t stream) {
   const dim3 block(kSkThreads);
+#define CONCH_SK(R, S)                                                                                                            \
+  do {                                                                                                                           \
+    if (gather)                                                                                                                  \
+      hipLaunchKernelGGL((skinny_splitk_kernel<MMA, OUT_DT, R, S, FUSED, 0, true>), grid, block, 0, stream, p, ws, counters);     \
+    else                                                                                                                         \
+      hipLaunchKernelGGL((skinny_splitk_kernel<MMA, OUT_DT, R, S, FUSED, 0, false>), grid, block, 0, stream, p, ws, counters);    \
+  } while (0)
   if constexpr (FUSED) {
     if (steps == 16) {  // 2048-byte slices: half the slabs, rows split instead (rows <= 64: 16 units of 64 rows fill the LDS)
-      if (rows == 32) hipLaunchKernelGGL((skinny_splitk_kernel<MMA, OUT_DT, 32, 16, true>), grid, block, 0, stream, p, ws, counters);
-      else hipLaunchKernelGGL((skinny_splitk_kernel<MMA, OUT_DT, 64, 16, true>), grid, block, 0, stream, p, ws, counters);
+      if (rows == 32) CONCH_SK(32, 16);
+      else CONCH_SK(64, 16);
       return;
     }
   }
@@ -471,12 +580,13 @@ void launch_splitk_kernel(int rows, int steps, dim3 grid, const ScaledGemmArgs& 
       return;
     }
   }
-  if (rows == 32) hipLaunchKernelGGL((skinny_splitk_kernel<MMA, OUT_DT, 32, kSpSteps, FUSED>), grid, block, 0, stream, p, ws, counters);
-  else if (rows == 64) hipLaunchKernelGGL((skinny_splitk_kernel<MMA, OUT_DT, 64, kSpSteps, FUSED>), grid, block, 0, stream, p, ws, counters);
-  else hipLaunchKernelGGL((skinny_splitk_kernel<MMA, OUT_DT, 128, kSpSteps, FUSED>), grid, block, 0, stream, p, ws, counters);
+  if (rows == 32) CONCH_SK(32, kSpSteps);
+  else if (rows == 64) CONCH_SK(64, kSpSteps);
+  else CONCH_SK(128, kSpSteps);
+#undef CONCH_SK
 }
 
-constexpr int kSpMaxTiles = 16384;  // arrival counters per (device, stream): 64 KiB
+constexpr int kSpMaxTiles = 16384;  // arrival counters per (device, stream): 64 KiB; a tile uses kSpCountersPerTile of them
 
 int splitk_slices(const ScaledGemmArgs& p) {
   // slices of 1024 K-bytes, the last one possibly shorter (K % 128 == 0 is part of the MFMA contract): K = 11008, the Llama-7B
@@ -507,13 +617,16 @@ int launch_splitk(const ScaledGemmArgs& p, int slices, hipStream_t stream) {
   int mode = tuning(CONCH_TUNE_SKINNY_MODE);
   int rows = p.m <= 32 ? 32 : p.m <= 64 ? 64 : 128;
   if (mode == 0) {
-    // measured (profiles/r02/splitk_modes.txt, 14 decode shapes x {1, 3}): the one-launch form wins only where its workgroups --
-    // 2048-byte slices, two 64-row blocks -- fill exactly one round of the chip (C2: 13.0 against 13.5 us); for <= 64 rows its
-    // sixteen steps in flight per workgroup lose to the 8-step slices, and with 1024-byte slices (mode 2) the last arriver's
-    // serial pass over four or more slabs costs more than the second launch it saves (16.0 against 13.5 us on C2)
+    // measured (profiles/r03/sweep_skinny.txt, 22 decode shapes x {1, 2, 3} x both fetch orders; round 2's table:
+    // profiles/r02/splitk_modes.txt).  The one-launch forms pay the last arriver's serial pass over the slabs, so they want few
+    // slices: 2048-byte slices in two 64-row blocks where those fill at most one round of the chip (C2: 9.3 against 13.2 us; 96 rows
+    // 9.3 against 12.1), 1024-byte slices up to 64 rows while there are at most four of them (64 x 4096 x 11008: 15.4 against
+    // 16.4 us; at K = 8192 the two-launch form is level or ahead).  GEMV sizes (<= 32 rows): one launch always, the slab tile is 2-8 KiB.
     const int64_t wgs = ((p.n + kSpN - 1) / kSpN) * (p.k / (2 * kSpSliceK)) * ((p.m + 63) / 64);
-    if (p.m <= 32) mode = (p.k >= 8192 && p.k % (2 * kSpSliceK) == 0) ? 3 : 2;  // GEMV sizes: the slab tile is 2-8 KiB, one launch wins 4-10 %
-    else mode = (p.m > 96 && p.m <= 128 && p.k % (2 * kSpSliceK) == 0 && wgs <= device_cu_count()) ? 3 : 1;  // 96 rows: two launches 4 % ahead
+    const bool two_k = p.k % (2 * kSpSliceK) == 0;
+    if (p.m <= 32) mode = (p.k >= 8192 && two_k) ? 3 : 2;
+    else if (p.m <= 64) mode = slices <= 4 ? 2 : 1;
+    else mode = (p.m <= 128 && two_k && p.k >= 4 * kSpSliceK && wgs <= device_cu_count()) ? 3 : 1;
   }
   if (p.a_src_dtype) mode = 1;  // the quantising prologue lives in the two-launch form
   int steps = kSpSteps;
@@ -528,16 +641,27 @@ int launch_splitk(const ScaledGemmArgs& p, int slices, hipStream_t stream) {
   const size_t bytes = (size_t)slices * p.m * p.n * 4;
   // the in-launch reduce addresses all slabs through one 32-bit buffer descriptor and needs one counter per tile; the
   // gate/up fusion combines two tiles per output and keeps its reduce kernel
-  if (p.fuse_silu || p.a_src_dtype || bytes >= ((size_t)1 << 31) || (size_t)grid.x * grid.z > (size_t)kSpMaxTiles) mode = 1;
+  const bool c_fits_int = (p.m - 1) * p.c_stride_m + p.n < ((int64_t)1 << 31);  // the fused epilogue's 32-bit element offsets
+  if (p.fuse_silu || p.a_src_dtype || bytes >= ((size_t)1 << 31) || !c_fits_int ||
+      (size_t)grid.x * grid.z * kSpCountersPerTile > (size_t)kSpMaxTiles)
+    mode = 1;
+  // CONCH_TUNE_SKINNY_GATHER.  Measured (profiles/r03/skinny_gather_ab.txt, sweep_skinny.txt): with at most one workgroup per CU
+  // the launch is bound by how fast a wave gets its B^T loads ISSUED -- in operand order every quad of lanes touches four lines
+  // and the texture path takes them one line at a time -- and the gather form wins 7-11 %; so it does with 32-row blocks and
+  // 8-step slices whatever the grid (2-4 %: little A to read back from LDS).  With several rounds of 64- or 128-row workgroups
+  // the LDS is the busier unit and the gather's eight ds_bpermutes per step cost 3 %.
+  const int gather_mode = tuning(CONCH_TUNE_SKINNY_GATHER);
+  const bool gather = gather_mode == 2 || (gather_mode == 0 && ((size_t)grid.x * grid.y * grid.z <= (size_t)device_cu_count() ||
+                                                               (rows == 32 && steps == kSpSteps)));
   void* ws = nullptr;
   if (int rc = get_scratch(stream, kScratchSplitK, bytes, &ws)) return rc;
   if (mode != 1) {
     void* counters = nullptr;
     if (int rc = get_scratch(stream, kScratchCounters, (size_t)kSpMaxTiles * 4, &counters, /*zero_on_alloc=*/true)) return rc;
-    launch_splitk_kernel<MMA, OUT_DT, true>(rows, steps, grid, p, (int*)ws, (unsigned*)counters, stream);
+    launch_splitk_kernel<MMA, OUT_DT, true>(rows, steps, gather, grid, p, (int*)ws, (unsigned*)counters, stream);
     return check_launch("scaled_gemm_skinny_splitk_fused");
   }
-  launch_splitk_kernel<MMA, CONCH_DT_BF16, false>(rows, steps, grid, p, (int*)ws, nullptr, stream);
+  launch_splitk_kernel<MMA, CONCH_DT_BF16, false>(rows, steps, gather, grid, p, (int*)ws, nullptr, stream);
   if (p.fuse_silu) {  // p.n = 2d columns [gate | up], C has d
     hipLaunchKernelGGL((skinny_reduce_silu_kernel<MMA, OUT_DT>), dim3((unsigned)((p.n / 8 + 255) / 256), (unsigned)p.m), dim3(256), 0, stream, p,
                        (const int*)ws, slices);
@@ -581,3 +705,7 @@ int launch_scaled_gemm_skinny(const ScaledGemmArgs& p, hipStream_t stream) {
 }
 
 }  // namespace conch
+
+#ifdef CONCH_CLOCK_PROBE
+CONCH_PROBE_READER(conch_debug_probe_skinny, conch::g_probe_skinny)
+#endif

@@ -147,6 +147,10 @@ typedef enum conch_tuning_key {
   ,
   CONCH_TUNE_MIXED_SPLITK = 9 /* LDS-tiled mixed_precision_gemm: K slices per tile (fp32 slabs + reduce kernel) when the tiles
                                  leave most of the chip idle: 0 = auto, 1 = never, 2 / 4 / 8 = force */
+  ,
+  CONCH_TUNE_SKINNY_GATHER = 10 /* split-K skinny-M scaled GEMM, how a wave fetches its B^T fragments: 0 = auto (2 when the launch
+                                   is at most one workgroup per CU), 1 = in MFMA operand order (16 rows x 16 bytes per quarter-wave),
+                                   2 = four lanes per 64-byte row piece, put into operand order by a cross-lane gather */
 } conch_tuning_key_t;
 
 int conch_abi_version(void);

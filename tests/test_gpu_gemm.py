@@ -165,6 +165,7 @@ def _reset_tuning():
     _C.set_tuning(_C.TUNE_EPILOGUE, 0)
     _C.set_tuning(_C.TUNE_MID_STAGES, 0)
     _C.set_tuning(_C.TUNE_MIXED_SPLITK, 0)
+    _C.set_tuning(_C.TUNE_SKINNY_GATHER, 0)
 
 
 @pytest.mark.parametrize("iname", ["int8", "fn"])
@@ -311,6 +312,26 @@ def test_one_launch_splitk_is_bit_identical_to_two_launches(_reset_tuning, mode,
             np.testing.assert_array_equal(to_bits(one), to_bits(two))  # same slices, same order
     ref = oracle.scaled_gemm_ref(a, b, sa, sb, torch.bfloat16, bias)
     check_scaled(one, ref, IN_T[iname], torch.bfloat16, (a, b, sa, sb, bias))
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("iname", ["int8", "fn"])
+@pytest.mark.parametrize(("m", "k", "n"), [(128, 4096, 4096), (1, 1024, 24), (20, 2048, 4096), (33, 1152, 68), (48, 2048, 520), (200, 2048, 520),
+                                            (64, 4096, 11008), (100, 3072, 260), (7, 11008, 4096)])
+def test_splitk_fetch_orders_are_bit_identical(_reset_tuning, mode, iname, m, k, n):
+    """CONCH_TUNE_SKINNY_GATHER: a wave's B^T fragments fetched in MFMA operand order, or four lanes per 64-byte row piece and
+    gathered across lanes -- the same bytes in the same operand registers, so the launch forms agree bit for bit (ragged N and
+    M, a ragged last K slice and a row count past the last 16-row block included)."""
+    a, b, sa, sb, bias = make_scaled_inputs(m, k, n, IN_T[iname], torch.bfloat16, False, False, True)
+    _C.set_gemm_variant(_C.VARIANT_MFMA_SKINNY)
+    _C.set_tuning(_C.TUNE_SKINNY_MODE, mode)
+    _C.set_tuning(_C.TUNE_SKINNY_GATHER, 1)
+    plain = run_scaled(a, b, sa, sb, torch.bfloat16, bias)
+    _C.set_tuning(_C.TUNE_SKINNY_GATHER, 2)
+    for _ in range(2):
+        np.testing.assert_array_equal(to_bits(run_scaled(a, b, sa, sb, torch.bfloat16, bias)), to_bits(plain))
+    ref = oracle.scaled_gemm_ref(a, b, sa, sb, torch.bfloat16, bias)
+    check_scaled(plain, ref, IN_T[iname], torch.bfloat16, (a, b, sa, sb, bias))
 
 
 @pytest.mark.parametrize(("m", "k", "n", "mode", "iname"), [(128, 4096, 4096, 2, "int8"), (16, 4096, 11008, 2, "fn"), (32, 8192, 8192, 3, "int8"),
