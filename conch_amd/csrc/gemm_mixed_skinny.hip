@@ -44,16 +44,26 @@ __device__ __forceinline__ i32x4 dequant8(uint32_t w0, uint32_t w1, int off, uin
 
 // FUSED = the reduce of the slices runs in the same launch (same hand-off as gemm_skinny.hip's one-launch form, the first row of
 // MI355X_MICROARCH.md's table of measured hand-offs): every wave stores its partial tile write-through (sc1) and drains its own
-// stores, workgroup barrier, one lane draws a ticket from the tile's agent-scope counter; the workgroup that draws the last
-// ticket re-reads all slices with sc1 loads, adds them IN SLICE ORDER -- the order of the reduce kernel: bit-identical results --
+// stores, one lane draws a ticket from the (tile, wave) agent-scope counter -- per wave, no workgroup barrier: wave w of every
+// slice's workgroup owns the same 16 columns --; the wave that draws the last ticket re-reads all slices with sc1 loads, adds them IN SLICE ORDER -- the order of the reduce kernel: bit-identical results --
 // casts, stores C and puts the counter back to zero.  At GEMV sizes the slab tile of a workgroup is 4 KiB: the second launch
 // costs more than the last arriver's pass over the slices.
+#ifdef CONCH_CLOCK_PROBE
+__device__ unsigned long long g_probe_mixed_skinny[kProbeBlocks * 8];
+#define MS_STAMP(slot) CONCH_STAMP(g_probe_mixed_skinny, slot, (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)))
+#define MS_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define MS_STAMP(slot) do { } while (0)
+#define MS_DRAIN() do { } while (0)
+#endif
+
 template <int X_DT, int BITS, int ZP, int ROWS, bool FUSED = false, int OUT_DT = CONCH_DT_FP16>
 __global__ __launch_bounds__(kMsThreads) void mixed_skinny_kernel(MixedGemmArgs p, float* __restrict__ slabs, unsigned* __restrict__ counters) {
   constexpr int kUnit = ROWS * 128;            // one K step of X
   constexpr int kWpc = BITS == 4 ? 1 : 2;      // 32-bit words per 8-k chunk
   constexpr int kWordRows = kMsStepK * BITS / 32;  // word rows per K step (8 / 16)
   __shared__ __attribute__((aligned(1024))) char lds[kMsSteps * kUnit];
+  MS_STAMP(0);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int r = lane & 15, g = lane >> 4;
@@ -65,39 +75,35 @@ __global__ __launch_bounds__(kMsThreads) void mixed_skinny_kernel(MixedGemmArgs 
   // A ragged LAST slice (K % 1024 != 0; K % 64 == 0 always): the steps past K load X, the packed words, the scale and the zero
   // point from an out-of-range buffer offset (the range check is on the VGPR offset) -- zeros in LDS, and a zero SCALE makes
   // the dequantised weights zero whatever (0 - bias - zp) is: their MFMAs add 0 x 0.
-  const int valid_steps = min(kMsSteps, ((int)p.k - k0) / kMsStepK);  // workgroup-uniform
+  // Everything up to the last load is 32-bit and branch-free.  Round 3 (profiles/r03/probe_mixed_skinny.txt): the prologue had
+  // a 64-bit division (K / group_size), a 32-bit one per step (the step's group), and walked the X pieces with a branch per
+  // (step, piece) -- ~1100 instructions ahead of the last load, 4 of the launch's 7.6 us.
+  const int kk = (int)p.k;
+  const int valid_steps = min(kMsSteps, (kk - k0) / kMsStepK);  // workgroup-uniform
   // (a macro, not a lambda: a lambda in this kernel template makes hipcc's host pass drop the kernel's launch stub)
 #define CONCH_KILL(s) ((s) < valid_steps ? 0 : (int)0x80000000)
-  // ---- X slice -> LDS (8-row x 128-byte subtiles, source-side swizzle); piece q = rows 8q..8q+7 of a step
-  const __amdgpu_buffer_rsrc_t rx =
-      __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (uint32_t)(((p.m - 1) * p.x_stride_m + p.k) * 2), 0x00020000);
-  constexpr int kPieces = ROWS / 8;  // per step; dealt round-robin to the four waves
-#pragma unroll
-  for (int s = 0; s < kMsSteps; ++s)
-#pragma unroll
-    for (int q = 0; q < kPieces; ++q) {
-      if ((q & 3) != wave) continue;  // wave-uniform
-      const int row = 8 * q + (lane >> 3);
-      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-      const int voff = min(m0 + row, (int)p.m - 1) * (int)p.x_stride_m * 2 + chunk * 16;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t*)(lds + s * kUnit + q * 1024), 16, voff | CONCH_KILL(s), (k0 + s * kMsStepK) * 2, 0, 0);
-    }
 
-  // ---- weights, scales, zero points of the whole slice -> registers
-  const int64_t word_rows = p.k * BITS / 32, groups = p.k / p.group_size;
+  // ---- weights, scales, zero points of the whole slice -> registers (first: they come from HBM, the X slice from L2)
+  const uint32_t steps_per_group = (uint32_t)p.group_size / kMsStepK;                 // group_size % 64 == 0 (contract)
+  const uint32_t first_step = (uint32_t)blockIdx.y * kMsSteps;
+  const uint32_t first_group = first_step / steps_per_group;                          // the slice's ONE division
+  const uint32_t groups = (uint32_t)kk / (uint32_t)p.group_size;
+  const uint32_t word_rows = (uint32_t)kk * BITS / 32;
   const __amdgpu_buffer_rsrc_t rq =
-      __builtin_amdgcn_make_buffer_rsrc((void*)p.w_q, 0, (uint32_t)(((word_rows - 1) * p.wq_stride_k + p.n) * 4), 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.w_q, 0, ((word_rows - 1) * (uint32_t)p.wq_stride_k + (uint32_t)p.n) * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs =
-      __builtin_amdgcn_make_buffer_rsrc((void*)p.w_s, 0, (uint32_t)(((groups - 1) * p.ws_stride_g + p.n) * 2), 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.w_s, 0, ((groups - 1) * (uint32_t)p.ws_stride_g + (uint32_t)p.n) * 2, 0x00020000);
   __amdgpu_buffer_rsrc_t rz = rs;
   if constexpr (ZP == CONCH_ZP_TENSOR)
-    rz = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_zp, 0, (uint32_t)(((groups - 1) * p.wzp_stride_g + p.n) * 4), 0x00020000);
+    rz = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_zp, 0, ((groups - 1) * (uint32_t)p.wzp_stride_g + (uint32_t)p.n) * 4, 0x00020000);
   const int q_row = (int)p.wq_stride_k * 4;                         // bytes per word row
   const int vq = (g * kWpc) * q_row + n * 4;                        // this lane's k-group inside a half step
   const int q_base = (k0 * BITS / 32) * q_row;
   uint32_t wq[kMsSteps][2][kWpc];
   uint32_t sc[kMsSteps];
   int zp[kMsSteps];
+  int s_off = (int)first_group * (int)p.ws_stride_g * 2, z_off = (int)first_group * (int)p.wzp_stride_g * 4;
+  uint32_t left = steps_per_group - (first_step - first_group * steps_per_group);    // steps before the group changes
 #pragma unroll
   for (int s = 0; s < kMsSteps; ++s) {
 #pragma unroll
@@ -105,10 +111,36 @@ __global__ __launch_bounds__(kMsThreads) void mixed_skinny_kernel(MixedGemmArgs 
 #pragma unroll
       for (int i = 0; i < kWpc; ++i)
         wq[s][h][i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rq, vq | CONCH_KILL(s), q_base + (s * kWordRows + h * (kWordRows / 2) + i) * q_row, 0);
-    const int grp = (k0 + s * kMsStepK) / p.group_size;
-    sc[s] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs, (n * 2) | CONCH_KILL(s), grp * (int)p.ws_stride_g * 2, 0);
-    if constexpr (ZP == CONCH_ZP_TENSOR) zp[s] = (int)__builtin_amdgcn_raw_buffer_load_b32(rz, (n * 4) | CONCH_KILL(s), grp * (int)p.wzp_stride_g * 4, 0);
+    sc[s] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs, (n * 2) | CONCH_KILL(s), s_off, 0);
+    if constexpr (ZP == CONCH_ZP_TENSOR) zp[s] = (int)__builtin_amdgcn_raw_buffer_load_b32(rz, (n * 4) | CONCH_KILL(s), z_off, 0);
     else zp[s] = 0;
+    const bool wrap = left == 1;
+    left = wrap ? steps_per_group : left - 1;
+    s_off += wrap ? (int)p.ws_stride_g * 2 : 0;
+    z_off += wrap ? (int)p.wzp_stride_g * 4 : 0;
+  }
+
+  // ---- X slice -> LDS (8-row x 128-byte subtiles, source-side swizzle); piece q = rows 8q..8q+7 of a step.  The
+  // kMsSteps x kPieces (step, piece) items are dealt round-robin to the four waves: item t = wave + 4 j is step t / kPieces,
+  // piece t % kPieces -- a wave meets one piece (kPieces <= 4) or two (8), whose lane offsets are computed once.
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.x, 0, (((uint32_t)p.m - 1) * (uint32_t)p.x_stride_m + (uint32_t)kk) * 2, 0x00020000);
+  constexpr int kPieces = ROWS / 8;
+  constexpr int kMine = kPieces > 4 ? 2 : 1;
+  int voff_x[2];  // the first kMine are used (a dependent array bound here makes hipcc's host pass drop the kernel's stub)
+#pragma unroll
+  for (int v = 0; v < kMine; ++v) {
+    const int q = (int)(((unsigned)wave + 4u * v) % kPieces);
+    const int row = 8 * q + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    voff_x[v] = min(m0 + row, (int)p.m - 1) * (int)p.x_stride_m * 2 + chunk * 16;
+  }
+#pragma unroll
+  for (int j = 0; j < kMsSteps * kPieces / 4; ++j) {
+    const unsigned t = (unsigned)wave + 4u * j;
+    const int s = (int)(t / kPieces), q = (int)(t % kPieces);  // wave-uniform
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t*)(lds + s * kUnit + q * 1024), 16, voff_x[kMine == 2 ? (j & 1) : 0] | CONCH_KILL(s),
+                                             (k0 + s * kMsStepK) * 2, 0, 0);
   }
 #undef CONCH_KILL
   const int off_base = p.weight_bias + (ZP == CONCH_ZP_SCALAR ? p.w_zp[0] : 0);
@@ -120,8 +152,10 @@ __global__ __launch_bounds__(kMsThreads) void mixed_skinny_kernel(MixedGemmArgs 
 #pragma unroll
   for (int i = 0; i < ROWS / 16; ++i) acc[i] = f32x4{0, 0, 0, 0};
 
+  MS_STAMP(1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA pieces (and its register loads) have landed
   __builtin_amdgcn_s_barrier();                     // ... and so have the other waves' pieces
+  MS_STAMP(2);
 
   const int lane_off = (r >> 3) * 1024 + (r & 7) * 128 + ((g ^ ((r >> 1) & 7)) * 16);
 #pragma unroll
@@ -142,6 +176,7 @@ __global__ __launch_bounds__(kMsThreads) void mixed_skinny_kernel(MixedGemmArgs 
     }
   }
 
+  MS_STAMP(3);
   // D rows = n (4g + e), D columns = m (lane % 16): four consecutive n of one row per lane
   const int nn = nw + 4 * g;
   if constexpr (!FUSED) {
@@ -165,12 +200,14 @@ __global__ __launch_bounds__(kMsThreads) void mixed_skinny_kernel(MixedGemmArgs 
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i]), rs, voff_s[i] + (int)blockIdx.y * (int)slab_bytes, 0, 16);  // sc1; constant soffset: see gemm_mfma.hip epilogue_rows_body
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its own write-through stores
-    __syncthreads();
-    unsigned* flag = (unsigned*)lds;  // the X slice is dead: every wave's last ds_read fed an MFMA before the barrier
-    unsigned* cnt = counters + (blockIdx.z * gridDim.x + blockIdx.x);
-    if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    if (*flag != (unsigned)(slices - 1)) return;  // workgroup-uniform
+    MS_STAMP(4);
+    // the hand-off is per WAVE (gemm_skinny.hip, skinny_splitk_kernel): wave w of every slice's workgroup owns the same 16 columns
+    unsigned* cnt = counters + 4 * (blockIdx.z * gridDim.x + blockIdx.x) + wave;
+    unsigned ticket = 0;
+    if (lane == 0) ticket = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket);
+    MS_STAMP(5);
+    if (ticket != (unsigned)(slices - 1)) return;  // wave-uniform
     f32x4 sum[ROWS / 16];
     for (int sb = 0; sb < slices; sb += 4) {
       u32x4 part[4][ROWS / 16];
@@ -190,6 +227,8 @@ __global__ __launch_bounds__(kMsThreads) void mixed_skinny_kernel(MixedGemmArgs 
         }
       }
     }
+    MS_DRAIN();
+    MS_STAMP(6);
 #pragma unroll
     for (int i = 0; i < ROWS / 16; ++i) {
       const int m = m0 + i * 16 + r;
@@ -206,7 +245,9 @@ __global__ __launch_bounds__(kMsThreads) void mixed_skinny_kernel(MixedGemmArgs 
         }
       }
     }
-    if (threadIdx.x == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+    MS_DRAIN();
+    MS_STAMP(7);
+    if (lane == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
   }
 }
 
@@ -338,7 +379,7 @@ int launch_mixed_gemm_skinny(const MixedGemmArgs& p, hipStream_t stream) {
   // cheaper than a second launch: profiles/r02/mixed_decode_one_launch.txt)
   const int mode = tuning(CONCH_TUNE_SKINNY_MODE);
   const bool one_launch = !p.fuse_silu && rows <= 32 && slices >= 2 && mode != 1 && bytes < ((size_t)1 << 31) &&
-                          (size_t)grid.x * grid.z <= (size_t)kMsMaxTiles;
+                          (size_t)grid.x * grid.z * 4 <= (size_t)kMsMaxTiles;  // one counter per (tile, wave)
   unsigned* counters = nullptr;
   if (one_launch) {
     void* cbuf = nullptr;
@@ -368,3 +409,7 @@ int launch_mixed_gemm_skinny(const MixedGemmArgs& p, hipStream_t stream) {
 }
 
 }  // namespace conch
+
+#ifdef CONCH_CLOCK_PROBE
+CONCH_PROBE_READER(conch_debug_probe_mixed_skinny, conch::g_probe_mixed_skinny)
+#endif
