@@ -568,10 +568,17 @@ void launch_splitk_kernel(int rows, int steps, bool gather, dim3 grid, const Sca
     if (p.a_src_dtype) {  // quantise A on the way in (conch_static_quant_scaled_gemm)
 #define CONCH_QA(R)                                                                                                              \
   do {                                                                                                                           \
-    if (p.a_src_dtype == CONCH_DT_FP16)                                                                                          \
-      hipLaunchKernelGGL((skinny_splitk_kernel<MMA, OUT_DT, R, kSpSteps, false, CONCH_DT_FP16>), grid, block, 0, stream, p, ws, counters); \
-    else                                                                                                                         \
-      hipLaunchKernelGGL((skinny_splitk_kernel<MMA, OUT_DT, R, kSpSteps, false, CONCH_DT_BF16>), grid, block, 0, stream, p, ws, counters); \
+    if (p.a_src_dtype == CONCH_DT_FP16) {                                                                                        \
+      if (gather)                                                                                                                \
+        hipLaunchKernelGGL((skinny_splitk_kernel<MMA, OUT_DT, R, kSpSteps, false, CONCH_DT_FP16, true>), grid, block, 0, stream, p, ws, counters); \
+      else                                                                                                                       \
+        hipLaunchKernelGGL((skinny_splitk_kernel<MMA, OUT_DT, R, kSpSteps, false, CONCH_DT_FP16, false>), grid, block, 0, stream, p, ws, counters); \
+    } else {                                                                                                                     \
+      if (gather)                                                                                                                \
+        hipLaunchKernelGGL((skinny_splitk_kernel<MMA, OUT_DT, R, kSpSteps, false, CONCH_DT_BF16, true>), grid, block, 0, stream, p, ws, counters); \
+      else                                                                                                                       \
+        hipLaunchKernelGGL((skinny_splitk_kernel<MMA, OUT_DT, R, kSpSteps, false, CONCH_DT_BF16, false>), grid, block, 0, stream, p, ws, counters); \
+    }                                                                                                                            \
   } while (0)
       if (rows == 32) CONCH_QA(32);
       else if (rows == 64) CONCH_QA(64);
