@@ -109,6 +109,23 @@ def test_tuning_knob_roundtrip():
     assert _C.get_gemm_variant() == 0
 
 
+def test_every_tuning_key_of_the_header_is_settable_and_mirrored():
+    """include/conch_amd.h's conch_tuning_key_t, conch_amd/_C.py's TUNE_* constants and the library's key range agree."""
+    import re
+    from pathlib import Path
+
+    header = (Path(__file__).resolve().parent.parent / "include" / "conch_amd.h").read_text()
+    keys = {name: int(val) for name, val in re.findall(r"CONCH_(TUNE_[A-Z0-9_]+) = (\d+)", header)}
+    assert sorted(keys.values()) == list(range(len(keys)))
+    for name, val in keys.items():
+        assert getattr(_C, name) == val, name
+        _C.set_tuning(val, 1)
+        assert _C.load().conch_get_tuning(val) == 1
+        _C.set_tuning(val, 0)
+    with pytest.raises(Exception):
+        _C.set_tuning(len(keys), 1)
+
+
 def test_ops_refuse_cpu_tensors():
     """No silent CPU fallback: host tensors are an error."""
     x = torch.rand(4, 16)
