@@ -31,7 +31,6 @@ constexpr int kMsN = 64;                  // columns per workgroup
 constexpr int kMsStepK = 64;              // k elements per step (128 bytes of fp16 / bf16)
 constexpr int kMsSteps = 16;              // steps per slice
 constexpr int kMsSliceK = kMsSteps * kMsStepK;
-constexpr int kMsShortSteps = 8;          // one-launch form with at most one workgroup per CU at 16 steps: half slices, twice the workgroups
 constexpr int kMsMaxM = 256;
 constexpr int kMsMaxTiles = 16384;  // arrival counters per (device, stream): the 64 KiB slot gemm_skinny.hip uses too
 
@@ -58,19 +57,19 @@ __device__ unsigned long long g_probe_mixed_skinny[kProbeBlocks * 8];
 #define MS_DRAIN() do { } while (0)
 #endif
 
-template <int X_DT, int BITS, int ZP, int ROWS, bool FUSED = false, int OUT_DT = CONCH_DT_FP16, int STEPS = kMsSteps>
+template <int X_DT, int BITS, int ZP, int ROWS, bool FUSED = false, int OUT_DT = CONCH_DT_FP16>
 __global__ __launch_bounds__(kMsThreads) void mixed_skinny_kernel(MixedGemmArgs p, float* __restrict__ slabs, unsigned* __restrict__ counters) {
   constexpr int kUnit = ROWS * 128;            // one K step of X
   constexpr int kWpc = BITS == 4 ? 1 : 2;      // 32-bit words per 8-k chunk
   constexpr int kWordRows = kMsStepK * BITS / 32;  // word rows per K step (8 / 16)
-  __shared__ __attribute__((aligned(1024))) char lds[STEPS * kUnit];
+  __shared__ __attribute__((aligned(1024))) char lds[kMsSteps * kUnit];
   MS_STAMP(0);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int r = lane & 15, g = lane >> 4;
   const int nw = blockIdx.x * kMsN + wave * 16;       // first column of this wave
   const int n = min(nw + r, (int)p.n - 1);            // this lane's weight column
-  const int k0 = blockIdx.y * (STEPS * kMsStepK);
+  const int k0 = blockIdx.y * kMsSliceK;
   const int m0 = blockIdx.z * ROWS;
 
   // A ragged LAST slice (K % 1024 != 0; K % 64 == 0 always): the steps past K load X, the packed words, the scale and the zero
@@ -80,13 +79,13 @@ __global__ __launch_bounds__(kMsThreads) void mixed_skinny_kernel(MixedGemmArgs 
   // a 64-bit division (K / group_size), a 32-bit one per step (the step's group), and walked the X pieces with a branch per
   // (step, piece) -- ~1100 instructions ahead of the last load, 4 of the launch's 7.6 us.
   const int kk = (int)p.k;
-  const int valid_steps = min(STEPS, (kk - k0) / kMsStepK);  // workgroup-uniform
+  const int valid_steps = min(kMsSteps, (kk - k0) / kMsStepK);  // workgroup-uniform
   // (a macro, not a lambda: a lambda in this kernel template makes hipcc's host pass drop the kernel's launch stub)
 #define CONCH_KILL(s) ((s) < valid_steps ? 0 : (int)0x80000000)
 
   // ---- weights, scales, zero points of the whole slice -> registers (first: they come from HBM, the X slice from L2)
   const uint32_t steps_per_group = (uint32_t)p.group_size / kMsStepK;                 // group_size % 64 == 0 (contract)
-  const uint32_t first_step = (uint32_t)blockIdx.y * STEPS;
+  const uint32_t first_step = (uint32_t)blockIdx.y * kMsSteps;
   const uint32_t first_group = first_step / steps_per_group;                          // the slice's ONE division
   const uint32_t groups = (uint32_t)kk / (uint32_t)p.group_size;
   const uint32_t word_rows = (uint32_t)kk * BITS / 32;
@@ -100,13 +99,13 @@ __global__ __launch_bounds__(kMsThreads) void mixed_skinny_kernel(MixedGemmArgs 
   const int q_row = (int)p.wq_stride_k * 4;                         // bytes per word row
   const int vq = (g * kWpc) * q_row + n * 4;                        // this lane's k-group inside a half step
   const int q_base = (k0 * BITS / 32) * q_row;
-  uint32_t wq[STEPS][2][kWpc];
-  uint32_t sc[STEPS];
-  int zp[STEPS];
+  uint32_t wq[kMsSteps][2][kWpc];
+  uint32_t sc[kMsSteps];
+  int zp[kMsSteps];
   int s_off = (int)first_group * (int)p.ws_stride_g * 2, z_off = (int)first_group * (int)p.wzp_stride_g * 4;
   uint32_t left = steps_per_group - (first_step - first_group * steps_per_group);    // steps before the group changes
 #pragma unroll
-  for (int s = 0; s < STEPS; ++s) {
+  for (int s = 0; s < kMsSteps; ++s) {
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -122,7 +121,7 @@ __global__ __launch_bounds__(kMsThreads) void mixed_skinny_kernel(MixedGemmArgs 
   }
 
   // ---- X slice -> LDS (8-row x 128-byte subtiles, source-side swizzle); piece q = rows 8q..8q+7 of a step.  The
-  // STEPS x kPieces (step, piece) items are dealt round-robin to the four waves: item t = wave + 4 j is step t / kPieces,
+  // kMsSteps x kPieces (step, piece) items are dealt round-robin to the four waves: item t = wave + 4 j is step t / kPieces,
   // piece t % kPieces -- a wave meets one piece (kPieces <= 4) or two (8), whose lane offsets are computed once.
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
       (void*)p.x, 0, (((uint32_t)p.m - 1) * (uint32_t)p.x_stride_m + (uint32_t)kk) * 2, 0x00020000);
@@ -137,7 +136,7 @@ __global__ __launch_bounds__(kMsThreads) void mixed_skinny_kernel(MixedGemmArgs 
     voff_x[v] = min(m0 + row, (int)p.m - 1) * (int)p.x_stride_m * 2 + chunk * 16;
   }
 #pragma unroll
-  for (int j = 0; j < STEPS * kPieces / 4; ++j) {
+  for (int j = 0; j < kMsSteps * kPieces / 4; ++j) {
     const unsigned t = (unsigned)wave + 4u * j;
     const int s = (int)(t / kPieces), q = (int)(t % kPieces);  // wave-uniform
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t*)(lds + s * kUnit + q * 1024), 16, voff_x[kMine == 2 ? (j & 1) : 0] | CONCH_KILL(s),
@@ -160,7 +159,7 @@ __global__ __launch_bounds__(kMsThreads) void mixed_skinny_kernel(MixedGemmArgs 
 
   const int lane_off = (r >> 3) * 1024 + (r & 7) * 128 + ((g ^ ((r >> 1) & 7)) * 16);
 #pragma unroll
-  for (int s = 0; s < STEPS; ++s) {
+  for (int s = 0; s < kMsSteps; ++s) {
     // the lane's 8 + 8 weights of this step: k = 8g..8g+7 (first half step) and 32 + 8g.. (second), column n
     const i32x4 w_lo = dequant8<X_DT, BITS, ZP>(wq[s][0][0], wq[s][0][kWpc - 1], off_base + zp[s], sc[s], and_mask, or_magic, and_mask_hi);
     const i32x4 w_hi = dequant8<X_DT, BITS, ZP>(wq[s][1][0], wq[s][1][kWpc - 1], off_base + zp[s], sc[s], and_mask, or_magic, and_mask_hi);
@@ -316,23 +315,18 @@ __global__ __launch_bounds__(256) void mixed_skinny_reduce_silu_kernel(MixedGemm
 }
 
 template <int X_DT, int BITS, int ZP>
-void launch_rows(const MixedGemmArgs& p, int rows, int steps, dim3 grid, float* ws, unsigned* counters, hipStream_t stream) {
+void launch_rows(const MixedGemmArgs& p, int rows, dim3 grid, float* ws, unsigned* counters, hipStream_t stream) {
   const dim3 block(kMsThreads);
   if (counters) {  // one launch (rows <= 32 only: the GEMV sizes it is for); output dtype = the activation dtype or the other one
-#define CONCH_ONE(R, S)                                                                                                              \
+#define CONCH_ONE(R)                                                                                                                 \
   do {                                                                                                                               \
     if (p.out_dtype == CONCH_DT_FP16)                                                                                                \
-      hipLaunchKernelGGL((mixed_skinny_kernel<X_DT, BITS, ZP, R, true, CONCH_DT_FP16, S>), grid, block, 0, stream, p, ws, counters);  \
+      hipLaunchKernelGGL((mixed_skinny_kernel<X_DT, BITS, ZP, R, true, CONCH_DT_FP16>), grid, block, 0, stream, p, ws, counters);     \
     else                                                                                                                             \
-      hipLaunchKernelGGL((mixed_skinny_kernel<X_DT, BITS, ZP, R, true, CONCH_DT_BF16, S>), grid, block, 0, stream, p, ws, counters);  \
+      hipLaunchKernelGGL((mixed_skinny_kernel<X_DT, BITS, ZP, R, true, CONCH_DT_BF16>), grid, block, 0, stream, p, ws, counters);     \
   } while (0)
-    if (steps == kMsShortSteps) {
-      if (rows == 16) CONCH_ONE(16, kMsShortSteps);
-      else CONCH_ONE(32, kMsShortSteps);
-    } else {
-      if (rows == 16) CONCH_ONE(16, kMsSteps);
-      else CONCH_ONE(32, kMsSteps);
-    }
+    if (rows == 16) CONCH_ONE(16);
+    else CONCH_ONE(32);
 #undef CONCH_ONE
     return;
   }
@@ -342,10 +336,10 @@ void launch_rows(const MixedGemmArgs& p, int rows, int steps, dim3 grid, float* 
 }
 
 template <int X_DT, int BITS>
-void launch_zp_mode(const MixedGemmArgs& p, int rows, int steps, dim3 grid, float* ws, unsigned* counters, hipStream_t stream) {
-  if (p.zp_mode == CONCH_ZP_NONE) launch_rows<X_DT, BITS, CONCH_ZP_NONE>(p, rows, steps, grid, ws, counters, stream);
-  else if (p.zp_mode == CONCH_ZP_SCALAR) launch_rows<X_DT, BITS, CONCH_ZP_SCALAR>(p, rows, steps, grid, ws, counters, stream);
-  else launch_rows<X_DT, BITS, CONCH_ZP_TENSOR>(p, rows, steps, grid, ws, counters, stream);
+void launch_zp_mode(const MixedGemmArgs& p, int rows, dim3 grid, float* ws, unsigned* counters, hipStream_t stream) {
+  if (p.zp_mode == CONCH_ZP_NONE) launch_rows<X_DT, BITS, CONCH_ZP_NONE>(p, rows, grid, ws, counters, stream);
+  else if (p.zp_mode == CONCH_ZP_SCALAR) launch_rows<X_DT, BITS, CONCH_ZP_SCALAR>(p, rows, grid, ws, counters, stream);
+  else launch_rows<X_DT, BITS, CONCH_ZP_TENSOR>(p, rows, grid, ws, counters, stream);
 }
 
 }  // namespace
@@ -374,34 +368,18 @@ bool mixed_gemm_skinny_supported(const MixedGemmArgs& p) {
 }
 
 int launch_mixed_gemm_skinny(const MixedGemmArgs& p, hipStream_t stream) {
-  int slices = (int)((p.k + kMsSliceK - 1) / kMsSliceK);
+  const int slices = (int)((p.k + kMsSliceK - 1) / kMsSliceK);
   const int rows = p.m <= 16 ? 16 : p.m <= 32 ? 32 : 64;
-  dim3 grid((unsigned)((p.n + kMsN - 1) / kMsN), (unsigned)slices, (unsigned)((p.m + rows - 1) / rows));
-  // CONCH_TUNE_SKINNY_MODE (shared with the scaled split-K kernel): 0 = auto, 1 = two launches, 2 = one launch with 1024-element
-  // slices, 3 = one launch with 512-element slices.  Auto: one launch for up to 32 rows (GEMV sizes: the slab tile of a
-  // workgroup is 2-8 KiB, the last arriver's pass over the slices is cheaper than a second launch:
-  // profiles/r02/mixed_decode_one_launch.txt); HALF slices when the full ones leave at most one workgroup per CU -- a lone wave
-  // per SIMD gets one instruction per five clocks, and both the prologue (~420 instructions) and the dequantisation of the
-  // slice (~45 per step) are instruction streams: two workgroups per CU of half the length overlap them
-  // (profiles/r03/mixed_decode_short_slices.txt)
-  const int mode = tuning(CONCH_TUNE_SKINNY_MODE);
-  const bool one_launch_ok = !p.fuse_silu && rows <= 32 && mode != 1;
-  // one counter per (tile, wave); all slabs behind one 32-bit buffer descriptor
-  const auto fits_one_launch = [&](int sl) {
-    return sl >= 2 && (size_t)sl * p.m * p.n * 4 < ((size_t)1 << 31) && (size_t)grid.x * grid.z * 4 <= (size_t)kMsMaxTiles;
-  };
-  int steps = kMsSteps;
-  const int short_slices = (int)((p.k + kMsShortSteps * kMsStepK - 1) / (kMsShortSteps * kMsStepK));
-  if (one_launch_ok && fits_one_launch(short_slices) &&
-      (mode == 3 || (mode == 0 && (size_t)grid.x * grid.y * grid.z <= (size_t)device_cu_count()))) {
-    steps = kMsShortSteps;
-    slices = short_slices;
-    grid.y = (unsigned)slices;
-  }
   void* ws = nullptr;
   const size_t bytes = (size_t)slices * p.m * p.n * 4;
   if (int rc = get_scratch(stream, kScratchMixedSplitK, bytes, &ws)) return rc;
-  const bool one_launch = one_launch_ok && fits_one_launch(slices);  // (the short slices are only ever taken by the one-launch form)
+  const dim3 grid((unsigned)((p.n + kMsN - 1) / kMsN), (unsigned)slices, (unsigned)((p.m + rows - 1) / rows));
+  // CONCH_TUNE_SKINNY_MODE (shared with the scaled split-K kernel): 0 = auto, 1 = two launches, 2 / 3 = one launch.  Auto: one
+  // launch for up to 32 rows (GEMV sizes: the slab tile of a workgroup is 2-8 KiB, the last arriver's pass over the slices is
+  // cheaper than a second launch: profiles/r02/mixed_decode_one_launch.txt)
+  const int mode = tuning(CONCH_TUNE_SKINNY_MODE);
+  const bool one_launch = !p.fuse_silu && rows <= 32 && slices >= 2 && mode != 1 && bytes < ((size_t)1 << 31) &&
+                          (size_t)grid.x * grid.z * 4 <= (size_t)kMsMaxTiles;  // one counter per (tile, wave)
   unsigned* counters = nullptr;
   if (one_launch) {
     void* cbuf = nullptr;
@@ -409,11 +387,11 @@ int launch_mixed_gemm_skinny(const MixedGemmArgs& p, hipStream_t stream) {
     counters = (unsigned*)cbuf;
   }
   if (p.x_dtype == CONCH_DT_FP16) {
-    if (p.bits == 4) launch_zp_mode<CONCH_DT_FP16, 4>(p, rows, steps, grid, (float*)ws, counters, stream);
-    else launch_zp_mode<CONCH_DT_FP16, 8>(p, rows, steps, grid, (float*)ws, counters, stream);
+    if (p.bits == 4) launch_zp_mode<CONCH_DT_FP16, 4>(p, rows, grid, (float*)ws, counters, stream);
+    else launch_zp_mode<CONCH_DT_FP16, 8>(p, rows, grid, (float*)ws, counters, stream);
   } else {
-    if (p.bits == 4) launch_zp_mode<CONCH_DT_BF16, 4>(p, rows, steps, grid, (float*)ws, counters, stream);
-    else launch_zp_mode<CONCH_DT_BF16, 8>(p, rows, steps, grid, (float*)ws, counters, stream);
+    if (p.bits == 4) launch_zp_mode<CONCH_DT_BF16, 4>(p, rows, grid, (float*)ws, counters, stream);
+    else launch_zp_mode<CONCH_DT_BF16, 8>(p, rows, grid, (float*)ws, counters, stream);
   }
   if (one_launch) return check_launch("mixed_gemm_skinny_one_launch");
   if (p.fuse_silu) {  // p.n = 2d columns [gate | up], C has d (caller: mixed_gemm_skinny_supported(wide) && d % 4 == 0)

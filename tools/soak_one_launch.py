@@ -28,17 +28,8 @@ for (m, k, n) in [(1, 4096, 4096), (16, 4096, 11008), (32, 8192, 8192), (8, 1100
     fn = lambda x=x, wq=wq, ws=ws: mixed_precision_gemm(x, wq, ws, None, 4, 8, 128)
     cases.append((f"mixed {m}x{k}x{n}", fn))
 _C.set_tuning(_C.TUNE_SKINNY_MODE, 1)
-two = [fn().clone() for _, fn in cases]
-_C.set_tuning(_C.TUNE_SKINNY_MODE, 0)
-torch.cuda.synchronize()
-# the automatic form on an idle chip: bit-identical to the two-launch form where it cuts the same slices; where it takes half
-# slices (int4 decode with at most one workgroup per CU) the fp32 summation order across slices differs -- close, and from then
-# on the reference every launch under load must reproduce bit for bit
 want = [fn().clone() for _, fn in cases]
-same = sum(bool(torch.equal(w, t)) for w, t in zip(want, two))
-for (name, _), w, t in zip(cases, want, two):
-    assert torch.allclose(w.float(), t.float(), rtol=2e-2, atol=2e-2 * float(t.float().abs().max())), name
-print(f"{same} of {len(cases)} automatic forms are bit-identical to their two-launch form; the others cut other slices")
+_C.set_tuning(_C.TUNE_SKINNY_MODE, 0)
 side = torch.cuda.Stream(); noise = torch.randn((3000, 3000), device="cuda")
 bad = 0
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
@@ -54,4 +45,4 @@ for i in range(N):
             print("MISMATCH", i, cases[j][0], flush=True)
             if bad > 5: break
 torch.cuda.synchronize()
-print(f"{N} launches of the automatic (one-launch) forms in random order under uneven load: {bad} mismatches against the idle-chip results")
+print(f"{N} launches of the automatic (one-launch) forms in random order under uneven load: {bad} mismatches against the two-launch results")

@@ -64,10 +64,9 @@ for m, k, n in ((1, 4096, 4096), (8, 4096, 4096), (16, 4096, 4096), (32, 4096, 4
     ws = (0.05 * torch.rand((k // 128, n), device="cuda") + 0.01).to(torch.float16)
     fn = lambda: mixed_precision_gemm(x, wq, ws, None, 4, 8, 128)  # noqa: E731
     res = {}
-    for name, mode in (("two launches", 1), ("one launch", 2), ("half slices", 3), ("auto", 0)):
+    for name, mode in (("two launches", 1), ("one launch", 2)):
         _C.set_tuning(_C.TUNE_SKINNY_MODE, mode)
-        res[name] = (graph_time(fn), eager_time(fn) if mode in (1, 2) else 0.0)
+        res[name] = (graph_time(fn), eager_time(fn))
     _C.set_tuning(_C.TUNE_SKINNY_MODE, 0)
     (g2, e2), (g1, e1) = res["two launches"], res["one launch"]
-    print(f"int4 x fp16 {m:3d}x{k}x{n}: GPU time two launches {g2:5.1f} us, one launch {g1:5.1f} us ({g2 / g1:.2f}x), one launch with 512-element "
-          f"slices {res['half slices'][0]:5.1f} us, automatic {res['auto'][0]:5.1f} us;   eager op level {e2:5.1f} -> {e1:5.1f} us", flush=True)
+    print(f"int4 x fp16 {m:3d}x{k}x{n}: GPU time two launches {g2:5.1f} us, one launch {g1:5.1f} us ({g2 / g1:.2f}x);   eager op level {e2:5.1f} -> {e1:5.1f} us", flush=True)
