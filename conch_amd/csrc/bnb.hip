@@ -333,11 +333,22 @@ constexpr int kBgStepK = 64;    // k elements per step (128 bytes of fp16 / bf16
 constexpr int kBgSteps = 16;    // steps per slice
 constexpr int kBgSliceK = kBgSteps * kBgStepK;
 
-template <int X_DT, int ADT, int QT, int ROWS>
+// WLDS (rows <= 32): the packed codes take the LDS-DMA path too.  A lane of the MFMA's weight operand is (row n, k-group g), and
+// W's rows are K-contiguous -- the four lanes of a quad sit on four different rows, four different 128-byte lines: the texture
+// path takes a quad one line at a time, and a wave instruction brought 16 bytes from each of 16 lines (every line touched by
+// eight instructions).  Here lane L fetches row L >> 2, one 16-byte chunk of the row's 64 bytes of two K steps (a quad = 64
+// contiguous bytes; 8 instructions per wave instead of 32), straight into the wave's 8 KiB of LDS, and the operand lane reads its
+// word back with ds_read_b32.  The chunk a lane fetches is rotated by (row >> 2) so that the read -- lane (r, g) wants chunk c of
+// row r: dword 16 (r & 3) + 4 ((c + (r >> 2)) & 3) + g of its 64-dword row group -- touches 64 different banks.
+// Blocks of 64 (bitsandbytes' default): the absmax of a row's 16 steps are 16 consecutive elements -- four loads of 16 rows x 4
+// elements and a ds_bpermute per step instead of 16 loads of one element from each of 16 lines.
+template <int X_DT, int ADT, int QT, int ROWS, bool WLDS>
 __global__ __launch_bounds__(kBgThreads) void bnb_decode_gemm_kernel(BnbGemmArgs p, float* __restrict__ slabs) {
   using namespace tile;
+  static_assert(!WLDS || ROWS <= 32, "the code staging does not fit beside 64 rows of X");
   constexpr int kUnit = ROWS * 128;  // one K step of X
-  __shared__ __attribute__((aligned(1024))) char lds[kBgSteps * kUnit + 2048];
+  constexpr int kWBytes = WLDS ? 4 * (kBgSteps / 2) * 1024 : 0;  // per wave: one KiB per pair of steps
+  __shared__ __attribute__((aligned(1024))) char lds[kBgSteps * kUnit + 2048 + kWBytes];
   // byte -> its two numbers (code byte >> 4 first): ONE 8-byte LDS read per packed byte instead of two 4-byte reads and twice the
   // address arithmetic (the loop is bound by vector instructions, not by the LDS)
   f32x2* lut = (f32x2*)(lds + kBgSteps * kUnit);
@@ -352,44 +363,79 @@ __global__ __launch_bounds__(kBgThreads) void bnb_decode_gemm_kernel(BnbGemmArgs
   const int n = min(nw + r, (int)p.n - 1);  // this lane's weight row
   const int k0 = blockIdx.y * kBgSliceK;
   const int m0 = blockIdx.z * ROWS;
+  const int kk = (int)p.k;
   // a ragged last slice: the steps past K load from an out-of-range VGPR offset (zeros for X in LDS; absmax 0 -> weights 0)
-  const int valid_steps = min(kBgSteps, ((int)p.k - k0) / kBgStepK);
+  const int valid_steps = min(kBgSteps, (kk - k0) / kBgStepK);
 #define CONCH_KILL(s) ((s) < valid_steps ? 0 : (int)0x80000000)
 
-  const __amdgpu_buffer_rsrc_t rx =
-      __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (uint32_t)(((p.m - 1) * p.x_stride_m + p.k) * 2), 0x00020000);
-  constexpr int kPieces = ROWS / 8;
-#pragma unroll
-  for (int s = 0; s < kBgSteps; ++s)
-#pragma unroll
-    for (int q = 0; q < kPieces; ++q) {
-      if ((q & 3) != wave) continue;  // wave-uniform
-      const int row = 8 * q + (lane >> 3);
-      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-      const int voff = min(m0 + row, (int)p.m - 1) * (int)p.x_stride_m * 2 + chunk * 16;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t*)(lds + s * kUnit + q * 1024), 16, voff | CONCH_KILL(s), (k0 + s * kBgStepK) * 2, 0, 0);
-    }
-
-  // packed words and absmax of the whole slice -> registers
+  // ---- packed codes and absmax of the whole slice (first: they come from HBM, the X slice from L2); all 32-bit arithmetic
   constexpr int kAbsBytes = ADT == CONCH_DT_FP32 ? 4 : 2;
-  const int64_t blocks = p.n * p.k / p.blocksize;
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (uint32_t)(p.n * p.k / 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.absmax, 0, (uint32_t)(blocks * kAbsBytes), 0x00020000);
   const int bs_shift = __builtin_ctz((unsigned)p.blocksize);  // a power of two (check_common)
-  const int vw = n * (int)(p.k / 2) + 4 * g;                         // byte offset of the lane's k-group inside a half step
-  const int va = n * (int)(p.k >> bs_shift) * kAbsBytes;           // ... of the row's first block
-  uint32_t wq[kBgSteps][2];
+  const uint32_t w_bytes = (uint32_t)(p.n * p.k / 2);         // below 2 GiB (bnb_decode_supported)
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ra =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.absmax, 0, (uint32_t)(((uint64_t)w_bytes * 2) >> bs_shift) * kAbsBytes, 0x00020000);
+  char* wl = lds + kBgSteps * kUnit + 2048 + wave * (kWBytes / 4);  // this wave's code staging (WLDS)
+  uint32_t wq[kBgSteps][2];  // register path only (a dependent bound makes hipcc's host pass drop the kernel's stub)
+  if constexpr (WLDS) {
+    const int rho = lane >> 2;
+    const int chunk = ((lane & 3) - (rho >> 2)) & 3;
+    const int vw = min(nw + rho, (int)p.n - 1) * (kk / 2) + 16 * chunk;
+#pragma unroll
+    for (int i = 0; i < kBgSteps / 2; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_t*)(wl + i * 1024), 16, vw | CONCH_KILL(2 * i), k0 / 2 + i * 64, 0, 0);
+  } else {
+    const int vw = n * (kk / 2) + 4 * g;  // byte offset of the lane's k-group inside a half step
+#pragma unroll
+    for (int s = 0; s < kBgSteps; ++s)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        wq[s][h] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rw, vw | CONCH_KILL(s), (k0 + s * kBgStepK + 32 * h) / 2, 0);
+  }
   float am[kBgSteps];
+  uint32_t am_raw[4] = {0, 0, 0, 0};
+  const bool blocks_of_64 = bs_shift == 6;  // workgroup-uniform
+  if (blocks_of_64) {
+    // lane L: row L >> 2, blocks 4 j + (L & 3) of the slice
+    const int va = min(nw + (lane >> 2), (int)p.n - 1) * (kk >> 6) * kAbsBytes + (lane & 3) * kAbsBytes;
 #pragma unroll
-  for (int s = 0; s < kBgSteps; ++s) {
+    for (int j = 0; j < 4; ++j) {
+      const int kill = 4 * j + (lane & 3) < valid_steps ? 0 : (int)0x80000000;
+      if constexpr (ADT == CONCH_DT_FP32) am_raw[j] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(ra, va | kill, ((k0 >> 6) + 4 * j) * 4, 0);
+      else am_raw[j] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(ra, va | kill, ((k0 >> 6) + 4 * j) * 2, 0);
+    }
+  } else {
+    const int va = n * (kk >> bs_shift) * kAbsBytes;  // ... of the row's first block
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
-      wq[s][h] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rw, vw | CONCH_KILL(s), (k0 + s * kBgStepK + 32 * h) / 2, 0);
-    const int blk = (k0 + s * kBgStepK) >> bs_shift;
-    if constexpr (ADT == CONCH_DT_FP32)
-      am[s] = __builtin_bit_cast(float, (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(ra, va | CONCH_KILL(s), blk * 4, 0));
-    else
-      am[s] = bits16_to_float<ADT>((uint16_t)__builtin_amdgcn_raw_buffer_load_b16(ra, va | CONCH_KILL(s), blk * 2, 0));
+    for (int s = 0; s < kBgSteps; ++s) {
+      const int blk = (k0 + s * kBgStepK) >> bs_shift;
+      if constexpr (ADT == CONCH_DT_FP32)
+        am[s] = __builtin_bit_cast(float, (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(ra, va | CONCH_KILL(s), blk * 4, 0));
+      else
+        am[s] = bits16_to_float<ADT>((uint16_t)__builtin_amdgcn_raw_buffer_load_b16(ra, va | CONCH_KILL(s), blk * 2, 0));
+    }
+  }
+
+  // ---- X slice -> LDS (8-row x 128-byte subtiles, source-side swizzle): the kBgSteps x kPieces (step, piece) items dealt
+  // round-robin to the four waves without a branch (item t = wave + 4 j is step t / kPieces, piece t % kPieces)
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.x, 0, (((uint32_t)p.m - 1) * (uint32_t)p.x_stride_m + (uint32_t)kk) * 2, 0x00020000);
+  constexpr int kPieces = ROWS / 8;
+  constexpr int kMine = kPieces > 4 ? 2 : 1;
+  int voff_x[2];  // the first kMine are used (a dependent array bound makes hipcc's host pass drop the kernel's stub)
+#pragma unroll
+  for (int v = 0; v < kMine; ++v) {
+    const int q = (int)(((unsigned)wave + 4u * v) % kPieces);
+    const int row = 8 * q + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    voff_x[v] = min(m0 + row, (int)p.m - 1) * (int)p.x_stride_m * 2 + chunk * 16;
+  }
+#pragma unroll
+  for (int j = 0; j < kBgSteps * kPieces / 4; ++j) {
+    const unsigned t = (unsigned)wave + 4u * j;
+    const int s = (int)(t / kPieces), q = (int)(t % kPieces);  // wave-uniform
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t*)(lds + s * kUnit + q * 1024), 16, voff_x[kMine == 2 ? (j & 1) : 0] | CONCH_KILL(s),
+                                             (k0 + s * kBgStepK) * 2, 0, 0);
   }
 #undef CONCH_KILL
 
@@ -398,7 +444,17 @@ __global__ __launch_bounds__(kBgThreads) void bnb_decode_gemm_kernel(BnbGemmArgs
   for (int i = 0; i < ROWS / 16; ++i) acc[i] = f32x4{0, 0, 0, 0};
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();  // the X pieces of every wave and the table have landed
+  __syncthreads();  // the X pieces and the codes of every wave and the table have landed
+
+  if (blocks_of_64) {
+    // step s = block s of the slice: element s & 3 of load s >> 2, held by lane 4 r + (s & 3)
+#pragma unroll
+    for (int s = 0; s < kBgSteps; ++s) {
+      const uint32_t raw = (uint32_t)__builtin_amdgcn_ds_bpermute((4 * r + (s & 3)) * 4, (int)am_raw[s >> 2]);
+      if constexpr (ADT == CONCH_DT_FP32) am[s] = __builtin_bit_cast(float, raw);
+      else am[s] = bits16_to_float<ADT>((uint16_t)raw);
+    }
+  }
 
   // eight codes of one word -> eight numbers of the activation dtype: output dword j = (k 2j, k 2j + 1) = (high, low nibble of byte j)
   // the table reads of a step are all in flight together (lookup), then the arithmetic (scale8); pin_f32 keeps the fp32 product
@@ -425,11 +481,23 @@ __global__ __launch_bounds__(kBgThreads) void bnb_decode_gemm_kernel(BnbGemmArgs
   };
 
   const int lane_off = (r >> 3) * 1024 + (r & 7) * 128 + ((g ^ ((r >> 1) & 7)) * 16);
+  // WLDS: byte address, inside a pair of steps' KiB, of this lane's word in chunk c = 2 (s & 1) + h
+  int w_read[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) w_read[c] = (4 * r + ((c + (r >> 2)) & 3)) * 16 + 4 * g;
 #pragma unroll
   for (int s = 0; s < kBgSteps; ++s) {
+    uint32_t w0, w1;
+    if constexpr (WLDS) {
+      w0 = *(const uint32_t*)(wl + (s >> 1) * 1024 + w_read[2 * (s & 1)]);
+      w1 = *(const uint32_t*)(wl + (s >> 1) * 1024 + w_read[2 * (s & 1) + 1]);
+    } else {
+      w0 = wq[s][0];
+      w1 = wq[s][1];
+    }
     f32x2 t_lo[4], t_hi[4];
-    lookup(wq[s][0], t_lo);
-    lookup(wq[s][1], t_hi);
+    lookup(w0, t_lo);
+    lookup(w1, t_hi);
     const i32x4 w_lo = scale8(t_lo, am[s]);
     const i32x4 w_hi = scale8(t_hi, am[s]);
 #pragma unroll
@@ -455,12 +523,21 @@ __global__ __launch_bounds__(kBgThreads) void bnb_decode_gemm_kernel(BnbGemmArgs
   }
 }
 
+// CONCH_TUNE_SKINNY_GATHER 1 (the same question as in gemm_skinny.hip: how a wave fetches its weight operand) = the register path
+// for the codes at every row count
 template <int X_DT, int ADT, int QT>
 void launch_decode_rows(const BnbGemmArgs& p, int rows, dim3 grid, float* ws, hipStream_t stream) {
   const dim3 block(kBgThreads);
-  if (rows == 16) hipLaunchKernelGGL((bnb_decode_gemm_kernel<X_DT, ADT, QT, 16>), grid, block, 0, stream, p, ws);
-  else if (rows == 32) hipLaunchKernelGGL((bnb_decode_gemm_kernel<X_DT, ADT, QT, 32>), grid, block, 0, stream, p, ws);
-  else hipLaunchKernelGGL((bnb_decode_gemm_kernel<X_DT, ADT, QT, 64>), grid, block, 0, stream, p, ws);
+  const bool wlds = tuning(CONCH_TUNE_SKINNY_GATHER) != 1;
+  if (rows == 16) {
+    if (wlds) hipLaunchKernelGGL((bnb_decode_gemm_kernel<X_DT, ADT, QT, 16, true>), grid, block, 0, stream, p, ws);
+    else hipLaunchKernelGGL((bnb_decode_gemm_kernel<X_DT, ADT, QT, 16, false>), grid, block, 0, stream, p, ws);
+  } else if (rows == 32) {
+    if (wlds) hipLaunchKernelGGL((bnb_decode_gemm_kernel<X_DT, ADT, QT, 32, true>), grid, block, 0, stream, p, ws);
+    else hipLaunchKernelGGL((bnb_decode_gemm_kernel<X_DT, ADT, QT, 32, false>), grid, block, 0, stream, p, ws);
+  } else {
+    hipLaunchKernelGGL((bnb_decode_gemm_kernel<X_DT, ADT, QT, 64, false>), grid, block, 0, stream, p, ws);
+  }
 }
 
 template <int X_DT, int ADT>

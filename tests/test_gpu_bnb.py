@@ -197,6 +197,35 @@ def test_matmul_4bit_decode_kernel(qt, dname, absmax_dt, m, k, n, blocksize):
     assert torch.equal(auto, got) or torch.equal(auto, first)  # auto = the decode kernel up to 64 rows, a cost rule above
 
 
+@pytest.mark.parametrize("qt", ["nf4", "fp4"])
+@pytest.mark.parametrize(("dname", "absmax_dt"), [("f16", torch.float32), ("bf16", torch.bfloat16)])
+@pytest.mark.parametrize(("m", "k", "n", "blocksize"), [(1, 1024, 64, 64), (16, 2048, 520, 128), (20, 4096, 1376, 64), (32, 1152, 260, 128),
+                                                         (8, 11008, 512, 64), (3, 192, 68, 64), (24, 2048, 256, 2048)])
+def test_matmul_4bit_decode_fetch_orders_are_bit_identical(qt, dname, absmax_dt, m, k, n, blocksize):
+    """Up to 32 rows the packed codes reach the MFMA operands through LDS-DMA (four lanes per 64-byte row piece, read back per
+    lane) and the absmax of 64-element blocks through four wide loads and a cross-lane gather; CONCH_TUNE_SKINNY_GATHER = 1 is
+    the register path in MFMA operand order.  Same bytes in the same operand registers: bit-identical, ragged K / N included."""
+    from conch_amd import _C
+
+    seed_everything(7)
+    dt = DT[dname]
+    w = torch.randn(n, k, dtype=dt)
+    x = (torch.rand(m, k) - 0.5).to(dt)
+    wq, am = oracle.quantize_blockwise_ref(w, blocksize, qt, None, absmax_dtype=absmax_dt)
+    state = QuantState(absmax=am.cuda(), shape=w.shape, blocksize=blocksize, quant_type=qt, dtype=dt)
+    q = wq.cuda()
+    try:
+        _C.set_gemm_variant(_C.VARIANT_MFMA_SKINNY)
+        _C.set_tuning(_C.TUNE_SKINNY_GATHER, 1)
+        regs = matmul_4bit(x.cuda(), q, state)
+        _C.set_tuning(_C.TUNE_SKINNY_GATHER, 0)
+        for _ in range(2):
+            assert torch.equal(matmul_4bit(x.cuda(), q, state), regs)
+    finally:
+        _C.set_gemm_variant(_C.VARIANT_AUTO)
+        _C.set_tuning(_C.TUNE_SKINNY_GATHER, 0)
+
+
 def test_matmul_4bit_decode_dequant_is_bit_exact():
     """Unit-vector activations isolate the in-register dequantisation: row i of the product is column j_i of the dequantised
     weight, bit for bit (nf4 and fp4, fp16 and bf16, fp32 and fp16 absmax)."""
