@@ -57,12 +57,20 @@ __device__ unsigned long long g_probe_mixed_skinny[kProbeBlocks * 8];
 #define MS_DRAIN() do { } while (0)
 #endif
 
-template <int X_DT, int BITS, int ZP, int ROWS, bool FUSED = false, int OUT_DT = CONCH_DT_FP16>
+// WLDS (int4 words, 16-byte aligned word rows): the packed words take the LDS-DMA path too.  A 4-byte load per lane moves 256
+// bytes per wave instruction and the address path charges a wave instruction 16 cycles whatever its width (profiles/r03/
+// probe_mixed_skinny.txt: 56 vector-memory instructions per wave, 224 per CU = 1.7 of the 2.8 us the slice's loads take to issue).
+// Lane L fetches word row L >> 2 of a PAIR of steps, columns 4 (L & 3) .. + 3 (16 bytes; 8 instructions per wave instead of 32)
+// into the wave's 8 KiB of LDS -- the image is row-major [16 word rows][16 columns], so operand lane (column r, k-group g) reads
+// dword 16 (8 (s & 1) + 4 h + g) + r: 64 different banks.
+template <int X_DT, int BITS, int ZP, int ROWS, bool FUSED = false, int OUT_DT = CONCH_DT_FP16, bool WLDS = false>
 __global__ __launch_bounds__(kMsThreads) void mixed_skinny_kernel(MixedGemmArgs p, float* __restrict__ slabs, unsigned* __restrict__ counters) {
+  static_assert(!WLDS || BITS == 4, "the word staging is built for int4 (one word per lane and half step)");
   constexpr int kUnit = ROWS * 128;            // one K step of X
   constexpr int kWpc = BITS == 4 ? 1 : 2;      // 32-bit words per 8-k chunk
   constexpr int kWordRows = kMsStepK * BITS / 32;  // word rows per K step (8 / 16)
-  __shared__ __attribute__((aligned(1024))) char lds[kMsSteps * kUnit];
+  constexpr int kWBytes = WLDS ? 4 * (kMsSteps / 2) * 1024 : 0;  // per wave: one KiB per pair of steps
+  __shared__ __attribute__((aligned(1024))) char lds[kMsSteps * kUnit + kWBytes];
   MS_STAMP(0);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -99,18 +107,27 @@ __global__ __launch_bounds__(kMsThreads) void mixed_skinny_kernel(MixedGemmArgs 
   const int q_row = (int)p.wq_stride_k * 4;                         // bytes per word row
   const int vq = (g * kWpc) * q_row + n * 4;                        // this lane's k-group inside a half step
   const int q_base = (k0 * BITS / 32) * q_row;
-  uint32_t wq[kMsSteps][2][kWpc];
+  uint32_t wq[kMsSteps][2][kWpc];  // register path
+  char* wl = lds + kMsSteps * kUnit + wave * (kWBytes / 4);  // this wave's word staging (WLDS)
+  if constexpr (WLDS) {
+    const int vw = (lane >> 2) * q_row + (nw + 4 * (lane & 3)) * 4;  // columns past N: never stored; past the tensor: zeros
+#pragma unroll
+    for (int i = 0; i < kMsSteps / 2; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_void_t*)(wl + i * 1024), 16, vw | CONCH_KILL(2 * i), q_base + i * 16 * q_row, 0, 0);
+  }
   uint32_t sc[kMsSteps];
   int zp[kMsSteps];
   int s_off = (int)first_group * (int)p.ws_stride_g * 2, z_off = (int)first_group * (int)p.wzp_stride_g * 4;
   uint32_t left = steps_per_group - (first_step - first_group * steps_per_group);    // steps before the group changes
 #pragma unroll
   for (int s = 0; s < kMsSteps; ++s) {
+    if constexpr (!WLDS) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+      for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int i = 0; i < kWpc; ++i)
-        wq[s][h][i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rq, vq | CONCH_KILL(s), q_base + (s * kWordRows + h * (kWordRows / 2) + i) * q_row, 0);
+        for (int i = 0; i < kWpc; ++i)
+          wq[s][h][i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rq, vq | CONCH_KILL(s), q_base + (s * kWordRows + h * (kWordRows / 2) + i) * q_row, 0);
+    }
     sc[s] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs, (n * 2) | CONCH_KILL(s), s_off, 0);
     if constexpr (ZP == CONCH_ZP_TENSOR) zp[s] = (int)__builtin_amdgcn_raw_buffer_load_b32(rz, (n * 4) | CONCH_KILL(s), z_off, 0);
     else zp[s] = 0;
@@ -158,11 +175,19 @@ __global__ __launch_bounds__(kMsThreads) void mixed_skinny_kernel(MixedGemmArgs 
   MS_STAMP(2);
 
   const int lane_off = (r >> 3) * 1024 + (r & 7) * 128 + ((g ^ ((r >> 1) & 7)) * 16);
+  const int w_read = 64 * g + 4 * r;  // WLDS: this lane's word inside a half step's four word rows
 #pragma unroll
   for (int s = 0; s < kMsSteps; ++s) {
     // the lane's 8 + 8 weights of this step: k = 8g..8g+7 (first half step) and 32 + 8g.. (second), column n
-    const i32x4 w_lo = dequant8<X_DT, BITS, ZP>(wq[s][0][0], wq[s][0][kWpc - 1], off_base + zp[s], sc[s], and_mask, or_magic, and_mask_hi);
-    const i32x4 w_hi = dequant8<X_DT, BITS, ZP>(wq[s][1][0], wq[s][1][kWpc - 1], off_base + zp[s], sc[s], and_mask, or_magic, and_mask_hi);
+    uint32_t w00, w01, w10, w11;
+    if constexpr (WLDS) {
+      w00 = w01 = *(const uint32_t*)(wl + (s >> 1) * 1024 + (s & 1) * 512 + w_read);
+      w10 = w11 = *(const uint32_t*)(wl + (s >> 1) * 1024 + (s & 1) * 512 + 256 + w_read);
+    } else {
+      w00 = wq[s][0][0], w01 = wq[s][0][kWpc - 1], w10 = wq[s][1][0], w11 = wq[s][1][kWpc - 1];
+    }
+    const i32x4 w_lo = dequant8<X_DT, BITS, ZP>(w00, w01, off_base + zp[s], sc[s], and_mask, or_magic, and_mask_hi);
+    const i32x4 w_hi = dequant8<X_DT, BITS, ZP>(w10, w11, off_base + zp[s], sc[s], and_mask, or_magic, and_mask_hi);
 #pragma unroll
     for (int i = 0; i < ROWS / 16; ++i) {
       const Frag fx = read_frag(lds, s * kUnit + lane_off + i * 2048);
@@ -314,25 +339,40 @@ __global__ __launch_bounds__(256) void mixed_skinny_reduce_silu_kernel(MixedGemm
   }
 }
 
-template <int X_DT, int BITS, int ZP>
-void launch_rows(const MixedGemmArgs& p, int rows, dim3 grid, float* ws, unsigned* counters, hipStream_t stream) {
+// WL = the int4 words through LDS-DMA (see mixed_skinny_kernel): 16-byte aligned word rows, CONCH_TUNE_SKINNY_GATHER != 1
+template <int X_DT, int BITS, int ZP, bool WL>
+void launch_rows_wl(const MixedGemmArgs& p, int rows, dim3 grid, float* ws, unsigned* counters, hipStream_t stream) {
   const dim3 block(kMsThreads);
   if (counters) {  // one launch (rows <= 32 only: the GEMV sizes it is for); output dtype = the activation dtype or the other one
-#define CONCH_ONE(R)                                                                                                                 \
-  do {                                                                                                                               \
-    if (p.out_dtype == CONCH_DT_FP16)                                                                                                \
-      hipLaunchKernelGGL((mixed_skinny_kernel<X_DT, BITS, ZP, R, true, CONCH_DT_FP16>), grid, block, 0, stream, p, ws, counters);     \
-    else                                                                                                                             \
-      hipLaunchKernelGGL((mixed_skinny_kernel<X_DT, BITS, ZP, R, true, CONCH_DT_BF16>), grid, block, 0, stream, p, ws, counters);     \
+#define CONCH_ONE(R)                                                                                                                   \
+  do {                                                                                                                                 \
+    if (p.out_dtype == CONCH_DT_FP16)                                                                                                  \
+      hipLaunchKernelGGL((mixed_skinny_kernel<X_DT, BITS, ZP, R, true, CONCH_DT_FP16, WL>), grid, block, 0, stream, p, ws, counters);   \
+    else                                                                                                                               \
+      hipLaunchKernelGGL((mixed_skinny_kernel<X_DT, BITS, ZP, R, true, CONCH_DT_BF16, WL>), grid, block, 0, stream, p, ws, counters);   \
   } while (0)
     if (rows == 16) CONCH_ONE(16);
     else CONCH_ONE(32);
 #undef CONCH_ONE
     return;
   }
-  if (rows == 16) hipLaunchKernelGGL((mixed_skinny_kernel<X_DT, BITS, ZP, 16>), grid, block, 0, stream, p, ws, counters);
-  else if (rows == 32) hipLaunchKernelGGL((mixed_skinny_kernel<X_DT, BITS, ZP, 32>), grid, block, 0, stream, p, ws, counters);
-  else hipLaunchKernelGGL((mixed_skinny_kernel<X_DT, BITS, ZP, 64>), grid, block, 0, stream, p, ws, counters);
+  if (rows == 16) hipLaunchKernelGGL((mixed_skinny_kernel<X_DT, BITS, ZP, 16, false, CONCH_DT_FP16, WL>), grid, block, 0, stream, p, ws, counters);
+  else if (rows == 32) hipLaunchKernelGGL((mixed_skinny_kernel<X_DT, BITS, ZP, 32, false, CONCH_DT_FP16, WL>), grid, block, 0, stream, p, ws, counters);
+  else hipLaunchKernelGGL((mixed_skinny_kernel<X_DT, BITS, ZP, 64, false, CONCH_DT_FP16, WL>), grid, block, 0, stream, p, ws, counters);
+}
+
+template <int X_DT, int BITS, int ZP>
+void launch_rows(const MixedGemmArgs& p, int rows, dim3 grid, float* ws, unsigned* counters, hipStream_t stream) {
+  if constexpr (BITS == 4) {
+    // measured (profiles/r03/int4_decode_wlds.txt): 3-5 % ahead while the launch is at most one workgroup per CU (16 x 4096 x 4096
+    // 7.0 -> 6.7 us); with several workgroups per CU the 32 KiB of staging cost residency -- 16 x 4096 x 11008 9.1 -> 10.4 us,
+    // 32 x 4096 x 11008 12.6 -> 16.7 us -- so only then (2 = always)
+    const int mode = tuning(CONCH_TUNE_SKINNY_GATHER);
+    const bool one_round = (size_t)grid.x * grid.y * grid.z <= (size_t)device_cu_count();
+    if ((((uintptr_t)p.w_q) & 15) == 0 && p.wq_stride_k % 4 == 0 && (mode == 2 || (mode == 0 && one_round)))
+      return launch_rows_wl<X_DT, BITS, ZP, true>(p, rows, grid, ws, counters, stream);
+  }
+  launch_rows_wl<X_DT, BITS, ZP, false>(p, rows, grid, ws, counters, stream);
 }
 
 template <int X_DT, int BITS>

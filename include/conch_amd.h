@@ -151,8 +151,9 @@ typedef enum conch_tuning_key {
   CONCH_TUNE_SKINNY_GATHER = 10 /* split-K skinny-M scaled GEMM, how a wave fetches its B^T fragments: 0 = auto (2 when the launch
                                    is at most one workgroup per CU), 1 = in MFMA operand order (16 rows x 16 bytes per quarter-wave),
                                    2 = four lanes per 64-byte row piece, put into operand order by a cross-lane gather.  The 4-bit
-                                   decode GEMM of conch_bnb_gemm_4bit (<= 32 rows): 1 = packed codes in operand order into registers,
-                                   otherwise four lanes per 64-byte row piece through LDS */
+                                   decode GEMM of conch_bnb_gemm_4bit (<= 32 rows) and the int4 decode-batch kernel of
+                                   mixed_precision_gemm: 1 = packed words in operand order into registers, otherwise 16 bytes per
+                                   lane through LDS (LDS-DMA) */
 } conch_tuning_key_t;
 
 int conch_abi_version(void);

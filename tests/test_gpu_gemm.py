@@ -1415,6 +1415,26 @@ def test_mixed_decode_one_launch_is_bit_identical_to_two_launches(_reset_tuning,
     check_mixed(two, a, w_ref, k)
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize(("m", "k", "n"), [(1, 4096, 4096), (8, 1024, 64), (16, 2048, 520), (20, 11008, 512), (32, 1152, 256), (48, 2048, 1376), (3, 8192, 68)])
+@pytest.mark.parametrize(("wname", "use_zp", "dname"), [("uint4b8", False, "f16"), ("uint4", True, "bf16")])
+def test_mixed_decode_word_fetch_orders_are_bit_identical(_reset_tuning, mode, m, k, n, wname, use_zp, dname):
+    """int4 decode kernel: the packed words in MFMA operand order into registers (CONCH_TUNE_SKINNY_GATHER = 1) against 16 bytes
+    per lane through LDS-DMA (= 2; the automatic choice while the launch is at most one workgroup per CU): the same words in the
+    same operand registers, in both launch forms, ragged N / K and a column block past N included."""
+    wt = WTYPES[wname]
+    a, w_ref, packed, w_s, w_zp = make_mixed_inputs(m, k, n, wt, use_zp, DT[dname])
+    dev = lambda t: None if t is None else t.cuda()  # noqa: E731
+    args = (dev(a), dev(packed), dev(w_s), dev(w_zp), wt.size_bits, wt.bias, 128)
+    _C.set_tuning(_C.TUNE_SKINNY_MODE, mode)
+    _C.set_tuning(_C.TUNE_SKINNY_GATHER, 1)
+    regs = mixed_precision_gemm(*args)
+    _C.set_tuning(_C.TUNE_SKINNY_GATHER, 2)
+    for _ in range(2):
+        assert torch.equal(mixed_precision_gemm(*args), regs)
+    check_mixed(regs, a, w_ref, k)
+
+
 @pytest.mark.parametrize(("m", "k", "n"), [(16, 4096, 11008), (32, 8192, 8192), (8, 4096, 28672)])
 def test_mixed_decode_one_launch_with_several_workgroups_per_cu(_reset_tuning, m, k, n):
     """688 / 1024 / 1792 workgroups of the one-launch decode kernel on 256 CUs (two to four resident per CU, several rounds):
