@@ -394,7 +394,11 @@ __global__ __launch_bounds__(kBgThreads) void bnb_decode_gemm_kernel(BnbGemmArgs
   }
   float am[kBgSteps];
   uint32_t am_raw[4] = {0, 0, 0, 0};
+#ifdef CONCH_EXP_BNB_ABSMAX_PER_STEP
+  const bool blocks_of_64 = false;
+#else
   const bool blocks_of_64 = bs_shift == 6;  // workgroup-uniform
+#endif
   if (blocks_of_64) {
     // lane L: row L >> 2, blocks 4 j + (L & 3) of the slice
     const int va = min(nw + (lane >> 2), (int)p.n - 1) * (kk >> 6) * kAbsBytes + (lane & 3) * kAbsBytes;

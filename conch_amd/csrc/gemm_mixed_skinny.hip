@@ -128,6 +128,10 @@ __global__ __launch_bounds__(kMsThreads) void mixed_skinny_kernel(MixedGemmArgs 
         for (int i = 0; i < kWpc; ++i)
           wq[s][h][i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rq, vq | CONCH_KILL(s), q_base + (s * kWordRows + h * (kWordRows / 2) + i) * q_row, 0);
     }
+    // (one scale load per step although a group spans two or more: fetching the slice's group rows in two loads and handing
+    // them out with a ds_bpermute per step behind the barrier took 1 us off the ISSUE of the loads and made the launch 3-8 %
+    // SLOWER -- the gather sits on the critical path, the loads it saves were issued under the latency of earlier ones:
+    // profiles/r03/ms_scale_ab.txt)
     sc[s] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs, (n * 2) | CONCH_KILL(s), s_off, 0);
     if constexpr (ZP == CONCH_ZP_TENSOR) zp[s] = (int)__builtin_amdgcn_raw_buffer_load_b32(rz, (n * 4) | CONCH_KILL(s), z_off, 0);
     else zp[s] = 0;
