@@ -134,7 +134,10 @@ enum ScaledKernel { kKernelTiled = 0, kKernelMid = 1, kKernelSkinny = 2 };
 //   split-K skinny  5.3 + c(M) N K        (re-reads the A slice per 64-column block; two row blocks above M = 128)
 //   256x256 tiles   rounds x (41 + 0.06 t) K/4096,  t = tiles per round of 256 workgroups
 //   128x128 tiles   rounds x (31 + 0.02 t) K/4096,  t = tiles per round of 512 workgroups (two per CU); with at most one tile
-//                   per CU (the 4-stage ring): (23 + 0.04 max(0, t - 128)) K/4096
+//                   per CU (the 4-stage ring): (23 + 0.08 max(0, t - 128)) K/4096
+// Round 3 re-ran the sweep after the split-K and decode kernels got faster (profiles/r03/dispatch_cold_sweep.txt: "before" =
+// the round-2 constants): c(M <= 16) 2.1 / 2.2 -> 2.0 / 2.1 and the ring's slope 0.04 -> 0.08 (8-16 x 4096 x 28672 had gone to
+// the 128x128 tiles at 30.5 us where the split-K form now takes 27.4-28.9).
 // The warm fit (round 1) was 4.5-5.5 + c N K with c 1.7 .. 9.7, rounds x (34 + 0.05 t), rounds x (19 + 0.0176 t): with it the
 // dispatcher picked the 128x128 tiles where the split-K form is 15-47 % faster on cold weights (96-128 x 4096 x 11008,
 // 8-32 x 4096 x 28672, 256 x 4096 x 4096).
@@ -146,7 +149,7 @@ ScaledKernel choose_scaled_kernel(const ScaledGemmArgs& p) {
   const int64_t tiles128 = ((p.m + 127) / 128) * ((p.n + 127) / 128);
   const int64_t rounds128 = (tiles128 + 511) / 512;
   // at most one tile per CU: the 4-stage ring (gemm_mid.hip), three K steps in flight per CU instead of one
-  const double mid_us = tiles128 <= device_cu_count() ? (23.0 + 0.04 * (double)std::max<int64_t>(0, tiles128 - 128)) * kscale
+  const double mid_us = tiles128 <= device_cu_count() ? (23.0 + 0.08 * (double)std::max<int64_t>(0, tiles128 - 128)) * kscale
                                                       : (double)rounds128 * (31.0 + 0.02 * (double)tiles128 / (double)rounds128) * kscale;
   ScaledKernel pick = kKernelTiled;
   double best = tiled_us;
@@ -155,7 +158,7 @@ ScaledKernel choose_scaled_kernel(const ScaledGemmArgs& p) {
     pick = kKernelMid;
   }
   if (scaled_gemm_skinny_supported(p)) {
-    const double c = p.m <= 8 ? 2.1 : p.m <= 16 ? 2.2 : p.m <= 32 ? 2.5 : p.m <= 48 ? 2.7 : p.m <= 64 ? 3.0 : p.m <= 96 ? 4.5
+    const double c = p.m <= 8 ? 2.0 : p.m <= 16 ? 2.1 : p.m <= 32 ? 2.5 : p.m <= 48 ? 2.7 : p.m <= 64 ? 3.0 : p.m <= 96 ? 4.5
                      : p.m <= 128 ? 5.15 : p.m <= 192 ? 9.3 : 10.2;  // steps at the 32- / 64- / 128-row forms and at the second row block
     const double skinny_us = 5.3 + c * 1e-7 * (double)p.n * (double)p.k;
     if (skinny_us < best) pick = kKernelSkinny;
@@ -324,13 +327,15 @@ int check_mixed(const MixedGemmArgs& p) {
 
 // 64 < M <= 256: two to four row blocks of the decode kernel (each streams the weights; the later ones mostly from L2) against ONE
 // row of tiles of the LDS-tiled kernel, which for so few rows is bound by what a CU can pull per K step, not by N.  Fitted on
-// weights streamed from HBM (profiles/r02/dispatch_cold_sweep_after.txt), us: decode 5 + 0.475e-6 N K per row block; tiles
-// 15.5 K/1024 per round.  (96-128 x 4096 x 4096: 21 against 62 us; 128 x 11008 x 4096: 50 against 162 us.)
+// weights streamed from HBM (profiles/r02/dispatch_cold_sweep_after.txt; refitted in round 3 after the decode kernel's prologue
+// was rewritten -- 0.475e-6 -> 0.41e-6, tiles 15.5 -> 16.5: 256 x 8192 x 8192 and 192 x 4096 x 11008 had stayed on the tiles at
+// 127 / 69 us where the decode kernel now takes 112 / 63), us: decode 5 + 0.41e-6 N K per row block; tiles 16.5 K/1024 per round.
+// (96-128 x 4096 x 4096: 18 against 66 us; 128 x 11008 x 4096: 46 against 172 us.)
 bool mixed_decode_beats_tiles(const MixedGemmArgs& p) {
   const double blocks = (double)((p.m + 63) / 64);
-  const double decode_us = 5.0 + 0.475e-6 * (double)p.n * (double)p.k * blocks * (p.bits == 8 ? 1.6 : 1.0);
+  const double decode_us = 5.0 + 0.41e-6 * (double)p.n * (double)p.k * blocks * (p.bits == 8 ? 1.85 : 1.0);
   const int64_t tiles = (p.n + 127) / 128;  // the narrowest tile: the most workgroups a single row of tiles can have
-  const double tile_us = 15.5 * (double)p.k / 1024.0 * (double)((tiles + 255) / 256);
+  const double tile_us = 16.5 * (double)p.k / 1024.0 * (double)((tiles + 255) / 256);
   return decode_us < tile_us;
 }
 
