@@ -131,7 +131,8 @@ __global__ __launch_bounds__(kMsThreads) void mixed_skinny_kernel(MixedGemmArgs 
     // (one scale load per step although a group spans two or more: fetching the slice's group rows in two loads and handing
     // them out with a ds_bpermute per step behind the barrier took 1 us off the ISSUE of the loads and made the launch 3-8 %
     // SLOWER -- the gather sits on the critical path, the loads it saves were issued under the latency of earlier ones:
-    // profiles/r03/ms_scale_ab.txt)
+    // profiles/r03/ms_scale_ab.txt; and skipping the load of a step that shares its group with the step before it, by a
+    // workgroup-uniform branch, is 30-80 % SLOWER: hipcc drains the loads in flight at every branch of the issue loop)
     sc[s] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs, (n * 2) | CONCH_KILL(s), s_off, 0);
     if constexpr (ZP == CONCH_ZP_TENSOR) zp[s] = (int)__builtin_amdgcn_raw_buffer_load_b32(rz, (n * 4) | CONCH_KILL(s), z_off, 0);
     else zp[s] = 0;
