@@ -399,15 +399,35 @@ def _flush_c_stdio() -> None:
         pass
 
 
+_REAL_STDOUT: int | None = None
+
+
+def claim_stdout() -> None:
+    """From here on whatever any library writes to stdout (RCCL's banner, gloo's "Expected number of connected peer ranks",
+    torch warnings that pick stdout) lands on stderr: file descriptor 1 is pointed at stderr and the JSON line alone is written to
+    the descriptor that WAS stdout -- the driver parses one line, whatever the libraries feel like printing."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _flush_c_stdio()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
 def emit(result: dict, world: int, rank: int) -> None:
-    """The ONE JSON line, as the last thing any rank writes to stdout: every rank flushes what the libraries buffered, the ranks
+    """The ONE JSON line, as the only thing any rank writes to stdout: every rank flushes what the libraries buffered, the ranks
     meet, rank 0 prints, then the group is torn down."""
     sys.stdout.flush()
     _flush_c_stdio()
     if world > 1:
         torch.distributed.barrier()
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        line = (json.dumps(result) + "\n").encode()
+        if _REAL_STDOUT is not None:
+            os.write(_REAL_STDOUT, line)
+        else:
+            sys.stdout.buffer.write(line)
+            sys.stdout.flush()
     if world > 1:
         torch.distributed.destroy_process_group()
         _flush_c_stdio()
@@ -431,6 +451,7 @@ def main() -> None:
     ap.add_argument("--all-ranks-on-device0", action="store_true",
                     help="dry-run aid: put every rank on cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
+    claim_stdout()
 
     rank, local_rank, world = dist_env()
     if args.gpus > 1 and world == 1:
