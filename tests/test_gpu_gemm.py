@@ -1554,3 +1554,18 @@ def test_whole_line_epilogue_into_a_strided_column_block(_reset_tuning, col_off,
     torch.cuda.synchronize()
     np.testing.assert_array_equal(to_bits(buf[:, col_off:col_off + n].contiguous()), to_bits(want))
     assert bool((buf[:, :col_off] == -7.0).all()) and bool((buf[:, col_off + n:] == -7.0).all())
+
+
+def test_randomised_dispatch_cross_check():
+    """tools/fuzz_dispatch.py as a test: 600 random (op, dtype, M, K, N, scale shape, bias / zero point) draws through the AUTOMATIC
+    kernel choice -- every dispatcher branch: split-K 32 / 64 / 128 rows in all launch forms, 128 x 128 and 256 x 256 tiles, repack,
+    decode-batch and tiled mixed kernels -- against the generic device kernel (int8 bit for bit, fp8 and mixed within 2 eps of
+    max|C|).  A child process: the tool owns the tuning state it flips."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "tools" / "fuzz_dispatch.py"), "600", "3"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "600 cases, 0 mismatches" in r.stdout
