@@ -532,7 +532,7 @@ __global__ __launch_bounds__(kBgThreads) void bnb_decode_gemm_kernel(BnbGemmArgs
 template <int X_DT, int ADT, int QT>
 void launch_decode_rows(const BnbGemmArgs& p, int rows, dim3 grid, float* ws, hipStream_t stream) {
   const dim3 block(kBgThreads);
-  const bool wlds = tuning(CONCH_TUNE_SKINNY_GATHER) != 1;
+  const bool wlds = tuning(CONCH_TUNE_SKINNY_GATHER) != 1 && (((uintptr_t)p.w) & 15) == 0;  // 16-byte LDS-DMA pieces (K % 32 == 0 holds)
   if (rows == 16) {
     if (wlds) hipLaunchKernelGGL((bnb_decode_gemm_kernel<X_DT, ADT, QT, 16, true>), grid, block, 0, stream, p, ws);
     else hipLaunchKernelGGL((bnb_decode_gemm_kernel<X_DT, ADT, QT, 16, false>), grid, block, 0, stream, p, ws);
