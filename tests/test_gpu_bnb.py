@@ -226,6 +226,28 @@ def test_matmul_4bit_decode_fetch_orders_are_bit_identical(qt, dname, absmax_dt,
         _C.set_tuning(_C.TUNE_SKINNY_GATHER, 0)
 
 
+@pytest.mark.parametrize("offset", [1, 4, 8, 16])
+def test_matmul_4bit_takes_a_weight_at_any_byte_offset(offset):
+    """The packed weight as a slice of a larger byte tensor (storage offsets of 1, 4, 8, 16 bytes: the LDS-DMA path wants 16-byte
+    pieces, the register path dwords): the same product as from an aligned copy, bit for bit, at decode and at tile sizes."""
+    from conch_amd import _C
+
+    seed_everything(8)
+    n, k = 260, 2048
+    w = torch.randn(n, k, dtype=torch.float16)
+    wq, am = oracle.quantize_blockwise_ref(w, 64, "nf4", None, absmax_dtype=torch.float32)
+    flat = wq.reshape(-1).cuda()
+    buf = torch.zeros(flat.numel() + 64, dtype=torch.uint8, device="cuda")
+    buf[offset:offset + flat.numel()] = flat
+    shifted = buf[offset:offset + flat.numel()].reshape(wq.shape)
+    assert shifted.data_ptr() % 16 == offset % 16
+    state = QuantState(absmax=am.cuda(), shape=w.shape, blocksize=64, quant_type="nf4", dtype=torch.float16)
+    for m in (16, 48, 300):
+        x = (torch.rand(m, k) - 0.5).to(torch.float16).cuda()
+        want = matmul_4bit(x, flat.reshape(wq.shape), state)
+        assert torch.equal(matmul_4bit(x, shifted, state), want), f"M={m}"
+
+
 def test_matmul_4bit_decode_dequant_is_bit_exact():
     """Unit-vector activations isolate the in-register dequantisation: row i of the product is column j_i of the dequantised
     weight, bit for bit (nf4 and fp4, fp16 and bf16, fp32 and fp16 absmax)."""
