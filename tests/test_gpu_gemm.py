@@ -1556,6 +1556,24 @@ def test_whole_line_epilogue_into_a_strided_column_block(_reset_tuning, col_off,
     assert bool((buf[:, :col_off] == -7.0).all()) and bool((buf[:, col_off + n:] == -7.0).all())
 
 
+@pytest.mark.parametrize("m", [16, 48, 300])
+def test_mixed_gemm_takes_packed_weights_that_are_a_column_slice(_reset_tuning, m):
+    """`w_q_packed` as columns [1, 1 + N) of a wider int32 tensor (row stride N + 9 words, base pointer 4 bytes off a 16-byte
+    boundary): the decode kernel's 16-byte LDS-DMA pieces do not apply, its dword loads and the tiled kernel do -- the same result
+    as from a contiguous copy, bit for bit."""
+    wt = scalar_types.uint4b8
+    k, n = 2048, 520
+    a, w_ref, packed, w_s, _ = make_mixed_inputs(m, k, n, wt, False, torch.float16)
+    wide = torch.zeros((packed.shape[0], n + 9), dtype=torch.int32, device="cuda")
+    wide[:, 1:1 + n] = packed.cuda()
+    view = wide[:, 1:1 + n]
+    assert view.stride(0) == n + 9 and view.data_ptr() % 16 == 4
+    want = mixed_precision_gemm(a.cuda(), packed.cuda(), w_s.cuda(), None, wt.size_bits, wt.bias, 128)
+    got = mixed_precision_gemm(a.cuda(), view, w_s.cuda(), None, wt.size_bits, wt.bias, 128)
+    assert torch.equal(got, want)
+    check_mixed(want, a, w_ref, k)
+
+
 def test_randomised_dispatch_cross_check():
     """tools/fuzz_dispatch.py as a test: 600 random (op, dtype, M, K, N, scale shape, bias / zero point) draws through the AUTOMATIC
     kernel choice -- every dispatcher branch: split-K 32 / 64 / 128 rows in all launch forms, 128 x 128 and 256 x 256 tiles, repack,
