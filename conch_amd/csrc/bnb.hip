@@ -345,9 +345,11 @@ constexpr int kBgSliceK = kBgSteps * kBgStepK;
 template <int X_DT, int ADT, int QT, int ROWS, bool WLDS>
 __global__ __launch_bounds__(kBgThreads) void bnb_decode_gemm_kernel(BnbGemmArgs p, float* __restrict__ slabs) {
   using namespace tile;
-  static_assert(!WLDS || ROWS <= 32, "the code staging does not fit beside 64 rows of X");
   constexpr int kUnit = ROWS * 128;  // one K step of X
-  constexpr int kWBytes = WLDS ? 4 * (kBgSteps / 2) * 1024 : 0;  // per wave: one KiB per pair of steps
+  // pairs of steps whose codes are staged through LDS: all eight beside 16 / 32 rows of X; beside 64 rows (128 KiB) seven -- 28 KiB
+  // + the 2 KiB table = 158 of the 160 KiB -- and the last pair takes the register path
+  constexpr int kDmaPairs = !WLDS ? 0 : ROWS <= 32 ? kBgSteps / 2 : kBgSteps / 2 - 1;
+  constexpr int kWBytes = 4 * kDmaPairs * 1024;  // per wave: one KiB per pair of steps
   __shared__ __attribute__((aligned(1024))) char lds[kBgSteps * kUnit + 2048 + kWBytes];
   // byte -> its two numbers (code byte >> 4 first): ONE 8-byte LDS read per packed byte instead of two 4-byte reads and twice the
   // address arithmetic (the loop is bound by vector instructions, not by the LDS)
@@ -377,17 +379,18 @@ __global__ __launch_bounds__(kBgThreads) void bnb_decode_gemm_kernel(BnbGemmArgs
       __builtin_amdgcn_make_buffer_rsrc((void*)p.absmax, 0, (uint32_t)(((uint64_t)w_bytes * 2) >> bs_shift) * kAbsBytes, 0x00020000);
   char* wl = lds + kBgSteps * kUnit + 2048 + wave * (kWBytes / 4);  // this wave's code staging (WLDS)
   uint32_t wq[kBgSteps][2];  // register path only (a dependent bound makes hipcc's host pass drop the kernel's stub)
-  if constexpr (WLDS) {
+  if constexpr (kDmaPairs > 0) {
     const int rho = lane >> 2;
     const int chunk = ((lane & 3) - (rho >> 2)) & 3;
     const int vw = min(nw + rho, (int)p.n - 1) * (kk / 2) + 16 * chunk;
 #pragma unroll
-    for (int i = 0; i < kBgSteps / 2; ++i)
+    for (int i = 0; i < kDmaPairs; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_t*)(wl + i * 1024), 16, vw | CONCH_KILL(2 * i), k0 / 2 + i * 64, 0, 0);
-  } else {
+  }
+  if constexpr (2 * kDmaPairs < kBgSteps) {
     const int vw = n * (kk / 2) + 4 * g;  // byte offset of the lane's k-group inside a half step
 #pragma unroll
-    for (int s = 0; s < kBgSteps; ++s)
+    for (int s = 2 * kDmaPairs; s < kBgSteps; ++s)
 #pragma unroll
       for (int h = 0; h < 2; ++h)
         wq[s][h] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rw, vw | CONCH_KILL(s), (k0 + s * kBgStepK + 32 * h) / 2, 0);
@@ -492,7 +495,7 @@ __global__ __launch_bounds__(kBgThreads) void bnb_decode_gemm_kernel(BnbGemmArgs
 #pragma unroll
   for (int s = 0; s < kBgSteps; ++s) {
     uint32_t w0, w1;
-    if constexpr (WLDS) {
+    if ((s >> 1) < kDmaPairs) {  // (a constant in every unrolled copy)
       w0 = *(const uint32_t*)(wl + (s >> 1) * 1024 + w_read[2 * (s & 1)]);
       w1 = *(const uint32_t*)(wl + (s >> 1) * 1024 + w_read[2 * (s & 1) + 1]);
     } else {
@@ -540,7 +543,8 @@ void launch_decode_rows(const BnbGemmArgs& p, int rows, dim3 grid, float* ws, hi
     if (wlds) hipLaunchKernelGGL((bnb_decode_gemm_kernel<X_DT, ADT, QT, 32, true>), grid, block, 0, stream, p, ws);
     else hipLaunchKernelGGL((bnb_decode_gemm_kernel<X_DT, ADT, QT, 32, false>), grid, block, 0, stream, p, ws);
   } else {
-    hipLaunchKernelGGL((bnb_decode_gemm_kernel<X_DT, ADT, QT, 64, false>), grid, block, 0, stream, p, ws);
+    if (wlds) hipLaunchKernelGGL((bnb_decode_gemm_kernel<X_DT, ADT, QT, 64, true>), grid, block, 0, stream, p, ws);
+    else hipLaunchKernelGGL((bnb_decode_gemm_kernel<X_DT, ADT, QT, 64, false>), grid, block, 0, stream, p, ws);
   }
 }
 
@@ -565,7 +569,7 @@ bool bnb_decode_supported(int64_t m, int64_t n, int64_t k, int blocksize, bool f
   if (m > 256 || n % 4 || k % blocksize || n * k / 2 >= ((int64_t)1 << 31)) return false;
   if (m <= 64 || forced) return true;
   const double nk = (double)n * (double)k;
-  return (double)((m + 63) / 64) * (5.0 + 0.68e-6 * nk) < 15.0 * (double)k / 1024.0 + 0.7e-6 * nk;  // round 3: 0.85 -> 0.68 (64 x 4096 x 11008 42.3 -> 34.8 us)
+  return (double)((m + 63) / 64) * (5.0 + 0.56e-6 * nk) < 15.0 * (double)k / 1024.0 + 0.7e-6 * nk;  // round 3: 0.85 -> 0.56 (64 x 4096 x 11008 42.3 -> 29.2 us)
 }
 
 int launch_bnb_decode_gemm(const BnbGemmArgs& p, int qt, int adt, int x_dtype, int out_dtype, hipStream_t stream) {

@@ -200,10 +200,11 @@ def test_matmul_4bit_decode_kernel(qt, dname, absmax_dt, m, k, n, blocksize):
 @pytest.mark.parametrize("qt", ["nf4", "fp4"])
 @pytest.mark.parametrize(("dname", "absmax_dt"), [("f16", torch.float32), ("bf16", torch.bfloat16)])
 @pytest.mark.parametrize(("m", "k", "n", "blocksize"), [(1, 1024, 64, 64), (16, 2048, 520, 128), (20, 4096, 1376, 64), (32, 1152, 260, 128),
-                                                         (8, 11008, 512, 64), (3, 192, 68, 64), (24, 2048, 256, 2048)])
+                                                         (8, 11008, 512, 64), (3, 192, 68, 64), (24, 2048, 256, 2048),
+                                                         (64, 2048, 520, 64), (48, 1920, 132, 64), (130, 4096, 256, 128)])
 def test_matmul_4bit_decode_fetch_orders_are_bit_identical(qt, dname, absmax_dt, m, k, n, blocksize):
-    """Up to 32 rows the packed codes reach the MFMA operands through LDS-DMA (four lanes per 64-byte row piece, read back per
-    lane) and the absmax of 64-element blocks through four wide loads and a cross-lane gather; CONCH_TUNE_SKINNY_GATHER = 1 is
+    """The packed codes reach the MFMA operands through LDS-DMA (four lanes per 64-byte row piece, read back per lane; the
+    64-row form stages seven of its eight pairs of steps that way and the last through registers) and the absmax of 64-element blocks through four wide loads and a cross-lane gather; CONCH_TUNE_SKINNY_GATHER = 1 is
     the register path in MFMA operand order.  Same bytes in the same operand registers: bit-identical, ragged K / N included."""
     from conch_amd import _C
 
