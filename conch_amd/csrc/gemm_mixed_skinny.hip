@@ -371,10 +371,11 @@ void launch_rows(const MixedGemmArgs& p, int rows, dim3 grid, float* ws, unsigne
   if constexpr (BITS == 4) {
     // measured (profiles/r03/int4_decode_wlds.txt): 3-5 % ahead while the launch is at most one workgroup per CU (16 x 4096 x 4096
     // 7.0 -> 6.7 us); with several workgroups per CU the 32 KiB of staging cost residency -- 16 x 4096 x 11008 9.1 -> 10.4 us,
-    // 32 x 4096 x 11008 12.6 -> 16.7 us -- so only then (2 = always)
+    // 32 x 4096 x 11008 12.6 -> 16.7 us -- so only then, and for the 64-row form, whose 128 KiB of X hold a CU to one workgroup
+    // anyway (1-3.5 % ahead on nine shapes: profiles/r03/int4_decode_wlds.txt); 2 = always
     const int mode = tuning(CONCH_TUNE_SKINNY_GATHER);
     const bool one_round = (size_t)grid.x * grid.y * grid.z <= (size_t)device_cu_count();
-    if ((((uintptr_t)p.w_q) & 15) == 0 && p.wq_stride_k % 4 == 0 && (mode == 2 || (mode == 0 && one_round)))
+    if ((((uintptr_t)p.w_q) & 15) == 0 && p.wq_stride_k % 4 == 0 && (mode == 2 || (mode == 0 && (one_round || rows == 64))))
       return launch_rows_wl<X_DT, BITS, ZP, true>(p, rows, grid, ws, counters, stream);
   }
   launch_rows_wl<X_DT, BITS, ZP, false>(p, rows, grid, ws, counters, stream);
