@@ -474,6 +474,19 @@ __global__ __launch_bounds__(256) void skinny_reduce_kernel(ScaledGemmArgs p, co
   const int m = blockIdx.y, n = q * 4;
   // four slices of loads in flight at a time (a plain `for s` loop is one dependent L2 round trip per slice), added in
   // slice order: exact for int32, deterministic for fp32
+#ifndef CONCH_EXP_REDUCE_LATE_SCALES
+  // the scales and the bias are requested ahead of the slabs (as in the one-launch form): no dependent load behind the sum
+  const float sa = p.scale_a[p.scale_a_numel != 1 ? m : 0];
+  float sb4[4];
+  uint32_t bias4[4];
+  const uint16_t* bias_src = p.bias ? (const uint16_t*)p.bias + n : (const uint16_t*)p.b;  // unconditional loads (see skinny_splitk_kernel)
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    sb4[e] = p.scale_b[p.scale_b_numel != 1 ? n + e : 0];
+    bias4[e] = bias_src[e];
+  }
+  asm volatile("" ::: "memory");
+#endif
   typename AccT<MMA>::type sum;
   for (int sb = 0; sb < slices; sb += 4) {
     i32x4 part[4];
@@ -485,28 +498,12 @@ __global__ __launch_bounds__(256) void skinny_reduce_kernel(ScaledGemmArgs p, co
       sum = (sb + j == 0) ? v : (sb + j < slices) ? sum + v : sum;
     }
   }
-  const float sa = p.scale_a[p.scale_a_numel != 1 ? m : 0];
-  uint16_t o[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const float sb = p.scale_b[p.scale_b_numel != 1 ? n + e : 0];
-    float v = sa * (float)sum[e];   // scaled_gemm.py:21
-    v = pin_f32(sb * v);            // :22
-    uint16_t h = float_to_bits16<OUT_DT>(v);  // :23
-    if (p.bias)                     // :24-25
-      h = float_to_bits16<OUT_DT>(pin_f32(bits16_to_float<OUT_DT>(h) + bits16_to_float<OUT_DT>(((const uint16_t*)p.bias)[n + e])));
-    o[e] = h;
-  }
-  uint16_t* dst = (uint16_t*)p.c + (int64_t)m * p.c_stride_m + n;
-  if ((((uintptr_t)dst) & 7) == 0) {
-    i32x2 pk;
-    pk[0] = (int)((uint32_t)o[0] | ((uint32_t)o[1] << 16));
-    pk[1] = (int)((uint32_t)o[2] | ((uint32_t)o[3] << 16));
-    *(i32x2*)dst = pk;
-  } else {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) dst[e] = o[e];
-  }
+#ifndef CONCH_EXP_REDUCE_LATE_SCALES
+  const i32x2 pk = sp_epilogue4_vals<OUT_DT>(sum, sa, sb4, bias4, p.bias != nullptr);
+#else
+  const i32x2 pk = sp_epilogue4<OUT_DT>(p, sum, m, n);
+#endif
+  __builtin_memcpy((uint16_t*)p.c + (int64_t)m * p.c_stride_m + n, &pk, 8);  // one 8-byte store at whatever alignment C has
 }
 
 // The same with the gate/up FFN fusion (conch_scaled_gemm_silu_and_mul at decode batch sizes): the slabs hold the plain
