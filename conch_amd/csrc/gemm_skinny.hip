@@ -515,24 +515,40 @@ __global__ __launch_bounds__(256) void skinny_reduce_silu_kernel(ScaledGemmArgs 
   const int q = (int)blockIdx.x * 256 + (int)threadIdx.x;
   if (q >= (int)(d / 4)) return;
   const int m = blockIdx.y, j0 = q * 4;
+  // scales and bias of both halves ahead of the slabs; the slabs of a half four slices in flight at a time (the loop had been one
+  // dependent L2 round trip per slice and half), added in slice order
   const float sa = p.scale_a[p.scale_a_numel != 1 ? m : 0];
+  float sb4[2][4];
+  uint32_t bias4[2][4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int n = j0 + h * (int)d;
+    const uint16_t* bias_src = p.bias ? (const uint16_t*)p.bias + n : (const uint16_t*)p.b;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      sb4[h][e] = p.scale_b[p.scale_b_numel != 1 ? n + e : 0];
+      bias4[h][e] = bias_src[e];
+    }
+  }
+  asm volatile("" ::: "memory");
   uint16_t gu[2][4];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int n = j0 + h * (int)d;
-    typename AccT<MMA>::type sum = __builtin_bit_cast(typename AccT<MMA>::type, *(const i32x4*)(slabs + (int64_t)m * p.n + n));
-    for (int s = 1; s < slices; ++s)
-      sum += __builtin_bit_cast(typename AccT<MMA>::type, *(const i32x4*)(slabs + ((int64_t)s * p.m + m) * p.n + n));
+    typename AccT<MMA>::type sum;
+    for (int sb = 0; sb < slices; sb += 4) {
+      i32x4 part[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float sb = p.scale_b[p.scale_b_numel != 1 ? n + e : 0];
-      float v = sa * (float)sum[e];
-      v = pin_f32(sb * v);
-      uint16_t hb = float_to_bits16<OUT_DT>(v);
-      if (p.bias)
-        hb = float_to_bits16<OUT_DT>(pin_f32(bits16_to_float<OUT_DT>(hb) + bits16_to_float<OUT_DT>(((const uint16_t*)p.bias)[n + e])));
-      gu[h][e] = hb;
+      for (int j = 0; j < 4; ++j) part[j] = *(const i32x4*)(slabs + ((int64_t)min(sb + j, slices - 1) * p.m + m) * p.n + n);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const typename AccT<MMA>::type v = __builtin_bit_cast(typename AccT<MMA>::type, part[j]);
+        sum = (sb + j == 0) ? v : (sb + j < slices) ? sum + v : sum;
+      }
     }
+    const i32x2 pk = sp_epilogue4_vals<OUT_DT>(sum, sa, sb4[h], bias4[h], p.bias != nullptr);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) gu[h][e] = (uint16_t)((uint32_t)pk[e >> 1] >> (16 * (e & 1)));
   }
   uint16_t* dst = (uint16_t*)p.c + (int64_t)m * p.c_stride_m + j0;
 #pragma unroll
