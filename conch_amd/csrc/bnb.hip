@@ -342,7 +342,10 @@ constexpr int kBgSliceK = kBgSteps * kBgStepK;
 // row r: dword 16 (r & 3) + 4 ((c + (r >> 2)) & 3) + g of its 64-dword row group -- touches 64 different banks.
 // Blocks of 64 (bitsandbytes' default): the absmax of a row's 16 steps are 16 consecutive elements -- four loads of 16 rows x 4
 // elements and a ds_bpermute per step instead of 16 loads of one element from each of 16 lines.
-template <int X_DT, int ADT, int QT, int ROWS, bool WLDS>
+// B64 = blocks of 64 elements, a template parameter although the blocksize is a kernel argument: as a run-time branch in the issue
+// phase the two absmax forms shared their registers, and hipcc waited for the code loads in flight before it let the 64-form
+// write "its" copy of them (s_waitcnt vmcnt(4) ahead of the X slice's loads: a drain of the whole code stream per launch).
+template <int X_DT, int ADT, int QT, int ROWS, bool WLDS, bool B64>
 __global__ __launch_bounds__(kBgThreads) void bnb_decode_gemm_kernel(BnbGemmArgs p, float* __restrict__ slabs) {
   using namespace tile;
   constexpr int kUnit = ROWS * 128;  // one K step of X
@@ -353,11 +356,7 @@ __global__ __launch_bounds__(kBgThreads) void bnb_decode_gemm_kernel(BnbGemmArgs
   __shared__ __attribute__((aligned(1024))) char lds[kBgSteps * kUnit + 2048 + kWBytes];
   // byte -> its two numbers (code byte >> 4 first): ONE 8-byte LDS read per packed byte instead of two 4-byte reads and twice the
   // address arithmetic (the loop is bound by vector instructions, not by the LDS)
-  f32x2* lut = (f32x2*)(lds + kBgSteps * kUnit);
-  {
-    const float* t16 = QT == kQtNf4 ? kNf4Values : kFp4Values;
-    lut[threadIdx.x] = f32x2{t16[threadIdx.x >> 4], t16[threadIdx.x & 15]};
-  }
+  f32x2* lut = (f32x2*)(lds + kBgSteps * kUnit);  // (filled behind the slice's loads: its two table reads are loads too)
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int r = lane & 15, g = lane >> 4;
@@ -397,12 +396,8 @@ __global__ __launch_bounds__(kBgThreads) void bnb_decode_gemm_kernel(BnbGemmArgs
   }
   float am[kBgSteps];
   uint32_t am_raw[4] = {0, 0, 0, 0};
-#ifdef CONCH_EXP_BNB_ABSMAX_PER_STEP
-  const bool blocks_of_64 = false;
-#else
-  const bool blocks_of_64 = bs_shift == 6;  // workgroup-uniform
-#endif
-  if (blocks_of_64) {
+  constexpr bool blocks_of_64 = B64;
+  if constexpr (blocks_of_64) {
     // lane L: row L >> 2, blocks 4 j + (L & 3) of the slice
     const int va = min(nw + (lane >> 2), (int)p.n - 1) * (kk >> 6) * kAbsBytes + (lane & 3) * kAbsBytes;
 #pragma unroll
@@ -450,10 +445,16 @@ __global__ __launch_bounds__(kBgThreads) void bnb_decode_gemm_kernel(BnbGemmArgs
 #pragma unroll
   for (int i = 0; i < ROWS / 16; ++i) acc[i] = f32x4{0, 0, 0, 0};
 
+  {
+    // the table, AFTER the slice's loads are in flight: filled first, its two reads from the constant table put an s_waitcnt
+    // vmcnt(0) -- a memory round trip -- ahead of the first code load of every launch
+    const float* t16 = QT == kQtNf4 ? kNf4Values : kFp4Values;
+    lut[threadIdx.x] = f32x2{t16[threadIdx.x >> 4], t16[threadIdx.x & 15]};
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();  // the X pieces and the codes of every wave and the table have landed
 
-  if (blocks_of_64) {
+  if constexpr (blocks_of_64) {
     // step s = block s of the slice: element s & 3 of load s >> 2, held by lane 4 r + (s & 3)
 #pragma unroll
     for (int s = 0; s < kBgSteps; ++s) {
@@ -532,20 +533,28 @@ __global__ __launch_bounds__(kBgThreads) void bnb_decode_gemm_kernel(BnbGemmArgs
 
 // CONCH_TUNE_SKINNY_GATHER 1 (the same question as in gemm_skinny.hip: how a wave fetches its weight operand) = the register path
 // for the codes at every row count
-template <int X_DT, int ADT, int QT>
-void launch_decode_rows(const BnbGemmArgs& p, int rows, dim3 grid, float* ws, hipStream_t stream) {
+template <int X_DT, int ADT, int QT, bool B64>
+void launch_decode_rows_b(const BnbGemmArgs& p, int rows, dim3 grid, float* ws, hipStream_t stream) {
   const dim3 block(kBgThreads);
   const bool wlds = tuning(CONCH_TUNE_SKINNY_GATHER) != 1 && (((uintptr_t)p.w) & 15) == 0;  // 16-byte LDS-DMA pieces (K % 32 == 0 holds)
   if (rows == 16) {
-    if (wlds) hipLaunchKernelGGL((bnb_decode_gemm_kernel<X_DT, ADT, QT, 16, true>), grid, block, 0, stream, p, ws);
-    else hipLaunchKernelGGL((bnb_decode_gemm_kernel<X_DT, ADT, QT, 16, false>), grid, block, 0, stream, p, ws);
+    if (wlds) hipLaunchKernelGGL((bnb_decode_gemm_kernel<X_DT, ADT, QT, 16, true, B64>), grid, block, 0, stream, p, ws);
+    else hipLaunchKernelGGL((bnb_decode_gemm_kernel<X_DT, ADT, QT, 16, false, B64>), grid, block, 0, stream, p, ws);
   } else if (rows == 32) {
-    if (wlds) hipLaunchKernelGGL((bnb_decode_gemm_kernel<X_DT, ADT, QT, 32, true>), grid, block, 0, stream, p, ws);
-    else hipLaunchKernelGGL((bnb_decode_gemm_kernel<X_DT, ADT, QT, 32, false>), grid, block, 0, stream, p, ws);
+    if (wlds) hipLaunchKernelGGL((bnb_decode_gemm_kernel<X_DT, ADT, QT, 32, true, B64>), grid, block, 0, stream, p, ws);
+    else hipLaunchKernelGGL((bnb_decode_gemm_kernel<X_DT, ADT, QT, 32, false, B64>), grid, block, 0, stream, p, ws);
   } else {
-    if (wlds) hipLaunchKernelGGL((bnb_decode_gemm_kernel<X_DT, ADT, QT, 64, true>), grid, block, 0, stream, p, ws);
-    else hipLaunchKernelGGL((bnb_decode_gemm_kernel<X_DT, ADT, QT, 64, false>), grid, block, 0, stream, p, ws);
+    if (wlds) hipLaunchKernelGGL((bnb_decode_gemm_kernel<X_DT, ADT, QT, 64, true, B64>), grid, block, 0, stream, p, ws);
+    else hipLaunchKernelGGL((bnb_decode_gemm_kernel<X_DT, ADT, QT, 64, false, B64>), grid, block, 0, stream, p, ws);
   }
+}
+
+// CONCH_TUNE_SKINNY_GATHER 1 (the same question as in gemm_skinny.hip: how a wave fetches its weight operand) = the register path
+// for the codes at every row count
+template <int X_DT, int ADT, int QT>
+void launch_decode_rows(const BnbGemmArgs& p, int rows, dim3 grid, float* ws, hipStream_t stream) {
+  if (p.blocksize == 64) launch_decode_rows_b<X_DT, ADT, QT, true>(p, rows, grid, ws, stream);
+  else launch_decode_rows_b<X_DT, ADT, QT, false>(p, rows, grid, ws, stream);
 }
 
 template <int X_DT, int ADT>
