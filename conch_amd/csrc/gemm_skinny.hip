@@ -345,30 +345,45 @@ __global__ __launch_bounds__(kSkThreads, 1) void skinny_splitk_kernel(ScaledGemm
     constexpr int kKind = MMA == kMmaInt8 ? quant::kInt8 : quant::kFp8Fn;
     const float inv = 1.0f / p.scale_a[0];
     constexpr int kItems = STEPS * ROWS * 8;  // (step, unit row, 16-byte position)
-#pragma unroll 4
-    for (int it = threadIdx.x; it < kItems; it += kSkThreads) {
-      const int s = it / (ROWS * 8), rem = it - s * (ROWS * 8);
-      const int rho = rem >> 3, pos = rem & 7;
-      const int chunk = pos ^ ((rho >> 1) & 7);
-      const int kill = s < valid_steps ? 0 : (int)0x80000000;
-      const int voff = (min(m0 + rho, (int)p.m - 1) * (int)p.a_stride_m + chunk * 16) * 2;
-      // the step's byte offset depends on the thread (s = it / ...): it belongs in the VGPR offset.  As an soffset hipcc wrapped
-      // both loads in a waterfall loop over its distinct values (up to eight trips per load; round 3, tools/isa_waterfalls.py)
-      const int koff = voff + (k_begin + s * kStepBytes) * 2;
-      const i32x4 lo = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, koff | kill, 0, 0));
-      const i32x4 hi = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, (koff + 16) | kill, 0, 0));
-      float f[16];
+    constexpr int kPer = kItems / kSkThreads;  // items per thread: ROWS / 4 at eight steps
+    constexpr int kBatch = 8;                  // items whose loads are in flight together (64 VGPRs)
+    static_assert(kItems % kSkThreads == 0 && kPer % kBatch == 0, "whole batches of items per thread");
+    // a batch's sixteen loads are requested before its first item is converted (the loop had been one memory round trip per
+    // item: load, wait, convert, store -- tools/isa_issue_waits.py)
+#pragma unroll 1
+    for (int b0 = 0; b0 < kPer; b0 += kBatch) {
+      i32x4 lo[kBatch], hi[kBatch];
+      int dst[kBatch];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        f[2 * j] = bits16_to_float<A_SRC>((uint16_t)((uint32_t)lo[j] & 0xffffu));
-        f[2 * j + 1] = bits16_to_float<A_SRC>((uint16_t)((uint32_t)lo[j] >> 16));
-        f[8 + 2 * j] = bits16_to_float<A_SRC>((uint16_t)((uint32_t)hi[j] & 0xffffu));
-        f[8 + 2 * j + 1] = bits16_to_float<A_SRC>((uint16_t)((uint32_t)hi[j] >> 16));
+      for (int j = 0; j < kBatch; ++j) {
+        const int it = (int)threadIdx.x + (b0 + j) * kSkThreads;
+        const int s = it / (ROWS * 8), rem = it - s * (ROWS * 8);
+        const int rho = rem >> 3, pos = rem & 7;
+        const int chunk = pos ^ ((rho >> 1) & 7);
+        const int kill = s < valid_steps ? 0 : (int)0x80000000;
+        const int voff = (min(m0 + rho, (int)p.m - 1) * (int)p.a_stride_m + chunk * 16) * 2;
+        // the step's byte offset depends on the thread (s = it / ...): it belongs in the VGPR offset.  As an soffset hipcc wrapped
+        // both loads in a waterfall loop over its distinct values (up to eight trips per load; round 3, tools/isa_waterfalls.py)
+        const int koff = voff + (k_begin + s * kStepBytes) * 2;
+        lo[j] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, koff | kill, 0, 0));
+        hi[j] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, (koff + 16) | kill, 0, 0));
+        dst[j] = s * kUnit + rho * kStepBytes + pos * 16;
       }
-      i32x4 q;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) q[j] = (int)quant::quant_four<kKind>(f[4 * j], f[4 * j + 1], f[4 * j + 2], f[4 * j + 3], inv);
-      *(i32x4*)(lds + s * kUnit + rho * kStepBytes + pos * 16) = q;
+      for (int j = 0; j < kBatch; ++j) {
+        float f[16];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          f[2 * e] = bits16_to_float<A_SRC>((uint16_t)((uint32_t)lo[j][e] & 0xffffu));
+          f[2 * e + 1] = bits16_to_float<A_SRC>((uint16_t)((uint32_t)lo[j][e] >> 16));
+          f[8 + 2 * e] = bits16_to_float<A_SRC>((uint16_t)((uint32_t)hi[j][e] & 0xffffu));
+          f[8 + 2 * e + 1] = bits16_to_float<A_SRC>((uint16_t)((uint32_t)hi[j][e] >> 16));
+        }
+        i32x4 q;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q[e] = (int)quant::quant_four<kKind>(f[4 * e], f[4 * e + 1], f[4 * e + 2], f[4 * e + 3], inv);
+        *(i32x4*)(lds + dst[j]) = q;
+      }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // B^T fragments and this thread's ds_writes are complete
   }
