@@ -67,23 +67,27 @@ __global__ __launch_bounds__(kMidThreads, 2) void scaled_gemm_mid_kernel(ScaledG
     }
   };
 
-  // epilogue constants: threads 0-127 fetch scale_a[row], 128-255 scale_b[col] and the bias
+  // epilogue constants: threads 0-127 fetch scale_a[row], 128-255 scale_b[col] and the bias -- requested ahead of the operands,
+  // kept in registers through the K loop and put into LDS behind it.  (Round 3, tools/isa_issue_waits.py: stored to LDS right
+  // after the first stages were requested, the ds_write made hipcc wait for ALL the LDS-DMA in flight -- the ring's three steps
+  // instead of its first -- and a bias loaded under `if (p.bias)` was waited for, a memory round trip, before the first operand
+  // load was requested.)
+  const bool epi_is_b = threadIdx.x >= 128;
+  float epi_v0;
+  uint32_t epi_bits;
   {
-    const int t = threadIdx.x, tt = t & 127;
-    const bool is_b = t >= 128;
-    const int idx = is_b ? min(bn0 + tt, (int)p.n - 1) : min(bm0 + tt, (int)p.m - 1);
-    const float* base = is_b ? p.scale_b : p.scale_a;
-    const bool vec = (is_b ? p.scale_b_numel : p.scale_a_numel) != 1;
-    const float v0 = base[vec ? idx : 0];
-    uint32_t bits = 0;
-    if (p.bias) bits = ((const uint16_t*)p.bias)[min(bn0 + tt, (int)p.n - 1)];
+    const int tt = threadIdx.x & 127;
+    const int idx = epi_is_b ? min(bn0 + tt, (int)p.n - 1) : min(bm0 + tt, (int)p.m - 1);
+    const float* base = epi_is_b ? p.scale_b : p.scale_a;
+    const bool vec = (epi_is_b ? p.scale_b_numel : p.scale_a_numel) != 1;
+    epi_v0 = base[vec ? idx : 0];
+    // unconditional (without a bias: two readable bytes of A, never used)
+    const uint16_t* bias_src = p.bias ? (const uint16_t*)p.bias + min(bn0 + tt, (int)p.n - 1) : (const uint16_t*)p.a;
+    epi_bits = *bias_src;
     const int steps0 = (int)(p.k / kStepBytes);
 #pragma unroll
     for (int s0 = 0; s0 < STAGES - 1; ++s0)
       if (s0 < steps0) stage(s0);
-    float* f = (float*)(lds + kMidEpi);
-    f[t] = v0;
-    if (is_b) f[t + 128] = bits16_to_float<OUT_DT>((uint16_t)bits);
   }
 
   const int r = lane & 15, g = lane >> 4;
@@ -138,8 +142,13 @@ __global__ __launch_bounds__(kMidThreads, 2) void scaled_gemm_mid_kernel(ScaledG
   // epilogue: sb * (sa * acc), RNE cast, bias in the output dtype (reference/quantization/scaled_gemm.py:21-25).
   // Whole tiles: row-major through 2 KiB of LDS per wave, whole-line write-through stores (epilogue_rows.hpp; a wave's 64
   // columns are one 128-byte line per row); CONCH_TUNE_EPILOGUE = 1 and ragged tiles store from the accumulator layout.
+  {
+    float* f = (float*)(lds + kMidEpi);
+    f[threadIdx.x] = epi_v0;
+    if (epi_is_b) f[threadIdx.x + 128] = bits16_to_float<OUT_DT>((uint16_t)epi_bits);
+  }
+  __syncthreads();  // the constants are in LDS; every wave is past its last operand read; nothing is in flight (the last steps drained)
   if (p.rows_epilogue && tile_stores_whole_lines(p, bm0, bn0, kMidTile, kMidTile)) {  // workgroup-uniform
-    __syncthreads();  // every wave is past its last operand read; nothing is in flight (the last steps drained)
     if (p.bias) epilogue_rows_body<MMA, OUT_DT, true, 4, kMidTile>(acc, p, lds, 0, bm0, bn0, wr, wc, lane, wave, kMidEpi);
     else epilogue_rows_body<MMA, OUT_DT, false, 4, kMidTile>(acc, p, lds, 0, bm0, bn0, wr, wc, lane, wave, kMidEpi);
     return;
