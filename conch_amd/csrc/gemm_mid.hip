@@ -24,7 +24,9 @@ constexpr int kMidBuf = 2 * kUnitBytes;                 // U (128 rows of A) + V
 // flight each.  STAGES = 4 (128 KiB + 1.5 KiB): ONE workgroup per CU with three K steps (96 KiB) in flight, for problems of at
 // most one tile per CU -- there a CU holds a single 2-stage workgroup anyway, its one step in flight is issued after the barrier
 // and waited for before the next (32 KiB per memory latency: 1 MiB of operands in 31 us at K = 4096 on weights streamed from HBM,
-// whatever N and M are; profiles/r02/dispatch_cold_sweep_before.txt).
+// whatever N and M are; profiles/r02/dispatch_cold_sweep_before.txt).  (A FIVE-stage ring -- all 160 KiB as operand buffers, the
+// epilogue constants in the dead ones behind the loop -- measured 2-8 % slower than four stages on nine shapes, warm and on
+// weights streamed from HBM: profiles/r03/mid_stages_ab.txt; the kernel is not short of bytes in flight.)
 
 struct MidOffsets {
   int u[4], v[4];  // byte offset of this lane's 16-byte source chunk for the wave's four pieces of a unit
