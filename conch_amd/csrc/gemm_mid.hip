@@ -26,7 +26,8 @@ constexpr int kMidBuf = 2 * kUnitBytes;                 // U (128 rows of A) + V
 // and waited for before the next (32 KiB per memory latency: 1 MiB of operands in 31 us at K = 4096 on weights streamed from HBM,
 // whatever N and M are; profiles/r02/dispatch_cold_sweep_before.txt).  (A FIVE-stage ring -- all 160 KiB as operand buffers, the
 // epilogue constants in the dead ones behind the loop -- measured 2-8 % slower than four stages on nine shapes, warm and on
-// weights streamed from HBM: profiles/r03/mid_stages_ab.txt; the kernel is not short of bytes in flight.)
+// weights streamed from HBM; reading the fragments of step t + 1 under the MFMAs of step t -- which makes the wave wait for step
+// t + 1, one step less of lead -- 15-20 % slower: profiles/r03/mid_stages_ab.txt.)
 
 struct MidOffsets {
   int u[4], v[4];  // byte offset of this lane's 16-byte source chunk for the wave's four pieces of a unit
