@@ -115,13 +115,23 @@ __global__ __launch_bounds__(kMidThreads, 2) void scaled_gemm_mid_kernel(ScaledG
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();                                // ... and every wave is done with the buffer of step t - 1
-    if (t + STAGES - 1 < steps) stage(t + STAGES - 1);
+    // fp8: the step's LDS-DMA requests ahead of its fragment reads; int8 (twice the MFMA instructions per step): the reads first --
+    // measured (profiles/r03/mid_reads_first_ab.txt): int8 -6 % with the reads first, fp8 +1 %
+    constexpr bool kReadsFirst = MMA != kMmaFp8;
+    if constexpr (!kReadsFirst) {
+      if (t + STAGES - 1 < steps) stage(t + STAGES - 1);
+    }
     const int buf = (t % STAGES) * kMidBuf;
     Frag fn[4], fm[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) fn[q] = read_frag(lds, buf + n_base + q * 2048);
 #pragma unroll
     for (int i = 0; i < 4; ++i) fm[i] = read_frag(lds, buf + m_base + i * 2048);
+    if constexpr (kReadsFirst) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + STAGES - 1 < steps) stage(t + STAGES - 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     // D rows = n, D cols = m.  Boustrophedon over (m tile, n tile) so that consecutive MFMAs share an operand, the int8 form's two
     // instructions per tile pair as two passes (gemm_mfma.hip, cluster_mma); every accumulator keeps its order of products
 #pragma unroll
