@@ -21,7 +21,7 @@ LIB_PATH = Path(os.environ.get("CONCH_AMD_LIBRARY", _PKG / "libconch_amd.so"))
 DT_FP32, DT_FP16, DT_BF16, DT_FP8_E4M3FN, DT_INT8, DT_UINT8, DT_INT32, DT_UINT32, DT_FP8_E5M2, DT_FP8_E4M3FNUZ = range(10)
 ZP_NONE, ZP_SCALAR, ZP_TENSOR = range(3)
 (TUNE_GEMM_VARIANT, TUNE_MIXED_TILE_NT, TUNE_SKINNY_NO_SPLITK, TUNE_SKINNY_MODE, TUNE_TILE_SCHEDULE, TUNE_PERSISTENT, TUNE_EPILOGUE, TUNE_DIAG,
- TUNE_MID_STAGES, TUNE_MIXED_SPLITK, TUNE_SKINNY_GATHER) = range(11)
+ TUNE_MID_STAGES, TUNE_MIXED_SPLITK, TUNE_SKINNY_GATHER, TUNE_MIXED_KERNEL, TUNE_COUNT) = range(13)
 (VARIANT_AUTO, VARIANT_GENERIC, VARIANT_MFMA_SIMPLE, VARIANT_MFMA_PINGPONG, VARIANT_MFMA_SKINNY,
  VARIANT_MFMA_PINGPONG2, VARIANT_MFMA_MID) = range(7)
 
@@ -38,6 +38,9 @@ TORCH_TO_DT = {
 }
 if hasattr(torch, "uint32"):
     TORCH_TO_DT[torch.uint32] = DT_UINT32
+
+
+ABI_VERSION = 2  # CONCH_AMD_ABI_VERSION of include/conch_amd.h (checked by load_library and by tests/test_host_helpers.py)
 
 
 class ConchLibraryError(RuntimeError):
@@ -62,6 +65,7 @@ _SIGNATURES = {
     "conch_reserve_scratch": (c_int, [c_void_p, _I64]),
     "conch_reset_scratch": (c_int, [c_void_p]),
     "conch_static_scaled_int8_quant": (c_int, [c_void_p, c_void_p, c_void_p, _I64, _I64, _I64, _I64, c_int, c_void_p]),
+    "conch_static_scaled_int8_quant_typed": (c_int, [c_void_p, c_void_p, c_void_p, _I64, _I64, _I64, _I64, c_int, c_int, c_void_p]),
     "conch_static_scaled_fp8_quant": (
         c_int,
         [c_void_p, c_void_p, c_void_p, _I64, _I64, _I64, _I64, c_int, c_int, c_void_p],
@@ -146,8 +150,22 @@ def load_library(path: Path) -> ctypes.CDLL:
         lib = ctypes.CDLL(str(path))
     except OSError as exc:
         raise ConchLibraryError(f"cannot load {path}: {exc}") from exc
+    # a stale binary (CONCH_AMD_LIBRARY override, or a build older than this file) must fail as a version mismatch, not as
+    # an AttributeError on whichever symbol it happens to lack
+    try:
+        lib.conch_abi_version.restype = c_int
+        lib.conch_abi_version.argtypes = []
+        have = int(lib.conch_abi_version())
+    except AttributeError:
+        have = -1
+    if have != ABI_VERSION:
+        raise ConchLibraryError(f"{path} implements C-ABI version {have}, this package binds version {ABI_VERSION}: "
+                                "rebuild it with `python -m conch_amd._build --force`")
     for name, (restype, argtypes) in _SIGNATURES.items():
-        fn = getattr(lib, name)
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as exc:
+            raise ConchLibraryError(f"{path} does not export {name}: rebuild it with `python -m conch_amd._build --force`") from exc
         fn.restype = restype
         fn.argtypes = argtypes
     return lib

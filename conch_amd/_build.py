@@ -5,6 +5,7 @@ from __future__ import annotations
 import os
 import subprocess
 import sys
+import threading
 from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
@@ -24,6 +25,12 @@ FLAGS = [
     f"-I{ROOT / 'include'}",
     f"-I{CSRC}",
 ]
+
+
+# every hipcc process of this interpreter -- the product build, the diagnostic twin and experiment variants may run at the same
+# time (__graft_entry__.build) -- takes a slot here first
+JOBS = max(1, int(os.environ.get("CONCH_BUILD_JOBS", "4")))
+_COMPILE_SLOTS = threading.BoundedSemaphore(JOBS)
 
 
 def _stale(target: Path, deps: list[Path]) -> bool:
@@ -66,12 +73,13 @@ def build(force: bool = False, verbose: bool = False, probe: bool = False, varia
             cmd = [HIPCC, *flags, "-c", str(s), "-o", str(o)]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
-            subprocess.run(cmd, check=True)
+            with _COMPILE_SLOTS:
+                subprocess.run(cmd, check=True)
         return o
 
     if variant and only:
         build(verbose=verbose)  # the objects the variant borrows
-    with ThreadPoolExecutor(max_workers=min(4, len(SOURCES))) as pool:
+    with ThreadPoolExecutor(max_workers=min(JOBS, len(SOURCES))) as pool:
         objs = list(pool.map(compile_one, SOURCES))
     if force or _stale(lib, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(lib), *map(str, objs)]

@@ -15,7 +15,7 @@
 namespace conch {
 
 static thread_local char g_error[512] = "";
-static std::atomic<int> g_tuning[11] = {};
+static std::atomic<int> g_tuning[CONCH_TUNE__COUNT] = {};
 
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -24,7 +24,7 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-int tuning(int key) { return (key >= 0 && key < 11) ? g_tuning[key].load() : 0; }
+int tuning(int key) { return (key >= 0 && key < CONCH_TUNE__COUNT) ? g_tuning[key].load() : 0; }
 
 int device_cu_count() {
   static std::atomic<int> cache[64] = {};
@@ -208,6 +208,29 @@ int run_scaled(const ScaledGemmArgs& p_in, hipStream_t stream) {
   }
   const int variant = tuning(CONCH_TUNE_GEMM_VARIANT);
   if (variant != 1 && scaled_gemm_mfma_supported(p)) return run_scaled_fast(p, variant, stream);
+  if (variant == 0 && p.in_dtype == CONCH_DT_FP8_E4M3FNUZ && !p.fuse_silu) {
+    // e4m3fnuz (the dtype the reference gives AMD users: conch/ops/quantization/fp8.py:27,54) at the fp8 rate: see gemm.hpp,
+    // ScaledGemmArgs::acc_scale.  Tile kernels only (one launch each; the split-K forms keep the expansion path).  On the
+    // stream: zero the flag, scan both operands, the fp8 kernel (runs if no special code), the expansion + bf16 kernel (run
+    // if one is there).  Three of the launches return at once; the host never learns which.
+    ScaledGemmArgs f = p;
+    f.in_dtype = CONCH_DT_FP8_E4M3FN;
+    if (scaled_gemm_mfma_supported(f) && choose_scaled_kernel(f) != kKernelSkinny && fnuz_expansion_fits(p)) {
+      void* flag = nullptr;
+      if (int rc = get_scratch(stream, kScratchFlags, 256, &flag)) return rc;
+      CONCH_HIP(hipMemsetAsync(flag, 0, 4, stream));
+      if (int rc = launch_fnuz_scan(p, (int*)flag, stream)) return rc;
+      f.acc_scale = 0.25f;
+      f.gate = (const int*)flag;
+      f.gate_run_if = 0;
+      if (int rc = run_scaled_fast(f, 0, stream)) return rc;
+      ScaledGemmArgs e;
+      if (int rc = expand_fnuz_to_bf16(p, &e, stream, (const int*)flag)) return rc;
+      e.gate = (const int*)flag;
+      e.gate_run_if = 1;
+      return launch_scaled_gemm_mfma_bf16(e, stream);
+    }
+  }
   if (variant >= 2 && variant <= 6) {
     set_error("scaled_gemm: MFMA variant %d forced but the layout contract is not met "
               "(need K-contiguous A and B^T, K %% 128 == 0, 16-byte aligned rows)", variant);
@@ -476,7 +499,7 @@ extern "C" int conch_abi_version(void) { return CONCH_AMD_ABI_VERSION; }
 extern "C" const char* conch_last_error(void) { return g_error; }
 
 extern "C" int conch_set_tuning(int key, int value) {
-  CONCH_CHECK_ARG(key >= 0 && key < 11, "conch_set_tuning: unknown key %d", key);
+  CONCH_CHECK_ARG(key >= 0 && key < CONCH_TUNE__COUNT, "conch_set_tuning: unknown key %d", key);
   g_tuning[key].store(value);
   return CONCH_OK;
 }

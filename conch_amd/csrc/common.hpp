@@ -61,7 +61,8 @@ enum ScratchSlot {
   kScratchMixedSplitK = 2,  // gemm_mixed_skinny.hip: split-K partial slabs
   kScratchWide = 3,       // unfused FFN pair: the [M][2d] intermediate
   kScratchCounters = 4,   // split-K arrival counters (zeroed at allocation, reset by the last arriver)
-  kScratchSlots = 5
+  kScratchFlags = 5,      // device-side dispatch words (e4m3fnuz: "an operand holds a code the fp8 MFMA cannot take")
+  kScratchSlots = 6
 };
 int get_scratch(hipStream_t stream, int slot, size_t bytes, void** out, bool zero_on_alloc = false);
 

@@ -35,6 +35,10 @@ __device__ __forceinline__ bool tile_stores_whole_lines(const ScaledGemmArgs& p,
          ((p.m - 1) * p.c_stride_m + p.n) * 2 < ((int64_t)1 << 32);
 }
 
+// Vector-memory operations ONE wave issues in epilogue_rows_body: two whole-line stores per 16-row block, nothing else (the
+// scales come from LDS).  The persistent kernel's hand-counted vmcnt waits (gemm_mfma.hip) are derived from this number.
+constexpr int epilogue_rows_vm_ops(int mt) { return 2 * mt; }
+
 // MT = 16-row blocks per wave (8: 128 rows, 4: 64 rows), TILE = rows = columns of the workgroup tile (the parked constants are
 // float sa[TILE] | sb[TILE] | bias[TILE] at epi_off); a wave owns 64 columns = one line per row.
 template <int MMA, int OUT_DT, bool BIAS, int MT = 8, int TILE = 256>
@@ -68,6 +72,8 @@ __device__ __forceinline__ void epilogue_rows_body(const typename AccT<MMA>::typ
   const uint32_t voff = (uint32_t)(bm0 + wr * (16 * MT) + rr) * stride_b + (uint32_t)(bn0 + wc * 64 + ch * 8) * 2u;
   const uint32_t step8 = 8u * stride_b;  // scalar: eight rows further down
   i32x4 rd0, rd1;
+  // exactly two buffer stores per block below and no other vector-memory instruction in this function: counted waits depend on it
+  static_assert(epilogue_rows_vm_ops(MT) == 2 * MT, "epilogue_rows_body issues two stores per 16-row block");
 #pragma unroll
   for (int b = 0; b < MT + 1; ++b) {
     if (b >= 1) {  // block b - 1 back, row-wise: lands under the conversion below

@@ -35,11 +35,33 @@ struct ScaledGemmArgs {
   // (profiles/r03/probe_setup.txt).  raster_shift < 0: not set, the kernel divides.
   uint32_t raster_magic = 0;
   int raster_shift = -1;
+  // The e4m3fnuz operands of the reference's AMD platform (conch/ops/quantization/fp8.py:27,54) on gfx950's OCP fp8 MFMA: every
+  // fnuz code except 0x80 (NaN), 0x7F and 0xFF (+-240) is, read as OCP e4m3fn, exactly TWICE its fnuz value -- normal numbers
+  // (bias 8 against 7) and subnormals (2^-7 m/8 against 2^-6 m/8) alike -- so the fp8 kernels run on the raw bytes and the
+  // exact factor 1/4 rides on scale_a (`acc_scale`, a power of two: every rounding of the epilogue commutes with it).
+  // `gate` points at a device word a scan of both operands has set to 1 if any of the three codes occurs; a gated launch
+  // returns at once unless (*gate != 0) == (gate_run_if != 0) -- the fp8 kernel runs if none does, the exact bf16-expansion
+  // path (repack.hip) if one does, and the host never reads the word (no synchronisation, graph-capturable).
+  float acc_scale = 1.0f;
+  const int* gate = nullptr;
+  int gate_run_if = 0;
 };
+
+#ifdef __HIPCC__
+// workgroup-uniform: true = this gated launch is the branch NOT taken
+__device__ __forceinline__ bool gated_off(const int* gate, int run_if) {
+  return gate != nullptr && ((*gate != 0) != (run_if != 0));
+}
+#endif
 
 // n / d for n < 2^31 as mulhi(n, magic) >> shift (d not a power of two: shift = ceil(log2 d) - 1, magic = ceil(2^(32 + shift) / d),
 // exact because n d < 2^(32 + shift + 1)), or n >> shift with magic = 0 (d = 2^shift).
 inline void set_raster_divisor(uint32_t d, uint32_t* magic, int* shift) {
+  if (d < 1) {  // no divisor: leave "not set" (the kernel divides)
+    *magic = 0;
+    *shift = -1;
+    return;
+  }
   int s = 0;
   while ((1u << s) < d) ++s;
   if ((1u << s) == d) {
@@ -99,7 +121,10 @@ int launch_scaled_gemm_skinny(const ScaledGemmArgs& p, hipStream_t stream);
 bool scaled_gemm_skinny_fused_supported(const ScaledGemmArgs& wide);  // silu_and_mul fused into the split-K reduce kernel
 // repack.hip -- copy operands into the MFMA layout contract (stream-ordered scratch)
 int repack_for_mfma(const ScaledGemmArgs& p, ScaledGemmArgs* q, void** scratch, hipStream_t stream);
-int expand_fnuz_to_bf16(const ScaledGemmArgs& p, ScaledGemmArgs* q, hipStream_t stream);
+int expand_fnuz_to_bf16(const ScaledGemmArgs& p, ScaledGemmArgs* q, hipStream_t stream, const int* gate = nullptr);
+bool fnuz_expansion_fits(const ScaledGemmArgs& p);  // expand_fnuz_to_bf16 will take the problem (sizes, C layout)
+// *flag = 1 if A or B^T (K-contiguous e4m3fnuz rows, the tile contract) holds a code the OCP fp8 MFMA cannot take: 0x80, 0x7F, 0xFF
+int launch_fnuz_scan(const ScaledGemmArgs& p, int* flag, hipStream_t stream);
 int launch_scaled_gemm_mfma_bf16(const ScaledGemmArgs& p, hipStream_t stream);
 int launch_scaled_gemm_mfma_16bit(const ScaledGemmArgs& p, hipStream_t stream);  // p.in_dtype = FP16 | BF16, byte units
 // gemm_modes.hip -- weight-group / channel-scale modes beyond the two conch.ops produces (dequantise first, then 16-bit MFMA)

@@ -135,6 +135,7 @@ __device__ __forceinline__ EpiPrefetch epilogue_prefetch(const ScaledGemmArgs& p
   const float* base = is_b ? p.scale_b : p.scale_a;
   const bool vec = (is_b ? p.scale_b_numel : p.scale_a_numel) != 1;
   e.v0 = base ? base[vec ? idx : 0] : 1.0f;  // NULL scale pointer = 1 (the 16-bit operand path of gemm_modes.hip)
+  if (!is_b) e.v0 *= p.acc_scale;  // 1, or the exact 1/4 of e4m3fnuz operands on the OCP fp8 MFMA (gemm.hpp)
   uint32_t bits = 0;
   if (p.bias) bits = ((const uint16_t*)p.bias)[col];
   e.bias_bits = bits;
@@ -418,6 +419,7 @@ __device__ __forceinline__ void zero_acc(WaveTile<MMA>& w) {
 template <int MMA, int OUT_DT>
 __global__ __launch_bounds__(kThreads, 2) void scaled_gemm_simple_kernel(ScaledGemmArgs p) {
   __shared__ __attribute__((aligned(1024))) char lds[kLdsTotal];
+  if (gated_off(p.gate, p.gate_run_if)) return;
   const BlockSetup s = setup_block(p);
   WaveTile<MMA> w;
   zero_acc<MMA>(w);
@@ -494,6 +496,7 @@ __device__ __forceinline__ void pingpong_step(WaveTile<MMA>& w, char* lds, const
 template <int MMA, int OUT_DT>
 __global__ __launch_bounds__(kThreads, 2) void scaled_gemm_pingpong_kernel(ScaledGemmArgs p) {
   __shared__ __attribute__((aligned(1024))) char lds[kLdsTotal];
+  if (gated_off(p.gate, p.gate_run_if)) return;
   const BlockSetup s = setup_block(p);
   WaveTile<MMA> w;
   zero_acc<MMA>(w);
@@ -647,6 +650,7 @@ __device__ __forceinline__ void pp2_tile(const ScaledGemmArgs& p, char* lds, con
 template <int MMA, int OUT_DT, bool SILU, bool ROWS = false>
 __global__ __launch_bounds__(kThreads, 2) void scaled_gemm_pp2_kernel(ScaledGemmArgs p, TileSchedule ts) {
   __shared__ __attribute__((aligned(1024))) char lds[kLdsTotal];
+  if (gated_off(p.gate, p.gate_run_if)) return;
 #ifndef CONCH_EXP_PROBE_AFTER_SETUP
   CONCH_PROBE(g_probe_scaled, 2);
 #endif
@@ -699,6 +703,24 @@ __global__ __launch_bounds__(kThreads, 2) void scaled_gemm_pp2_kernel(ScaledGemm
 // hipcc drains the whole queue for those while LDS-DMA is in flight), uniform 256-column tiles.  Edge tiles (ragged M / N or
 // unaligned C rows: a store count that is not 16 per wave) drain fully instead of counting.
 // ---------------------------------------------------------------------------------------------
+// The counted waits of the persistent walk, from what a wave puts into its vector-memory queue around a tile boundary (vmcnt
+// retires loads, LDS-DMA and stores together, IN ISSUE ORDER -- the property all of this rests on):
+//   [stage_scales: kScaleOps] [stage_two_steps: 2 K steps x 4 units x kPiecesPerUnit] [epilogue_rows_body: kStoreOps stores]
+constexpr int kPiecesPerUnit = 2;                               // stage_unit issues two LDS-DMA wave-instructions
+constexpr int kUnitsPerStep = 4;                                // U1, V1, V2, U2
+constexpr int kScaleOps = 1;                                    // stage_scales: one 4-byte LDS-DMA per wave (the OLDEST of the group)
+constexpr int kStoreOps = epilogue_rows_vm_ops(8);              // 16 whole-line stores per wave and whole tile
+constexpr int kRingPieces = 2 * kUnitsPerStep * kPiecesPerUnit; // the whole ring in flight: 16 pieces
+// boundary: units 0-2 of the next tile landed (the plain kernel's prologue wait) = all but the youngest 5 units + the stores
+constexpr int kVmBoundary = (2 * kUnitsPerStep - 3) * kPiecesPerUnit + kStoreOps;               // 26
+// A(0): units <= U2(0) landed = step 1's four units and the stores may stay in flight
+constexpr int kVmA0 = kUnitsPerStep * kPiecesPerUnit + kStoreOps;                                 // 24
+// B(0): units <= V2(1) landed; B(0) has issued U1(2), V1(2) itself: U2(1) + those two + the stores
+constexpr int kVmB0 = 3 * kPiecesPerUnit + kStoreOps;                                             // 22
+// A(1): units <= U2(1) landed; issued since: U1(2), V1(2), V2(2), U2(2) = the steady-state 8, plus the stores
+constexpr int kVmA1 = kUnitsPerStep * kPiecesPerUnit + kStoreOps;                                 // 24
+static_assert(kVmBoundary == 26 && kVmA0 == 24 && kVmB0 == 22 && kVmA1 == 24, "persistent walk: counted waits re-derived");
+static_assert(kVmBoundary < 64, "vmcnt is a 6-bit field");
 constexpr int kEpiBytes = 3 * 1024;
 constexpr int kStageOffPersistent = kLdsBytes + 2 * kEpiBytes;          // 2 KiB per wave for the row-major epilogue
 constexpr int kLdsTotalPersistent = kStageOffPersistent + 8 * 2048;     // operand ring + two sets of parked scales + staging
@@ -730,7 +752,7 @@ __device__ __forceinline__ void stage_two_steps(char* lds, const BlockSetup& s) 
 }
 
 template <int MMA, int OUT_DT>
-__global__ __launch_bounds__(kThreads, 2) void scaled_gemm_pp2_persistent_kernel(ScaledGemmArgs p, TileSchedule ts, int total_tiles) {
+__global__ __launch_bounds__(kThreads, 2) void scaled_gemm_pp2_persistent_kernel(ScaledGemmArgs p, TileSchedule ts, int total_tiles, int direct_epilogue) {
   __shared__ __attribute__((aligned(1024))) char lds[kLdsTotalPersistent];
   const int steps = (int)(p.k / kStepBytes);  // >= 4 (dispatcher)
   int vb = blockIdx.x;
@@ -750,8 +772,8 @@ __global__ __launch_bounds__(kThreads, 2) void scaled_gemm_pp2_persistent_kernel
     // for exactly the loads the plain kernel's counts wait for: A(0) units <= U2(0), B(0) <= V2(1), A(1) <= U2(1); the
     // stores may stay in flight until B(1), whose wait (6) is for a load issued behind them.  (First tile, edge tiles:
     // everything has drained and the counts are trivially met.)
-    pp2_step<MMA, 4, 0, 1, 24, 22>(w, lds, s, 0);  // V2 / U2 of step 1 are already in flight or landed
-    pp2_step<MMA, 4, 1, 1, 24, 6>(w, lds, s, 1);
+    pp2_step<MMA, 4, 0, 1, kVmA0, kVmB0>(w, lds, s, 0);  // V2 / U2 of step 1 are already in flight or landed
+    pp2_step<MMA, 4, 1, 1, kVmA1, 6>(w, lds, s, 1);
     int t = 2;
     for (; t + 2 < steps; ++t) pp2_step<MMA, 4, 1, 1, 8, 6>(w, lds, s, t);
     pp2_step<MMA, 4, 1, 0, 8, 2>(w, lds, s, t);
@@ -779,14 +801,17 @@ __global__ __launch_bounds__(kThreads, 2) void scaled_gemm_pp2_persistent_kernel
       stage_two_steps(lds, sn);
       __builtin_amdgcn_sched_barrier(0);  // the loads go out before the first store
     }
-    // whole tiles: row-major through the spare LDS (the operand ring is being refilled), 16 whole-line stores per wave
-    epilogue_rows<MMA, OUT_DT>(w.acc, p, lds, kStageOffPersistent, bm0, bn0, s.wr, s.wc, s.lane, s.wave, kLdsBytes + eb * kEpiBytes);
+    // whole tiles: row-major through the spare LDS (the operand ring is being refilled), kStoreOps whole-line stores per wave;
+    // direct_epilogue (CONCH_TUNE_EPILOGUE = 1) and tiles that are not whole store from the accumulator layout and drain
+    const bool counted = !direct_epilogue && tile_stores_whole_lines(p, bm0, bn0);  // workgroup-uniform
+    if (direct_epilogue) epilogue<MMA, OUT_DT, 4>(w.acc, p, lds, bm0, bn0, s.wr, s.wc, s.lane, kLdsBytes + eb * kEpiBytes);
+    else epilogue_rows<MMA, OUT_DT>(w.acc, p, lds, kStageOffPersistent, bm0, bn0, s.wr, s.wc, s.lane, s.wave, kLdsBytes + eb * kEpiBytes);
     CONCH_PROBE_AT(g_probe_scaled, 3, vb);
     if (!more) return;
     __builtin_amdgcn_sched_barrier(0);
-    // a whole tile issues exactly 16 stores per wave: 16 + the 10 youngest LDS-DMA pieces may stay in flight = units 0-2
-    // of the next tile have landed (the plain kernel's prologue wait); anything else (masked stores) drains
-    if (tile_stores_whole_lines(p, bm0, bn0)) wait_vmcnt_n<26>();
+    // a whole tile issues exactly kStoreOps stores per wave: they and the 10 youngest LDS-DMA pieces may stay in flight = units
+    // 0-2 of the next tile have landed (the plain kernel's prologue wait); anything else (masked / direct stores) drains
+    if (counted) wait_vmcnt_n<kVmBoundary>();
     else CONCH_VMCNT(0);
     __builtin_amdgcn_s_barrier();
     int tid2 = threadIdx.x;
@@ -891,13 +916,14 @@ int launch_scaled_gemm_mfma(const ScaledGemmArgs& p_in, int variant, hipStream_t
   const int persist_mode = tuning(CONCH_TUNE_PERSISTENT);
   const int cus = device_cu_count();
   const int total_tiles = (int)grid.x;
-  const bool contract = !p.fuse_silu && (variant == 0 || variant == 5) && ts.narrow_cols == 0 && !p.bias && p.k >= 4 * kStepBytes;
+  const bool contract = !p.fuse_silu && (variant == 0 || variant == 5) && ts.narrow_cols == 0 && !p.bias && p.k >= 4 * kStepBytes &&
+                        p.acc_scale == 1.0f && !p.gate;  // (its scales reach LDS by LDS-DMA: nothing multiplies them on the way)
   const bool persistent = contract && persist_mode >= 2;  // auto = plain launch: profiles/r02/probe_boundary.txt
   if (persistent) grid = dim3((unsigned)std::min(total_tiles, persist_mode > 2 ? persist_mode : cus));
 #define CONCH_LAUNCH(MMA, OUT)                                                                           \
   do {                                                                                                   \
     if (persistent)                                                                                      \
-      hipLaunchKernelGGL((scaled_gemm_pp2_persistent_kernel<MMA, OUT>), grid, dim3(kThreads), 0, stream, p, ts, total_tiles); \
+      hipLaunchKernelGGL((scaled_gemm_pp2_persistent_kernel<MMA, OUT>), grid, dim3(kThreads), 0, stream, p, ts, total_tiles, rows_epilogue ? 0 : 1); \
     else if (variant == 2)                                                                               \
       hipLaunchKernelGGL((scaled_gemm_simple_kernel<MMA, OUT>), grid, dim3(kThreads), 0, stream, p);     \
     else if (p.fuse_silu)                                                                                \

@@ -38,6 +38,7 @@ __global__ __launch_bounds__(kMidThreads, 2) void scaled_gemm_mid_kernel(ScaledG
   constexpr int kMidEpi = STAGES * kMidBuf;
   constexpr int kMidLds = kMidEpi + 3 * 128 * 4;
   __shared__ __attribute__((aligned(1024))) char lds[kMidLds];
+  if (gated_off(p.gate, p.gate_run_if)) return;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int wr = wave >> 1, wc = wave & 1;
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(kMidThreads, 2) void scaled_gemm_mid_kernel(ScaledG
     const float* base = epi_is_b ? p.scale_b : p.scale_a;
     const bool vec = (epi_is_b ? p.scale_b_numel : p.scale_a_numel) != 1;
     epi_v0 = base[vec ? idx : 0];
+    if (!epi_is_b) epi_v0 *= p.acc_scale;  // 1, or the exact 1/4 of e4m3fnuz operands on the OCP fp8 MFMA (gemm.hpp)
     // unconditional (without a bias: two readable bytes of A, never used)
     const uint16_t* bias_src = p.bias ? (const uint16_t*)p.bias + min(bn0 + tt, (int)p.n - 1) : (const uint16_t*)p.a;
     epi_bits = *bias_src;

@@ -16,7 +16,16 @@ namespace {
 using namespace quant;
 
 // Flat, 16-byte aligned, contiguous view of n elements.
-template <int XDT, int KIND>
+// ROUNDP (int8, 16-bit inputs): the product is rounded to the INPUT dtype before the clamp -- what torch's type promotion
+// makes of `x * scale.reciprocal()` when `scale` is a 0-dim tensor (conch/reference/quantization/int8.py:12-18: a 0-dim
+// operand does not take part in the result dtype; the fp32 reciprocal itself is not rounded).
+template <int XDT, int KIND, bool ROUNDP>
+__device__ __forceinline__ float round_product(float v) {
+  if constexpr (ROUNDP && XDT != CONCH_DT_FP32) return bits16_to_float<XDT>(float_to_bits16<XDT>(v));
+  return v;
+}
+
+template <int XDT, int KIND, bool ROUNDP = false>
 __global__ __launch_bounds__(kQuantThreads) void quant_flat_kernel(uint8_t* __restrict__ out,
                                                                    const void* __restrict__ x,
                                                                    const float* __restrict__ scale,
@@ -27,20 +36,28 @@ __global__ __launch_bounds__(kQuantThreads) void quant_flat_kernel(uint8_t* __re
   for (int64_t v = (int64_t)blockIdx.x * kQuantThreads + threadIdx.x; v < nvec; v += stride) {
     float f[kVec];
     load16<XDT>(x, v * kVec, f);
+    if constexpr (ROUNDP) {  // quant_four multiplies by its last argument: hand it the rounded product and 1
+#pragma unroll
+      for (int j = 0; j < kVec; ++j) f[j] = round_product<XDT, KIND, ROUNDP>(pin_f32(f[j] * inv));
+    }
+    const float mul = ROUNDP ? 1.0f : inv;
     i32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      o[j] = (int)quant_four<KIND>(f[4 * j], f[4 * j + 1], f[4 * j + 2], f[4 * j + 3], inv);
+      o[j] = (int)quant_four<KIND>(f[4 * j], f[4 * j + 1], f[4 * j + 2], f[4 * j + 3], mul);
     __builtin_nontemporal_store(o, (i32x4*)(out + v * kVec));
   }
   // scalar tail (< 16 elements)
   const int64_t tail0 = nvec * kVec;
   const int64_t t = tail0 + (int64_t)blockIdx.x * kQuantThreads + threadIdx.x;
-  if (t < n) out[t] = (uint8_t)quant_one<KIND>(load_as_float<XDT>(x, t), inv);
+  if (t < n) {
+    const float v = load_as_float<XDT>(x, t);
+    out[t] = ROUNDP ? (uint8_t)quant_one<KIND>(round_product<XDT, KIND, ROUNDP>(pin_f32(v * inv)), 1.0f) : (uint8_t)quant_one<KIND>(v, inv);
+  }
 }
 
 // Row-strided or unaligned tensors: one block walks one row with scalar accesses.
-template <int XDT, int KIND>
+template <int XDT, int KIND, bool ROUNDP = false>
 __global__ __launch_bounds__(kQuantThreads) void quant_rows_kernel(uint8_t* __restrict__ out,
                                                                    const void* __restrict__ x,
                                                                    const float* __restrict__ scale,
@@ -51,12 +68,14 @@ __global__ __launch_bounds__(kQuantThreads) void quant_rows_kernel(uint8_t* __re
   for (int64_t row = blockIdx.x; row < tokens; row += gridDim.x) {
     const int64_t xb = row * x_row_stride;
     const int64_t ob = row * out_row_stride;
-    for (int64_t h = threadIdx.x; h < hidden; h += kQuantThreads)
-      out[ob + h] = (uint8_t)quant_one<KIND>(load_as_float<XDT>(x, xb + h), inv);
+    for (int64_t h = threadIdx.x; h < hidden; h += kQuantThreads) {
+      const float v = load_as_float<XDT>(x, xb + h);
+      out[ob + h] = ROUNDP ? (uint8_t)quant_one<KIND>(round_product<XDT, KIND, ROUNDP>(pin_f32(v * inv)), 1.0f) : (uint8_t)quant_one<KIND>(v, inv);
+    }
   }
 }
 
-template <int XDT, int KIND>
+template <int XDT, int KIND, bool ROUNDP = false>
 int launch_quant(uint8_t* out, const void* x, const float* scale, int64_t tokens, int64_t hidden,
                  int64_t x_row_stride, int64_t out_row_stride, hipStream_t stream) {
   const int64_t n = tokens * hidden;
@@ -70,11 +89,11 @@ int launch_quant(uint8_t* out, const void* x, const float* scale, int64_t tokens
     // 16 blocks per CU, grid-stride beyond that (C1 = 4096 blocks: one vector per thread, no loop trip: 9.74 -> 9.42 us
     // against a cap of 8, graph-replayed; two vectors per trip with all loads up front measured 1-3 % slower)
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL((quant_flat_kernel<XDT, KIND>), dim3((unsigned)blocks), dim3(kQuantThreads),
+    hipLaunchKernelGGL((quant_flat_kernel<XDT, KIND, ROUNDP>), dim3((unsigned)blocks), dim3(kQuantThreads),
                        0, stream, out, x, scale, n);
   } else {
     int64_t blocks = tokens < 256 * 8 ? tokens : 256 * 8;
-    hipLaunchKernelGGL((quant_rows_kernel<XDT, KIND>), dim3((unsigned)blocks), dim3(kQuantThreads),
+    hipLaunchKernelGGL((quant_rows_kernel<XDT, KIND, ROUNDP>), dim3((unsigned)blocks), dim3(kQuantThreads),
                        0, stream, out, x, scale, tokens, hidden, x_row_stride, out_row_stride);
   }
   return check_launch("static_scaled_quant");
@@ -119,6 +138,20 @@ extern "C" int conch_static_scaled_int8_quant(int8_t* out, const void* x, const 
   if (int rc = check_quant_args(out, x, scale, tokens, hidden, x_row_stride, out_row_stride)) return rc;
   return dispatch_xdtype<kInt8>((uint8_t*)out, x, scale, tokens, hidden, x_row_stride,
                                 out_row_stride, x_dtype, (hipStream_t)stream);
+}
+
+extern "C" int conch_static_scaled_int8_quant_typed(int8_t* out, const void* x, const float* scale,
+                                                    int64_t tokens, int64_t hidden, int64_t x_row_stride,
+                                                    int64_t out_row_stride, int x_dtype, int product_dtype, void* stream) {
+  using namespace conch;
+  if (product_dtype == CONCH_DT_FP32)
+    return conch_static_scaled_int8_quant(out, x, scale, tokens, hidden, x_row_stride, out_row_stride, x_dtype, stream);
+  if (int rc = check_quant_args(out, x, scale, tokens, hidden, x_row_stride, out_row_stride)) return rc;
+  CONCH_CHECK_ARG(product_dtype == x_dtype && (x_dtype == CONCH_DT_FP16 || x_dtype == CONCH_DT_BF16),
+                  "static int8 quant: product dtype %d must be FP32 or the 16-bit input dtype (input dtype %d)", product_dtype, x_dtype);
+  if (x_dtype == CONCH_DT_FP16)
+    return launch_quant<CONCH_DT_FP16, kInt8, true>((uint8_t*)out, x, scale, tokens, hidden, x_row_stride, out_row_stride, (hipStream_t)stream);
+  return launch_quant<CONCH_DT_BF16, kInt8, true>((uint8_t*)out, x, scale, tokens, hidden, x_row_stride, out_row_stride, (hipStream_t)stream);
 }
 
 extern "C" int conch_static_scaled_fp8_quant(uint8_t* out, const void* x, const float* scale,

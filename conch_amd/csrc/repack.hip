@@ -42,8 +42,9 @@ __global__ __launch_bounds__(256) void repack_rows_kernel(uint8_t* __restrict__ 
 // dst[r][k] (bf16, row stride kp elements) = decode_fnuz(src[r * sr + k * sk])
 __global__ __launch_bounds__(256) void fnuz_to_bf16_rows_kernel(uint16_t* __restrict__ dst, const uint8_t* __restrict__ src,
                                                                 int64_t rows, int64_t k_dim, int64_t kp, int64_t sr,
-                                                                int64_t sk) {
+                                                                int64_t sk, const int* __restrict__ gate) {
   __shared__ uint8_t tile[kRpTile][kRpTile + 4];  // [r][k]
+  if (gated_off(gate, 1)) return;  // the operands hold none of the codes the fp8 MFMA cannot take: the fp8 kernel runs instead
   const int64_t k0 = (int64_t)blockIdx.x * kRpTile, r0 = (int64_t)blockIdx.y * kRpTile;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const bool k_fast = sk <= sr;
@@ -114,12 +115,60 @@ int repack_for_mfma(const ScaledGemmArgs& p, ScaledGemmArgs* q, void** scratch, 
 // e4m3fnuz operands: expand both to bf16 in scratch (exact) and describe them to the tiled MFMA kernel in
 // BYTE units (a 128-byte K step = 64 elements).  The MI300-era flavour cannot use gfx950's OCP fp8 MFMA
 // (different bias, 0x7F/0xFF are numbers, 0x80 is NaN), so it runs at the bf16 MFMA rate instead.
-int expand_fnuz_to_bf16(const ScaledGemmArgs& p, ScaledGemmArgs* q, hipStream_t stream) {
-  *q = p;
-  if (p.in_dtype != CONCH_DT_FP8_E4M3FNUZ || p.c_stride_n != 1 || p.k < 1) return CONCH_ERR_UNSUPPORTED;
+// Does A or B^T hold 0x80 (fnuz NaN; OCP -0), 0x7F or 0xFF (fnuz +-240; OCP NaN)?  One pass over both operands, 16 bytes per
+// lane; `flag` was zeroed on the stream before.  Rows are K-contiguous and 16-byte aligned, K % 16 == 0 (the tile contract).
+__device__ __forceinline__ uint32_t fnuz_special_in(uint32_t x) {
+  const uint32_t t = x & 0x7f7f7f7fu;                                   // a byte is 0x7F or 0xFF  <=>  its low seven bits are all set
+  const uint32_t top = (t + 0x01010101u) & 0x80808080u;                 // (no carry between bytes: 0x7F + 1 = 0x80)
+  const uint32_t y = x ^ 0x80808080u;                                   // a byte is 0x80  <=>  it is zero here
+  const uint32_t nan = (y - 0x01010101u) & ~y & 0x80808080u;            // the classic zero-byte test (false positives impossible
+  return top | nan;                                                     // for the lowest zero byte; any hit means "some byte")
+}
+
+__global__ __launch_bounds__(256) void fnuz_scan_kernel(const uint8_t* __restrict__ a, int rows_a, int64_t stride_a,
+                                                        const uint8_t* __restrict__ b, int rows_b, int64_t stride_b, int k_vecs,
+                                                        int* __restrict__ flag) {
+  uint32_t found = 0;
+  const int rows = rows_a + rows_b;
+  for (int r0 = blockIdx.x * 4; r0 < rows; r0 += gridDim.x * 4) {
+    for (int c = threadIdx.x; c < k_vecs; c += 256) {
+      u32x4 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {  // four rows' loads in flight
+        const int r = min(r0 + j, rows - 1);
+        const uint8_t* row = r < rows_a ? a + (int64_t)r * stride_a : b + (int64_t)(r - rows_a) * stride_b;
+        v[j] = *(const u32x4*)(row + (int64_t)c * 16);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) found |= fnuz_special_in(v[j][e]);
+    }
+  }
+  if (found) atomicOr(flag, 1);
+}
+
+int launch_fnuz_scan(const ScaledGemmArgs& p, int* flag, hipStream_t stream) {
+  const int rows = (int)(p.m + p.n);
+  int blocks = (rows + 3) / 4;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  hipLaunchKernelGGL(fnuz_scan_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const uint8_t*)p.a, (int)p.m, p.a_stride_m,
+                     (const uint8_t*)p.b, (int)p.n, p.b_stride_n, (int)(p.k / 16), flag);
+  return check_launch("fnuz_scan");
+}
+
+bool fnuz_expansion_fits(const ScaledGemmArgs& p) {
+  if (p.in_dtype != CONCH_DT_FP8_E4M3FNUZ || p.c_stride_n != 1 || p.k < 1) return false;
   const int64_t kp = (p.k + 63) / 64 * 64;  // elements; 128-byte steps
-  if (p.m * kp * 2 >= ((int64_t)1 << 31) || p.n * kp * 2 >= ((int64_t)1 << 31)) return CONCH_ERR_UNSUPPORTED;
-  if (p.m >= (1 << 24) || p.n >= (1 << 24) || ((uintptr_t)p.c & 1)) return CONCH_ERR_UNSUPPORTED;
+  if (p.m * kp * 2 >= ((int64_t)1 << 31) || p.n * kp * 2 >= ((int64_t)1 << 31)) return false;
+  if (p.m >= (1 << 24) || p.n >= (1 << 24) || ((uintptr_t)p.c & 1)) return false;
+  return true;
+}
+
+int expand_fnuz_to_bf16(const ScaledGemmArgs& p, ScaledGemmArgs* q, hipStream_t stream, const int* gate) {
+  *q = p;
+  if (!fnuz_expansion_fits(p)) return CONCH_ERR_UNSUPPORTED;
+  const int64_t kp = (p.k + 63) / 64 * 64;  // elements; 128-byte steps
   const size_t a_bytes = (size_t)(p.m * kp * 2 + 255) / 256 * 256;
   const size_t b_bytes = (size_t)(p.n * kp * 2 + 255) / 256 * 256;
   void* ws = nullptr;
@@ -128,13 +177,13 @@ int expand_fnuz_to_bf16(const ScaledGemmArgs& p, ScaledGemmArgs* q, hipStream_t 
   {
     const dim3 grid((unsigned)((kp + kRpTile - 1) / kRpTile), (unsigned)((p.m + kRpTile - 1) / kRpTile));
     hipLaunchKernelGGL(fnuz_to_bf16_rows_kernel, grid, block, 0, stream, (uint16_t*)ws, (const uint8_t*)p.a, p.m, p.k,
-                       kp, p.a_stride_m, p.a_stride_k);
+                       kp, p.a_stride_m, p.a_stride_k, gate);
   }
   uint8_t* bt = (uint8_t*)ws + a_bytes;
   {
     const dim3 grid((unsigned)((kp + kRpTile - 1) / kRpTile), (unsigned)((p.n + kRpTile - 1) / kRpTile));
     hipLaunchKernelGGL(fnuz_to_bf16_rows_kernel, grid, block, 0, stream, (uint16_t*)bt, (const uint8_t*)p.b, p.n, p.k,
-                       kp, p.b_stride_n, p.b_stride_k);
+                       kp, p.b_stride_n, p.b_stride_k, gate);
   }
   q->a = ws;
   q->b = bt;

@@ -196,6 +196,10 @@ def static_quant_scaled_gemm_launcher(
         raise ValueError(f"output shape {tuple(output.shape)} != {(m, n)}")
     if scale_x.numel() != 1 or scale_x.dtype != torch.float32:
         raise ValueError("scale_x must be one float32 (static per-tensor activation scale)")
+    if scale_x.dim() == 0 and b.dtype == torch.int8:
+        raise ValueError("a 0-dim scale_x changes the int8 quantiser's arithmetic (product in x's dtype, like torch's type "
+                         "promotion in conch/reference/quantization/int8.py:16): pass a (1,)-shaped scale, or call the op "
+                         "conch_amd.ops.quantization.gemm.static_quant_scaled_gemm, which runs the unfused pair for it")
     sb = _as_fp32_vector(scale_b, "scale_b")
     if bias is not None:
         if bias.dtype != output.dtype:

@@ -29,8 +29,13 @@ def static_scaled_int8_quant_launcher(
     if scale.dtype != torch.float32 or scale.numel() != 1:
         raise ValueError(f"scale must be a one-element float32 tensor (got {scale.dtype}, {scale.numel()} elements)")
     tokens, hidden = x.shape
+    # a 0-dim scale does not take part in torch's type promotion: the reference oracle's `x * scale.reciprocal()`
+    # (conch/reference/quantization/int8.py:16) is then rounded to x's dtype before the clamp; any other one-element
+    # shape -- the (1,) of the reference's tests and benchmarks -- makes the product fp32
+    x_dt = _C.dtype_id(x.dtype)
+    product_dt = x_dt if scale.dim() == 0 and x.dtype in (torch.float16, torch.bfloat16) else _C.DT_FP32
     with _C.on_device_of(out, x, scale):
-        status = _C.load().conch_static_scaled_int8_quant(
+        status = _C.load().conch_static_scaled_int8_quant_typed(
             _C.ptr(out),
             _C.ptr(x),
             _C.ptr(scale),
@@ -38,7 +43,8 @@ def static_scaled_int8_quant_launcher(
             hidden,
             x.stride(0) if tokens > 1 else hidden,
             out.stride(0) if tokens > 1 else hidden,
-            _C.dtype_id(x.dtype),
+            x_dt,
+            product_dt,
             _C.current_stream_handle(x.device),
         )
     _C.check(status, "static_scaled_int8_quant")

@@ -107,6 +107,12 @@ def static_quant_scaled_gemm(x: torch.Tensor, b: torch.Tensor, scale_x: torch.Te
     (the activation quantiser fused into the GEMM).  `x`: fp16 / bf16 activations [M, K]; `b`: int8 / fp8
     weights [K, N] (its dtype is the one x is quantised to); `scale_x`: the static per-tensor activation scale (one float32).
     At decode batch sizes the quantisation happens on the way into the GEMM kernel's LDS; larger M runs the two kernels."""
+    if scale_x.dim() == 0 and b.dtype == torch.int8 and x.dtype in (torch.float16, torch.bfloat16):
+        # a 0-dim scale makes the int8 quantiser round its product to x's dtype (kernels/quantization/int8.py); the fused
+        # kernel multiplies in fp32, so this one case runs the pair it is defined by
+        from conch_amd.ops.quantization.int8 import scaled_int8_quant
+
+        return scaled_gemm(scaled_int8_quant(x, scale_x)[0], b, scale_x, scale_b, output_dtype, bias)
     out = torch.empty((x.shape[0], b.shape[1]), dtype=output_dtype, device=x.device)
     static_quant_scaled_gemm_launcher(out, x, b, scale_x, scale_b, bias)
     return out

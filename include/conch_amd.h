@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define CONCH_AMD_ABI_VERSION 1
+#define CONCH_AMD_ABI_VERSION 2
 
 typedef enum conch_status {
   CONCH_OK = 0,
@@ -148,12 +148,25 @@ typedef enum conch_tuning_key {
   CONCH_TUNE_MIXED_SPLITK = 9 /* LDS-tiled mixed_precision_gemm: K slices per tile (fp32 slabs + reduce kernel) when the tiles
                                  leave most of the chip idle: 0 = auto, 1 = never, 2 / 4 / 8 = force */
   ,
-  CONCH_TUNE_SKINNY_GATHER = 10 /* split-K skinny-M scaled GEMM, how a wave fetches its B^T fragments: 0 = auto (2 when the launch
-                                   is at most one workgroup per CU), 1 = in MFMA operand order (16 rows x 16 bytes per quarter-wave),
-                                   2 = four lanes per 64-byte row piece, put into operand order by a cross-lane gather.  The 4-bit
-                                   decode GEMM of conch_bnb_gemm_4bit (<= 32 rows) and the int4 decode-batch kernel of
-                                   mixed_precision_gemm: 1 = packed words in operand order into registers, otherwise 16 bytes per
-                                   lane through LDS (LDS-DMA) */
+  CONCH_TUNE_SKINNY_GATHER = 10 /* fetch order of the decode kernels' operands (all forms bit-identical):
+                                   - split-K skinny-M scaled GEMM (gemm_skinny.hip), the wave's B^T fragments: 0 = auto (2 when the
+                                     launch is at most one workgroup per CU, or for 32-row blocks with 8-step slices), 1 = in MFMA
+                                     operand order (16 rows x 16 bytes per quarter-wave), 2 = four lanes per 64-byte row piece, put
+                                     into operand order by a cross-lane gather;
+                                   - int4 decode-batch kernel of mixed_precision_gemm (gemm_mixed_skinny.hip), the packed words:
+                                     1 = operand order into registers; 2 = 16 bytes per lane through LDS (LDS-DMA); 0 = auto = the
+                                     LDS form when the launch is at most one workgroup per CU or the block has 64 rows.  The LDS form
+                                     needs a 16-byte aligned w_q with wq_stride_k % 4 == 0 and int4 weights: otherwise registers,
+                                     whatever the key says;
+                                   - 4-bit decode GEMM of conch_bnb_gemm_4bit (bnb.hip, <= 32 rows): 1 = codes and absmax in operand
+                                     order into registers, anything else = LDS-DMA staging + gather; a packed-weight pointer that is
+                                     not 16-byte aligned takes the register form whatever the key says */
+  ,
+  CONCH_TUNE_MIXED_KERNEL = 11 /* mixed_precision_gemm, M > 256: 0 = auto, 1 = the LDS-tiled kernel (dequantised weights pass
+                                  through LDS: gemm_mixed.hip), 2 = the column-strip kernel (every wave dequantises its own 16 / 32
+                                  columns straight into MFMA operand registers: gemm_mixed_strip.hip) wherever its contract holds */
+  ,
+  CONCH_TUNE__COUNT = 12 /* number of keys (array bound; not a key) */
 } conch_tuning_key_t;
 
 int conch_abi_version(void);
@@ -184,6 +197,16 @@ int conch_reset_scratch(void* stream);
 int conch_static_scaled_int8_quant(int8_t* out, const void* x, const float* scale, int64_t tokens,
                                    int64_t hidden, int64_t x_row_stride, int64_t out_row_stride,
                                    int x_dtype, void* stream);
+/*
+ * The same with the dtype of the PRODUCT made explicit: CONCH_DT_FP32 (the call above), or x_dtype (FP16 / BF16):
+ *   out[t][h] = (int8) trunc( clamp( x_dtype( (float)x[t][h] * (1.0f / *scale) ), -128, 127 ) )
+ * -- what reference/quantization/int8.py:16 computes when `scale` is a 0-dim tensor: torch's type promotion ignores a 0-dim
+ * operand of the same category, so `x * scale.reciprocal()` is rounded to x's dtype (the fp32 reciprocal is not).  The
+ * Python wrapper picks it by scale.dim() == 0; the (1,)-shaped scale of the reference's tests and benchmarks gives FP32.
+ */
+int conch_static_scaled_int8_quant_typed(int8_t* out, const void* x, const float* scale, int64_t tokens,
+                                         int64_t hidden, int64_t x_row_stride, int64_t out_row_stride,
+                                         int x_dtype, int product_dtype, void* stream);
 
 /*
  * static_scaled_fp8_quant  (replaces kernels/quantization/fp8.py:65-97;

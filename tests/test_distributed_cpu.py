@@ -170,3 +170,45 @@ def test_force_collective_runs_the_exchange_path_with_one_rank():
     """`force_collective=True` sends a one-rank group through the staging buffers and the all-gather (the GPU suite does the same
     through a one-rank RCCL group: the exchange path on the real backend, as far as a one-GPU box allows)."""
     mp.spawn(_one_rank_worker, args=(1, _free_port()), nprocs=1, join=True)
+
+
+_CHILD = '''
+import json, os, sys
+import torch
+import torch.distributed as dist
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+t = torch.tensor([rank + 1.0])
+dist.all_reduce(t)
+print("library chatter on stdout, rank", rank, flush=True)
+if "--fail" in sys.argv and rank == 1:
+    sys.exit(7)
+dist.barrier()
+if rank == 0 and "--silent" not in sys.argv:
+    print(json.dumps({"metric": "m", "value": t.item(), "n_gpus": world, "argv": sys.argv[1:]}), flush=True)
+dist.destroy_process_group()
+'''
+
+
+def test_bench_starts_its_own_ranks_when_called_bare(tmp_path, capfd):
+    """`python bench.py --gpus N` without a torchrun environment (how the driver calls N = 1) must start the N ranks itself --
+    as child processes of a parent that never touches the GPU -- relay the ONE JSON line and the ranks' return code.  The
+    ranks here are a stand-in script on gloo (bench.py proper needs a GPU); the launcher under test is bench.spawn_ranks."""
+    import json
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    import bench
+
+    child = tmp_path / "child.py"
+    child.write_text(_CHILD)
+    assert bench.spawn_ranks(2, ["--gpus", "2", "--steps", "3"], script=child) == 0
+    out = capfd.readouterr().out.strip().splitlines()
+    assert len(out) == 1, out  # the ranks' other stdout lines are not relayed
+    line = json.loads(out[0])
+    assert line["n_gpus"] == 2 and line["value"] == 3.0 and line["argv"] == ["--gpus", "2", "--steps", "3"]
+    assert bench.spawn_ranks(2, ["--fail"], script=child) != 0  # a failing rank is a failing bench
+    capfd.readouterr()
+    assert bench.spawn_ranks(2, ["--silent"], script=child) == 1  # rc 0 without a line is not a result
+    assert capfd.readouterr().out.strip() == ""

@@ -274,6 +274,10 @@ def test_persistent_tile_walk_is_bit_identical_and_correct(_reset_tuning, workgr
     for _ in range(2):
         walk = run_scaled(a, b, sa, sb, torch.bfloat16, None)
         np.testing.assert_array_equal(to_bits(walk), to_bits(plain))
+    # CONCH_TUNE_EPILOGUE = 1 is honoured by the persistent walk too: direct stores, every boundary drained instead of counted
+    _C.set_tuning(_C.TUNE_EPILOGUE, 1)
+    np.testing.assert_array_equal(to_bits(run_scaled(a, b, sa, sb, torch.bfloat16, None)), to_bits(plain))
+    _C.set_tuning(_C.TUNE_EPILOGUE, 0)
     ref = oracle.scaled_gemm_ref(a, b, sa, sb, torch.bfloat16, None)
     check_scaled(walk, ref, IN_T[iname], torch.bfloat16, (a, b, sa, sb, None))
 
@@ -377,8 +381,10 @@ def test_scaled_gemm_every_kernel_variant(variant, iname, m, k, n):
 
 
 @pytest.mark.parametrize("iname", list(IN_T))
-@pytest.mark.parametrize("key_tail", ["f16_sa1_sb1_b1", "bf16_sa0_sb0_b1", "bf16_sa0_sb1_b0", "f16_sa1_sb0_b0"])
+@pytest.mark.parametrize("key_tail", [f"{o}_sa{sa}_sb{sb}_b{b}" for o in ("f16", "bf16") for sa in (0, 1) for sb in (0, 1) for b in (0, 1)])
 def test_scaled_gemm_golden_from_reference(golden, iname, key_tail):
+    """All 48 fixtures the reference's own oracle produced (16 scale / bias / dtype combinations x int8, e4m3fn, e4m3fnuz:
+    conch/tests/scaled_gemm_test.py's matrix at its first shape) through the HIP path."""
     g = golden("scaled_gemm")
     key = f"{iname}_{key_tail}"
     oname = key_tail.split("_")[0]
@@ -660,8 +666,6 @@ def check_mixed(got, a, w_ref, k):
 @pytest.mark.parametrize("use_zp", [True, False])
 @pytest.mark.parametrize("dname", ["f16", "bf16"])
 def test_mixed_precision_gemm_matrix(m, k, n, wname, use_zp, dname):
-    if (m, k, n) == SHAPES[2] and not (wname, use_zp, dname) in (("uint4b8", False, "f16"), ("uint8b128", True, "bf16")):
-        pytest.skip("large shape: two representative cases (CPU oracle time)")
     wt = WTYPES[wname]
     a, w_ref, packed, w_s, w_zp = make_mixed_inputs(m, k, n, wt, use_zp, DT[dname])
     got = mixed_precision_gemm(a.cuda(), packed.cuda(), w_s.cuda(), None if w_zp is None else w_zp.cuda(),
@@ -741,6 +745,44 @@ def test_scaled_gemm_c3_size_e4m3fnuz():
     rows = torch.cat([torch.arange(0, 48), torch.arange(2040, 2072), torch.arange(4080, 4096)])
     ref = oracle.scaled_gemm_ref(a[rows], b, sa[rows], sb, torch.bfloat16, None)
     check_scaled(got[rows.cuda()], ref, torch.float8_e4m3fnuz, torch.bfloat16, (a[rows], b, sa[rows], sb, None))
+
+
+@pytest.mark.parametrize(("m", "k", "n"), [(1024, 1024, 1024), (4096, 512, 2048), (600, 384, 1376)])
+@pytest.mark.parametrize("where", ["none", "a", "b", "both", "nan"])
+def test_scaled_gemm_e4m3fnuz_special_codes_take_the_exact_path(m, k, n, where):
+    """e4m3fnuz at the fp8 rate (round 4): the tile kernels run the raw bytes on the OCP fp8 MFMA (every code is twice its
+    fnuz value there, the exact 1/4 rides on scale_a) -- except the three codes that do not map: 0x7F / 0xFF are +-240 in fnuz
+    and NaN in OCP, 0x80 is NaN in fnuz and -0 in OCP.  A scan of both operands sets a device-side flag and the launch falls
+    to the exact bf16 expansion; the host never reads the flag.  Saturated operands (what a clamping quantiser emits) must
+    come out right, per element, wherever the codes sit; a fnuz NaN must poison exactly its row / column."""
+    a, b, sa, sb, bias = make_scaled_inputs(m, k, n, torch.float8_e4m3fnuz, torch.bfloat16, False, False, True)
+    ab, bb = a.view(torch.uint8).clone(), b.T.contiguous().view(torch.uint8).clone()  # [M][K], [N][K]
+    gen = torch.Generator().manual_seed(3)
+    if where in ("a", "both"):
+        idx = torch.randint(0, m * k, (37,), generator=gen)
+        ab.view(-1)[idx] = torch.where(torch.rand(37, generator=gen) < 0.5, 0x7F, 0xFF).to(torch.uint8)
+    if where in ("b", "both"):
+        bb[n - 1, k - 1] = 0xFF  # the very last byte of the operand
+        bb[5, 17] = 0x7F
+    if where == "nan":
+        ab[3, 100] = 0x80
+        bb[7, 1] = 0x80
+    a2, b2 = ab.view(torch.float8_e4m3fnuz), bb.view(torch.float8_e4m3fnuz).T
+    ref = oracle.scaled_gemm_ref(a2, b2, sa, sb, torch.bfloat16, bias)
+    for _ in range(2):  # twice: the flag is re-made by every call
+        got = run_scaled(a2, b2, sa, sb, torch.bfloat16, bias)
+        if where == "nan":
+            bad = torch.zeros((m, n), dtype=torch.bool)
+            bad[3, :] = True
+            bad[:, 7] = True
+            assert torch.equal(torch.isnan(got.float().cpu()), bad) and torch.equal(torch.isnan(ref.float()), bad)
+            ok = ~bad
+            assert (got.float().cpu()[ok] - ref.float()[ok]).abs().max().item() <= 2.0 * EPS[torch.bfloat16] * ref.float()[ok].abs().max().item()
+        else:
+            check_scaled(got, ref, torch.float8_e4m3fnuz, torch.bfloat16, (a2, b2, sa, sb, bias))
+    # and a clean call right behind a flagged one takes the fp8 kernel again (same bound)
+    clean = run_scaled(a, b, sa, sb, torch.bfloat16, bias)
+    check_scaled(clean, oracle.scaled_gemm_ref(a, b, sa, sb, torch.bfloat16, bias), torch.float8_e4m3fnuz, torch.bfloat16, (a, b, sa, sb, bias))
 
 
 @pytest.mark.parametrize("wname", list(WTYPES))

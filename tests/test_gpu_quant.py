@@ -67,17 +67,44 @@ def test_default_fp8_flavour_is_ocp_on_gfx950():
 
 
 @pytest.mark.parametrize("dname", list(DT))
-@pytest.mark.parametrize("sname", ["one", "s2p1"])
+@pytest.mark.parametrize("sname", ["one", "s2p1", "zdim"])
 def test_quant_edge_vectors_from_reference(golden, dname, sname):
-    """Ties, negative fractions, overflow both ways, subnormals: golden outputs of the reference."""
+    """Ties, negative fractions, overflow both ways, subnormals: golden outputs of the reference (`zdim`: a 0-dim scale)."""
     gi, gf = golden("quant_int8"), golden("quant_fp8")
     x = from_bits(gi[f"edge_x_{dname}_{sname}"], DT[dname]).cuda()
-    s = torch.from_numpy(gi[f"edge_s_{dname}_{sname}"]).cuda()
+    s = torch.from_numpy(np.asarray(gi[f"edge_s_{dname}_{sname}"])).cuda()
+    assert s.dim() == (0 if sname == "zdim" else 1)
     q, _ = scaled_int8_quant(x, s)
     np.testing.assert_array_equal(q.cpu().numpy(), gi[f"edge_q_{dname}_{sname}"])
     for flav, (_, tdt) in FP8.items():
         q8, _ = scaled_fp8_quant(x, s, output_dtype=tdt)
         np.testing.assert_array_equal(to_bits(q8), gf[f"edge_q{flav}_{dname}_{sname}"])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("scale", [0.3, 2.1, 0.0123])
+@pytest.mark.parametrize("shape", [(83, 768), (7, 67), (33, 200)])
+def test_int8_quant_with_a_0dim_scale_rounds_the_product_like_torch(dtype, scale, shape):
+    """A 0-dim scale does not take part in torch's type promotion: the reference oracle's `x * scale.reciprocal()`
+    (conch/reference/quantization/int8.py:16) is rounded to x's dtype before the clamp.  The kernel reproduces that (and the
+    fp32 product for every other one-element shape); the two differ on a few elements in a thousand, so the test also
+    requires that they DO differ somewhere for the 16-bit dtypes -- the path is really taken.  fp8 always multiplies in fp32
+    (fp8.py:16 casts x first)."""
+    seed_everything(0)
+    x = (torch.rand(*shape, dtype=torch.float32) * 400 - 150).to(dtype)
+    if shape == (33, 200):
+        x = torch.cat([x, x], dim=1)[:, 3:203]  # row-strided, unaligned: the per-row kernel
+    s0, s1 = torch.tensor(scale, dtype=torch.float32), torch.tensor([scale], dtype=torch.float32)
+    q0, ret = scaled_int8_quant(x.cuda(), s0.cuda())
+    q1, _ = scaled_int8_quant(x.cuda(), s1.cuda())
+    assert ret.dim() == 0
+    assert torch.equal(q0.cpu(), oracle.scaled_int8_quant_ref(x, s0))
+    assert torch.equal(q1.cpu(), oracle.scaled_int8_quant_ref(x, s1))
+    if dtype != torch.float and shape == (83, 768):
+        assert not torch.equal(q0, q1)
+    for name, tdt in FP8.values():
+        q8, _ = scaled_fp8_quant(x.cuda() / 100, s0.cuda(), output_dtype=tdt)
+        np.testing.assert_array_equal(to_bits(q8), to_bits(oracle.scaled_fp8_quant_ref(x / 100, s0, name)))
 
 
 def test_quant_golden_grid_subset(golden):
