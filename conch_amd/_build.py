@@ -13,7 +13,7 @@ PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libconch_amd.so"
-SOURCES = ["capi.hip", "quant.hip", "quant_dynamic.hip", "gemm_generic.hip", "repack.hip", "gemm_mfma.hip", "gemm_mid.hip", "gemm_skinny.hip", "gemm_mixed.hip", "gemm_mixed_skinny.hip", "gemm_modes.hip", "bnb.hip"]
+SOURCES = ["capi.hip", "quant.hip", "quant_dynamic.hip", "gemm_generic.hip", "repack.hip", "gemm_mfma.hip", "gemm_mid.hip", "gemm_skinny.hip", "gemm_mixed.hip", "gemm_mixed_strip.hip", "gemm_mixed_skinny.hip", "gemm_modes.hip", "bnb.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [
     "--offload-arch=gfx950",

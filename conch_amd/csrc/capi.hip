@@ -386,6 +386,10 @@ int run_mixed(const MixedGemmArgs& p, hipStream_t stream) {
     }
     return launch_mixed_gemm_generic(p, stream);
   }
+  // CONCH_TUNE_MIXED_KERNEL: 2 = the column-strip kernel (gemm_mixed_strip.hip) wherever its contract holds, 1 = never,
+  // 0 = auto (see mixed_strip_beats_tiles)
+  const int kernel = tuning(CONCH_TUNE_MIXED_KERNEL);
+  if (kernel != 1 && mixed_gemm_strip_supported(p) && (kernel == 2 || mixed_strip_beats_tiles(p))) return launch_mixed_gemm_strip(p, stream);
   return launch_mixed_gemm_mfma(p, stream);
 }
 

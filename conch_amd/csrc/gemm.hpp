@@ -141,6 +141,10 @@ int prepack_mixed_weights(uint32_t* image, uint32_t* plain, int64_t k, int64_t n
                           hipStream_t stream);
 int mixed_gemm_tile_nt(const MixedGemmArgs& p);
 int launch_mixed_gemm_mfma(const MixedGemmArgs& p, hipStream_t stream);
+// gemm_mixed_strip.hip: every wave dequantises its own column strip straight into MFMA operand registers
+bool mixed_gemm_strip_supported(const MixedGemmArgs& p);
+bool mixed_strip_beats_tiles(const MixedGemmArgs& p);
+int launch_mixed_gemm_strip(const MixedGemmArgs& p, hipStream_t stream);
 // gemm_mixed_skinny.hip -- decode batches (M <= 256 by a cost rule, N % 4 == 0, any K % 64 == 0): weights straight to MFMA registers, split-K (variant 4)
 bool mixed_gemm_skinny_supported(const MixedGemmArgs& p);
 int launch_mixed_gemm_skinny(const MixedGemmArgs& p, hipStream_t stream);

@@ -1,0 +1,574 @@
+// mixed_precision_gemm, M > 256: the COLUMN-STRIP kernel (round 4).
+//
+// Replaces, like gemm_mixed.hip, the mixed-precision instantiation of the reference's Triton kernel
+// (conch/kernels/quantization/gemm.py:176-216 dequantisation, :219-457 K loop, launcher :482-545).
+//
+// gemm_mixed.hip passes the dequantised weights through LDS: a thread converts its share of the tile's weights, writes them
+// with ds_write_b128 into the image the MFMA loop reads, and ONE workgroup barrier per K step separates the two.  Its loop
+// is two streams of ~2000 cycles per step -- the MFMAs and everything else -- that overlap to ~2900.  Here a
+// wave owns a COLUMN STRIP of the tile instead of a 128 x 64 block:
+//
+//   * tile = 256 rows x (64 WA + 64 WB) columns, eight waves: waves 0-3 own 16 WA columns each, waves 4-7 own 16 WB -- the two
+//     waves that share a SIMD (w, w + 4) are one wide and one narrow strip, so every SIMD carries the same MFMA work at every
+//     tile width: 256 (2, 2), 192 (2, 1), 128 (1, 1) columns;
+//   * a lane of the MFMA's weight operand is (column, 8-element k-group) = ONE packed int4 word (two int8 words) of the
+//     [K/pf][N] tensor: the wave fetches the words of its own columns, dequantises them in registers (ChunkDequant: the same
+//     arithmetic, bit-identical to w_ref) and multiplies -- no ds_write of weights, no weight fragment reads, no duplicated
+//     dequantisation (the columns of a strip belong to one wave), and the weights do not wait for the workgroup barrier;
+//   * the activations X (256 rows x 64 k per step = 32 KiB) are shared by all eight waves: LDS-DMA into a three-stage ring of
+//     the swizzled 8-row x 128-byte image every kernel of this library reads with conflict-free ds_read_b128; each X
+//     fragment feeds the strip's one or two MFMA tiles;
+//   * EVERYTHING a wave requests from memory is an LDS-DMA piece -- its four X pieces, the 1 KiB of packed words of its
+//     32-column group (16-byte chunks XOR-swizzled on the source side: conflict-free ds_read_b32), a 4-byte-per-lane piece
+//     with the group's scales (and one with its zero points) -- so the vector-memory queue holds no VGPR destination, hipcc
+//     inserts no wait of its own, and one counted `s_waitcnt vmcnt(ops per step)` per step keeps two K steps in flight;
+//   * per step and wave: 32 (16) x W MFMAs, 32 X-fragment reads, 2 W chunks dequantised for the NEXT step between the MFMAs
+//     (hand-placed slots, as in gemm_mixed.hip), one workgroup barrier.
+//
+// Contract on top of mixed_gemm_mfma_supported: plain [K/pf][N] weights with 16-byte aligned word rows, output dtype =
+// activation dtype, no fused gate/up form, no split-K (the LDS-tiled kernel keeps those).
+#include <algorithm>
+
+#include "common.hpp"
+#include "gemm.hpp"
+#include "mfma_tile.hpp"
+#include "epilogue_rows.hpp"
+#include "mixed_dequant.hpp"
+
+namespace conch {
+namespace {
+
+using namespace tile;
+using mixed::ChunkDequant;
+
+constexpr int kSsRows = 256;
+constexpr int kSsStepK = 64;                       // k elements per step = 128 bytes of fp16 / bf16
+constexpr int kSsXStage = kSsRows * kStepBytes;    // 32 KiB: 32 subtiles of 8 rows x 128 bytes
+constexpr int kSsStages = 3;                       // X ring (and every per-wave ring): step t read, t + 1 landing, t + 2 requested
+constexpr int kSsMeta = 256;                       // bytes of one 4-byte-per-lane LDS-DMA piece
+
+#ifdef CONCH_CLOCK_PROBE
+__device__ unsigned long long g_probe_mixed_strip[kProbeBlocks * 8];
+#endif
+
+template <int BITS, bool ZPT>
+struct StripLds {
+  static constexpr int kWPieces = BITS == 4 ? 1 : 2;             // 8 (16) word rows x 128 bytes (32 columns) per K step
+  static constexpr int kWSlot = kWPieces * 1024;
+  static constexpr int kW = kSsStages * kSsXStage;               // + (wave * kSsStages + slot) * kWSlot
+  static constexpr int kS = kW + 8 * kSsStages * kWSlot;         // + (wave * kSsStages + slot) * kSsMeta
+  static constexpr int kZ = kS + 8 * kSsStages * kSsMeta;
+  static constexpr int kRing = kZ + (ZPT ? 8 * kSsStages * kSsMeta : 0);
+  static constexpr int kOps = 4 + kWPieces + 1 + (ZPT ? 1 : 0);  // vector-memory operations per wave and K step
+};
+
+// wave-uniform descriptors and strides
+struct StripSrc {
+  __amdgpu_buffer_rsrc_t x, q, s, z;
+  int x_rows8;          // bytes of X between two of a wave's pieces (8 rows)
+  int q_step;           // bytes of w_q per K step
+  int s_group, z_group; // bytes per group row of w_s / w_zp
+  int steps_per_group;
+};
+
+// per-lane constants (few: the wide strips run at the 256-register limit)
+struct StripLane {
+  int vx[2];            // source byte offsets of the wave's X pieces 0 / 1 (pieces 2 / 3: + 16 rows, in the scalar offset; the
+                        // swizzle (row >> 1) & 7 of a piece's rows differs between even and odd pieces only)
+  int vq;               // ... of its packed-word piece(s), less the wave-uniform column-group part (in StripIssue::q_off)
+  int lane4;            // 4 * lane: the 4-byte-per-lane scale / zero-point pieces (column group in the scalar offset)
+  int a_lo, a_hi;       // X fragment read offset of this lane inside a stage (chunk g / chunk g + 4), m tile 0
+  int w_rd;             // packed-word read offset inside the wave's word slot: n tile 0, k half 0, first word (n tile 1: ^ 64)
+  int c2;               // 2 * (this lane's column inside the wave's 32-column group), n tile 0: scale read offset (zero point: 2 x)
+};
+
+// wave-uniform cursor of the NEXT K step to request
+struct StripIssue {
+  int step, slot, q_off, s_off, z_off, left;
+};
+
+template <int BITS, bool ZPT>
+__device__ __forceinline__ void issue_op(int op, char* lds, const StripSrc& u, const StripLane& ln, int wave, const StripIssue& is) {
+  using L = StripLds<BITS, ZPT>;
+  if (op < 4) {
+#ifdef CONCH_EXP_STRIP_NOXDMA
+    if (is.step > 2) return;
+#endif
+    char* dst = lds + is.slot * kSsXStage + (4 * wave + op) * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(u.x, (lds_void_t*)dst, 16, ln.vx[op & 1], is.step * kStepBytes + (op >> 1) * 2 * u.x_rows8, 0, 0);
+  } else if (op < 4 + L::kWPieces) {
+    const int e = op - 4;
+    char* dst = lds + L::kW + (wave * kSsStages + is.slot) * L::kWSlot + e * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(u.q, (lds_void_t*)dst, 16, ln.vq, is.q_off + e * (u.q_step / L::kWPieces), 0, 0);
+  } else if (op == 4 + L::kWPieces) {
+    char* dst = lds + L::kS + (wave * kSsStages + is.slot) * kSsMeta;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(u.s, (lds_void_t*)dst, 4, ln.lane4, is.s_off, 0, 0);
+  } else if (ZPT) {
+    char* dst = lds + L::kZ + (wave * kSsStages + is.slot) * kSsMeta;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(u.z, (lds_void_t*)dst, 4, ln.lane4, is.z_off, 0, 0);
+  }
+}
+
+__device__ __forceinline__ void advance(StripIssue& is, const StripSrc& u) {
+  const bool wrap = is.left == 1;
+  is.step += 1;
+  is.slot = is.slot == kSsStages - 1 ? 0 : is.slot + 1;
+  is.q_off += u.q_step;
+  is.left = wrap ? u.steps_per_group : is.left - 1;
+  is.s_off += wrap ? u.s_group : 0;
+  is.z_off += wrap ? u.z_group : 0;
+}
+
+template <int BITS, bool ZPT>
+__device__ __forceinline__ void issue_all(char* lds, const StripSrc& u, const StripLane& ln, int wave, StripIssue& is) {
+#pragma unroll
+  for (int op = 0; op < StripLds<BITS, ZPT>::kOps; ++op) issue_op<BITS, ZPT>(op, lds, u, ln, wave, is);
+  advance(is, u);
+}
+
+// the dequantised weights of one K step: [n tile][k half] -> the 8 halfs a lane holds of its column
+template <int W>
+struct StripB {
+  i32x4 v[W][2];
+};
+
+// packed words / scale / zero point of one K step as read back from the wave's LDS slots
+template <int BITS, int W>
+struct StripRaw {
+  uint32_t w[W][2][BITS == 4 ? 1 : 2];
+  uint32_t scale[W];
+  int zp[W];
+};
+
+template <int BITS, bool ZPT, int W>
+__device__ __forceinline__ void read_raw(StripRaw<BITS, W>& r, const char* lds, const StripLane& ln, int wave, int slot) {
+  using L = StripLds<BITS, ZPT>;
+  const char* wq = lds + L::kW + (wave * kSsStages + slot) * L::kWSlot;
+  const char* ws = lds + L::kS + (wave * kSsStages + slot) * kSsMeta;
+  const char* wz = lds + L::kZ + (wave * kSsStages + slot) * kSsMeta;
+#pragma unroll
+  for (int nt = 0; nt < W; ++nt) {
+    // n tile 1 (wide strips: the group's columns 16-31): chunk index + 4 = ^ 4 (the wave's columns start a group), i.e. ^ 64 bytes
+    const int wo = nt ? (ln.w_rd ^ 64) : ln.w_rd;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if constexpr (BITS == 4) {
+        r.w[nt][h][0] = *(const uint32_t*)(wq + wo + h * 512);           // word row 4 h + g
+      } else {
+        r.w[nt][h][0] = *(const uint32_t*)(wq + wo + h * 1024);          // word rows 8 h + 2 g, + 1
+        r.w[nt][h][1] = *(const uint32_t*)(wq + wo + h * 1024 + 128);
+      }
+    }
+    r.scale[nt] = *(const uint16_t*)(ws + ln.c2 + nt * 32);
+    if constexpr (ZPT) r.zp[nt] = *(const int*)(wz + 2 * ln.c2 + nt * 64);
+    else r.zp[nt] = 0;
+  }
+}
+
+template <int X_DT>
+__device__ __forceinline__ void strip_mma(f32x4& acc, const i32x4& wfrag, const i32x4& xfrag) {
+  // operands swapped as everywhere in this library: D rows = n (4 g + e), D columns = m (lane % 16)
+#ifdef CONCH_EXP_STRIP_NOMFMA  // timing experiments (wrong results; experiment builds only): see tools/ab_strip_variants.py
+  asm volatile("" ::"v"(wfrag), "v"(xfrag));
+  return;
+#endif
+  if constexpr (X_DT == CONCH_DT_FP16)
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wfrag), __builtin_bit_cast(f16x8, xfrag), acc, 0, 0, 0);
+  else
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wfrag), __builtin_bit_cast(bf16x8, xfrag), acc, 0, 0, 0);
+}
+
+template <int X_DT, int BITS>
+using StripDequant = ChunkDequant<X_DT, BITS, (X_DT == CONCH_DT_BF16 && BITS == 8)>;  // rounding the difference is a no-op without a zero point
+
+struct StripConst {
+  int off_base;
+  uint32_t and_mask, or_magic, and_mask_hi;
+};
+
+template <int W>
+struct StripSlots {
+  static constexpr int kSlots = 32 * W;       // MFMAs of a wave and K step: pair p = (k half p / 16, m tile p % 16) x W n tiles
+  static constexpr int kHalf = 16 * W;        // first slot of the second k half
+  static constexpr int kWait = kHalf - 2;     // the counted wait for this wave's pieces of step t + 1
+  static constexpr int kRaw = kHalf - 1;      // ... whose packed words / scales are read back here
+  static constexpr int kBar = 24 * W;         // the workgroup barrier sits in FRONT of this slot's MFMA (behind m tile 7 of k half 1)
+  static constexpr int kIssue0 = kBar;        // first of the kOps request slots (step t + 3): the fillers of slot kBar run behind the barrier
+  static constexpr int kSl = 9;               // ChunkDequant slices that make a chunk (the tenth is gemm_mixed.hip's ds_write)
+  static constexpr int kN = kSl * W;          // slices per k half
+  static constexpr int kSpan1 = kHalf - 2;    // k half 1 of THIS step is converted in slots [0, kSpan1), one slice per slot at most
+  static constexpr int kSpan0 = kHalf;        // k half 0 of the NEXT step in slots [kHalf, kSlots)
+  // slice i of a half sits at slot base + i * span / kN (span >= kN: distinct slots); -1 = no slice in this slot
+  static constexpr int slice_at(int s, int base, int span) {
+    if (s < base || s >= base + span) return -1;
+    const int i = ((s - base) * kN + span - 1) / span;
+    return (i < kN && base + i * span / kN == s) ? i : -1;
+  }
+};
+
+// one slice of the conversion of chunk (n tile NT, k half H)
+template <int X_DT, int BITS, int W, int NT, int H, int SUB>
+__device__ __forceinline__ void strip_slice(StripB<W>& b, const StripRaw<BITS, W>& raw, StripDequant<X_DT, BITS>& cv, const StripConst& k) {
+  cv.slice(SUB, raw.w[NT][H][0], raw.w[NT][H][BITS == 4 ? 0 : 1], k.off_base + raw.zp[NT], raw.scale[NT], nullptr, k.and_mask, k.or_magic, k.and_mask_hi);
+  if constexpr (SUB == StripSlots<W>::kSl - 1) b.v[NT][H] = cv.out;
+}
+
+// The work placed behind MFMA number SL of a step.  Slot numbers are TEMPLATE parameters and the step below is a compile-time
+// recursion over them: as a `#pragma unroll` loop with the slot in a variable the body was "too large to unroll fully as directed"
+// for hipcc, the accumulator array stayed indexed by a run-time value and went to scratch.
+// MODE 0: steps t + 1 .. t + 3 exist (t + 3 is requested here); 1: t + 1, t + 2 exist; 2: t + 1 exists; 3: last step.
+template <int X_DT, int BITS, bool ZPT, int W, int MODE, int SL>
+__device__ __forceinline__ void strip_filler(StripB<W>& b, StripRaw<BITS, W>& raw, StripDequant<X_DT, BITS>& cv, char* lds, const StripSrc& u,
+                                             const StripLane& ln, const StripConst& k, int wave, StripIssue& is, int next_slot) {
+  using L = StripLds<BITS, ZPT>;
+  using S = StripSlots<W>;
+#ifndef CONCH_EXP_STRIP_NODQ
+  {  // k half 1 of this step: raw still holds this step's words
+    constexpr int i = S::slice_at(SL, 0, S::kSpan1);
+    if constexpr (i >= 0) strip_slice<X_DT, BITS, W, i / S::kSl, 1, i % S::kSl>(b, raw, cv, k);
+  }
+#endif
+  if constexpr (MODE <= 2) {
+#ifndef CONCH_EXP_STRIP_NOWAIT
+    if constexpr (SL == S::kWait) {  // this wave's pieces of step t + 1 have landed; the requests of step t + 2 may stay in flight
+      if constexpr (MODE <= 1) wait_vmcnt_n<L::kOps>();
+      else CONCH_VMCNT(0);
+    }
+#endif
+    if constexpr (SL == S::kRaw) read_raw<BITS, ZPT, W>(raw, lds, ln, wave, next_slot);
+#ifndef CONCH_EXP_STRIP_NODQ
+    {  // k half 0 of the next step, into the registers this step's first half has finished with
+      constexpr int i = S::slice_at(SL, S::kHalf, S::kSpan0);
+      if constexpr (i >= 0) strip_slice<X_DT, BITS, W, i / S::kSl, 0, i % S::kSl>(b, raw, cv, k);
+    }
+#endif
+  }
+  if constexpr (MODE == 0) {
+    if constexpr (SL >= S::kIssue0 && SL < S::kIssue0 + L::kOps) issue_op<BITS, ZPT>(SL - S::kIssue0, lds, u, ln, wave, is);
+    if constexpr (SL == S::kIssue0 + L::kOps - 1) advance(is, u);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+struct StripPtrs {
+  const char* xlo;  // this step's X stage + the lane's fragment offset, chunk g
+  const char* xhi;  // ... chunk g + 4
+  const char* nlo;  // the next step's stage, chunk g
+};
+
+// Slots SL .. 32 W - 1 of one K step of one wave: pair p = SL / W = (k half p / 16, m tile p % 16), n tile SL % W.
+template <int X_DT, int BITS, bool ZPT, int W, int MODE, int SL>
+__device__ __forceinline__ void strip_slots(f32x4 (&acc)[16][W], StripB<W>& b, StripRaw<BITS, W>& raw, StripDequant<X_DT, BITS>& cv, i32x4 (&a)[8],
+                                            const StripPtrs& px, char* lds, const StripSrc& u, const StripLane& ln, const StripConst& k, int wave,
+                                            StripIssue& is, int next_slot) {
+  using S = StripSlots<W>;
+  constexpr int P = 8;  // X fragments in flight
+  constexpr int p = SL / W, nt = SL % W;
+  if constexpr (MODE <= 2 && SL == S::kBar) {
+    // Every read of this step's X stage has been ISSUED (the last refill sits behind pair 23); retire them, then meet: behind
+    // the barrier every wave's pieces of step t + 1 have landed (each waited for its own at kWait) and this step's stage is
+    // free for the requests of step t + 3.
+#ifndef CONCH_EXP_STRIP_NOBAR
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+  }
+  strip_mma<X_DT>(acc[p & 15][nt], b.v[nt][p >> 4], a[p % P]);
+#ifndef CONCH_EXP_STRIP_NOREAD
+  if constexpr (nt == W - 1) {
+    constexpr int q = p + P;
+    if constexpr (q < 32) a[p % P] = *(const i32x4*)((q >> 4 ? px.xhi : px.xlo) + (q & 15) * 2048);
+    else if constexpr (MODE <= 2) a[p % P] = *(const i32x4*)(px.nlo + (q - 32) * 2048);  // pairs 0-7 of the next step: k half 0
+  }
+#endif
+  strip_filler<X_DT, BITS, ZPT, W, MODE, SL>(b, raw, cv, lds, u, ln, k, wave, is, next_slot);
+  if constexpr (SL + 1 < S::kSlots) strip_slots<X_DT, BITS, ZPT, W, MODE, SL + 1>(acc, b, raw, cv, a, px, lds, u, ln, k, wave, is, next_slot);
+}
+
+// One K step of one wave.  On entry the first 8 X fragments of the step are in `a` (read behind the previous step's barrier).
+// `slot` = ring slot of step t, `next_slot` = of step t + 1.
+template <int X_DT, int BITS, bool ZPT, int W, int MODE>
+__device__ __forceinline__ void strip_step(f32x4 (&acc)[16][W], StripB<W>& b, StripRaw<BITS, W>& raw, i32x4 (&a)[8], char* lds, const StripSrc& u,
+                                           const StripLane& ln, const StripConst& k, int wave, StripIssue& is, int slot, int next_slot) {
+  using L = StripLds<BITS, ZPT>;
+  using S = StripSlots<W>;
+  static_assert(S::kIssue0 + L::kOps <= S::kSlots, "the step's requests fit behind its barrier");
+  static_assert(S::kSpan1 >= S::kN && S::kSpan0 >= S::kN, "one dequantisation slice per slot at most");
+  const StripPtrs px = {lds + slot * kSsXStage + ln.a_lo, lds + slot * kSsXStage + ln.a_hi, lds + next_slot * kSsXStage + ln.a_lo};
+  StripDequant<X_DT, BITS> cv;  // ONE conversion in progress: a chunk's slices occupy consecutive slice slots
+  strip_slots<X_DT, BITS, ZPT, W, MODE, 0>(acc, b, raw, cv, a, px, lds, u, ln, k, wave, is, next_slot);
+}
+
+template <int X_DT, int BITS, bool ZPT, int W>
+__device__ __forceinline__ void strip_loop(f32x4 (&acc)[16][W], char* lds, const StripSrc& u, const StripLane& ln, const StripConst& k, int wave,
+                                           int steps, int q0, int s0, int z0) {
+  using L = StripLds<BITS, ZPT>;
+  StripIssue is = {0, 0, q0, s0, z0, u.steps_per_group};
+  issue_all<BITS, ZPT>(lds, u, ln, wave, is);
+  if (steps > 1) issue_all<BITS, ZPT>(lds, u, ln, wave, is);
+  if (steps > 2) issue_all<BITS, ZPT>(lds, u, ln, wave, is);
+  if (steps > 2) wait_vmcnt_n<2 * L::kOps>();
+  else if (steps > 1) wait_vmcnt_n<L::kOps>();
+  else CONCH_VMCNT(0);
+  __builtin_amdgcn_sched_barrier(0);
+  // k half 0 of step 0, converted at once (k half 1 follows inside the step, like every step's)
+  StripB<W> b;
+  StripRaw<BITS, W> raw;
+  read_raw<BITS, ZPT, W>(raw, lds, ln, wave, 0);
+#pragma unroll
+  for (int nt = 0; nt < W; ++nt) {
+    StripDequant<X_DT, BITS> cv;
+#pragma unroll
+    for (int s = 0; s < 9; ++s)
+      cv.slice(s, raw.w[nt][0][0], raw.w[nt][0][BITS == 4 ? 0 : 1], k.off_base + raw.zp[nt], raw.scale[nt], nullptr, k.and_mask, k.or_magic, k.and_mask_hi);
+    b.v[nt][0] = cv.out;
+    b.v[nt][1] = i32x4{0, 0, 0, 0};
+  }
+  __builtin_amdgcn_s_barrier();  // every wave's X pieces of step 0 have landed
+  __builtin_amdgcn_sched_barrier(0);
+  i32x4 a[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a[j] = *(const i32x4*)(lds + ln.a_lo + j * 2048);
+  int slot = 0;
+  int t = 0;
+  auto next_of = [](int sl_) { return sl_ == kSsStages - 1 ? 0 : sl_ + 1; };
+  for (; t + 3 < steps; ++t) {
+    strip_step<X_DT, BITS, ZPT, W, 0>(acc, b, raw, a, lds, u, ln, k, wave, is, slot, next_of(slot));
+    slot = next_of(slot);
+  }
+  if (steps > 2) {
+    strip_step<X_DT, BITS, ZPT, W, 1>(acc, b, raw, a, lds, u, ln, k, wave, is, slot, next_of(slot));
+    slot = next_of(slot);
+  }
+  if (steps > 1) {
+    strip_step<X_DT, BITS, ZPT, W, 2>(acc, b, raw, a, lds, u, ln, k, wave, is, slot, next_of(slot));
+    slot = next_of(slot);
+  }
+  strip_step<X_DT, BITS, ZPT, W, 3>(acc, b, raw, a, lds, u, ln, k, wave, is, slot, 0);
+}
+
+// Epilogue of one wave: cast to the output dtype (one rounding of the fp32 sum, as the reference's `accumulator.to(out)`), then
+// whole tiles leave through the workgroup-built row-major image (epilogue_rows.hpp), others by direct 8-byte stores.
+template <int OUT_DT, int W, int TILE_N>
+__device__ __forceinline__ void strip_epilogue(const f32x4 (&acc)[16][W], const MixedGemmArgs& p, char* lds, int bm0, int bn0, int col0, int lane,
+                                               int wave, bool whole) {
+  constexpr int kPitch = TILE_N * 2;
+  const int g = lane >> 4, r = lane & 15;
+  if (whole) {
+    // (the caller's closing __syncthreads() made the rings dead)
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+      for (int nt = 0; nt < W; ++nt) {
+        const f32x4& v = acc[i][nt];
+        const i32x2 pk = {(int)pack2_bits16<OUT_DT>(f32x2{v[0], v[1]}), (int)pack2_bits16<OUT_DT>(f32x2{v[2], v[3]})};
+        const int row = 16 * i + r;
+        const int chunk = (col0 >> 3) + 2 * nt + (g >> 1);
+        *(i32x2*)(lds + image_chunk_offset<kPitch>(row, chunk) + (g & 1) * 8) = pk;
+      }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int m = bm0 + 16 * i + r;
+      if (m >= (int)p.m) continue;
+#pragma unroll
+      for (int nt = 0; nt < W; ++nt) {
+        const f32x4& v = acc[i][nt];
+        const i32x2 pk = {(int)pack2_bits16<OUT_DT>(f32x2{v[0], v[1]}), (int)pack2_bits16<OUT_DT>(f32x2{v[2], v[3]})};
+        const int n0 = bn0 + col0 + 16 * nt + 4 * g;
+        uint16_t* dst = (uint16_t*)p.c + (int64_t)m * p.c_stride_m + n0;
+        if (n0 + 4 <= (int)p.n && (((uintptr_t)dst) & 7) == 0) {
+          *(i32x2*)dst = pk;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n0 + e < (int)p.n) dst[e] = (uint16_t)((uint32_t)pk[e >> 1] >> (16 * (e & 1)));
+        }
+      }
+    }
+  }
+}
+
+template <int X_DT, int BITS, bool ZPT, int W, int TILE_N>
+__device__ __forceinline__ void strip_wave(const MixedGemmArgs& p, char* lds, const StripSrc& u, StripLane& ln, const StripConst& k, int wave, int lane,
+                                           int bm0, int bn0, int col0, int steps) {
+  const int r = lane & 15, g = lane >> 4;
+  const int gb = col0 & ~31, local = col0 & 31;  // the 32-column group whose words / scales this wave fetches, and its place in it
+  // packed words: piece row L >> 3 (a word row), 16-byte chunk L & 7 = four columns; chunks XORed with 4 for odd word rows
+  // (int8: odd PAIRS of word rows) so that the operand read -- lanes (r, g): word row [2] g, column local + 16 nt + r --
+  // spreads its two word rows per half-wave over both halves of the bank row
+  {
+    const int prow = lane >> 3, pos = lane & 7;
+    const int swz = 4 * ((BITS == 4 ? prow : prow >> 1) & 1);
+    ln.vq = prow * (u.q_step / (kSsStepK * BITS / 32)) + (pos ^ swz) * 16;
+    ln.lane4 = lane * 4;
+  }
+  {
+    const int c = local + r;  // n tile 0
+    ln.w_rd = (BITS == 4 ? g : 2 * g) * 128 + ((((c >> 2) ^ (4 * (g & 1)))) * 16) + (c & 3) * 4;
+    ln.c2 = c * 2;
+  }
+  const int q0 = (bn0 + gb) * 4, s0 = (bn0 + gb) * 2, z0 = (bn0 + gb) * 4;  // the column group, in the scalar offsets
+  CONCH_PROBE(g_probe_mixed_strip, 0);
+  f32x4 acc[16][W];
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+#pragma unroll
+    for (int nt = 0; nt < W; ++nt) acc[i][nt] = f32x4{0, 0, 0, 0};
+  strip_loop<X_DT, BITS, ZPT, W>(acc, lds, u, ln, k, wave, steps, q0, s0, z0);
+  CONCH_PROBE(g_probe_mixed_strip, 1);
+  const bool whole = p.rows_epilogue && (p.c_stride_m % 8 == 0) && (((uintptr_t)p.c & 15) == 0) && bm0 + kSsRows <= (int)p.m && bn0 + TILE_N <= (int)p.n &&
+                     ((p.m - 1) * p.c_stride_m + p.n) * 2 < ((int64_t)1 << 32);  // workgroup-uniform
+  __syncthreads();  // every wave is past its last read of the rings (a fence too: see gemm_mixed.hip, mixed_epilogue_rows)
+  strip_epilogue<X_DT, W, TILE_N>(acc, p, lds, bm0, bn0, col0, lane, wave, whole);
+  if (whole) {
+    __syncthreads();
+    image_store_rows<kSsRows, TILE_N * 2>(lds, p.c, p.m, p.n, p.c_stride_m, bm0, bn0, lane, wave);
+  }
+}
+
+template <int X_DT, int BITS, bool ZPT, int WA, int WB>
+__global__ __launch_bounds__(kThreads, 2) void mixed_strip_kernel(MixedGemmArgs p) {
+  using L = StripLds<BITS, ZPT>;
+  constexpr int kTileN = 64 * WA + 64 * WB;
+  constexpr int kImage = kSsRows * kTileN * 2;
+  constexpr int kLds = L::kRing > kImage ? L::kRing : kImage;
+  static_assert(kLds <= 160 * 1024, "LDS budget");
+  __shared__ __attribute__((aligned(1024))) char lds[kLds];
+#if defined(__HIP_DEVICE_COMPILE__)  // the HOST pass of hipcc (ROCm 7.2) fails to substitute issue_op<> inside strip_filler<> ("no
+                                     // matching function", no reason given; the device pass takes it): it only needs the stub
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int tiles_m = ((int)p.m + kSsRows - 1) / kSsRows;
+  const int tiles_n = ((int)p.n + kTileN - 1) / kTileN;
+  const TileCoord tc = map_tile(blockIdx.x, tiles_m, tiles_n, p.raster_magic, p.raster_shift);
+  const int bm0 = tc.tm * kSsRows, bn0 = tc.tn * kTileN;
+  const int steps = (int)(p.k / kSsStepK);
+
+  StripSrc u;
+  const int64_t word_rows = p.k * BITS / 32, groups = p.k / p.group_size;
+  u.x = make_uniform_rsrc(p.x, (uint32_t)(((p.m - 1) * p.x_stride_m + p.k) * 2));
+  u.q = make_uniform_rsrc(p.w_q, (uint32_t)(((word_rows - 1) * p.wq_stride_k + p.n) * 4));
+  u.s = make_uniform_rsrc(p.w_s, (uint32_t)(((groups - 1) * p.ws_stride_g + p.n) * 2));
+  u.z = u.s;
+  if constexpr (ZPT) u.z = make_uniform_rsrc(p.w_zp, (uint32_t)(((groups - 1) * p.wzp_stride_g + p.n) * 4));
+  u.q_step = (kSsStepK * BITS / 32) * (int)p.wq_stride_k * 4;
+  u.s_group = (int)p.ws_stride_g * 2;
+  u.z_group = (int)p.wzp_stride_g * 4;
+  u.steps_per_group = p.group_size / kSsStepK;
+
+  StripLane ln;
+  {
+    // piece j of the wave = rows 32 wave + 8 j .. + 7; rows past M are past the END of the buffer (row M starts at M ldx >=
+    // (M - 1) ldx + K): the range check of the buffer load zero-fills them, no clamp
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = 32 * wave + 8 * j + (lane >> 3);
+      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+      ln.vx[j] = (bm0 + row) * ((int)p.x_stride_m * 2) + chunk * 16;
+    }
+  }
+  u.x_rows8 = 8 * (int)p.x_stride_m * 2;
+  {
+    const int fr = lane & 15, fg = lane >> 4;
+    ln.a_lo = (fr >> 3) * 1024 + (fr & 7) * 128 + ((fg ^ ((fr >> 1) & 7)) * 16);
+    ln.a_hi = ln.a_lo ^ 64;
+  }
+  StripConst k;
+  k.off_base = p.weight_bias + (p.zp_mode == CONCH_ZP_SCALAR ? p.w_zp[0] : 0);
+  k.and_mask = BITS == 4 ? 0x000f000fu : 0x00ff00ffu;
+  k.or_magic = 0x64006400u;
+  k.and_mask_hi = k.and_mask << 4;
+  asm volatile("" : "+v"(k.and_mask), "+s"(k.or_magic), "+v"(k.and_mask_hi));
+
+  if constexpr (WA == WB) {
+    strip_wave<X_DT, BITS, ZPT, WA, kTileN>(p, lds, u, ln, k, wave, lane, bm0, bn0, wave * 16 * WA, steps);
+  } else {
+    if (wave < 4) strip_wave<X_DT, BITS, ZPT, WA, kTileN>(p, lds, u, ln, k, wave, lane, bm0, bn0, wave * 16 * WA, steps);
+    else strip_wave<X_DT, BITS, ZPT, WB, kTileN>(p, lds, u, ln, k, wave, lane, bm0, bn0, 64 * WA + (wave - 4) * 16 * WB, steps);
+  }
+#endif
+}
+
+template <int X_DT, int BITS, bool ZPT>
+int launch_width(const MixedGemmArgs& p, int nt, hipStream_t stream) {
+  const int tile_n = 64 * nt;
+  const int tiles_m = (int)((p.m + kSsRows - 1) / kSsRows), tiles_n = (int)((p.n + tile_n - 1) / tile_n);
+  const dim3 grid((unsigned)(tiles_m * tiles_n)), block(kThreads);
+  if (nt == 4) hipLaunchKernelGGL((mixed_strip_kernel<X_DT, BITS, ZPT, 2, 2>), grid, block, 0, stream, p);
+  else if (nt == 3) hipLaunchKernelGGL((mixed_strip_kernel<X_DT, BITS, ZPT, 2, 1>), grid, block, 0, stream, p);
+  else hipLaunchKernelGGL((mixed_strip_kernel<X_DT, BITS, ZPT, 1, 1>), grid, block, 0, stream, p);
+  return check_launch("mixed_gemm_strip");
+}
+
+template <int X_DT, int BITS>
+int launch_zp(const MixedGemmArgs& p, int nt, hipStream_t stream) {
+  return p.zp_mode == CONCH_ZP_TENSOR ? launch_width<X_DT, BITS, true>(p, nt, stream) : launch_width<X_DT, BITS, false>(p, nt, stream);
+}
+
+}  // namespace
+
+bool mixed_gemm_strip_supported(const MixedGemmArgs& p) {
+  if (!mixed_gemm_mfma_supported(p)) return false;
+  if (p.fuse_silu || p.prepacked || p.split_steps || p.slabs) return false;
+  if (p.out_dtype != p.x_dtype) return false;
+  // bf16 x 8-bit weights: the widening dequantisation (fp32 pairs, the difference rounded to bf16 first) on top of 128 accumulators
+  // and 16 + 16 operand registers spills in the wide strips (288 bytes of scratch per lane inside the K loop); the LDS-tiled
+  // kernel keeps that combination
+  if (p.x_dtype == CONCH_DT_BF16 && p.bits == 8) return false;
+  // LDS-DMA of 16 bytes per lane: aligned word rows; of 4 bytes per lane: aligned scale / zero-point rows
+  if ((((uintptr_t)p.w_q) & 15) || p.wq_stride_k % 4) return false;
+  if ((((uintptr_t)p.w_s) & 3) || p.ws_stride_g % 2) return false;
+  if (p.zp_mode == CONCH_ZP_TENSOR && ((((uintptr_t)p.w_zp) & 3))) return false;
+  return true;
+}
+
+int pick_strip_nt(const MixedGemmArgs& p, int num_cus);
+
+// Auto rule, from the interleaved sweep of 48 shapes x the two kernels (profiles/r04/mixed_strip_sweep.txt).  On the benchmark's
+// data both kernels run against the chip's POWER limit (in-loop clock 1.75-1.85 GHz; on all-zero activations, where the clock stays
+// at 2.4 GHz, the strip kernel is 4-8 % ahead: profiles/r04/mixed_strip_zero_data.txt), so the strip kernel's better schedule buys
+// 1-9 % where its tiles fill the chip and N is wide (N >= 8192: 384..768 x 4096 x 11008 -4..-9 %, x 28672 -1..-7 %, M >= 1536 -1..-3 %)
+// and nothing at N = 4096; with few tiles the LDS-tiled kernel's split-K form wins by 5-120 % (the strip kernel has none).
+bool mixed_strip_beats_tiles(const MixedGemmArgs& p) {
+  if (p.n < 8192) return false;
+  const int cus = device_cu_count();
+  const int nt = pick_strip_nt(p, cus);
+  const int64_t tiles = ((p.m + kSsRows - 1) / kSsRows) * ((p.n + 64 * nt - 1) / (64 * nt));
+  return tiles * 100 >= (int64_t)cus * 65;
+}
+
+// tile width (64 nt columns) that needs the least (rounds of workgroups) x (work per workgroup): every SIMD carries nt / 4 of
+// the 256-column tile's MFMAs at every width
+int pick_strip_nt(const MixedGemmArgs& p, int num_cus) {
+  const int64_t tiles_m = (p.m + kSsRows - 1) / kSsRows;
+  int best = 4;
+  double best_cost = 1e30;
+  for (int nt = 4; nt >= 2; --nt) {
+    const int64_t tiles = tiles_m * ((p.n + 64 * nt - 1) / (64 * nt));
+    const double cost = (double)((tiles + num_cus - 1) / num_cus) * (nt + 0.6);
+    if (cost < best_cost - 1e-9) {
+      best_cost = cost;
+      best = nt;
+    }
+  }
+  return best;
+}
+
+int launch_mixed_gemm_strip(const MixedGemmArgs& p_in, hipStream_t stream) {
+  MixedGemmArgs p = p_in;
+  p.rows_epilogue = tuning(CONCH_TUNE_EPILOGUE) != 1;
+  const int forced = tuning(CONCH_TUNE_MIXED_TILE_NT);
+  const int nt = (forced >= 2 && forced <= 4) ? forced : pick_strip_nt(p, device_cu_count());
+  set_raster_divisor((uint32_t)(kGroupM * ((p.n + 64 * nt - 1) / (64 * nt))), &p.raster_magic, &p.raster_shift);
+  if (p.x_dtype == CONCH_DT_FP16) return p.bits == 4 ? launch_zp<CONCH_DT_FP16, 4>(p, nt, stream) : launch_zp<CONCH_DT_FP16, 8>(p, nt, stream);
+  return launch_zp<CONCH_DT_BF16, 4>(p, nt, stream);  // (bf16 x 8-bit: not built, see mixed_gemm_strip_supported)
+}
+
+}  // namespace conch
+
+#ifdef CONCH_CLOCK_PROBE
+CONCH_PROBE_READER(conch_debug_probe_mixed_strip, conch::g_probe_mixed_strip)
+#endif
