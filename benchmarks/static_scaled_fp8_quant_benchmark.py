@@ -21,7 +21,9 @@ from conch_amd.third_party.vllm.utils import seed_everything
 @click.option("--verbose", is_flag=True)
 @click.option("--gpu", default="cuda:0")
 @click.option("--csv", is_flag=True)
-def main(hidden_size, num_tokens, scale, dynamic, dtype_name, fnuz, iteration_time_ms, warmup_time_ms, verbose, gpu, csv):
+@click.option("--compile-ref", is_flag=True, help="torch.compile() the PyTorch baseline (the reference's flag; needs a working Inductor backend)")
+@click.option("--compile-conch", is_flag=True, help="torch.compile() the conch_amd op: captured as ONE opaque custom op (ops/quantization/_compile.py)")
+def main(hidden_size, num_tokens, scale, dynamic, dtype_name, fnuz, iteration_time_ms, warmup_time_ms, verbose, gpu, csv, compile_ref, compile_conch):
     seed_everything(0)
     device = torch.device(gpu)
     dtype = DTYPES[dtype_name]
@@ -53,7 +55,13 @@ def main(hidden_size, num_tokens, scale, dynamic, dtype_name, fnuz, iteration_ti
         amax = x.float().abs().amax(dim=-1, keepdim=True)
         return (x.float() * (amax / lim).reciprocal()).clamp(-lim, lim).to(fp8)
 
-    run_pair("dynamic_scaled_fp8_quant" if dynamic else "static_scaled_fp8_quant", lambda: scaled_fp8_quant(x, s, output_dtype=fp8),
+    ours = lambda: scaled_fp8_quant(x, s, output_dtype=fp8)  # noqa: E731
+    if compile_conch and not dynamic:  # (the dynamic op has no custom-op form: it is this build's extension)
+        compiled = torch.compile(lambda t, sc: scaled_fp8_quant(t, sc, output_dtype=fp8), fullgraph=True)
+        ours = lambda: compiled(x, s)  # noqa: E731
+    if compile_ref:
+        baseline = torch.compile(baseline)
+    run_pair("dynamic_scaled_fp8_quant" if dynamic else "static_scaled_fp8_quant", ours,
              baseline, params, iteration_time_ms, warmup_time_ms, csv,
              nbytes=float(x.numel() * (x.element_size() + 1)))
 

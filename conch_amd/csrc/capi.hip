@@ -325,14 +325,17 @@ int run_scaled_silu(const ScaledGemmArgs& p, hipStream_t stream) {
 
 int check_mixed(const MixedGemmArgs& p) {
   CONCH_CHECK_ARG(p.m >= 0 && p.n >= 0 && p.k >= 0, "mixed_precision_gemm: negative shape");
-  if (p.x_dtype != CONCH_DT_FP16 && p.x_dtype != CONCH_DT_BF16) {
-    set_error("mixed_precision_gemm: unsupported activation dtype %d (want FP16 or BF16)", p.x_dtype);
+  const bool f32 = p.x_dtype == CONCH_DT_FP32;  // fp32 activations, scales and result: the one-thread-per-output kernel only
+  if (p.x_dtype != CONCH_DT_FP16 && p.x_dtype != CONCH_DT_BF16 && !f32) {
+    set_error("mixed_precision_gemm: unsupported activation dtype %d (want FP16, BF16 or FP32)", p.x_dtype);
     return CONCH_ERR_UNSUPPORTED;
   }
-  if (!is_out16(p.out_dtype)) {
-    set_error("mixed_precision_gemm: unsupported output dtype %d (want FP16 or BF16)", p.out_dtype);
+  if (f32 ? p.out_dtype != CONCH_DT_FP32 : !is_out16(p.out_dtype)) {
+    set_error("mixed_precision_gemm: unsupported output dtype %d for activation dtype %d (FP16 / BF16 activations give FP16 / BF16, "
+              "FP32 activations give FP32)", p.out_dtype, p.x_dtype);
     return CONCH_ERR_UNSUPPORTED;
   }
+  if (f32) CONCH_CHECK_ARG(p.group_size % (32 / p.bits) == 0, "mixed_precision_gemm (fp32): group_size %d must hold whole packed words", p.group_size);
   CONCH_CHECK_ARG(p.bits == 1 || p.bits == 2 || p.bits == 4 || p.bits == 8 || p.bits == 16 || p.bits == 32,
                   "mixed_precision_gemm: weight_bits %d does not divide 32", p.bits);
   CONCH_CHECK_ARG(p.group_size > 0, "mixed_precision_gemm: group_size %d", p.group_size);
@@ -372,6 +375,13 @@ int run_mixed(const MixedGemmArgs& p, hipStream_t stream) {
   if (variant == 4 && !mixed_gemm_skinny_supported(p)) {
     set_error("mixed_precision_gemm: skinny variant forced but its contract is not met (M <= 256, N %% 4 == 0)");
     return CONCH_ERR_UNSUPPORTED;
+  }
+  if (p.x_dtype == CONCH_DT_FP32) {
+    if (variant >= 2) {
+      set_error("mixed_precision_gemm: MFMA variant %d forced but fp32 activations run on the generic kernel only", variant);
+      return CONCH_ERR_UNSUPPORTED;
+    }
+    return launch_mixed_gemm_generic(p, stream);
   }
   // auto: the decode-batch kernel for every shape it takes (M <= 64; up to four row blocks = 256 rows where mixed_decode_beats_tiles says so).  Round 1 stopped at 32 rows for N x K >= 9e7, where the two
   // kernels tie on a cache-resident weight (64x4096x28672: 58 us each); on weights streamed from HBM the decode kernel is 6-13 %

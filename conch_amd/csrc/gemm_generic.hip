@@ -76,6 +76,34 @@ __global__ __launch_bounds__(256) void mixed_gemm_generic_kernel(MixedGemmArgs p
   ((uint16_t*)p.c)[m * p.c_stride_m + n] = float_to_bits16<OUT_DT>(acc);
 }
 
+// fp32 activations (the reference's benchmark offers --input-dtype fp32: benchmarks/mixed_precision_gemm_benchmark.py:99-105; its
+// kernel then dequantises and accumulates in fp32, kernels/quantization/gemm.py:201-216): scales fp32, result fp32,
+// w = float(q - bias - zp) * s rounded once to fp32 (= w_ref in fp32, quant_utils.py:74), fmaf accumulation in k order.  gfx950 has
+// no fp32-input MFMA above the vector rate, so this is a completeness path, one thread per output: ~1 TFLOP/s.
+__global__ __launch_bounds__(256) void mixed_gemm_generic_f32_kernel(MixedGemmArgs p) {
+  const int64_t n = (int64_t)blockIdx.x * 16 + (threadIdx.x & 15);
+  const int64_t m = (int64_t)blockIdx.y * 16 + (threadIdx.x >> 4);
+  if (m >= p.m || n >= p.n) return;
+  const int per_word = 32 / p.bits;
+  const uint32_t mask = (p.bits == 32) ? 0xffffffffu : ((1u << p.bits) - 1u);
+  const float* x = (const float*)p.x + m * p.x_stride_m;
+  const float* ws = (const float*)p.w_s;
+  const int zp_scalar = p.zp_mode == CONCH_ZP_SCALAR ? p.w_zp[0] : 0;
+  float acc = 0.f;
+  for (int64_t k0 = 0; k0 < p.k; k0 += per_word) {
+    const uint32_t word = (uint32_t)p.w_q[(k0 / per_word) * p.wq_stride_k + n];
+    const int64_t g = k0 / p.group_size;  // group_size is a multiple of the words' span (checked by the caller)
+    const int zp = p.zp_mode == CONCH_ZP_TENSOR ? p.w_zp[g * p.wzp_stride_g + n] : zp_scalar;
+    const float s = ws[g * p.ws_stride_g + n];
+    for (int j = 0; j < per_word; ++j) {
+      const int q = (int)((word >> (j * p.bits)) & mask) - p.weight_bias - zp;
+      const float w = pin_f32((float)q * s);
+      acc = fmaf(x[k0 + j], w, acc);
+    }
+  }
+  ((float*)p.c)[m * p.c_stride_m + n] = acc;
+}
+
 }  // namespace
 
 int launch_scaled_gemm_generic(const ScaledGemmArgs& p, hipStream_t stream) {
@@ -102,6 +130,10 @@ int launch_mixed_gemm_generic(const MixedGemmArgs& p, hipStream_t stream) {
 #define CONCH_LAUNCH(X, OUT)                                                                  \
   hipLaunchKernelGGL((mixed_gemm_generic_kernel<X, OUT>), grid, dim3(256), 0, stream, p);     \
   return check_launch("mixed_gemm_generic")
+  if (p.x_dtype == CONCH_DT_FP32 && p.out_dtype == CONCH_DT_FP32) {
+    hipLaunchKernelGGL(mixed_gemm_generic_f32_kernel, grid, dim3(256), 0, stream, p);
+    return check_launch("mixed_gemm_generic_f32");
+  }
   if (p.x_dtype == CONCH_DT_FP16 && p.out_dtype == CONCH_DT_FP16) { CONCH_LAUNCH(CONCH_DT_FP16, CONCH_DT_FP16); }
   if (p.x_dtype == CONCH_DT_FP16 && p.out_dtype == CONCH_DT_BF16) { CONCH_LAUNCH(CONCH_DT_FP16, CONCH_DT_BF16); }
   if (p.x_dtype == CONCH_DT_BF16 && p.out_dtype == CONCH_DT_BF16) { CONCH_LAUNCH(CONCH_DT_BF16, CONCH_DT_BF16); }

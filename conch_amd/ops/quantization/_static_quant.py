@@ -11,6 +11,8 @@ from collections.abc import Callable
 
 import torch
 
+from conch_amd.ops.quantization import _compile
+
 Launcher = Callable[[torch.Tensor, torch.Tensor, torch.Tensor], None]
 
 
@@ -36,6 +38,10 @@ def quantize_new(x: torch.Tensor, scale: torch.Tensor | None, out_dtype: torch.d
     scale[t] = absmax(x[t]) / QMAX, returned with shape x.shape[:-1] + (1,) -- for a 2-D input exactly the (M, 1) fp32
     `scale_a` of `scaled_gemm`.
     """
+    if scale is not None and _compile.compiling():  # torch.compile: one opaque custom op (see _compile.py)
+        if out_dtype is torch.int8:
+            return torch.ops.conch_amd.static_scaled_int8_quant(x, scale), scale
+        return torch.ops.conch_amd.static_scaled_fp8_quant(x, scale, out_dtype is torch.float8_e4m3fnuz), scale
     out = torch.empty_like(x, dtype=out_dtype)
     if scale is None:
         scales = torch.empty((*x.shape[:-1], 1), dtype=torch.float32, device=x.device)
@@ -43,3 +49,6 @@ def quantize_new(x: torch.Tensor, scale: torch.Tensor | None, out_dtype: torch.d
         return out, scales
     quantize_into(out, x, scale, launcher, allowed_out_dtypes)
     return out, scale
+
+
+_compile.ensure_defined()

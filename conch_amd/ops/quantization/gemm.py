@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import torch
 
+from conch_amd.kernels.quantization import _fast
 from conch_amd.kernels.quantization.gemm import (
     mixed_precision_gemm_gelu_tanh_and_mul_launcher,
     mixed_precision_gemm_launcher,
@@ -18,6 +19,7 @@ from conch_amd.kernels.quantization.gemm import (
     scaled_gemm_silu_and_mul_launcher,
     static_quant_scaled_gemm_launcher,
 )
+from conch_amd.ops.quantization import _compile
 from conch_amd.ops.quantization._metadata import create_mixed_precision_metadata, create_scaled_metadata
 
 __all__ = ["create_mixed_precision_metadata", "create_scaled_metadata", "mixed_precision_gemm", "scaled_gemm",
@@ -31,6 +33,13 @@ def mixed_precision_gemm(x: torch.Tensor, w_q_packed: torch.Tensor, w_s: torch.T
                          meta_dtype: torch.dtype | None = None, scaled_activations: bool = False,
                          strict: bool = False) -> torch.Tensor:
     """x @ dequant(w_q_packed): int4/int8 group-quantized packed weights, fp16/bf16 activations."""
+    plain = not (strict or scaled_activations) and output_dtype is None and acc_dtype is None and meta_dtype is None
+    if plain and _compile.compiling():  # torch.compile: one opaque custom op (see _compile.py)
+        return torch.ops.conch_amd.mixed_precision_gemm(x, w_q_packed, w_s, w_zp, weight_size_bits, weight_bias, group_size)
+    if plain:
+        out = _fast.mixed_precision_gemm(x, w_q_packed, w_s, w_zp, weight_size_bits, weight_bias, group_size)
+        if out is not None:
+            return out
     meta = create_mixed_precision_metadata(x, w_q_packed, w_s, w_zp, weight_size_bits, weight_bias, group_size,
                                            output_dtype=output_dtype, acc_dtype=acc_dtype, meta_dtype=meta_dtype,
                                            scaled_activations=scaled_activations, strict=strict)
@@ -43,6 +52,12 @@ def mixed_precision_gemm(x: torch.Tensor, w_q_packed: torch.Tensor, w_s: torch.T
 def scaled_gemm(a: torch.Tensor, b: torch.Tensor, scale_a: torch.Tensor, scale_b: torch.Tensor,
                 output_dtype: torch.dtype, bias: torch.Tensor | None = None, strict: bool = False) -> torch.Tensor:
     """cast(scale_b * (scale_a * (a @ b))) [+ bias] for int8 / fp8 operands, fp16 / bf16 output."""
+    if _compile.compiling():  # torch.compile: one opaque custom op (see _compile.py)
+        return torch.ops.conch_amd.scaled_gemm(a, b, scale_a, scale_b, output_dtype, bias)
+    if not strict:  # the plain case without the metadata round trip (same C entry point, same arguments: _fast.py)
+        out = _fast.scaled_gemm(a, b, scale_a, scale_b, output_dtype, bias)
+        if out is not None:
+            return out
     meta = create_scaled_metadata(a, b, scale_a, scale_b, output_dtype, strict=strict)
     out = a.new_empty((meta.m_dim, meta.n_dim), dtype=output_dtype)
     # bias goes into the kernel epilogue (the reference runs a separate in-place add afterwards)
@@ -116,3 +131,6 @@ def static_quant_scaled_gemm(x: torch.Tensor, b: torch.Tensor, scale_x: torch.Te
     out = torch.empty((x.shape[0], b.shape[1]), dtype=output_dtype, device=x.device)
     static_quant_scaled_gemm_launcher(out, x, b, scale_x, scale_b, bias)
     return out
+
+
+_compile.ensure_defined()

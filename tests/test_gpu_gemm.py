@@ -711,6 +711,27 @@ def test_mixed_strip_kernel_is_bit_identical_and_correct(_reset_tuning, m, k, n,
     check_mixed(mixed_precision_gemm(*args), a, w_ref, k)
 
 
+@pytest.mark.parametrize(("m", "k", "n"), [(128, 256, 128), (33, 384, 200)])
+@pytest.mark.parametrize("wname", list(WTYPES))
+@pytest.mark.parametrize("use_zp", [True, False])
+def test_mixed_precision_gemm_fp32_activations(m, k, n, wname, use_zp):
+    """fp32 activations (the reference's benchmark offers them: benchmarks/mixed_precision_gemm_benchmark.py:99-105): scales and
+    result fp32, weights dequantised in fp32 (= w_ref), fp32 accumulation -- the generic kernel (gfx950 has no fp32 matrix rate to
+    speak of).  Against the oracle's fp32 matmul: the worst-case accumulation-order error of each output's own products."""
+    wt = WTYPES[wname]
+    a, w_ref, packed, w_s, w_zp = make_mixed_inputs(m, k, n, wt, use_zp, torch.float32)
+    assert w_s.dtype == torch.float32 and w_ref.dtype == torch.float32
+    got = mixed_precision_gemm(a.cuda(), packed.cuda(), w_s.cuda(), None if w_zp is None else w_zp.cuda(), wt.size_bits, wt.bias, 128)
+    assert got.dtype == torch.float32 and got.shape == (m, n)
+    ref = oracle.mixed_precision_gemm_ref(a, w_ref)
+    exact = a.double() @ w_ref.double()
+    bound = (k * 2.0**-23) * (a.double().abs() @ w_ref.double().abs()) + 1e-30
+    assert ((got.cpu().double() - exact).abs() <= bound).all()
+    assert ((ref.double() - exact).abs() <= bound).all()  # the oracle sits inside the same bound
+    with pytest.raises(NotImplementedError):  # fp32 activations need fp32 scales (the meta dtype is the activation dtype)
+        mixed_precision_gemm(a.cuda(), packed.cuda(), w_s.half().cuda(), None, wt.size_bits, wt.bias, 128)
+
+
 def test_mixed_precision_c4_config_properties():
     """BASELINE config C4 (uint4b8, group 128, fp16, 1024x4096x11008) at full size.
 
