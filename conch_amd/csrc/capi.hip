@@ -166,6 +166,10 @@ ScaledKernel choose_scaled_kernel(const ScaledGemmArgs& p) {
   return pick;
 }
 
+}  // namespace
+int scaled_kernel_choice(const ScaledGemmArgs& p) { return (int)choose_scaled_kernel(p); }
+namespace {
+
 int run_scaled_fast(const ScaledGemmArgs& p, int variant, hipStream_t stream) {
   if (variant == 4 && !scaled_gemm_skinny_supported(p)) {
     set_error("scaled_gemm: skinny variant forced but its contract is not met (M <= 256; N %% 4 == 0 or K %% 1024 == 0)");

@@ -115,6 +115,8 @@ bool scaled_gemm_mfma_supported(const ScaledGemmArgs& p);
 int launch_scaled_gemm_mfma(const ScaledGemmArgs& p, int variant, hipStream_t stream);
 // gemm_mid.hip -- 128x128 tiles, two workgroups per CU, for shapes with few 256x256 tiles (variant 6); same contract
 int launch_scaled_gemm_mid(const ScaledGemmArgs& p, hipStream_t stream);
+// the dispatcher's cost model (capi.hip, choose_scaled_kernel): 0 = 256 x 256 tiles, 1 = 128 x 128 tiles, 2 = split-K skinny
+int scaled_kernel_choice(const ScaledGemmArgs& p);
 // gemm_skinny.hip -- M <= 256: 128x16 blocks, K split over the waves, register streaming (variant 4)
 bool scaled_gemm_skinny_supported(const ScaledGemmArgs& p);
 int launch_scaled_gemm_skinny(const ScaledGemmArgs& p, hipStream_t stream);

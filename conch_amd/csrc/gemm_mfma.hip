@@ -951,6 +951,9 @@ int launch_scaled_gemm_mfma(const ScaledGemmArgs& p_in, int variant, hipStream_t
 // construction; p.in_dtype says which 16-bit MFMA runs.
 int launch_scaled_gemm_mfma_16bit(const ScaledGemmArgs& p_in, hipStream_t stream) {
   ScaledGemmArgs p = p_in;
+  // few 256 x 256 tiles (M of a few hundred rows): the 128 x 128-tile kernel, by the cost model the 8-bit dispatcher uses
+  // (its unit is the 128-byte K step, the same here) -- round 4: these completeness paths had run the 256 x 256 tiles whatever M was
+  if (tuning(CONCH_TUNE_GEMM_VARIANT) == 0 && !p.fuse_silu && scaled_kernel_choice(p) == 1) return launch_scaled_gemm_mid(p, stream);
   const int tiles_m = (int)((p.m + kTileM - 1) / kTileM);
   const int tiles_n = (int)((p.n + kTileN - 1) / kTileN);
   set_raster_divisor((uint32_t)(kGroupM * tiles_n), &p.raster_magic, &p.raster_shift);

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(kMidThreads, 2) void scaled_gemm_mid_kernel(ScaledG
     const int idx = epi_is_b ? min(bn0 + tt, (int)p.n - 1) : min(bm0 + tt, (int)p.m - 1);
     const float* base = epi_is_b ? p.scale_b : p.scale_a;
     const bool vec = (epi_is_b ? p.scale_b_numel : p.scale_a_numel) != 1;
-    epi_v0 = base[vec ? idx : 0];
+    epi_v0 = base ? base[vec ? idx : 0] : 1.0f;  // NULL scale pointer = 1 (the 16-bit operand paths of gemm_modes.hip / bnb.hip)
     if (!epi_is_b) epi_v0 *= p.acc_scale;  // 1, or the exact 1/4 of e4m3fnuz operands on the OCP fp8 MFMA (gemm.hpp)
     // unconditional (without a bias: two readable bytes of A, never used)
     const uint16_t* bias_src = p.bias ? (const uint16_t*)p.bias + min(bn0 + tt, (int)p.n - 1) : (const uint16_t*)p.a;
@@ -235,6 +235,16 @@ int launch_scaled_gemm_mid(const ScaledGemmArgs& p_in, hipStream_t stream) {
   if (p.in_dtype == CONCH_DT_FP8_E4M3FN) {
     if (p.out_dtype == CONCH_DT_BF16) CONCH_LAUNCH_MID(kMmaFp8, CONCH_DT_BF16);
     CONCH_LAUNCH_MID(kMmaFp8, CONCH_DT_FP16);
+  }
+  // 16-bit operands in byte units (launch_scaled_gemm_mfma_16bit: the dequantise-first paths of gemm_modes.hip and bnb.hip, the
+  // e4m3fnuz expansion): the same loop on v_mfma_f32_16x16x32_{f16,bf16}, two instructions per 128-byte K step like int8
+  if (p.in_dtype == CONCH_DT_FP16) {
+    if (p.out_dtype == CONCH_DT_BF16) CONCH_LAUNCH_MID(kMmaF16, CONCH_DT_BF16);
+    CONCH_LAUNCH_MID(kMmaF16, CONCH_DT_FP16);
+  }
+  if (p.in_dtype == CONCH_DT_BF16) {
+    if (p.out_dtype == CONCH_DT_BF16) CONCH_LAUNCH_MID(kMmaBf16, CONCH_DT_BF16);
+    CONCH_LAUNCH_MID(kMmaBf16, CONCH_DT_FP16);
   }
   if (p.out_dtype == CONCH_DT_BF16) CONCH_LAUNCH_MID(kMmaInt8, CONCH_DT_BF16);
   CONCH_LAUNCH_MID(kMmaInt8, CONCH_DT_FP16);
