@@ -89,6 +89,35 @@ def build(force: bool = False, verbose: bool = False, probe: bool = False, varia
     return lib
 
 
+HOST_SHIM = PKG / "_conch_host.so"
+
+
+def build_host_shim(force: bool = False, verbose: bool = False) -> Path:
+    """Compile conch_amd/csrc_host/host_shim.cpp (g++, against this interpreter's torch): the C++ host path of the hot ops
+    (checks + allocation + C-ABI call; kernels/quantization/_fast.py uses it when it is there).  ~30 s."""
+    import sysconfig
+
+    import pybind11
+    from torch.utils import cpp_extension as ce
+
+    src = PKG / "csrc_host" / "host_shim.cpp"
+    if not (force or _stale(HOST_SHIM, [src, Path(__file__)])):
+        return HOST_SHIM
+    inc = [*ce.include_paths(), pybind11.get_include(), sysconfig.get_paths()["include"], "/opt/rocm/include"]
+    libdir = ce.library_paths()[0]
+    import torch
+
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-DUSE_ROCM",
+           "-DTORCH_EXTENSION_NAME=_conch_host", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", str(src), "-o", str(HOST_SHIM),
+           *[f"-I{i}" for i in inc], f"-L{libdir}", "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-ltorch_hip", "-ltorch_python",
+           f"-Wl,-rpath,{libdir}", "-ldl"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    with _COMPILE_SLOTS:
+        subprocess.run(cmd, check=True)
+    return HOST_SHIM
+
+
 if __name__ == "__main__":
     if "--variant" in sys.argv:  # python -m conch_amd._build --variant NAME -DMACRO ...
         name = sys.argv[sys.argv.index("--variant") + 1]
@@ -101,3 +130,4 @@ if __name__ == "__main__":
         print(build(force="--force" in sys.argv, verbose=True, probe=True))
     if "--probe" not in sys.argv:
         print(build(force="--force" in sys.argv, verbose=True, probe=False))
+        print(build_host_shim(force="--force" in sys.argv, verbose=True))

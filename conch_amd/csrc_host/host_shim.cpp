@@ -1,0 +1,166 @@
+// Host-side shim of the hot ops: argument checks, output allocation and the C-ABI call in C++ (round 4).
+//
+// A decode-size op call is host-bound: 13-14 us of Python per call in round 3, ~9 us with the short Python path of
+// kernels/quantization/_fast.py (torch.empty 1.8, ~30 tensor attribute calls, the 20-argument ctypes marshalling), against 6-9 us
+// of GPU time.  This module does the same steps with ATen from C++ -- the SAME entry points of libconch_amd.so (include/conch_amd.h),
+// bound by dlsym from the library the package has already loaded, the same checks as _fast.py, None for anything but the plain case
+// (the Python paths then handle or refuse it) -- so the ops keep their behaviour and lose ~3 us per call.  PyTorch is used for what
+// the task uses it for: device memory and the current stream.
+#include <dlfcn.h>
+
+#include <string>
+
+#include <c10/hip/HIPStream.h>
+#include <torch/csrc/Dtype.h>
+#include <torch/extension.h>
+
+namespace {
+
+typedef int (*scaled_gemm_fn)(void*, const void*, const void*, const float*, const float*, const void*, int64_t, int64_t, int64_t, int64_t, int64_t,
+                              int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int, int, void*);
+typedef int (*mixed_gemm_fn)(void*, const void*, const int32_t*, const void*, const int32_t*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t,
+                             int64_t, int64_t, int, int, int, int, int, int, void*);
+typedef int (*int8_quant_fn)(int8_t*, const void*, const float*, int64_t, int64_t, int64_t, int64_t, int, int, void*);
+typedef int (*fp8_quant_fn)(uint8_t*, const void*, const float*, int64_t, int64_t, int64_t, int64_t, int, int, void*);
+typedef const char* (*last_error_fn)();
+
+scaled_gemm_fn g_scaled = nullptr;
+mixed_gemm_fn g_mixed = nullptr;
+int8_quant_fn g_int8 = nullptr;
+fp8_quant_fn g_fp8 = nullptr;
+last_error_fn g_last_error = nullptr;
+
+// conch_dtype_t of include/conch_amd.h
+enum { DT_FP32 = 0, DT_FP16 = 1, DT_BF16 = 2, DT_FP8_E4M3FN = 3, DT_INT8 = 4, DT_FP8_E4M3FNUZ = 9 };
+
+int dtype_code(at::ScalarType t) {
+  switch (t) {
+    case at::kFloat: return DT_FP32;
+    case at::kHalf: return DT_FP16;
+    case at::kBFloat16: return DT_BF16;
+    case at::kFloat8_e4m3fn: return DT_FP8_E4M3FN;
+    case at::kFloat8_e4m3fnuz: return DT_FP8_E4M3FNUZ;
+    case at::kChar: return DT_INT8;
+    default: return -1;
+  }
+}
+
+void bind_library(const std::string& path) {
+  void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);  // already loaded by ctypes: the same handle, the same library state
+  if (!h) throw std::runtime_error(std::string("conch_amd host shim: cannot open ") + path + ": " + dlerror());
+  g_scaled = (scaled_gemm_fn)dlsym(h, "conch_scaled_gemm");
+  g_mixed = (mixed_gemm_fn)dlsym(h, "conch_mixed_precision_gemm");
+  g_int8 = (int8_quant_fn)dlsym(h, "conch_static_scaled_int8_quant_typed");
+  g_fp8 = (fp8_quant_fn)dlsym(h, "conch_static_scaled_fp8_quant");
+  g_last_error = (last_error_fn)dlsym(h, "conch_last_error");
+  if (!g_scaled || !g_mixed || !g_int8 || !g_fp8 || !g_last_error) throw std::runtime_error("conch_amd host shim: " + path + " lacks an entry point");
+}
+
+[[noreturn]] void raise_status(int status, const char* what) {
+  const std::string msg = std::string(what) + ": " + (g_last_error ? g_last_error() : "");
+  if (status == 1) throw py::value_error(msg);
+  if (status == 2) {
+    PyErr_SetString(PyExc_NotImplementedError, msg.c_str());
+    throw py::error_already_set();
+  }
+  throw std::runtime_error(std::string(what) + " failed with status " + std::to_string(status) + ": " + (g_last_error ? g_last_error() : ""));
+}
+
+inline bool on_current_device(const at::Tensor& t, c10::DeviceIndex dev) { return t.is_cuda() && t.get_device() == dev; }
+
+at::ScalarType dtype_of(const py::object& o) {
+  if (!THPDtype_Check(o.ptr())) throw py::type_error("expected a torch.dtype");
+  return reinterpret_cast<THPDtype*>(o.ptr())->scalar_type;
+}
+
+// conch_scaled_gemm for 2-D a, b of one 8-bit dtype on the current device, contiguous float32 scales, contiguous bias in the output
+// dtype; None = not that case (kernels/quantization/_fast.py has the same contract in Python)
+py::object scaled_gemm(const at::Tensor& a, const at::Tensor& b, const at::Tensor& sa, const at::Tensor& sb, const py::object& out_dtype_obj,
+                       const c10::optional<at::Tensor>& bias) {
+  if (!a.is_cuda()) return py::none();
+  const c10::DeviceIndex dev = a.get_device();
+  if (dev != c10::hip::current_device() || !on_current_device(b, dev) || !on_current_device(sa, dev) || !on_current_device(sb, dev)) return py::none();
+  const at::ScalarType out_dtype = dtype_of(out_dtype_obj);
+  const int code = dtype_code(a.scalar_type()), out_code = dtype_code(out_dtype);
+  if (code < 0 || out_code < 0 || b.scalar_type() != a.scalar_type() || sa.scalar_type() != at::kFloat || sb.scalar_type() != at::kFloat) return py::none();
+  if (a.dim() != 2 || b.dim() != 2 || a.size(1) != b.size(0) || !sa.is_contiguous() || !sb.is_contiguous()) return py::none();
+  const int64_t m = a.size(0), k = a.size(1), n = b.size(1);
+  const void* bias_ptr = nullptr;
+  if (bias.has_value()) {
+    const at::Tensor& bt = *bias;
+    if (bt.scalar_type() != out_dtype || !on_current_device(bt, dev) || bt.numel() != n || !bt.is_contiguous()) return py::none();
+    bias_ptr = bt.data_ptr();
+  }
+  at::Tensor out = at::empty({m, n}, a.options().dtype(out_dtype));
+  const int status = g_scaled(out.data_ptr(), a.data_ptr(), b.data_ptr(), (const float*)sa.data_ptr(), (const float*)sb.data_ptr(), bias_ptr, m, n, k,
+                              a.stride(0), a.stride(1), b.stride(0), b.stride(1), n, 1, sa.numel(), sb.numel(), code, out_code,
+                              (void*)c10::hip::getCurrentHIPStream(dev).stream());
+  if (status) raise_status(status, "scaled_gemm");
+  return py::cast(out);
+}
+
+py::object mixed_precision_gemm(const at::Tensor& x, const at::Tensor& wq, const at::Tensor& ws, const c10::optional<at::Tensor>& wzp, int64_t bits,
+                                int64_t weight_bias, int64_t group_size) {
+  if (!x.is_cuda()) return py::none();
+  const c10::DeviceIndex dev = x.get_device();
+  if (dev != c10::hip::current_device() || !on_current_device(wq, dev) || !on_current_device(ws, dev)) return py::none();
+  const at::ScalarType dt = x.scalar_type();
+  if ((dt != at::kHalf && dt != at::kBFloat16) || ws.scalar_type() != dt || wq.scalar_type() != at::kInt || (bits != 4 && bits != 8)) return py::none();
+  if (x.dim() != 2 || wq.dim() != 2 || ws.dim() != 2 || x.stride(1) != 1 || wq.stride(1) != 1 || ws.stride(1) != 1) return py::none();
+  const int64_t m = x.size(0), k = x.size(1), n = wq.size(1);
+  if (wq.size(0) * (32 / bits) != k || group_size <= 0 || k % group_size || ws.size(0) * group_size != k || ws.size(1) != n) return py::none();
+  const int32_t* zp_ptr = nullptr;
+  int zp_mode = 0;
+  int64_t zp_stride = 0;
+  if (wzp.has_value()) {
+    const at::Tensor& z = *wzp;
+    if (!on_current_device(z, dev) || z.scalar_type() != at::kInt) return py::none();
+    if (z.numel() == 1) zp_mode = 1;
+    else if (z.dim() == 2 && z.size(0) == ws.size(0) && z.size(1) == n && z.stride(1) == 1) {
+      zp_mode = 2;
+      zp_stride = z.stride(0);
+    } else return py::none();
+    zp_ptr = (const int32_t*)z.data_ptr();
+  }
+  at::Tensor out = at::empty({m, n}, x.options());
+  const int code = dtype_code(dt);
+  const int status = g_mixed(out.data_ptr(), x.data_ptr(), (const int32_t*)wq.data_ptr(), ws.data_ptr(), zp_ptr, m, n, k, x.stride(0), wq.stride(0),
+                             ws.stride(0), zp_stride, n, (int)bits, (int)weight_bias, (int)group_size, zp_mode, code, code,
+                             (void*)c10::hip::getCurrentHIPStream(dev).stream());
+  if (status) raise_status(status, "mixed_precision_gemm");
+  return py::cast(out);
+}
+
+// static per-tensor quantisation of a contiguous tensor: int8 (kind 0), e4m3fn (1), e4m3fnuz (2); None = not the plain case
+py::object static_quant(const at::Tensor& x, const at::Tensor& scale, int64_t kind) {
+  if (!x.is_cuda() || x.dim() < 1 || !x.is_contiguous()) return py::none();
+  const c10::DeviceIndex dev = x.get_device();
+  if (dev != c10::hip::current_device() || !on_current_device(scale, dev) || scale.scalar_type() != at::kFloat || scale.numel() != 1) return py::none();
+  const int xcode = dtype_code(x.scalar_type());
+  if (xcode != DT_FP32 && xcode != DT_FP16 && xcode != DT_BF16) return py::none();
+  const int64_t hidden = x.size(-1), tokens = hidden ? x.numel() / hidden : 0;
+  void* stream = (void*)c10::hip::getCurrentHIPStream(dev).stream();
+  if (kind == 0) {
+    at::Tensor out = at::empty_like(x, x.options().dtype(at::kChar));
+    // a 0-dim scale makes torch round the product to x's dtype (kernels/quantization/int8.py)
+    const int product = (scale.dim() == 0 && xcode != DT_FP32) ? xcode : DT_FP32;
+    const int status = g_int8((int8_t*)out.data_ptr(), x.data_ptr(), (const float*)scale.data_ptr(), tokens, hidden, hidden, hidden, xcode, product, stream);
+    if (status) raise_status(status, "static_scaled_int8_quant");
+    return py::cast(out);
+  }
+  const at::ScalarType odt = kind == 2 ? at::kFloat8_e4m3fnuz : at::kFloat8_e4m3fn;
+  at::Tensor out = at::empty_like(x, x.options().dtype(odt));
+  const int status = g_fp8((uint8_t*)out.data_ptr(), x.data_ptr(), (const float*)scale.data_ptr(), tokens, hidden, hidden, hidden, xcode, dtype_code(odt), stream);
+  if (status) raise_status(status, "static_scaled_fp8_quant");
+  return py::cast(out);
+}
+
+}  // namespace
+
+PYBIND11_MODULE(_conch_host, mod) {
+  mod.doc() = "conch_amd host shim: checks + allocation + C-ABI call of the hot ops in C++";
+  mod.def("bind_library", &bind_library);
+  mod.def("scaled_gemm", &scaled_gemm);
+  mod.def("mixed_precision_gemm", &mixed_precision_gemm);
+  mod.def("static_quant", &static_quant);
+}

@@ -28,6 +28,20 @@ def _device(index: int) -> torch.device:
     return d
 
 
+def _load_host_shim():
+    """The C++ form of the functions below (conch_amd/csrc_host/host_shim.cpp, built by conch_amd._build.build_host_shim): the same
+    checks, allocation and C-ABI call without the interpreter in between (~3 us less per call).  Absent or unloadable (another torch
+    build): the Python forms serve."""
+    try:
+        from conch_amd import _conch_host  # type: ignore[attr-defined]
+
+        _C.load()
+        _conch_host.bind_library(str(_C.LIB_PATH))
+    except Exception:  # noqa: BLE001 -- an optional accelerator of the HOST path; the ops themselves do not depend on it
+        return None
+    return _conch_host
+
+
 def _fn(name: str):
     f = _fns.get(name)
     if f is None:
@@ -105,3 +119,16 @@ def mixed_precision_gemm(x: torch.Tensor, w_q_packed: torch.Tensor, w_s: torch.T
     if status:
         _C.check(status, "mixed_precision_gemm")
     return out
+
+
+# static per-tensor quantisation, contiguous input: kind 0 = int8, 1 = e4m3fn, 2 = e4m3fnuz (host shim only; None without it)
+def static_quant(x: torch.Tensor, scale: torch.Tensor, kind: int) -> torch.Tensor | None:
+    return None
+
+
+_py_scaled_gemm, _py_mixed_precision_gemm = scaled_gemm, mixed_precision_gemm
+_host = None if __import__("os").environ.get("CONCH_AMD_NO_HOST_SHIM") else _load_host_shim()
+if _host is not None:
+    scaled_gemm = _host.scaled_gemm  # noqa: F811
+    mixed_precision_gemm = _host.mixed_precision_gemm  # noqa: F811
+    static_quant = _host.static_quant  # noqa: F811

@@ -11,7 +11,10 @@ from collections.abc import Callable
 
 import torch
 
+from conch_amd.kernels.quantization import _fast
 from conch_amd.ops.quantization import _compile
+
+_KIND = {torch.int8: 0, torch.float8_e4m3fn: 1, torch.float8_e4m3fnuz: 2}
 
 Launcher = Callable[[torch.Tensor, torch.Tensor, torch.Tensor], None]
 
@@ -42,6 +45,10 @@ def quantize_new(x: torch.Tensor, scale: torch.Tensor | None, out_dtype: torch.d
         if out_dtype is torch.int8:
             return torch.ops.conch_amd.static_scaled_int8_quant(x, scale), scale
         return torch.ops.conch_amd.static_scaled_fp8_quant(x, scale, out_dtype is torch.float8_e4m3fnuz), scale
+    if scale is not None:  # the plain case through the C++ host path, when it is built (kernels/quantization/_fast.py)
+        out = _fast.static_quant(x, scale, _KIND.get(out_dtype, -1))
+        if out is not None:
+            return out, scale
     out = torch.empty_like(x, dtype=out_dtype)
     if scale is None:
         scales = torch.empty((*x.shape[:-1], 1), dtype=torch.float32, device=x.device)

@@ -323,3 +323,21 @@ def test_headline_kernels_have_no_waterfalled_buffer_instructions():
     res = subprocess.run([sys.executable, str(ROOT / "tools" / "isa_waterfalls.py"), str(csrc / "gemm_mfma.hip"), str(csrc / "gemm_mid.hip")],
                          capture_output=True, text=True, check=False)
     assert res.returncode == 0, "tools/isa_waterfalls.py failed (a waterfall loop, or the compile itself):\n" + res.stdout + res.stderr
+
+
+def test_host_shim_builds_loads_and_declines_what_it_does_not_take():
+    """The C++ host path of the hot ops (conch_amd/csrc_host/host_shim.cpp): built in-tree by conch_amd._build.build_host_shim, bound
+    to the SAME libconch_amd.so, and strictly a fast path -- anything but the plain device case gets None and the Python
+    launchers decide (here: host tensors, which they refuse loudly)."""
+    from conch_amd import _build
+    from conch_amd.kernels.quantization import _fast
+
+    assert _build.build_host_shim().exists()
+    host = _fast._load_host_shim()
+    assert host is not None, "conch_amd/_conch_host.so does not load against this torch build"
+    a = torch.zeros(4, 128, dtype=torch.int8)
+    s = torch.ones(1)
+    assert host.scaled_gemm(a, a.T, s, s, torch.bfloat16, None) is None
+    assert host.static_quant(torch.rand(4, 16), s, 0) is None
+    x = torch.rand(4, 128, dtype=torch.float16)
+    assert host.mixed_precision_gemm(x, torch.zeros(16, 8, dtype=torch.int32), torch.ones(1, 8, dtype=torch.float16), None, 4, 8, 128) is None
