@@ -40,7 +40,7 @@ if hasattr(torch, "uint32"):
     TORCH_TO_DT[torch.uint32] = DT_UINT32
 
 
-ABI_VERSION = 2  # CONCH_AMD_ABI_VERSION of include/conch_amd.h (checked by load_library and by tests/test_host_helpers.py)
+ABI_VERSION = 3  # CONCH_AMD_ABI_VERSION of include/conch_amd.h (checked by load_library and by tests/test_host_helpers.py)
 
 
 class ConchLibraryError(RuntimeError):
@@ -94,6 +94,10 @@ _SIGNATURES = {
     "conch_time_scaled_gemm_silu_and_mul": (
         c_int,
         [c_void_p] * 6 + [_I64] * 11 + [c_int, c_int, c_void_p, c_int, ctypes.POINTER(c_float)],
+    ),
+    "conch_scaled_gemm_multi": (
+        c_int,
+        [c_void_p] * 6 + [_I64] * 11 + [c_int, c_int, ctypes.POINTER(c_void_p), c_int, c_void_p],
     ),
     "conch_static_quant_scaled_gemm": (
         c_int,

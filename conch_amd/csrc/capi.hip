@@ -595,6 +595,36 @@ extern "C" int conch_scaled_gemm(void* c, const void* a, const void* b, const fl
   return run_scaled(p, (hipStream_t)stream);
 }
 
+extern "C" int conch_scaled_gemm_multi(void* c, const void* a, const void* b, const float* scale_a, const float* scale_b, const void* bias,
+                                       int64_t m, int64_t n, int64_t k, int64_t a_stride_m, int64_t a_stride_k, int64_t b_stride_k,
+                                       int64_t b_stride_n, int64_t c_stride_m, int64_t c_stride_n, int64_t scale_a_numel,
+                                       int64_t scale_b_numel, int in_dtype, int out_dtype, void* const* c_more, int n_more, void* stream) {
+  ScaledGemmArgs p{c, a, b, scale_a, scale_b, bias, m, n, k, a_stride_m, a_stride_k, b_stride_k,
+                   b_stride_n, c_stride_m, c_stride_n, scale_a_numel, scale_b_numel, in_dtype, out_dtype};
+  if (n_more == 0) return run_scaled(p, (hipStream_t)stream);
+  CONCH_CHECK_ARG(n_more > 0 && n_more <= 7 && c_more, "scaled_gemm_multi: %d further destinations (0 .. 7)", n_more);
+  for (int d = 0; d < n_more; ++d) {
+    CONCH_CHECK_ARG(c_more[d], "scaled_gemm_multi: NULL destination %d", d + 1);
+    p.c_more[d] = c_more[d];
+  }
+  p.n_more = n_more;
+  if (int rc = check_scaled(p)) return rc;
+  if (p.m == 0 || p.n == 0) return CONCH_OK;
+  if (!p.scale_a || !p.scale_b) {
+    const float* one = nullptr;
+    if (int rc = unit_scale(&one)) return rc;
+    if (!p.scale_a) { p.scale_a = one; p.scale_a_numel = 1; }
+    if (!p.scale_b) { p.scale_b = one; p.scale_b_numel = 1; }
+  }
+  // the 256 x 256 tile kernel only (its row-major epilogue is where the further stores live): native layout, K >= 256 bytes
+  if (!scaled_gemm_mfma_supported(p) || p.k < 256 || p.c_stride_n != 1) {
+    set_error("scaled_gemm_multi: needs the tile kernel's layout (K-contiguous int8 / e4m3fn A and B^T, K %% 128 == 0, K >= 256, "
+              "16-byte aligned rows, unit-stride C rows)");
+    return CONCH_ERR_UNSUPPORTED;
+  }
+  return launch_scaled_gemm_mfma(p, 5, (hipStream_t)stream);
+}
+
 extern "C" int conch_static_quant_scaled_gemm(void* c, const void* x, const void* b, const float* scale_x, const float* scale_b,
                                               const void* bias, int64_t m, int64_t n, int64_t k, int64_t x_stride_m,
                                               int64_t x_stride_k, int64_t b_stride_k, int64_t b_stride_n, int64_t c_stride_m,

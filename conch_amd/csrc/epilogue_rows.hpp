@@ -41,7 +41,7 @@ constexpr int epilogue_rows_vm_ops(int mt) { return 2 * mt; }
 
 // MT = 16-row blocks per wave (8: 128 rows, 4: 64 rows), TILE = rows = columns of the workgroup tile (the parked constants are
 // float sa[TILE] | sb[TILE] | bias[TILE] at epi_off); a wave owns 64 columns = one line per row.
-template <int MMA, int OUT_DT, bool BIAS, int MT = 8, int TILE = 256>
+template <int MMA, int OUT_DT, bool BIAS, int MT = 8, int TILE = 256, bool MULTI = false>
 __device__ __forceinline__ void epilogue_rows_body(const typename AccT<MMA>::type (&acc)[MT][4], const ScaledGemmArgs& p, char* lds,
                                                    int stage_off, int bm0, int bn0, int wr, int wc, int lane, int wave, int epi_off) {
   asm volatile("" ::: "memory");  // nothing of this is moved above the caller's closing barrier
@@ -124,6 +124,13 @@ __device__ __forceinline__ void epilogue_rows_body(const typename AccT<MMA>::typ
       // a few lanes of some launches (gemm_mixed.hip's row-major epilogue, round 3)
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rd0), rc, (int)(voff + (uint32_t)(2 * b - 2) * step8), 0, kCStoreAux);
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rd1), rc, (int)(voff + (uint32_t)(2 * b - 1) * step8), 0, kCStoreAux);
+      if constexpr (MULTI) {  // the same two row groups into the other ranks' results (peer-mapped: the stores leave over xGMI)
+        for (int d = 0; d < p.n_more; ++d) {
+          const __amdgpu_buffer_rsrc_t rd = make_uniform_rsrc(p.c_more[d], (uint32_t)(((p.m - 1) * p.c_stride_m + p.n) * 2));
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rd0), rd, (int)(voff + (uint32_t)(2 * b - 2) * step8), 0, kCStoreAux);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rd1), rd, (int)(voff + (uint32_t)(2 * b - 1) * step8), 0, kCStoreAux);
+        }
+      }
     }
   }
 }

@@ -45,6 +45,12 @@ struct ScaledGemmArgs {
   float acc_scale = 1.0f;
   const int* gate = nullptr;
   int gate_run_if = 0;
+  // N-sharded multi-GPU form, direct mode (conch_scaled_gemm_multi; conch_amd/distributed.py): the 256 x 256 tile kernel stores every
+  // tile into `n_more` further buffers besides `c` -- the peer-mapped [M, N] results of the other ranks, same element (row,
+  // column) and row stride in each -- so that the all-gather happens in the epilogue, over all xGMI links at once, and
+  // nothing is staged or unpacked afterwards.  A separate instantiation of the kernel: the one-destination code is untouched.
+  void* c_more[7] = {};
+  int n_more = 0;
 };
 
 #ifdef __HIPCC__

@@ -250,16 +250,24 @@ __device__ __forceinline__ void epilogue(const typename AccT<MMA>::type (&acc)[8
   }
 }
 
-template <int MMA, int OUT_DT>
+template <int MMA, int OUT_DT, bool MULTI = false>
 __device__ __forceinline__ void epilogue_rows(const typename AccT<MMA>::type (&acc)[8][4], const ScaledGemmArgs& p, char* lds,
                                               int stage_off, int bm0, int bn0, int wr, int wc, int lane, int wave,
                                               int epi_off = kEpiOff) {
-  if (!tile_stores_whole_lines(p, bm0, bn0))  // workgroup-uniform
+  if (!tile_stores_whole_lines(p, bm0, bn0)) {  // workgroup-uniform
     epilogue<MMA, OUT_DT, 4>(acc, p, lds, bm0, bn0, wr, wc, lane, epi_off);
-  else if (p.bias)
-    epilogue_rows_body<MMA, OUT_DT, true>(acc, p, lds, stage_off, bm0, bn0, wr, wc, lane, wave, epi_off);
-  else
-    epilogue_rows_body<MMA, OUT_DT, false>(acc, p, lds, stage_off, bm0, bn0, wr, wc, lane, wave, epi_off);
+    if constexpr (MULTI) {  // ragged tiles: the direct epilogue once more per further destination (rare: edge tiles only)
+      for (int d = 0; d < p.n_more; ++d) {
+        ScaledGemmArgs q = p;
+        q.c = p.c_more[d];
+        epilogue<MMA, OUT_DT, 4>(acc, q, lds, bm0, bn0, wr, wc, lane, epi_off);
+      }
+    }
+  } else if (p.bias) {
+    epilogue_rows_body<MMA, OUT_DT, true, 8, 256, MULTI>(acc, p, lds, stage_off, bm0, bn0, wr, wc, lane, wave, epi_off);
+  } else {
+    epilogue_rows_body<MMA, OUT_DT, false, 8, 256, MULTI>(acc, p, lds, stage_off, bm0, bn0, wr, wc, lane, wave, epi_off);
+  }
 }
 
 // Fused gate/up epilogue (scaled_gemm_silu_and_mul): the lane's accumulator tiles 0,1 are the gate values and tiles 2,3
@@ -631,7 +639,7 @@ __device__ __forceinline__ void pp2_step(WaveTile<MMA>& w, char* lds, const Bloc
 
 // K loop + epilogue of one tile; NT = 4 (256 columns) or 3 (192 columns: 24 instead of 32 MFMAs per wave and K step, the same
 // staging stream and waits)
-template <int MMA, int OUT_DT, bool SILU, int NT, bool ROWS = false>
+template <int MMA, int OUT_DT, bool SILU, int NT, bool ROWS = false, bool MULTI = false>
 __device__ __forceinline__ void pp2_tile(const ScaledGemmArgs& p, char* lds, const BlockSetup& s, WaveTile<MMA>& w, int steps) {
   CONCH_PROBE(g_probe_scaled, 0);
   int t = 0;
@@ -642,12 +650,12 @@ __device__ __forceinline__ void pp2_tile(const ScaledGemmArgs& p, char* lds, con
   if (s.wr == 0) __builtin_amdgcn_s_barrier();  // re-balance the barrier count
 
   if constexpr (SILU) epilogue_silu<MMA, OUT_DT>(w.acc, p, lds, s.bm0, s.bn0, s.wr, s.wc, s.lane);
-  else if constexpr (NT == 4 && ROWS) epilogue_rows<MMA, OUT_DT>(w.acc, p, lds, 0, s.bm0, s.bn0, s.wr, s.wc, s.lane, s.wave);
+  else if constexpr (NT == 4 && ROWS) epilogue_rows<MMA, OUT_DT, MULTI>(w.acc, p, lds, 0, s.bm0, s.bn0, s.wr, s.wc, s.lane, s.wave);
   else epilogue<MMA, OUT_DT, NT>(w.acc, p, lds, s.bm0, s.bn0, s.wr, s.wc, s.lane);
 }
 
 // ROWS: the row-major epilogue through LDS (epilogue_rows) instead of the direct accumulator-layout stores
-template <int MMA, int OUT_DT, bool SILU, bool ROWS = false>
+template <int MMA, int OUT_DT, bool SILU, bool ROWS = false, bool MULTI = false>
 __global__ __launch_bounds__(kThreads, 2) void scaled_gemm_pp2_kernel(ScaledGemmArgs p, TileSchedule ts) {
   __shared__ __attribute__((aligned(1024))) char lds[kLdsTotal];
   if (gated_off(p.gate, p.gate_run_if)) return;
@@ -682,7 +690,7 @@ __global__ __launch_bounds__(kThreads, 2) void scaled_gemm_pp2_kernel(ScaledGemm
       return;
     }
   }
-  pp2_tile<MMA, OUT_DT, SILU, 4, ROWS>(p, lds, s, w, steps);
+  pp2_tile<MMA, OUT_DT, SILU, 4, ROWS, MULTI>(p, lds, s, w, steps);
   CONCH_PROBE(g_probe_scaled, 3);
 }
 
@@ -900,7 +908,7 @@ int launch_scaled_gemm_mfma(const ScaledGemmArgs& p_in, int variant, hipStream_t
   if (p.fuse_silu) variant = 5;
   dim3 grid((unsigned)(tiles_m * tiles_n));
   TileSchedule ts{tiles_m, tiles_n, 0, 0};
-  if (!p.fuse_silu && variant != 2 && variant != 3 && p.k >= 2 * kStepBytes) {
+  if (!p.fuse_silu && variant != 2 && variant != 3 && p.k >= 2 * kStepBytes && p.n_more == 0) {  // (further destinations: uniform tiles)
     ts = choose_tile_schedule(p);
     grid = dim3((unsigned)(ts.tiles_m * (ts.big_cols + ts.narrow_cols)));
   }
@@ -918,7 +926,9 @@ int launch_scaled_gemm_mfma(const ScaledGemmArgs& p_in, int variant, hipStream_t
   const int total_tiles = (int)grid.x;
   const bool contract = !p.fuse_silu && (variant == 0 || variant == 5) && ts.narrow_cols == 0 && !p.bias && p.k >= 4 * kStepBytes &&
                         p.acc_scale == 1.0f && !p.gate;  // (its scales reach LDS by LDS-DMA: nothing multiplies them on the way)
-  const bool persistent = contract && persist_mode >= 2;  // auto = plain launch: profiles/r02/probe_boundary.txt
+  // further destinations (conch_scaled_gemm_multi): the plain two-phase kernel with the row-major epilogue, uniform tiles
+  const bool multi = p.n_more > 0;
+  const bool persistent = contract && persist_mode >= 2 && !multi;  // auto = plain launch: profiles/r02/probe_boundary.txt
   if (persistent) grid = dim3((unsigned)std::min(total_tiles, persist_mode > 2 ? persist_mode : cus));
 #define CONCH_LAUNCH(MMA, OUT)                                                                           \
   do {                                                                                                   \
@@ -926,6 +936,8 @@ int launch_scaled_gemm_mfma(const ScaledGemmArgs& p_in, int variant, hipStream_t
       hipLaunchKernelGGL((scaled_gemm_pp2_persistent_kernel<MMA, OUT>), grid, dim3(kThreads), 0, stream, p, ts, total_tiles, rows_epilogue ? 0 : 1); \
     else if (variant == 2)                                                                               \
       hipLaunchKernelGGL((scaled_gemm_simple_kernel<MMA, OUT>), grid, dim3(kThreads), 0, stream, p);     \
+    else if (multi)                                                                                      \
+      hipLaunchKernelGGL((scaled_gemm_pp2_kernel<MMA, OUT, false, true, true>), grid, dim3(kThreads), 0, stream, p, ts); \
     else if (p.fuse_silu)                                                                                \
       hipLaunchKernelGGL((scaled_gemm_pp2_kernel<MMA, OUT, true>), grid, dim3(kThreads), 0, stream, p, ts);  \
     else if (variant != 3 && p.k >= 2 * kStepBytes && rows_epilogue)                                     \

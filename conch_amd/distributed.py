@@ -22,6 +22,16 @@ Data movement, designed for xGMI (point-to-point links: the gather, not the GEMM
   stream, behind its own gather and under the next panel's gather -- the one whole-matrix permuting copy of round 1
   is gone.  With world_size == 1 the GEMM writes the row-major result directly (column offset + row stride N) and
   there is no gather and no copy.
+* DIRECT mode (round 4; `direct=True`, SURVEY.md H7 / 8(e): "the epilogue writes to peers"): every rank's row-major [M, N]
+  result lives in memory every other rank has mapped (torch symmetric memory = HIP IPC handles exchanged once, at
+  construction), and the tile kernel stores each of its tiles into ALL G results (`conch_scaled_gemm_multi`: one local
+  destination and G - 1 peer-mapped ones) -- the all-gather is the GEMM's epilogue, its stores leave over all xGMI links at
+  once, there is no staging buffer, no collective on the data path and no unpack pass (`__call__` issues no `copy_`).  What is
+  left of the exchange is completion: a barrier of the group behind the last panel, so that a rank reads its result only after
+  every peer's stores have landed (and one ahead of the first panel of the next call, so that nobody overwrites a result a peer
+  is still reading).  UNMEASURED ON HARDWARE: no box with two GPUs was available to any round; the layout logic is covered by
+  a world-size-2 gloo test with injected shared-memory "peers", the kernel by a one-GPU test with three local destinations.
+  The RCCL all-gather path stays the default.
 """
 
 from __future__ import annotations
@@ -47,6 +57,51 @@ def _default_gemm_into(out, a, b, scale_a, scale_b, bias):
 
     meta = create_scaled_metadata(a, b, scale_a, scale_b, out.dtype)
     scaled_gemm_launcher(out, a, b, scale_a, scale_b, meta, bias=bias)
+
+
+def _default_gemm_multi(outs, a, b, scale_a, scale_b, bias):
+    """The product path of direct mode: ONE launch whose epilogue stores the block into every tensor of `outs` (views of the
+    G results with one shape and one row stride: outs[0] local, the others peer-mapped)."""
+    from conch_amd.kernels.quantization.gemm import scaled_gemm_multi_launcher
+    from conch_amd.ops.quantization._metadata import create_scaled_metadata
+
+    meta = create_scaled_metadata(a, b, scale_a, scale_b, outs[0].dtype)
+    scaled_gemm_multi_launcher(outs, a, b, scale_a, scale_b, meta, bias=bias)
+
+
+def symmetric_results(m: int, n: int, dtype: torch.dtype, device: torch.device, group=None):
+    """([M, N] result of every rank as seen from THIS rank, barrier callable): torch symmetric memory -- every rank allocates
+    its result from the symmetric-memory allocator and the rendezvous exchanges the IPC handles, so `results[r]` is a tensor on
+    this device's address space that aliases rank r's buffer (stores to it travel over xGMI)."""
+    import torch.distributed._symmetric_memory as symm
+
+    grp = group if group is not None else dist.group.WORLD
+    buf = symm.empty((m, n), dtype=dtype, device=device)
+    hdl = symm.rendezvous(buf, grp)
+    rank, world = dist.get_rank(grp), dist.get_world_size(grp)
+    results = [buf if r == rank else hdl.get_buffer(r, (m, n), dtype) for r in range(world)]
+    return results, (lambda: hdl.barrier(channel=0))
+
+
+def ipc_results(m: int, n: int, dtype: torch.dtype, device: torch.device, group=None):
+    """The same contract as symmetric_results() on plain HIP IPC handles (torch's tensor-sharing reductions: what
+    torch.multiprocessing sends a CUDA tensor with), exchanged through the group's object collectives: the fallback where the
+    symmetric-memory allocator is not available -- and the only form two ranks on ONE device (a dry run) can use, since the
+    allocator refuses ranks that share a device.  The barrier drains this rank's stream, then meets on the host."""
+    from torch.multiprocessing.reductions import reduce_tensor
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    buf = torch.empty((m, n), dtype=dtype, device=device)
+    rebuild, args = reduce_tensor(buf)
+    shared = [None] * world
+    dist.all_gather_object(shared, (rebuild, args), group=group)
+    results = [buf if r == rank else shared[r][0](*shared[r][1]) for r in range(world)]
+
+    def barrier() -> None:
+        torch.cuda.current_stream(device).synchronize()
+        dist.barrier(group)
+
+    return results, barrier
 
 
 def default_panels(m: int, n_local: int, tile: int = 256, cus: int = 256) -> int:
@@ -80,6 +135,9 @@ class NShardedScaledGemm:
         gemm_fn: Callable | None = None,
         panels: int | None = None,
         force_collective: bool = False,
+        direct: bool = False,
+        peer_results=None,
+        gemm_multi_fn: Callable | None = None,
     ) -> None:
         self.group = group
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -103,10 +161,28 @@ class NShardedScaledGemm:
         self.h = m // self.panels
         g = self.world_size
         self._blocks = None  # [G, M, N/G] staging of gathered_blocks(), allocated on first use
-        self._c = torch.empty((m, n), dtype=output_dtype, device=self.device)  # row-major result
+        self._c = None if (direct and self.world_size > 1) else torch.empty((m, n), dtype=output_dtype, device=self.device)  # row-major result
         # gather staging, one [G, h, N/G] buffer per panel (unused when world_size == 1)
-        self._stage = torch.empty((self.panels, g, self.h, self.n_local), dtype=output_dtype, device=self.device) if self._exchange else None
-        self._side = torch.cuda.Stream(self.device) if self.device.type == "cuda" and self._exchange else None
+        # direct mode: the G row-major results as seen from this rank ([rank] = the local one) + a completion barrier.
+        # `peer_results` = (results, barrier) injects them (tests; another IPC scheme); default: torch symmetric memory.
+        # `gemm_multi_fn(outs, a, b, scale_a, scale_b, bias)` injects the multi-destination product (the CPU tests' oracle).
+        self.direct = bool(direct) and self.world_size > 1
+        self.gemm_multi_fn = gemm_multi_fn
+        self._results, self._barrier = None, None
+        if self.direct:
+            if peer_results is not None:
+                self._results, self._barrier = peer_results
+            else:
+                try:
+                    self._results, self._barrier = symmetric_results(m, n, output_dtype, self.device, group)
+                except Exception:  # noqa: BLE001 -- no symmetric-memory allocator for this group (or ranks sharing a device)
+                    self._results, self._barrier = ipc_results(m, n, output_dtype, self.device, group)
+            if len(self._results) != g or any(tuple(t.shape) != (m, n) or t.dtype != output_dtype for t in self._results):
+                raise ValueError("direct mode: one [M, N] result of the output dtype per rank")
+            self._c = self._results[self.rank]
+        staged = self._exchange and not self.direct
+        self._stage = torch.empty((self.panels, g, self.h, self.n_local), dtype=output_dtype, device=self.device) if staged else None
+        self._side = torch.cuda.Stream(self.device) if self.device.type == "cuda" and staged else None
 
     # -- the local product -------------------------------------------------------------------------------------------
     def _gemm_into(self, out: torch.Tensor, a, b_shard, scale_a, scale_b_shard, bias_shard) -> None:
@@ -126,9 +202,29 @@ class NShardedScaledGemm:
         return out
 
     # -- the exchange ------------------------------------------------------------------------------------------------
+    def _run_direct(self, a, b_shard, scale_a, scale_b_shard, bias_shard) -> None:
+        """Direct mode: per row panel ONE launch that stores this rank's [h, N/G] block into all G results; no collective on the
+        data path, no staging, no unpack."""
+        self._barrier()  # nobody still reads the results of the previous call
+        order = [self.rank] + [r for r in range(self.world_size) if r != self.rank]  # the local destination first
+        for p in range(self.panels):
+            a_p, sa_p = self._panel_inputs(p, a, scale_a)
+            rows = slice(p * self.h, (p + 1) * self.h)
+            outs = [self._results[r][rows, self.lo : self.hi] for r in order]
+            if self.gemm_multi_fn is not None:
+                self.gemm_multi_fn(outs, a_p, b_shard, sa_p, scale_b_shard, bias_shard)
+            else:
+                _default_gemm_multi(outs, a_p, b_shard, sa_p, scale_b_shard, bias_shard)
+        self._barrier()  # every peer's stores into this rank's result have landed
+
     def _run(self, a, b_shard, scale_a, scale_b_shard, bias_shard, unpack: bool) -> None:
         if not self._exchange:
             self.local_gemm(a, b_shard, scale_a, scale_b_shard, bias_shard)
+            return
+        if self.direct:
+            if not unpack:
+                raise RuntimeError("direct mode produces the row-major result only (gathered_panels / gathered_blocks are layouts of the all-gather path)")
+            self._run_direct(a, b_shard, scale_a, scale_b_shard, bias_shard)
             return
         cuda = self._side is not None
         main = torch.cuda.current_stream(self.device) if cuda else None
@@ -172,6 +268,8 @@ class NShardedScaledGemm:
         overlapped form of the same data is gathered_panels()."""
         if not self._exchange:
             return self.local_gemm(a, b_shard, scale_a, scale_b_shard, bias_shard).view(1, self.m, self.n_local)
+        if self.direct:
+            raise RuntimeError("direct mode produces the row-major result only")
         if self._blocks is None:
             self._blocks = torch.empty((self.world_size, self.m, self.n_local), dtype=self.output_dtype, device=self.device)
         slot = self._blocks[self.rank]

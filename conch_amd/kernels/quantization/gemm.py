@@ -102,6 +102,7 @@ def _scaled_gemm_call(
     extra: tuple = (),
     n_out: int | None = None,
     lib=None,
+    extra_before_stream: tuple = (),
 ) -> int:
     """`n_out`: columns of `output` when they are not metadata.n_dim (the fused gate/up form passes N / 2); `lib`: a
     library handle other than the default one (bench.py times the diagnostic twin through the same marshalling)."""
@@ -139,7 +140,7 @@ def _scaled_gemm_call(
         metadata.m_dim, metadata.n_dim if n_out is None else n_out, metadata.k_dim,
         a.stride(0), a.stride(1), b.stride(0), b.stride(1), output.stride(0), output.stride(1),
         1 if sa is None else sa.numel(), 1 if sb is None else sb.numel(), _C.dtype_id(a.dtype), _C.dtype_id(output.dtype),
-        _C.current_stream_handle(a.device), *extra,
+        *extra_before_stream, _C.current_stream_handle(a.device), *extra,
     )
     with _C.on_device_of(output, a, b, sa, sb, bias):
         return getattr(lib or _C.load(), fn_name)(*args)
@@ -170,6 +171,24 @@ def scaled_gemm_launcher(
         if late_bias.numel() != metadata.n_dim:
             raise ValueError(f"bias has {late_bias.numel()} elements, want N={metadata.n_dim}")
         output.add_(late_bias.reshape(-1))
+
+
+def scaled_gemm_multi_launcher(outputs, a, b, scale_a, scale_b, metadata: ScaledMatmulMetadata, bias: torch.Tensor | None = None) -> None:
+    """conch_scaled_gemm_multi: the product stored into every tensor of `outputs` (1 to 8 views of one shape, dtype and row
+    stride: the N-sharded multi-GPU form whose epilogue does the all-gather -- outputs[0] local, the rest peer-mapped results;
+    conch_amd/distributed.py, direct mode).  No reference counterpart.  Tile-kernel layouts only."""
+    import ctypes
+
+    first = outputs[0]
+    if not 1 <= len(outputs) <= 8:
+        raise ValueError(f"1 to 8 destinations, got {len(outputs)}")
+    for t in outputs[1:]:
+        if t.shape != first.shape or t.dtype != first.dtype or t.stride() != first.stride() or t.device != first.device:
+            raise ValueError("every destination needs the shape, dtype, strides and (mapped) device of the first")
+    more = (ctypes.c_void_p * max(1, len(outputs) - 1))(*[t.data_ptr() for t in outputs[1:]])
+    status = _scaled_gemm_call("conch_scaled_gemm_multi", first, a, b, scale_a, scale_b, metadata, bias,
+                               extra_before_stream=(more, len(outputs) - 1))
+    _C.check(status, "scaled_gemm_multi")
 
 
 def static_quant_scaled_gemm_launcher(

@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define CONCH_AMD_ABI_VERSION 2
+#define CONCH_AMD_ABI_VERSION 3
 
 typedef enum conch_status {
   CONCH_OK = 0,
@@ -250,6 +250,20 @@ int conch_scaled_gemm(void* c, const void* a, const void* b, const float* scale_
                       int64_t b_stride_n, int64_t c_stride_m, int64_t c_stride_n,
                       int64_t scale_a_numel, int64_t scale_b_numel, int in_dtype, int out_dtype,
                       void* stream);
+
+/*
+ * The same product stored into 1 + n_more buffers: `c` and c_more[0 .. n_more-1] (n_more <= 7), every one a [M][N] result with the
+ * SAME row stride, written at the same (row, column).  No reference counterpart (the reference has no multi-GPU code): this is the
+ * N-sharded form of BASELINE config C5 with the all-gather done by the GEMM's epilogue -- rank r passes its column block of its own
+ * result as `c` and the same block of every peer's result, mapped into its address space (HIP IPC / symmetric memory), as c_more;
+ * the stores to peers leave over xGMI from the epilogue, nothing is staged or unpacked (conch_amd/distributed.py, direct mode).
+ * Tile-kernel layout only (K-contiguous int8 / e4m3fn A and B^T, K % 128 == 0, K >= 256, 16-byte aligned rows, unit-stride C rows):
+ * CONCH_ERR_UNSUPPORTED otherwise.  n_more == 0 is conch_scaled_gemm.  Every destination receives bit-identical values.
+ */
+int conch_scaled_gemm_multi(void* c, const void* a, const void* b, const float* scale_a, const float* scale_b, const void* bias,
+                            int64_t m, int64_t n, int64_t k, int64_t a_stride_m, int64_t a_stride_k, int64_t b_stride_k,
+                            int64_t b_stride_n, int64_t c_stride_m, int64_t c_stride_n, int64_t scale_a_numel,
+                            int64_t scale_b_numel, int in_dtype, int out_dtype, void* const* c_more, int n_more, void* stream);
 
 /*
  * scaled_gemm_silu_and_mul  (the FFN pair `silu_and_mul(scaled_gemm(a, b, ...))` in one launch;

@@ -212,3 +212,50 @@ def test_bench_starts_its_own_ranks_when_called_bare(tmp_path, capfd):
     capfd.readouterr()
     assert bench.spawn_ranks(2, ["--silent"], script=child) == 1  # rc 0 without a line is not a result
     assert capfd.readouterr().out.strip() == ""
+
+
+def _direct_worker(rank: int, world: int, port: int, results) -> None:
+    """Direct mode: every rank's row-major result is visible to every rank (here: CPU tensors in shared memory standing in for
+    peer-mapped HBM), the product is stored into ALL of them by ONE call per panel (here: the oracle, injected), and the only
+    collective is the completion barrier."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        m, k, n = 48, 128, 96
+        a = torch.randint(-32, 32, (m, k), dtype=torch.int8)
+        b = torch.randint(-32, 32, (n, k), dtype=torch.int8).T
+        sa, sb = 0.25 * torch.rand(m, 1), 0.25 * torch.rand(n, 1)
+        bias = torch.rand(n, dtype=torch.bfloat16)
+        full = oracle.scaled_gemm_ref(a, b, sa, sb, torch.bfloat16, bias)
+        calls = []
+
+        def gemm_multi(outs, a_, b_, sa_, sb_, bias_):
+            calls.append(len(outs))
+            block = oracle.scaled_gemm_ref(a_, b_, sa_, sb_, torch.bfloat16, bias_)
+            assert all(o.shape == block.shape and o.stride() == outs[0].stride() for o in outs)
+            for o in outs:  # the kernel's epilogue stores every tile into every destination
+                o.copy_(block)
+
+        for panels in (1, 3):
+            op = NShardedScaledGemm(m, n, torch.bfloat16, torch.device("cpu"), panels=panels, direct=True,
+                                    peer_results=(results, lambda: dist.barrier()), gemm_multi_fn=gemm_multi)
+            lo, hi = op.lo, op.hi
+            for _ in range(2):  # results are reused across calls
+                calls.clear()
+                got = op(a, b[:, lo:hi], sa, sb[lo:hi], bias[lo:hi])
+                assert got is results[rank] and calls == [world] * panels  # ONE multi-destination product per panel
+                assert torch.equal(got.view(torch.int16), full.view(torch.int16)), f"rank {rank}: direct result differs"
+                dist.barrier()
+            with pytest.raises(RuntimeError):
+                op.gathered_blocks(a, b[:, lo:hi], sa, sb[lo:hi], bias[lo:hi])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_nsharded_gemm_direct_mode_world2_layout():
+    """the epilogue writes its column block into every peer's row-major [M, N] result -- no staging, no
+    all-gather, no unpack.  World size 2 on gloo with shared-memory results and an injected multi-destination product: the
+    wrapper's layout logic (which view of which result, panel rows, barriers) bit for bit against the unsharded product."""
+    results = [torch.zeros((48, 96), dtype=torch.bfloat16).share_memory_() for _ in range(2)]
+    mp.spawn(_direct_worker, args=(2, _free_port(), results), nprocs=2, join=True)

@@ -800,6 +800,33 @@ def test_scaled_gemm_c3_size_e4m3fnuz():
     check_scaled(got[rows.cuda()], ref, torch.float8_e4m3fnuz, torch.bfloat16, (a[rows], b, sa[rows], sb, None))
 
 
+@pytest.mark.parametrize("iname", ["int8", "fn"])
+@pytest.mark.parametrize(("m", "k", "n", "n_dest", "use_bias"), [(512, 512, 512, 4, False), (1024, 256, 768, 8, True), (300, 384, 200, 3, True),
+                                                                  (256, 1024, 256, 2, False), (2048, 512, 1792, 8, False)])
+def test_scaled_gemm_multi_destinations_are_bit_identical(iname, m, k, n, n_dest, use_bias):
+    """conch_scaled_gemm_multi (round 4, the direct all-gather of the N-sharded form): ONE launch stores the product into up to
+    eight buffers -- here column blocks of eight local [M, 3N] "results" standing in for the peer-mapped ones.  Every
+    destination must hold exactly what scaled_gemm returns, whole and ragged tiles alike, and nothing outside its block may be
+    touched."""
+    from conch_amd.kernels.quantization.gemm import scaled_gemm_multi_launcher
+    from conch_amd.ops.quantization.gemm import create_scaled_metadata
+
+    a, b, sa, sb, bias = make_scaled_inputs(m, k, n, IN_T[iname], torch.bfloat16, False, False, use_bias)
+    ad, bd, sad, sbd = a.cuda(), b.T.contiguous().cuda().T, sa.cuda(), sb.cuda()
+    biasd = None if bias is None else bias.cuda()
+    want = scaled_gemm(ad, bd, sad, sbd, torch.bfloat16, biasd)
+    lo = n  # the middle third of each result
+    results = [torch.full((m, 3 * n), -7.0, dtype=torch.bfloat16, device="cuda") for _ in range(n_dest)]
+    meta = create_scaled_metadata(ad, bd, sad, sbd, torch.bfloat16)
+    for _ in range(2):
+        scaled_gemm_multi_launcher([r[:, lo:lo + n] for r in results], ad, bd, sad, sbd, meta, bias=biasd)
+        for r in results:
+            assert torch.equal(r[:, lo:lo + n], want)
+            assert bool((r[:, :lo] == -7.0).all()) and bool((r[:, lo + n:] == -7.0).all())
+    with pytest.raises(ValueError):  # destinations of different strides
+        scaled_gemm_multi_launcher([results[0][:, lo:lo + n], torch.empty((m, n), dtype=torch.bfloat16, device="cuda")], ad, bd, sad, sbd, meta)
+
+
 @pytest.mark.parametrize(("m", "k", "n"), [(1024, 1024, 1024), (4096, 512, 2048), (600, 384, 1376)])
 @pytest.mark.parametrize("where", ["none", "a", "b", "both", "nan"])
 def test_scaled_gemm_e4m3fnuz_special_codes_take_the_exact_path(m, k, n, where):

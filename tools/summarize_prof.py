@@ -19,7 +19,7 @@ for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
             agg[row["Kernel_Name"][:70]][row["Counter_Name"]].append(float(row["Counter_Value"]))
         print(f"== counters ({sub}): per-launch averages")
         for kname, ctrs in agg.items():
-            if not any(k in kname for k in ("gemm", "quant", "skinny", "repack", "fnuz")):
+            if not any(k in kname for k in ("gemm", "quant", "skinny", "repack", "fnuz", "strip")):
                 continue
             print("  ", kname)
             for c, v in sorted(ctrs.items()):
