@@ -278,7 +278,8 @@ def timed_region(fn, steps: int, warmup: int, world: int, device: torch.device) 
     return elapsed
 
 
-def nshard_c5(world: int, rank: int, device: torch.device, steps: int, warmup: int, shape: tuple[int, int, int] | None = None) -> dict:
+def nshard_c5(world: int, rank: int, device: torch.device, steps: int, warmup: int, shape: tuple[int, int, int] | None = None,
+              direct: bool = False) -> dict:
     """C5: M=8192 K=8192 N=28672 with N sharded over the ranks, C all-gathered over xGMI (RCCL).
 
     Timed: (1) the local GEMM only, (2) GEMM + all-gather in the block-major layout the collective produces, (3) GEMM +
@@ -314,7 +315,22 @@ def nshard_c5(world: int, rank: int, device: torch.device, steps: int, warmup: i
     t_blocks = timed_region(lambda: op.gathered_panels(a, bt_loc.T, sa, sb_loc), steps, warmup, world, device)
     t_full = timed_region(lambda: op(a, bt_loc.T, sa, sb_loc), steps, warmup, world, device)
     flops = 2.0 * m * n * k
+    direct_fields = {}
+    if direct and world > 1:
+        # opt-in (--c5-direct): the epilogue-writes-to-peers form (conch_scaled_gemm_multi; no collective on the data path).  Never
+        # on by default: it has not met real xGMI links in any round, and a hang here would take the headline with it.
+        try:
+            op_d = NShardedScaledGemm(m, n, torch.bfloat16, device, direct=True)
+            c_d = op_d(a, bt_loc.T, sa, sb_loc)
+            torch.cuda.synchronize()
+            same = bool(torch.equal(c_d, c))
+            t_direct = timed_region(lambda: op_d(a, bt_loc.T, sa, sb_loc), steps, warmup, world, device)
+            direct_fields = {"tflops_direct_rowmajor": round(2.0 * m * n * k * steps / t_direct / 1e12, 2), "ms_direct_rowmajor": round(t_direct / steps * 1e3, 4),
+                             "direct_equals_allgather_result": same}
+        except Exception as exc:  # noqa: BLE001
+            direct_fields = {"direct_error": repr(exc)}
     return {
+        **direct_fields,
         "workload": f"scaled_gemm fp8 {m}x{k}x{n}, N/{world} = {n_loc} columns per rank, {op.panels} row panel(s)",
         "scaling": "strong",
         "exchange": "RCCL all_gather_into_tensor per row panel on a side stream, in place, + unpack to row-major" if world > 1 else "none (1 rank)",
@@ -485,6 +501,8 @@ def main() -> None:
     ap.add_argument("--no-c5-base", action="store_true",
                     help="N = 1, workload c3: leave out the one-GPU figure of BASELINE config C5 (the strong-scaling base of --gpus N > 1); "
                          "for rocprofv3 kernel-trace passes, whose per-kernel average it would skew")
+    ap.add_argument("--c5-direct", action="store_true",
+                    help="with --gpus N > 1: also time the direct form of C5 (the GEMM's epilogue stores into every peer's result; side field)")
     ap.add_argument("--dp", action="store_true",
                     help="with --gpus N > 1: make the weak-scaling data-parallel C3 run the headline instead of N-sharded C5")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
@@ -516,7 +534,7 @@ def main() -> None:
     result: dict = {}
     if args.workload == "c5" or (world > 1 and args.workload == "c3" and not args.dp):
         # multi-GPU headline (and `--workload c5` on one GPU): BASELINE config C5, strong scaling over N
-        res = nshard_c5(world, rank, device, args.steps, args.warmup)
+        res = nshard_c5(world, rank, device, args.steps, args.warmup, direct=args.c5_direct)
         extra = {}
         if world > 1 and args.workload == "c3":
             try:  # side field: weak-scaling data parallel C3 (no collective on the data path)
