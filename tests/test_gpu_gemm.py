@@ -476,7 +476,7 @@ def test_scaled_gemm_c2_config_bit_exact():
 def test_scaled_gemm_c3_config_properties():
     """BASELINE config C3 (fp8 -> bf16, 4096x4096x11008) at full size.
 
-    (1) a band of rows is checked against the oracle; (2) the MFMA kernel agrees with the generic
+    (1) every element is checked against the oracle, per element; (2) the MFMA kernel agrees with the generic
     device kernel everywhere up to accumulation order; (3) row-linearity: permuting the rows of A
     permutes the rows of C bit-for-bit (each output row depends only on its own row of A).
     """
@@ -484,9 +484,13 @@ def test_scaled_gemm_c3_config_properties():
     a, b, sa, sb, _ = make_scaled_inputs(m, k, n, torch.float8_e4m3fn, torch.bfloat16, False, False, False)
     a_d, bt_d, sa_d, sb_d = a.cuda(), b.T.contiguous().cuda(), sa.cuda(), sb.cuda()
     got = scaled_gemm(a_d, bt_d.T, sa_d, sb_d, torch.bfloat16)
-    rows = torch.cat([torch.arange(0, 48), torch.arange(2040, 2072), torch.arange(4080, 4096)])
-    ref = oracle.scaled_gemm_ref(a[rows], b, sa[rows], sb, torch.bfloat16, None)
-    check_scaled(got[rows.cuda()], ref, torch.float8_e4m3fn, torch.bfloat16)
+    # EVERY element of the headline output against the oracle, per element (round 4: rounds 1-3 checked 96 rows here and the
+    # rest against the build's own generic kernel; the oracle's fp32 matmul of the full problem is a second on the GPU box's host)
+    got_h = got.cpu()
+    for r0 in range(0, m, 1024):
+        rows = slice(r0, r0 + 1024)
+        ref = oracle.scaled_gemm_ref(a[rows], b, sa[rows], sb, torch.bfloat16, None)
+        check_scaled(got_h[rows], ref, torch.float8_e4m3fn, torch.bfloat16, (a[rows], b, sa[rows], sb, None))
     _C.set_gemm_variant(_C.VARIANT_GENERIC)
     slow = scaled_gemm(a_d, bt_d.T, sa_d, sb_d, torch.bfloat16)
     _C.set_gemm_variant(_C.VARIANT_AUTO)
@@ -502,7 +506,7 @@ def test_scaled_gemm_c5_config_shard_invariance():
 
     (1) the column block a rank would compute (N/8 = 3584 columns, rank 0, 3 and 7) from ITS slice of B / scale_b
     equals the same columns of the full product bit-for-bit -- the property the multi-GPU path rests on
-    (no reduction, so sharding must not change a single bit); (2) a band of rows of the full product
+    (no reduction, so sharding must not change a single bit); (2) every element of the full product
     against the CPU oracle.
     """
     m, k, n, world = 8192, 8192, 28672, 8
@@ -517,9 +521,12 @@ def test_scaled_gemm_c5_config_shard_invariance():
         lo, hi = rank * shard, (rank + 1) * shard
         part = scaled_gemm(a, bt[lo:hi].T, sa, sb[lo:hi], torch.bfloat16)
         assert torch.equal(part, full[:, lo:hi]), f"rank {rank}"
-    rows = torch.cat([torch.arange(0, 16), torch.arange(8176, 8192)])
-    ref = oracle.scaled_gemm_ref(a[rows.cuda()].cpu(), bt.cpu().T, sa[rows.cuda()].cpu(), sb.cpu(), torch.bfloat16, None)
-    check_scaled(full[rows.cuda()], ref, torch.float8_e4m3fn, torch.bfloat16)
+    # every element of the full product against the oracle (round 4; 32 rows until then), in blocks of 1024 rows
+    a_h, b_h, sa_h, sb_h, full_h = a.cpu(), bt.cpu().T, sa.cpu(), sb.cpu(), full.cpu()
+    for r0 in range(0, m, 1024):
+        rows = slice(r0, r0 + 1024)
+        ref = oracle.scaled_gemm_ref(a_h[rows], b_h, sa_h[rows], sb_h, torch.bfloat16, None)
+        check_scaled(full_h[rows], ref, torch.float8_e4m3fn, torch.bfloat16)
 
 
 # ---------------------------------------------------------------------------------------------
