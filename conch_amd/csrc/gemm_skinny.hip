@@ -291,9 +291,18 @@ __global__ __launch_bounds__(kSkThreads, 1) void skinny_splitk_kernel(ScaledGemm
     const int chunk = (lane & 7) ^ ((rho >> 1) & 7);
     voff_a[j] = min(m0 + rho, (int)p.m - 1) * (int)p.a_stride_m + chunk * 16;
   }
-  const int voff_b = GATHER ? min(n0 + (lane >> 2), (int)p.n - 1) * (int)p.b_stride_n + 16 * (lane & 3)
+  // GATHER: lane L fetches row L >> 2; its chunk is L & 3 for rows 0-7 and (L + 2) & 3 for rows 8-15 (a quad still covers the
+  // row's 64 contiguous bytes).  Without the rotation operand lane (r, g) would read lane 4 r + g, and the lanes (r, g) and
+  // (r + 8, g) of one half-wave -- sources 32 lanes apart -- hit the same ds_bpermute bank: two extra LDS cycles per
+  // instruction, ALL of C2's SQ_LDS_BANK_CONFLICT (262 144 = 131 072 bpermutes x 2: profiles/r03/c2_rocprofv3_summary.txt).
+#ifdef CONCH_EXP_GATHER_PLAIN  // A/B variant: round 3's order
+  const int rot = 0;
+#else
+  const int rot = 2;
+#endif
+  const int voff_b = GATHER ? min(n0 + (lane >> 2), (int)p.n - 1) * (int)p.b_stride_n + 16 * (((lane & 3) + rot * (lane >> 5)) & 3)
                                : min(n0 + r, (int)p.n - 1) * (int)p.b_stride_n + 16 * g;
-  const int gather = (4 * r + g) * 4;
+  const int gather = (4 * r + ((g - rot * (r >> 3)) & 3)) * 4;
   const int lane_off = (r >> 3) * 1024 + (r & 7) * 128 + ((g ^ ((r >> 1) & 7)) * 16);
 
   // One-launch form: the scales and the bias of this lane's outputs are requested BEFORE the K slice (they are older than
