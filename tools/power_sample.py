@@ -26,6 +26,28 @@ def child(pattern: str, seconds: float) -> None:
 
     torch.manual_seed(0)
     f8 = torch.float8_e4m3fn
+    if pattern.startswith("mixed"):  # the reference's README shape, int4 x fp16: the benchmark's data / all-zero activations
+        from conch_amd.ops.quantization.gemm import create_mixed_precision_metadata
+
+        m, k, n = 4096, 8192, 4096
+        x = (10 * (torch.rand((m, k), device="cuda") - 0.3)).to(torch.float16)
+        if pattern == "mixed_zero":
+            x.zero_()
+        wq = torch.randint(-2**31, 2**31 - 1, (k // 8, n), dtype=torch.int32, device="cuda")
+        ws = (0.1 * torch.rand((k // 128, n), device="cuda") + 0.01).to(torch.float16)
+        md = create_mixed_precision_metadata(x, wq, ws, None, 4, 8, 128)
+        out = torch.empty((m, n), dtype=torch.float16, device="cuda")
+        ms = ctypes.c_float()
+        torch.cuda.synchronize()
+        print("READY", flush=True)
+        t_end = time.perf_counter() + seconds
+        last = []
+        while time.perf_counter() < t_end:
+            _C.check(kg._mixed_gemm_call("conch_time_mixed_precision_gemm", out, x, wq, ws, None, md, (100, ctypes.byref(ms))), "time")
+            last.append(ms.value)
+        tail = sorted(last[len(last) // 2:])
+        print(f"LAUNCH_US {tail[len(tail) // 2] * 1e3:.1f}", flush=True)
+        return
     if pattern == "bench":
         a, bt = (0.25 * torch.rand((M, K), device="cuda")).to(f8), (0.25 * torch.rand((N, K), device="cuda")).to(f8)
     elif pattern == "zero":
@@ -78,6 +100,7 @@ def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--child", default=None)
     ap.add_argument("--seconds", type=float, default=8.0)
+    ap.add_argument("--patterns", default="idle,bench,zero,bytes,bench,mixed,mixed_zero,mixed")
     ap.add_argument("--raw", action="store_true", help="print every SMI sample")
     args = ap.parse_args()
     if args.child:
@@ -87,8 +110,8 @@ def main() -> None:
         r = subprocess.run(["amd-smi", "static", "-l", "-g", "0"], capture_output=True, text=True, timeout=30)
         print("# amd-smi static -l:", " ; ".join(re.sub(r"\s+", " ", l.strip()) for l in r.stdout.splitlines() if re.search(r"POWER_LIMIT", l))[:300])
     print("# C3 (fp8 4096x4096x11008) looping back to back on: idle = context only; bench = the benchmark's data (0.25 x rand); zero = all-zero operands; "
-          "bytes = full-range random bytes; launch = median time of a launch (200 per timing)")
-    for pattern in ("idle", "bench", "zero", "bytes", "bench"):
+          "bytes = full-range random bytes; mixed / mixed_zero = mixed_precision_gemm int4 x fp16 4096x8192x4096 on the benchmark's data / zero activations; launch = median time of a launch (200 per timing)")
+    for pattern in args.patterns.split(","):
         p = subprocess.Popen([sys.executable, __file__, "--child", pattern, "--seconds", str(args.seconds)], stdout=subprocess.PIPE, text=True)
         assert p.stdout is not None
         while True:
@@ -110,7 +133,7 @@ def main() -> None:
         p.wait()
         launch = [l.split()[1] for l in rest.splitlines() if l.startswith("LAUNCH_US")]
         med = lambda v: statistics.median(v) if v else float("nan")  # noqa: E731
-        print(f"{pattern:6s}: socket power {min(power, default=0)}-{max(power, default=0)} W (median {med(power):.0f}, {len(power)} samples), "
+        print(f"{pattern:10s}: socket power {min(power, default=0)}-{max(power, default=0)} W (median {med(power):.0f}, {len(power)} samples), "
               f"XCD clocks median {med(gfx):.0f} MHz (amd-smi), sclk {med(sclk):.0f} MHz (rocm-smi), junction {med(temp):.0f} C"
               + (f", launch {launch[0]} us" if launch else ""), flush=True)
 
