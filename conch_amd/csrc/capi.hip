@@ -554,6 +554,7 @@ extern "C" int conch_reserve_scratch(void* stream, int64_t bytes) {
   void* ignored = nullptr;
   for (int slot = 0; slot < kScratchCounters; ++slot)
     if (int rc = get_scratch((hipStream_t)stream, slot, (size_t)bytes, &ignored)) return rc;
+  if (int rc = get_scratch((hipStream_t)stream, kScratchFlags, 256, &ignored)) return rc;  // e4m3fnuz dispatch word
   return get_scratch((hipStream_t)stream, kScratchCounters, (size_t)64 * 1024, &ignored, /*zero_on_alloc=*/true);
 }
 

@@ -96,6 +96,37 @@ def test_scratch_growth_inside_a_capture_is_refused_not_fatal():
     assert torch.equal(out, want)
 
 
+@pytest.mark.parametrize("special", [False, True])
+def test_e4m3fnuz_gemm_captures_after_the_reservation_alone(special):
+    """The e4m3fnuz flow (flag memset, scan, gated fp8 kernel, gated expansion + bf16 kernel: capi.hip run_scaled) is stream work
+    only, and conch_reserve_scratch covers its flag word and its expansion buffers: it captures on a stream that never ran it
+    eagerly, and a replay takes whichever branch the operands of THAT replay ask for."""
+    seed_everything(14)
+    m, k, n = 512, 1024, 768
+    dev = torch.device("cuda")
+    fnuz = torch.float8_e4m3fnuz
+    a = (torch.rand((m, k), device=dev) - 0.5).to(fnuz)
+    bt = (torch.rand((n, k), device=dev) - 0.5).to(fnuz)
+    sa, sb = 0.25 * torch.rand((m, 1), device=dev), 0.25 * torch.rand((n, 1), device=dev)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        _C.reserve_scratch(_C.load().conch_scaled_gemm_workspace_bytes(m, n, k))
+    stream.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=stream):
+        out = scaled_gemm(a, bt.T, sa, sb, torch.bfloat16)
+    for trial in range(2):
+        if special and trial == 1:  # a code the fp8 MFMA reads differently (0x7F: 240 in fnuz, NaN in fn): the other branch
+            a.view(torch.uint8)[3, 5] = 0x7F
+        graph.replay()
+        torch.cuda.synchronize()
+        got = out.clone()
+        want = scaled_gemm(a, bt.T, sa, sb, torch.bfloat16)
+        torch.cuda.synchronize()
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16)), f"trial {trial}"
+        assert torch.isfinite(got.float()).all()
+
+
 def test_reset_scratch_is_harmless_between_one_launch_calls():
     """conch_reset_scratch zeroes the arrival counters of the current stream with a memset ordered ON that stream: between two
     one-launch split-K calls it changes nothing (the counters are zero there by construction); on a stream that never used a
