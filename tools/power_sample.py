@@ -26,6 +26,29 @@ def child(pattern: str, seconds: float) -> None:
 
     torch.manual_seed(0)
     f8 = torch.float8_e4m3fn
+    if pattern.startswith("vendor"):  # torch.matmul (hipBLASLt / rocBLAS) on fp16 weights dequantised beforehand, README shape
+        m, k, n = 4096, 8192, 4096
+        x = (10 * (torch.rand((m, k), device="cuda") - 0.3)).to(torch.float16)
+        if pattern == "vendor_zero":
+            x.zero_()
+        w = ((torch.randint(0, 16, (k, n), device="cuda") - 8).float() * (0.1 * torch.rand((k // 128, n), device="cuda") + 0.01).repeat_interleave(128, 0)).to(torch.float16)
+        out = torch.empty((m, n), dtype=torch.float16, device="cuda")
+        torch.matmul(x, w, out=out)
+        torch.cuda.synchronize()
+        print("READY", flush=True)
+        t_end = time.perf_counter() + seconds
+        last = []
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        while time.perf_counter() < t_end:
+            e0.record()
+            for _ in range(100):
+                torch.matmul(x, w, out=out)
+            e1.record()
+            e1.synchronize()
+            last.append(e0.elapsed_time(e1) / 100)
+        tail = sorted(last[len(last) // 2:])
+        print(f"LAUNCH_US {tail[len(tail) // 2] * 1e3:.1f}", flush=True)
+        return
     if pattern.startswith("mixed"):  # the reference's README shape, int4 x fp16: the benchmark's data / all-zero activations
         from conch_amd.ops.quantization.gemm import create_mixed_precision_metadata
 
