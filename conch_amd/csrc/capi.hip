@@ -1,6 +1,7 @@
 // extern "C" entry points of libconch_amd.so (declared in include/conch_amd.h): argument
 // validation, kernel selection, error strings.  No torch types, no exceptions across the boundary.
 #include <algorithm>
+#include <cmath>
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
@@ -149,8 +150,18 @@ ScaledKernel choose_scaled_kernel(const ScaledGemmArgs& p) {
   const int64_t tiles128 = ((p.m + 127) / 128) * ((p.n + 127) / 128);
   const int64_t rounds128 = (tiles128 + 511) / 512;
   // at most one tile per CU: the 4-stage ring (gemm_mid.hip), three K steps in flight per CU instead of one
-  const double mid_us = tiles128 <= device_cu_count() ? (23.0 + 0.08 * (double)std::max<int64_t>(0, tiles128 - 128)) * kscale
-                                                      : (double)rounds128 * (31.0 + 0.02 * (double)tiles128 / (double)rounds128) * kscale;
+  double mid_us = tiles128 <= device_cu_count() ? (23.0 + 0.08 * (double)std::max<int64_t>(0, tiles128 - 128)) * kscale
+                                                : (double)rounds128 * (31.0 + 0.02 * (double)tiles128 / (double)rounds128) * kscale;
+  // split-K form of the 128 x 128 tiles (gemm_mid.hip, mid_split_slices; round 4, profiles/r04/mid_splitk_sweep.txt): two launches
+  // (~7 us of fixed cost between them), a K step 0.52-0.68 us with up to one workgroup per CU and ~1.0 us with two, the slabs written
+  // and read back at ~8 bytes per us and CU-free MB
+  if (const int msl = mid_split_slices(p); msl > 1) {
+    const double cus = (double)device_cu_count();
+    const double wgs = (double)tiles128 * msl;
+    const double steps_slice = std::ceil((double)(p.k / 128) / msl);
+    const double per_step = wgs <= cus ? 0.52 + 0.16 * wgs / cus : std::ceil(wgs / (2.0 * cus));
+    mid_us = 7.0 + steps_slice * per_step + (double)msl * (double)p.m * (double)p.n * 1e-6;
+  }
   ScaledKernel pick = kKernelTiled;
   double best = tiled_us;
   if (mid_us < best) {

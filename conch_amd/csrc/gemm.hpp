@@ -51,6 +51,11 @@ struct ScaledGemmArgs {
   // nothing is staged or unpacked afterwards.  A separate instantiation of the kernel: the one-destination code is untouched.
   void* c_more[7] = {};
   int n_more = 0;
+  // 128 x 128-tile kernel, split-K form (few tiles, long K: gemm_mid.hip): blockIdx.y = K slice of `split_steps` 128-byte steps,
+  // the raw fp32 / int32 partial tiles go to `slabs` [slice][M][N] and the split-K reduce kernel of gemm_skinny.hip sums them in
+  // slice order and applies the epilogue.  0 = the whole K in one workgroup (no slabs).
+  int split_steps = 0;
+  void* slabs = nullptr;
 };
 
 #ifdef __HIPCC__
@@ -121,11 +126,15 @@ bool scaled_gemm_mfma_supported(const ScaledGemmArgs& p);
 int launch_scaled_gemm_mfma(const ScaledGemmArgs& p, int variant, hipStream_t stream);
 // gemm_mid.hip -- 128x128 tiles, two workgroups per CU, for shapes with few 256x256 tiles (variant 6); same contract
 int launch_scaled_gemm_mid(const ScaledGemmArgs& p, hipStream_t stream);
+int mid_split_slices(const ScaledGemmArgs& p);  // K slices that launcher will use for `p` (1 = no split-K)
 // the dispatcher's cost model (capi.hip, choose_scaled_kernel): 0 = 256 x 256 tiles, 1 = 128 x 128 tiles, 2 = split-K skinny
 int scaled_kernel_choice(const ScaledGemmArgs& p);
 // gemm_skinny.hip -- M <= 256: 128x16 blocks, K split over the waves, register streaming (variant 4)
 bool scaled_gemm_skinny_supported(const ScaledGemmArgs& p);
 int launch_scaled_gemm_skinny(const ScaledGemmArgs& p, hipStream_t stream);
+// the split-K reduce kernel on its own: C = epilogue(sum over `slices` slabs [slice][M][N] of fp32 / int32 partial sums, in slice
+// order); N % 4 == 0.  Used by the 128 x 128-tile kernel's split-K form (gemm_mid.hip)
+int launch_splitk_reduce(const ScaledGemmArgs& p, const void* slabs, int slices, hipStream_t stream);
 bool scaled_gemm_skinny_fused_supported(const ScaledGemmArgs& wide);  // silu_and_mul fused into the split-K reduce kernel
 // repack.hip -- copy operands into the MFMA layout contract (stream-ordered scratch)
 int repack_for_mfma(const ScaledGemmArgs& p, ScaledGemmArgs* q, void** scratch, hipStream_t stream);

@@ -33,7 +33,12 @@ struct MidOffsets {
   int u[4], v[4];  // byte offset of this lane's 16-byte source chunk for the wave's four pieces of a unit
 };
 
-template <int MMA, int OUT_DT, int STAGES>
+// SPLIT (round 4): blockIdx.y is a K slice of p.split_steps steps; the workgroup leaves its raw fp32 / int32 partial tile in
+// p.slabs [slice][M][N] and the split-K reduce kernel (gemm_skinny.hip) finishes the op.  For few tiles and a long K -- e.g.
+// 256 x 11008 x 4096, the Llama-7B down projection at a prefill chunk of 256 rows: 64 tiles of 86 steps each left three
+// quarters of the chip idle (51.5 us against 24 for the vendor's GEMM: profiles/r04/vendor_grid_fp8.txt).  A separate
+// instantiation: the whole-K kernels are unchanged.
+template <int MMA, int OUT_DT, int STAGES, bool SPLIT = false>
 __global__ __launch_bounds__(kMidThreads, 2) void scaled_gemm_mid_kernel(ScaledGemmArgs p) {
   constexpr int kMidEpi = STAGES * kMidBuf;
   constexpr int kMidLds = kMidEpi + 3 * 128 * 4;
@@ -61,9 +66,12 @@ __global__ __launch_bounds__(kMidThreads, 2) void scaled_gemm_mid_kernel(ScaledG
     so.u[j] = min(bm0 + rho, (int)p.m - 1) * (int)p.a_stride_m + chunk * 16;
     so.v[j] = min(bn0 + nrow, (int)p.n - 1) * (int)p.b_stride_n + chunk * 16;
   }
+  const int total_steps = (int)(p.k / kStepBytes);
+  const int step0 = SPLIT ? (int)blockIdx.y * p.split_steps : 0;
+  const int steps = SPLIT ? min(p.split_steps, total_steps - step0) : total_steps;
   auto stage = [&](int step) {
     char* dst = lds + (step % STAGES) * kMidBuf + wave * 4096;
-    const int koff = step * kStepBytes;
+    const int koff = (step0 + step) * kStepBytes;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(src.a, (lds_void_t*)(dst + j * 1024), 16, so.u[j], koff, 0, 0);
@@ -77,9 +85,13 @@ __global__ __launch_bounds__(kMidThreads, 2) void scaled_gemm_mid_kernel(ScaledG
   // instead of its first -- and a bias loaded under `if (p.bias)` was waited for, a memory round trip, before the first operand
   // load was requested.)
   const bool epi_is_b = threadIdx.x >= 128;
-  float epi_v0;
-  uint32_t epi_bits;
-  {
+  [[maybe_unused]] float epi_v0 = 0.0f;
+  [[maybe_unused]] uint32_t epi_bits = 0;
+  if constexpr (SPLIT) {
+#pragma unroll
+    for (int s0 = 0; s0 < STAGES - 1; ++s0)
+      if (s0 < steps) stage(s0);
+  } else {
     const int tt = threadIdx.x & 127;
     const int idx = epi_is_b ? min(bn0 + tt, (int)p.n - 1) : min(bm0 + tt, (int)p.m - 1);
     const float* base = epi_is_b ? p.scale_b : p.scale_a;
@@ -89,10 +101,9 @@ __global__ __launch_bounds__(kMidThreads, 2) void scaled_gemm_mid_kernel(ScaledG
     // unconditional (without a bias: two readable bytes of A, never used)
     const uint16_t* bias_src = p.bias ? (const uint16_t*)p.bias + min(bn0 + tt, (int)p.n - 1) : (const uint16_t*)p.a;
     epi_bits = *bias_src;
-    const int steps0 = (int)(p.k / kStepBytes);
 #pragma unroll
     for (int s0 = 0; s0 < STAGES - 1; ++s0)
-      if (s0 < steps0) stage(s0);
+      if (s0 < steps) stage(s0);
   }
 
   const int r = lane & 15, g = lane >> 4;
@@ -106,7 +117,6 @@ __global__ __launch_bounds__(kMidThreads, 2) void scaled_gemm_mid_kernel(ScaledG
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[i][t] = typename AccT<MMA>::type{0, 0, 0, 0};
 
-  const int steps = (int)(p.k / kStepBytes);
   for (int t = 0; t < steps; ++t) {
     // this wave's pieces of step t have landed (the steps behind it -- up to STAGES - 2, eight LDS-DMA instructions each, the
     // only vector-memory work in the loop -- may still be in flight; the last steps simply drain) ...
@@ -154,6 +164,25 @@ __global__ __launch_bounds__(kMidThreads, 2) void scaled_gemm_mid_kernel(ScaledG
     }
   }
 
+  if constexpr (SPLIT) {
+    // the raw partial tile, row-major: lane (r, g) holds eight consecutive columns of row r of every (m tile, column half) --
+    // 32 bytes, a 128-byte line per quad of g
+    int* slab = (int*)p.slabs + (int64_t)blockIdx.y * p.m * p.n;
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) {
+      const int n0 = bn0 + wc * 64 + nh * 32 + 8 * g;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const int m = bm0 + wr * 64 + mt * 16 + r;
+        if (m >= p.m) continue;
+        int* dst = slab + (int64_t)m * p.n + n0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)  // N % 4 == 0 (launcher): whole 16-byte quads
+          if (n0 + 4 * h + 4 <= p.n) *(i32x4*)(dst + 4 * h) = __builtin_bit_cast(i32x4, acc[mt][nh * 2 + h]);
+      }
+    }
+    return;
+  }
   // epilogue: sb * (sa * acc), RNE cast, bias in the output dtype (reference/quantization/scaled_gemm.py:21-25).
   // Whole tiles: row-major through 2 KiB of LDS per wave, whole-line write-through stores (epilogue_rows.hpp; a wave's 64
   // columns are one 128-byte line per row); CONCH_TUNE_EPILOGUE = 1 and ragged tiles store from the accumulator layout.
@@ -215,6 +244,36 @@ __global__ __launch_bounds__(kMidThreads, 2) void scaled_gemm_mid_kernel(ScaledG
 
 }  // namespace
 
+// K slices the 128 x 128-tile kernel splits a problem into (1 = whole K per workgroup).  Plain fp8 / int8 problems only (the
+// reduce kernel applies scale_a / scale_b / bias: no e4m3fnuz gate, no 16-bit operand forms); N % 4 == 0 (16-byte slab quads).
+// Measured (profiles/r04/mid_splitk_sweep.txt, 18 shapes x 1..8 slices x both ring depths): the launch wants EITHER about one
+// workgroup per CU (the 4-stage ring) OR about two (the 2-stage loop) -- 1.5 per CU leaves half the chip with twice the work
+// (256 x 28672 x 8192: 73.5 us in 2 slices, 99 in 3, 83 in 4) -- so: up to half a chip of tiles, as many slices as fit one
+// workgroup per CU; up to ~0.7 of a chip, as many as fit two; beyond that the reduce pass costs what the idle CUs would give.
+// A slice is at least eight K steps, and K at least 8192 bytes (4096 for at most a quarter chip of tiles), at most 8 slabs.
+// CONCH_TUNE_MID_SPLITK: 0 = auto, 1 = never, 2..8 = that many slices where the form applies.
+int mid_split_slices(const ScaledGemmArgs& p) {
+  const int forced = tuning(CONCH_TUNE_MID_SPLITK);
+  if (forced == 1) return 1;
+  if (p.in_dtype != CONCH_DT_FP8_E4M3FN && p.in_dtype != CONCH_DT_INT8) return 1;
+  if (p.gate || p.acc_scale != 1.0f || !p.scale_a || !p.scale_b || p.fuse_silu || p.n_more || p.n % 4 || p.c_stride_n != 1) return 1;
+  const int64_t tiles = ((p.m + kMidTile - 1) / kMidTile) * ((p.n + kMidTile - 1) / kMidTile);
+  const int64_t steps = p.k / kStepBytes;
+  if ((p.m * p.n * 4) >= ((int64_t)1 << 28) || tiles < 1) return 1;
+  int64_t slices;
+  if (forced >= 2) slices = forced;
+  else {
+    const int64_t cus = device_cu_count();
+    if (tiles * 10 > cus * 7) return 1;
+    if (steps < (tiles * 4 <= cus ? 32 : 64)) return 1;
+    slices = tiles * 2 <= cus ? cus / tiles : (2 * cus) / tiles;
+  }
+  slices = std::min<int64_t>(std::min<int64_t>(slices, 8), steps / 8);
+  if (slices < 2) return 1;
+  const int64_t per = (steps + slices - 1) / slices;
+  return (int)((steps + per - 1) / per);  // no empty slice
+}
+
 // Same layout contract as the 256x256 kernels (scaled_gemm_mfma_supported).
 int launch_scaled_gemm_mid(const ScaledGemmArgs& p_in, hipStream_t stream) {
   ScaledGemmArgs p = p_in;
@@ -222,10 +281,26 @@ int launch_scaled_gemm_mid(const ScaledGemmArgs& p_in, hipStream_t stream) {
   set_raster_divisor((uint32_t)(kGroupM * ((p.n + kMidTile - 1) / kMidTile)), &p.raster_magic, &p.raster_shift);
   const int tiles_m = (int)((p.m + kMidTile - 1) / kMidTile);
   const int tiles_n = (int)((p.n + kMidTile - 1) / kMidTile);
-  const dim3 grid((unsigned)(tiles_m * tiles_n));
-  // at most one tile per CU: the deep ring (one workgroup per CU either way); CONCH_TUNE_MID_STAGES forces 2 or 4
+  const int slices = mid_split_slices(p);
+  const dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)slices);
+  // at most one workgroup per CU: the deep ring (one workgroup per CU either way); CONCH_TUNE_MID_STAGES forces 2 or 4
   const int forced = tuning(CONCH_TUNE_MID_STAGES);
-  const bool deep = forced == 4 || (forced != 2 && (int64_t)tiles_m * tiles_n <= device_cu_count());
+  const bool deep = forced == 4 || (forced != 2 && (int64_t)tiles_m * tiles_n * slices <= device_cu_count());
+  if (slices > 1) {
+    const int64_t steps = p.k / kStepBytes;
+    p.split_steps = (int)((steps + slices - 1) / slices);
+    if (int rc = get_scratch(stream, kScratchSplitK, (size_t)slices * (size_t)p.m * (size_t)p.n * 4, &p.slabs)) return rc;
+#define CONCH_LAUNCH_MID_SPLIT(MMA)                                                                                      \
+  do {                                                                                                                   \
+    if (deep) hipLaunchKernelGGL((scaled_gemm_mid_kernel<MMA, CONCH_DT_BF16, 4, true>), grid, dim3(kMidThreads), 0, stream, p); \
+    else hipLaunchKernelGGL((scaled_gemm_mid_kernel<MMA, CONCH_DT_BF16, 2, true>), grid, dim3(kMidThreads), 0, stream, p);  \
+  } while (0)
+    if (p.in_dtype == CONCH_DT_FP8_E4M3FN) CONCH_LAUNCH_MID_SPLIT(kMmaFp8);
+    else CONCH_LAUNCH_MID_SPLIT(kMmaInt8);
+#undef CONCH_LAUNCH_MID_SPLIT
+    if (int rc = check_launch("scaled_gemm_mid_split")) return rc;
+    return launch_splitk_reduce(p, p.slabs, slices, stream);
+  }
 #define CONCH_LAUNCH_MID(MMA, OUT)                                                                         \
   do {                                                                                                     \
     if (deep) hipLaunchKernelGGL((scaled_gemm_mid_kernel<MMA, OUT, 4>), grid, dim3(kMidThreads), 0, stream, p); \

@@ -716,6 +716,22 @@ int launch_splitk(const ScaledGemmArgs& p, int slices, hipStream_t stream) {
   return check_launch("scaled_gemm_skinny_splitk");
 }
 
+int launch_splitk_reduce(const ScaledGemmArgs& p, const void* slabs, int slices, hipStream_t stream) {
+  CONCH_CHECK_ARG(p.n % 4 == 0 && slices >= 1, "split-K reduce: N %% 4 != 0 or no slices");
+  const dim3 grid((unsigned)((p.n / 4 + 255) / 256), (unsigned)p.m);
+  const bool f = p.in_dtype != CONCH_DT_INT8;  // fp32 partial sums (fp8 and the 16-bit operand forms) or int32
+#define CONCH_RED(MMA, OUT) hipLaunchKernelGGL((skinny_reduce_kernel<MMA, OUT>), grid, dim3(256), 0, stream, p, (const int*)slabs, slices)
+  if (p.out_dtype == CONCH_DT_BF16) {
+    if (f) CONCH_RED(kMmaFp8, CONCH_DT_BF16);
+    else CONCH_RED(kMmaInt8, CONCH_DT_BF16);
+  } else {
+    if (f) CONCH_RED(kMmaFp8, CONCH_DT_FP16);
+    else CONCH_RED(kMmaInt8, CONCH_DT_FP16);
+  }
+#undef CONCH_RED
+  return check_launch("scaled_gemm_splitk_reduce");
+}
+
 int launch_scaled_gemm_skinny(const ScaledGemmArgs& p, hipStream_t stream) {
   // fuse_silu: `p` is the WIDE problem (n = 2d) whose reduce kernel writes the d-column FFN result (the caller has checked
   // scaled_gemm_skinny_fused_supported); only the split-K form has a reduce kernel

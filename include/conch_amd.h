@@ -166,7 +166,9 @@ typedef enum conch_tuning_key {
                                   through LDS: gemm_mixed.hip), 2 = the column-strip kernel (every wave dequantises its own 16 / 32
                                   columns straight into MFMA operand registers: gemm_mixed_strip.hip) wherever its contract holds */
   ,
-  CONCH_TUNE__COUNT = 12 /* number of keys (array bound; not a key) */
+  CONCH_TUNE_MID_SPLITK = 12 /* 128x128-tile scaled GEMM: K slices per tile (fp32 / int32 slabs + the split-K reduce kernel) when the
+                               tiles leave at least half the chip idle and K >= 4096: 0 = auto, 1 = never, 2..8 = that many */,
+  CONCH_TUNE__COUNT = 13 /* number of keys (array bound; not a key) */
 } conch_tuning_key_t;
 
 int conch_abi_version(void);

@@ -171,6 +171,37 @@ def _reset_tuning():
     _C.set_tuning(_C.TUNE_SKINNY_GATHER, 0)
     _C.set_tuning(_C.TUNE_MIXED_KERNEL, 0)
     _C.set_tuning(_C.TUNE_MIXED_TILE_NT, 0)
+    _C.set_tuning(_C.TUNE_MID_SPLITK, 0)
+
+
+@pytest.mark.parametrize("slices", [2, 3, 5, 8])
+@pytest.mark.parametrize("iname", ["int8", "fn"])
+@pytest.mark.parametrize(("m", "k", "n", "with_bias"), [(256, 4096, 1024, True), (300, 2176, 520, False), (129, 1024, 8, True), (512, 11008, 256, False),
+                                                         (1000, 1152, 132, True)])
+def test_mid_kernel_split_k(_reset_tuning, slices, iname, m, k, n, with_bias):
+    """The 128x128-tile kernel with K split over `slices` workgroups per tile (raw partial tiles to slabs, the split-K reduce kernel
+    sums them in slice order and applies the epilogue): int8 bit-identical to the whole-K kernel (integer sums), fp8 within the
+    oracle's per-element bound (fp32 partial sums meet in a different order); both ring depths; ragged tiles, slices of unequal
+    length (K of 17 steps in 3, 5 or 8 slices)."""
+    a, b, sa, sb, bias = make_scaled_inputs(m, k, n, IN_T[iname], torch.bfloat16, False, False, with_bias)
+    ref = oracle.scaled_gemm_ref(a, b, sa, sb, torch.bfloat16, bias)
+    _C.set_gemm_variant(_C.VARIANT_MFMA_MID)
+    try:
+        _C.set_tuning(_C.TUNE_MID_SPLITK, 1)
+        whole = run_scaled(a, b, sa, sb, torch.bfloat16, bias)
+        _C.set_tuning(_C.TUNE_MID_SPLITK, slices)
+        outs = []
+        for stages in (2, 4):
+            _C.set_tuning(_C.TUNE_MID_STAGES, stages)
+            outs.append(run_scaled(a, b, sa, sb, torch.bfloat16, bias))
+        assert torch.equal(outs[0], outs[1])  # the ring depth moves loads, not sums
+        check_scaled(outs[0], ref, IN_T[iname], torch.bfloat16, (a, b, sa, sb, bias))
+        if iname == "int8":
+            assert torch.equal(outs[0], whole)
+        for _ in range(2):
+            assert torch.equal(run_scaled(a, b, sa, sb, torch.bfloat16, bias), outs[1])
+    finally:
+        _C.set_gemm_variant(0)
 
 
 @pytest.mark.parametrize("iname", ["int8", "fn"])

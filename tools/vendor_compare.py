@@ -75,7 +75,34 @@ def int8_case(m, k, n):
     print(line, flush=True)
 
 
+def grid():
+    """LLM projection shapes x batch sizes, ours against the vendor's, one line per shape: where does the dispatcher leave time?"""
+    dims = [(4096, 4096), (4096, 11008), (11008, 4096), (4096, 12288), (8192, 8192), (8192, 28672), (28672, 8192), (5120, 13824), (13824, 5120)]
+    for k, n in dims:
+        for m in (16, 64, 256, 512, 1024, 2048, 4096, 8192):
+            if m * n * k > 8192 * 8192 * 28672 // 2:
+                continue
+            torch.manual_seed(0)
+            a = (0.25 * torch.rand((m, k), device="cuda")).to(torch.float8_e4m3fn)
+            bt = (0.25 * torch.rand((n, k), device="cuda")).to(torch.float8_e4m3fn)
+            sa, sb = 0.25 * torch.rand((m, 1), device="cuda"), 0.25 * torch.rand((n, 1), device="cuda")
+            sbt = sb.T.contiguous()
+            it = 200 if m * n * k < 2**36 else 40
+            ours = timeit(lambda: scaled_gemm(a, bt.T, sa, sb, torch.bfloat16), iters=it, rounds=3)
+            try:
+                ref = timeit(lambda: torch._scaled_mm(a, bt.T, scale_a=sa, scale_b=sbt, out_dtype=torch.bfloat16), iters=it, rounds=3)
+            except Exception:  # noqa: BLE001
+                ref = float("nan")
+            fl = 2.0 * m * n * k
+            flag = "  <-- vendor ahead" if ref < ours * 0.97 else ""
+            print(f"fp8 M={m:5d} K={k:5d} N={n:5d}: ours {ours * 1e3:8.1f} us ({fl / ours / 1e9 / 5000:.3f})  vendor {ref * 1e3:8.1f} us  x{ours / ref:.2f}{flag}", flush=True)
+            del a, bt
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--grid":
+        grid()
+        sys.exit(0)
     for shape in [(128, 4096, 4096), (32, 8192, 8192), (256, 4096, 11008)]:
         int8_case(*shape)
     for shape in [(4096, 4096, 11008), (8192, 8192, 8192), (8192, 8192, 3584)]:
