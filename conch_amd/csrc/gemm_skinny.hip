@@ -257,7 +257,7 @@ __device__ unsigned long long g_probe_skinny[kProbeBlocks * 8];
 #define SK_DRAIN() do { } while (0)
 #endif
 
-template <int MMA, int OUT_DT, int ROWS, int STEPS, bool FUSED, int A_SRC = 0, bool GATHER = false>
+template <int MMA, int OUT_DT, int ROWS, int STEPS, bool FUSED, int A_SRC = 0, bool GATHER = false, bool LOOP = false>
 __global__ __launch_bounds__(kSkThreads, 1) void skinny_splitk_kernel(ScaledGemmArgs p, int* __restrict__ slabs,
                                                                        unsigned* __restrict__ counters) {
   static_assert(A_SRC == 0 || !FUSED, "the quantising prologue is built for the two-launch form");
@@ -276,7 +276,12 @@ __global__ __launch_bounds__(kSkThreads, 1) void skinny_splitk_kernel(ScaledGemm
   const int r = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * kSpN + wave * 16, m0 = blockIdx.z * ROWS;
   const int slice = blockIdx.y;
-  const int k_begin = slice * (STEPS * kStepBytes);
+  // A slice is `chunks` passes of STEPS K steps (p.split_steps steps in all; 0 = one pass): the accumulators stay in registers
+  // from pass to pass, so a long K costs one slab per slice, not one per STEPS steps (round 4: 64 x 28672 x 8192 went through
+  // 28 slabs, 117 MB of partial sums beside 235 MB of weights)
+  // (LOOP = a separate instantiation: the one-pass kernels -- C2's among them -- keep their code)
+  const int chunks = LOOP ? p.split_steps / STEPS : 1;
+  const int slice_begin = LOOP ? slice * chunks * (STEPS * kStepBytes) : slice * (STEPS * kStepBytes);
 
   const uint32_t a_bytes = (uint32_t)(((p.m - 1) * p.a_stride_m + p.k) * (A_SRC ? 2 : 1));
   const uint32_t b_bytes = (uint32_t)((p.n - 1) * p.b_stride_n + p.k);
@@ -333,6 +338,24 @@ __global__ __launch_bounds__(kSkThreads, 1) void skinny_splitk_kernel(ScaledGemm
 
   // A ragged LAST slice (K % slice != 0; K % 128 == 0 always): the steps past K load from an out-of-range buffer offset --
   // zeros into the registers and into LDS alike (the range check is on the VGPR offset) -- and their MFMAs add 0 x 0.
+  typename AccT<MMA>::type acc[ROWS / 16];
+  if constexpr (LOOP) {
+#pragma unroll
+    for (int i = 0; i < ROWS / 16; ++i) acc[i] = typename AccT<MMA>::type{0, 0, 0, 0};
+  }
+  // The passes are a goto loop that exists only in the LOOP instantiations: with a `for` around the body the ONE-pass kernels
+  // came out 20 instructions different and 2-4 % slower (C2 9.03 -> 9.24 us, same box), although the loop folds away.
+  [[maybe_unused]] int chunk = 0;
+pass_begin: __attribute__((unused));
+  {
+  const int k_begin = LOOP ? slice_begin + chunk * (STEPS * kStepBytes) : slice_begin;
+  if constexpr (LOOP) {
+    if (k_begin >= (int)p.k) goto pass_end;  // a ragged last slice ends early (workgroup-uniform)
+    if (chunk > 0) {  // every wave is done reading the units of the previous pass before the next pass's LDS-DMA overwrites them
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
   const int valid_steps = min(STEPS, ((int)p.k - k_begin) / kStepBytes);  // workgroup-uniform
   Frag fb[STEPS];
 #pragma unroll
@@ -398,11 +421,16 @@ __global__ __launch_bounds__(kSkThreads, 1) void skinny_splitk_kernel(ScaledGemm
   }
 
   SK_STAMP(1);
-  typename AccT<MMA>::type acc[ROWS / 16];
+  if constexpr (!LOOP) {  // one pass: zeroed behind the slice's requests, as in rounds 2-3 (same code as before the loop existed)
 #pragma unroll
-  for (int i = 0; i < ROWS / 16; ++i) acc[i] = typename AccT<MMA>::type{0, 0, 0, 0};
-
+    for (int i = 0; i < ROWS / 16; ++i) acc[i] = typename AccT<MMA>::type{0, 0, 0, 0};
+  }
   sp_consume<MMA, ROWS, STEPS, GATHER, 0>(acc, fb, lds, lane_off, gather);
+  }  // pass
+  if constexpr (LOOP) {
+    if (++chunk < chunks) goto pass_begin;
+  }
+pass_end: __attribute__((unused));
   SK_STAMP(2);
   SK_CLOCK(1);
 
@@ -587,9 +615,15 @@ template <int MMA, int OUT_DT, bool FUSED>
 void launch_splitk_kernel(int rows, int steps, bool gather, dim3 grid, const ScaledGemmArgs& p, int* ws, unsigned* counters,
                           hipStream_t stream) {
   const dim3 block(kSkThreads);
+  const bool loop = p.split_steps > steps;  // several passes per slice
 #define CONCH_SK(R, S)                                                                                                            \
   do {                                                                                                                           \
-    if (gather)                                                                                                                  \
+    if (loop) {                                                                                                                  \
+      if (gather)                                                                                                                \
+        hipLaunchKernelGGL((skinny_splitk_kernel<MMA, OUT_DT, R, S, FUSED, 0, true, true>), grid, block, 0, stream, p, ws, counters);  \
+      else                                                                                                                       \
+        hipLaunchKernelGGL((skinny_splitk_kernel<MMA, OUT_DT, R, S, FUSED, 0, false, true>), grid, block, 0, stream, p, ws, counters); \
+    } else if (gather)                                                                                                           \
       hipLaunchKernelGGL((skinny_splitk_kernel<MMA, OUT_DT, R, S, FUSED, 0, true>), grid, block, 0, stream, p, ws, counters);     \
     else                                                                                                                         \
       hipLaunchKernelGGL((skinny_splitk_kernel<MMA, OUT_DT, R, S, FUSED, 0, false>), grid, block, 0, stream, p, ws, counters);    \
@@ -639,6 +673,17 @@ int splitk_slices(const ScaledGemmArgs& p) {
   return (int)((p.k + kSpSliceK - 1) / kSpSliceK);
 }
 
+// passes of `steps`-step units a slice makes before it leaves its partial sums (1 = a slab per unit, rounds 2-3)
+int splitk_chunks(const ScaledGemmArgs& p, int slices, int rows) {
+  const int forced = tuning(CONCH_TUNE_SKINNY_CHUNKS);
+  if (forced >= 1) return std::min(forced, std::max(slices, 1));
+  // auto: keep about two workgroups per CU in the grid
+  const int64_t wgs = ((p.n + kSpN - 1) / kSpN) * ((p.m + rows - 1) / rows) * slices;
+  const int64_t want = 2 * (int64_t)device_cu_count();
+  if (wgs <= want || slices < 2) return 1;
+  return (int)std::min<int64_t>(slices, std::max<int64_t>(1, wgs / want));
+}
+
 }  // namespace
 
 // `wide` = the plain GEMM on [gate | up] (n = 2d): can the split-K form run it with the silu fused into its reduce kernel?
@@ -681,6 +726,13 @@ int launch_splitk(const ScaledGemmArgs& p, int slices, hipStream_t stream) {
   } else if (mode == 3) {
     mode = 2;
   }
+  // Passes per slice (skinny_splitk_kernel, `chunks`): CONCH_TUNE_SKINNY_CHUNKS forces a count; auto = see splitk_chunks
+  const int chunks = p.a_src_dtype ? 1 : splitk_chunks(p, slices, rows);
+  ScaledGemmArgs q = p;
+  if (chunks > 1) {
+    q.split_steps = chunks * steps;
+    slices = (slices + chunks - 1) / chunks;
+  }
   const dim3 grid((unsigned)((p.n + kSpN - 1) / kSpN), (unsigned)slices, (unsigned)((p.m + rows - 1) / rows));
   const size_t bytes = (size_t)slices * p.m * p.n * 4;
   // the in-launch reduce addresses all slabs through one 32-bit buffer descriptor and needs one counter per tile; the
@@ -702,10 +754,10 @@ int launch_splitk(const ScaledGemmArgs& p, int slices, hipStream_t stream) {
   if (mode != 1) {
     void* counters = nullptr;
     if (int rc = get_scratch(stream, kScratchCounters, (size_t)kSpMaxTiles * 4, &counters, /*zero_on_alloc=*/true)) return rc;
-    launch_splitk_kernel<MMA, OUT_DT, true>(rows, steps, gather, grid, p, (int*)ws, (unsigned*)counters, stream);
+    launch_splitk_kernel<MMA, OUT_DT, true>(rows, steps, gather, grid, q, (int*)ws, (unsigned*)counters, stream);
     return check_launch("scaled_gemm_skinny_splitk_fused");
   }
-  launch_splitk_kernel<MMA, CONCH_DT_BF16, false>(rows, steps, gather, grid, p, (int*)ws, nullptr, stream);
+  launch_splitk_kernel<MMA, CONCH_DT_BF16, false>(rows, steps, gather, grid, q, (int*)ws, nullptr, stream);
   if (p.fuse_silu) {  // p.n = 2d columns [gate | up], C has d
     hipLaunchKernelGGL((skinny_reduce_silu_kernel<MMA, OUT_DT>), dim3((unsigned)((p.n / 8 + 255) / 256), (unsigned)p.m), dim3(256), 0, stream, p,
                        (const int*)ws, slices);

@@ -168,7 +168,9 @@ typedef enum conch_tuning_key {
   ,
   CONCH_TUNE_MID_SPLITK = 12 /* 128x128-tile scaled GEMM: K slices per tile (fp32 / int32 slabs + the split-K reduce kernel) when the
                                tiles leave at least half the chip idle and K >= 4096: 0 = auto, 1 = never, 2..8 = that many */,
-  CONCH_TUNE__COUNT = 13 /* number of keys (array bound; not a key) */
+  CONCH_TUNE_SKINNY_CHUNKS = 13 /* split-K skinny-M scaled GEMM: passes of one 1024- / 2048-byte K unit a workgroup makes before it
+                                  leaves its partial sums (fewer slabs for a long K): 0 = auto, n >= 1 = that many */,
+  CONCH_TUNE__COUNT = 14 /* number of keys (array bound; not a key) */
 } conch_tuning_key_t;
 
 int conch_abi_version(void);

@@ -172,6 +172,7 @@ def _reset_tuning():
     _C.set_tuning(_C.TUNE_MIXED_KERNEL, 0)
     _C.set_tuning(_C.TUNE_MIXED_TILE_NT, 0)
     _C.set_tuning(_C.TUNE_MID_SPLITK, 0)
+    _C.set_tuning(_C.TUNE_SKINNY_CHUNKS, 0)
 
 
 @pytest.mark.parametrize("slices", [2, 3, 5, 8])
@@ -352,6 +353,29 @@ def test_one_launch_splitk_is_bit_identical_to_two_launches(_reset_tuning, mode,
             np.testing.assert_array_equal(to_bits(one), to_bits(two))  # same slices, same order
     ref = oracle.scaled_gemm_ref(a, b, sa, sb, torch.bfloat16, bias)
     check_scaled(one, ref, IN_T[iname], torch.bfloat16, (a, b, sa, sb, bias))
+
+
+@pytest.mark.parametrize("chunks", [2, 3, 7])
+@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("iname", ["int8", "fn"])
+@pytest.mark.parametrize(("m", "k", "n"), [(64, 7168, 520), (20, 11008, 256), (128, 8192, 132), (200, 5120, 64), (7, 14336, 24), (33, 3072, 68)])
+def test_splitk_passes_per_slice(_reset_tuning, chunks, mode, iname, m, k, n):
+    """CONCH_TUNE_SKINNY_CHUNKS: a split-K workgroup makes several passes over its K slice (accumulators kept in registers from
+    pass to pass) and leaves ONE slab: int8 bit-identical to a slab per pass, fp8 within the oracle's bound (the fp32 partial
+    sums meet in a different order); ragged last slices that end after any number of passes, all launch forms, K below one
+    slice of `chunks` passes included."""
+    a, b, sa, sb, bias = make_scaled_inputs(m, k, n, IN_T[iname], torch.bfloat16, False, False, True)
+    _C.set_gemm_variant(_C.VARIANT_MFMA_SKINNY)
+    _C.set_tuning(_C.TUNE_SKINNY_MODE, mode)
+    _C.set_tuning(_C.TUNE_SKINNY_CHUNKS, 1)
+    one = run_scaled(a, b, sa, sb, torch.bfloat16, bias)
+    _C.set_tuning(_C.TUNE_SKINNY_CHUNKS, chunks)
+    for _ in range(3):
+        got = run_scaled(a, b, sa, sb, torch.bfloat16, bias)
+        if iname == "int8":
+            np.testing.assert_array_equal(to_bits(got), to_bits(one))
+    ref = oracle.scaled_gemm_ref(a, b, sa, sb, torch.bfloat16, bias)
+    check_scaled(got, ref, IN_T[iname], torch.bfloat16, (a, b, sa, sb, bias))
 
 
 @pytest.mark.parametrize("mode", [1, 2, 3])
