@@ -367,14 +367,17 @@ int check_mixed(const MixedGemmArgs& p) {
 }
 
 // 64 < M <= 256: two to four row blocks of the decode kernel (each streams the weights; the later ones mostly from L2) against ONE
-// row of tiles of the LDS-tiled kernel, which for so few rows is bound by what a CU can pull per K step, not by N.  Fitted on
+// row of tiles of the LDS-tiled kernel, which for so few rows is bound by what a CU can pull per K step, not by N.  Decode: fitted on
 // weights streamed from HBM (profiles/r02/dispatch_cold_sweep_after.txt; refitted in round 3 after the decode kernel's prologue
-// was rewritten -- 0.475e-6 -> 0.41e-6, tiles 15.5 -> 16.5: 256 x 8192 x 8192 and 192 x 4096 x 11008 had stayed on the tiles at
-// 127 / 69 us where the decode kernel now takes 112 / 63), us: decode 5 + 0.41e-6 N K per row block; tiles 16.5 K/1024 per round.
-// (96-128 x 4096 x 4096: 18 against 66 us; 128 x 11008 x 4096: 46 against 172 us.)
-bool mixed_decode_beats_tiles(const MixedGemmArgs& p) {
+// was rewritten -- 0.475e-6 -> 0.41e-6), us: 5 + 0.41e-6 N K per row block.  Tiles: round 4 lets the one row of tiles split K
+// (gemm_mixed.hip, pick_split) and takes that model's time -- before, the comparison was against an unsplit row of tiles
+// (16.5 us per 1024 of K) and the decode kernel kept 192-256 rows at up to 3.8x the split tiles' time
+// (profiles/r04/mixed_splitk_sweep.txt: 256 x 28672 x 8192 458 -> 122 us, 256 x 8192 x 8192 110 -> 46, 128 x 11008 x 4096 44 -> 31).
+// `tiles_may_split` = false for the fused gate/up form, whose 256-row tile does not split.
+bool mixed_decode_beats_tiles(const MixedGemmArgs& p, bool tiles_may_split = true) {
   const double blocks = (double)((p.m + 63) / 64);
   const double decode_us = 5.0 + 0.41e-6 * (double)p.n * (double)p.k * blocks * (p.bits == 8 ? 1.85 : 1.0);
+  if (tiles_may_split && mixed_gemm_mfma_supported(p) && tuning(CONCH_TUNE_MIXED_SPLITK) == 0) return decode_us < mixed_tiles_estimate_us(p);
   const int64_t tiles = (p.n + 127) / 128;  // the narrowest tile: the most workgroups a single row of tiles can have
   const double tile_us = 16.5 * (double)p.k / 1024.0 * (double)((tiles + 255) / 256);
   return decode_us < tile_us;
@@ -467,7 +470,7 @@ int run_mixed_silu(const MixedGemmArgs& p, hipStream_t stream) {
   MixedGemmArgs probe = wide;  // the contract check wants a C row that holds n columns; the fused reduce writes only d
   probe.c_stride_m = wide.n;
   const bool decode = variant == 0 && mixed_gemm_skinny_supported(probe) && wide.n % 8 == 0 &&
-                      (p.m <= 64 || mixed_decode_beats_tiles(wide));  // the plain op's rule (run_mixed)
+                      (p.m <= 64 || mixed_decode_beats_tiles(wide, /*tiles_may_split=*/false));  // the plain op's rule, against the fused tile
   if (decode) {
     MixedGemmArgs q = wide;  // n = 2d for the partial sums; c / c_stride_m describe the d-column result
     q.fuse_silu = p.fuse_silu;
@@ -556,7 +559,7 @@ extern "C" int64_t conch_mixed_precision_gemm_workspace_bytes(int64_t m, int64_t
   if (m <= 0 || n <= 0 || k < 0) return 0;
   int64_t need = m * n * 2;
   if (m <= 256) need = std::max(need, (k / 1024 + 1) * m * n * 4);  // gemm_mixed_skinny.hip slabs
-  else need = std::max(need, (int64_t)8 * m * n * 4);                   // gemm_mixed.hip split-K slabs (at most 8 slices)
+  need = std::max(need, (int64_t)8 * m * n * 4);                     // gemm_mixed.hip split-K slabs (at most 8 slices, any M)
   return need + ((int64_t)1 << 20);
 }
 

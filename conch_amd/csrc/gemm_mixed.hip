@@ -972,25 +972,37 @@ bool mixed_gemm_mfma_supported(const MixedGemmArgs& p) {
 // Split-K for problems whose tiles leave most of the chip idle (M of a few hundred rows x N of a few thousand columns: 512 x 4096 x
 // 4096 is 64 tiles): S slices of the K range per tile, fp32 partial sums to slabs, the fp32-slab reduce.  Worth it while the tile
 // kernel's time (~ steps per workgroup) drops by more than the slabs cost (S x M x N x 4 bytes written and read again).
-int pick_split(const MixedGemmArgs& p, int nt, int num_cus) {
-  if (p.fuse_silu || p.n % 4 || p.m <= 256) return 1;
+// Round 4: one row of tiles (M <= 256) splits too -- it had been left to the decode-batch kernel, whose time grows with every 64
+// rows (256 x 8192 x 8192: 110 us there, 46 here in four slices; 256 x 28672 x 8192: 458 against 122:
+// profiles/r04/mixed_splitk_sweep.txt).  `us_out` = the model's time for the pick (the dispatcher compares it with the decode kernel's).
+int pick_split(const MixedGemmArgs& p, int nt, int num_cus, double* us_out = nullptr) {
   const int rows = nt == kMixedTall ? kTallRows : kTileM, cols = nt == kMixedTall ? 128 : 64 * nt;
   const int64_t tiles = ((p.m + rows - 1) / rows) * ((p.n + cols - 1) / cols);
   const int steps = (int)(p.k / kStepK), spg = p.group_size / kStepK;
+  const double rounds = (double)((tiles + num_cus - 1) / num_cus);
   int best = 1;
   double best_us = 1e30;
   for (int s = 1; s <= 8; s *= 2) {
-    if (s > 1 && (tiles * s > num_cus || steps / s < 16)) break;
+    if (s > 1 && (p.fuse_silu || p.n % 4 || tiles * s > num_cus || steps / s < 8)) break;  // (a slice of 8 steps: 192 x 4096 x 4096 22.8 us in eight, 25.5 in four)
     const int per = ((steps + s - 1) / s + spg - 1) / spg * spg;  // steps per slice, whole groups
     // ~0.97 us per step on a sparsely filled chip (profiles/r02/dispatch_cold_sweep_after.txt: one row of tiles, 15.5 us per 1024 of
     // K) + the slabs: written once, read once, ~4 TB/s, plus the reduce launch
-    const double us = 0.97 * per + (s > 1 ? 3.0 + 2.0 * (double)s * (double)p.m * (double)p.n * 4.0 / 4.0e6 : 0.0);
+    const double us = 0.97 * per * rounds + (s > 1 ? 3.0 + 2.0 * (double)s * (double)p.m * (double)p.n * 4.0 / 4.0e6 : 0.0);
     if (us < best_us - 1e-9) {
       best_us = us;
       best = s;
     }
   }
+  if (us_out) *us_out = best_us;
   return best;
+}
+
+// the cost model's time (us) for the LDS-tiled kernel on `p` with the tile shape and the K split it would pick
+double mixed_tiles_estimate_us(const MixedGemmArgs& p) {
+  const int cus = device_cu_count();
+  double us = 0.0;
+  pick_split(p, pick_nt(p, cus), cus, &us);
+  return us * (p.bits == 8 ? 1.1 : 1.0);
 }
 
 int launch_mixed_gemm_mfma(const MixedGemmArgs& p_in, hipStream_t stream) {

@@ -1500,7 +1500,8 @@ def test_mixed_precision_ragged_slice_ignores_inf_behind_k():
 # split-K form of the LDS-tiled mixed kernel (few tiles: M of a few hundred rows, N of a few thousand columns)
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("split", [2, 4, 8])
-@pytest.mark.parametrize(("m", "k", "n"), [(512, 2048, 1024), (300, 2048, 520), (1024, 1152, 256), (700, 2048, 1024)])
+@pytest.mark.parametrize(("m", "k", "n"), [(512, 2048, 1024), (300, 2048, 520), (1024, 1152, 256), (700, 2048, 1024), (256, 2048, 1024), (100, 4096, 520),
+                                            (192, 2176, 256)])
 @pytest.mark.parametrize(("wname", "use_zp", "dname"), [("uint4b8", False, "f16"), ("uint4", True, "bf16"), ("uint8b128", False, "bf16")])
 def test_mixed_precision_split_k(_reset_tuning, split, m, k, n, wname, use_zp, dname):
     """K slices per tile, fp32 slabs, reduce in slice order: against the oracle, against the unsplit kernel (another summation

@@ -99,9 +99,33 @@ def grid():
             del a, bt
 
 
+def grid_mixed():
+    """int4 x fp16 (group 128, symmetric): the fused kernel against torch.matmul on weights dequantised beforehand (4x the weight bytes)."""
+    dims = [(4096, 4096), (4096, 11008), (11008, 4096), (4096, 12288), (8192, 8192), (8192, 28672), (28672, 8192), (5120, 13824), (13824, 5120)]
+    for k, n in dims:
+        for m in (1, 16, 64, 128, 256, 512, 1024, 2048, 4096, 8192):
+            if m * n * k > 8192 * 8192 * 8192:
+                continue
+            torch.manual_seed(0)
+            x = (10 * (torch.rand((m, k), device="cuda") - 0.3)).to(torch.float16)
+            w = (0.1 * torch.rand((k, n), device="cuda")).to(torch.float16)
+            wq = torch.randint(-2**31, 2**31 - 1, (k // 8, n), dtype=torch.int32, device="cuda")
+            ws = (0.1 * torch.rand((k // 128, n), device="cuda") + 0.01).to(torch.float16)
+            it = 200 if m * n * k < 2**36 else 40
+            ours = timeit(lambda: mixed_precision_gemm(x, wq, ws, None, 4, 8, 128), iters=it, rounds=3)
+            ref = timeit(lambda: torch.matmul(x, w), iters=it, rounds=3)
+            fl = 2.0 * m * n * k
+            flag = "  <-- vendor ahead" if ref < ours * 0.97 else ""
+            print(f"int4xfp16 M={m:5d} K={k:5d} N={n:5d}: ours {ours * 1e3:8.1f} us ({fl / ours / 1e9 / 2500:.3f})  vendor fp16 {ref * 1e3:8.1f} us  x{ours / ref:.2f}{flag}", flush=True)
+            del x, w, wq, ws
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--grid":
         grid()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "--grid-mixed":
+        grid_mixed()
         sys.exit(0)
     for shape in [(128, 4096, 4096), (32, 8192, 8192), (256, 4096, 11008)]:
         int8_case(*shape)
