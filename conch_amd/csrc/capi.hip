@@ -230,12 +230,23 @@ int run_scaled(const ScaledGemmArgs& p_in, hipStream_t stream) {
     // if one is there).  Three of the launches return at once; the host never learns which.
     ScaledGemmArgs f = p;
     f.in_dtype = CONCH_DT_FP8_E4M3FN;
-    if (scaled_gemm_mfma_supported(f) && choose_scaled_kernel(f) != kKernelSkinny && fnuz_expansion_fits(p)) {
+    if (scaled_gemm_mfma_supported(f) && fnuz_expansion_fits(p) && p.scale_a_numel <= kFnuzMaxScales) {
       void* flag = nullptr;
-      if (int rc = get_scratch(stream, kScratchFlags, 256, &flag)) return rc;
+      if (int rc = get_scratch(stream, kScratchFlags, kFlagsBytes, &flag)) return rc;
       CONCH_HIP(hipMemsetAsync(flag, 0, 4, stream));
-      if (int rc = launch_fnuz_scan(p, (int*)flag, stream)) return rc;
-      f.acc_scale = 0.25f;
+      const ScaledKernel pick = choose_scaled_kernel(f);
+      if (pick == kKernelTiled) {  // the 256 x 256 tiles carry the factor themselves (acc_scale) and honour the gate
+        if (int rc = launch_fnuz_scan(p, (int*)flag, stream)) return rc;
+        f.acc_scale = 0.25f;
+      } else {
+        // the 128 x 128 tiles' split-K form and the split-K skinny kernels (decode batches: 68 us through the expansion where
+        // e4m3fn takes 6.4, round 4) know neither acc_scale nor -- their reduce kernels -- the gate: they get a scaled COPY of
+        // scale_a, made by the scan, and run whatever the flag says; if a special code is there, the gated expansion path below
+        // overwrites every element of C afterwards.
+        float* sa_quarter = (float*)((char*)flag + 256);
+        if (int rc = launch_fnuz_scan(p, (int*)flag, stream, sa_quarter)) return rc;
+        f.scale_a = sa_quarter;
+      }
       f.gate = (const int*)flag;
       f.gate_run_if = 0;
       if (int rc = run_scaled_fast(f, 0, stream)) return rc;
@@ -568,7 +579,7 @@ extern "C" int conch_reserve_scratch(void* stream, int64_t bytes) {
   void* ignored = nullptr;
   for (int slot = 0; slot < kScratchCounters; ++slot)
     if (int rc = get_scratch((hipStream_t)stream, slot, (size_t)bytes, &ignored)) return rc;
-  if (int rc = get_scratch((hipStream_t)stream, kScratchFlags, 256, &ignored)) return rc;  // e4m3fnuz dispatch word
+  if (int rc = get_scratch((hipStream_t)stream, kScratchFlags, kFlagsBytes, &ignored)) return rc;  // e4m3fnuz dispatch word + scaled scale_a
   return get_scratch((hipStream_t)stream, kScratchCounters, (size_t)64 * 1024, &ignored, /*zero_on_alloc=*/true);
 }
 

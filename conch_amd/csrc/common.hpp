@@ -64,6 +64,10 @@ enum ScratchSlot {
   kScratchFlags = 5,      // device-side dispatch words (e4m3fnuz: "an operand holds a code the fp8 MFMA cannot take")
   kScratchSlots = 6
 };
+// kScratchFlags layout: the e4m3fnuz dispatch word at byte 0, a 0.25 x scale_a copy of up to kFnuzMaxScales floats at byte 256
+constexpr int kFnuzMaxScales = 65536;
+constexpr size_t kFlagsBytes = 256 + 4 * (size_t)kFnuzMaxScales;
+
 int get_scratch(hipStream_t stream, int slot, size_t bytes, void** out, bool zero_on_alloc = false);
 
 // Compute units of the CURRENT device (cached per device id; 256 if the query fails).

@@ -141,7 +141,8 @@ int repack_for_mfma(const ScaledGemmArgs& p, ScaledGemmArgs* q, void** scratch, 
 int expand_fnuz_to_bf16(const ScaledGemmArgs& p, ScaledGemmArgs* q, hipStream_t stream, const int* gate = nullptr);
 bool fnuz_expansion_fits(const ScaledGemmArgs& p);  // expand_fnuz_to_bf16 will take the problem (sizes, C layout)
 // *flag = 1 if A or B^T (K-contiguous e4m3fnuz rows, the tile contract) holds a code the OCP fp8 MFMA cannot take: 0x80, 0x7F, 0xFF
-int launch_fnuz_scan(const ScaledGemmArgs& p, int* flag, hipStream_t stream);
+// sa_quarter (optional): also writes 0.25 x scale_a[i] there (scale_a_numel floats), for kernels without acc_scale
+int launch_fnuz_scan(const ScaledGemmArgs& p, int* flag, hipStream_t stream, float* sa_quarter = nullptr);
 int launch_scaled_gemm_mfma_bf16(const ScaledGemmArgs& p, hipStream_t stream);
 int launch_scaled_gemm_mfma_16bit(const ScaledGemmArgs& p, hipStream_t stream);  // p.in_dtype = FP16 | BF16, byte units
 // gemm_modes.hip -- weight-group / channel-scale modes beyond the two conch.ops produces (dequantise first, then 16-bit MFMA)

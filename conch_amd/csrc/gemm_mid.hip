@@ -245,7 +245,7 @@ __global__ __launch_bounds__(kMidThreads, 2) void scaled_gemm_mid_kernel(ScaledG
 }  // namespace
 
 // K slices the 128 x 128-tile kernel splits a problem into (1 = whole K per workgroup).  Plain fp8 / int8 problems only (the
-// reduce kernel applies scale_a / scale_b / bias: no e4m3fnuz gate, no 16-bit operand forms); N % 4 == 0 (16-byte slab quads).
+// reduce kernel applies scale_a / scale_b / bias: no acc_scale -- the e4m3fnuz flow hands these forms a scaled copy of scale_a --, no 16-bit operand forms); N % 4 == 0 (16-byte slab quads).
 // Measured (profiles/r04/mid_splitk_sweep.txt, 18 shapes x 1..8 slices x both ring depths): the launch wants EITHER about one
 // workgroup per CU (the 4-stage ring) OR about two (the 2-stage loop) -- 1.5 per CU leaves half the chip with twice the work
 // (256 x 28672 x 8192: 73.5 us in 2 slices, 99 in 3, 83 in 4) -- so: up to half a chip of tiles, as many slices as fit one
@@ -256,7 +256,7 @@ int mid_split_slices(const ScaledGemmArgs& p) {
   const int forced = tuning(CONCH_TUNE_MID_SPLITK);
   if (forced == 1) return 1;
   if (p.in_dtype != CONCH_DT_FP8_E4M3FN && p.in_dtype != CONCH_DT_INT8) return 1;
-  if (p.gate || p.acc_scale != 1.0f || !p.scale_a || !p.scale_b || p.fuse_silu || p.n_more || p.n % 4 || p.c_stride_n != 1) return 1;
+  if (p.acc_scale != 1.0f || !p.scale_a || !p.scale_b || p.fuse_silu || p.n_more || p.n % 4 || p.c_stride_n != 1) return 1;
   const int64_t tiles = ((p.m + kMidTile - 1) / kMidTile) * ((p.n + kMidTile - 1) / kMidTile);
   const int64_t steps = p.k / kStepBytes;
   if ((p.m * p.n * 4) >= ((int64_t)1 << 28) || tiles < 1) return 1;

@@ -127,7 +127,12 @@ __device__ __forceinline__ uint32_t fnuz_special_in(uint32_t x) {
 
 __global__ __launch_bounds__(256) void fnuz_scan_kernel(const uint8_t* __restrict__ a, int rows_a, int64_t stride_a,
                                                         const uint8_t* __restrict__ b, int rows_b, int64_t stride_b, int k_vecs,
-                                                        int* __restrict__ flag) {
+                                                        int* __restrict__ flag, const float* __restrict__ sa, int sa_numel,
+                                                        float* __restrict__ sa_quarter) {
+  // the exact factor 1/4 of the raw-bits product (gemm.hpp, acc_scale) as a scaled copy of scale_a: kernels that know nothing
+  // of acc_scale (split-K forms, their reduce kernel) then run the e4m3fnuz problem unchanged.  0.25 x sa is exact (a power of two)
+  if (sa_quarter && blockIdx.x == 0)
+    for (int i = threadIdx.x; i < sa_numel; i += 256) sa_quarter[i] = 0.25f * sa[i];
   uint32_t found = 0;
   const int rows = rows_a + rows_b;
   for (int r0 = blockIdx.x * 4; r0 < rows; r0 += gridDim.x * 4) {
@@ -148,12 +153,12 @@ __global__ __launch_bounds__(256) void fnuz_scan_kernel(const uint8_t* __restric
   if (found) atomicOr(flag, 1);
 }
 
-int launch_fnuz_scan(const ScaledGemmArgs& p, int* flag, hipStream_t stream) {
+int launch_fnuz_scan(const ScaledGemmArgs& p, int* flag, hipStream_t stream, float* sa_quarter) {
   const int rows = (int)(p.m + p.n);
   int blocks = (rows + 3) / 4;
   if (blocks > 256 * 8) blocks = 256 * 8;
   hipLaunchKernelGGL(fnuz_scan_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const uint8_t*)p.a, (int)p.m, p.a_stride_m,
-                     (const uint8_t*)p.b, (int)p.n, p.b_stride_n, (int)(p.k / 16), flag);
+                     (const uint8_t*)p.b, (int)p.n, p.b_stride_n, (int)(p.k / 16), flag, p.scale_a, (int)p.scale_a_numel, sa_quarter);
   return check_launch("fnuz_scan");
 }
 

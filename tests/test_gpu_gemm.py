@@ -889,7 +889,10 @@ def test_scaled_gemm_multi_destinations_are_bit_identical(iname, m, k, n, n_dest
         scaled_gemm_multi_launcher([results[0][:, lo:lo + n], torch.empty((m, n), dtype=torch.bfloat16, device="cuda")], ad, bd, sad, sbd, meta)
 
 
-@pytest.mark.parametrize(("m", "k", "n"), [(1024, 1024, 1024), (4096, 512, 2048), (600, 384, 1376)])
+@pytest.mark.parametrize(("m", "k", "n"), [(1024, 1024, 1024), (4096, 512, 2048), (600, 384, 1376),
+                                            # decode batches (split-K skinny kernels, one- and two-launch forms) and few tiles with a
+                                            # long K (the 128 x 128 tiles' split-K form): these run on a scaled copy of scale_a
+                                            (16, 4096, 4096), (128, 4096, 1024), (64, 2048, 520), (8, 1024, 24), (256, 11008, 512), (200, 8192, 260)])
 @pytest.mark.parametrize("where", ["none", "a", "b", "both", "nan"])
 def test_scaled_gemm_e4m3fnuz_special_codes_take_the_exact_path(m, k, n, where):
     """e4m3fnuz at the fp8 rate (round 4): the tile kernels run the raw bytes on the OCP fp8 MFMA (every code is twice its
