@@ -578,7 +578,16 @@ bool bnb_decode_supported(int64_t m, int64_t n, int64_t k, int blocksize, bool f
   if (m > 256 || n % 4 || k % blocksize || n * k / 2 >= ((int64_t)1 << 31)) return false;
   if (m <= 64 || forced) return true;
   const double nk = (double)n * (double)k;
-  return (double)((m + 63) / 64) * (5.0 + 0.56e-6 * nk) < 15.0 * (double)k / 1024.0 + 0.7e-6 * nk;  // round 3: 0.85 -> 0.56 (64 x 4096 x 11008 42.3 -> 29.2 us)
+  // round 4: the 16-bit tile kernels split K too (gemm_mid.hip), so the tile side is the 8-bit dispatcher's model on the same problem
+  // in byte units, not 15 us per 1024 of K (256 x 11008 x 4096: 96 us here against 64 for dequantise + GEMM: profiles/r04/fused_ops_sweep.txt)
+  ScaledGemmArgs g{};
+  g.m = m;
+  g.n = n;
+  g.k = k * 2;
+  g.in_dtype = CONCH_DT_FP16;
+  g.c_stride_n = 1;
+  const double tiles_us = std::min(15.0 * (double)k / 1024.0, scaled_tiles_estimate_us(g));
+  return (double)((m + 63) / 64) * (5.0 + 0.56e-6 * nk) < tiles_us + 0.7e-6 * nk;  // round 3: 0.85 -> 0.56 (64 x 4096 x 11008 42.3 -> 29.2 us)
 }
 
 int launch_bnb_decode_gemm(const BnbGemmArgs& p, int qt, int adt, int x_dtype, int out_dtype, hipStream_t stream) {

@@ -142,7 +142,7 @@ enum ScaledKernel { kKernelTiled = 0, kKernelMid = 1, kKernelSkinny = 2 };
 // The warm fit (round 1) was 4.5-5.5 + c N K with c 1.7 .. 9.7, rounds x (34 + 0.05 t), rounds x (19 + 0.0176 t): with it the
 // dispatcher picked the 128x128 tiles where the split-K form is 15-47 % faster on cold weights (96-128 x 4096 x 11008,
 // 8-32 x 4096 x 28672, 256 x 4096 x 4096).
-ScaledKernel choose_scaled_kernel(const ScaledGemmArgs& p) {
+ScaledKernel choose_scaled_kernel(const ScaledGemmArgs& p, double* tiles_us_out = nullptr) {
   const double kscale = (double)p.k / 4096.0;
   const int64_t tiles256 = ((p.m + 255) / 256) * ((p.n + 255) / 256);
   const int64_t rounds256 = (tiles256 + 255) / 256;
@@ -168,6 +168,7 @@ ScaledKernel choose_scaled_kernel(const ScaledGemmArgs& p) {
     best = mid_us;
     pick = kKernelMid;
   }
+  if (tiles_us_out) *tiles_us_out = best;
   if (scaled_gemm_skinny_supported(p)) {
     const double c = p.m <= 8 ? 2.0 : p.m <= 16 ? 2.1 : p.m <= 32 ? 2.5 : p.m <= 48 ? 2.7 : p.m <= 64 ? 3.0 : p.m <= 96 ? 4.5
                      : p.m <= 128 ? 5.15 : p.m <= 192 ? 9.3 : 10.2;  // steps at the 32- / 64- / 128-row forms and at the second row block
@@ -179,6 +180,11 @@ ScaledKernel choose_scaled_kernel(const ScaledGemmArgs& p) {
 
 }  // namespace
 int scaled_kernel_choice(const ScaledGemmArgs& p) { return (int)choose_scaled_kernel(p); }
+double scaled_tiles_estimate_us(const ScaledGemmArgs& p) {
+  double us = 0.0;
+  choose_scaled_kernel(p, &us);
+  return us;
+}
 namespace {
 
 int run_scaled_fast(const ScaledGemmArgs& p, int variant, hipStream_t stream) {
@@ -192,6 +198,7 @@ int run_scaled_fast(const ScaledGemmArgs& p, int variant, hipStream_t stream) {
   return launch_scaled_gemm_mfma(p, (variant == 2 || variant == 3) ? variant : 5, stream);
 }
 
+}  // namespace
 // One fp32 1.0 per device, for "no scale on this side" (NULL scale pointer): every kernel then runs unchanged.
 int unit_scale(const float** out) {
   static std::mutex mu;
@@ -210,6 +217,7 @@ int unit_scale(const float** out) {
   *out = ones[dev];
   return CONCH_OK;
 }
+namespace {
 
 int run_scaled(const ScaledGemmArgs& p_in, hipStream_t stream) {
   ScaledGemmArgs p = p_in;
@@ -480,14 +488,28 @@ int run_mixed_silu(const MixedGemmArgs& p, hipStream_t stream) {
   // decode batches: the decode-batch kernel on the wide problem with the silu fused into its reduce kernel
   MixedGemmArgs probe = wide;  // the contract check wants a C row that holds n columns; the fused reduce writes only d
   probe.c_stride_m = wide.n;
-  const bool decode = variant == 0 && mixed_gemm_skinny_supported(probe) && wide.n % 8 == 0 &&
-                      (p.m <= 64 || mixed_decode_beats_tiles(wide, /*tiles_may_split=*/false));  // the plain op's rule, against the fused tile
+  bool decode = variant == 0 && mixed_gemm_skinny_supported(probe) && wide.n % 8 == 0 &&
+                (p.m <= 64 || mixed_decode_beats_tiles(wide, /*tiles_may_split=*/false));  // the plain op's rule, against the fused tile
+  // 65-256 rows (round 4, profiles/r04/fused_ops_sweep.txt): the plain op now splits K over one row of tiles, and the pair
+  // "split tiles into scratch + the elementwise tail" beats both fused forms there (128 x 4096 x 22016: 88 us fused, 62 as two ops)
+  bool pair_wins = false;
+  if (variant == 0 && p.m > 64 && p.m <= 256 && mixed_gemm_mfma_supported(wide) && tuning(CONCH_TUNE_MIXED_SPLITK) == 0) {
+    const double pair_us = mixed_tiles_estimate_us(wide) + 4.0;
+    const double blocks = (double)((p.m + 63) / 64);
+    const double decode_us = decode ? 5.0 + 0.41e-6 * (double)wide.n * (double)p.k * blocks * (p.bits == 8 ? 1.85 : 1.0) : 1e30;
+    // the fused tile is 256 gate/up columns wide (128 of the result) and never splits: 1.35 us per 64 of K at one tile per CU
+    // (86 us at K = 4096 whatever M <= 256 is; profiles/r04/fused_ops_sweep.txt)
+    const double fused_rounds = (double)(((p.n + 127) / 128 + device_cu_count() - 1) / device_cu_count());
+    const double fused_us = mixed_gemm_silu_fused_supported(p) ? 1.35 * (double)(p.k / 64) * fused_rounds : 1e30;
+    pair_wins = pair_us < std::min(decode_us, fused_us);
+    if (pair_wins) decode = false;
+  }
   if (decode) {
     MixedGemmArgs q = wide;  // n = 2d for the partial sums; c / c_stride_m describe the d-column result
     q.fuse_silu = p.fuse_silu;
     return launch_mixed_gemm_skinny(q, stream);
   }
-  if (variant != 1 && variant != 2 && mixed_gemm_silu_fused_supported(p)) return launch_mixed_gemm_mfma(p, stream);
+  if (!pair_wins && variant != 1 && variant != 2 && mixed_gemm_silu_fused_supported(p)) return launch_mixed_gemm_mfma(p, stream);
   void* tmp = nullptr;
   if (int rc = get_scratch(stream, kScratchWide, (size_t)p.m * (size_t)wide.n * 2, &tmp)) return rc;
   wide.c = tmp;

@@ -129,6 +129,8 @@ int launch_scaled_gemm_mid(const ScaledGemmArgs& p, hipStream_t stream);
 int mid_split_slices(const ScaledGemmArgs& p);  // K slices that launcher will use for `p` (1 = no split-K)
 // the dispatcher's cost model (capi.hip, choose_scaled_kernel): 0 = 256 x 256 tiles, 1 = 128 x 128 tiles, 2 = split-K skinny
 int scaled_kernel_choice(const ScaledGemmArgs& p);
+double scaled_tiles_estimate_us(const ScaledGemmArgs& p);  // the same model's time (us) for the better of the two tile kernels
+int unit_scale(const float** out);                          // one fp32 1.0 on the current device ("no scale on this side")
 // gemm_skinny.hip -- M <= 256: 128x16 blocks, K split over the waves, register streaming (variant 4)
 bool scaled_gemm_skinny_supported(const ScaledGemmArgs& p);
 int launch_scaled_gemm_skinny(const ScaledGemmArgs& p, hipStream_t stream);

@@ -255,8 +255,11 @@ __global__ __launch_bounds__(kMidThreads, 2) void scaled_gemm_mid_kernel(ScaledG
 int mid_split_slices(const ScaledGemmArgs& p) {
   const int forced = tuning(CONCH_TUNE_MID_SPLITK);
   if (forced == 1) return 1;
-  if (p.in_dtype != CONCH_DT_FP8_E4M3FN && p.in_dtype != CONCH_DT_INT8) return 1;
-  if (p.acc_scale != 1.0f || !p.scale_a || !p.scale_b || p.fuse_silu || p.n_more || p.n % 4 || p.c_stride_n != 1) return 1;
+  const bool bits16 = p.in_dtype == CONCH_DT_FP16 || p.in_dtype == CONCH_DT_BF16;  // the dequantise-first paths (NULL scales = 1)
+  if (p.in_dtype != CONCH_DT_FP8_E4M3FN && p.in_dtype != CONCH_DT_INT8 && !bits16) return 1;
+  if (p.acc_scale != 1.0f || (!bits16 && (!p.scale_a || !p.scale_b)) || p.fuse_silu || p.n_more || p.n % 4 || p.c_stride_n != 1) return 1;
+  // the exact leg of the e4m3fnuz flow (gated on "flag set"): its reduce kernel knows no gate and would overwrite what the fp8 leg wrote
+  if (p.gate && p.gate_run_if) return 1;
   const int64_t tiles = ((p.m + kMidTile - 1) / kMidTile) * ((p.n + kMidTile - 1) / kMidTile);
   const int64_t steps = p.k / kStepBytes;
   if ((p.m * p.n * 4) >= ((int64_t)1 << 28) || tiles < 1) return 1;
@@ -290,12 +293,20 @@ int launch_scaled_gemm_mid(const ScaledGemmArgs& p_in, hipStream_t stream) {
     const int64_t steps = p.k / kStepBytes;
     p.split_steps = (int)((steps + slices - 1) / slices);
     if (int rc = get_scratch(stream, kScratchSplitK, (size_t)slices * (size_t)p.m * (size_t)p.n * 4, &p.slabs)) return rc;
+    if (!p.scale_a || !p.scale_b) {  // the reduce kernel multiplies by both
+      const float* one = nullptr;
+      if (int rc = unit_scale(&one)) return rc;
+      if (!p.scale_a) { p.scale_a = one; p.scale_a_numel = 1; }
+      if (!p.scale_b) { p.scale_b = one; p.scale_b_numel = 1; }
+    }
 #define CONCH_LAUNCH_MID_SPLIT(MMA)                                                                                      \
   do {                                                                                                                   \
     if (deep) hipLaunchKernelGGL((scaled_gemm_mid_kernel<MMA, CONCH_DT_BF16, 4, true>), grid, dim3(kMidThreads), 0, stream, p); \
     else hipLaunchKernelGGL((scaled_gemm_mid_kernel<MMA, CONCH_DT_BF16, 2, true>), grid, dim3(kMidThreads), 0, stream, p);  \
   } while (0)
     if (p.in_dtype == CONCH_DT_FP8_E4M3FN) CONCH_LAUNCH_MID_SPLIT(kMmaFp8);
+    else if (p.in_dtype == CONCH_DT_FP16) CONCH_LAUNCH_MID_SPLIT(kMmaF16);
+    else if (p.in_dtype == CONCH_DT_BF16) CONCH_LAUNCH_MID_SPLIT(kMmaBf16);
     else CONCH_LAUNCH_MID_SPLIT(kMmaInt8);
 #undef CONCH_LAUNCH_MID_SPLIT
     if (int rc = check_launch("scaled_gemm_mid_split")) return rc;

@@ -22,12 +22,15 @@ typedef int (*mixed_gemm_fn)(void*, const void*, const int32_t*, const void*, co
                              int64_t, int64_t, int, int, int, int, int, int, void*);
 typedef int (*int8_quant_fn)(int8_t*, const void*, const float*, int64_t, int64_t, int64_t, int64_t, int, int, void*);
 typedef int (*fp8_quant_fn)(uint8_t*, const void*, const float*, int64_t, int64_t, int64_t, int64_t, int, int, void*);
+typedef int (*quant_gemm_fn)(void*, const void*, const void*, const float*, const float*, const void*, int64_t, int64_t, int64_t, int64_t, int64_t,
+                             int64_t, int64_t, int64_t, int64_t, int64_t, int, int, int, void*);
 typedef const char* (*last_error_fn)();
 
 scaled_gemm_fn g_scaled = nullptr;
 mixed_gemm_fn g_mixed = nullptr;
 int8_quant_fn g_int8 = nullptr;
 fp8_quant_fn g_fp8 = nullptr;
+quant_gemm_fn g_quant_gemm = nullptr;
 last_error_fn g_last_error = nullptr;
 
 // conch_dtype_t of include/conch_amd.h
@@ -52,8 +55,9 @@ void bind_library(const std::string& path) {
   g_mixed = (mixed_gemm_fn)dlsym(h, "conch_mixed_precision_gemm");
   g_int8 = (int8_quant_fn)dlsym(h, "conch_static_scaled_int8_quant_typed");
   g_fp8 = (fp8_quant_fn)dlsym(h, "conch_static_scaled_fp8_quant");
+  g_quant_gemm = (quant_gemm_fn)dlsym(h, "conch_static_quant_scaled_gemm");
   g_last_error = (last_error_fn)dlsym(h, "conch_last_error");
-  if (!g_scaled || !g_mixed || !g_int8 || !g_fp8 || !g_last_error) throw std::runtime_error("conch_amd host shim: " + path + " lacks an entry point");
+  if (!g_scaled || !g_mixed || !g_int8 || !g_fp8 || !g_quant_gemm || !g_last_error) throw std::runtime_error("conch_amd host shim: " + path + " lacks an entry point");
 }
 
 [[noreturn]] void raise_status(int status, const char* what) {
@@ -155,6 +159,36 @@ py::object static_quant(const at::Tensor& x, const at::Tensor& scale, int64_t ki
   return py::cast(out);
 }
 
+// conch_static_quant_scaled_gemm for 2-D fp16 / bf16 activations, 2-D int8 / e4m3fn weights, one float32 activation scale (not 0-dim
+// with int8 weights: that form runs the unfused pair, ops/quantization/gemm.py), contiguous float32 scale_b, contiguous bias in the
+// output dtype; None = not that case
+py::object static_quant_scaled_gemm(const at::Tensor& x, const at::Tensor& b, const at::Tensor& sx, const at::Tensor& sb, const py::object& out_dtype_obj,
+                                    const c10::optional<at::Tensor>& bias) {
+  if (!x.is_cuda()) return py::none();
+  const c10::DeviceIndex dev = x.get_device();
+  if (dev != c10::hip::current_device() || !on_current_device(b, dev) || !on_current_device(sx, dev) || !on_current_device(sb, dev)) return py::none();
+  const at::ScalarType out_dtype = dtype_of(out_dtype_obj);
+  const int xcode = dtype_code(x.scalar_type()), bcode = dtype_code(b.scalar_type()), out_code = dtype_code(out_dtype);
+  if ((xcode != DT_FP16 && xcode != DT_BF16) || (bcode != DT_INT8 && bcode != DT_FP8_E4M3FN) || (out_code != DT_FP16 && out_code != DT_BF16)) return py::none();
+  if (x.dim() != 2 || b.dim() != 2 || x.size(1) != b.size(0)) return py::none();
+  if (sx.scalar_type() != at::kFloat || sx.numel() != 1 || (sx.dim() == 0 && bcode == DT_INT8)) return py::none();
+  if (sb.scalar_type() != at::kFloat || !sb.is_contiguous()) return py::none();
+  const int64_t m = x.size(0), k = x.size(1), n = b.size(1);
+  if (sb.numel() != 1 && sb.numel() != n) return py::none();
+  const void* bias_ptr = nullptr;
+  if (bias.has_value()) {
+    const at::Tensor& bt = *bias;
+    if (bt.scalar_type() != out_dtype || !on_current_device(bt, dev) || bt.numel() != n || !bt.is_contiguous()) return py::none();
+    bias_ptr = bt.data_ptr();
+  }
+  at::Tensor out = at::empty({m, n}, x.options().dtype(out_dtype));
+  const int status = g_quant_gemm(out.data_ptr(), x.data_ptr(), b.data_ptr(), (const float*)sx.data_ptr(), (const float*)sb.data_ptr(), bias_ptr, m, n, k,
+                                  x.stride(0), x.stride(1), b.stride(0), b.stride(1), n, 1, sb.numel(), xcode, bcode, out_code,
+                                  (void*)c10::hip::getCurrentHIPStream(dev).stream());
+  if (status) raise_status(status, "static_quant_scaled_gemm");
+  return py::cast(out);
+}
+
 }  // namespace
 
 PYBIND11_MODULE(_conch_host, mod) {
@@ -163,4 +197,5 @@ PYBIND11_MODULE(_conch_host, mod) {
   mod.def("scaled_gemm", &scaled_gemm);
   mod.def("mixed_precision_gemm", &mixed_precision_gemm);
   mod.def("static_quant", &static_quant);
+  mod.def("static_quant_scaled_gemm", &static_quant_scaled_gemm);
 }

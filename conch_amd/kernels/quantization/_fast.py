@@ -126,9 +126,17 @@ def static_quant(x: torch.Tensor, scale: torch.Tensor, kind: int) -> torch.Tenso
     return None
 
 
+# scaled_gemm(static quant(x, scale_x), b, scale_x, scale_b) in one C-ABI call (host shim only; None without it)
+def static_quant_scaled_gemm(x: torch.Tensor, b: torch.Tensor, scale_x: torch.Tensor, scale_b: torch.Tensor, output_dtype: torch.dtype,
+                             bias: torch.Tensor | None) -> torch.Tensor | None:
+    return None
+
+
 _py_scaled_gemm, _py_mixed_precision_gemm = scaled_gemm, mixed_precision_gemm
 _host = None if __import__("os").environ.get("CONCH_AMD_NO_HOST_SHIM") else _load_host_shim()
 if _host is not None:
     scaled_gemm = _host.scaled_gemm  # noqa: F811
     mixed_precision_gemm = _host.mixed_precision_gemm  # noqa: F811
     static_quant = _host.static_quant  # noqa: F811
+    if hasattr(_host, "static_quant_scaled_gemm"):  # (a shim built before round 4's last additions lacks it)
+        static_quant_scaled_gemm = _host.static_quant_scaled_gemm  # noqa: F811

@@ -128,6 +128,10 @@ def static_quant_scaled_gemm(x: torch.Tensor, b: torch.Tensor, scale_x: torch.Te
         from conch_amd.ops.quantization.int8 import scaled_int8_quant
 
         return scaled_gemm(scaled_int8_quant(x, scale_x)[0], b, scale_x, scale_b, output_dtype, bias)
+    if not _compile.compiling():  # the plain case through the C++ host path, when it is built (kernels/quantization/_fast.py)
+        out = _fast.static_quant_scaled_gemm(x, b, scale_x, scale_b, output_dtype, bias)
+        if out is not None:
+            return out
     out = torch.empty((x.shape[0], b.shape[1]), dtype=output_dtype, device=x.device)
     static_quant_scaled_gemm_launcher(out, x, b, scale_x, scale_b, bias)
     return out

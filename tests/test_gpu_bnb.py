@@ -143,7 +143,9 @@ def test_blockwise_8bit_round_trip_via_ops():
 
 @pytest.mark.parametrize("qt", ["nf4", "fp4"])
 @pytest.mark.parametrize("dname", ["f16", "bf16"])
-@pytest.mark.parametrize(("m", "k", "n", "blocksize"), [(16, 1024, 768, 64), (300, 512, 1000, 128), (1024, 4096, 1376, 64)])
+@pytest.mark.parametrize(("m", "k", "n", "blocksize"), [(16, 1024, 768, 64), (300, 512, 1000, 128), (1024, 4096, 1376, 64),
+                                                         # few tiles and a long K: the 16-bit tile kernel's split-K form (round 4)
+                                                         (300, 4096, 520, 64), (512, 11008, 256, 128)])
 def test_matmul_4bit(qt, dname, m, k, n, blocksize):
     """x @ dequantize_4bit(W).T: the dequantised weights are bit-exact (previous tests); the product is compared with the same
     product of the oracle's dequantised weights in fp64, to one output rounding plus fp32 accumulation order."""
