@@ -33,7 +33,55 @@ __global__ __launch_bounds__(kQuantThreads) void quant_flat_kernel(uint8_t* __re
   const float inv = 1.0f / scale[0];
   const int64_t nvec = n / kVec;
   const int64_t stride = (int64_t)gridDim.x * kQuantThreads;
-  for (int64_t v = (int64_t)blockIdx.x * kQuantThreads + threadIdx.x; v < nvec; v += stride) {
+  int64_t v_first = (int64_t)blockIdx.x * kQuantThreads + threadIdx.x;
+#ifndef CONCH_EXP_QUANT_LANE_CHUNKS  // (the A/B variant: rounds 1-3's form, 16 consecutive elements per lane, below)
+  // Every load instruction of a wave covers one contiguous kilobyte (lane l its 16 bytes at 16 l), not 16 bytes per lane at a
+  // 32- / 64-byte lane stride: a thread's 16 elements sit in 2 (16-bit input) or 4 (fp32) pieces of a 4096-element chunk and leave
+  // as 8- / 4-byte stores.  Round 4, profiles/r04/quant_coalesced_ab.txt: C1 9.32 -> 7.81 us (5.4 -> 6.45 TB/s), the other
+  // 16-bit cases -9 %, fp32 inputs -32...-36 % (they had been SLOWER than the scalar row kernel), bit-identical.
+  {
+    constexpr int kPieces = XDT == CONCH_DT_FP32 ? 4 : 2, kPer = kVec / kPieces;
+    const int64_t nchunk = n / (kQuantThreads * kVec);
+    for (int64_t c = blockIdx.x; c < nchunk; c += gridDim.x) {
+      const int64_t base = c * (kQuantThreads * kVec) + threadIdx.x * kPer;
+      float f[kVec];
+      if constexpr (XDT == CONCH_DT_FP32) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 v = __builtin_nontemporal_load((const f32x4*)((const float*)x + base + j * (kQuantThreads * kPer)));
+#pragma unroll
+          for (int i = 0; i < 4; ++i) f[j * 4 + i] = v[i];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const u16x8 v = __builtin_nontemporal_load((const u16x8*)((const uint16_t*)x + base + j * (kQuantThreads * kPer)));
+#pragma unroll
+          for (int i = 0; i < 8; ++i) f[j * 8 + i] = bits16_to_float<XDT>(v[i]);
+        }
+      }
+      if constexpr (ROUNDP) {
+#pragma unroll
+        for (int j = 0; j < kVec; ++j) f[j] = round_product<XDT, KIND, ROUNDP>(pin_f32(f[j] * inv));
+      }
+      const float mul = ROUNDP ? 1.0f : inv;
+#pragma unroll
+      for (int j = 0; j < kPieces; ++j) {
+        uint8_t* dst = out + base + j * (kQuantThreads * kPer);
+        if constexpr (kPer == 4) {
+          __builtin_nontemporal_store((int)quant_four<KIND>(f[4 * j], f[4 * j + 1], f[4 * j + 2], f[4 * j + 3], mul), (int*)dst);
+        } else {
+          i32x2 o;
+          o[0] = (int)quant_four<KIND>(f[8 * j], f[8 * j + 1], f[8 * j + 2], f[8 * j + 3], mul);
+          o[1] = (int)quant_four<KIND>(f[8 * j + 4], f[8 * j + 5], f[8 * j + 6], f[8 * j + 7], mul);
+          __builtin_nontemporal_store(o, (i32x2*)dst);
+        }
+      }
+    }
+    v_first += nchunk * kQuantThreads;  // the rest (< 4096 elements + the scalar tail) in the per-thread form below
+  }
+#endif
+  for (int64_t v = v_first; v < nvec; v += stride) {
     float f[kVec];
     load16<XDT>(x, v * kVec, f);
     if constexpr (ROUNDP) {  // quant_four multiplies by its last argument: hand it the rounded product and 1
@@ -75,6 +123,29 @@ __global__ __launch_bounds__(kQuantThreads) void quant_rows_kernel(uint8_t* __re
   }
 }
 
+// Row-strided but 16-byte aligned rows of a multiple of 16 elements (a column slice of a wider activation): one block walks one
+// row in chunks of 4096 elements with the contiguous-per-instruction loads of the flat kernel (quant_common.hpp, load_pieces).
+template <int XDT, int KIND, bool ROUNDP = false>
+__global__ __launch_bounds__(kQuantThreads) void quant_rows_vec_kernel(uint8_t* __restrict__ out, const void* __restrict__ x,
+                                                                       const float* __restrict__ scale, int64_t tokens, int64_t hidden,
+                                                                       int64_t x_row_stride, int64_t out_row_stride) {
+  const float inv = 1.0f / scale[0];
+  const float mul = ROUNDP ? 1.0f : inv;
+  for (int64_t row = blockIdx.x; row < tokens; row += gridDim.x) {
+    const int64_t xb = row * x_row_stride;
+    uint8_t* orow = out + row * out_row_stride;
+    for (int64_t e0 = 0; e0 < hidden; e0 += (int64_t)kQuantThreads * kVec) {
+      float f[kVec];
+      load_pieces<XDT, kQuantThreads>(x, xb + e0, (int)threadIdx.x, xb + hidden, f);
+      if constexpr (ROUNDP) {
+#pragma unroll
+        for (int j = 0; j < kVec; ++j) f[j] = round_product<XDT, KIND, ROUNDP>(pin_f32(f[j] * inv));
+      }
+      store_pieces<XDT, KIND, kQuantThreads>(orow, e0, (int)threadIdx.x, hidden, f, mul);
+    }
+  }
+}
+
 template <int XDT, int KIND, bool ROUNDP = false>
 int launch_quant(uint8_t* out, const void* x, const float* scale, int64_t tokens, int64_t hidden,
                  int64_t x_row_stride, int64_t out_row_stride, hipStream_t stream) {
@@ -93,8 +164,15 @@ int launch_quant(uint8_t* out, const void* x, const float* scale, int64_t tokens
                        0, stream, out, x, scale, n);
   } else {
     int64_t blocks = tokens < 256 * 8 ? tokens : 256 * 8;
-    hipLaunchKernelGGL((quant_rows_kernel<XDT, KIND, ROUNDP>), dim3((unsigned)blocks), dim3(kQuantThreads),
-                       0, stream, out, x, scale, tokens, hidden, x_row_stride, out_row_stride);
+    constexpr int kElem = XDT == CONCH_DT_FP32 ? 4 : 2;
+    const bool vec_rows = hidden % kVec == 0 && (x_row_stride * kElem) % 16 == 0 && ((uintptr_t)x % 16 == 0) && out_row_stride % 8 == 0 &&
+                          ((uintptr_t)out % 8 == 0);
+    if (vec_rows)
+      hipLaunchKernelGGL((quant_rows_vec_kernel<XDT, KIND, ROUNDP>), dim3((unsigned)blocks), dim3(kQuantThreads), 0, stream, out, x, scale, tokens,
+                         hidden, x_row_stride, out_row_stride);
+    else
+      hipLaunchKernelGGL((quant_rows_kernel<XDT, KIND, ROUNDP>), dim3((unsigned)blocks), dim3(kQuantThreads),
+                         0, stream, out, x, scale, tokens, hidden, x_row_stride, out_row_stride);
   }
   return check_launch("static_scaled_quant");
 }

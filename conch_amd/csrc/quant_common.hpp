@@ -72,5 +72,55 @@ __device__ __forceinline__ void load16(const void* x, int64_t base, float (&f)[k
   }
 }
 
+// The same 16 elements per thread, laid out so that every load instruction of a wave covers CONTIGUOUS memory: a group of G threads
+// works on a chunk of G x 16 elements starting at element e0, thread t takes piece j = elements [e0 + j G P + t P, + P), P = 8 for
+// 16-bit inputs (2 pieces, one 16-byte load each), P = 4 for fp32 (4 pieces).  Elements at or beyond `limit` read as 0 and are not
+// stored (limit - e0 is a multiple of 16).  Round 4: against 16 consecutive elements per lane (a 32- / 64-byte lane stride per load
+// instruction) the static quantiser gained 9-16 % on 16-bit inputs and 33 % on fp32 (profiles/r04/quant_coalesced_ab.txt).
+template <int XDT>
+constexpr int kPieceElems = XDT == CONCH_DT_FP32 ? 4 : 8;
+
+template <int XDT, int G>
+__device__ __forceinline__ void load_pieces(const void* x, int64_t e0, int t, int64_t limit, float (&f)[kVec]) {
+  constexpr int P = kPieceElems<XDT>;
+#pragma unroll
+  for (int j = 0; j < kVec / P; ++j) {
+    const int64_t e = e0 + (int64_t)j * (G * P) + (int64_t)t * P;
+    if (e < limit) {
+      if constexpr (XDT == CONCH_DT_FP32) {
+        const f32x4 v = __builtin_nontemporal_load((const f32x4*)((const float*)x + e));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[j * 4 + i] = v[i];
+      } else {
+        const u16x8 v = __builtin_nontemporal_load((const u16x8*)((const uint16_t*)x + e));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[j * 8 + i] = bits16_to_float<XDT>(v[i]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < P; ++i) f[j * P + i] = 0.0f;
+    }
+  }
+}
+
+template <int XDT, int KIND, int G>
+__device__ __forceinline__ void store_pieces(uint8_t* out, int64_t e0, int t, int64_t limit, const float (&f)[kVec], float mul) {
+  constexpr int P = kPieceElems<XDT>;
+#pragma unroll
+  for (int j = 0; j < kVec / P; ++j) {
+    const int64_t e = e0 + (int64_t)j * (G * P) + (int64_t)t * P;
+    if (e < limit) {
+      if constexpr (P == 4) {
+        __builtin_nontemporal_store((int)quant_four<KIND>(f[4 * j], f[4 * j + 1], f[4 * j + 2], f[4 * j + 3], mul), (int*)(out + e));
+      } else {
+        i32x2 o;
+        o[0] = (int)quant_four<KIND>(f[8 * j], f[8 * j + 1], f[8 * j + 2], f[8 * j + 3], mul);
+        o[1] = (int)quant_four<KIND>(f[8 * j + 4], f[8 * j + 5], f[8 * j + 6], f[8 * j + 7], mul);
+        __builtin_nontemporal_store(o, (i32x2*)(out + e));
+      }
+    }
+  }
+}
+
 }  // namespace quant
 }  // namespace conch

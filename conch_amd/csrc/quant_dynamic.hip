@@ -48,6 +48,32 @@ __global__ __launch_bounds__(kQuantThreads) void dyn_quant_vec_kernel(uint8_t* _
   const int64_t xb = (live ? row : 0) * x_row_stride;
   float cache[CACHE][kVec];
   float amax = 0.0f;
+#ifndef CONCH_EXP_QUANT_LANE_CHUNKS
+  constexpr bool kPiecesForm = XDT == CONCH_DT_FP32;
+#else
+  constexpr bool kPiecesForm = false;
+#endif
+  // fp32 rows: chunks of GROUP x 16 elements, every load instruction contiguous across the lanes (quant_common.hpp, load_pieces):
+  // 1.4-1.6x (profiles/r04/quant_coalesced_ab.txt).  16-bit rows keep 16 consecutive elements per lane (two loads at a 32-byte lane
+  // stride, one 16-byte store): with a row in registers between the two passes the pieces form measured 2-5 % SLOWER there.
+  constexpr int64_t kChunk = (int64_t)GROUP * kVec;
+  const int64_t x_end = xb + hidden;
+  if constexpr (kPiecesForm) {
+#pragma unroll
+  for (int c = 0; c < CACHE; ++c) {
+    if ((int64_t)c * kChunk < hidden) {
+      load_pieces<XDT, GROUP>(x, xb + c * kChunk, tid, x_end, cache[c]);
+#pragma unroll
+      for (int j = 0; j < kVec; ++j) amax = fmaxf(amax, fabsf(cache[c][j]));
+    }
+  }
+  for (int64_t e0 = (int64_t)CACHE * kChunk; e0 < hidden; e0 += kChunk) {
+    float f[kVec];
+    load_pieces<XDT, GROUP>(x, xb + e0, tid, x_end, f);
+#pragma unroll
+    for (int j = 0; j < kVec; ++j) amax = fmaxf(amax, fabsf(f[j]));
+  }
+  } else {
 #pragma unroll
   for (int c = 0; c < CACHE; ++c) {
     const int64_t v = tid + (int64_t)c * GROUP;
@@ -63,6 +89,7 @@ __global__ __launch_bounds__(kQuantThreads) void dyn_quant_vec_kernel(uint8_t* _
 #pragma unroll
     for (int j = 0; j < kVec; ++j) amax = fmaxf(amax, fabsf(f[j]));
   }
+  }
   amax = wave_max(amax);
   if constexpr (GROUP == 256) {
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
@@ -74,6 +101,17 @@ __global__ __launch_bounds__(kQuantThreads) void dyn_quant_vec_kernel(uint8_t* _
   const float inv = 1.0f / scale;
   if (tid == 0) scale_out[row] = scale;
   uint8_t* orow = out + row * out_row_stride;
+  if constexpr (kPiecesForm) {
+#pragma unroll
+    for (int c = 0; c < CACHE; ++c)
+      if ((int64_t)c * kChunk < hidden) store_pieces<XDT, KIND, GROUP>(orow, c * kChunk, tid, hidden, cache[c], inv);
+    for (int64_t e0 = (int64_t)CACHE * kChunk; e0 < hidden; e0 += kChunk) {
+      float f[kVec];
+      load_pieces<XDT, GROUP>(x, xb + e0, tid, x_end, f);
+      store_pieces<XDT, KIND, GROUP>(orow, e0, tid, hidden, f, inv);
+    }
+    return;
+  }
 #pragma unroll
   for (int c = 0; c < CACHE; ++c) {
     const int64_t v = tid + (int64_t)c * GROUP;

@@ -153,6 +153,31 @@ def test_quant_empty_and_row_strided_inputs():
     np.testing.assert_array_equal(to_bits(out8), to_bits(oracle.scaled_fp8_quant_ref(view.cpu(), s.cpu())))
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize(("tokens", "hidden", "wide"), [(33, 4096, 12288), (5, 4112, 8224), (300, 16, 48), (2, 11008, 11008 + 64)])
+def test_static_quant_of_an_aligned_column_slice(dt, tokens, hidden, wide):
+    """A 16-byte aligned column slice of a wider activation (one part of a fused qkv projection) -- rows strided, not flat: the
+    vectorised row kernel (contiguous 1 KiB per load instruction, chunks of 4096 elements with a tail), into a contiguous and
+    into a row-strided result, int8 (fp32 product and the 0-dim-scale x.dtype product) and both fp8 flavours, bit for bit."""
+    seed_everything(5)
+    base = ((torch.rand(tokens, wide, device="cuda") - 0.5) * 600).to(dt)
+    off = 16 if wide - hidden >= 16 else 0
+    view = base[:, off:off + hidden]
+    s = torch.tensor([0.7], device="cuda")
+    out = torch.empty(tokens, hidden, dtype=torch.int8, device="cuda")
+    static_scaled_int8_quant(out, view, s)
+    assert torch.equal(out.cpu(), oracle.scaled_int8_quant_ref(view.cpu(), s.cpu()))
+    big = torch.zeros(tokens, hidden + 24, dtype=torch.int8, device="cuda")
+    static_scaled_int8_quant(big[:, 8:8 + hidden], view, s)
+    assert torch.equal(big[:, 8:8 + hidden].cpu(), out.cpu()) and not bool(big[:, :8].any()) and not bool(big[:, 8 + hidden:].any())
+    q0, _ = scaled_int8_quant(view, torch.tensor(0.7, device="cuda"))  # 0-dim: the product is rounded to x.dtype first
+    assert torch.equal(q0.cpu(), oracle.scaled_int8_quant_ref(view.cpu(), torch.tensor(0.7)))
+    for f8 in (torch.float8_e4m3fn, torch.float8_e4m3fnuz):
+        out8 = torch.empty(tokens, hidden, dtype=f8, device="cuda")
+        static_scaled_fp8_quant(out8, view, s)
+        np.testing.assert_array_equal(to_bits(out8), to_bits(oracle.scaled_fp8_quant_ref(view.cpu(), s.cpu(), oracle.FP8_E4M3FNUZ if f8 is torch.float8_e4m3fnuz else oracle.FP8_E4M3FN)))
+
+
 def test_quant_c1_config_bit_exact():
     """BASELINE config C1: 4096x4096 fp16, scale 2.1 (int8 bench :124-125)."""
     seed_everything(0)
