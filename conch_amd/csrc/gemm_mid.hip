@@ -258,8 +258,6 @@ int mid_split_slices(const ScaledGemmArgs& p) {
   const bool bits16 = p.in_dtype == CONCH_DT_FP16 || p.in_dtype == CONCH_DT_BF16;  // the dequantise-first paths (NULL scales = 1)
   if (p.in_dtype != CONCH_DT_FP8_E4M3FN && p.in_dtype != CONCH_DT_INT8 && !bits16) return 1;
   if (p.acc_scale != 1.0f || (!bits16 && (!p.scale_a || !p.scale_b)) || p.fuse_silu || p.n_more || p.n % 4 || p.c_stride_n != 1) return 1;
-  // the exact leg of the e4m3fnuz flow (gated on "flag set"): its reduce kernel knows no gate and would overwrite what the fp8 leg wrote
-  if (p.gate && p.gate_run_if) return 1;
   const int64_t tiles = ((p.m + kMidTile - 1) / kMidTile) * ((p.n + kMidTile - 1) / kMidTile);
   const int64_t steps = p.k / kStepBytes;
   if ((p.m * p.n * 4) >= ((int64_t)1 << 28) || tiles < 1) return 1;

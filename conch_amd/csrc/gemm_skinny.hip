@@ -523,6 +523,7 @@ __global__ __launch_bounds__(256) void skinny_reduce_kernel(ScaledGemmArgs p, co
   // per thread had put ~200 instructions ahead of the first load of a kernel that lives 3-4 us)
   const int q = (int)blockIdx.x * 256 + (int)threadIdx.x;
   if (q >= (int)(p.n / 4)) return;
+  if (gated_off(p.gate, p.gate_run_if)) return;  // the exact leg of the e4m3fnuz flow (gemm.hpp): nothing to reduce, C is not ours
   const int m = blockIdx.y, n = q * 4;
   // four slices of loads in flight at a time (a plain `for s` loop is one dependent L2 round trip per slice), added in
   // slice order: exact for int32, deterministic for fp32

@@ -29,10 +29,13 @@ for m, k, n in [(1, 4096, 4096), (16, 4096, 4096), (64, 4096, 11008), (128, 4096
     x, w = 0.25 * torch.rand((m, k), device="cuda"), 0.25 * torch.rand((n, k), device="cuda")
     sa, sb = 0.25 * torch.rand((m, 1), device="cuda"), 0.25 * torch.rand((n, 1), device="cuda")
     res = {}
-    for name, dt in (("fn", torch.float8_e4m3fn), ("fnuz", torch.float8_e4m3fnuz)):
+    for name, dt in (("fn", torch.float8_e4m3fn), ("fnuz", torch.float8_e4m3fnuz), ("sat", torch.float8_e4m3fnuz)):
         a, bt = x.to(dt), w.to(dt)
+        if name == "sat":  # one saturated code in the weights: the exact path
+            bt.view(torch.uint8)[5, 17] = 0x7F
         res[name] = timeit(lambda: scaled_gemm(a, bt.T, sa, sb, torch.bfloat16), 200 if m < 2048 else 50)
-    print(f"{m:5d}x{k:5d}x{n:5d}: e4m3fn {res['fn']:7.1f} us   e4m3fnuz {res['fnuz']:7.1f} us   x{res['fnuz'] / res['fn']:.2f}", flush=True)
+    print(f"{m:5d}x{k:5d}x{n:5d}: e4m3fn {res['fn']:7.1f} us   e4m3fnuz {res['fnuz']:7.1f} us (x{res['fnuz'] / res['fn']:.2f})   "
+          f"e4m3fnuz with a saturated weight {res['sat']:7.1f} us (x{res['sat'] / res['fn']:.2f})", flush=True)
 
 # GPU-side time of the e4m3fnuz flow alone: the same call replayed from a HIP graph (no host launch cost)
 from conch_amd import _C  # noqa: E402
