@@ -153,14 +153,14 @@ ScaledKernel choose_scaled_kernel(const ScaledGemmArgs& p, double* tiles_us_out 
   double mid_us = tiles128 <= device_cu_count() ? (23.0 + 0.08 * (double)std::max<int64_t>(0, tiles128 - 128)) * kscale
                                                 : (double)rounds128 * (31.0 + 0.02 * (double)tiles128 / (double)rounds128) * kscale;
   // split-K form of the 128 x 128 tiles (gemm_mid.hip, mid_split_slices; round 4, profiles/r04/mid_splitk_sweep.txt): two launches
-  // (~9 us of fixed cost: with 7 the fp8 sibling of C2, 128 x 4096 x 4096, left the one-launch split-K kernel's 10.1 us for 15.1), a K step 0.52-0.68 us with up to one workgroup per CU and ~1.0 us with two, the slabs written
+  // (~8 us of fixed cost: with 7 the fp8 sibling of C2, 128 x 4096 x 4096, left the one-launch split-K kernel's 10.1 us for 15.1; with 9, 32-48 x 11008 x 4096 stayed on the skinny kernel at 13-22 % more on weights streamed from HBM: profiles/r04/dispatch_cold_sweep.txt), a K step 0.52-0.68 us with up to one workgroup per CU and ~1.0 us with two, the slabs written
   // and read back at ~8 bytes per us and CU-free MB
   if (const int msl = mid_split_slices(p); msl > 1) {
     const double cus = (double)device_cu_count();
     const double wgs = (double)tiles128 * msl;
     const double steps_slice = std::ceil((double)(p.k / 128) / msl);
     const double per_step = wgs <= cus ? 0.52 + 0.16 * wgs / cus : std::ceil(wgs / (2.0 * cus));
-    mid_us = 9.0 + steps_slice * per_step + (double)msl * (double)p.m * (double)p.n * 1e-6;
+    mid_us = 8.0 + steps_slice * per_step + (double)msl * (double)p.m * (double)p.n * 1e-6;
   }
   ScaledKernel pick = kKernelTiled;
   double best = tiled_us;

@@ -987,7 +987,11 @@ int pick_split(const MixedGemmArgs& p, int nt, int num_cus, double* us_out = nul
     const int per = ((steps + s - 1) / s + spg - 1) / spg * spg;  // steps per slice, whole groups
     // ~0.97 us per step on a sparsely filled chip (profiles/r02/dispatch_cold_sweep_after.txt: one row of tiles, 15.5 us per 1024 of
     // K) + the slabs: written once, read once, ~4 TB/s, plus the reduce launch
-    const double us = 0.97 * per * rounds + (s > 1 ? 3.0 + 2.0 * (double)s * (double)p.m * (double)p.n * 4.0 / 4.0e6 : 0.0);
+    // Refitted in round 4 on weights streamed from HBM (profiles/r04/dispatch_cold_sweep.txt): 4 us of prologue + epilogue per
+    // workgroup whatever its K range, 5 us for the second launch, the slabs at ~8 bytes per ns (written once, read once, mostly
+    // out of L2 / Infinity Cache).  With 3 us and 4 bytes per ns 256 x 4096 x 4096 took four slices (30.6 us) where eight take
+    // 25.8, and 96 x 4096 x 4096 left the decode kernel's 17.3 us for 21.1.
+    const double us = 4.0 + 0.97 * per * rounds + (s > 1 ? 5.0 + (double)s * (double)p.m * (double)p.n * 1.0e-6 : 0.0);
     if (us < best_us - 1e-9) {
       best_us = us;
       best = s;

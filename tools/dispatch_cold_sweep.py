@@ -53,11 +53,13 @@ def scaled_case(m, k, n, dtype):
     res = {}
     for regime, rot in (("warm", 1), ("cold", count)):
         LIB.conch_set_timing_rotation(rot, n * k)
-        for name, variant in (("auto", 0), ("skinny", 4), ("mid128", 6), ("mid128x2", 6), ("tile256", 5)):
+        # mid128 = the 128 x 128 tiles with their own K-split rule (round 4), mid128w = whole K per workgroup, mid128x2 = whole K, 2-stage loop
+        for name, variant in (("auto", 0), ("skinny", 4), ("mid128", 6), ("mid128w", 6), ("mid128x2", 6), ("tile256", 5)):
             if variant == 4 and m > 256:
                 continue
             _C.set_gemm_variant(variant)
-            _C.set_tuning(_C.TUNE_MID_STAGES, 2 if name == "mid128x2" else 0)  # mid128x2 = the 2-stage loop forced
+            _C.set_tuning(_C.TUNE_MID_STAGES, 2 if name == "mid128x2" else 0)
+            _C.set_tuning(_C.TUNE_MID_SPLITK, 0 if name in ("auto", "mid128") else 1)
             try:
                 res[(regime, name)] = timed(run, 30.0)
             except Exception:  # noqa: BLE001 -- a forced variant whose contract the shape does not meet
@@ -65,7 +67,8 @@ def scaled_case(m, k, n, dtype):
     _C.set_gemm_variant(0)
     LIB.conch_set_timing_rotation(1, 0)
     _C.set_tuning(_C.TUNE_MID_STAGES, 0)
-    report(f"scaled {str(dtype)[6:]:13s} {m:5d}x{k}x{n}", res, ("skinny", "mid128", "mid128x2", "tile256"))
+    _C.set_tuning(_C.TUNE_MID_SPLITK, 0)
+    report(f"scaled {str(dtype)[6:]:13s} {m:5d}x{k}x{n}", res, ("skinny", "mid128", "mid128w", "mid128x2", "tile256"))
 
 
 def mixed_case(m, k, n, dtype=torch.float16, bits=4):
@@ -86,8 +89,6 @@ def mixed_case(m, k, n, dtype=torch.float16, bits=4):
         LIB.conch_set_timing_rotation(rot, words * n * 4)
         for name, variant in (("auto", 0), ("decode", 4), ("tile", 5), ("tile/2", 5), ("tile/4", 5), ("tile/8", 5)):
             if variant == 4 and m > 256:
-                continue
-            if "/" in name and m <= 256:
                 continue
             _C.set_gemm_variant(variant)
             _C.set_tuning(_C.TUNE_MIXED_SPLITK, int(name.split("/")[1]) if "/" in name else (1 if name == "tile" else 0))
@@ -120,7 +121,8 @@ MIXED_MS = [384, 512, 768, 1024, 2048] if "--mixed-mid" in sys.argv else [1, 8, 
 
 if __name__ == "__main__":
     ms_ = [8, 32, 64, 128, 256, 512] if QUICK else [8, 16, 32, 48, 64, 96, 128, 192, 256, 384, 512, 768, 1024]
-    shapes = [(4096, 4096), (4096, 11008)] if QUICK else [(4096, 4096), (4096, 11008), (8192, 8192), (4096, 28672), (8192, 28672), (11008, 4096)]
+    shapes = [(4096, 4096), (4096, 11008)] if QUICK else [(4096, 4096), (4096, 11008), (8192, 8192), (4096, 28672), (8192, 28672), (11008, 4096),
+                                                          (28672, 8192), (13824, 5120)]
     if "--mixed-mid" not in sys.argv:
         for k, n in shapes:
             for m in ms_:
