@@ -655,6 +655,7 @@ extern "C" int64_t conch_bnb_gemm_4bit_workspace_bytes(int64_t m, int64_t n, int
   if (m <= 0 || n <= 0 || k <= 0) return 0;
   int64_t need = n * k * 2;
   if (m <= 256) need = std::max(need, (k / kBgSliceK + 1) * m * n * 4);
+  need = std::max(need, mid_split_slab_bytes(m, n));  // the 16-bit tile kernel's split-K slabs (gemm_mid.hip)
   return need + ((int64_t)1 << 20);
 }
 

@@ -584,6 +584,7 @@ extern "C" int64_t conch_scaled_gemm_workspace_bytes(int64_t m, int64_t n, int64
   const int64_t kpad = (k + 127) / 128 * 128;
   int64_t need = 2 * (m + n) * kpad + 512;                      // repack.hip: both operands, 2 bytes per element at most
   if (m <= 256) need = std::max(need, (k / 1024 + 1) * m * n * 4);  // gemm_skinny.hip slabs
+  need = std::max(need, mid_split_slab_bytes(m, n));            // gemm_mid.hip split-K slabs (few tiles)
   need = std::max(need, m * n * 2);                             // unfused silu pair: `n` = the wide width there
   return need + ((int64_t)1 << 20);
 }

@@ -127,6 +127,7 @@ int launch_scaled_gemm_mfma(const ScaledGemmArgs& p, int variant, hipStream_t st
 // gemm_mid.hip -- 128x128 tiles, two workgroups per CU, for shapes with few 256x256 tiles (variant 6); same contract
 int launch_scaled_gemm_mid(const ScaledGemmArgs& p, hipStream_t stream);
 int mid_split_slices(const ScaledGemmArgs& p);  // K slices that launcher will use for `p` (1 = no split-K)
+int64_t mid_split_slab_bytes(int64_t m, int64_t n);  // scratch bound of that form (workspace queries)
 // the dispatcher's cost model (capi.hip, choose_scaled_kernel): 0 = 256 x 256 tiles, 1 = 128 x 128 tiles, 2 = split-K skinny
 int scaled_kernel_choice(const ScaledGemmArgs& p);
 double scaled_tiles_estimate_us(const ScaledGemmArgs& p);  // the same model's time (us) for the better of the two tile kernels

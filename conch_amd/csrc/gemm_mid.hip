@@ -275,6 +275,12 @@ int mid_split_slices(const ScaledGemmArgs& p) {
   return (int)((steps + per - 1) / per);  // no empty slice
 }
 
+// upper bound of the slabs the split-K form may ask for on an m x n result (auto rule: at most 0.7 of a chip of tiles, 8 slices)
+int64_t mid_split_slab_bytes(int64_t m, int64_t n) {
+  const int64_t tiles = ((m + kMidTile - 1) / kMidTile) * ((n + kMidTile - 1) / kMidTile);
+  return tiles * 10 > (int64_t)device_cu_count() * 7 ? 0 : 8 * m * n * 4;
+}
+
 // Same layout contract as the 256x256 kernels (scaled_gemm_mfma_supported).
 int launch_scaled_gemm_mid(const ScaledGemmArgs& p_in, hipStream_t stream) {
   ScaledGemmArgs p = p_in;

@@ -127,6 +127,29 @@ def test_e4m3fnuz_gemm_captures_after_the_reservation_alone(special):
         assert torch.isfinite(got.float()).all()
 
 
+@pytest.mark.parametrize(("m", "k", "n"), [(256, 8192, 512), (64, 28672, 256), (512, 11008, 384)])
+def test_split_k_forms_capture_after_the_reservation_alone(m, k, n):
+    """The workspace query covers the slabs of every split-K form the dispatcher may pick (the 128 x 128 tiles' split, several passes
+    per slice in the skinny kernel): a fresh stream, the reservation, a capture without an eager warm-up, replays equal to eager."""
+    seed_everything(15)
+    dev = torch.device("cuda")
+    a = torch.randint(-32, 32, (m, k), dtype=torch.int8, device=dev)
+    bt = torch.randint(-32, 32, (n, k), dtype=torch.int8, device=dev)
+    sa, sb = 0.25 * torch.rand((m, 1), device=dev), 0.25 * torch.rand((n, 1), device=dev)
+    want = scaled_gemm(a, bt.T, sa, sb, torch.bfloat16)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        _C.reserve_scratch(_C.load().conch_scaled_gemm_workspace_bytes(m, n, k))
+    stream.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=stream):
+        out = scaled_gemm(a, bt.T, sa, sb, torch.bfloat16)
+    for _ in range(2):
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want)
+
+
 def test_reset_scratch_is_harmless_between_one_launch_calls():
     """conch_reset_scratch zeroes the arrival counters of the current stream with a memset ordered ON that stream: between two
     one-launch split-K calls it changes nothing (the counters are zero there by construction); on a stream that never used a
