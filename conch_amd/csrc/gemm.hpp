@@ -161,7 +161,8 @@ int64_t prepacked_weight_words(int64_t k, int64_t n, int bits, int nt);
 int prepack_mixed_weights(uint32_t* image, uint32_t* plain, int64_t k, int64_t n, int64_t plain_stride, int bits, int nt, bool unpack,
                           hipStream_t stream);
 int mixed_gemm_tile_nt(const MixedGemmArgs& p);
-double mixed_tiles_estimate_us(const MixedGemmArgs& p);  // cost model: the LDS-tiled kernel with the tile shape and K split it would pick
+double mixed_tiles_estimate_us(const MixedGemmArgs& p);
+int mixed_tiles_auto_split(const MixedGemmArgs& p);  // K slices the LDS-tiled kernel would use on `p` (automatic tuning)  // cost model: the LDS-tiled kernel with the tile shape and K split it would pick
 int launch_mixed_gemm_mfma(const MixedGemmArgs& p, hipStream_t stream);
 // gemm_mixed_strip.hip: every wave dequantises its own column strip straight into MFMA operand registers
 bool mixed_gemm_strip_supported(const MixedGemmArgs& p);

@@ -987,11 +987,11 @@ int pick_split(const MixedGemmArgs& p, int nt, int num_cus, double* us_out = nul
     const int per = ((steps + s - 1) / s + spg - 1) / spg * spg;  // steps per slice, whole groups
     // ~0.97 us per step on a sparsely filled chip (profiles/r02/dispatch_cold_sweep_after.txt: one row of tiles, 15.5 us per 1024 of
     // K) + the slabs: written once, read once, ~4 TB/s, plus the reduce launch
-    // Refitted in round 4 on weights streamed from HBM (profiles/r04/dispatch_cold_sweep.txt): 4 us of prologue + epilogue per
+    // Refitted in round 4 on weights streamed from HBM (profiles/r04/dispatch_cold_sweep.txt): 3 us of prologue + epilogue per
     // workgroup whatever its K range, 5 us for the second launch, the slabs at ~8 bytes per ns (written once, read once, mostly
     // out of L2 / Infinity Cache).  With 3 us and 4 bytes per ns 256 x 4096 x 4096 took four slices (30.6 us) where eight take
     // 25.8, and 96 x 4096 x 4096 left the decode kernel's 17.3 us for 21.1.
-    const double us = 4.0 + 0.97 * per * rounds + (s > 1 ? 5.0 + (double)s * (double)p.m * (double)p.n * 1.0e-6 : 0.0);
+    const double us = 3.0 + 0.97 * per * rounds + (s > 1 ? 5.0 + (double)s * (double)p.m * (double)p.n * 1.0e-6 : 0.0);
     if (us < best_us - 1e-9) {
       best_us = us;
       best = s;
@@ -1001,12 +1001,54 @@ int pick_split(const MixedGemmArgs& p, int nt, int num_cus, double* us_out = nul
   return best;
 }
 
+// More than one row of tiles (M > 256): tile shape AND K split together.  pick_nt ignores the split and pick_split takes the
+// shape as given, which left 6-15 % at 768-1536 rows (1024 x 28672 x 8192: 445 us on 256 x 128 tiles where 256 x 256 tiles in two K
+// slices take 387; 1024 x 13824 x 5120: 167 against 147 on 192-column tiles in two slices).  One model for all (shape, slices)
+// candidates, fitted to tools/sweep_mixed_nt_split.py's 120 timings (RMS error 4.5 %, the fastest candidate picked on all ten
+// shapes: profiles/r04/mixed_nt_split_sweep.txt): rounds x steps per slice x 0.24 us x (nt + 1.2; 5.4 for the 512 x 128 tile)
+// x (1 + 0.2 x the fraction of the chip the launch fills -- a full chip runs each K step ~20 % slower than half a chip: the
+// power limit) + 5 us and 1.5 us per MB-slab for a split.  `p` without forced tuning, not fused, not pre-packed.
+bool pick_tile_and_split(const MixedGemmArgs& p, int num_cus, int* nt_out, int* split_out, double* us_out) {
+  if (p.m <= kTileM || p.fuse_silu || p.prepacked) return false;
+  const int steps = (int)(p.k / kStepK), spg = p.group_size / kStepK;
+  double best_us = 1e30;
+  for (int nt = 2; nt <= kMixedTall; ++nt) {
+    if (nt == 4 && p.zp_mode == CONCH_ZP_TENSOR) continue;  // not built (see launch_zp)
+    const int rows = nt == kMixedTall ? kTallRows : kTileM, cols = nt == kMixedTall ? 128 : 64 * nt;
+    const int64_t tiles = ((p.m + rows - 1) / rows) * ((p.n + cols - 1) / cols);
+    const double w = nt == kMixedTall ? 5.4 : nt + 1.2;
+    for (int s = 1; s <= 8; s *= 2) {
+      if (s > 1 && (p.n % 4 || tiles * s > num_cus || steps / s < 8)) break;
+      const int per = ((steps + s - 1) / s + spg - 1) / spg * spg;
+      const int64_t wgs = tiles * s, rounds = (wgs + num_cus - 1) / num_cus;
+      const double fill = (double)wgs / (double)(rounds * num_cus);
+      const double us = (double)rounds * per * 0.24 * w * (1.0 + 0.2 * fill) + (s > 1 ? 5.0 + (double)s * (double)p.m * (double)p.n * 1.5e-6 : 0.0);
+      if (us < best_us - 1e-9) {
+        best_us = us;
+        *nt_out = nt;
+        *split_out = s;
+      }
+    }
+  }
+  if (us_out) *us_out = best_us;
+  return best_us < 1e29;
+}
+
 // the cost model's time (us) for the LDS-tiled kernel on `p` with the tile shape and the K split it would pick
 double mixed_tiles_estimate_us(const MixedGemmArgs& p) {
   const int cus = device_cu_count();
   double us = 0.0;
-  pick_split(p, pick_nt(p, cus), cus, &us);
+  int nt = 0, split = 1;
+  if (!pick_tile_and_split(p, cus, &nt, &split, &us)) pick_split(p, pick_nt(p, cus), cus, &us);
   return us * (p.bits == 8 ? 1.1 : 1.0);
+}
+
+// K slices the LDS-tiled kernel would use on `p` with automatic tuning (the strip kernel, which has no split, defers to a split pick)
+int mixed_tiles_auto_split(const MixedGemmArgs& p) {
+  const int cus = device_cu_count();
+  int nt = 0, split = 1;
+  if (pick_tile_and_split(p, cus, &nt, &split, nullptr)) return split;
+  return pick_split(p, pick_nt(p, cus), cus);
 }
 
 int launch_mixed_gemm_mfma(const MixedGemmArgs& p_in, hipStream_t stream) {
@@ -1014,13 +1056,15 @@ int launch_mixed_gemm_mfma(const MixedGemmArgs& p_in, hipStream_t stream) {
   p.rows_epilogue = tuning(CONCH_TUNE_EPILOGUE) != 1;  // auto = row-major (profiles/r03/mixed_epilogue_ab.txt)
   const int num_cus = device_cu_count();
   const int forced = tuning(1);  // CONCH_TUNE_MIXED_TILE_NT: 0 = auto, 2..4 = force 64 NT columns, 5 = force the 512 x 128 tile
-  int nt = p.fuse_silu ? 4 : (forced >= 2 && forced <= kMixedTall) ? forced : pick_nt(p, num_cus);
+  // CONCH_TUNE_MIXED_SPLITK: 0 = auto, 1 = never, 2 / 4 / 8 = force that many K slices (where the shape allows)
+  const int forced_split = tuning(CONCH_TUNE_MIXED_SPLITK);
+  int joint_nt = 0, joint_split = 1;
+  const bool joint = !(forced >= 2 && forced <= kMixedTall) && forced_split == 0 && pick_tile_and_split(p, num_cus, &joint_nt, &joint_split, nullptr);
+  int nt = p.fuse_silu ? 4 : (forced >= 2 && forced <= kMixedTall) ? forced : joint ? joint_nt : pick_nt(p, num_cus);
   if (p.zp_mode == CONCH_ZP_TENSOR && nt == 4 && !p.fuse_silu) nt = 3;  // a forced 4
   // a pre-packed image was laid out for one tile width; the 128-column image serves both the 256 x 128 and the 512 x 128 tile
   if (p.prepacked) nt = (p.prepacked == 2 && nt == kMixedTall) ? kMixedTall : p.prepacked;
-  // CONCH_TUNE_MIXED_SPLITK: 0 = auto, 1 = never, 2 / 4 / 8 = force that many K slices (where the shape allows)
-  const int forced_split = tuning(CONCH_TUNE_MIXED_SPLITK);
-  int split = forced_split == 0 ? pick_split(p, nt, num_cus) : forced_split;
+  int split = forced_split != 0 ? forced_split : joint ? joint_split : pick_split(p, nt, num_cus);
   const int steps = (int)(p.k / kStepK), spg = p.group_size / kStepK;
   if (p.fuse_silu || p.n % 4 || steps / std::max(split, 1) < 2) split = 1;
   if (split > 1) {

@@ -537,7 +537,10 @@ bool mixed_strip_beats_tiles(const MixedGemmArgs& p) {
   const int cus = device_cu_count();
   const int nt = pick_strip_nt(p, cus);
   const int64_t tiles = ((p.m + kSsRows - 1) / kSsRows) * ((p.n + 64 * nt - 1) / (64 * nt));
-  return tiles * 100 >= (int64_t)cus * 65;
+  if (tiles * 100 < (int64_t)cus * 65) return false;
+  // ... and the LDS-tiled kernel would not split K on this problem (1024 x 28672 x 8192: 256 x 256 tiles in two K slices take 387 us
+  // where either kernel's unsplit 256 x 128 tiles take 420-445)
+  return mixed_tiles_auto_split(p) == 1;
 }
 
 // tile width (64 nt columns) that needs the least (rounds of workgroups) x (work per workgroup): every SIMD carries nt / 4 of
