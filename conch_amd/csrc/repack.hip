@@ -64,6 +64,26 @@ __global__ __launch_bounds__(256) void fnuz_to_bf16_rows_kernel(uint16_t* __rest
   }
 }
 
+// The same for K-contiguous rows (stride 1 along K, 8-byte aligned rows, K % 8 == 0 -- every operand the MFMA contract admits):
+// eight codes per thread, one 8-byte load and one 16-byte store, both contiguous across the lanes (the transposing kernel above
+// moves one byte per lane and instruction).
+__global__ __launch_bounds__(256) void fnuz_to_bf16_vec_kernel(uint16_t* __restrict__ dst, const uint8_t* __restrict__ src, int64_t rows, int64_t k_dim,
+                                                               int64_t kp, int64_t sr, const int* __restrict__ gate) {
+  if (gated_off(gate, 1)) return;
+  // at most 2048 workgroups walk the rows: in the common case the launch is gated off, and an empty launch costs by its
+  // workgroup count (30 000 empty workgroups at C3 size took 12 us)
+  for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+    for (int64_t k = (int64_t)threadIdx.x * 8; k < kp; k += 256 * 8) {
+      i32x2 w = {0, 0};
+      if (k < k_dim) w = *(const i32x2*)(src + r * sr + k);  // K % 8 == 0: a group of eight is inside K or in the zero padding
+      u16x8 o;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = float_to_bf16_bits(decode_fp8_sw<true>((uint8_t)((uint32_t)w[i >> 2] >> (8 * (i & 3)))));
+      *(u16x8*)(dst + r * kp + k) = o;
+    }
+  }
+}
+
 bool k_major_ok(const void* ptr, int64_t stride_k, int64_t stride_row, int64_t k_dim, int64_t k_mult) {
   return stride_k == 1 && stride_row % 16 == 0 && ((uintptr_t)ptr & 15) == 0 && k_dim % k_mult == 0;
 }
@@ -179,17 +199,18 @@ int expand_fnuz_to_bf16(const ScaledGemmArgs& p, ScaledGemmArgs* q, hipStream_t 
   void* ws = nullptr;
   if (int rc = get_scratch(stream, kScratchRepack, a_bytes + b_bytes, &ws)) return rc;
   const dim3 block(256);
-  {
-    const dim3 grid((unsigned)((kp + kRpTile - 1) / kRpTile), (unsigned)((p.m + kRpTile - 1) / kRpTile));
-    hipLaunchKernelGGL(fnuz_to_bf16_rows_kernel, grid, block, 0, stream, (uint16_t*)ws, (const uint8_t*)p.a, p.m, p.k,
-                       kp, p.a_stride_m, p.a_stride_k, gate);
-  }
+  auto expand = [&](uint16_t* out, const void* src, int64_t rows, int64_t stride_row, int64_t stride_k) {
+    if (stride_k == 1 && stride_row % 8 == 0 && ((uintptr_t)src & 7) == 0 && p.k % 8 == 0) {
+      const dim3 grid((unsigned)std::min<int64_t>(rows, 2048));
+      hipLaunchKernelGGL(fnuz_to_bf16_vec_kernel, grid, block, 0, stream, out, (const uint8_t*)src, rows, p.k, kp, stride_row, gate);
+    } else {
+      const dim3 grid((unsigned)((kp + kRpTile - 1) / kRpTile), (unsigned)((rows + kRpTile - 1) / kRpTile));
+      hipLaunchKernelGGL(fnuz_to_bf16_rows_kernel, grid, block, 0, stream, out, (const uint8_t*)src, rows, p.k, kp, stride_row, stride_k, gate);
+    }
+  };
+  expand((uint16_t*)ws, p.a, p.m, p.a_stride_m, p.a_stride_k);
   uint8_t* bt = (uint8_t*)ws + a_bytes;
-  {
-    const dim3 grid((unsigned)((kp + kRpTile - 1) / kRpTile), (unsigned)((p.n + kRpTile - 1) / kRpTile));
-    hipLaunchKernelGGL(fnuz_to_bf16_rows_kernel, grid, block, 0, stream, (uint16_t*)bt, (const uint8_t*)p.b, p.n, p.k,
-                       kp, p.b_stride_n, p.b_stride_k, gate);
-  }
+  expand((uint16_t*)bt, p.b, p.n, p.b_stride_n, p.b_stride_k);
   q->a = ws;
   q->b = bt;
   q->a_stride_m = q->b_stride_n = kp * 2;  // bytes
