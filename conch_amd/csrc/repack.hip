@@ -38,6 +38,45 @@ __global__ __launch_bounds__(256) void repack_rows_kernel(uint8_t* __restrict__ 
   }
 }
 
+// The common non-native case -- row-major [K][N] weights handed over as b: element (r = n, k) at src[k * sk + r], sr == 1, 16-byte
+// aligned rows of the source -- as a 64 x 64-byte transpose with 16-byte global accesses on both sides (the generic kernel above moves
+// one byte per lane and instruction: 20 us for a 4096 x 4096 weight where this takes a third; round 4, tools/time_layouts.py).
+// Thread t loads 16 consecutive r of source row k0 + (t >> 2), then gathers 16 consecutive k of result row r0 + (t >> 2) from LDS.
+__global__ __launch_bounds__(256) void repack_transpose_vec_kernel(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, int64_t rows,
+                                                                   int64_t k_dim, int64_t kp, int64_t sk) {
+  __shared__ __attribute__((aligned(16))) uint8_t tile[kRpTile][kRpTile + 16];  // [k][r], rows 16-byte aligned
+  const int64_t k0 = (int64_t)blockIdx.x * kRpTile, r0 = (int64_t)blockIdx.y * kRpTile;
+  const int line = threadIdx.x >> 2, piece = threadIdx.x & 3;
+  {
+    const int64_t k = k0 + line, r = r0 + 16 * piece;
+    i32x4 v = {0, 0, 0, 0};
+    if (k < k_dim) {
+      if (r + 16 <= rows) {
+        v = *(const i32x4*)(src + k * sk + r);
+      } else {
+        uint8_t* b = (uint8_t*)&v;
+        for (int i = 0; i < 16; ++i)
+          if (r + i < rows) b[i] = src[k * sk + r + i];
+      }
+    }
+    // row block b = line >> 4 keeps its columns rotated by 16 b: the four lanes of a quad below read rows 16 apart and would
+    // otherwise all hit one bank group
+    *(i32x4*)&tile[line][16 * ((piece + (line >> 4)) & 3)] = v;
+  }
+  __syncthreads();
+  const int64_t r = r0 + line, k = k0 + 16 * piece;
+  if (r >= rows || k >= kp) return;  // kp % 64 == 0 (callers pad K to 128 or 1024): whole 16-byte groups
+  i32x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w |= (uint32_t)tile[16 * piece + 4 * j + i][(line + 16 * piece) & 63] << (8 * i);
+    o[j] = (int)w;
+  }
+  *(i32x4*)(dst + r * kp + k) = o;
+}
+
 // e4m3fnuz -> bf16 (every e4m3 value is exactly representable), K-contiguous, zero padded:
 // dst[r][k] (bf16, row stride kp elements) = decode_fnuz(src[r * sr + k * sk])
 __global__ __launch_bounds__(256) void fnuz_to_bf16_rows_kernel(uint16_t* __restrict__ dst, const uint8_t* __restrict__ src,
@@ -113,8 +152,11 @@ int repack_for_mfma(const ScaledGemmArgs& p, ScaledGemmArgs* q, void** scratch, 
   const dim3 block(256);
   if (copy_a) {
     const dim3 grid((unsigned)((kp + kRpTile - 1) / kRpTile), (unsigned)((p.m + kRpTile - 1) / kRpTile));
-    hipLaunchKernelGGL(repack_rows_kernel, grid, block, 0, stream, (uint8_t*)ws, (const uint8_t*)p.a, p.m, p.k, kp,
-                       p.a_stride_m, p.a_stride_k);
+    if (p.a_stride_m == 1 && p.a_stride_k % 16 == 0 && ((uintptr_t)p.a & 15) == 0)  // a transposed activation view
+      hipLaunchKernelGGL(repack_transpose_vec_kernel, grid, block, 0, stream, (uint8_t*)ws, (const uint8_t*)p.a, p.m, p.k, kp, p.a_stride_k);
+    else
+      hipLaunchKernelGGL(repack_rows_kernel, grid, block, 0, stream, (uint8_t*)ws, (const uint8_t*)p.a, p.m, p.k, kp,
+                         p.a_stride_m, p.a_stride_k);
     q->a = ws;
     q->a_stride_m = kp;
     q->a_stride_k = 1;
@@ -122,8 +164,11 @@ int repack_for_mfma(const ScaledGemmArgs& p, ScaledGemmArgs* q, void** scratch, 
   if (copy_b) {
     uint8_t* bt = (uint8_t*)ws + a_bytes;
     const dim3 grid((unsigned)((kp + kRpTile - 1) / kRpTile), (unsigned)((p.n + kRpTile - 1) / kRpTile));
-    hipLaunchKernelGGL(repack_rows_kernel, grid, block, 0, stream, bt, (const uint8_t*)p.b, p.n, p.k, kp,
-                       p.b_stride_n, p.b_stride_k);
+    if (p.b_stride_n == 1 && p.b_stride_k % 16 == 0 && ((uintptr_t)p.b & 15) == 0)  // row-major [K][N] weights
+      hipLaunchKernelGGL(repack_transpose_vec_kernel, grid, block, 0, stream, bt, (const uint8_t*)p.b, p.n, p.k, kp, p.b_stride_k);
+    else
+      hipLaunchKernelGGL(repack_rows_kernel, grid, block, 0, stream, bt, (const uint8_t*)p.b, p.n, p.k, kp,
+                         p.b_stride_n, p.b_stride_k);
     q->b = bt;
     q->b_stride_n = kp;
     q->b_stride_k = 1;

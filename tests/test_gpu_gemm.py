@@ -476,7 +476,7 @@ def test_scaled_gemm_layouts_and_edge_cases():
 
 @pytest.mark.parametrize("iname", ["int8", "fn"])
 @pytest.mark.parametrize(("m", "k", "n"), [(300, 200, 520), (96, 1000, 72), (1024, 384, 256), (130, 4096, 64)])
-@pytest.mark.parametrize("layout", ["b_row_major", "a_transposed", "misaligned_views", "odd_k_only"])
+@pytest.mark.parametrize("layout", ["b_row_major", "b_row_major_slice", "a_transposed", "misaligned_views", "odd_k_only"])
 def test_scaled_gemm_non_native_layouts_are_repacked(iname, m, k, n, layout):
     """Legal inputs outside the MFMA layout contract (row-major [K][N] weights, a transposed activation
     view, slices that start at odd byte offsets, K not a multiple of 128) are repacked on the device and
@@ -493,7 +493,11 @@ def test_scaled_gemm_non_native_layouts_are_repacked(iname, m, k, n, layout):
     bias = torch.rand((n,), dtype=torch.bfloat16)
     ref = oracle.scaled_gemm_ref(a, b, sa, sb, torch.bfloat16, bias)
     a_d, b_d = a.cuda(), b.cuda()  # both row-major: b has strides (n, 1)
-    if layout == "a_transposed":
+    if layout == "b_row_major_slice":  # the first n columns of a wider row-major tensor: 16-byte aligned rows, ragged 16-column groups
+        wide_b = torch.zeros((k, (n + 15) // 16 * 16 + 32), dtype=torch.uint8).view(dt).cuda()
+        wide_b[:, :n] = b.cuda()
+        b_d = wide_b[:, :n]
+    elif layout == "a_transposed":
         a_d = a.T.contiguous().cuda().T  # strides (1, m)
         b_d = b.T.contiguous().cuda().T  # native for b
     elif layout == "misaligned_views":
