@@ -79,7 +79,18 @@ __global__ __launch_bounds__(kDqThreads) void dequant_modes_kernel(uint16_t* __r
     if (kw >= words) return;
     const uint32_t word = (uint32_t)q.w_q[kw * q.wq_stride_k + n];
     uint16_t* dst = wt + n * ldw + kw * pf;
-    for (int e = 0; e < pf; ++e) dst[e] = dequant_one<XDT>(q, word, e, kw * pf + e, n, zs);
+    if (pf % 8 == 0 && (((uintptr_t)dst) & 15) == 0) {
+      // 16-byte stores of eight elements (1-, 2- and 4-bit weights; the per-thread rows are ldw apart whatever the store width, so
+      // fewer, wider stores are all there is to gain here): round 4, one 2-byte store per element before
+      for (int e0 = 0; e0 < pf; e0 += 8) {
+        u16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = dequant_one<XDT>(q, word, e0 + e, kw * pf + e0 + e, n, zs);
+        *(u16x8*)(dst + e0) = v;
+      }
+    } else {
+      for (int e = 0; e < pf; ++e) dst[e] = dequant_one<XDT>(q, word, e, kw * pf + e, n, zs);
+    }
   }
 }
 
