@@ -165,9 +165,38 @@ __global__ __launch_bounds__(kMidThreads, 2) void scaled_gemm_mid_kernel(ScaledG
   }
 
   if constexpr (SPLIT) {
+    int* slab = (int*)p.slabs + (int64_t)blockIdx.y * p.m * p.n;
+#ifndef CONCH_EXP_MID_SLAB_DIRECT
+    // The raw partial tile leaves in WHOLE rows: from the accumulator layout a store instruction covers 16 rows x 64 bytes -- half
+    // lines, each line written by two instructions.  A wave's 64 x 64 sub-tile goes through a private 32-row x 68-dword LDS image
+    // (the operand ring is dead by now), two halves, and every store instruction writes 4 rows x 256 contiguous bytes: 1-3 % of
+    // the op (profiles/r04/mid_slab_store_ab.txt).  The slabs cost 6-11 us of a 25-32 us op whatever their store shape (measured by
+    // leaving them out): the traffic itself, which a second kernel sees only after the L2 write-back at the kernel boundary.
+    const bool whole_cols = bn0 + wc * 64 + 64 <= (int)p.n;  // wave-uniform; ragged columns keep the direct stores below
+    __syncthreads();                                          // every wave is past its last operand read
+    if (whole_cols) {
+      int* wl = (int*)(lds + wave * (32 * 68 * 4));
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int mt2 = 0; mt2 < 2; ++mt2)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *(i32x4*)(wl + (mt2 * 16 + r) * 68 + (q >> 1) * 32 + 8 * g + 4 * (q & 1)) = __builtin_bit_cast(i32x4, acc[half * 2 + mt2][q]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int row = 4 * i + (lane >> 4), col = 4 * (lane & 15);
+          const i32x4 v = *(const i32x4*)(wl + row * 68 + col);
+          const int m = bm0 + wr * 64 + half * 32 + row;
+          if (m < p.m) *(i32x4*)(slab + (int64_t)m * p.n + bn0 + wc * 64 + col) = v;
+        }
+      }
+      return;
+    }
+#endif
     // the raw partial tile, row-major: lane (r, g) holds eight consecutive columns of row r of every (m tile, column half) --
     // 32 bytes, a 128-byte line per quad of g
-    int* slab = (int*)p.slabs + (int64_t)blockIdx.y * p.m * p.n;
 #pragma unroll
     for (int nh = 0; nh < 2; ++nh) {
       const int n0 = bn0 + wc * 64 + nh * 32 + 8 * g;
