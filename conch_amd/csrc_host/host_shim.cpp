@@ -9,6 +9,7 @@
 #include <dlfcn.h>
 
 #include <string>
+#include <vector>
 
 #include <c10/hip/HIPStream.h>
 #include <torch/csrc/Dtype.h>
@@ -22,6 +23,8 @@ typedef int (*mixed_gemm_fn)(void*, const void*, const int32_t*, const void*, co
                              int64_t, int64_t, int, int, int, int, int, int, void*);
 typedef int (*int8_quant_fn)(int8_t*, const void*, const float*, int64_t, int64_t, int64_t, int64_t, int, int, void*);
 typedef int (*fp8_quant_fn)(uint8_t*, const void*, const float*, int64_t, int64_t, int64_t, int64_t, int, int, void*);
+typedef int (*dyn_int8_fn)(int8_t*, float*, const void*, int64_t, int64_t, int64_t, int64_t, int, void*);
+typedef int (*dyn_fp8_fn)(uint8_t*, float*, const void*, int64_t, int64_t, int64_t, int64_t, int, int, void*);
 typedef int (*quant_gemm_fn)(void*, const void*, const void*, const float*, const float*, const void*, int64_t, int64_t, int64_t, int64_t, int64_t,
                              int64_t, int64_t, int64_t, int64_t, int64_t, int, int, int, void*);
 typedef const char* (*last_error_fn)();
@@ -31,6 +34,8 @@ mixed_gemm_fn g_mixed = nullptr;
 int8_quant_fn g_int8 = nullptr;
 fp8_quant_fn g_fp8 = nullptr;
 quant_gemm_fn g_quant_gemm = nullptr;
+dyn_int8_fn g_dyn_int8 = nullptr;
+dyn_fp8_fn g_dyn_fp8 = nullptr;
 last_error_fn g_last_error = nullptr;
 
 // conch_dtype_t of include/conch_amd.h
@@ -56,8 +61,10 @@ void bind_library(const std::string& path) {
   g_int8 = (int8_quant_fn)dlsym(h, "conch_static_scaled_int8_quant_typed");
   g_fp8 = (fp8_quant_fn)dlsym(h, "conch_static_scaled_fp8_quant");
   g_quant_gemm = (quant_gemm_fn)dlsym(h, "conch_static_quant_scaled_gemm");
+  g_dyn_int8 = (dyn_int8_fn)dlsym(h, "conch_dynamic_scaled_int8_quant");
+  g_dyn_fp8 = (dyn_fp8_fn)dlsym(h, "conch_dynamic_scaled_fp8_quant");
   g_last_error = (last_error_fn)dlsym(h, "conch_last_error");
-  if (!g_scaled || !g_mixed || !g_int8 || !g_fp8 || !g_quant_gemm || !g_last_error) throw std::runtime_error("conch_amd host shim: " + path + " lacks an entry point");
+  if (!g_scaled || !g_mixed || !g_int8 || !g_fp8 || !g_quant_gemm || !g_dyn_int8 || !g_dyn_fp8 || !g_last_error) throw std::runtime_error("conch_amd host shim: " + path + " lacks an entry point");
 }
 
 [[noreturn]] void raise_status(int status, const char* what) {
@@ -159,6 +166,32 @@ py::object static_quant(const at::Tensor& x, const at::Tensor& scale, int64_t ki
   return py::cast(out);
 }
 
+// dynamic per-token quantisation of a contiguous tensor (>= 1 dimension): (codes, scales of shape x.shape[:-1] + (1,)) -- what
+// ops/quantization/_static_quant.py quantize_new returns for scale=None; kind 0 = int8, 1 = e4m3fn, 2 = e4m3fnuz; None = not the plain case
+py::object dynamic_quant(const at::Tensor& x, int64_t kind) {
+  if (!x.is_cuda() || x.dim() < 1 || !x.is_contiguous() || x.numel() == 0) return py::none();
+  const c10::DeviceIndex dev = x.get_device();
+  if (dev != c10::hip::current_device()) return py::none();
+  const int xcode = dtype_code(x.scalar_type());
+  if (xcode != DT_FP32 && xcode != DT_FP16 && xcode != DT_BF16) return py::none();
+  const int64_t hidden = x.size(-1), tokens = x.numel() / hidden;
+  std::vector<int64_t> sshape(x.sizes().begin(), x.sizes().end());
+  sshape.back() = 1;
+  at::Tensor scales = at::empty(sshape, x.options().dtype(at::kFloat));
+  void* stream = (void*)c10::hip::getCurrentHIPStream(dev).stream();
+  if (kind == 0) {
+    at::Tensor out = at::empty_like(x, x.options().dtype(at::kChar));
+    const int status = g_dyn_int8((int8_t*)out.data_ptr(), (float*)scales.data_ptr(), x.data_ptr(), tokens, hidden, hidden, hidden, xcode, stream);
+    if (status) raise_status(status, "dynamic_scaled_int8_quant");
+    return py::make_tuple(out, scales);
+  }
+  const at::ScalarType odt = kind == 2 ? at::kFloat8_e4m3fnuz : at::kFloat8_e4m3fn;
+  at::Tensor out = at::empty_like(x, x.options().dtype(odt));
+  const int status = g_dyn_fp8((uint8_t*)out.data_ptr(), (float*)scales.data_ptr(), x.data_ptr(), tokens, hidden, hidden, hidden, xcode, dtype_code(odt), stream);
+  if (status) raise_status(status, "dynamic_scaled_fp8_quant");
+  return py::make_tuple(out, scales);
+}
+
 // conch_static_quant_scaled_gemm for 2-D fp16 / bf16 activations, 2-D int8 / e4m3fn weights, one float32 activation scale (not 0-dim
 // with int8 weights: that form runs the unfused pair, ops/quantization/gemm.py), contiguous float32 scale_b, contiguous bias in the
 // output dtype; None = not that case
@@ -198,4 +231,5 @@ PYBIND11_MODULE(_conch_host, mod) {
   mod.def("mixed_precision_gemm", &mixed_precision_gemm);
   mod.def("static_quant", &static_quant);
   mod.def("static_quant_scaled_gemm", &static_quant_scaled_gemm);
+  mod.def("dynamic_quant", &dynamic_quant);
 }

@@ -132,6 +132,11 @@ def static_quant_scaled_gemm(x: torch.Tensor, b: torch.Tensor, scale_x: torch.Te
     return None
 
 
+# dynamic per-token quantisation of a contiguous tensor -> (codes, scales [..., 1]) (host shim only; None without it)
+def dynamic_quant(x: torch.Tensor, kind: int) -> tuple[torch.Tensor, torch.Tensor] | None:
+    return None
+
+
 _py_scaled_gemm, _py_mixed_precision_gemm = scaled_gemm, mixed_precision_gemm
 _host = None if __import__("os").environ.get("CONCH_AMD_NO_HOST_SHIM") else _load_host_shim()
 if _host is not None:
@@ -140,3 +145,5 @@ if _host is not None:
     static_quant = _host.static_quant  # noqa: F811
     if hasattr(_host, "static_quant_scaled_gemm"):  # (a shim built before round 4's last additions lacks it)
         static_quant_scaled_gemm = _host.static_quant_scaled_gemm  # noqa: F811
+    if hasattr(_host, "dynamic_quant"):
+        dynamic_quant = _host.dynamic_quant  # noqa: F811

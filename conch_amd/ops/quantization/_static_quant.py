@@ -49,6 +49,10 @@ def quantize_new(x: torch.Tensor, scale: torch.Tensor | None, out_dtype: torch.d
         out = _fast.static_quant(x, scale, _KIND.get(out_dtype, -1))
         if out is not None:
             return out, scale
+    if scale is None and not _compile.compiling():  # dynamic per-token, the plain case through the C++ host path
+        pair = _fast.dynamic_quant(x, _KIND.get(out_dtype, -1)) if out_dtype in _KIND else None
+        if pair is not None:
+            return pair
     out = torch.empty_like(x, dtype=out_dtype)
     if scale is None:
         scales = torch.empty((*x.shape[:-1], 1), dtype=torch.float32, device=x.device)
