@@ -29,8 +29,8 @@ typedef int (*quant_gemm_fn)(void*, const void*, const void*, const float*, cons
                              int64_t, int64_t, int64_t, int64_t, int64_t, int, int, int, void*);
 typedef const char* (*last_error_fn)();
 
-scaled_gemm_fn g_scaled = nullptr;
-mixed_gemm_fn g_mixed = nullptr;
+scaled_gemm_fn g_scaled = nullptr, g_scaled_silu = nullptr, g_scaled_gelu = nullptr;
+mixed_gemm_fn g_mixed = nullptr, g_mixed_silu = nullptr, g_mixed_gelu = nullptr;
 int8_quant_fn g_int8 = nullptr;
 fp8_quant_fn g_fp8 = nullptr;
 quant_gemm_fn g_quant_gemm = nullptr;
@@ -58,12 +58,18 @@ void bind_library(const std::string& path) {
   if (!h) throw std::runtime_error(std::string("conch_amd host shim: cannot open ") + path + ": " + dlerror());
   g_scaled = (scaled_gemm_fn)dlsym(h, "conch_scaled_gemm");
   g_mixed = (mixed_gemm_fn)dlsym(h, "conch_mixed_precision_gemm");
+  // the fused gate/up FFN forms share their plain op's signature (n = the OUTPUT width, half of b's columns)
+  g_scaled_silu = (scaled_gemm_fn)dlsym(h, "conch_scaled_gemm_silu_and_mul");
+  g_scaled_gelu = (scaled_gemm_fn)dlsym(h, "conch_scaled_gemm_gelu_tanh_and_mul");
+  g_mixed_silu = (mixed_gemm_fn)dlsym(h, "conch_mixed_precision_gemm_silu_and_mul");
+  g_mixed_gelu = (mixed_gemm_fn)dlsym(h, "conch_mixed_precision_gemm_gelu_tanh_and_mul");
   g_int8 = (int8_quant_fn)dlsym(h, "conch_static_scaled_int8_quant_typed");
   g_fp8 = (fp8_quant_fn)dlsym(h, "conch_static_scaled_fp8_quant");
   g_quant_gemm = (quant_gemm_fn)dlsym(h, "conch_static_quant_scaled_gemm");
   g_dyn_int8 = (dyn_int8_fn)dlsym(h, "conch_dynamic_scaled_int8_quant");
   g_dyn_fp8 = (dyn_fp8_fn)dlsym(h, "conch_dynamic_scaled_fp8_quant");
   g_last_error = (last_error_fn)dlsym(h, "conch_last_error");
+  if (!g_scaled_silu || !g_scaled_gelu || !g_mixed_silu || !g_mixed_gelu) throw std::runtime_error("conch_amd host shim: " + path + " lacks a fused FFN entry point");
   if (!g_scaled || !g_mixed || !g_int8 || !g_fp8 || !g_quant_gemm || !g_dyn_int8 || !g_dyn_fp8 || !g_last_error) throw std::runtime_error("conch_amd host shim: " + path + " lacks an entry point");
 }
 
@@ -86,8 +92,9 @@ at::ScalarType dtype_of(const py::object& o) {
 
 // conch_scaled_gemm for 2-D a, b of one 8-bit dtype on the current device, contiguous float32 scales, contiguous bias in the output
 // dtype; None = not that case (kernels/quantization/_fast.py has the same contract in Python)
-py::object scaled_gemm(const at::Tensor& a, const at::Tensor& b, const at::Tensor& sa, const at::Tensor& sb, const py::object& out_dtype_obj,
-                       const c10::optional<at::Tensor>& bias) {
+// act: 0 = the plain op; 1 / 2 = the fused gate/up forms (silu / gelu-tanh): b, scale_b and bias have 2d columns [gate | up], the result d
+py::object scaled_gemm_act(const at::Tensor& a, const at::Tensor& b, const at::Tensor& sa, const at::Tensor& sb, const py::object& out_dtype_obj,
+                           const c10::optional<at::Tensor>& bias, int act) {
   if (!a.is_cuda()) return py::none();
   const c10::DeviceIndex dev = a.get_device();
   if (dev != c10::hip::current_device() || !on_current_device(b, dev) || !on_current_device(sa, dev) || !on_current_device(sb, dev)) return py::none();
@@ -96,22 +103,30 @@ py::object scaled_gemm(const at::Tensor& a, const at::Tensor& b, const at::Tenso
   if (code < 0 || out_code < 0 || b.scalar_type() != a.scalar_type() || sa.scalar_type() != at::kFloat || sb.scalar_type() != at::kFloat) return py::none();
   if (a.dim() != 2 || b.dim() != 2 || a.size(1) != b.size(0) || !sa.is_contiguous() || !sb.is_contiguous()) return py::none();
   const int64_t m = a.size(0), k = a.size(1), n = b.size(1);
+  if (act && (n % 2 || (out_code != DT_FP16 && out_code != DT_BF16))) return py::none();
   const void* bias_ptr = nullptr;
   if (bias.has_value()) {
     const at::Tensor& bt = *bias;
     if (bt.scalar_type() != out_dtype || !on_current_device(bt, dev) || bt.numel() != n || !bt.is_contiguous()) return py::none();
     bias_ptr = bt.data_ptr();
   }
-  at::Tensor out = at::empty({m, n}, a.options().dtype(out_dtype));
-  const int status = g_scaled(out.data_ptr(), a.data_ptr(), b.data_ptr(), (const float*)sa.data_ptr(), (const float*)sb.data_ptr(), bias_ptr, m, n, k,
-                              a.stride(0), a.stride(1), b.stride(0), b.stride(1), n, 1, sa.numel(), sb.numel(), code, out_code,
-                              (void*)c10::hip::getCurrentHIPStream(dev).stream());
-  if (status) raise_status(status, "scaled_gemm");
+  const int64_t n_out = act ? n / 2 : n;
+  at::Tensor out = at::empty({m, n_out}, a.options().dtype(out_dtype));
+  const scaled_gemm_fn fn = act == 1 ? g_scaled_silu : act == 2 ? g_scaled_gelu : g_scaled;
+  const int status = fn(out.data_ptr(), a.data_ptr(), b.data_ptr(), (const float*)sa.data_ptr(), (const float*)sb.data_ptr(), bias_ptr, m, n_out, k,
+                        a.stride(0), a.stride(1), b.stride(0), b.stride(1), n_out, 1, sa.numel(), sb.numel(), code, out_code,
+                        (void*)c10::hip::getCurrentHIPStream(dev).stream());
+  if (status) raise_status(status, act == 1 ? "scaled_gemm_silu_and_mul" : act == 2 ? "scaled_gemm_gelu_tanh_and_mul" : "scaled_gemm");
   return py::cast(out);
 }
 
-py::object mixed_precision_gemm(const at::Tensor& x, const at::Tensor& wq, const at::Tensor& ws, const c10::optional<at::Tensor>& wzp, int64_t bits,
-                                int64_t weight_bias, int64_t group_size) {
+py::object scaled_gemm(const at::Tensor& a, const at::Tensor& b, const at::Tensor& sa, const at::Tensor& sb, const py::object& out_dtype_obj,
+                       const c10::optional<at::Tensor>& bias) {
+  return scaled_gemm_act(a, b, sa, sb, out_dtype_obj, bias, 0);
+}
+
+py::object mixed_precision_gemm_act(const at::Tensor& x, const at::Tensor& wq, const at::Tensor& ws, const c10::optional<at::Tensor>& wzp, int64_t bits,
+                                    int64_t weight_bias, int64_t group_size, int act) {
   if (!x.is_cuda()) return py::none();
   const c10::DeviceIndex dev = x.get_device();
   if (dev != c10::hip::current_device() || !on_current_device(wq, dev) || !on_current_device(ws, dev)) return py::none();
@@ -133,13 +148,21 @@ py::object mixed_precision_gemm(const at::Tensor& x, const at::Tensor& wq, const
     } else return py::none();
     zp_ptr = (const int32_t*)z.data_ptr();
   }
-  at::Tensor out = at::empty({m, n}, x.options());
+  if (act && n % 2) return py::none();
+  const int64_t n_out = act ? n / 2 : n;
+  at::Tensor out = at::empty({m, n_out}, x.options());
   const int code = dtype_code(dt);
-  const int status = g_mixed(out.data_ptr(), x.data_ptr(), (const int32_t*)wq.data_ptr(), ws.data_ptr(), zp_ptr, m, n, k, x.stride(0), wq.stride(0),
-                             ws.stride(0), zp_stride, n, (int)bits, (int)weight_bias, (int)group_size, zp_mode, code, code,
-                             (void*)c10::hip::getCurrentHIPStream(dev).stream());
-  if (status) raise_status(status, "mixed_precision_gemm");
+  const mixed_gemm_fn fn = act == 1 ? g_mixed_silu : act == 2 ? g_mixed_gelu : g_mixed;
+  const int status = fn(out.data_ptr(), x.data_ptr(), (const int32_t*)wq.data_ptr(), ws.data_ptr(), zp_ptr, m, n_out, k, x.stride(0), wq.stride(0),
+                        ws.stride(0), zp_stride, n_out, (int)bits, (int)weight_bias, (int)group_size, zp_mode, code, code,
+                        (void*)c10::hip::getCurrentHIPStream(dev).stream());
+  if (status) raise_status(status, act == 1 ? "mixed_precision_gemm_silu_and_mul" : act == 2 ? "mixed_precision_gemm_gelu_tanh_and_mul" : "mixed_precision_gemm");
   return py::cast(out);
+}
+
+py::object mixed_precision_gemm(const at::Tensor& x, const at::Tensor& wq, const at::Tensor& ws, const c10::optional<at::Tensor>& wzp, int64_t bits,
+                                int64_t weight_bias, int64_t group_size) {
+  return mixed_precision_gemm_act(x, wq, ws, wzp, bits, weight_bias, group_size, 0);
 }
 
 // static per-tensor quantisation of a contiguous tensor: int8 (kind 0), e4m3fn (1), e4m3fnuz (2); None = not the plain case
@@ -232,4 +255,6 @@ PYBIND11_MODULE(_conch_host, mod) {
   mod.def("static_quant", &static_quant);
   mod.def("static_quant_scaled_gemm", &static_quant_scaled_gemm);
   mod.def("dynamic_quant", &dynamic_quant);
+  mod.def("scaled_gemm_act", &scaled_gemm_act);
+  mod.def("mixed_precision_gemm_act", &mixed_precision_gemm_act);
 }

@@ -137,6 +137,15 @@ def dynamic_quant(x: torch.Tensor, kind: int) -> tuple[torch.Tensor, torch.Tenso
     return None
 
 
+# the fused gate/up FFN forms, act 1 = silu, 2 = gelu-tanh (host shim only; None without it)
+def scaled_gemm_act(a, b, scale_a, scale_b, output_dtype, bias, act: int) -> torch.Tensor | None:
+    return None
+
+
+def mixed_precision_gemm_act(x, w_q_packed, w_s, w_zp, weight_size_bits: int, weight_bias: int, group_size: int, act: int) -> torch.Tensor | None:
+    return None
+
+
 _py_scaled_gemm, _py_mixed_precision_gemm = scaled_gemm, mixed_precision_gemm
 _host = None if __import__("os").environ.get("CONCH_AMD_NO_HOST_SHIM") else _load_host_shim()
 if _host is not None:
@@ -147,3 +156,6 @@ if _host is not None:
         static_quant_scaled_gemm = _host.static_quant_scaled_gemm  # noqa: F811
     if hasattr(_host, "dynamic_quant"):
         dynamic_quant = _host.dynamic_quant  # noqa: F811
+    if hasattr(_host, "scaled_gemm_act"):
+        scaled_gemm_act = _host.scaled_gemm_act  # noqa: F811
+        mixed_precision_gemm_act = _host.mixed_precision_gemm_act  # noqa: F811

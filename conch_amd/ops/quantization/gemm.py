@@ -73,6 +73,10 @@ def scaled_gemm_silu_and_mul(a: torch.Tensor, b: torch.Tensor, scale_a: torch.Te
     return -- never written to memory.  Same arguments as `scaled_gemm`; the reference runs the two ops
     (conch.ops.quantization.gemm.scaled_gemm, conch.ops.activation.silu_and_mul) back to back.
     """
+    if not strict and not _compile.compiling():  # the plain case through the C++ host path (kernels/quantization/_fast.py)
+        out = _fast.scaled_gemm_act(a, b, scale_a, scale_b, output_dtype, bias, 1)
+        if out is not None:
+            return out
     meta = create_scaled_metadata(a, b, scale_a, scale_b, output_dtype, strict=strict)
     out = a.new_empty((meta.m_dim, meta.n_dim // 2), dtype=output_dtype)
     scaled_gemm_silu_and_mul_launcher(out, a, b, scale_a, scale_b, meta, bias=bias)
@@ -86,6 +90,10 @@ def mixed_precision_gemm_silu_and_mul(x: torch.Tensor, w_q_packed: torch.Tensor,
 
     The packed weights, scales and zero points have 2d columns [gate | up]; the result is (M, d).
     """
+    if not strict and output_dtype is None and not _compile.compiling():  # the plain case through the C++ host path
+        out = _fast.mixed_precision_gemm_act(x, w_q_packed, w_s, w_zp, weight_size_bits, weight_bias, group_size, 1)
+        if out is not None:
+            return out
     meta = create_mixed_precision_metadata(x, w_q_packed, w_s, w_zp, weight_size_bits, weight_bias, group_size,
                                            output_dtype=output_dtype, strict=strict)
     out = x.new_empty((meta.m_dim, meta.n_dim // 2), dtype=meta.output_dtype)
@@ -98,6 +106,10 @@ def scaled_gemm_gelu_tanh_and_mul(a: torch.Tensor, b: torch.Tensor, scale_a: tor
     """gelu_tanh_and_mul(scaled_gemm(a, b, scale_a, scale_b, output_dtype, bias)) in one launch (the GeGLU FFN pair; SURVEY.md
     8(f) N3).  `b` is (K, 2d) = [gate | up]; the result is (M, d): gelu(G[:, :d], approximate="tanh") * G[:, d:].  The
     reference runs conch.ops.quantization.gemm.scaled_gemm and conch.ops.activation.gelu_tanh_and_mul back to back."""
+    if not strict and not _compile.compiling():  # the plain case through the C++ host path (kernels/quantization/_fast.py)
+        out = _fast.scaled_gemm_act(a, b, scale_a, scale_b, output_dtype, bias, 2)
+        if out is not None:
+            return out
     meta = create_scaled_metadata(a, b, scale_a, scale_b, output_dtype, strict=strict)
     out = a.new_empty((meta.m_dim, meta.n_dim // 2), dtype=output_dtype)
     scaled_gemm_gelu_tanh_and_mul_launcher(out, a, b, scale_a, scale_b, meta, bias=bias)
@@ -109,6 +121,10 @@ def mixed_precision_gemm_gelu_tanh_and_mul(x: torch.Tensor, w_q_packed: torch.Te
                                            output_dtype: torch.dtype | None = None, strict: bool = False) -> torch.Tensor:
     """gelu_tanh_and_mul(mixed_precision_gemm(x, w_q_packed, ...)) in one launch; packed weights, scales and zero points have 2d
     columns [gate | up], the result is (M, d)."""
+    if not strict and output_dtype is None and not _compile.compiling():  # the plain case through the C++ host path
+        out = _fast.mixed_precision_gemm_act(x, w_q_packed, w_s, w_zp, weight_size_bits, weight_bias, group_size, 2)
+        if out is not None:
+            return out
     meta = create_mixed_precision_metadata(x, w_q_packed, w_s, w_zp, weight_size_bits, weight_bias, group_size,
                                            output_dtype=output_dtype, strict=strict)
     out = x.new_empty((meta.m_dim, meta.n_dim // 2), dtype=meta.output_dtype)
