@@ -20,7 +20,7 @@ EPS = {torch.float16: 2.0**-10, torch.bfloat16: 2.0**-7}
 bad = 0
 for case in range(CASES):
     m = random.choice([1, 3, 16, 17, 32, 33, 48, 64, 65, 100, 128, 129, 192, 256, 257, 300, 512, 700, 1024, 1500])
-    k = random.choice([128, 256, 384, 1024, 1152, 2048, 2944, 3072, 4096, 11008])
+    k = random.choice([128, 256, 384, 1024, 1152, 2048, 2944, 3072, 4096, 8192, 11008, 13824, 28672])  # long K: the split-K forms of round 4
     n = random.choice([8, 24, 64, 100, 128, 260, 520, 1376, 2048, 4096, 4100, 11008])
     out_dt = random.choice([torch.float16, torch.bfloat16])
     torch.manual_seed(case)
