@@ -7,22 +7,31 @@ synthetic inputs that are already resident in HBM, built with the reference benc
 (benchmarks/scaled_gemm_benchmark.py:198-210).  Prints ONE JSON line on rank 0.
 
   value      effective TFLOP/s = 2*M*N*K * steps / wall time of the timed region (barrier + synchronize on both sides,
-             max over ranks): exactly `--steps` calls after `--warmup` untimed ones.
+             max over ranks): exactly `--steps` calls after `--warmup` untimed ones.  On one GPU the chip is kept under
+             the kernel's own load for SUSTAINED_S (2 s) BEFORE the warm-up steps, so the timed steps run at the clock
+             the part settles to (the MFMA-dense kernels run against the board's power limit; a cold chip is up to 4 %
+             faster for its first milliseconds).  The figure of a cold start rides along as the side field `burst`.
   roofline   dominant kernel (the MFMA GEMM): algorithmic FLOPs per launch / average launch duration measured with HIP
              events recorded on the launch stream inside the library (conch_time_*), against the dense MFMA peak of
-             /opt/skills/guides/MI355X_MICROARCH.md.  Three regimes are reported, because the chip's clock under an
-             MFMA-dense load settles over seconds and the reference's own protocol flushes the caches:
-               frac            back-to-back launches right after the short timed region ("burst")
-               frac_sustained  the same launches averaged over the second half of >= 2 s of continuous load
-                               (steady-state clock; this is the number rocprofv3 sessions reproduce)
+             /opt/skills/guides/MI355X_MICROARCH.md.
+               frac            launches averaged over the second half of >= 2 s of continuous load (steady-state clock:
+                               the number a rocprofv3 --kernel-trace --stats pass of this command reproduces)
+               frac_burst      back-to-back launches after 0.15 s of load (what rounds 1-4 reported as `frac`)
                frac_cold       the reference's benchmark protocol (conch/utils/benchmark.py:82-112 = do_bench): op-level
                                (allocation + kernel), L2 / Infinity Cache flushed before every run, median
              plus the clock the chip holds inside the K loop (`held_clock_mhz`: s_memtime / s_memrealtime stamps of the
-             diagnostic twin of the library under the same sustained load; null if the twin is not built).
+             diagnostic twin of the library under the same sustained load; null if the twin is not built), and
+               measured_peak   what THIS box sustains on THIS data in a bare MFMA loop fed from LDS (libconch_micro.so,
+                               csrc_diag/micro_peak.hip: the product kernel's per-wave tile, fragment reads and MFMAs, no
+                               global traffic, no barrier, no epilogue; LDS filled with the benchmark's operand bytes):
+                               TFLOP/s, held clock, and `frac_of_measured` = achieved / that.
              `traffic` = PMC-measured HBM bytes per launch, read from profiles/traffic.json (separate rocprofv3 --pmc
              passes; `traffic_source` names the profile and the commit it was taken at), or null.
   cpu_baseline  the CPU oracle (oracle.scaled_gemm_ref: the reference's PyTorch-only path restated)
              timed on this host on the same workload, rank 0, N=1 only.
+  c1 c2 c4 c4readme   (N = 1, workload c3) the other BASELINE configs and the reference README's mixed-GEMM shape, each
+             measured the same way in the same run: op-level `ms_per_step` / `value` after sustained load, `roofline`
+             (kernel events, sustained), `cpu_baseline` (bounded sample).  --no-side-legs leaves them out.
 
 Multi-GPU (`--gpus N` > 1; launched by torch.distributed.run, or called bare -- `python bench.py --gpus N` then starts its own
 N ranks as child processes and relays their one JSON line): the headline is BASELINE config C5 -- scaled GEMM fp8
@@ -75,8 +84,9 @@ WORKLOADS = {
     "c4decode": ("mixed_int4", 16, 4096, 11008),
     "midm": ("scaled_int8", 256, 4096, 11008),
 }
-CLOCK_RAMP_S = 0.15  # the GPU needs ~20 ms of load to leave its idle clocks; ramp before the W warm-up steps
-SUSTAINED_S = 2.0  # continuous load behind `frac_sustained`
+CLOCK_RAMP_S = 0.15  # the GPU needs ~20 ms of load to leave its idle clocks: the ramp of the `burst` side figure
+SUSTAINED_S = 2.0  # continuous load in front of the timed region and behind `roofline.frac`
+SIDE_SUSTAINED_S = 0.8  # the same for the side legs (c1, c2, c4, c4readme)
 
 
 def dist_env() -> tuple[int, int, int]:
@@ -256,13 +266,17 @@ def barrier_sync(world: int) -> None:
     torch.cuda.synchronize()
 
 
-def timed_region(fn, steps: int, warmup: int, world: int, device: torch.device) -> float:
-    """Clock ramp, W warm-up calls, then exactly `steps` calls between barrier+synchronize; max over ranks (s)."""
-    t_end = time.perf_counter() + CLOCK_RAMP_S
-    while time.perf_counter() < t_end:
-        for _ in range(20):
-            fn()
-        torch.cuda.synchronize()
+def timed_region(fn, steps: int, warmup: int, world: int, device: torch.device, ramp_s: float = CLOCK_RAMP_S, load=None) -> float:
+    """Load phase (`load()` if given -- seconds of the kernel's own launches -- else `ramp_s` of calls), W warm-up calls, then
+    exactly `steps` calls between barrier+synchronize; max over ranks (s)."""
+    if load is not None:
+        load()
+    else:
+        t_end = time.perf_counter() + ramp_s
+        while time.perf_counter() < t_end:
+            for _ in range(20):
+                fn()
+            torch.cuda.synchronize()
     for _ in range(warmup):
         fn()
     barrier_sync(world)
@@ -362,51 +376,205 @@ def c5_headline(res: dict, world: int, steps: int, warmup: int, extra: dict | No
     return line
 
 
-def run_quant_bench(args, tokens: int, hidden: int, device: torch.device, world: int, rank: int) -> None:
-    """C1: static int8 quantisation of a 4096x4096 fp16 tensor (HBM-bound feeder)."""
-    from conch_amd.ops.quantization.int8 import scaled_int8_quant
+class Leg:
+    """One workload: the public op as `step`, a kernel-event timer, its algorithmic work and the roof that bounds it."""
 
-    torch.manual_seed(rank)
-    x = torch.rand(tokens, hidden, dtype=torch.float16, device=device) * 1000
-    scale = torch.tensor([2.1], dtype=torch.float32, device=device)
-    elapsed = timed_region(lambda: scaled_int8_quant(x, scale), args.steps, args.warmup, world, device)
-    bytes_alg = tokens * hidden * 3
-    # kernel-only time: events on the current stream around back-to-back launches into a reused output
-    from conch_amd.ops.quantization.int8 import static_scaled_int8_quant
+    def __init__(self, workload: str, device: torch.device, seed: int):
+        kind, m, k, n = WORKLOADS[workload]
+        self.workload, self.kind, self.m, self.k, self.n, self.device = workload, kind, m, k, n, device
+        self.micro_mode = None  # libconch_micro.so mode of the measured ceiling (MFMA-bound legs only)
+        if kind == "quant_int8":
+            from conch_amd.ops.quantization.int8 import scaled_int8_quant, static_scaled_int8_quant
 
-    out = torch.empty_like(x, dtype=torch.int8)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(100):
-        static_scaled_int8_quant(out, x, scale)
-    e1.record()
-    torch.cuda.synchronize()
-    k_ms = e0.elapsed_time(e1) / 100
-    result = {
-        "metric": "GB/s, static_scaled_int8_quant 4096x4096 fp16 (bytes = 2 in + 1 out per element)",
-        "value": round(bytes_alg * args.steps * world / elapsed / 1e9, 1), "unit": "GB/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"static_scaled_int8_quant fp16 [{tokens}x{hidden}], scale 2.1"},
-        "roofline": {"bound": "hbm", "achieved": round(bytes_alg / (k_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(bytes_alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                     "traffic": load_traffic("c1")[0], "traffic_source": load_traffic("c1")[1],
-                     "kernel_avg_ms": round(k_ms, 5), "algorithmic_bytes": bytes_alg},
-    }
-    if world == 1 and not args.no_cpu_baseline:
-        import oracle
+            torch.manual_seed(seed)
+            self.x = torch.rand(m, n, dtype=torch.float16, device=device) * 1000
+            self.scale = torch.tensor([2.1], dtype=torch.float32, device=device)
+            self.step = lambda: scaled_int8_quant(self.x, self.scale)
+            out = torch.empty_like(self.x, dtype=torch.int8)
 
-        xc, sc = x.cpu(), scale.cpu()
-        oracle.scaled_int8_quant_ref(xc, sc)
-        times = []
-        for _ in range(5):
-            t0 = time.perf_counter()
+            def timer(iters: int) -> float:  # the quantiser launches on torch's current stream: torch events see it
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(iters):
+                    static_scaled_int8_quant(out, self.x, self.scale)
+                e1.record()
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1) / iters
+
+            self.timer_for_lib = lambda lib: timer
+            self.flops, self.bytes_alg = 0.0, m * n * 3
+            self.peak, self.dtype_name = HBM_PEAK_GBS, "f32"
+            self.desc = f"static_scaled_int8_quant fp16 [{m}x{n}], scale 2.1"
+            self.hbm_bound, self.probe_blocks = True, 0
+        elif kind.startswith("scaled"):
+            self.a, self.b, self.sa, self.sb = make_scaled(kind, m, k, n, device, seed)
+            self.step = lambda: scaled_gemm(self.a, self.b, self.sa, self.sb, torch.bfloat16)
+            out = torch.empty((m, n), dtype=torch.bfloat16, device=device)
+            self.timer_for_lib = lambda lib: (lambda iters: kernel_avg_ms_scaled(self.a, self.b, self.sa, self.sb, out, iters, lib))
+            self.flops = 2.0 * m * n * k
+            self.bytes_alg = m * k + k * n + 2 * m * n + 4 * (m + n)
+            self.peak, self.dtype_name = (FP8_PEAK_TFLOPS, "fp8_e4m3fn") if kind == "scaled_fp8" else (I8_PEAK_TFLOPS, "int8")
+            self.desc = f"scaled_gemm {self.dtype_name} x {self.dtype_name} -> bf16, per-row/per-column fp32 scales, M={m} K={k} N={n}"
+            self.probe_blocks = -(-m // 256) * -(-n // 192)
+            self.micro_mode, self.micro_src = (0 if kind == "scaled_fp8" else None), self.a
+        else:
+            self.x, self.packed, self.w_s, self.w_ref, self.wt = make_mixed(m, k, n, device, seed)
+            self.step = lambda: mixed_precision_gemm(self.x, self.packed, self.w_s, None, self.wt.size_bits, self.wt.bias, 128)
+            out = torch.empty((m, n), dtype=torch.float16, device=device)
+            self.timer_for_lib = lambda lib: (lambda iters: kernel_avg_ms_mixed(self.x, self.packed, self.w_s, out, self.wt, iters, lib))
+            self.flops = 2.0 * m * n * k
+            self.bytes_alg = 2 * m * k + k * n // 2 + 2 * (k // 128) * n + 2 * m * n
+            self.peak, self.dtype_name = F16_PEAK_TFLOPS, "fp16"
+            self.desc = f"mixed_precision_gemm uint4b8(g128) x fp16 -> fp16, M={m} K={k} N={n}"
+            self.probe_blocks = -(-m // 256) * -(-n // 128)
+            self.micro_mode, self.micro_src = 1, self.x
+        if kind != "quant_int8":
+            # C2-like shapes are HBM/latency bound: report against the HBM roof instead of the MFMA roof
+            self.hbm_bound = self.flops / self.bytes_alg < self.peak * 1e12 / (HBM_PEAK_GBS * 1e9)
+        self.timer = self.timer_for_lib(None)
+
+    def rate(self, ms: float) -> float:
+        return self.bytes_alg / (ms * 1e-3) / 1e9 if self.hbm_bound else self.flops / (ms * 1e-3) / 1e12
+
+    @property
+    def roof_peak(self) -> float:
+        return HBM_PEAK_GBS if self.hbm_bound else self.peak
+
+    @property
+    def unit(self) -> str:
+        return "GB/s" if self.hbm_bound else "TFLOP/s"
+
+    def value(self, steps: int, world: int, elapsed: float) -> float:
+        """Whole-job throughput in the metric's unit: TFLOP/s for the GEMMs, GB/s for the quantiser."""
+        work = self.bytes_alg / 1e9 if self.kind == "quant_int8" else self.flops / 1e12
+        return work * steps * world / elapsed
+
+    def cpu_baseline(self) -> dict:
+        if self.kind == "quant_int8":
+            import oracle
+
+            xc, sc = self.x.cpu(), self.scale.cpu()
             oracle.scaled_int8_quant_ref(xc, sc)
-            times.append(time.perf_counter() - t0)
-        med = sorted(times)[2]
-        result["cpu_baseline"] = {"value": round(bytes_alg / med / 1e9, 2), "unit": "GB/s", "cores": torch.get_num_threads(),
-                                  "kind": "port", "sample": f"full tensor, median of 5 runs, {med * 1e3:.1f} ms each"}
-    emit(result, world, rank)
+            times = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                oracle.scaled_int8_quant_ref(xc, sc)
+                times.append(time.perf_counter() - t0)
+            med = sorted(times)[2]
+            return {"value": round(self.bytes_alg / med / 1e9, 2), "unit": "GB/s", "cores": torch.get_num_threads(), "kind": "port",
+                    "sample": f"full tensor through oracle.scaled_int8_quant_ref, median of 5 runs, {med * 1e3:.1f} ms each, host has {os.cpu_count()} logical CPUs"}
+        if self.kind.startswith("scaled"):
+            return cpu_baseline_scaled(self.kind, self.m, self.k, self.n)
+        return cpu_baseline_mixed(self.x, self.w_ref, self.m, self.k, self.n)
+
+
+_MICRO = None
+
+
+def micro_lib():
+    """libconch_micro.so (csrc_diag/micro_peak.hip): the achievable-peak loop.  None if it was not built."""
+    global _MICRO
+    if _MICRO is None:
+        from conch_amd import _build
+
+        if not _build.MICRO_LIB.exists():
+            _MICRO = False
+        else:
+            lib = ctypes.CDLL(str(_build.MICRO_LIB))
+            lib.conch_micro_mfma_peak.restype = ctypes.c_int
+            lib.conch_micro_mfma_peak.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                                  ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_float)]
+            _MICRO = lib
+    return _MICRO or None
+
+
+def measured_peak(leg: Leg, seconds: float) -> dict | None:
+    """What this box sustains on this leg's operand bytes in the bare LDS-fed MFMA loop: launches of ~4 ms for `seconds`, the
+    second half averaged (TFLOP/s and in-loop clock)."""
+    lib = micro_lib()
+    if lib is None or leg.micro_mode is None:
+        return None
+    try:
+        src = leg.micro_src.contiguous().view(torch.uint8).reshape(-1)
+        words = 1 << ((src.numel() // 4).bit_length() - 1)
+        iters = 3000 if leg.micro_mode == 0 else 3000
+        ms, fl, clk = ctypes.c_float(), ctypes.c_double(), ctypes.c_float()
+        stream = torch.cuda.current_stream().cuda_stream
+        samples = []
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds or len(samples) < 4:
+            rc = lib.conch_micro_mfma_peak(src.data_ptr(), words, leg.micro_mode, iters, stream, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(clk))
+            if rc != 0:
+                return {"error": f"conch_micro_mfma_peak returned {rc}"}
+            samples.append((time.perf_counter() - t0, fl.value / (ms.value * 1e-3) / 1e12, clk.value))
+        total = time.perf_counter() - t0
+        late = [x for x in samples if x[0] >= total / 2] or samples[-1:]
+        tf = sum(x[1] for x in late) / len(late)
+        return {"tflops": round(tf, 1), "frac_of_datasheet": round(tf / leg.peak, 4), "held_clock_mhz": round(sum(x[2] for x in late) / len(late), 1),
+                "loop": ("32 x v_mfma_f32_16x16x128_f8f6f4" if leg.micro_mode == 0 else "64 x v_mfma_f32_16x16x32_f16") +
+                        " per 12 ds_read_b128 fragment pairs, 128 x 64 per wave, 2 waves per SIMD, every CU, operands = this workload's bytes",
+                "seconds": round(total, 2), "launches": len(samples)}
+    except Exception as exc:  # noqa: BLE001 - a diagnostic must never take the headline down
+        return {"error": repr(exc)}
+
+
+def measure_leg(leg: Leg, steps: int, warmup: int, world: int, sustained_s: float, with_burst: bool, with_cold: bool, with_probe: bool,
+                with_peak: bool, with_cpu: bool) -> dict:
+    """One workload, measured: op-level timed region after `sustained_s` of the kernel's own load, kernel-level roofline
+    (sustained / burst / cold), the measured ceiling and the CPU oracle's rate."""
+    device = leg.device
+    burst = None
+    if with_burst:  # a cold chip's figure (rounds 1-4's headline protocol), taken FIRST
+        t = timed_region(leg.step, steps, warmup, world, device)
+        k_burst_ms = leg.timer(max(20, min(steps, 200)))
+        burst = {"ms_per_step": round(t / steps * 1e3, 5), "value": round(leg.value(steps, world, t), 2), "kernel_avg_ms": round(k_burst_ms, 5),
+                 "clock_ramp_s": CLOCK_RAMP_S}
+    sus: dict = {}
+
+    def load() -> None:
+        sus["ms"], sus["s"] = sustained_kernel_ms(leg.timer, sustained_s)
+
+    if sustained_s > 0:
+        elapsed = timed_region(leg.step, steps, warmup, world, device, load=load)
+    else:
+        elapsed = timed_region(leg.step, steps, warmup, world, device)
+        sus["ms"], sus["s"] = leg.timer(max(20, min(steps, 200))), 0.0
+    k_ms = sus["ms"]
+    roofline = {"bound": "hbm" if leg.hbm_bound else "mfma", "achieved": round(leg.rate(k_ms), 2), "peak": leg.roof_peak, "unit": leg.unit,
+                "frac": round(leg.rate(k_ms) / leg.roof_peak, 4)}
+    roofline["traffic"], roofline["traffic_source"] = load_traffic(leg.workload)
+    roofline["kernel_avg_ms"] = round(k_ms, 5)
+    roofline["sustained_seconds"] = round(sus["s"], 2)
+    if burst is not None:
+        roofline["kernel_burst_ms"] = burst["kernel_avg_ms"]
+        roofline["frac_burst"] = round(leg.rate(burst["kernel_avg_ms"]) / leg.roof_peak, 4)
+    if with_cold:
+        cold = cold_op_ms(leg.step)
+        roofline["op_cold_median_ms"] = round(cold["median_ms"], 5)
+        roofline["op_cold_min_ms"] = round(cold["min_ms"], 5)
+        roofline["op_cold_runs"] = cold["runs"]
+        roofline["frac_cold"] = round(leg.rate(cold["median_ms"]) / leg.roof_peak, 4)
+        roofline["cold_protocol"] = "public op (allocation + kernel), 512 MiB cache flush before every run, median (reference: conch/utils/benchmark.py:82-112)"
+    if with_probe and leg.probe_blocks:
+        clock = held_clock_mhz(leg.kind, leg.timer_for_lib, leg.probe_blocks)
+        if clock:
+            roofline.update(clock)
+    if with_peak and not leg.hbm_bound:
+        mp = measured_peak(leg, 1.5 if sustained_s >= SUSTAINED_S else 1.0)
+        if mp:
+            roofline["measured_peak"] = mp
+            if "tflops" in mp:
+                roofline["frac_of_measured"] = round(leg.rate(k_ms) / mp["tflops"], 4)
+    roofline["algorithmic_bytes"] = leg.bytes_alg
+    roofline["algorithmic_flops"] = leg.flops
+    res = {"value": round(leg.value(steps, world, elapsed), 2), "unit": "GB/s" if leg.kind == "quant_int8" else "TFLOP/s",
+           "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 5), "dtype": leg.dtype_name,
+           "config": {"workload": leg.desc}, "roofline": roofline}
+    if burst is not None:
+        res["burst"] = burst
+    if with_cpu:
+        res["cpu_baseline"] = leg.cpu_baseline()
+    return res
 
 
 def _flush_c_stdio() -> None:
@@ -457,17 +625,14 @@ def spawn_ranks(n: int, argv: list[str], script: Path | None = None) -> int:
     JSON line rank 0 prints.  This parent never touches the GPU -- no HIP call, no torch.cuda.is_available(), no exec: on this
     pool replacing a process that has initialised the GPU takes the machine down, so the launcher is a child
     (`python -m torch.distributed.run`, the command the driver itself uses for N > 1) and this process only waits for it."""
-    import socket
     import subprocess
 
-    with socket.socket() as sock:  # a free rendezvous port on the loopback
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this host driver
     env.setdefault("MASTER_ADDR", "127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), str(script or Path(__file__).resolve()), *argv]
+    # --standalone: torchrun picks a free rendezvous port itself (no bind-then-close race with another launcher on the box)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", f"--nproc-per-node={n}",
+           str(script or Path(__file__).resolve()), *argv]
     proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, check=False)  # stderr passes through
     line = None
     for raw in proc.stdout.decode("utf-8", "replace").splitlines():
@@ -497,6 +662,9 @@ def main() -> None:
     ap.add_argument("--quick", action="store_true", help="skip the sustained / cold / clock legs (PMC profiling passes)")
     ap.add_argument("--no-cold", action="store_true", help="skip the cache-flushed op-level leg")
     ap.add_argument("--no-probe", action="store_true", help="skip the diagnostic-twin clock probe (kernel-trace profiling: its kernels share names)")
+    ap.add_argument("--no-peak", action="store_true", help="skip the measured-ceiling microbenchmark (libconch_micro.so)")
+    ap.add_argument("--no-side-legs", action="store_true",
+                    help="N = 1, workload c3: leave out the c1 / c2 / c4 / c4readme side fields (rocprofv3 passes of the headline kernel)")
     ap.add_argument("--c5-base", action="store_true", help="(default now; kept for old command lines)")
     ap.add_argument("--no-c5-base", action="store_true",
                     help="N = 1, workload c3: leave out the one-GPU figure of BASELINE config C5 (the strong-scaling base of --gpus N > 1); "
@@ -505,6 +673,8 @@ def main() -> None:
                     help="with --gpus N > 1: also time the direct form of C5 (the GEMM's epilogue stores into every peer's result; side field)")
     ap.add_argument("--dp", action="store_true",
                     help="with --gpus N > 1: make the weak-scaling data-parallel C3 run the headline instead of N-sharded C5")
+    ap.add_argument("--c5-shape", default=None, metavar="M,K,N",
+                    help="dry-run aid: another (smaller) problem for the N-sharded C5 path; the line says so in config.workload")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
     ap.add_argument("--all-ranks-on-device0", action="store_true",
                     help="dry-run aid: put every rank on cuda:0 (needs --backend gloo)")
@@ -534,7 +704,8 @@ def main() -> None:
     result: dict = {}
     if args.workload == "c5" or (world > 1 and args.workload == "c3" and not args.dp):
         # multi-GPU headline (and `--workload c5` on one GPU): BASELINE config C5, strong scaling over N
-        res = nshard_c5(world, rank, device, args.steps, args.warmup, direct=args.c5_direct)
+        shape = tuple(int(v) for v in args.c5_shape.split(",")) if args.c5_shape else None
+        res = nshard_c5(world, rank, device, args.steps, args.warmup, shape=shape, direct=args.c5_direct)
         extra = {}
         if world > 1 and args.workload == "c3":
             try:  # side field: weak-scaling data parallel C3 (no collective on the data path)
@@ -548,87 +719,44 @@ def main() -> None:
         emit(c5_headline(res, world, args.steps, args.warmup, extra), world, rank)
         return
 
-    if kind == "quant_int8":
-        run_quant_bench(args, m, n, device, world, rank)
-        return
-
-    flops = 2.0 * m * n * k
-    if kind.startswith("scaled"):
-        a, b, sa, sb = make_scaled(kind, m, k, n, device, seed=rank)
-        step = lambda: scaled_gemm(a, b, sa, sb, torch.bfloat16)  # noqa: E731
-        elapsed = timed_region(step, args.steps, args.warmup, world, device)
-        out = torch.empty((m, n), dtype=torch.bfloat16, device=device)
-        timer_for_lib = lambda lib: (lambda iters: kernel_avg_ms_scaled(a, b, sa, sb, out, iters, lib))  # noqa: E731
-        peak, dtype_name = (FP8_PEAK_TFLOPS, "fp8_e4m3fn") if kind == "scaled_fp8" else (I8_PEAK_TFLOPS, "int8")
-        desc = f"scaled_gemm {dtype_name} x {dtype_name} -> bf16, per-row/per-column fp32 scales, M={m} K={k} N={n}"
-        bytes_alg = m * k + k * n + 2 * m * n + 4 * (m + n)
-        probe_blocks = -(-m // 256) * -(-n // 192)
+    full = not args.quick
+    leg = Leg(args.workload, device, seed=rank)
+    sustained_s = (SUSTAINED_S if world == 1 else 0.0) if full else 0.0
+    res = measure_leg(leg, args.steps, args.warmup, world, sustained_s, with_burst=full and world == 1,
+                      with_cold=full and not args.no_cold and leg.kind != "quant_int8", with_probe=world == 1 and full and not args.no_probe,
+                      with_peak=world == 1 and full and not args.no_peak, with_cpu=world == 1 and rank == 0 and not args.no_cpu_baseline)
+    if args.workload == "c3":
+        metric = "effective TFLOP/s + % MFMA roofline, scaled-GEMM fp8xbf16 4096x4096x11008"
+    elif leg.kind == "quant_int8":
+        metric = "GB/s, static_scaled_int8_quant 4096x4096 fp16 (bytes = 2 in + 1 out per element)"
     else:
-        x, packed, w_s, w_ref, wt = make_mixed(m, k, n, device, seed=rank)
-        step = lambda: mixed_precision_gemm(x, packed, w_s, None, wt.size_bits, wt.bias, 128)  # noqa: E731
-        elapsed = timed_region(step, args.steps, args.warmup, world, device)
-        out = torch.empty((m, n), dtype=torch.float16, device=device)
-        timer_for_lib = lambda lib: (lambda iters: kernel_avg_ms_mixed(x, packed, w_s, out, wt, iters, lib))  # noqa: E731
-        peak, dtype_name = F16_PEAK_TFLOPS, "fp16"
-        desc = f"mixed_precision_gemm uint4b8(g128) x fp16 -> fp16, M={m} K={k} N={n}"
-        bytes_alg = 2 * m * k + k * n // 2 + 2 * (k // 128) * n + 2 * m * n
-        probe_blocks = -(-m // 256) * -(-n // 128)
-    timer = timer_for_lib(None)
-    k_ms = timer(max(20, min(args.steps, 200)))  # burst: right behind the short timed region
-    k_sus_ms, sus_s = sustained_kernel_ms(timer) if not args.quick else (k_ms, 0.0)
-    cold = cold_op_ms(step) if not (args.quick or args.no_cold) else None
-
-    # C2-like shapes are HBM/latency bound: report against the HBM roof instead of the MFMA roof
-    ai = flops / bytes_alg
-    hbm_bound = ai < peak * 1e12 / (HBM_PEAK_GBS * 1e9)
-
-    def rate(ms: float) -> float:
-        return bytes_alg / (ms * 1e-3) / 1e9 if hbm_bound else flops / (ms * 1e-3) / 1e12
-
-    roof_peak = HBM_PEAK_GBS if hbm_bound else peak
-    roofline = {"bound": "hbm" if hbm_bound else "mfma", "achieved": round(rate(k_ms), 2), "peak": roof_peak,
-                "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": round(rate(k_ms) / roof_peak, 4)}
-    roofline["traffic"], roofline["traffic_source"] = load_traffic(args.workload)
-    roofline["kernel_avg_ms"] = round(k_ms, 5)
-    roofline["kernel_sustained_ms"] = round(k_sus_ms, 5)
-    roofline["achieved_sustained"] = round(rate(k_sus_ms), 2)
-    roofline["frac_sustained"] = round(rate(k_sus_ms) / roof_peak, 4)
-    roofline["sustained_seconds"] = round(sus_s, 2)
-    if cold is not None:
-        roofline["op_cold_median_ms"] = round(cold["median_ms"], 5)
-        roofline["op_cold_min_ms"] = round(cold["min_ms"], 5)
-        roofline["op_cold_runs"] = cold["runs"]
-        roofline["frac_cold"] = round(rate(cold["median_ms"]) / roof_peak, 4)
-        roofline["cold_protocol"] = "public op (allocation + kernel), 512 MiB cache flush before every run, median (reference: conch/utils/benchmark.py:82-112)"
-    if world == 1 and not (args.quick or args.no_probe):
-        clock = held_clock_mhz(kind, timer_for_lib, probe_blocks)
-        if clock:
-            roofline.update(clock)
-    roofline["algorithmic_bytes"] = bytes_alg
-    roofline["algorithmic_flops"] = flops
-
+        metric = f"effective TFLOP/s, {leg.desc}"
     result = {
-        "metric": "effective TFLOP/s + % MFMA roofline, scaled-GEMM fp8xbf16 4096x4096x11008"
-        if args.workload == "c3" else f"effective TFLOP/s, {desc}",
-        "value": round(flops * args.steps * world / elapsed / 1e12, 2),
-        "unit": "TFLOP/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 5),
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": dtype_name,
+        "metric": metric, "value": res["value"], "unit": res["unit"], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": leg.dtype_name,
         "data": "synthetic",
         "config": {
-            "workload": desc,
+            "workload": leg.desc,
             "parallelism": "single GPU" if world == 1 else f"dp{world} over tokens (M={m} per rank, weights replicated)",
             "gemm_variant": "auto",
-            "clock_ramp_s": CLOCK_RAMP_S,
+            "load_before_timed_region_s": sustained_s if sustained_s else CLOCK_RAMP_S,
         },
-        "roofline": roofline,
+        "roofline": res["roofline"],
     }
+    if "burst" in res:
+        result["burst"] = res["burst"]
+    if world == 1 and args.workload == "c3" and full and not args.no_side_legs:
+        # the other BASELINE configs and the README comparator, driver-timed in the same run
+        del leg
+        for name in ("c1", "c2", "c4", "c4readme"):
+            try:
+                side = Leg(name, device, seed=0)
+                result[name] = measure_leg(side, 50, 10, 1, SIDE_SUSTAINED_S, with_burst=False, with_cold=False, with_probe=False,
+                                           with_peak=not args.no_peak and name == "c4", with_cpu=not args.no_cpu_baseline)
+                del side
+            except Exception as exc:  # noqa: BLE001 -- a side field must not take the headline down
+                result[name] = {"error": repr(exc)}
+            torch.cuda.empty_cache()
     if world == 1 and args.workload == "c3" and not (args.no_c5_base or args.quick):
         # The strong-scaling base of the multi-GPU lines: `--gpus N` (N > 1) reports BASELINE config C5 (a different metric than
         # this line's C3), so its one-GPU figure rides along on EVERY N = 1 line and strong-scaling efficiency is computable from
@@ -642,11 +770,8 @@ def main() -> None:
                                     "ms_per_step": r5["ms_gemm_plus_allgather_rowmajor"], "steps": 10, "warmup": 3}
         except Exception as exc:  # noqa: BLE001 -- a side field must not take the headline down
             result["c5_one_gpu"] = {"error": repr(exc)}
-    if world == 1 and rank == 0 and not args.no_cpu_baseline:
-        if kind.startswith("scaled"):
-            result["cpu_baseline"] = cpu_baseline_scaled(kind, m, k, n)
-        else:
-            result["cpu_baseline"] = cpu_baseline_mixed(x, w_ref, m, k, n)
+    if "cpu_baseline" in res:
+        result["cpu_baseline"] = res["cpu_baseline"]
     emit(result, world, rank)
 
 

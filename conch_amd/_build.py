@@ -89,6 +89,22 @@ def build(force: bool = False, verbose: bool = False, probe: bool = False, varia
     return lib
 
 
+MICRO_LIB = PKG / "libconch_micro.so"
+
+
+def build_micro(force: bool = False, verbose: bool = False) -> Path:
+    """libconch_micro.so: the achievable-peak microbenchmark bench.py reports beside the datasheet peak
+    (csrc_diag/micro_peak.hip; a measurement helper, never on a product path)."""
+    src = PKG / "csrc_diag" / "micro_peak.hip"
+    if force or _stale(MICRO_LIB, [src, Path(__file__)]):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", str(src), "-o", str(MICRO_LIB)]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        with _COMPILE_SLOTS:
+            subprocess.run(cmd, check=True)
+    return MICRO_LIB
+
+
 HOST_SHIM = PKG / "_conch_host.so"
 
 
@@ -101,12 +117,16 @@ def build_host_shim(force: bool = False, verbose: bool = False) -> Path:
     from torch.utils import cpp_extension as ce
 
     src = PKG / "csrc_host" / "host_shim.cpp"
-    if not (force or _stale(HOST_SHIM, [src, Path(__file__)])):
-        return HOST_SHIM
-    inc = [*ce.include_paths(), pybind11.get_include(), sysconfig.get_paths()["include"], "/opt/rocm/include"]
-    libdir = ce.library_paths()[0]
     import torch
 
+    # stale when the shim's source, the C ABI it is typed from, the library it binds or the torch it links changed
+    deps = [src, Path(__file__), ROOT / "include" / "conch_amd.h", Path(torch.__file__)]
+    if LIB.exists():
+        deps.append(LIB)
+    if not (force or _stale(HOST_SHIM, deps)):
+        return HOST_SHIM
+    inc = [str(ROOT / "include"), *ce.include_paths(), pybind11.get_include(), sysconfig.get_paths()["include"], "/opt/rocm/include"]
+    libdir = ce.library_paths()[0]
     cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-DUSE_ROCM",
            "-DTORCH_EXTENSION_NAME=_conch_host", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", str(src), "-o", str(HOST_SHIM),
            *[f"-I{i}" for i in inc], f"-L{libdir}", "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-ltorch_hip", "-ltorch_python",
@@ -131,3 +151,4 @@ if __name__ == "__main__":
     if "--probe" not in sys.argv:
         print(build(force="--force" in sys.argv, verbose=True, probe=False))
         print(build_host_shim(force="--force" in sys.argv, verbose=True))
+        print(build_micro(force="--force" in sys.argv, verbose=True))

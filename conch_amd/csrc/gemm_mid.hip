@@ -304,8 +304,13 @@ int mid_split_slices(const ScaledGemmArgs& p) {
   return (int)((steps + per - 1) / per);  // no empty slice
 }
 
-// upper bound of the slabs the split-K form may ask for on an m x n result (auto rule: at most 0.7 of a chip of tiles, 8 slices)
+// upper bound of the slabs the split-K form may ask for on an m x n result (auto rule: at most 0.7 of a chip of tiles, 8 slices;
+// a FORCED slice count -- CONCH_TUNE_MID_SPLITK >= 2 -- bypasses the tile rule in mid_split_slices, so it does here too: a caller
+// that sized its scratch by this query and then captures a graph with the forced split must not run out)
 int64_t mid_split_slab_bytes(int64_t m, int64_t n) {
+  const int forced = tuning(CONCH_TUNE_MID_SPLITK);
+  if (forced == 1) return 0;
+  if (forced >= 2) return (int64_t)std::min(forced, 8) * m * n * 4;
   const int64_t tiles = ((m + kMidTile - 1) / kMidTile) * ((n + kMidTile - 1) / kMidTile);
   return tiles * 10 > (int64_t)device_cu_count() * 7 ? 0 : 8 * m * n * 4;
 }

@@ -9,25 +9,33 @@
 #include <dlfcn.h>
 
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include <c10/hip/HIPStream.h>
 #include <torch/csrc/Dtype.h>
 #include <torch/extension.h>
 
+#include "conch_amd.h"
+
 namespace {
 
-typedef int (*scaled_gemm_fn)(void*, const void*, const void*, const float*, const float*, const void*, int64_t, int64_t, int64_t, int64_t, int64_t,
-                              int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int, int, void*);
-typedef int (*mixed_gemm_fn)(void*, const void*, const int32_t*, const void*, const int32_t*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t,
-                             int64_t, int64_t, int, int, int, int, int, int, void*);
-typedef int (*int8_quant_fn)(int8_t*, const void*, const float*, int64_t, int64_t, int64_t, int64_t, int, int, void*);
-typedef int (*fp8_quant_fn)(uint8_t*, const void*, const float*, int64_t, int64_t, int64_t, int64_t, int, int, void*);
-typedef int (*dyn_int8_fn)(int8_t*, float*, const void*, int64_t, int64_t, int64_t, int64_t, int, void*);
-typedef int (*dyn_fp8_fn)(uint8_t*, float*, const void*, int64_t, int64_t, int64_t, int64_t, int, int, void*);
-typedef int (*quant_gemm_fn)(void*, const void*, const void*, const float*, const float*, const void*, int64_t, int64_t, int64_t, int64_t, int64_t,
-                             int64_t, int64_t, int64_t, int64_t, int64_t, int, int, int, void*);
-typedef const char* (*last_error_fn)();
+// The entry points are typed FROM the header (decltype), so a changed signature in include/conch_amd.h fails to compile here instead of
+// calling through a mismatched function pointer; bind_library also compares conch_abi_version() with the header's number.
+typedef decltype(&conch_scaled_gemm) scaled_gemm_fn;                      // also the two fused gate/up forms (same signature)
+typedef decltype(&conch_mixed_precision_gemm) mixed_gemm_fn;              // ditto
+typedef decltype(&conch_static_scaled_int8_quant_typed) int8_quant_fn;
+typedef decltype(&conch_static_scaled_fp8_quant) fp8_quant_fn;
+typedef decltype(&conch_dynamic_scaled_int8_quant) dyn_int8_fn;
+typedef decltype(&conch_dynamic_scaled_fp8_quant) dyn_fp8_fn;
+typedef decltype(&conch_static_quant_scaled_gemm) quant_gemm_fn;
+typedef decltype(&conch_last_error) last_error_fn;
+typedef decltype(&conch_abi_version) abi_version_fn;
+static_assert(std::is_same<decltype(&conch_scaled_gemm_silu_and_mul), scaled_gemm_fn>::value && std::is_same<decltype(&conch_scaled_gemm_gelu_tanh_and_mul), scaled_gemm_fn>::value,
+              "the fused scaled forms share conch_scaled_gemm's signature");
+static_assert(std::is_same<decltype(&conch_mixed_precision_gemm_silu_and_mul), mixed_gemm_fn>::value &&
+                  std::is_same<decltype(&conch_mixed_precision_gemm_gelu_tanh_and_mul), mixed_gemm_fn>::value,
+              "the fused mixed forms share conch_mixed_precision_gemm's signature");
 
 scaled_gemm_fn g_scaled = nullptr, g_scaled_silu = nullptr, g_scaled_gelu = nullptr;
 mixed_gemm_fn g_mixed = nullptr, g_mixed_silu = nullptr, g_mixed_gelu = nullptr;
@@ -56,6 +64,10 @@ int dtype_code(at::ScalarType t) {
 void bind_library(const std::string& path) {
   void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);  // already loaded by ctypes: the same handle, the same library state
   if (!h) throw std::runtime_error(std::string("conch_amd host shim: cannot open ") + path + ": " + dlerror());
+  const abi_version_fn abi = (abi_version_fn)dlsym(h, "conch_abi_version");
+  if (!abi || abi() != CONCH_AMD_ABI_VERSION)
+    throw std::runtime_error("conch_amd host shim: " + path + " reports ABI version " + (abi ? std::to_string(abi()) : std::string("(none)")) +
+                             ", this shim was compiled against " + std::to_string(CONCH_AMD_ABI_VERSION) + " (rebuild: python -m conch_amd._build)");
   g_scaled = (scaled_gemm_fn)dlsym(h, "conch_scaled_gemm");
   g_mixed = (mixed_gemm_fn)dlsym(h, "conch_mixed_precision_gemm");
   // the fused gate/up FFN forms share their plain op's signature (n = the OUTPUT width, half of b's columns)
@@ -167,6 +179,7 @@ py::object mixed_precision_gemm(const at::Tensor& x, const at::Tensor& wq, const
 
 // static per-tensor quantisation of a contiguous tensor: int8 (kind 0), e4m3fn (1), e4m3fnuz (2); None = not the plain case
 py::object static_quant(const at::Tensor& x, const at::Tensor& scale, int64_t kind) {
+  if (kind < 0 || kind > 2) return py::none();  // an output dtype this path does not know: the general path raises the proper error
   if (!x.is_cuda() || x.dim() < 1 || !x.is_contiguous()) return py::none();
   const c10::DeviceIndex dev = x.get_device();
   if (dev != c10::hip::current_device() || !on_current_device(scale, dev) || scale.scalar_type() != at::kFloat || scale.numel() != 1) return py::none();
@@ -192,6 +205,7 @@ py::object static_quant(const at::Tensor& x, const at::Tensor& scale, int64_t ki
 // dynamic per-token quantisation of a contiguous tensor (>= 1 dimension): (codes, scales of shape x.shape[:-1] + (1,)) -- what
 // ops/quantization/_static_quant.py quantize_new returns for scale=None; kind 0 = int8, 1 = e4m3fn, 2 = e4m3fnuz; None = not the plain case
 py::object dynamic_quant(const at::Tensor& x, int64_t kind) {
+  if (kind < 0 || kind > 2) return py::none();
   if (!x.is_cuda() || x.dim() < 1 || !x.is_contiguous() || x.numel() == 0) return py::none();
   const c10::DeviceIndex dev = x.get_device();
   if (dev != c10::hip::current_device()) return py::none();

@@ -104,9 +104,59 @@ def ipc_results(m: int, n: int, dtype: torch.dtype, device: torch.device, group=
     return results, barrier
 
 
-def default_panels(m: int, n_local: int, tile: int = 256, cus: int = 256) -> int:
+def device_cus(device=None) -> int:
+    """Compute units of `device` (256 on MI355X); 256 where there is no GPU to ask (CPU dry runs of the layout logic)."""
+    try:
+        if torch.cuda.is_available():
+            return int(torch.cuda.get_device_properties(device).multi_processor_count)
+    except Exception:  # noqa: BLE001, S110 -- a heuristic's input, never a reason to fail
+        pass
+    return 256
+
+
+def direct_results(m: int, n: int, dtype: torch.dtype, device: torch.device, group=None, scheme: str | None = None):
+    """(results, barrier, scheme name) of direct mode.  EXPERIMENTAL: has only met two ranks on one device, never xGMI.
+
+    `scheme` (or $CONCH_AMD_DIRECT_SCHEME): "symmetric" = torch symmetric memory (device-side barrier), "ipc" = plain HIP IPC
+    handles with a host barrier, None / "auto" = symmetric memory where EVERY rank can have it, else IPC.  Both constructors are
+    collective, so the choice is made collectively: each rank reports whether symmetric memory is possible for it (the module is
+    there and no two ranks share a device -- the allocator refuses that, and a refusal INSIDE its rendezvous would leave the ranks
+    on different collective sequences), the flags are reduced with MIN, and all ranks take the same branch.  A failure inside the
+    chosen constructor is raised, never papered over; the scheme in use is logged once per process."""
+    import logging
+    import os
+
+    scheme = (scheme or os.environ.get("CONCH_AMD_DIRECT_SCHEME") or "auto").lower()
+    if scheme not in ("auto", "symmetric", "ipc"):
+        raise ValueError(f"direct mode: unknown scheme {scheme!r} (want auto, symmetric or ipc)")
+    if scheme == "auto":
+        world = dist.get_world_size(group)
+        try:
+            import torch.distributed._symmetric_memory  # noqa: F401
+
+            can = 1
+        except ImportError:
+            can = 0
+        mine = (device.index if device.index is not None else torch.cuda.current_device()) if device.type == "cuda" else -1
+        seen = [None] * world
+        dist.all_gather_object(seen, (can, os.uname().nodename, mine), group=group)
+        shared_device = len({(host, idx) for _, host, idx in seen}) < world
+        scheme = "symmetric" if all(c for c, _, _ in seen) and not shared_device and device.type == "cuda" else "ipc"
+    logging.getLogger("conch_amd.distributed").warning(
+        "direct mode (experimental, unmeasured on xGMI): peer results through %s",
+        "torch symmetric memory (device-side barrier)" if scheme == "symmetric" else "HIP IPC handles + host barrier (stream.synchronize + dist.barrier per call)")
+    if scheme == "symmetric":
+        results, barrier = symmetric_results(m, n, dtype, device, group)
+    else:
+        results, barrier = ipc_results(m, n, dtype, device, group)
+    return results, barrier, scheme
+
+
+def default_panels(m: int, n_local: int, tile: int = 256, cus: int | None = None, device=None) -> int:
     """Row panels per call: as many as keep every panel's GEMM at >= ~0.85 of one full round of 256x256 tiles (a panel
-    below one round idles CUs; C5 on 8 GPUs: 32 x 14 tiles -> 2 panels of 224 tiles)."""
+    below one round idles CUs; C5 on 8 GPUs: 32 x 14 tiles -> 2 panels of 224 tiles).  `cus` defaults to the device's count."""
+    if cus is None:
+        cus = device_cus(device)
     tiles_n = -(-n_local // tile)
     tiles_m = -(-m // tile)
     best = 1
@@ -138,6 +188,7 @@ class NShardedScaledGemm:
         direct: bool = False,
         peer_results=None,
         gemm_multi_fn: Callable | None = None,
+        scheme: str | None = None,
     ) -> None:
         self.group = group
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -154,7 +205,7 @@ class NShardedScaledGemm:
         # row panels exist to overlap the gather of one panel with the GEMM of the next: with one rank there is no gather,
         # the heuristic is not consulted and an explicit `panels` only shapes gathered_panels()' view
         if panels is None:
-            panels = default_panels(m, self.n_local) if self.world_size > 1 else 1
+            panels = default_panels(m, self.n_local, device=self.device if self.device.type == "cuda" else None) if self.world_size > 1 else 1
         self.panels = panels
         if self.panels < 1 or m % self.panels:
             raise ValueError(f"M={m} is not divisible into {self.panels} panels")
@@ -169,14 +220,12 @@ class NShardedScaledGemm:
         self.direct = bool(direct) and self.world_size > 1
         self.gemm_multi_fn = gemm_multi_fn
         self._results, self._barrier = None, None
+        self.direct_scheme = "injected" if peer_results is not None else None
         if self.direct:
             if peer_results is not None:
                 self._results, self._barrier = peer_results
             else:
-                try:
-                    self._results, self._barrier = symmetric_results(m, n, output_dtype, self.device, group)
-                except Exception:  # noqa: BLE001 -- no symmetric-memory allocator for this group (or ranks sharing a device)
-                    self._results, self._barrier = ipc_results(m, n, output_dtype, self.device, group)
+                self._results, self._barrier, self.direct_scheme = direct_results(m, n, output_dtype, self.device, group, scheme)
             if len(self._results) != g or any(tuple(t.shape) != (m, n) or t.dtype != output_dtype for t in self._results):
                 raise ValueError("direct mode: one [M, N] result of the output dtype per rank")
             self._c = self._results[self.rank]

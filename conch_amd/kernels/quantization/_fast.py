@@ -34,10 +34,21 @@ def _load_host_shim():
     build): the Python forms serve."""
     try:
         from conch_amd import _conch_host  # type: ignore[attr-defined]
+    except ImportError as exc:
+        if (_C._PKG / "_conch_host.so").exists():  # built, but not loadable (another torch build, a stale ABI): say so once
+            import warnings
 
+            warnings.warn(f"conch_amd: the C++ host shim is present but failed to import ({exc}); the Python host paths serve "
+                          "(rebuild it with `python -m conch_amd._build`)", RuntimeWarning, stacklevel=2)
+        return None
+    try:
         _C.load()
         _conch_host.bind_library(str(_C.LIB_PATH))
-    except Exception:  # noqa: BLE001 -- an optional accelerator of the HOST path; the ops themselves do not depend on it
+    except Exception as exc:  # noqa: BLE001 -- an optional accelerator of the HOST path; the ops themselves do not depend on it
+        import warnings
+
+        warnings.warn(f"conch_amd: the C++ host shim could not bind libconch_amd.so ({exc}); the Python host paths serve",
+                      RuntimeWarning, stacklevel=2)
         return None
     return _conch_host
 

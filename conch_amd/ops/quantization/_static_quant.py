@@ -41,16 +41,17 @@ def quantize_new(x: torch.Tensor, scale: torch.Tensor | None, out_dtype: torch.d
     scale[t] = absmax(x[t]) / QMAX, returned with shape x.shape[:-1] + (1,) -- for a 2-D input exactly the (M, 1) fp32
     `scale_a` of `scaled_gemm`.
     """
-    if scale is not None and _compile.compiling():  # torch.compile: one opaque custom op (see _compile.py)
+    known = out_dtype in _KIND and out_dtype in allowed_out_dtypes  # anything else: the general path below raises the proper error
+    if scale is not None and known and _compile.compiling():  # torch.compile: one opaque custom op (see _compile.py)
         if out_dtype is torch.int8:
             return torch.ops.conch_amd.static_scaled_int8_quant(x, scale), scale
         return torch.ops.conch_amd.static_scaled_fp8_quant(x, scale, out_dtype is torch.float8_e4m3fnuz), scale
-    if scale is not None:  # the plain case through the C++ host path, when it is built (kernels/quantization/_fast.py)
-        out = _fast.static_quant(x, scale, _KIND.get(out_dtype, -1))
+    if scale is not None and known:  # the plain case through the C++ host path, when it is built (kernels/quantization/_fast.py)
+        out = _fast.static_quant(x, scale, _KIND[out_dtype])
         if out is not None:
             return out, scale
     if scale is None and not _compile.compiling():  # dynamic per-token, the plain case through the C++ host path
-        pair = _fast.dynamic_quant(x, _KIND.get(out_dtype, -1)) if out_dtype in _KIND else None
+        pair = _fast.dynamic_quant(x, _KIND[out_dtype]) if known else None
         if pair is not None:
             return pair
     out = torch.empty_like(x, dtype=out_dtype)

@@ -7,6 +7,7 @@ process's allocation, the completion barriers, buffer reuse across calls."""
 
 from __future__ import annotations
 
+import json
 import os
 import re
 import socket
@@ -34,3 +35,28 @@ def test_direct_mode_two_ranks_share_one_gpu():
     # the two ranks write to one pipe: their lines may interleave without a newline between them, so count matches, not lines
     verdicts = re.findall(r"rank (\d) call (\d): direct result equals the unsharded product: (True|False)", out)
     assert sorted(verdicts) == [(str(r), str(c), "True") for r in range(2) for c in range(3)], out[-3000:]  # 2 ranks x 3 calls
+
+
+@pytest.mark.parametrize("direct", [False, True])
+def test_bench_two_ranks_on_device0(direct):
+    """`bench.py --gpus 2` end to end with both ranks on cuda:0 (gloo rendezvous; a one-GPU box has no second device): the
+    launcher's child process tree, the N-sharded GEMM, the gather + unpack path -- and with --c5-direct the epilogue-writes-to-peer
+    form over HIP IPC -- and the exchange check bench.py runs before it times anything: every rank recomputes a band of every
+    other rank's block from its seed and compares the gathered columns bit for bit."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo",
+           "--all-ranks-on-device0", "--c5-shape", "2048,1024,4096"]
+    if direct:
+        cmd.append("--c5-direct")
+    # a CHILD process tree (this interpreter has initialised the GPU: it must not exec into another program)
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, check=False)
+    assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong"
+    assert line["detail"]["exchange_check_mismatches"] == 0
+    assert line["value"] > 0
+    if direct:
+        assert "direct_error" not in line["detail"], line["detail"].get("direct_error")
+        assert line["detail"]["direct_equals_allgather_result"] is True

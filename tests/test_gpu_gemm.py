@@ -453,7 +453,7 @@ def test_scaled_gemm_golden_from_reference(golden, iname, key_tail):
     sa, sb = torch.from_numpy(g[f"sa_{key}"]), torch.from_numpy(g[f"sb_{key}"])
     bias = from_bits(g[f"bias_{key}"], DT[oname]) if key_tail.endswith("b1") else None
     got = run_scaled(a, b, sa, sb, DT[oname], bias)
-    check_scaled(got, from_bits(g[f"c_{key}"], DT[oname]).reshape(128, 128), IN_T[iname], DT[oname])
+    check_scaled(got, from_bits(g[f"c_{key}"], DT[oname]).reshape(128, 128), IN_T[iname], DT[oname], (a, b, sa, sb, bias))
 
 
 def test_scaled_gemm_layouts_and_edge_cases():
@@ -585,7 +585,7 @@ def test_scaled_gemm_c5_config_shard_invariance():
     for r0 in range(0, m, 1024):
         rows = slice(r0, r0 + 1024)
         ref = oracle.scaled_gemm_ref(a_h[rows], b_h, sa_h[rows], sb_h, torch.bfloat16, None)
-        check_scaled(full_h[rows], ref, torch.float8_e4m3fn, torch.bfloat16)
+        check_scaled(full_h[rows], ref, torch.float8_e4m3fn, torch.bfloat16, (a_h[rows], b_h, sa_h[rows], sb_h, None))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -732,6 +732,25 @@ def check_mixed(got, a, w_ref, k):
     torch.testing.assert_close(g, ref, rtol=1e-1, atol=atol)  # the reference's own bar
 
 
+def check_mixed_whole(got, a, w_ref, k, block=1024):
+    """EVERY element of `got` against the fp64 product of the reference's own operands, a.double() @ w_ref.double() (w_ref =
+    quantize_weights' dequantised weights, conch/third_party/vllm/quant_utils.py:74: the tensor tests/mixed_precision_gemm_test.py:70
+    multiplies), with check_mixed's per-element bound: one rounding of the exact value to the output dtype plus the worst-case fp32
+    accumulation-order error of that element's own products.  The half-precision CPU matmul of the oracle is minutes at these
+    sizes (it stays on bands of rows); the fp64 product is seconds -- in blocks of rows to bound the host memory."""
+    eps = EPS[got.dtype]
+    g = got.float().cpu()
+    wd = w_ref.double()
+    wabs = wd.abs()
+    worst = -1e30
+    for r0 in range(0, a.shape[0], block):
+        ad = a[r0:r0 + block].double()
+        exact = ad @ wd
+        bound = eps * exact.abs() + (k * 2.0**-24) * (ad.abs() @ wabs) + 1e-30
+        worst = max(worst, ((g[r0:r0 + block].double() - exact).abs() - bound).max().item())
+    assert worst <= 0, f"per-element bound exceeded by {worst:.4g}"
+
+
 @pytest.mark.parametrize(("m", "k", "n"), SHAPES)
 @pytest.mark.parametrize("wname", list(WTYPES))
 @pytest.mark.parametrize("use_zp", [True, False])
@@ -746,6 +765,7 @@ def test_mixed_precision_gemm_matrix(m, k, n, wname, use_zp, dname):
         # half-precision matmul on the CPU is very slow (minutes for 4096 rows): check three bands of rows
         rows = torch.cat([torch.arange(0, 64), torch.arange(m // 2 - 32, m // 2 + 32), torch.arange(m - 64, m)])
         check_mixed(got[rows.cuda()], a[rows], w_ref, k)
+        check_mixed_whole(got, a, w_ref, k)  # ... and every element against the fp64 product
     else:
         check_mixed(got, a, w_ref, k)
 
@@ -813,6 +833,7 @@ def test_mixed_precision_c4_config_properties():
     got = mixed_precision_gemm(a_d, p_d, s_d, None, wt.size_bits, wt.bias, 128)
     rows = torch.cat([torch.arange(0, 64), torch.arange(480, 544), torch.arange(960, 1024)])
     check_mixed(got[rows.cuda()], a[rows], w_ref, k)
+    check_mixed_whole(got, a, w_ref, k)  # (1b) every element against the fp64 product of the reference's operands
     _C.set_gemm_variant(_C.VARIANT_GENERIC)
     slow = mixed_precision_gemm(a_d, p_d, s_d, None, wt.size_bits, wt.bias, 128)
     _C.set_gemm_variant(_C.VARIANT_AUTO)
@@ -837,6 +858,36 @@ def test_mixed_precision_c4_config_properties():
         assert (auto.float() - part.float()).abs().max().item() <= 2.0 * EPS[torch.float16] * part.float().abs().max().item()
 
 
+def test_mixed_precision_readme_shape():
+    """The shape behind the reference's ONLY published mixed-GEMM number (README.md:70, 1.656 ms on H100 for Conch's Triton
+    kernel): the benchmark's defaults M = 4096, K = 8192, N = 4096, fp16 x uint4b8, group 128, no zero points
+    (benchmarks/mixed_precision_gemm_benchmark.py:82-110, 187), inputs by its recipe (:205-214).  Bands of rows against the
+    oracle (torch.matmul(a, w_ref) in fp16), every element against the fp64 product, and the two kernels that can serve the shape
+    (LDS-tiled: the automatic choice at N = 4096; column-strip) against each other bit for bit."""
+    m, k, n = 4096, 8192, 4096
+    wt = scalar_types.uint4b8
+    a, w_ref, packed, w_s, _ = make_mixed_inputs(m, k, n, wt, False, torch.float16)
+    args = (a.cuda(), packed.cuda(), w_s.cuda(), None, wt.size_bits, wt.bias, 128)
+    got = mixed_precision_gemm(*args)
+    assert got.shape == (m, n) and got.dtype == torch.float16
+    rows = torch.cat([torch.arange(0, 32), torch.arange(2032, 2064), torch.arange(4064, 4096)])
+    check_mixed(got[rows.cuda()], a[rows], w_ref, k)
+    check_mixed_whole(got, a, w_ref, k)
+    try:
+        _C.set_gemm_variant(_C.VARIANT_MFMA_PINGPONG2)
+        _C.set_tuning(_C.TUNE_MIXED_SPLITK, 1)
+        _C.set_tuning(_C.TUNE_MIXED_KERNEL, 1)
+        tiled = mixed_precision_gemm(*args)
+        _C.set_tuning(_C.TUNE_MIXED_KERNEL, 2)
+        strip = mixed_precision_gemm(*args)
+    finally:
+        _C.set_tuning(_C.TUNE_MIXED_KERNEL, 0)
+        _C.set_tuning(_C.TUNE_MIXED_SPLITK, 0)
+        _C.set_gemm_variant(_C.VARIANT_AUTO)
+    assert torch.equal(tiled, strip)
+    assert torch.equal(got, tiled) or torch.equal(got, strip)
+
+
 @pytest.mark.parametrize(("wname", "use_zp", "dname"), [("uint4", True, "bf16"), ("uint8b128", False, "f16"), ("uint8", True, "bf16"),
                                                          ("uint4b8", False, "bf16"), ("uint4", True, "f16")])
 def test_mixed_precision_c4_size_other_weight_types(wname, use_zp, dname):
@@ -849,6 +900,7 @@ def test_mixed_precision_c4_size_other_weight_types(wname, use_zp, dname):
     got = mixed_precision_gemm(*args)
     rows = torch.cat([torch.arange(0, 32), torch.arange(500, 532), torch.arange(992, 1024)])
     check_mixed(got[rows.cuda()], a[rows], w_ref, k)
+    check_mixed_whole(got, a, w_ref, k)
     _C.set_gemm_variant(_C.VARIANT_GENERIC)
     slow = mixed_precision_gemm(*args)
     _C.set_gemm_variant(_C.VARIANT_AUTO)

@@ -341,3 +341,32 @@ def test_host_shim_builds_loads_and_declines_what_it_does_not_take():
     assert host.static_quant(torch.rand(4, 16), s, 0) is None
     x = torch.rand(4, 128, dtype=torch.float16)
     assert host.mixed_precision_gemm(x, torch.zeros(16, 8, dtype=torch.int32), torch.ones(1, 8, dtype=torch.float16), None, 4, 8, 128) is None
+
+
+def test_install_as_conch_aliases_the_reference_import_paths():
+    """`conch_amd.install_as_conch()`: the import lines of the reference's tests (tests/scaled_gemm_test.py:11,
+    mixed_precision_gemm_test.py:12, int8_quant_kernels_test.py:11, fp8_quant_kernels_test.py:11) resolve to this package.
+    Run in a child interpreter so that the aliases do not leak into this session."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import conch_amd\n"
+        "names = conch_amd.install_as_conch()\n"
+        "from conch.ops.quantization.gemm import scaled_gemm, mixed_precision_gemm\n"
+        "from conch.ops.quantization.int8 import scaled_int8_quant\n"
+        "from conch.ops.quantization.fp8 import scaled_fp8_quant\n"
+        "from conch.third_party.vllm.quant_utils import quantize_weights, pack_rows\n"
+        "from conch.third_party.vllm.scalar_type import scalar_types\n"
+        "from conch.platforms import current_platform\n"
+        "from conch.utils.benchmark import BenchmarkMetadata, benchmark_it\n"
+        "import conch_amd.ops.quantization.gemm as g\n"
+        "assert scaled_gemm is g.scaled_gemm and mixed_precision_gemm is g.mixed_precision_gemm\n"
+        "assert 'conch' in names and 'conch.ops.quantization.gemm' in names\n"
+        "print('ok')\n" % str(root)
+    )
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, check=False)
+    assert res.returncode == 0 and res.stdout.strip().endswith("ok"), res.stdout + res.stderr
