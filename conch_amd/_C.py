@@ -23,7 +23,7 @@ ZP_NONE, ZP_SCALAR, ZP_TENSOR = range(3)
 (TUNE_GEMM_VARIANT, TUNE_MIXED_TILE_NT, TUNE_SKINNY_NO_SPLITK, TUNE_SKINNY_MODE, TUNE_TILE_SCHEDULE, TUNE_PERSISTENT, TUNE_EPILOGUE, TUNE_DIAG,
  TUNE_MID_STAGES, TUNE_MIXED_SPLITK, TUNE_SKINNY_GATHER, TUNE_MIXED_KERNEL, TUNE_MID_SPLITK, TUNE_SKINNY_CHUNKS, TUNE_COUNT) = range(15)
 (VARIANT_AUTO, VARIANT_GENERIC, VARIANT_MFMA_SIMPLE, VARIANT_MFMA_PINGPONG, VARIANT_MFMA_SKINNY,
- VARIANT_MFMA_PINGPONG2, VARIANT_MFMA_MID) = range(7)
+ VARIANT_MFMA_PINGPONG2, VARIANT_MFMA_MID, VARIANT_MFMA_ASM1W) = range(8)
 
 TORCH_TO_DT = {
     torch.float32: DT_FP32,

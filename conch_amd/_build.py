@@ -13,7 +13,7 @@ PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libconch_amd.so"
-SOURCES = ["capi.hip", "quant.hip", "quant_dynamic.hip", "gemm_generic.hip", "repack.hip", "gemm_mfma.hip", "gemm_mid.hip", "gemm_skinny.hip", "gemm_mixed.hip", "gemm_mixed_strip.hip", "gemm_mixed_skinny.hip", "gemm_modes.hip", "bnb.hip"]
+SOURCES = ["capi.hip", "gemm_asm.hip", "quant.hip", "quant_dynamic.hip", "gemm_generic.hip", "repack.hip", "gemm_mfma.hip", "gemm_mid.hip", "gemm_skinny.hip", "gemm_mixed.hip", "gemm_mixed_strip.hip", "gemm_mixed_skinny.hip", "gemm_modes.hip", "bnb.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [
     "--offload-arch=gfx950",
@@ -41,6 +41,31 @@ def _stale(target: Path, deps: list[Path]) -> bool:
 
 
 PROBE_LIB = PKG / "libconch_amd_probe.so"
+LLVM_BIN = Path(os.environ.get("CONCH_LLVM_BIN", "/opt/rocm/lib/llvm/bin"))
+ASM_GENERATORS = {"gemm1w": CSRC / "asm" / "gen_gemm1w.py"}  # name -> script that writes NAME.s (hand-allocated gfx950 assembly)
+
+
+def build_asm(objdir: Path, force: bool = False, verbose: bool = False) -> list[Path]:
+    """The hand-written assembly kernels: generator script -> NAME.s -> (clang -x assembler, gfx950) -> NAME.o -> (ld.lld
+    -shared) -> NAME.hsaco -> NAME_hsaco.inc, a comma-separated byte list that csrc/gemm_asm.hip embeds.  Returns the .inc
+    files (dependencies of that translation unit)."""
+    incs = []
+    for name, script in ASM_GENERATORS.items():
+        inc = objdir / f"{name}_hsaco.inc"
+        incs.append(inc)
+        if not (force or _stale(inc, [script, Path(__file__)])):
+            continue
+        src, obj, hsaco = objdir / f"{name}.s", objdir / f"{name}.o", objdir / f"{name}.hsaco"
+        cmds = [[sys.executable, str(script), str(src)],
+                [str(LLVM_BIN / "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", str(src), "-o", str(obj)],
+                [str(LLVM_BIN / "ld.lld"), "-shared", str(obj), "-o", str(hsaco)]]
+        for cmd in cmds:
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.run(cmd, check=True)
+        data = hsaco.read_bytes()
+        inc.write_text(",\n".join(",".join(str(b) for b in data[i:i + 32]) for i in range(0, len(data), 32)) + "\n")
+    return incs
 
 
 def build(force: bool = False, verbose: bool = False, probe: bool = False, variant: str | None = None, defines: tuple[str, ...] = (),
@@ -63,14 +88,16 @@ def build(force: bool = False, verbose: bool = False, probe: bool = False, varia
         flags = [*FLAGS, *defines]
         lib = PKG / f"libconch_amd_{variant}.so"
     objdir.mkdir(exist_ok=True)
+    asm_incs = build_asm(objdir, force=force, verbose=verbose)
 
     def compile_one(src: str) -> Path:
         s = CSRC / src
         if variant and only and src not in only:
             return PKG / "build" / (s.stem + ".o")  # the product build's object (built below if missing)
         o = objdir / (s.stem + ".o")
-        if force or _stale(o, [s, *headers]):
-            cmd = [HIPCC, *flags, "-c", str(s), "-o", str(o)]
+        deps = [s, *headers, *(asm_incs if src == "gemm_asm.hip" else [])]
+        if force or _stale(o, deps):
+            cmd = [HIPCC, *flags, f"-I{objdir}", "-c", str(s), "-o", str(o)]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             with _COMPILE_SLOTS:

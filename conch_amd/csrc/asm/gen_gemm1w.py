@@ -1,0 +1,606 @@
+#!/usr/bin/env python3
+"""Generator of the ONE-WAVE-PER-SIMD fp8 scaled-GEMM kernel for gfx950 (hand-allocated registers; writes an assembly file).
+
+Why it exists (scaled GEMM): the 256 x 256 tile of gemm_mfma.hip (eight waves, two per SIMD, 128 x 64 per wave) is
+what 256 registers per wave allow.  BASELINE config C3 (4096 x 4096 x 11008) is 688 such tiles on 256 CUs = 2.69 rounds run as
+three, with three epilogues per CU, 24 KiB of fragment reads per 32 MFMAs and 64 KiB of L2 -> LDS traffic per 64 MFMAs of a SIMD.
+With ONE wave per SIMD a wave may use all 512 registers of its SIMD (256 architectural + 256 accumulation registers), which
+hipcc cannot allocate without shuffling accumulators through v_accvgpr moves (profiles/r03/mfma_shape.txt) -- hence this file:
+
+  * tile 256 rows x 352 columns per 256-thread workgroup: four waves as 2 (m) x 2 (n), 128 x 176 per wave = 8 x 11 accumulator
+    tiles of 16 x 16 = 352 registers (tiles 0-63 in a[0:255], tiles 64-87 in v[160:255]).  C3 = 16 x 32 = 512 tiles = exactly
+    TWO rounds on 256 CUs (97.7 % of the MFMAs are useful: the last tile column is 96 of 352 columns wide);
+  * per 128-byte K step and wave: 88 MFMAs (v_mfma_f32_16x16x128_f8f6f4) on 8 + 11 fragments = 38 KiB of ds_read_b128 -- 42 %
+    fewer fragment bytes per MFMA than the 128 x 64 wave tile -- and 76 KiB staged per step and workgroup for 352 MFMAs -- 14 %
+    fewer L2 -> LDS bytes per MFMA;
+  * LDS: two stages of (256 + 352) rows x 128 bytes = 152 KiB, the library's row image (8-row x 128-byte pieces written by
+    `buffer_load_dwordx4 ... lds`, 16-byte chunks XOR-swizzled on the SOURCE side, conflict-free ds_read_b128);
+  * the wave's instruction stream is one MFMA slot after another; fragment reads, LDS-DMA issues and scalar bookkeeping sit in
+    the gaps (an MFMA occupies the matrix pipe for 32 cycles and the SIMD's issue port for 8).  A fragments (64 registers) are
+    reloaded for the NEXT step under the last n tile of this one; B fragments stream through three 8-register slots one n tile
+    ahead.  Two workgroup barriers per step: Z (after n tile 5's fragment is read: the A part and B tiles 0-5 of this stage are
+    dead -> 14 DMA pieces of step t + 2 follow) and X (after n tile 10's: the rest is dead -> 5 pieces; and everything of step
+    t + 1 has landed: `s_waitcnt vmcnt(14)` before it).  vmcnt retires in order, so the counts are exact.
+
+The kernel takes M, N, K, leading dimensions and scale vectors at run time; what is fixed: fp8 e4m3 (OCP) operands, K-contiguous
+A and B^T with 16-byte aligned rows, K a multiple of 256 bytes, bf16 or fp16 row-major C, N a multiple of 16, no bias (the
+launcher in gemm_asm.hip checks; other problems keep the HIP kernels).
+
+usage: gen_gemm1w.py OUT.s
+"""
+from __future__ import annotations
+
+import sys
+
+NT = 11                      # 16-column n tiles per wave
+MT = 8                       # 16-row m tiles per wave
+TILE_M, TILE_N = 256, 2 * 16 * NT            # 256 x 352
+A_BYTES = TILE_M * 128                       # 32 KiB of a stage
+B_WAVECOL = 16 * NT * 128                    # 22528: one wave column's rows of a stage
+STAGE = A_BYTES + 2 * B_WAVECOL              # 77824
+LDS_SA = 2 * STAGE                           # 155648: float sa[256]
+LDS_SB = LDS_SA + 1024                       # float sb[512] (352 used)
+LDS_TOTAL = LDS_SB + 2048                    # 158720
+SLOTS = MT * NT                              # 88 MFMAs per step and wave
+Z_SLOT, X_SLOT = 36, 76                      # barrier in FRONT of this slot's MFMA
+PIECES_Z, PIECES_X = 14, 5                   # LDS-DMA pieces issued behind each barrier (8 A + B tiles 0-5 | B tiles 6-10)
+
+# ---- register map ------------------------------------------------------------------------------------------------------------
+# SGPRs
+S_KARG = 0          # s[0:1]
+S_WG = 2
+S_A, S_B, S_C, S_SA = 8, 10, 12, 14          # pointers (pairs) as loaded
+S_SB = 16
+S_M, S_N, S_K, S_LDA, S_LDB, S_LDC = 18, 19, 20, 21, 22, 23
+S_TM, S_TN, S_NWG, S_MAGIC_PG, S_SHIFT_PG, S_MAGIC_LAST, S_SAVEC, S_SBVEC = 24, 25, 26, 27, 28, 29, 30, 31
+S_ACCSCALE, S_OUTDT = 32, 33
+S_T = 34            # s34..s47 temporaries
+S_WAVE, S_WR, S_WC = 48, 49, 50
+S_BM0, S_BN0 = 51, 52
+S_M0A, S_M0B = 53, 54                        # LDS-DMA destination bases of this wave's A / B pieces (stage 0)
+S_KOFF = 55                                  # K byte offset of the step whose pieces are being issued
+S_CNT = 56                                   # step pairs left
+S_NRA, S_NRB = 57, 58                        # num_records of the operand descriptors
+S_DA, S_DB, S_DC = 60, 64, 68                # buffer descriptors s[60:63], s[64:67], s[68:71]
+S_NVALID = 72                                # n tiles of this wave that start below N
+S_END = 73
+
+# VGPRs
+V_TID = 0
+V_DMA = 1           # v1..v19: per-lane source byte offsets of the wave's 8 A + 11 B pieces
+V_ALO = (20, 21)    # fragment read bases, stage 0 / 1, chunk g
+V_AHI = (22, 23)    # ... chunk g + 4
+V_BLO = (24, 25)
+V_BHI = (26, 27)
+V_T = 28            # v28..v31 temporaries of the prologue
+V_FA = 32           # v32..v95: A fragments of the 8 m tiles (8 registers each)
+V_FB = 96           # v96..v119: three B fragment slots
+V_E = 120           # v120..v159: epilogue temporaries
+V_ACC = 160         # v160..v255: accumulator tiles 64..87
+A_ACC = 0           # a0..a255: accumulator tiles 0..63
+
+
+def fb_slot(j: int) -> int:
+    return 2 if j == NT - 1 else j % 2
+
+
+def acc_reg(i: int, j: int) -> str:
+    t = 8 * j + i
+    return f"a[{4 * t}:{4 * t + 3}]" if t < 64 else f"v[{V_ACC + 4 * (t - 64)}:{V_ACC + 4 * (t - 64) + 3}]"
+
+
+class Gen:
+    def __init__(self, name: str, out_fp16: bool = False, pad_nops: int = 0):
+        self.name = name
+        self.lines: list[str] = []
+        self.lgkm: list[str] = []        # outstanding LDS reads, oldest first (tags)
+        self.out_fp16 = out_fp16
+
+    def L(self, s: str) -> str:
+        return f".L{self.name}_{s}"
+
+    # -- emission ------------------------------------------------------------------------------------------------------------
+    def e(self, s: str, comment: str = "") -> None:
+        self.lines.append(f"\t{s}" + (f"\t; {comment}" if comment else ""))
+
+    def label(self, s: str) -> None:
+        self.lines.append(f"{s}:")
+
+    def c(self, s: str) -> None:
+        self.lines.append(f"\t; {s}")
+
+    # -- LDS read tracking (lgkmcnt retires LDS operations in order) ---------------------------------------------------------
+    def ds_read128(self, dst: int, addr: int, off: int, tag: str) -> None:
+        assert 0 <= off < 65536, off
+        self.e(f"ds_read_b128 v[{dst}:{dst + 3}], v{addr} offset:{off}", tag)
+        self.lgkm.append(tag)
+
+    def wait_tags(self, tags: list[str]) -> None:
+        """s_waitcnt lgkmcnt(n) so that every read in `tags` has returned (no instruction if none is outstanding)."""
+        idx = max((i for i, t in enumerate(self.lgkm) if t in tags), default=-1)
+        if idx < 0:
+            return
+        after = len(self.lgkm) - 1 - idx
+        self.e(f"s_waitcnt lgkmcnt({min(after, 15)})")
+        self.lgkm = self.lgkm[idx + 1:] if after <= 15 else self.lgkm[len(self.lgkm) - 15:]
+
+    def wait_all_lds(self) -> None:
+        self.e("s_waitcnt lgkmcnt(0)")
+        self.lgkm = []
+
+    # -- fragments -------------------------------------------------------------------------------------------------------------
+    def read_fa(self, i: int, stage: int, step_tag: str) -> None:
+        base = V_FA + 8 * i
+        self.ds_read128(base, V_ALO[stage], 2048 * i, f"{step_tag}.A{i}.lo")
+        self.ds_read128(base + 4, V_AHI[stage], 2048 * i, f"{step_tag}.A{i}.hi")
+
+    def read_fb_half(self, j: int, stage: int, step_tag: str, half: int) -> None:
+        base = V_FB + 8 * fb_slot(j)
+        if half == 0:
+            self.ds_read128(base, V_BLO[stage], 2048 * j, f"{step_tag}.B{j}.lo")
+        else:
+            self.ds_read128(base + 4, V_BHI[stage], 2048 * j, f"{step_tag}.B{j}.hi")
+
+    # -- LDS-DMA ----------------------------------------------------------------------------------------------------------------
+    def dma_piece(self, idx: int, stage: int) -> None:
+        """Piece idx of this wave (0-7: A rows 8 (4 idx + wave) .., 8-18: B n tile idx - 8) of the step at S_KOFF into `stage`."""
+        if idx < 8:
+            self.e(f"s_add_i32 m0, s{S_M0A}, {stage * STAGE + 4096 * idx}")
+            self.e("s_nop 0")
+            self.e(f"buffer_load_dwordx4 v{V_DMA + idx}, s[{S_DA}:{S_DA + 3}], s{S_KOFF} offen lds", f"A piece {idx} -> stage {stage}")
+        else:
+            j = idx - 8
+            self.e(f"s_add_i32 m0, s{S_M0B}, {stage * STAGE + 2048 * j}")
+            self.e("s_nop 0")
+            self.e(f"buffer_load_dwordx4 v{V_DMA + idx}, s[{S_DB}:{S_DB + 3}], s{S_KOFF} offen lds", f"B tile {j} piece -> stage {stage}")
+
+    # -- one K step -----------------------------------------------------------------------------------------------------------------
+    def step(self, st: int, tag: str, nxt: str) -> None:
+        """88 MFMA slots of the step staged in `st`; `tag` / `nxt` name this step's and the next step's fragment reads."""
+        # DMA issue slots: after Z every third slot that carries no fragment read, after X every other one
+        busy = {8 * j + h for j in range(NT) for h in (0, 1)} | {78, 79} | set(range(80, 88)) | {0}
+        z_slots = [q for q in range(Z_SLOT, X_SLOT) if q not in busy][::2][:PIECES_Z]
+        assert len(z_slots) == PIECES_Z, z_slots
+        x_slots = [76, 77, 82, 84, 86]
+        dma_at = {q: k for k, q in enumerate(z_slots)}
+        dma_at.update({q: PIECES_Z + k for k, q in enumerate(x_slots)})
+        for q in range(SLOTS):
+            j, ii = divmod(q, MT)
+            i = ii if j % 2 == 0 else MT - 1 - ii
+            if q == Z_SLOT:
+                self.c("---- barrier Z: every wave has read this stage's A part and B tiles 0-5 ----")
+                self.wait_all_lds()
+                self.e("s_barrier")
+            if q == X_SLOT:
+                self.c("---- barrier X: the next stage has landed; this stage's B tiles 6-10 are dead ----")
+                self.e(f"s_waitcnt vmcnt({PIECES_Z})")
+                self.wait_all_lds()
+                self.e("s_barrier")
+            self.wait_tags([f"{tag}.A{i}.lo", f"{tag}.A{i}.hi", f"{tag}.B{j}.lo", f"{tag}.B{j}.hi"])
+            fb = V_FB + 8 * fb_slot(j)
+            fa = V_FA + 8 * i
+            acc = acc_reg(i, j)
+            self.e(f"v_mfma_f32_16x16x128_f8f6f4 {acc}, v[{fb}:{fb + 7}], v[{fa}:{fa + 7}], {acc}", f"slot {q}: m tile {i}, n tile {j}")
+            # ---- fillers behind this MFMA ----
+            if q == 0:
+                self.read_fa(7, st, tag)          # FA[7] of THIS step (its registers were busy until the previous step's last MFMA)
+            if ii in (0, 1) and j + 1 <= NT - 2:
+                self.read_fb_half(j + 1, st, tag, ii)
+            if q in (72, 73):
+                self.read_fb_half(NT - 1, st, tag, q - 72)
+            if q in (78, 79):
+                self.read_fb_half(0, 1 - st, nxt, q - 78)
+            if j == NT - 1 and ii >= 1:
+                self.read_fa(ii - 1, 1 - st, nxt)   # FA[ii - 1] was last used one slot ago
+            if q in dma_at:
+                k = dma_at[q]
+                piece = k if k < PIECES_Z else k   # order: A 0-7, B tiles 0-5 | B tiles 6-10
+                self.dma_piece(piece, st)
+            if q == 2:
+                # the step whose pieces this step issues is t + 2: past the end of K the descriptors are switched to zero
+                # records (every lane out of range: no memory traffic, zeros land in a stage nobody reads)
+                self.e(f"s_add_u32 s{S_KOFF}, s{S_KOFF}, 128")
+                self.e(f"s_cmp_lt_u32 s{S_KOFF}, s{S_K}")
+                self.e(f"s_cselect_b32 s{S_DA + 2}, s{S_NRA}, 0")
+                self.e(f"s_cselect_b32 s{S_DB + 2}, s{S_NRB}, 0")
+
+    # -- whole kernel ---------------------------------------------------------------------------------------------------------------
+    def prologue(self) -> None:
+        e = self.e
+        T = S_T
+        e(f"s_load_dwordx8 s[8:15], s[{S_KARG}:{S_KARG + 1}], 0x0")
+        e(f"s_load_dwordx8 s[16:23], s[{S_KARG}:{S_KARG + 1}], 0x20")
+        e(f"s_load_dwordx8 s[24:31], s[{S_KARG}:{S_KARG + 1}], 0x40")
+        e(f"s_load_dwordx2 s[{S_ACCSCALE}:{S_ACCSCALE + 1}], s[{S_KARG}:{S_KARG + 1}], 0x60")
+        # lane / wave
+        e(f"v_and_b32 v{V_T}, 63, v{V_TID}", "lane")
+        e(f"v_lshrrev_b32 v{V_T + 1}, 6, v{V_TID}")
+        e("s_nop 0")
+        e(f"v_readfirstlane_b32 s{S_WAVE}, v{V_T + 1}")
+        e(f"s_lshr_b32 s{S_WR}, s{S_WAVE}, 1")
+        e(f"s_and_b32 s{S_WC}, s{S_WAVE}, 1")
+        e("s_waitcnt lgkmcnt(0)")
+        # ---- tile of this workgroup: XCD-contiguous runs of a GROUP_M = 8 raster ----
+        e(f"s_and_b32 s{T}, s{S_WG}, 7", "xcd")
+        e(f"s_lshr_b32 s{T + 1}, s{S_WG}, 3", "index inside the XCD's run")
+        e(f"s_lshr_b32 s{T + 2}, s{S_NWG}, 3")
+        e(f"s_and_b32 s{T + 3}, s{S_NWG}, 7")
+        e(f"s_mul_i32 s{T + 4}, s{T}, s{T + 2}")
+        e(f"s_min_u32 s{T + 5}, s{T}, s{T + 3}")
+        e(f"s_add_u32 s{T + 4}, s{T + 4}, s{T + 5}")
+        e(f"s_add_u32 s{T + 4}, s{T + 4}, s{T + 1}", "lin")
+        e(f"s_mul_hi_u32 s{T + 5}, s{T + 4}, s{S_MAGIC_PG}", "group = lin / (8 tiles_n)")
+        e(f"s_lshl_b32 s{T + 6}, s{S_TN}, 3")
+        e(f"s_mul_i32 s{T + 7}, s{T + 5}, s{T + 6}")
+        e(f"s_sub_u32 s{T + 7}, s{T + 4}, s{T + 7}", "in_group")
+        e(f"s_lshl_b32 s{T + 8}, s{T + 5}, 3", "first_m")
+        e(f"s_sub_u32 s{T + 9}, s{S_TM}, s{T + 8}")
+        e(f"s_min_u32 s{T + 9}, s{T + 9}, 8", "group height")
+        e(f"s_cmp_eq_u32 s{T + 9}, 8")
+        e(f"s_cbranch_scc0 {self.L('partial_group')}")
+        e(f"s_lshr_b32 s{T + 10}, s{T + 7}, 3", "tn")
+        e(f"s_and_b32 s{T + 11}, s{T + 7}, 7", "tm in group")
+        e(f"s_branch {self.L('tile_done')}")
+        self.label(self.L("partial_group"))
+        e(f"s_mul_hi_u32 s{T + 10}, s{T + 7}, s{S_MAGIC_LAST}")
+        e(f"s_mul_i32 s{T + 11}, s{T + 10}, s{T + 9}")
+        e(f"s_sub_u32 s{T + 11}, s{T + 7}, s{T + 11}")
+        self.label(self.L("tile_done"))
+        e(f"s_add_u32 s{T + 11}, s{T + 11}, s{T + 8}", "tm")
+        e(f"s_lshl_b32 s{S_BM0}, s{T + 11}, 8")
+        e(f"s_mul_i32 s{S_BN0}, s{T + 10}, {TILE_N}")
+        # ---- descriptors ----
+        e(f"s_sub_u32 s{T}, s{S_M}, 1")
+        e(f"s_mul_i32 s{T}, s{T}, s{S_LDA}")
+        e(f"s_add_u32 s{S_NRA}, s{T}, s{S_K}", "A bytes")
+        e(f"s_sub_u32 s{T}, s{S_N}, 1")
+        e(f"s_mul_i32 s{T}, s{T}, s{S_LDB}")
+        e(f"s_add_u32 s{S_NRB}, s{T}, s{S_K}", "B bytes")
+        e(f"s_sub_u32 s{T}, s{S_M}, 1")
+        e(f"s_mul_i32 s{T}, s{T}, s{S_LDC}")
+        e(f"s_add_u32 s{T}, s{T}, s{S_N}")
+        e(f"s_lshl_b32 s{T}, s{T}, 1", "C bytes")
+        for d, p, nr in ((S_DA, S_A, f"s{S_NRA}"), (S_DB, S_B, f"s{S_NRB}"), (S_DC, S_C, f"s{T}")):
+            e(f"s_mov_b32 s{d}, s{p}")
+            e(f"s_and_b32 s{d + 1}, s{p + 1}, 0xffff")
+            e(f"s_mov_b32 s{d + 2}, {nr}")
+            e(f"s_mov_b32 s{d + 3}, 0x00020000")
+        # ---- LDS-DMA: destination bases and per-lane source offsets ----
+        e(f"s_lshl_b32 s{S_M0A}, s{S_WAVE}, 10")
+        e(f"s_mul_i32 s{T}, s{S_WR}, {B_WAVECOL}", "(wave >> 1): which wave column's B rows this wave stages")
+        e(f"s_lshl_b32 s{T + 1}, s{S_WC}, 10", "(wave & 1): first or second 8 rows of the n tile")
+        e(f"s_add_u32 s{S_M0B}, s{T}, s{T + 1}")
+        e(f"s_add_u32 s{S_M0B}, s{S_M0B}, {A_BYTES}")
+        vl, v3, vc, vr, vt = V_T, V_T + 1, V_T + 2, V_T + 3, V_E    # lane, lane >> 3, chunk * 16, row, temp
+        e(f"v_lshrrev_b32 v{v3}, 3, v{vl}")
+        e(f"v_and_b32 v{vc}, 7, v{vl}")
+        e(f"v_lshrrev_b32 v{vt}, 1, v{v3}")
+        e(f"s_lshl_b32 s{T}, s{S_WC}, 2")
+        e(f"v_add_u32 v{vt}, s{T}, v{vt}", "swizzle = 4 (wave & 1) + (lane >> 4)")
+        e(f"v_xor_b32 v{vc}, v{vc}, v{vt}")
+        e(f"v_lshlrev_b32 v{vc}, 4, v{vc}", "source chunk * 16")
+        e(f"s_lshl_b32 s{T}, s{S_WAVE}, 3")
+        e(f"s_add_u32 s{T}, s{T}, s{S_BM0}")
+        e(f"v_add_u32 v{vr}, s{T}, v{v3}", "A row of piece 0")
+        e(f"s_sub_u32 s{T + 1}, s{S_M}, 1")
+        for p in range(8):
+            e(f"v_add_u32 v{vt}, {32 * p}, v{vr}")
+            e(f"v_min_u32 v{vt}, s{T + 1}, v{vt}")
+            e(f"v_mul_lo_u32 v{vt}, v{vt}, s{S_LDA}")
+            e(f"v_add_u32 v{V_DMA + p}, v{vt}, v{vc}")
+        e(f"s_mul_i32 s{T}, s{S_WR}, {16 * NT}")
+        e(f"s_lshl_b32 s{T + 2}, s{S_WC}, 3")
+        e(f"s_add_u32 s{T}, s{T}, s{T + 2}")
+        e(f"s_add_u32 s{T}, s{T}, s{S_BN0}")
+        e(f"v_add_u32 v{vr}, s{T}, v{v3}", "B^T row of n tile 0's piece")
+        e(f"s_sub_u32 s{T + 1}, s{S_N}, 1")
+        for j in range(NT):
+            e(f"v_add_u32 v{vt}, {16 * j}, v{vr}")
+            e(f"v_min_u32 v{vt}, s{T + 1}, v{vt}")
+            e(f"v_mul_lo_u32 v{vt}, v{vt}, s{S_LDB}")
+            e(f"v_add_u32 v{V_DMA + 8 + j}, v{vt}, v{vc}")
+        # ---- scales of this tile: loads now, parked in LDS behind the first DMA pieces ----
+        vsa, vsb1, vsb2 = V_E + 1, V_E + 2, V_E + 3
+        e(f"v_add_u32 v{vt}, s{S_BM0}, v{V_TID}")
+        e(f"s_sub_u32 s{T}, s{S_M}, 1")
+        e(f"v_min_u32 v{vt}, s{T}, v{vt}")
+        e(f"s_cmp_lg_u32 s{S_SAVEC}, 0")
+        e(f"s_cselect_b32 s{T + 2}, -1, 0")
+        e(f"v_and_b32 v{vt}, s{T + 2}, v{vt}", "scalar scale: element 0")
+        e(f"v_lshlrev_b32 v{vt}, 2, v{vt}")
+        e(f"global_load_dword v{vsa}, v{vt}, s[{S_SA}:{S_SA + 1}]")
+        e(f"s_sub_u32 s{T}, s{S_N}, 1")
+        e(f"s_cmp_lg_u32 s{S_SBVEC}, 0")
+        e(f"s_cselect_b32 s{T + 2}, -1, 0")
+        for k, dst in ((0, vsb1), (256, vsb2)):
+            e(f"v_add_u32 v{vt}, s{S_BN0}, v{V_TID}")
+            if k:
+                e(f"v_add_u32 v{vt}, {k}, v{vt}")
+            e(f"v_min_u32 v{vt}, s{T}, v{vt}")
+            e(f"v_and_b32 v{vt}, s{T + 2}, v{vt}")
+            e(f"v_lshlrev_b32 v{vt}, 2, v{vt}")
+            e(f"global_load_dword v{dst}, v{vt}, s[{S_SB}:{S_SB + 1}]")
+        # ---- first two stages in flight ----
+        e(f"s_mov_b32 s{S_KOFF}, 0")
+        e("s_nop 3")
+        for idx in range(19):
+            self.dma_piece(idx, 0)
+        e(f"s_mov_b32 s{S_KOFF}, 128")
+        e("s_nop 3")
+        for idx in range(19):
+            self.dma_piece(idx, 1)
+        # fragment read bases
+        r, g, lo = V_E + 4, V_E + 5, V_E + 6
+        e(f"v_and_b32 v{r}, 15, v{vl}")
+        e(f"v_lshrrev_b32 v{g}, 4, v{vl}")
+        e(f"v_lshrrev_b32 v{lo}, 3, v{r}")
+        e(f"v_lshlrev_b32 v{lo}, 10, v{lo}", "(r >> 3) * 1024")
+        e(f"v_and_b32 v{vt}, 7, v{r}")
+        e(f"v_lshlrev_b32 v{vt}, 7, v{vt}")
+        e(f"v_add_u32 v{lo}, v{lo}, v{vt}", "+ (r & 7) * 128")
+        e(f"v_lshrrev_b32 v{vt}, 1, v{r}")
+        e(f"v_and_b32 v{vt}, 7, v{vt}")
+        e(f"v_xor_b32 v{vt}, v{vt}, v{g}")
+        e(f"v_lshlrev_b32 v{vt}, 4, v{vt}")
+        e(f"v_add_u32 v{lo}, v{lo}, v{vt}", "+ (g ^ ((r >> 1) & 7)) * 16")
+        e(f"s_lshl_b32 s{T}, s{S_WR}, 14")
+        e(f"v_add_u32 v{V_ALO[0]}, s{T}, v{lo}")
+        e(f"v_xor_b32 v{V_AHI[0]}, 64, v{V_ALO[0]}")
+        e(f"s_mul_i32 s{T}, s{S_WC}, {B_WAVECOL}")
+        e(f"s_add_u32 s{T}, s{T}, {A_BYTES}")
+        e(f"v_add_u32 v{V_BLO[0]}, s{T}, v{lo}")
+        e(f"v_xor_b32 v{V_BHI[0]}, 64, v{V_BLO[0]}")
+        e(f"s_mov_b32 s{T}, {STAGE}")
+        for pair in (V_ALO, V_AHI, V_BLO, V_BHI):
+            e(f"v_add_u32 v{pair[1]}, s{T}, v{pair[0]}")
+        # accumulators
+        for k in range(256):
+            e(f"v_accvgpr_write_b32 a{k}, 0")
+        for k in range(96):
+            e(f"v_mov_b32 v{V_ACC + k}, 0")
+        # park the scales (the three loads are the oldest vector-memory operations)
+        e("s_waitcnt vmcnt(38)")
+        e(f"v_mul_f32 v{vsa}, s{S_ACCSCALE}, v{vsa}", "acc_scale: 1, or the exact 1/4 of e4m3fnuz bytes run as OCP e4m3")
+        e(f"v_lshlrev_b32 v{vt}, 2, v{V_TID}")
+        e(f"v_add_u32 v{vt}, {LDS_SA}, v{vt}", "(DS offsets are 16 bits: the scale area's base goes into the address)")
+        e(f"ds_write_b32 v{vt}, v{vsa}")
+        e(f"ds_write_b32 v{vt}, v{vsb1} offset:{LDS_SB - LDS_SA}")
+        e(f"ds_write_b32 v{vt}, v{vsb2} offset:{LDS_SB - LDS_SA + 1024}")
+        # loop control
+        e(f"s_lshr_b32 s{S_CNT}, s{S_K}, 8", "pairs of K steps")
+        # stage 0 landed -> first fragments
+        e("s_waitcnt vmcnt(19)")
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_barrier")
+        # (the first fragment reads follow in build(): exactly the reads a step leaves outstanding for its successor)
+
+    def loop(self) -> None:
+        self.label(self.L("loop"))
+        self.step(0, "t0", "t1")
+        self.step(1, "t1", "t0")
+        self.e(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
+        self.e(f"s_cmp_lg_u32 s{S_CNT}, 0")
+        self.e(f"s_cbranch_scc1 {self.L('loop')}")
+
+    def epilogue(self) -> None:
+        e = self.e
+        T = S_T
+        e("s_waitcnt vmcnt(0)")
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_nop 15", "last MFMA's result -> VALU")
+        e("s_nop 7")
+        vl, vc, vg, vt = V_T, V_T + 1, V_T + 2, V_T + 3
+        e(f"v_and_b32 v{vl}, 63, v{V_TID}")
+        e(f"v_and_b32 v{vc}, 15, v{vl}", "c: m inside a tile")
+        e(f"v_lshrrev_b32 v{vg}, 4, v{vl}", "g: n quad inside a tile")
+        # row offsets into C (bytes), rows past M -> out of range of the descriptor
+        rowoff = V_FA            # 8 registers (the fragments are dead)
+        sa = V_FA + 8            # 8 registers
+        e(f"s_lshl_b32 s{T}, s{S_WR}, 7")
+        e(f"s_add_u32 s{T}, s{T}, s{S_BM0}")
+        e(f"v_add_u32 v{vt}, s{T}, v{vc}", "row of m tile 0")
+        e(f"s_mul_i32 s{T + 1}, s{S_WC}, {16 * NT}")
+        e(f"s_add_u32 s{T + 1}, s{T + 1}, s{S_BN0}", "first column of this wave")
+        e(f"v_lshlrev_b32 v{V_E}, 2, v{vg}")
+        e(f"v_add_u32 v{V_E}, s{T + 1}, v{V_E}", "column of n tile 0")
+        e(f"v_lshlrev_b32 v{V_E}, 1, v{V_E}", "bytes")
+        e(f"s_lshl_b32 s{T + 2}, s{S_LDC}, 1", "row pitch in bytes")
+        for i in range(MT):
+            e(f"v_add_u32 v{V_E + 1}, {16 * i}, v{vt}")
+            e(f"v_mul_lo_u32 v{V_E + 2}, v{V_E + 1}, s{T + 2}")
+            e(f"v_add_u32 v{V_E + 2}, v{V_E + 2}, v{V_E}")
+            e(f"v_cmp_gt_u32 vcc, s{S_M}, v{V_E + 1}")
+            e(f"v_mov_b32 v{V_E + 3}, 0x80000000")
+            e(f"v_cndmask_b32 v{rowoff + i}, v{V_E + 3}, v{V_E + 2}, vcc")
+        # scales from LDS
+        e(f"s_lshl_b32 s{T}, s{S_WR}, 7")
+        e(f"v_add_u32 v{V_E + 1}, s{T}, v{vc}")
+        e(f"v_lshlrev_b32 v{V_E + 1}, 2, v{V_E + 1}")
+        e(f"v_add_u32 v{V_E + 1}, {LDS_SA}, v{V_E + 1}", "sa address")
+        for i in range(MT):
+            e(f"ds_read_b32 v{sa + i}, v{V_E + 1} offset:{64 * i}")
+        e(f"s_mul_i32 s{T}, s{S_WC}, {16 * NT}")
+        e(f"v_lshlrev_b32 v{V_E + 2}, 2, v{vg}")
+        e(f"v_add_u32 v{V_E + 2}, s{T}, v{V_E + 2}")
+        e(f"v_lshlrev_b32 v{V_E + 2}, 2, v{V_E + 2}")
+        e(f"v_add_u32 v{V_E + 2}, {LDS_SB}, v{V_E + 2}", "sb address")
+        sbreg = V_FA + 16        # 4 registers per n tile, double buffered
+        # n tiles of this wave that start below N (N is a multiple of 16: whole tiles)
+        e(f"s_sub_u32 s{S_NVALID}, s{S_N}, s{T + 1}", "columns left of N from this wave's first one (may be <= 0)")
+        e(f"s_cmp_gt_i32 s{S_NVALID}, 0")
+        e(f"s_cbranch_scc0 {self.L('end')}")
+        e(f"s_lshr_b32 s{S_NVALID}, s{S_NVALID}, 4")
+        for j in range(NT):
+            e(f"s_cmp_gt_u32 s{S_NVALID}, {j}")
+            e(f"s_cbranch_scc0 {self.L('end')}")
+            e(f"ds_read_b128 v[{sbreg}:{sbreg + 3}], v{V_E + 2} offset:{64 * j}")
+            e("s_waitcnt lgkmcnt(0)")
+            for i in range(MT):
+                t = 8 * j + i
+                x = V_E + 4      # 4 values
+                if t < 64:
+                    for k in range(4):
+                        e(f"v_accvgpr_read_b32 v{x + k}, a{4 * t + k}")
+                    src = [f"v{x + k}" for k in range(4)]
+                else:
+                    src = [f"v{V_ACC + 4 * (t - 64) + k}" for k in range(4)]
+                for k in range(4):
+                    e(f"v_mul_f32 v{x + k}, v{sa + i}, {src[k]}", "sa * acc" if k == 0 else "")
+                for k in range(4):
+                    e(f"v_mul_f32 v{x + k}, v{sbreg + k}, v{x + k}", "sb * (sa * acc)" if k == 0 else "")
+                if self.out_fp16:
+                    for k in range(4):
+                        e(f"v_cvt_f16_f32 v{x + k}, v{x + k}")
+                    e(f"v_pack_b32_f16 v{x + 4}, v{x}, v{x + 1}")
+                    e(f"v_pack_b32_f16 v{x + 5}, v{x + 2}, v{x + 3}")
+                else:
+                    e(f"v_cvt_pk_bf16_f32 v{x + 4}, v{x}, v{x + 1}")
+                    e(f"v_cvt_pk_bf16_f32 v{x + 5}, v{x + 2}, v{x + 3}")
+                e(f"buffer_store_dwordx2 v[{x + 4}:{x + 5}], v{rowoff + i}, s[{S_DC}:{S_DC + 3}], 0 offen offset:{32 * j}")
+                e("s_nop 1")
+        self.label(self.L("end"))
+        e("s_endpgm")
+
+    def build(self) -> str:
+        self.prologue()
+        # steady-state queue: generate the pair once to learn what is outstanding at its end, then for real
+        probe = Gen(self.name, self.out_fp16)
+        probe.lgkm = []
+        probe.step(0, "t0", "t1")
+        probe.step(1, "t1", "t0")
+        steady = list(probe.lgkm)
+        # the loop body's counted lgkmcnt waits assume the reads a step leaves outstanding for its successor (B tile 0 and A
+        # tiles 0-6 of the next step, in their order of issue): the prologue issues exactly those, in that order
+        for t in steady:
+            _, what, half = t.split(".")
+            kind, idx = what[0], int(what[1:])
+            if kind == "A":
+                base = V_FA + 8 * idx + (4 if half == "hi" else 0)
+                self.ds_read128(base, (V_AHI if half == "hi" else V_ALO)[0], 2048 * idx, t)
+            else:
+                base = V_FB + 8 * fb_slot(idx) + (4 if half == "hi" else 0)
+                self.ds_read128(base, (V_BHI if half == "hi" else V_BLO)[0], 2048 * idx, t)
+        assert self.lgkm == steady, (self.lgkm, steady)
+        self.loop()
+        assert self.lgkm == steady, "the loop body must leave the queue as it found it"
+        self.epilogue()
+        return self.render()
+
+    def render(self) -> str:
+        name = self.name
+        head = f"""\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"
+\t.amdhsa_code_object_version 6
+\t.text
+\t.globl\t{name}
+\t.p2align\t8
+\t.type\t{name},@function
+{name}:
+"""
+        tail = f"""
+.Lfunc_end_{name}:
+\t.size\t{name}, .Lfunc_end_{name}-{name}
+
+\t.rodata
+\t.p2align\t6, 0x0
+\t.amdhsa_kernel {name}
+\t\t.amdhsa_group_segment_fixed_size {LDS_TOTAL}
+\t\t.amdhsa_private_segment_fixed_size 0
+\t\t.amdhsa_kernarg_size 112
+\t\t.amdhsa_user_sgpr_count 2
+\t\t.amdhsa_user_sgpr_dispatch_ptr 0
+\t\t.amdhsa_user_sgpr_queue_ptr 0
+\t\t.amdhsa_user_sgpr_kernarg_segment_ptr 1
+\t\t.amdhsa_user_sgpr_dispatch_id 0
+\t\t.amdhsa_user_sgpr_kernarg_preload_length 0
+\t\t.amdhsa_user_sgpr_kernarg_preload_offset 0
+\t\t.amdhsa_user_sgpr_private_segment_size 0
+\t\t.amdhsa_uses_dynamic_stack 0
+\t\t.amdhsa_enable_private_segment 0
+\t\t.amdhsa_system_sgpr_workgroup_id_x 1
+\t\t.amdhsa_system_sgpr_workgroup_id_y 0
+\t\t.amdhsa_system_sgpr_workgroup_id_z 0
+\t\t.amdhsa_system_sgpr_workgroup_info 0
+\t\t.amdhsa_system_vgpr_workitem_id 0
+\t\t.amdhsa_next_free_vgpr 512
+\t\t.amdhsa_next_free_sgpr {S_END + 1}
+\t\t.amdhsa_accum_offset 256
+\t\t.amdhsa_reserve_vcc 1
+\t\t.amdhsa_float_round_mode_32 0
+\t\t.amdhsa_float_round_mode_16_64 0
+\t\t.amdhsa_float_denorm_mode_32 3
+\t\t.amdhsa_float_denorm_mode_16_64 3
+\t\t.amdhsa_dx10_clamp 1
+\t\t.amdhsa_ieee_mode 1
+\t\t.amdhsa_fp16_overflow 0
+\t\t.amdhsa_tg_split 0
+\t\t.amdhsa_exception_fp_ieee_invalid_op 0
+\t\t.amdhsa_exception_fp_denorm_src 0
+\t\t.amdhsa_exception_fp_ieee_div_zero 0
+\t\t.amdhsa_exception_fp_ieee_overflow 0
+\t\t.amdhsa_exception_fp_ieee_underflow 0
+\t\t.amdhsa_exception_fp_ieee_inexact 0
+\t\t.amdhsa_exception_int_div_zero 0
+\t.end_amdhsa_kernel
+\t.text
+"""
+        return head + "\n".join(self.lines) + tail
+
+    @staticmethod
+    def metadata(names: list[str]) -> str:
+        kernels = ""
+        for name in names:
+            kernels += f"""  - .agpr_count:     256
+    .args:
+      - .offset:         0
+        .size:           112
+        .value_kind:     by_value
+    .group_segment_fixed_size: {LDS_TOTAL}
+    .kernarg_segment_align: 8
+    .kernarg_segment_size: 112
+    .language:       OpenCL C
+    .language_version:
+      - 2
+      - 0
+    .max_flat_workgroup_size: 256
+    .name:           {name}
+    .private_segment_fixed_size: 0
+    .sgpr_count:     {S_END + 7}
+    .sgpr_spill_count: 0
+    .symbol:         {name}.kd
+    .uniform_work_group_size: 1
+    .uses_dynamic_stack: false
+    .vgpr_count:     512
+    .vgpr_spill_count: 0
+    .wavefront_size: 64
+"""
+        return f"""\t.amdgpu_metadata
+---
+amdhsa.kernels:
+{kernels}amdhsa.target:   amdgcn-amd-amdhsa--gfx950
+amdhsa.version:
+  - 1
+  - 2
+...
+
+\t.end_amdgpu_metadata
+"""
+
+
+def main() -> None:
+    out = sys.argv[1]
+    text = ""
+    names = []
+    for name, fp16 in (("conch_gemm1w_fp8_bf16", False), ("conch_gemm1w_fp8_f16", True)):
+        g = Gen(name, out_fp16=fp16)
+        body = g.build()
+        if text:
+            body = body.split("\n", 2)[2]  # one target / code-object-version header per file
+        text += body
+        names.append(name)
+    text += Gen.metadata(names)
+    with open(out, "w") as f:
+        f.write(text)
+
+
+if __name__ == "__main__":
+    main()

@@ -192,6 +192,14 @@ int run_scaled_fast(const ScaledGemmArgs& p, int variant, hipStream_t stream) {
     set_error("scaled_gemm: skinny variant forced but its contract is not met (M <= 256; N %% 4 == 0 or K %% 1024 == 0)");
     return CONCH_ERR_UNSUPPORTED;
   }
+  if (variant == 7) {
+    if (!scaled_gemm_asm1w_supported(p)) {
+      set_error("scaled_gemm: variant 7 (one-wave-per-SIMD assembly kernel) forced but its contract is not met (e4m3fn, K %% 256 == 0, K >= 512, "
+                "N %% 16 == 0, bf16 / fp16 row-major C, no bias, arrays below 2 GiB)");
+      return CONCH_ERR_UNSUPPORTED;
+    }
+    return launch_scaled_gemm_asm1w(p, stream);
+  }
   const ScaledKernel pick = variant == 4 ? kKernelSkinny : variant == 6 ? kKernelMid : variant == 0 ? choose_scaled_kernel(p) : kKernelTiled;
   if (pick == kKernelSkinny && scaled_gemm_skinny_supported(p)) return launch_scaled_gemm_skinny(p, stream);
   if (pick == kKernelMid) return launch_scaled_gemm_mid(p, stream);
@@ -265,7 +273,7 @@ int run_scaled(const ScaledGemmArgs& p_in, hipStream_t stream) {
       return launch_scaled_gemm_mfma_bf16(e, stream);
     }
   }
-  if (variant >= 2 && variant <= 6) {
+  if (variant >= 2 && variant <= 7) {
     set_error("scaled_gemm: MFMA variant %d forced but the layout contract is not met "
               "(need K-contiguous A and B^T, K %% 128 == 0, 16-byte aligned rows)", variant);
     return CONCH_ERR_UNSUPPORTED;

@@ -1,0 +1,124 @@
+"""Bring-up / A-B driver of the one-wave-per-SIMD assembly kernel (variant 7) against the 256 x 256-tile kernel (variant 5).
+
+  python tools/try_asm1w.py [--check-only] [--time-only] [--rounds R]
+
+Check: bit equality with variant 5 on single tiles, ragged M / N, several K, both output dtypes, scalar / vector scales;
+where the two differ, WHERE (rows, columns, 16 x 16 tile coordinates inside the 256 x 352 tile) is printed.
+Time: interleaved rounds in one process (guide rule 24) on C3 and two more shapes, kernel-only (conch_time_scaled_gemm).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from conch_amd import _C  # noqa: E402
+from conch_amd.kernels.quantization import gemm as kgemm  # noqa: E402
+from conch_amd.ops.quantization.gemm import create_scaled_metadata, scaled_gemm  # noqa: E402
+
+
+def inputs(m, k, n, vec_a=True, vec_b=True, seed=0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    a = (0.25 * torch.rand((m, k), device="cuda", generator=g)).to(torch.float8_e4m3fn)
+    bt = (0.25 * torch.rand((n, k), device="cuda", generator=g)).to(torch.float8_e4m3fn)
+    sa = 0.25 * torch.rand((m, 1) if vec_a else (1, 1), device="cuda", generator=g) + 0.01
+    sb = 0.25 * torch.rand((n, 1) if vec_b else (1, 1), device="cuda", generator=g) + 0.01
+    return a, bt.T, sa, sb
+
+
+def run(variant, a, b, sa, sb, dt):
+    _C.set_gemm_variant(variant)
+    try:
+        out = scaled_gemm(a, b, sa, sb, dt)
+        torch.cuda.synchronize()
+        return out
+    finally:
+        _C.set_gemm_variant(_C.VARIANT_AUTO)
+
+
+def where(diff):
+    rows = diff.any(dim=1).nonzero().flatten()
+    cols = diff.any(dim=0).nonzero().flatten()
+    tiles = {}
+    idx = diff.nonzero()
+    for r, c in idx[:200000].tolist():
+        key = ((r % 256) // 16, (c % 352) // 16)
+        tiles[key] = tiles.get(key, 0) + 1
+    top = sorted(tiles.items(), key=lambda kv: -kv[1])[:12]
+    return (f"rows {rows.min().item()}..{rows.max().item()} ({rows.numel()} rows), cols {cols.min().item()}..{cols.max().item()} "
+            f"({cols.numel()} cols); (m tile, n tile) inside the 256x352 tile -> count: {top}")
+
+
+def check() -> int:
+    bad = 0
+    cases = [(256, 512, 352), (256, 512, 176), (256, 1024, 704), (512, 512, 352), (128, 512, 352), (300, 768, 400), (1000, 2048, 1008),
+             (2048, 4096, 2816), (4096, 4096, 11008)]
+    for m, k, n in cases:
+        for dt in (torch.bfloat16, torch.float16):
+            for vec_a, vec_b in ((True, True), (False, False)):
+                if (dt is torch.float16 or not vec_a) and m * n > 3e6:
+                    continue
+                a, b, sa, sb = inputs(m, k, n, vec_a, vec_b, seed=m + n)
+                ref = run(_C.VARIANT_MFMA_PINGPONG2, a, b, sa, sb, dt)
+                got = run(_C.VARIANT_MFMA_ASM1W, a, b, sa, sb, dt)
+                diff = ref.view(torch.int16) != got.view(torch.int16)
+                nd = int(diff.sum().item())
+                tag = f"{m}x{k}x{n} {str(dt)[6:]} sa{'v' if vec_a else 's'} sb{'v' if vec_b else 's'}"
+                if nd:
+                    bad += 1
+                    err = (ref.float() - got.float()).abs().max().item()
+                    print(f"MISMATCH {tag}: {nd} of {m * n} elements differ, max |diff| {err:.4g} (max |ref| {ref.float().abs().max().item():.4g}); {where(diff)}", flush=True)
+                else:
+                    print(f"ok       {tag}", flush=True)
+    return bad
+
+
+def timer(variant, a, b, sa, sb, out, iters):
+    md = create_scaled_metadata(a, b, sa, sb, out.dtype)
+    ms = ctypes.c_float()
+    _C.set_gemm_variant(variant)
+    try:
+        _C.check(kgemm._scaled_gemm_call("conch_time_scaled_gemm", out, a, b, sa, sb, md, None, (iters, ctypes.byref(ms))), "time")
+    finally:
+        _C.set_gemm_variant(_C.VARIANT_AUTO)
+    return ms.value
+
+
+def bench(rounds: int) -> None:
+    for m, k, n in ((4096, 4096, 11008), (8192, 8192, 3584), (4096, 8192, 4096), (8192, 8192, 28672)):
+        a, b, sa, sb = inputs(m, k, n)
+        out = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
+        flops = 2.0 * m * n * k
+        iters = max(10, int(0.15 / (flops / 3.0e15)))
+        for v in (_C.VARIANT_MFMA_PINGPONG2, _C.VARIANT_MFMA_ASM1W):  # load the chip first
+            t_end = time.perf_counter() + 1.0
+            while time.perf_counter() < t_end:
+                timer(v, a, b, sa, sb, out, iters)
+        res = {5: [], 7: []}
+        for _ in range(rounds):
+            for v in (_C.VARIANT_MFMA_PINGPONG2, _C.VARIANT_MFMA_ASM1W):
+                res[v].append(timer(v, a, b, sa, sb, out, iters))
+        for v, name in ((5, "256x256 two waves/SIMD (variant 5)"), (7, "256x352 one wave/SIMD  (variant 7)")):
+            xs = sorted(res[v])
+            med = xs[len(xs) // 2]
+            print(f"{m}x{k}x{n}  {name}: median {med * 1e3:8.1f} us  min {xs[0] * 1e3:8.1f} us   {flops / med / 1e9:7.1f} TFLOP/s = {flops / med / 1e9 / 5000:.3f} of 5 PF", flush=True)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--check-only", action="store_true")
+    ap.add_argument("--time-only", action="store_true")
+    ap.add_argument("--rounds", type=int, default=7)
+    args = ap.parse_args()
+    rc = 0
+    if not args.time_only:
+        rc = check()
+        print(f"check: {rc} mismatching case(s)", flush=True)
+    if not args.check_only:
+        bench(args.rounds)
+    sys.exit(1 if rc else 0)
