@@ -63,7 +63,10 @@ S_CNT = 56                                   # step pairs left
 S_NRA, S_NRB = 57, 58                        # num_records of the operand descriptors
 S_DA, S_DB, S_DC = 60, 64, 68                # buffer descriptors s[60:63], s[64:67], s[68:71]
 S_NVALID = 72                                # n tiles of this wave that start below N
-S_END = 73
+S_PROBE = 74                                 # s[74:75]: debug buffer of the diagnostic build (kernarg offset 104; 0 = none)
+S_STAMP = 76                                 # s[76:76+4*NSTAMPS): (s_memtime, s_memrealtime) pairs of the diagnostic build
+NSTAMPS = 5
+S_END = S_STAMP + 4 * NSTAMPS
 
 # VGPRs
 V_TID = 0
@@ -90,11 +93,13 @@ def acc_reg(i: int, j: int) -> str:
 
 
 class Gen:
-    def __init__(self, name: str, out_fp16: bool = False, pad_nops: int = 0):
+    def __init__(self, name: str, out_fp16: bool = False, probe: bool = False, rows: bool = True):
         self.name = name
+        self.probe = probe
         self.lines: list[str] = []
         self.lgkm: list[str] = []        # outstanding LDS reads, oldest first (tags)
         self.out_fp16 = out_fp16
+        self.rows = rows
 
     def L(self, s: str) -> str:
         return f".L{self.name}_{s}"
@@ -108,6 +113,32 @@ class Gen:
 
     def c(self, s: str) -> None:
         self.lines.append(f"\t; {s}")
+
+    def stamp(self, k: int) -> None:
+        """Diagnostic build only: shader clock and the constant 100 MHz clock at this point, kept in SGPRs until the end."""
+        if self.probe:
+            assert k < NSTAMPS
+            self.e(f"s_memtime s[{S_STAMP + 4 * k}:{S_STAMP + 4 * k + 1}]")
+            self.e(f"s_memrealtime s[{S_STAMP + 4 * k + 2}:{S_STAMP + 4 * k + 3}]")
+
+    def write_stamps(self) -> None:
+        """Wave 0 of every workgroup stores its stamps to probe[workgroup][NSTAMPS][2] (64-bit each) with scalar stores."""
+        if not self.probe:
+            return
+        e = self.e
+        e("s_waitcnt lgkmcnt(0)")
+        e(f"s_cmp_lg_u32 s{S_WAVE}, 0")
+        e(f"s_cbranch_scc1 {self.L('noprobe')}")
+        e(f"s_cmp_eq_u64 s[{S_PROBE}:{S_PROBE + 1}], 0")
+        e(f"s_cbranch_scc1 {self.L('noprobe')}")
+        e(f"s_mul_i32 s{S_T}, s{S_WG}, {16 * NSTAMPS}")
+        e(f"s_add_u32 s{S_PROBE}, s{S_PROBE}, s{S_T}")
+        e(f"s_addc_u32 s{S_PROBE + 1}, s{S_PROBE + 1}, 0")
+        for k in range(NSTAMPS):
+            e(f"s_store_dwordx4 s[{S_STAMP + 4 * k}:{S_STAMP + 4 * k + 3}], s[{S_PROBE}:{S_PROBE + 1}], {16 * k}")
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_dcache_wb")
+        self.label(self.L("noprobe"))
 
     # -- LDS read tracking (lgkmcnt retires LDS operations in order) ---------------------------------------------------------
     def ds_read128(self, dst: int, addr: int, off: int, tag: str) -> None:
@@ -212,6 +243,9 @@ class Gen:
         e(f"s_load_dwordx8 s[16:23], s[{S_KARG}:{S_KARG + 1}], 0x20")
         e(f"s_load_dwordx8 s[24:31], s[{S_KARG}:{S_KARG + 1}], 0x40")
         e(f"s_load_dwordx2 s[{S_ACCSCALE}:{S_ACCSCALE + 1}], s[{S_KARG}:{S_KARG + 1}], 0x60")
+        if self.probe:
+            e(f"s_load_dwordx2 s[{S_PROBE}:{S_PROBE + 1}], s[{S_KARG}:{S_KARG + 1}], 0x68")
+        self.stamp(0)
         # lane / wave
         e(f"v_and_b32 v{V_T}, 63, v{V_TID}", "lane")
         e(f"v_lshrrev_b32 v{V_T + 1}, 6, v{V_TID}")
@@ -242,7 +276,9 @@ class Gen:
         e(f"s_and_b32 s{T + 11}, s{T + 7}, 7", "tm in group")
         e(f"s_branch {self.L('tile_done')}")
         self.label(self.L("partial_group"))
-        e(f"s_mul_hi_u32 s{T + 10}, s{T + 7}, s{S_MAGIC_LAST}")
+        e(f"s_mul_hi_u32 s{T + 10}, s{T + 7}, s{S_MAGIC_LAST}", "tn = in_group / height, height 2..7 (magic = ceil(2^32 / height))")
+        e(f"s_cmp_eq_u32 s{T + 9}, 1")
+        e(f"s_cselect_b32 s{T + 10}, s{T + 7}, s{T + 10}", "height 1: tn = in_group (2^32 / 1 does not fit the magic)")
         e(f"s_mul_i32 s{T + 11}, s{T + 10}, s{T + 9}")
         e(f"s_sub_u32 s{T + 11}, s{T + 7}, s{T + 11}")
         self.label(self.L("tile_done"))
@@ -382,14 +418,149 @@ class Gen:
         self.e(f"s_cmp_lg_u32 s{S_CNT}, 0")
         self.e(f"s_cbranch_scc1 {self.L('loop')}")
 
+    def convert_tile(self, i: int, j: int, sa: int, sbreg: int, x: int) -> None:
+        """Accumulator tile (i, j) -> two registers v[x + 4 : x + 5] of packed 16-bit outputs: cast(sb * (sa * acc)) with both
+        products rounded to fp32 (conch/reference/quantization/scaled_gemm.py:21-23); packed multiplies: the same IEEE operation per
+        element.  `sa` = first of the 8 row-scale registers (sa + i: this m tile's), `sbreg` = the n tile's 4 column scales."""
+        e = self.e
+        t = 8 * j + i
+        if t < 64:
+            for k in range(4):
+                e(f"v_accvgpr_read_b32 v{x + k}, a{4 * t + k}")
+            src = x
+        else:
+            src = V_ACC + 4 * (t - 64)
+        # 64-bit VGPR operands must be even-aligned: the scale of an odd m tile is the HIGH half of the pair below it
+        pair = sa + (i & ~1)
+        sel = "op_sel_hi:[1,0]" if i % 2 == 0 else "op_sel:[0,1] op_sel_hi:[1,1]"
+        e(f"v_pk_mul_f32 v[{x}:{x + 1}], v[{src}:{src + 1}], v[{pair}:{pair + 1}] {sel}", "sa * acc")
+        e(f"v_pk_mul_f32 v[{x + 2}:{x + 3}], v[{src + 2}:{src + 3}], v[{pair}:{pair + 1}] {sel}")
+        e(f"v_pk_mul_f32 v[{x}:{x + 1}], v[{x}:{x + 1}], v[{sbreg}:{sbreg + 1}]", "sb * (sa * acc)")
+        e(f"v_pk_mul_f32 v[{x + 2}:{x + 3}], v[{x + 2}:{x + 3}], v[{sbreg + 2}:{sbreg + 3}]")
+        if self.out_fp16:
+            for k in range(4):
+                e(f"v_cvt_f16_f32 v{x + k}, v{x + k}")
+            e(f"v_pack_b32_f16 v{x + 4}, v{x}, v{x + 1}")
+            e(f"v_pack_b32_f16 v{x + 5}, v{x + 2}, v{x + 3}")
+        else:
+            e(f"v_cvt_pk_bf16_f32 v{x + 4}, v{x}, v{x + 1}")
+            e(f"v_cvt_pk_bf16_f32 v{x + 5}, v{x + 2}, v{x + 3}")
+
+    def epilogue_rows(self, vc: int, vg: int) -> None:
+        """Whole wave sub-tiles (128 x 176 inside M x N): every wave parks its cast outputs in ITS OWN 24 KiB of the dead operand
+        LDS as a row-major image (64 rows x 352 bytes at a pitch of 368, two passes of four m tiles), reads it back 16 bytes per
+        lane along the rows and stores contiguous 352-byte row segments with buffer_store_dwordx4 -- 8 line segments per store
+        instruction instead of 64 (T21 of the programming guide; profiles/r03/store_rate.txt).  A wave's LDS operations execute
+        in order, so no barrier separates its writes from its reads."""
+        e = self.e
+        T = S_T
+        PITCH = 368
+        REGION = 24576
+        NQ = 22                      # 64 rows x 22 sixteen-byte chunks / 64 lanes
+        sa = V_FA                    # 8 row scales (even-aligned base)
+        sbreg = V_FA + 8             # 4 column scales of the current n tile
+        waddr = V_FA + 12            # LDS write address of this lane (m tile 0 of the pass, n tile 0)
+        x = V_FA + 14                # 6 temporaries (even-aligned)
+        lds_q = V_FA + 20            # 22 LDS read addresses
+        glb_q = V_FA + 42            # 22 global byte offsets (pass 0; pass 1 = + 64 rows through the scalar offset)
+        buf = V_E                    # 8 x 4 data registers of the read-back
+        assert glb_q + NQ <= V_FB + 24 and buf + 32 <= V_ACC
+        # scales
+        e(f"s_lshl_b32 s{T}, s{S_WR}, 7")
+        e(f"v_add_u32 v{x}, s{T}, v{vc}")
+        e(f"v_lshlrev_b32 v{x}, 2, v{x}")
+        e(f"v_add_u32 v{x}, {LDS_SA}, v{x}")
+        for i in range(MT):
+            e(f"ds_read_b32 v{sa + i}, v{x} offset:{64 * i}")
+        e(f"s_mul_i32 s{T}, s{S_WC}, {16 * NT}")
+        e(f"v_lshlrev_b32 v{x + 1}, 2, v{vg}")
+        e(f"v_add_u32 v{x + 1}, s{T}, v{x + 1}")
+        e(f"v_lshlrev_b32 v{x + 1}, 2, v{x + 1}")
+        e(f"v_add_u32 v{x + 1}, {LDS_SB}, v{x + 1}", "sb address (n tile j: + 64 j)")
+        sbaddr = x + 1  # kept live: x+1 is overwritten by convert_tile -> move it
+        e(f"v_mov_b32 v{waddr + 1}, v{x + 1}")
+        sbaddr = waddr + 1
+        # this lane's write address inside the wave's region: row c, byte 8 g
+        e(f"s_mul_i32 s{T + 1}, s{S_WAVE}, {REGION}", "the wave's staging region")
+        e(f"v_mul_u32_u24 v{waddr}, {PITCH}, v{vc}")
+        e(f"v_lshl_add_u32 v{waddr}, v{vg}, 3, v{waddr}")
+        e(f"v_add_u32 v{waddr}, s{T + 1}, v{waddr}")
+        # read-back plan: lane L, round q handles chunk X = L + 64 q: row X / 22, chunk X % 22
+        e(f"s_lshl_b32 s{T + 2}, s{S_LDC}, 1", "C row pitch in bytes")
+        e(f"s_lshl_b32 s{T + 3}, s{S_WR}, 7")
+        e(f"s_add_u32 s{T + 3}, s{T + 3}, s{S_BM0}")
+        e(f"s_mul_i32 s{T + 3}, s{T + 3}, s{T + 2}", "first row of the wave, bytes")
+        e(f"s_mul_i32 s{T + 4}, s{S_WC}, {16 * NT}")
+        e(f"s_add_u32 s{T + 4}, s{T + 4}, s{S_BN0}")
+        e(f"s_lshl_b32 s{T + 4}, s{T + 4}, 1")
+        e(f"s_add_u32 s{T + 3}, s{T + 3}, s{T + 4}", "+ first column: byte offset of the wave's corner in C")
+        e(f"v_and_b32 v{x + 2}, 63, v{V_TID}", "lane")
+        for q in range(NQ):
+            e(f"v_add_u32 v{x + 3}, {64 * q}, v{x + 2}", f"X of round {q}")
+            e(f"v_mul_u32_u24 v{x + 4}, 2979, v{x + 3}")
+            e(f"v_lshrrev_b32 v{x + 4}, 16, v{x + 4}", "row = X / 22")
+            e(f"v_mul_u32_u24 v{x + 5}, 22, v{x + 4}")
+            e(f"v_sub_u32 v{x + 5}, v{x + 3}, v{x + 5}", "chunk = X % 22")
+            e(f"v_mul_u32_u24 v{lds_q + q}, {PITCH}, v{x + 4}")
+            e(f"v_lshl_add_u32 v{lds_q + q}, v{x + 5}, 4, v{lds_q + q}")
+            e(f"v_add_u32 v{lds_q + q}, s{T + 1}, v{lds_q + q}")
+            e(f"v_mul_lo_u32 v{glb_q + q}, v{x + 4}, s{T + 2}")
+            e(f"v_lshl_add_u32 v{glb_q + q}, v{x + 5}, 4, v{glb_q + q}")
+            e(f"v_add_u32 v{glb_q + q}, s{T + 3}, v{glb_q + q}")
+        e(f"s_lshl_b32 s{T + 5}, s{T + 2}, 6", "64 rows of C in bytes: the second pass's scalar offset")
+        e("s_waitcnt lgkmcnt(0)")
+        for h in range(2):
+            self.c(f"---- pass {h}: m tiles {4 * h}-{4 * h + 3} ----")
+            for j in range(NT):
+                e(f"ds_read_b128 v[{sbreg}:{sbreg + 3}], v{sbaddr} offset:{64 * j}")
+                e("s_waitcnt lgkmcnt(0)")
+                for i in range(4 * h, 4 * h + 4):
+                    self.convert_tile(i, j, sa, sbreg, x)
+                    e(f"ds_write_b64 v{waddr}, v[{x + 4}:{x + 5}] offset:{(i - 4 * h) * 16 * PITCH + 32 * j}")
+            e("s_waitcnt lgkmcnt(0)")
+            soff = "0" if h == 0 else f"s{T + 5}"
+            depth = 4
+            for q in range(NQ + depth):
+                if q < NQ:
+                    b = buf + 4 * (q % 8)
+                    e(f"ds_read_b128 v[{b}:{b + 3}], v{lds_q + q}")
+                if q >= depth:
+                    r = q - depth
+                    b = buf + 4 * (r % 8)
+                    left = min(depth, NQ - 1 - r)  # reads issued behind read r
+                    e(f"s_waitcnt lgkmcnt({left})")
+                    e(f"buffer_store_dwordx4 v[{b}:{b + 3}], v{glb_q + r}, s[{S_DC}:{S_DC + 3}], {soff} offen")
+        e(f"s_branch {self.L('end')}")
+
     def epilogue(self) -> None:
         e = self.e
         T = S_T
         e("s_waitcnt vmcnt(0)")
         e("s_waitcnt lgkmcnt(0)")
+        e("s_barrier", "every wave is past its last fragment read and every LDS-DMA has landed: the operand LDS is dead")
         e("s_nop 15", "last MFMA's result -> VALU")
         e("s_nop 7")
         vl, vc, vg, vt = V_T, V_T + 1, V_T + 2, V_T + 3
+        e(f"v_and_b32 v{vl}, 63, v{V_TID}")
+        e(f"v_and_b32 v{vc}, 15, v{vl}", "c: m inside a tile")
+        e(f"v_lshrrev_b32 v{vg}, 4, v{vl}", "g: n quad inside a tile")
+        if self.rows:
+            # whole sub-tile of this wave inside M x N?  (wave-uniform; the waves of a workgroup may take different paths)
+            e(f"s_lshl_b32 s{T}, s{S_WR}, 7")
+            e(f"s_add_u32 s{T}, s{T}, s{S_BM0}")
+            e(f"s_add_u32 s{T}, s{T}, 128")
+            e(f"s_cmp_le_u32 s{T}, s{S_M}")
+            e(f"s_cbranch_scc0 {self.L('direct')}")
+            e(f"s_mul_i32 s{T}, s{S_WC}, {16 * NT}")
+            e(f"s_add_u32 s{T}, s{T}, s{S_BN0}")
+            e(f"s_add_u32 s{T}, s{T}, {16 * NT}")
+            e(f"s_cmp_le_u32 s{T}, s{S_N}")
+            e(f"s_cbranch_scc0 {self.L('direct')}")
+            e(f"s_and_b32 s{T}, s{S_LDC}, 7", "16-byte stores: C rows 16-byte aligned (ldc % 8 == 0; the base is checked by the launcher)")
+            e(f"s_cmp_eq_u32 s{T}, 0")
+            e(f"s_cbranch_scc0 {self.L('direct')}")
+            self.epilogue_rows(vc, vg)
+            self.label(self.L("direct"))
         e(f"v_and_b32 v{vl}, 63, v{V_TID}")
         e(f"v_and_b32 v{vc}, 15, v{vl}", "c: m inside a tile")
         e(f"v_lshrrev_b32 v{vg}, 4, v{vl}", "g: n quad inside a tile")
@@ -459,12 +630,17 @@ class Gen:
                 e(f"buffer_store_dwordx2 v[{x + 4}:{x + 5}], v{rowoff + i}, s[{S_DC}:{S_DC + 3}], 0 offen offset:{32 * j}")
                 e("s_nop 1")
         self.label(self.L("end"))
+        self.stamp(3)
+        if self.probe:
+            e("s_waitcnt vmcnt(0)")
+        self.stamp(4)
+        self.write_stamps()
         e("s_endpgm")
 
     def build(self) -> str:
         self.prologue()
         # steady-state queue: generate the pair once to learn what is outstanding at its end, then for real
-        probe = Gen(self.name, self.out_fp16)
+        probe = Gen(self.name, self.out_fp16)  # (a scratch generator: only its final queue state is used)
         probe.lgkm = []
         probe.step(0, "t0", "t1")
         probe.step(1, "t1", "t0")
@@ -481,8 +657,10 @@ class Gen:
                 base = V_FB + 8 * fb_slot(idx) + (4 if half == "hi" else 0)
                 self.ds_read128(base, (V_BHI if half == "hi" else V_BLO)[0], 2048 * idx, t)
         assert self.lgkm == steady, (self.lgkm, steady)
+        self.stamp(1)
         self.loop()
         assert self.lgkm == steady, "the loop body must leave the queue as it found it"
+        self.stamp(2)
         self.epilogue()
         return self.render()
 
@@ -590,8 +768,9 @@ def main() -> None:
     out = sys.argv[1]
     text = ""
     names = []
-    for name, fp16 in (("conch_gemm1w_fp8_bf16", False), ("conch_gemm1w_fp8_f16", True)):
-        g = Gen(name, out_fp16=fp16)
+    for name, fp16, probe in (("conch_gemm1w_fp8_bf16", False, False), ("conch_gemm1w_fp8_f16", True, False),
+                              ("conch_gemm1w_fp8_bf16_probe", False, True)):
+        g = Gen(name, out_fp16=fp16, probe=probe)
         body = g.build()
         if text:
             body = body.split("\n", 2)[2]  # one target / code-object-version header per file

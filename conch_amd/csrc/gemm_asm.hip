@@ -6,6 +6,7 @@
 // The kernel is loaded from memory with hipModuleLoadData on first use (one module per process; one process per GPU) and
 // launched with hipModuleLaunchKernel on the caller's stream, so it is stream-ordered and graph-capturable like every other
 // kernel of the library.
+#include <atomic>
 #include <mutex>
 
 #include "common.hpp"
@@ -29,7 +30,7 @@ struct Gemm1wArgs {
   uint32_t tiles_m, tiles_n, nwg, magic_pg, shift_pg, magic_last, sa_vec, sb_vec;
   float acc_scale;
   uint32_t out_dtype;
-  uint32_t pad[2];
+  unsigned long long* probe;  // diagnostic kernel only: [workgroup][5][2] 64-bit stamps (s_memtime, s_memrealtime); else ignored
 };
 static_assert(sizeof(Gemm1wArgs) == 112, "kernarg block of conch_gemm1w_*: 112 bytes");
 static_assert(offsetof(Gemm1wArgs, m) == 40 && offsetof(Gemm1wArgs, tiles_m) == 64 && offsetof(Gemm1wArgs, acc_scale) == 96, "kernarg offsets");
@@ -38,7 +39,7 @@ constexpr int kTileM = 256, kTileN = 352;
 
 struct Gemm1wModule {
   hipModule_t mod = nullptr;
-  hipFunction_t bf16 = nullptr, f16 = nullptr;
+  hipFunction_t bf16 = nullptr, f16 = nullptr, bf16_probe = nullptr;
   int rc = CONCH_OK;
 };
 
@@ -49,6 +50,7 @@ Gemm1wModule& gemm1w_module() {
     hipError_t e = hipModuleLoadData(&m.mod, kGemm1wCodeObject);
     if (e == hipSuccess) e = hipModuleGetFunction(&m.bf16, m.mod, "conch_gemm1w_fp8_bf16");
     if (e == hipSuccess) e = hipModuleGetFunction(&m.f16, m.mod, "conch_gemm1w_fp8_f16");
+    if (e == hipSuccess) e = hipModuleGetFunction(&m.bf16_probe, m.mod, "conch_gemm1w_fp8_bf16_probe");
     if (e != hipSuccess) {
       set_error("scaled_gemm (one-wave-per-SIMD kernel): loading the embedded code object failed: %s", hipGetErrorString(e));
       m.rc = CONCH_ERR_HIP;
@@ -57,7 +59,20 @@ Gemm1wModule& gemm1w_module() {
   return m;
 }
 
+std::atomic<unsigned long long*> g_gemm1w_probe{nullptr};
+
 }  // namespace
+}  // namespace conch
+
+// Diagnostic: with a non-NULL buffer of (workgroups x 10) 64-bit words the NEXT bf16 launches run the stamped twin of the kernel
+// (the product kernel contains no stamp) and wave 0 of every workgroup writes (shader clock, 100 MHz clock) at kernel entry, K loop
+// start, K loop end, epilogue stores issued, stores retired.  NULL switches back.  Used by tools/try_asm1w.py only.
+extern "C" int conch_debug_gemm1w_probe(unsigned long long* buffer) {
+  conch::g_gemm1w_probe.store(buffer);
+  return CONCH_OK;
+}
+
+namespace conch {
 
 // Contract on top of scaled_gemm_mfma_supported (K-contiguous A and B^T, 16-byte aligned rows): OCP fp8, K a multiple of 256 bytes
 // and >= 512, N a multiple of 16, unit-stride C rows of bf16 / fp16, no bias, no fused gate/up form, one destination, every
@@ -67,7 +82,7 @@ bool scaled_gemm_asm1w_supported(const ScaledGemmArgs& p) {
   if (p.in_dtype != CONCH_DT_FP8_E4M3FN) return false;
   if (p.out_dtype != CONCH_DT_BF16 && p.out_dtype != CONCH_DT_FP16) return false;
   if (p.bias || p.fuse_silu || p.n_more || p.split_steps || p.gate || p.a_src_dtype) return false;
-  if (p.k < 512 || p.k % 256 || p.n % 16 || p.c_stride_n != 1) return false;
+  if (p.k < 512 || p.k % 256 || p.n % 16 || p.c_stride_n != 1 || (((uintptr_t)p.c) & 15)) return false;
   if (!p.scale_a || !p.scale_b) return false;
   const int64_t lim = (int64_t)1 << 31;
   if ((p.m - 1) * p.a_stride_m + p.k >= lim || (p.n - 1) * p.b_stride_n + p.k >= lim) return false;
@@ -107,7 +122,8 @@ int launch_scaled_gemm_asm1w(const ScaledGemmArgs& p, hipStream_t stream) {
   a.out_dtype = (uint32_t)p.out_dtype;
   size_t size = sizeof(a);
   void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-  const hipFunction_t f = p.out_dtype == CONCH_DT_BF16 ? mod.bf16 : mod.f16;
+  a.probe = p.out_dtype == CONCH_DT_BF16 ? g_gemm1w_probe.load() : nullptr;
+  const hipFunction_t f = a.probe ? mod.bf16_probe : p.out_dtype == CONCH_DT_BF16 ? mod.bf16 : mod.f16;
   CONCH_HIP(hipModuleLaunchKernel(f, a.nwg, 1, 1, 256, 1, 1, 0, stream, nullptr, extra));
   return CONCH_OK;
 }

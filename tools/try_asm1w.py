@@ -109,11 +109,49 @@ def bench(rounds: int) -> None:
             print(f"{m}x{k}x{n}  {name}: median {med * 1e3:8.1f} us  min {xs[0] * 1e3:8.1f} us   {flops / med / 1e9:7.1f} TFLOP/s = {flops / med / 1e9 / 5000:.3f} of 5 PF", flush=True)
 
 
+def probe(m=4096, k=4096, n=11008, seconds=1.5) -> None:
+    """In-kernel stamps of the diagnostic twin under sustained load: where a workgroup's time goes and the clock it holds."""
+    lib = _C.load()
+    fn = lib.conch_debug_gemm1w_probe
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p]
+    a, b, sa, sb = inputs(m, k, n)
+    out = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
+    nwg = -(-m // 256) * -(-n // 352)
+    buf = torch.zeros((nwg, 5, 2), dtype=torch.int64, device="cuda")
+    fn(buf.data_ptr())
+    try:
+        t_end = time.perf_counter() + seconds
+        while time.perf_counter() < t_end:
+            timer(_C.VARIANT_MFMA_ASM1W, a, b, sa, sb, out, 50)
+        torch.cuda.synchronize()
+    finally:
+        fn(None)
+    st = buf.cpu().double()
+    clk, rt = st[:, :, 0], st[:, :, 1]
+    names = ["entry -> K loop", "K loop", "K loop end -> stores issued", "stores issued -> retired"]
+    steps = k // 128
+    print(f"probe {m}x{k}x{n}: {nwg} workgroups, {steps} K steps (medians over workgroups)")
+    for i, name in enumerate(names):
+        us = ((rt[:, i + 1] - rt[:, i]) / 100.0).median().item()
+        cyc = (clk[:, i + 1] - clk[:, i]).median().item()
+        extra = f"  = {cyc / steps:7.0f} cycles per step ({SLOT_CYC * 88} are MFMA)" if i == 1 else ""
+        print(f"  {name:32s} {us:8.2f} us  {cyc:10.0f} cycles  clock {cyc / max(us, 1e-9) / 1e3:5.2f} GHz{extra}")
+    t0 = rt[:, 0].min()
+    first = ((rt[:, 0] - t0) / 100.0)
+    last = ((rt[:, 4] - t0) / 100.0)
+    print(f"  workgroup entries span {first.max().item():.1f} us (second-round entries from {first.sort().values[min(256, nwg - 1)].item():.1f} us), last exit {last.max().item():.1f} us")
+
+
+SLOT_CYC = 32
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--check-only", action="store_true")
     ap.add_argument("--time-only", action="store_true")
     ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--probe", action="store_true")
     args = ap.parse_args()
     rc = 0
     if not args.time_only:
@@ -121,4 +159,7 @@ if __name__ == "__main__":
         print(f"check: {rc} mismatching case(s)", flush=True)
     if not args.check_only:
         bench(args.rounds)
+    if args.probe:
+        probe()
+        probe(8192, 8192, 28672)
     sys.exit(1 if rc else 0)
