@@ -93,13 +93,14 @@ def acc_reg(i: int, j: int) -> str:
 
 
 class Gen:
-    def __init__(self, name: str, out_fp16: bool = False, probe: bool = False, rows: bool = True):
+    def __init__(self, name: str, out_fp16: bool = False, probe: bool = False, rows: bool = True, pk: bool = True):
         self.name = name
         self.probe = probe
         self.lines: list[str] = []
         self.lgkm: list[str] = []        # outstanding LDS reads, oldest first (tags)
         self.out_fp16 = out_fp16
         self.rows = rows
+        self.pk = pk
 
     def L(self, s: str) -> str:
         return f".L{self.name}_{s}"
@@ -418,74 +419,83 @@ class Gen:
         self.e(f"s_cmp_lg_u32 s{S_CNT}, 0")
         self.e(f"s_cbranch_scc1 {self.L('loop')}")
 
-    def convert_tile(self, i: int, j: int, sa: int, sbreg: int, x: int) -> None:
-        """Accumulator tile (i, j) -> two registers v[x + 4 : x + 5] of packed 16-bit outputs: cast(sb * (sa * acc)) with both
-        products rounded to fp32 (conch/reference/quantization/scaled_gemm.py:21-23); packed multiplies: the same IEEE operation per
-        element.  `sa` = first of the 8 row-scale registers (sa + i: this m tile's), `sbreg` = the n tile's 4 column scales."""
-        e = self.e
+    def convert_ops(self, i: int, j: int, sa: int, sb: int, x: int) -> list[str]:
+        """Instructions that turn accumulator tile (i, j) into two registers v[x + 4 : x + 5] of packed 16-bit outputs:
+        cast(sb * (sa * acc)), both products rounded to fp32 (conch/reference/quantization/scaled_gemm.py:21-23).  `sa` = first of
+        the 8 row-scale registers, `sb` = the n tile's 4 column scales.  Returned as a list so that two tiles' dependent chains
+        can be interleaved.  self.pk: packed multiplies (v_pk_mul_f32, the same IEEE operation per element) or scalar ones."""
+        ops = []
         t = 8 * j + i
         if t < 64:
-            for k in range(4):
-                e(f"v_accvgpr_read_b32 v{x + k}, a{4 * t + k}")
+            ops += [f"v_accvgpr_read_b32 v{x + k}, a{4 * t + k}" for k in range(4)]
             src = x
         else:
             src = V_ACC + 4 * (t - 64)
-        # 64-bit VGPR operands must be even-aligned: the scale of an odd m tile is the HIGH half of the pair below it
-        pair = sa + (i & ~1)
-        sel = "op_sel_hi:[1,0]" if i % 2 == 0 else "op_sel:[0,1] op_sel_hi:[1,1]"
-        e(f"v_pk_mul_f32 v[{x}:{x + 1}], v[{src}:{src + 1}], v[{pair}:{pair + 1}] {sel}", "sa * acc")
-        e(f"v_pk_mul_f32 v[{x + 2}:{x + 3}], v[{src + 2}:{src + 3}], v[{pair}:{pair + 1}] {sel}")
-        e(f"v_pk_mul_f32 v[{x}:{x + 1}], v[{x}:{x + 1}], v[{sbreg}:{sbreg + 1}]", "sb * (sa * acc)")
-        e(f"v_pk_mul_f32 v[{x + 2}:{x + 3}], v[{x + 2}:{x + 3}], v[{sbreg + 2}:{sbreg + 3}]")
-        if self.out_fp16:
-            for k in range(4):
-                e(f"v_cvt_f16_f32 v{x + k}, v{x + k}")
-            e(f"v_pack_b32_f16 v{x + 4}, v{x}, v{x + 1}")
-            e(f"v_pack_b32_f16 v{x + 5}, v{x + 2}, v{x + 3}")
+        if self.pk:
+            # 64-bit VGPR operands must be even-aligned: the scale of an odd m tile is the HIGH half of the pair below it
+            pair = sa + (i & ~1)
+            sel = "op_sel_hi:[1,0]" if i % 2 == 0 else "op_sel:[0,1] op_sel_hi:[1,1]"
+            ops.append(f"v_pk_mul_f32 v[{x}:{x + 1}], v[{src}:{src + 1}], v[{pair}:{pair + 1}] {sel}")
+            ops.append(f"v_pk_mul_f32 v[{x + 2}:{x + 3}], v[{src + 2}:{src + 3}], v[{pair}:{pair + 1}] {sel}")
+            ops.append(f"v_pk_mul_f32 v[{x}:{x + 1}], v[{x}:{x + 1}], v[{sb}:{sb + 1}]")
+            ops.append(f"v_pk_mul_f32 v[{x + 2}:{x + 3}], v[{x + 2}:{x + 3}], v[{sb + 2}:{sb + 3}]")
         else:
-            e(f"v_cvt_pk_bf16_f32 v{x + 4}, v{x}, v{x + 1}")
-            e(f"v_cvt_pk_bf16_f32 v{x + 5}, v{x + 2}, v{x + 3}")
+            ops += [f"v_mul_f32 v{x + k}, v{sa + i}, v{src + k}" for k in range(4)]
+            ops += [f"v_mul_f32 v{x + k}, v{sb + k}, v{x + k}" for k in range(4)]
+        if self.out_fp16:
+            ops += [f"v_cvt_f16_f32 v{x + k}, v{x + k}" for k in range(4)]
+            ops.append(f"v_pack_b32_f16 v{x + 4}, v{x}, v{x + 1}")
+            ops.append(f"v_pack_b32_f16 v{x + 5}, v{x + 2}, v{x + 3}")
+        else:
+            ops.append(f"v_cvt_pk_bf16_f32 v{x + 4}, v{x}, v{x + 1}")
+            ops.append(f"v_cvt_pk_bf16_f32 v{x + 5}, v{x + 2}, v{x + 3}")
+        return ops
 
     def epilogue_rows(self, vc: int, vg: int) -> None:
         """Whole wave sub-tiles (128 x 176 inside M x N): every wave parks its cast outputs in ITS OWN 24 KiB of the dead operand
-        LDS as a row-major image (64 rows x 352 bytes at a pitch of 368, two passes of four m tiles), reads it back 16 bytes per
-        lane along the rows and stores contiguous 352-byte row segments with buffer_store_dwordx4 -- 8 line segments per store
-        instruction instead of 64 (T21 of the programming guide; profiles/r03/store_rate.txt).  A wave's LDS operations execute
-        in order, so no barrier separates its writes from its reads."""
+        LDS as a row-major image -- four passes of two m tiles (32 rows x 352 bytes at a pitch of 368) through two alternating
+        buffers -- reads the previous pass's image back 16 bytes per lane (a wave instruction = 8 rows x 128 contiguous bytes)
+        and stores it with buffer_store_dwordx4 BETWEEN the conversions of the current pass: 8 line segments per store
+        instruction instead of 64 (T21 of the programming guide; profiles/r03/store_rate.txt), and the stores drain under the
+        conversion arithmetic.  A wave's LDS operations execute in order, so no barrier separates its writes from its reads.
+        Two tiles' conversion chains are interleaved (a lone wave pays every dependent VALU latency itself), the 44 column
+        scales are read once, and every read-back / store address is one per-lane base + an immediate (+ a scalar row-group
+        offset)."""
         e = self.e
         T = S_T
         PITCH = 368
         REGION = 24576
-        NQ = 22                      # 64 rows x 22 sixteen-byte chunks / 64 lanes
-        sa = V_FA                    # 8 row scales (even-aligned base)
-        sbreg = V_FA + 8             # 4 column scales of the current n tile
-        waddr = V_FA + 12            # LDS write address of this lane (m tile 0 of the pass, n tile 0)
-        x = V_FA + 14                # 6 temporaries (even-aligned)
-        lds_q = V_FA + 20            # 22 LDS read addresses
-        glb_q = V_FA + 42            # 22 global byte offsets (pass 0; pass 1 = + 64 rows through the scalar offset)
-        buf = V_E                    # 8 x 4 data registers of the read-back
-        assert glb_q + NQ <= V_FB + 24 and buf + 32 <= V_ACC
-        # scales
+        BUF = 32 * PITCH             # 11776: one pass's image
+        sa = V_FA                    # v32..39: 8 row scales (even-aligned)
+        sb = V_FA + 8                # v40..83: 4 column scales per n tile
+        waddr = V_FA + 52            # v84: LDS write address of this lane (first m tile of a pass, n tile 0, buffer 0)
+        rbase = V_FA + 53            # v85: LDS read-back address of this lane (row group 0, column group 0, buffer 0)
+        gbase = V_FA + 54            # v86: C byte offset of this lane's 16 bytes (row group 0, column group 0)
+        gmask = V_FA + 55            # v87: the same, or out of range for the lanes past the row's 22nd chunk (column group 2)
+        xa, xb = V_FA + 56, V_FA + 62  # v88..93, v94..99: temporaries of the two interleaved conversions (even-aligned)
+        buf = V_E                    # v120..127: 2 x 4 data registers of the read-back
+        assert xb + 6 <= V_E and buf + 8 <= V_ACC and 2 * BUF <= REGION
+        # row scales
         e(f"s_lshl_b32 s{T}, s{S_WR}, 7")
-        e(f"v_add_u32 v{x}, s{T}, v{vc}")
-        e(f"v_lshlrev_b32 v{x}, 2, v{x}")
-        e(f"v_add_u32 v{x}, {LDS_SA}, v{x}")
+        e(f"v_add_u32 v{xa}, s{T}, v{vc}")
+        e(f"v_lshlrev_b32 v{xa}, 2, v{xa}")
+        e(f"v_add_u32 v{xa}, {LDS_SA}, v{xa}")
         for i in range(MT):
-            e(f"ds_read_b32 v{sa + i}, v{x} offset:{64 * i}")
+            e(f"ds_read_b32 v{sa + i}, v{xa} offset:{64 * i}")
+        # column scales of all 11 n tiles
         e(f"s_mul_i32 s{T}, s{S_WC}, {16 * NT}")
-        e(f"v_lshlrev_b32 v{x + 1}, 2, v{vg}")
-        e(f"v_add_u32 v{x + 1}, s{T}, v{x + 1}")
-        e(f"v_lshlrev_b32 v{x + 1}, 2, v{x + 1}")
-        e(f"v_add_u32 v{x + 1}, {LDS_SB}, v{x + 1}", "sb address (n tile j: + 64 j)")
-        sbaddr = x + 1  # kept live: x+1 is overwritten by convert_tile -> move it
-        e(f"v_mov_b32 v{waddr + 1}, v{x + 1}")
-        sbaddr = waddr + 1
+        e(f"v_lshlrev_b32 v{xa + 1}, 2, v{vg}")
+        e(f"v_add_u32 v{xa + 1}, s{T}, v{xa + 1}")
+        e(f"v_lshlrev_b32 v{xa + 1}, 2, v{xa + 1}")
+        e(f"v_add_u32 v{xa + 1}, {LDS_SB}, v{xa + 1}")
+        for j in range(NT):
+            e(f"ds_read_b128 v[{sb + 4 * j}:{sb + 4 * j + 3}], v{xa + 1} offset:{64 * j}")
         # this lane's write address inside the wave's region: row c, byte 8 g
         e(f"s_mul_i32 s{T + 1}, s{S_WAVE}, {REGION}", "the wave's staging region")
         e(f"v_mul_u32_u24 v{waddr}, {PITCH}, v{vc}")
         e(f"v_lshl_add_u32 v{waddr}, v{vg}, 3, v{waddr}")
         e(f"v_add_u32 v{waddr}, s{T + 1}, v{waddr}")
-        # read-back plan: lane L, round q handles chunk X = L + 64 q: row X / 22, chunk X % 22
+        # read-back: lane L -> row L / 8 of a group of 8 rows, 16-byte chunk L % 8 of a group of 8 chunks (3 groups: 8 + 8 + 6)
         e(f"s_lshl_b32 s{T + 2}, s{S_LDC}, 1", "C row pitch in bytes")
         e(f"s_lshl_b32 s{T + 3}, s{S_WR}, 7")
         e(f"s_add_u32 s{T + 3}, s{T + 3}, s{S_BM0}")
@@ -494,42 +504,67 @@ class Gen:
         e(f"s_add_u32 s{T + 4}, s{T + 4}, s{S_BN0}")
         e(f"s_lshl_b32 s{T + 4}, s{T + 4}, 1")
         e(f"s_add_u32 s{T + 3}, s{T + 3}, s{T + 4}", "+ first column: byte offset of the wave's corner in C")
-        e(f"v_and_b32 v{x + 2}, 63, v{V_TID}", "lane")
-        for q in range(NQ):
-            e(f"v_add_u32 v{x + 3}, {64 * q}, v{x + 2}", f"X of round {q}")
-            e(f"v_mul_u32_u24 v{x + 4}, 2979, v{x + 3}")
-            e(f"v_lshrrev_b32 v{x + 4}, 16, v{x + 4}", "row = X / 22")
-            e(f"v_mul_u32_u24 v{x + 5}, 22, v{x + 4}")
-            e(f"v_sub_u32 v{x + 5}, v{x + 3}, v{x + 5}", "chunk = X % 22")
-            e(f"v_mul_u32_u24 v{lds_q + q}, {PITCH}, v{x + 4}")
-            e(f"v_lshl_add_u32 v{lds_q + q}, v{x + 5}, 4, v{lds_q + q}")
-            e(f"v_add_u32 v{lds_q + q}, s{T + 1}, v{lds_q + q}")
-            e(f"v_mul_lo_u32 v{glb_q + q}, v{x + 4}, s{T + 2}")
-            e(f"v_lshl_add_u32 v{glb_q + q}, v{x + 5}, 4, v{glb_q + q}")
-            e(f"v_add_u32 v{glb_q + q}, s{T + 3}, v{glb_q + q}")
-        e(f"s_lshl_b32 s{T + 5}, s{T + 2}, 6", "64 rows of C in bytes: the second pass's scalar offset")
+        e(f"v_and_b32 v{xb}, 63, v{V_TID}", "lane")
+        e(f"v_lshrrev_b32 v{xb + 1}, 3, v{xb}", "row in the group")
+        e(f"v_and_b32 v{xb + 2}, 7, v{xb}", "chunk in the group")
+        e(f"v_mul_u32_u24 v{rbase}, {PITCH}, v{xb + 1}")
+        e(f"v_lshl_add_u32 v{rbase}, v{xb + 2}, 4, v{rbase}")
+        e(f"v_add_u32 v{rbase}, s{T + 1}, v{rbase}")
+        e(f"v_mul_lo_u32 v{gbase}, v{xb + 1}, s{T + 2}")
+        e(f"v_lshl_add_u32 v{gbase}, v{xb + 2}, 4, v{gbase}")
+        e(f"v_add_u32 v{gbase}, s{T + 3}, v{gbase}")
+        e(f"v_cmp_gt_u32 vcc, 6, v{xb + 2}", "chunks 16-21 of a row: six lanes of eight")
+        e(f"v_mov_b32 v{xb + 3}, 0x80000000")
+        e(f"v_cndmask_b32 v{gmask}, v{xb + 3}, v{gbase}, vcc")
+        e(f"s_lshl_b32 s{T + 5}, s{T + 2}, 3", "8 rows of C in bytes: one row group")
+        e(f"s_mov_b32 s{T + 6}, 0", "scalar offset of the row group being stored")
         e("s_waitcnt lgkmcnt(0)")
-        for h in range(2):
-            self.c(f"---- pass {h}: m tiles {4 * h}-{4 * h + 3} ----")
+        units = [(rg, cg) for rg in range(4) for cg in range(3)]   # of one pass's image: 4 row groups x 3 column groups
+
+        def read_unit(p: int, u: int) -> None:
+            rg, cg = units[u]
+            b = buf + 4 * (u % 2)
+            e(f"ds_read_b128 v[{b}:{b + 3}], v{rbase} offset:{(p % 2) * BUF + rg * 8 * PITCH + cg * 128}")
+
+        def store_unit(u: int) -> None:
+            rg, cg = units[u]
+            b = buf + 4 * (u % 2)
+            e(f"buffer_store_dwordx4 v[{b}:{b + 3}], v{gmask if cg == 2 else gbase}, s[{S_DC}:{S_DC + 3}], s{T + 6} offen offset:{cg * 128}")
+            if cg == 2:
+                e(f"s_add_u32 s{T + 6}, s{T + 6}, s{T + 5}", "next row group")
+
+        for p in range(4):
+            self.c(f"---- pass {p}: m tiles {2 * p}, {2 * p + 1} -> buffer {p % 2}" + (f"; image of pass {p - 1} read back and stored in between" if p else "") + " ----")
+            if p:
+                read_unit(p - 1, 0)
             for j in range(NT):
-                e(f"ds_read_b128 v[{sbreg}:{sbreg + 3}], v{sbaddr} offset:{64 * j}")
+                oa = self.convert_ops(2 * p, j, sa, sb + 4 * j, xa)
+                ob = self.convert_ops(2 * p + 1, j, sa, sb + 4 * j, xb)
+                for k in range(max(len(oa), len(ob))):
+                    if k < len(oa):
+                        e(oa[k])
+                    if k < len(ob):
+                        e(ob[k])
+                if p:
+                    e("s_waitcnt lgkmcnt(0)", "the unit read one pair ago (and this wave's earlier image writes)")
+                    store_unit(j)
+                e(f"ds_write_b64 v{waddr}, v[{xa + 4}:{xa + 5}] offset:{(p % 2) * BUF + 32 * j}")
+                e(f"ds_write_b64 v{waddr}, v[{xb + 4}:{xb + 5}] offset:{(p % 2) * BUF + 16 * PITCH + 32 * j}")
+                if p:
+                    read_unit(p - 1, j + 1)
+            if p:
                 e("s_waitcnt lgkmcnt(0)")
-                for i in range(4 * h, 4 * h + 4):
-                    self.convert_tile(i, j, sa, sbreg, x)
-                    e(f"ds_write_b64 v{waddr}, v[{x + 4}:{x + 5}] offset:{(i - 4 * h) * 16 * PITCH + 32 * j}")
-            e("s_waitcnt lgkmcnt(0)")
-            soff = "0" if h == 0 else f"s{T + 5}"
-            depth = 4
-            for q in range(NQ + depth):
-                if q < NQ:
-                    b = buf + 4 * (q % 8)
-                    e(f"ds_read_b128 v[{b}:{b + 3}], v{lds_q + q}")
-                if q >= depth:
-                    r = q - depth
-                    b = buf + 4 * (r % 8)
-                    left = min(depth, NQ - 1 - r)  # reads issued behind read r
-                    e(f"s_waitcnt lgkmcnt({left})")
-                    e(f"buffer_store_dwordx4 v[{b}:{b + 3}], v{glb_q + r}, s[{S_DC}:{S_DC + 3}], {soff} offen")
+                store_unit(NT)
+        self.c("---- image of pass 3 ----")
+        e("s_waitcnt lgkmcnt(0)")
+        read_unit(3, 0)
+        for u in range(len(units)):
+            if u + 1 < len(units):
+                read_unit(3, u + 1)
+                e("s_waitcnt lgkmcnt(1)")
+            else:
+                e("s_waitcnt lgkmcnt(0)")
+            store_unit(u)
         e(f"s_branch {self.L('end')}")
 
     def epilogue(self) -> None:
@@ -768,9 +803,10 @@ def main() -> None:
     out = sys.argv[1]
     text = ""
     names = []
-    for name, fp16, probe in (("conch_gemm1w_fp8_bf16", False, False), ("conch_gemm1w_fp8_f16", True, False),
-                              ("conch_gemm1w_fp8_bf16_probe", False, True)):
-        g = Gen(name, out_fp16=fp16, probe=probe)
+    for name, fp16, probe, pk in (("conch_gemm1w_fp8_bf16", False, False, True), ("conch_gemm1w_fp8_f16", True, False, True),
+                                  ("conch_gemm1w_fp8_bf16_probe", False, True, True), ("conch_gemm1w_fp8_bf16_alt", False, False, False),
+                                  ("conch_gemm1w_fp8_bf16_alt_probe", False, True, False)):
+        g = Gen(name, out_fp16=fp16, probe=probe, pk=pk)
         body = g.build()
         if text:
             body = body.split("\n", 2)[2]  # one target / code-object-version header per file

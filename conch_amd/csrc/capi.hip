@@ -203,6 +203,8 @@ int run_scaled_fast(const ScaledGemmArgs& p, int variant, hipStream_t stream) {
   const ScaledKernel pick = variant == 4 ? kKernelSkinny : variant == 6 ? kKernelMid : variant == 0 ? choose_scaled_kernel(p) : kKernelTiled;
   if (pick == kKernelSkinny && scaled_gemm_skinny_supported(p)) return launch_scaled_gemm_skinny(p, stream);
   if (pick == kKernelMid) return launch_scaled_gemm_mid(p, stream);
+  // large fp8 problems whose 256 x 352 tiling fills the chip in fewer, fuller rounds: the one-wave-per-SIMD assembly kernel
+  if (variant == 0 && pick == kKernelTiled && scaled_asm1w_beats_tiles(p)) return launch_scaled_gemm_asm1w(p, stream);
   return launch_scaled_gemm_mfma(p, (variant == 2 || variant == 3) ? variant : 5, stream);
 }
 

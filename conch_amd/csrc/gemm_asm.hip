@@ -39,7 +39,7 @@ constexpr int kTileM = 256, kTileN = 352;
 
 struct Gemm1wModule {
   hipModule_t mod = nullptr;
-  hipFunction_t bf16 = nullptr, f16 = nullptr, bf16_probe = nullptr;
+  hipFunction_t bf16 = nullptr, f16 = nullptr, bf16_probe = nullptr, bf16_alt = nullptr, bf16_alt_probe = nullptr;
   int rc = CONCH_OK;
 };
 
@@ -51,6 +51,8 @@ Gemm1wModule& gemm1w_module() {
     if (e == hipSuccess) e = hipModuleGetFunction(&m.bf16, m.mod, "conch_gemm1w_fp8_bf16");
     if (e == hipSuccess) e = hipModuleGetFunction(&m.f16, m.mod, "conch_gemm1w_fp8_f16");
     if (e == hipSuccess) e = hipModuleGetFunction(&m.bf16_probe, m.mod, "conch_gemm1w_fp8_bf16_probe");
+    if (e == hipSuccess) e = hipModuleGetFunction(&m.bf16_alt, m.mod, "conch_gemm1w_fp8_bf16_alt");
+    if (e == hipSuccess) e = hipModuleGetFunction(&m.bf16_alt_probe, m.mod, "conch_gemm1w_fp8_bf16_alt_probe");
     if (e != hipSuccess) {
       set_error("scaled_gemm (one-wave-per-SIMD kernel): loading the embedded code object failed: %s", hipGetErrorString(e));
       m.rc = CONCH_ERR_HIP;
@@ -60,6 +62,7 @@ Gemm1wModule& gemm1w_module() {
 }
 
 std::atomic<unsigned long long*> g_gemm1w_probe{nullptr};
+std::atomic<int> g_gemm1w_alt{0};
 
 }  // namespace
 }  // namespace conch
@@ -69,6 +72,12 @@ std::atomic<unsigned long long*> g_gemm1w_probe{nullptr};
 // start, K loop end, epilogue stores issued, stores retired.  NULL switches back.  Used by tools/try_asm1w.py only.
 extern "C" int conch_debug_gemm1w_probe(unsigned long long* buffer) {
   conch::g_gemm1w_probe.store(buffer);
+  return CONCH_OK;
+}
+
+// Diagnostic: 1 = the bf16 launches run the A/B twin of the kernel (the generator's `alt` choice; bit-identical results), 0 = back.
+extern "C" int conch_debug_gemm1w_alt(int on) {
+  conch::g_gemm1w_alt.store(on);
   return CONCH_OK;
 }
 
@@ -90,6 +99,36 @@ bool scaled_gemm_asm1w_supported(const ScaledGemmArgs& p) {
   if (p.a_stride_m >= lim || p.b_stride_n >= lim || p.c_stride_m >= lim) return false;
   const int64_t tiles = ((p.m + kTileM - 1) / kTileM) * ((p.n + kTileN - 1) / kTileN);
   return tiles >= 1 && tiles < 65536 && 8 * ((p.n + kTileN - 1) / kTileN) < 65536;
+}
+
+// ---- when the 256 x 352 tiles beat the 256 x 256 tiles -----------------------------------------------------------------------
+// One table, with where each number comes from (refit: tools/try_asm1w.py prints the per-round times this table models).
+struct Asm1wFit {
+  double fixed352_us, step352_us;   // a 256 x 352 tile on a full chip: fixed part + per 128-byte K step
+  double fixed256_us, step256_us;   // a 256 x 256 tile of gemm_mfma.hip
+  double partial_base;              // a round on a fraction f of the CUs costs (partial_base + (1 - partial_base) f) of a full one
+  double margin;                    // take the 352-wide tiles only when they win by this factor
+};
+// profiles/r05/asm1w_rows_epilogue_v2.txt (commit of round 5, one box, interleaved): C3 2 rounds 115.5 us / 3 rounds (2.69) 123.8 us;
+// C5 10.25 rounds 1141 us / 14 rounds 1158.5 us; 8192 x 8192 x 3584 1.375 rounds 182.1 / 1.75 rounds 149.6; 4096 x 8192 x 4096 0.75
+// rounds 91.7 / 1 round 81.0.  Full-chip round: 352-wide 57.7 us at K = 4096, 104.8 at 8192; 256-wide 41.9 / 82.75.
+constexpr Asm1wFit kAsm1wFit = {10.6, 47.1 / 32.0, 1.05, 40.85 / 32.0, 0.85, 0.98};
+
+static double weighted_rounds(int64_t tiles, int cus, double base) {
+  const int64_t full = tiles / cus, rem = tiles % cus;
+  return (double)full + (rem ? base + (1.0 - base) * (double)rem / (double)cus : 0.0);
+}
+
+bool scaled_asm1w_beats_tiles(const ScaledGemmArgs& p) {
+  if (!scaled_gemm_asm1w_supported(p)) return false;
+  const Asm1wFit& f = kAsm1wFit;
+  const int cus = device_cu_count();
+  const double steps = (double)(p.k / 128);
+  const int64_t t352 = ((p.m + kTileM - 1) / kTileM) * ((p.n + kTileN - 1) / kTileN);
+  const int64_t t256 = ((p.m + 255) / 256) * ((p.n + 255) / 256);
+  const double us352 = weighted_rounds(t352, cus, f.partial_base) * (f.fixed352_us + f.step352_us * steps);
+  const double us256 = weighted_rounds(t256, cus, f.partial_base) * (f.fixed256_us + f.step256_us * steps);
+  return us352 < f.margin * us256;
 }
 
 int launch_scaled_gemm_asm1w(const ScaledGemmArgs& p, hipStream_t stream) {
@@ -123,7 +162,8 @@ int launch_scaled_gemm_asm1w(const ScaledGemmArgs& p, hipStream_t stream) {
   size_t size = sizeof(a);
   void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
   a.probe = p.out_dtype == CONCH_DT_BF16 ? g_gemm1w_probe.load() : nullptr;
-  const hipFunction_t f = a.probe ? mod.bf16_probe : p.out_dtype == CONCH_DT_BF16 ? mod.bf16 : mod.f16;
+  const bool alt = g_gemm1w_alt.load() != 0 && p.out_dtype == CONCH_DT_BF16;
+  const hipFunction_t f = a.probe ? (alt ? mod.bf16_alt_probe : mod.bf16_probe) : alt ? mod.bf16_alt : p.out_dtype == CONCH_DT_BF16 ? mod.bf16 : mod.f16;
   CONCH_HIP(hipModuleLaunchKernel(f, a.nwg, 1, 1, 256, 1, 1, 0, stream, nullptr, extra));
   return CONCH_OK;
 }

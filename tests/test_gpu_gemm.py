@@ -36,7 +36,7 @@ IN_T = {"int8": torch.int8, "fn": torch.float8_e4m3fn, "fnuz": torch.float8_e4m3
 SHAPES = [(128, 256, 128), (1024, 1024, 1024), (4096, 2048, 4096)]
 VARIANTS = {"auto": _C.VARIANT_AUTO, "generic": _C.VARIANT_GENERIC, "simple": _C.VARIANT_MFMA_SIMPLE,
             "pingpong": _C.VARIANT_MFMA_PINGPONG, "skinny": _C.VARIANT_MFMA_SKINNY, "pingpong2": _C.VARIANT_MFMA_PINGPONG2,
-            "mid": _C.VARIANT_MFMA_MID}
+            "mid": _C.VARIANT_MFMA_MID, "asm1w": _C.VARIANT_MFMA_ASM1W}
 # fp accumulation-order tolerance, relative to max|C| of the case, in output-dtype epsilons
 EPS = {torch.float16: 2.0**-10, torch.bfloat16: 2.0**-7}
 
@@ -438,6 +438,43 @@ def test_scaled_gemm_every_kernel_variant(variant, iname, m, k, n):
     ref = oracle.scaled_gemm_ref(a, b, sa, sb, torch.bfloat16, bias)
     _C.set_gemm_variant(VARIANTS[variant])
     check_scaled(run_scaled(a, b, sa, sb, torch.bfloat16, bias), ref, IN_T[iname], torch.bfloat16)
+
+
+@pytest.mark.parametrize("oname", ["bf16", "f16"])
+@pytest.mark.parametrize(("vec_a", "vec_b"), [(True, True), (False, False), (True, False)])
+@pytest.mark.parametrize(("m", "k", "n"), [(256, 512, 352), (256, 512, 176), (256, 1024, 704), (512, 768, 352), (128, 512, 352), (300, 768, 400),
+                                             (1000, 2048, 1008), (257, 512, 368), (2304, 1024, 1056), (16, 512, 16)])
+def test_asm1w_kernel_is_bit_identical_and_correct(_reset_tuning, m, k, n, vec_a, vec_b, oname):
+    """The one-wave-per-SIMD assembly kernel (round 5; csrc/asm/gen_gemm1w.py: 256 x 352 tiles, 352 accumulators per wave, two
+    workgroup barriers per K step) against the 256 x 256-tile HIP kernel: the same MFMA on the same 128-byte K steps in the same
+    order and the same epilogue arithmetic -- the same bits -- on single tiles, ragged M and N (the direct-store epilogue of edge
+    waves beside the row-major one of whole waves), one raster group of every height 1..8 (+ a partial ninth), scalar and vector
+    scales, both output dtypes; and against the oracle per element."""
+    a, b, sa, sb, _ = make_scaled_inputs(m, k, n, torch.float8_e4m3fn, DT[oname], not vec_a, not vec_b, False)
+    _C.set_gemm_variant(_C.VARIANT_MFMA_PINGPONG2)
+    want = run_scaled(a, b, sa, sb, DT[oname], None)
+    _C.set_gemm_variant(_C.VARIANT_MFMA_ASM1W)
+    for _ in range(2):
+        got = run_scaled(a, b, sa, sb, DT[oname], None)
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16)), f"{(got != want).sum().item()} elements differ"
+    _C.set_gemm_variant(_C.VARIANT_AUTO)
+    ref = oracle.scaled_gemm_ref(a, b, sa, sb, DT[oname], None)
+    check_scaled(got, ref, torch.float8_e4m3fn, DT[oname], (a, b, sa, sb, None))
+
+
+def test_asm1w_kernel_contract_is_enforced(_reset_tuning):
+    """Forced onto a problem outside its contract (bias; int8; K not a multiple of 256) the variant refuses with the library's
+    UNSUPPORTED status -- it never runs something else silently."""
+    _C.set_gemm_variant(_C.VARIANT_MFMA_ASM1W)
+    a, b, sa, sb, bias = make_scaled_inputs(256, 512, 352, torch.float8_e4m3fn, torch.bfloat16, False, False, True)
+    with pytest.raises(NotImplementedError):
+        run_scaled(a, b, sa, sb, torch.bfloat16, bias)
+    a8, b8, sa8, sb8, _ = make_scaled_inputs(256, 512, 352, torch.int8, torch.bfloat16, False, False, False)
+    with pytest.raises(NotImplementedError):
+        run_scaled(a8, b8, sa8, sb8, torch.bfloat16, None)
+    a3, b3, sa3, sb3, _ = make_scaled_inputs(256, 384, 352, torch.float8_e4m3fn, torch.bfloat16, False, False, False)
+    with pytest.raises(NotImplementedError):
+        run_scaled(a3, b3, sa3, sb3, torch.bfloat16, None)
 
 
 @pytest.mark.parametrize("iname", list(IN_T))

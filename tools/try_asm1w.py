@@ -75,17 +75,38 @@ def check() -> int:
                     print(f"MISMATCH {tag}: {nd} of {m * n} elements differ, max |diff| {err:.4g} (max |ref| {ref.float().abs().max().item():.4g}); {where(diff)}", flush=True)
                 else:
                     print(f"ok       {tag}", flush=True)
+    for m, k, n in ((512, 1024, 704), (4096, 4096, 11008)):
+        a, b, sa, sb = inputs(m, k, n, seed=5)
+        ref = run(_C.VARIANT_MFMA_PINGPONG2, a, b, sa, sb, torch.bfloat16)
+        set_alt(1)
+        try:
+            got = run(_C.VARIANT_MFMA_ASM1W, a, b, sa, sb, torch.bfloat16)
+        finally:
+            set_alt(0)
+        ok = torch.equal(ref.view(torch.int16), got.view(torch.int16))
+        bad += 0 if ok else 1
+        print(f"{'ok      ' if ok else 'MISMATCH'} {m}x{k}x{n} alt twin", flush=True)
     return bad
 
 
+def set_alt(on: int) -> None:
+    fn = _C.load().conch_debug_gemm1w_alt
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_int]
+    fn(on)
+
+
 def timer(variant, a, b, sa, sb, out, iters):
+    """variant 7 = the assembly kernel, 8 = its A/B twin (generator's `alt` choice)"""
     md = create_scaled_metadata(a, b, sa, sb, out.dtype)
     ms = ctypes.c_float()
-    _C.set_gemm_variant(variant)
+    set_alt(1 if variant == 8 else 0)
+    _C.set_gemm_variant(7 if variant == 8 else variant)
     try:
         _C.check(kgemm._scaled_gemm_call("conch_time_scaled_gemm", out, a, b, sa, sb, md, None, (iters, ctypes.byref(ms))), "time")
     finally:
         _C.set_gemm_variant(_C.VARIANT_AUTO)
+        set_alt(0)
     return ms.value
 
 
@@ -95,21 +116,22 @@ def bench(rounds: int) -> None:
         out = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
         flops = 2.0 * m * n * k
         iters = max(10, int(0.15 / (flops / 3.0e15)))
-        for v in (_C.VARIANT_MFMA_PINGPONG2, _C.VARIANT_MFMA_ASM1W):  # load the chip first
-            t_end = time.perf_counter() + 1.0
+        arms = (5, 7, 8)
+        for v in arms:  # load the chip first
+            t_end = time.perf_counter() + 0.7
             while time.perf_counter() < t_end:
                 timer(v, a, b, sa, sb, out, iters)
-        res = {5: [], 7: []}
+        res = {v: [] for v in arms}
         for _ in range(rounds):
-            for v in (_C.VARIANT_MFMA_PINGPONG2, _C.VARIANT_MFMA_ASM1W):
+            for v in arms:
                 res[v].append(timer(v, a, b, sa, sb, out, iters))
-        for v, name in ((5, "256x256 two waves/SIMD (variant 5)"), (7, "256x352 one wave/SIMD  (variant 7)")):
+        for v, name in ((5, "256x256 two waves/SIMD (variant 5)"), (7, "256x352 one wave/SIMD  (variant 7)"), (8, "  ... its A/B twin (alt)          ")):
             xs = sorted(res[v])
             med = xs[len(xs) // 2]
             print(f"{m}x{k}x{n}  {name}: median {med * 1e3:8.1f} us  min {xs[0] * 1e3:8.1f} us   {flops / med / 1e9:7.1f} TFLOP/s = {flops / med / 1e9 / 5000:.3f} of 5 PF", flush=True)
 
 
-def probe(m=4096, k=4096, n=11008, seconds=1.5) -> None:
+def probe(m=4096, k=4096, n=11008, seconds=1.5, alt=False) -> None:
     """In-kernel stamps of the diagnostic twin under sustained load: where a workgroup's time goes and the clock it holds."""
     lib = _C.load()
     fn = lib.conch_debug_gemm1w_probe
@@ -123,7 +145,7 @@ def probe(m=4096, k=4096, n=11008, seconds=1.5) -> None:
     try:
         t_end = time.perf_counter() + seconds
         while time.perf_counter() < t_end:
-            timer(_C.VARIANT_MFMA_ASM1W, a, b, sa, sb, out, 50)
+            timer(8 if alt else _C.VARIANT_MFMA_ASM1W, a, b, sa, sb, out, 50)
         torch.cuda.synchronize()
     finally:
         fn(None)
@@ -131,7 +153,7 @@ def probe(m=4096, k=4096, n=11008, seconds=1.5) -> None:
     clk, rt = st[:, :, 0], st[:, :, 1]
     names = ["entry -> K loop", "K loop", "K loop end -> stores issued", "stores issued -> retired"]
     steps = k // 128
-    print(f"probe {m}x{k}x{n}: {nwg} workgroups, {steps} K steps (medians over workgroups)")
+    print(f"probe{' (alt twin)' if alt else ''} {m}x{k}x{n}: {nwg} workgroups, {steps} K steps (medians over workgroups)")
     for i, name in enumerate(names):
         us = ((rt[:, i + 1] - rt[:, i]) / 100.0).median().item()
         cyc = (clk[:, i + 1] - clk[:, i]).median().item()
@@ -161,5 +183,6 @@ if __name__ == "__main__":
         bench(args.rounds)
     if args.probe:
         probe()
+        probe(alt=True)
         probe(8192, 8192, 28672)
     sys.exit(1 if rc else 0)
