@@ -163,6 +163,39 @@ def cold_op_ms(step, budget_ms: float = 400.0) -> dict:
     return {"median_ms": times[n // 2], "min_ms": times[0], "mean_ms": sum(times) / n, "runs": n}
 
 
+def held_clock_asm1w(timer, m: int, n: int) -> dict | None:
+    """The same measurement for the one-wave-per-SIMD assembly kernel (csrc/asm/gen_gemm1w.py), which carries its own stamped
+    twin INSIDE the product library (conch_debug_gemm1w_probe switches the next launches to it; the product kernel itself
+    contains no stamp): wave 0 of every workgroup stamps (s_memtime, s_memrealtime) at entry, K loop start, K loop end, stores
+    issued, stores retired.  None when the launches did not go to that kernel (nothing was stamped)."""
+    try:
+        fn = _C.load().conch_debug_gemm1w_probe
+    except AttributeError:
+        return None
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p]
+    nwg = -(-m // 256) * -(-n // 352)
+    buf = torch.zeros((nwg, 5, 2), dtype=torch.int64, device="cuda")
+    fn(buf.data_ptr())
+    try:
+        sustained_kernel_ms(timer, 1.0)
+        torch.cuda.synchronize()
+    finally:
+        fn(None)
+    st = buf.cpu().double()
+    clk, rt = st[:, :, 0], st[:, :, 1]
+    ok = rt[:, 2] > rt[:, 1]
+    if int(ok.sum()) < nwg // 2:
+        return None
+    loop_clk = ((clk[ok, 2] - clk[ok, 1]) / (rt[ok, 2] - rt[ok, 1]) * 100.0).median().item()
+    seg = lambda i: ((rt[ok, i + 1] - rt[ok, i]) / 100.0).median().item()  # noqa: E731  (us; the constant clock runs at 100 MHz)
+    return {"held_clock_mhz": round(loop_clk, 1),
+            "held_clock_source": "median over workgroups of d(s_memtime)/d(s_memrealtime) x 100 MHz around the K loop, stamped twin of the "
+                                 "assembly kernel (conch_debug_gemm1w_probe), after >= 1 s of back-to-back launches",
+            "workgroup_us": {"entry_to_k_loop": round(seg(0), 2), "k_loop": round(seg(1), 2), "epilogue_until_stores_issued": round(seg(2), 2),
+                             "stores_retired": round(seg(3), 2)}}
+
+
 def held_clock_mhz(kind: str, timer_for_lib, blocks: int) -> dict | None:
     """Clock inside the K loop under sustained load: the DIAGNOSTIC twin of the library (-DCONCH_CLOCK_PROBE: thread 0
     of every workgroup stamps s_memtime and the 100 MHz s_memrealtime around its K loop into a buffer nothing else
@@ -556,7 +589,9 @@ def measure_leg(leg: Leg, steps: int, warmup: int, world: int, sustained_s: floa
         roofline["frac_cold"] = round(leg.rate(cold["median_ms"]) / leg.roof_peak, 4)
         roofline["cold_protocol"] = "public op (allocation + kernel), 512 MiB cache flush before every run, median (reference: conch/utils/benchmark.py:82-112)"
     if with_probe and leg.probe_blocks:
-        clock = held_clock_mhz(leg.kind, leg.timer_for_lib, leg.probe_blocks)
+        clock = held_clock_asm1w(leg.timer, leg.m, leg.n) if leg.kind == "scaled_fp8" else None
+        if clock is None:
+            clock = held_clock_mhz(leg.kind, leg.timer_for_lib, leg.probe_blocks)
         if clock:
             roofline.update(clock)
     if with_peak and not leg.hbm_bound:

@@ -93,7 +93,7 @@ def acc_reg(i: int, j: int) -> str:
 
 
 class Gen:
-    def __init__(self, name: str, out_fp16: bool = False, probe: bool = False, rows: bool = True, pk: bool = True):
+    def __init__(self, name: str, out_fp16: bool = False, probe: bool = False, rows: bool = True, pk: bool = True, int8: bool = False):
         self.name = name
         self.probe = probe
         self.lines: list[str] = []
@@ -101,6 +101,7 @@ class Gen:
         self.out_fp16 = out_fp16
         self.rows = rows
         self.pk = pk
+        self.int8 = int8          # int8 operands: 2 x v_mfma_i32_16x16x64_i8 per tile and step, int32 accumulators
 
     def L(self, s: str) -> str:
         return f".L{self.name}_{s}"
@@ -212,7 +213,11 @@ class Gen:
             fb = V_FB + 8 * fb_slot(j)
             fa = V_FA + 8 * i
             acc = acc_reg(i, j)
-            self.e(f"v_mfma_f32_16x16x128_f8f6f4 {acc}, v[{fb}:{fb + 7}], v[{fa}:{fa + 7}], {acc}", f"slot {q}: m tile {i}, n tile {j}")
+            if self.int8:
+                self.e(f"v_mfma_i32_16x16x64_i8 {acc}, v[{fb}:{fb + 3}], v[{fa}:{fa + 3}], {acc}", f"slot {q}: m tile {i}, n tile {j}, K bytes 0-63")
+                self.e(f"v_mfma_i32_16x16x64_i8 {acc}, v[{fb + 4}:{fb + 7}], v[{fa + 4}:{fa + 7}], {acc}", "K bytes 64-127")
+            else:
+                self.e(f"v_mfma_f32_16x16x128_f8f6f4 {acc}, v[{fb}:{fb + 7}], v[{fa}:{fa + 7}], {acc}", f"slot {q}: m tile {i}, n tile {j}")
             # ---- fillers behind this MFMA ----
             if q == 0:
                 self.read_fa(7, st, tag)          # FA[7] of THIS step (its registers were busy until the previous step's last MFMA)
@@ -431,6 +436,9 @@ class Gen:
             src = x
         else:
             src = V_ACC + 4 * (t - 64)
+        if self.int8:  # (float)acc: exact below 2^24, RNE above -- what the reference's fp32 matmul of int8 values holds
+            ops += [f"v_cvt_f32_i32 v{x + k}, v{src + k}" for k in range(4)]
+            src = x
         if self.pk:
             # 64-bit VGPR operands must be even-aligned: the scale of an odd m tile is the HIGH half of the pair below it
             pair = sa + (i & ~1)
@@ -650,6 +658,10 @@ class Gen:
                     src = [f"v{x + k}" for k in range(4)]
                 else:
                     src = [f"v{V_ACC + 4 * (t - 64) + k}" for k in range(4)]
+                if self.int8:
+                    for k in range(4):
+                        e(f"v_cvt_f32_i32 v{x + k}, {src[k]}")
+                    src = [f"v{x + k}" for k in range(4)]
                 for k in range(4):
                     e(f"v_mul_f32 v{x + k}, v{sa + i}, {src[k]}", "sa * acc" if k == 0 else "")
                 for k in range(4):
@@ -803,10 +815,12 @@ def main() -> None:
     out = sys.argv[1]
     text = ""
     names = []
-    for name, fp16, probe, pk in (("conch_gemm1w_fp8_bf16", False, False, True), ("conch_gemm1w_fp8_f16", True, False, True),
-                                  ("conch_gemm1w_fp8_bf16_probe", False, True, True), ("conch_gemm1w_fp8_bf16_alt", False, False, False),
-                                  ("conch_gemm1w_fp8_bf16_alt_probe", False, True, False)):
-        g = Gen(name, out_fp16=fp16, probe=probe, pk=pk)
+    for name, fp16, probe, pk, int8 in (("conch_gemm1w_fp8_bf16", False, False, True, False), ("conch_gemm1w_fp8_f16", True, False, True, False),
+                                        ("conch_gemm1w_fp8_bf16_probe", False, True, True, False),
+                                        ("conch_gemm1w_fp8_bf16_alt", False, False, False, False),
+                                        ("conch_gemm1w_fp8_bf16_alt_probe", False, True, False, False),
+                                        ("conch_gemm1w_i8_bf16", False, False, True, True), ("conch_gemm1w_i8_f16", True, False, True, True)):
+        g = Gen(name, out_fp16=fp16, probe=probe, pk=pk, int8=int8)
         body = g.build()
         if text:
             body = body.split("\n", 2)[2]  # one target / code-object-version header per file

@@ -39,7 +39,7 @@ constexpr int kTileM = 256, kTileN = 352;
 
 struct Gemm1wModule {
   hipModule_t mod = nullptr;
-  hipFunction_t bf16 = nullptr, f16 = nullptr, bf16_probe = nullptr, bf16_alt = nullptr, bf16_alt_probe = nullptr;
+  hipFunction_t bf16 = nullptr, f16 = nullptr, bf16_probe = nullptr, bf16_alt = nullptr, bf16_alt_probe = nullptr, i8_bf16 = nullptr, i8_f16 = nullptr;
   int rc = CONCH_OK;
 };
 
@@ -53,6 +53,8 @@ Gemm1wModule& gemm1w_module() {
     if (e == hipSuccess) e = hipModuleGetFunction(&m.bf16_probe, m.mod, "conch_gemm1w_fp8_bf16_probe");
     if (e == hipSuccess) e = hipModuleGetFunction(&m.bf16_alt, m.mod, "conch_gemm1w_fp8_bf16_alt");
     if (e == hipSuccess) e = hipModuleGetFunction(&m.bf16_alt_probe, m.mod, "conch_gemm1w_fp8_bf16_alt_probe");
+    if (e == hipSuccess) e = hipModuleGetFunction(&m.i8_bf16, m.mod, "conch_gemm1w_i8_bf16");
+    if (e == hipSuccess) e = hipModuleGetFunction(&m.i8_f16, m.mod, "conch_gemm1w_i8_f16");
     if (e != hipSuccess) {
       set_error("scaled_gemm (one-wave-per-SIMD kernel): loading the embedded code object failed: %s", hipGetErrorString(e));
       m.rc = CONCH_ERR_HIP;
@@ -88,7 +90,7 @@ namespace conch {
 // array below 2 GiB (32-bit buffer offsets with the sign bit kept for "row out of range"), at most 65535 tiles.
 bool scaled_gemm_asm1w_supported(const ScaledGemmArgs& p) {
   if (!scaled_gemm_mfma_supported(p)) return false;
-  if (p.in_dtype != CONCH_DT_FP8_E4M3FN) return false;
+  if (p.in_dtype != CONCH_DT_FP8_E4M3FN && p.in_dtype != CONCH_DT_INT8) return false;
   if (p.out_dtype != CONCH_DT_BF16 && p.out_dtype != CONCH_DT_FP16) return false;
   if (p.bias || p.fuse_silu || p.n_more || p.split_steps || p.gate || p.a_src_dtype) return false;
   if (p.k < 512 || p.k % 256 || p.n % 16 || p.c_stride_n != 1 || (((uintptr_t)p.c) & 15)) return false;
@@ -162,8 +164,11 @@ int launch_scaled_gemm_asm1w(const ScaledGemmArgs& p, hipStream_t stream) {
   size_t size = sizeof(a);
   void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
   a.probe = p.out_dtype == CONCH_DT_BF16 ? g_gemm1w_probe.load() : nullptr;
-  const bool alt = g_gemm1w_alt.load() != 0 && p.out_dtype == CONCH_DT_BF16;
-  const hipFunction_t f = a.probe ? (alt ? mod.bf16_alt_probe : mod.bf16_probe) : alt ? mod.bf16_alt : p.out_dtype == CONCH_DT_BF16 ? mod.bf16 : mod.f16;
+  const bool fp8 = p.in_dtype == CONCH_DT_FP8_E4M3FN;
+  const bool alt = g_gemm1w_alt.load() != 0 && p.out_dtype == CONCH_DT_BF16 && fp8;
+  if (!fp8) a.probe = nullptr;
+  const hipFunction_t f = !fp8 ? (p.out_dtype == CONCH_DT_BF16 ? mod.i8_bf16 : mod.i8_f16)
+                          : a.probe ? (alt ? mod.bf16_alt_probe : mod.bf16_probe) : alt ? mod.bf16_alt : p.out_dtype == CONCH_DT_BF16 ? mod.bf16 : mod.f16;
   CONCH_HIP(hipModuleLaunchKernel(f, a.nwg, 1, 1, 256, 1, 1, 0, stream, nullptr, extra));
   return CONCH_OK;
 }

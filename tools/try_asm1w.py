@@ -22,10 +22,14 @@ from conch_amd.kernels.quantization import gemm as kgemm  # noqa: E402
 from conch_amd.ops.quantization.gemm import create_scaled_metadata, scaled_gemm  # noqa: E402
 
 
-def inputs(m, k, n, vec_a=True, vec_b=True, seed=0):
+def inputs(m, k, n, vec_a=True, vec_b=True, seed=0, int8=False):
     g = torch.Generator(device="cuda").manual_seed(seed)
-    a = (0.25 * torch.rand((m, k), device="cuda", generator=g)).to(torch.float8_e4m3fn)
-    bt = (0.25 * torch.rand((n, k), device="cuda", generator=g)).to(torch.float8_e4m3fn)
+    if int8:
+        a = torch.randint(-32, 32, (m, k), device="cuda", generator=g, dtype=torch.int8)
+        bt = torch.randint(-32, 32, (n, k), device="cuda", generator=g, dtype=torch.int8)
+    else:
+        a = (0.25 * torch.rand((m, k), device="cuda", generator=g)).to(torch.float8_e4m3fn)
+        bt = (0.25 * torch.rand((n, k), device="cuda", generator=g)).to(torch.float8_e4m3fn)
     sa = 0.25 * torch.rand((m, 1) if vec_a else (1, 1), device="cuda", generator=g) + 0.01
     sb = 0.25 * torch.rand((n, 1) if vec_b else (1, 1), device="cuda", generator=g) + 0.01
     return a, bt.T, sa, sb
@@ -75,6 +79,15 @@ def check() -> int:
                     print(f"MISMATCH {tag}: {nd} of {m * n} elements differ, max |diff| {err:.4g} (max |ref| {ref.float().abs().max().item():.4g}); {where(diff)}", flush=True)
                 else:
                     print(f"ok       {tag}", flush=True)
+    for m, k, n in ((256, 512, 352), (300, 768, 400), (1000, 2048, 1008), (4096, 4096, 11008)):
+        for dt in (torch.bfloat16, torch.float16):
+            a, b, sa, sb = inputs(m, k, n, seed=7, int8=True)
+            ref = run(_C.VARIANT_MFMA_PINGPONG2, a, b, sa, sb, dt)
+            got = run(_C.VARIANT_MFMA_ASM1W, a, b, sa, sb, dt)
+            diff = ref.view(torch.int16) != got.view(torch.int16)
+            nd = int(diff.sum().item())
+            bad += 1 if nd else 0
+            print((f"MISMATCH {m}x{k}x{n} int8 {str(dt)[6:]}: {nd} differ; {where(diff)}" if nd else f"ok       {m}x{k}x{n} int8 {str(dt)[6:]}"), flush=True)
     for m, k, n in ((512, 1024, 704), (4096, 4096, 11008)):
         a, b, sa, sb = inputs(m, k, n, seed=5)
         ref = run(_C.VARIANT_MFMA_PINGPONG2, a, b, sa, sb, torch.bfloat16)
@@ -131,6 +144,25 @@ def bench(rounds: int) -> None:
             print(f"{m}x{k}x{n}  {name}: median {med * 1e3:8.1f} us  min {xs[0] * 1e3:8.1f} us   {flops / med / 1e9:7.1f} TFLOP/s = {flops / med / 1e9 / 5000:.3f} of 5 PF", flush=True)
 
 
+def bench_int8(rounds: int) -> None:
+    m, k, n = 4096, 4096, 11008
+    a, b, sa, sb = inputs(m, k, n, int8=True)
+    out = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
+    flops = 2.0 * m * n * k
+    for v in (5, 7):
+        t_end = time.perf_counter() + 0.7
+        while time.perf_counter() < t_end:
+            timer(v, a, b, sa, sb, out, 200)
+    res = {5: [], 7: []}
+    for _ in range(rounds):
+        for v in (5, 7):
+            res[v].append(timer(v, a, b, sa, sb, out, 200))
+    for v in (5, 7):
+        xs = sorted(res[v])
+        med = xs[len(xs) // 2]
+        print(f"int8 {m}x{k}x{n} variant {v}: median {med * 1e3:8.1f} us   {flops / med / 1e9:7.1f} TOP/s = {flops / med / 1e9 / 5000:.3f} of 5 POP/s", flush=True)
+
+
 def probe(m=4096, k=4096, n=11008, seconds=1.5, alt=False) -> None:
     """In-kernel stamps of the diagnostic twin under sustained load: where a workgroup's time goes and the clock it holds."""
     lib = _C.load()
@@ -159,6 +191,15 @@ def probe(m=4096, k=4096, n=11008, seconds=1.5, alt=False) -> None:
         cyc = (clk[:, i + 1] - clk[:, i]).median().item()
         extra = f"  = {cyc / steps:7.0f} cycles per step ({SLOT_CYC * 88} are MFMA)" if i == 1 else ""
         print(f"  {name:32s} {us:8.2f} us  {cyc:10.0f} cycles  clock {cyc / max(us, 1e-9) / 1e3:5.2f} GHz{extra}")
+    wg = torch.arange(nwg)
+    per_xcd = []
+    for x in range(8):
+        sel = (wg % 8) == x
+        loop_us = ((rt[sel, 2] - rt[sel, 1]) / 100.0)
+        ghz = ((clk[sel, 2] - clk[sel, 1]) / (rt[sel, 2] - rt[sel, 1]) / 10.0)
+        total = ((rt[sel, 4] - rt[sel, 0]) / 100.0)
+        per_xcd.append(f"{x}: loop {loop_us.median().item():.1f} (max {loop_us.max().item():.1f}) us @ {ghz.median().item():.2f} GHz, workgroup {total.median().item():.1f} (max {total.max().item():.1f})")
+    print("  per XCD (workgroup id % 8): " + "; ".join(per_xcd))
     t0 = rt[:, 0].min()
     first = ((rt[:, 0] - t0) / 100.0)
     last = ((rt[:, 4] - t0) / 100.0)
@@ -181,6 +222,7 @@ if __name__ == "__main__":
         print(f"check: {rc} mismatching case(s)", flush=True)
     if not args.check_only:
         bench(args.rounds)
+        bench_int8(args.rounds)
     if args.probe:
         probe()
         probe(alt=True)
