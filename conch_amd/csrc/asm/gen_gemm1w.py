@@ -93,7 +93,7 @@ def acc_reg(i: int, j: int) -> str:
 
 
 class Gen:
-    def __init__(self, name: str, out_fp16: bool = False, probe: bool = False, rows: bool = True, pk: bool = True, int8: bool = False):
+    def __init__(self, name: str, out_fp16: bool = False, probe: bool = False, rows: bool = True, pk: bool = True, int8: bool = False, chains: int = 4):
         self.name = name
         self.probe = probe
         self.lines: list[str] = []
@@ -101,6 +101,7 @@ class Gen:
         self.out_fp16 = out_fp16
         self.rows = rows
         self.pk = pk
+        self.chains = chains
         self.int8 = int8          # int8 operands: 2 x v_mfma_i32_16x16x64_i8 per tile and step, int32 accumulators
 
     def L(self, s: str) -> str:
@@ -481,8 +482,8 @@ class Gen:
         gbase = V_FA + 54            # v86: C byte offset of this lane's 16 bytes (row group 0, column group 0)
         gmask = V_FA + 55            # v87: the same, or out of range for the lanes past the row's 22nd chunk (column group 2)
         xa, xb = V_FA + 56, V_FA + 62  # v88..93, v94..99: temporaries of the two interleaved conversions (even-aligned)
-        buf = V_E                    # v120..127: 2 x 4 data registers of the read-back
-        assert xb + 6 <= V_E and buf + 8 <= V_ACC and 2 * BUF <= REGION
+        buf = V_E                    # v120..135: 4 x 4 data registers of the read-back
+        assert buf + 16 <= V_ACC and 2 * BUF <= REGION
         # row scales
         e(f"s_lshl_b32 s{T}, s{S_WR}, 7")
         e(f"v_add_u32 v{xa}, s{T}, v{vc}")
@@ -531,38 +532,56 @@ class Gen:
 
         def read_unit(p: int, u: int) -> None:
             rg, cg = units[u]
-            b = buf + 4 * (u % 2)
+            b = buf + 4 * (u % 4)
             e(f"ds_read_b128 v[{b}:{b + 3}], v{rbase} offset:{(p % 2) * BUF + rg * 8 * PITCH + cg * 128}")
 
         def store_unit(u: int) -> None:
             rg, cg = units[u]
-            b = buf + 4 * (u % 2)
+            b = buf + 4 * (u % 4)
             e(f"buffer_store_dwordx4 v[{b}:{b + 3}], v{gmask if cg == 2 else gbase}, s[{S_DC}:{S_DC + 3}], s{T + 6} offen offset:{cg * 128}")
             if cg == 2:
                 e(f"s_add_u32 s{T + 6}, s{T + 6}, s{T + 5}", "next row group")
 
+        G = self.chains             # conversion chains interleaved (a lone wave pays the VALU latency of every dependent pair)
+        xs = [xa + 6 * c for c in range(G)]
+        assert xs[-1] + 6 <= V_E
         for p in range(4):
             self.c(f"---- pass {p}: m tiles {2 * p}, {2 * p + 1} -> buffer {p % 2}" + (f"; image of pass {p - 1} read back and stored in between" if p else "") + " ----")
+            tiles = [(2 * p + ii, j) for j in range(NT) for ii in range(2)]
+            groups = [tiles[k:k + G] for k in range(0, len(tiles), G)]
+            per = -(-len(units) // len(groups))          # read-back units handled per group boundary
+            nxt = 0                                      # next unit of pass p - 1 to read
+            pending: list[int] = []
             if p:
-                read_unit(p - 1, 0)
-            for j in range(NT):
-                oa = self.convert_ops(2 * p, j, sa, sb + 4 * j, xa)
-                ob = self.convert_ops(2 * p + 1, j, sa, sb + 4 * j, xb)
-                for k in range(max(len(oa), len(ob))):
-                    if k < len(oa):
-                        e(oa[k])
-                    if k < len(ob):
-                        e(ob[k])
+                for _ in range(per):
+                    if nxt < len(units):
+                        read_unit(p - 1, nxt)
+                        pending.append(nxt)
+                        nxt += 1
+            for grp in groups:
+                ops = [self.convert_ops(i, j, sa, sb + 4 * j, xs[c]) for c, (i, j) in enumerate(grp)]
+                for k in range(max(len(o) for o in ops)):
+                    for o in ops:
+                        if k < len(o):
+                            e(o[k])
                 if p:
-                    e("s_waitcnt lgkmcnt(0)", "the unit read one pair ago (and this wave's earlier image writes)")
-                    store_unit(j)
-                e(f"ds_write_b64 v{waddr}, v[{xa + 4}:{xa + 5}] offset:{(p % 2) * BUF + 32 * j}")
-                e(f"ds_write_b64 v{waddr}, v[{xb + 4}:{xb + 5}] offset:{(p % 2) * BUF + 16 * PITCH + 32 * j}")
+                    e("s_waitcnt lgkmcnt(0)", "the units read one group ago (and this wave's earlier image writes)")
+                    for u in pending:
+                        store_unit(u)
+                    pending = []
+                for c, (i, j) in enumerate(grp):
+                    e(f"ds_write_b64 v{waddr}, v[{xs[c] + 4}:{xs[c] + 5}] offset:{(p % 2) * BUF + (i - 2 * p) * 16 * PITCH + 32 * j}")
                 if p:
-                    read_unit(p - 1, j + 1)
+                    for _ in range(per):
+                        if nxt < len(units):
+                            read_unit(p - 1, nxt)
+                            pending.append(nxt)
+                            nxt += 1
             if p:
                 e("s_waitcnt lgkmcnt(0)")
-                store_unit(NT)
+                for u in pending:
+                    store_unit(u)
+                assert nxt == len(units)
         self.c("---- image of pass 3 ----")
         e("s_waitcnt lgkmcnt(0)")
         read_unit(3, 0)
@@ -820,7 +839,7 @@ def main() -> None:
                                         ("conch_gemm1w_fp8_bf16_alt", False, False, False, False),
                                         ("conch_gemm1w_fp8_bf16_alt_probe", False, True, False, False),
                                         ("conch_gemm1w_i8_bf16", False, False, True, True), ("conch_gemm1w_i8_f16", True, False, True, True)):
-        g = Gen(name, out_fp16=fp16, probe=probe, pk=pk, int8=int8)
+        g = Gen(name, out_fp16=fp16, probe=probe, pk=True, int8=int8, chains=4 if pk else 2)  # the A/B twin: two chains
         body = g.build()
         if text:
             body = body.split("\n", 2)[2]  # one target / code-object-version header per file

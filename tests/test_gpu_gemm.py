@@ -440,17 +440,18 @@ def test_scaled_gemm_every_kernel_variant(variant, iname, m, k, n):
     check_scaled(run_scaled(a, b, sa, sb, torch.bfloat16, bias), ref, IN_T[iname], torch.bfloat16)
 
 
+@pytest.mark.parametrize("iname", ["fn", "int8"])
 @pytest.mark.parametrize("oname", ["bf16", "f16"])
 @pytest.mark.parametrize(("vec_a", "vec_b"), [(True, True), (False, False), (True, False)])
 @pytest.mark.parametrize(("m", "k", "n"), [(256, 512, 352), (256, 512, 176), (256, 1024, 704), (512, 768, 352), (128, 512, 352), (300, 768, 400),
                                              (1000, 2048, 1008), (257, 512, 368), (2304, 1024, 1056), (16, 512, 16)])
-def test_asm1w_kernel_is_bit_identical_and_correct(_reset_tuning, m, k, n, vec_a, vec_b, oname):
+def test_asm1w_kernel_is_bit_identical_and_correct(_reset_tuning, m, k, n, vec_a, vec_b, oname, iname):
     """The one-wave-per-SIMD assembly kernel (round 5; csrc/asm/gen_gemm1w.py: 256 x 352 tiles, 352 accumulators per wave, two
     workgroup barriers per K step) against the 256 x 256-tile HIP kernel: the same MFMA on the same 128-byte K steps in the same
     order and the same epilogue arithmetic -- the same bits -- on single tiles, ragged M and N (the direct-store epilogue of edge
     waves beside the row-major one of whole waves), one raster group of every height 1..8 (+ a partial ninth), scalar and vector
     scales, both output dtypes; and against the oracle per element."""
-    a, b, sa, sb, _ = make_scaled_inputs(m, k, n, torch.float8_e4m3fn, DT[oname], not vec_a, not vec_b, False)
+    a, b, sa, sb, _ = make_scaled_inputs(m, k, n, IN_T[iname], DT[oname], not vec_a, not vec_b, False)
     _C.set_gemm_variant(_C.VARIANT_MFMA_PINGPONG2)
     want = run_scaled(a, b, sa, sb, DT[oname], None)
     _C.set_gemm_variant(_C.VARIANT_MFMA_ASM1W)
@@ -459,17 +460,17 @@ def test_asm1w_kernel_is_bit_identical_and_correct(_reset_tuning, m, k, n, vec_a
         assert torch.equal(got.view(torch.int16), want.view(torch.int16)), f"{(got != want).sum().item()} elements differ"
     _C.set_gemm_variant(_C.VARIANT_AUTO)
     ref = oracle.scaled_gemm_ref(a, b, sa, sb, DT[oname], None)
-    check_scaled(got, ref, torch.float8_e4m3fn, DT[oname], (a, b, sa, sb, None))
+    check_scaled(got, ref, IN_T[iname], DT[oname], (a, b, sa, sb, None))
 
 
 def test_asm1w_kernel_contract_is_enforced(_reset_tuning):
-    """Forced onto a problem outside its contract (bias; int8; K not a multiple of 256) the variant refuses with the library's
+    """Forced onto a problem outside its contract (bias; e4m3fnuz; K not a multiple of 256) the variant refuses with the library's
     UNSUPPORTED status -- it never runs something else silently."""
     _C.set_gemm_variant(_C.VARIANT_MFMA_ASM1W)
     a, b, sa, sb, bias = make_scaled_inputs(256, 512, 352, torch.float8_e4m3fn, torch.bfloat16, False, False, True)
     with pytest.raises(NotImplementedError):
         run_scaled(a, b, sa, sb, torch.bfloat16, bias)
-    a8, b8, sa8, sb8, _ = make_scaled_inputs(256, 512, 352, torch.int8, torch.bfloat16, False, False, False)
+    a8, b8, sa8, sb8, _ = make_scaled_inputs(256, 512, 352, torch.float8_e4m3fnuz, torch.bfloat16, False, False, False)
     with pytest.raises(NotImplementedError):
         run_scaled(a8, b8, sa8, sb8, torch.bfloat16, None)
     a3, b3, sa3, sb3, _ = make_scaled_inputs(256, 384, 352, torch.float8_e4m3fn, torch.bfloat16, False, False, False)
