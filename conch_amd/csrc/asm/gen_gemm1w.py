@@ -38,9 +38,10 @@ TILE_M, TILE_N = 256, 2 * 16 * NT            # 256 x 352
 A_BYTES = TILE_M * 128                       # 32 KiB of a stage
 B_WAVECOL = 16 * NT * 128                    # 22528: one wave column's rows of a stage
 STAGE = A_BYTES + 2 * B_WAVECOL              # 77824
-LDS_SA = 2 * STAGE                           # 155648: float sa[256]
+LDS_SA = 2 * STAGE                           # 155648: float sa[256] of scale buffer 0
 LDS_SB = LDS_SA + 1024                       # float sb[512] (352 used)
-LDS_TOTAL = LDS_SB + 2048                    # 158720
+SCALE_BUF = 3072                             # two scale buffers: the current tile's, and the next tile's parked under the epilogue
+LDS_TOTAL = LDS_SA + 2 * SCALE_BUF           # 161792 of 163840
 SLOTS = MT * NT                              # 88 MFMAs per step and wave
 Z_SLOT, X_SLOT = 36, 76                      # barrier in FRONT of this slot's MFMA
 PIECES_Z, PIECES_X = 14, 5                   # LDS-DMA pieces issued behind each barrier (8 A + B tiles 0-5 | B tiles 6-10)
@@ -52,7 +53,7 @@ S_WG = 2
 S_A, S_B, S_C, S_SA = 8, 10, 12, 14          # pointers (pairs) as loaded
 S_SB = 16
 S_M, S_N, S_K, S_LDA, S_LDB, S_LDC = 18, 19, 20, 21, 22, 23
-S_TM, S_TN, S_NWG, S_MAGIC_PG, S_SHIFT_PG, S_MAGIC_LAST, S_SAVEC, S_SBVEC = 24, 25, 26, 27, 28, 29, 30, 31
+S_TM, S_TN, S_NWG, S_MAGIC_PG, S_GRID, S_MAGIC_LAST, S_SAVEC, S_SBVEC = 24, 25, 26, 27, 28, 29, 30, 31
 S_ACCSCALE, S_OUTDT = 32, 33
 S_T = 34            # s34..s47 temporaries
 S_WAVE, S_WR, S_WC = 48, 49, 50
@@ -66,7 +67,12 @@ S_NVALID = 72                                # n tiles of this wave that start b
 S_PROBE = 74                                 # s[74:75]: debug buffer of the diagnostic build (kernarg offset 104; 0 = none)
 S_STAMP = 76                                 # s[76:76+4*NSTAMPS): (s_memtime, s_memrealtime) pairs of the diagnostic build
 NSTAMPS = 5
-S_END = S_STAMP + 4 * NSTAMPS
+S_END = S_STAMP + 4 * NSTAMPS                # 96 (s0..s101 exist)
+S_TILE = 3                                   # tile of this pass of the persistent walk (= virtual workgroup id)
+S_TNEXT = 4                                  # tile + grid
+S_BM0N, S_BN0N = 5, 6                        # first row / column of the NEXT tile
+S_SCOFF = 7                                  # LDS offset of the current tile's scale buffer (0 or SCALE_BUF)
+S_HASNEXT = 59                               # 1 = another tile follows
 
 # VGPRs
 V_TID = 0
@@ -78,7 +84,10 @@ V_BHI = (26, 27)
 V_T = 28            # v28..v31 temporaries of the prologue
 V_FA = 32           # v32..v95: A fragments of the 8 m tiles (8 registers each)
 V_FB = 96           # v96..v119: three B fragment slots
-V_E = 120           # v120..v159: epilogue temporaries
+V_E = 120           # v120..v151: epilogue temporaries
+V_NSC = 152         # v152..154: the NEXT tile's sa / sb / sb + 256 values, loaded before the epilogue, parked in LDS after it
+V_L3 = 155          # lane >> 3                       } per-lane constants of the LDS-DMA source offsets
+V_CH16 = 156        # swizzled source chunk * 16      }
 V_ACC = 160         # v160..v255: accumulator tiles 64..87
 A_ACC = 0           # a0..a255: accumulator tiles 0..63
 
@@ -125,20 +134,21 @@ class Gen:
             self.e(f"s_memrealtime s[{S_STAMP + 4 * k + 2}:{S_STAMP + 4 * k + 3}]")
 
     def write_stamps(self) -> None:
-        """Wave 0 of every workgroup stores its stamps to probe[workgroup][NSTAMPS][2] (64-bit each) with scalar stores."""
+        """Wave 0 of every workgroup stores its stamps to probe[tile][NSTAMPS][2] (64-bit each) with scalar stores."""
         if not self.probe:
             return
         e = self.e
+        T = S_T
         e("s_waitcnt lgkmcnt(0)")
         e(f"s_cmp_lg_u32 s{S_WAVE}, 0")
         e(f"s_cbranch_scc1 {self.L('noprobe')}")
         e(f"s_cmp_eq_u64 s[{S_PROBE}:{S_PROBE + 1}], 0")
         e(f"s_cbranch_scc1 {self.L('noprobe')}")
-        e(f"s_mul_i32 s{S_T}, s{S_WG}, {16 * NSTAMPS}")
-        e(f"s_add_u32 s{S_PROBE}, s{S_PROBE}, s{S_T}")
-        e(f"s_addc_u32 s{S_PROBE + 1}, s{S_PROBE + 1}, 0")
+        e(f"s_mul_i32 s{T}, s{S_TILE}, {16 * NSTAMPS}")
+        e(f"s_add_u32 s{T + 2}, s{S_PROBE}, s{T}")
+        e(f"s_addc_u32 s{T + 3}, s{S_PROBE + 1}, 0")
         for k in range(NSTAMPS):
-            e(f"s_store_dwordx4 s[{S_STAMP + 4 * k}:{S_STAMP + 4 * k + 3}], s[{S_PROBE}:{S_PROBE + 1}], {16 * k}")
+            e(f"s_store_dwordx4 s[{S_STAMP + 4 * k}:{S_STAMP + 4 * k + 3}], s[{T + 2}:{T + 3}], {16 * k}")
         e("s_waitcnt lgkmcnt(0)")
         e("s_dcache_wb")
         self.label(self.L("noprobe"))
@@ -176,21 +186,39 @@ class Gen:
             self.ds_read128(base + 4, V_BHI[stage], 2048 * j, f"{step_tag}.B{j}.hi")
 
     # -- LDS-DMA ----------------------------------------------------------------------------------------------------------------
-    def dma_piece(self, idx: int, stage: int) -> None:
-        """Piece idx of this wave (0-7: A rows 8 (4 idx + wave) .., 8-18: B n tile idx - 8) of the step at S_KOFF into `stage`."""
+    def dma_m0(self, idx: int, stage: int) -> None:
+        """M0 = LDS destination of piece idx of this wave (0-7: A rows 8 (4 idx + wave) .., 8-18: B n tile idx - 8) in `stage`."""
         if idx < 8:
             self.e(f"s_add_i32 m0, s{S_M0A}, {stage * STAGE + 4096 * idx}")
-            self.e("s_nop 0")
+        else:
+            self.e(f"s_add_i32 m0, s{S_M0B}, {stage * STAGE + 2048 * (idx - 8)}")
+
+    def dma_load(self, idx: int, stage: int) -> None:
+        """The LDS-DMA of piece idx of the step at S_KOFF (M0 set by dma_m0, at least one instruction earlier)."""
+        if idx < 8:
             self.e(f"buffer_load_dwordx4 v{V_DMA + idx}, s[{S_DA}:{S_DA + 3}], s{S_KOFF} offen lds", f"A piece {idx} -> stage {stage}")
         else:
-            j = idx - 8
-            self.e(f"s_add_i32 m0, s{S_M0B}, {stage * STAGE + 2048 * j}")
-            self.e("s_nop 0")
-            self.e(f"buffer_load_dwordx4 v{V_DMA + idx}, s[{S_DB}:{S_DB + 3}], s{S_KOFF} offen lds", f"B tile {j} piece -> stage {stage}")
+            self.e(f"buffer_load_dwordx4 v{V_DMA + idx}, s[{S_DB}:{S_DB + 3}], s{S_KOFF} offen lds", f"B tile {idx - 8} piece -> stage {stage}")
+
+    def dma_piece(self, idx: int, stage: int) -> None:
+        self.dma_m0(idx, stage)
+        self.e("s_nop 0")
+        self.dma_load(idx, stage)
+
+    def issue_stage(self, stage: int, koff: int) -> None:
+        """All 19 pieces of this wave for the K step at byte offset `koff` into `stage` (real descriptors)."""
+        e = self.e
+        e(f"s_mov_b32 s{S_KOFF}, {koff}")
+        e(f"s_mov_b32 s{S_DA + 2}, s{S_NRA}")
+        e(f"s_mov_b32 s{S_DB + 2}, s{S_NRB}")
+        e("s_nop 3")
+        for idx in range(19):
+            self.dma_piece(idx, stage)
 
     # -- one K step -----------------------------------------------------------------------------------------------------------------
-    def step(self, st: int, tag: str, nxt: str) -> None:
-        """88 MFMA slots of the step staged in `st`; `tag` / `nxt` name this step's and the next step's fragment reads."""
+    def step(self, st: int, tag: str, nxt: str, first: bool = False) -> None:
+        """88 MFMA slots of the step staged in `st`; `tag` / `nxt` name this step's and the next step's fragment reads.
+        `first`: the tile's first K step -- the MFMAs take the constant 0 as their addend (no accumulator is zeroed anywhere)."""
         # DMA issue slots: after Z every third slot that carries no fragment read, after X every other one
         busy = {8 * j + h for j in range(NT) for h in (0, 1)} | {78, 79} | set(range(80, 88)) | {0}
         z_slots = [q for q in range(Z_SLOT, X_SLOT) if q not in busy][::2][:PIECES_Z]
@@ -211,14 +239,17 @@ class Gen:
                 self.wait_all_lds()
                 self.e("s_barrier")
             self.wait_tags([f"{tag}.A{i}.lo", f"{tag}.A{i}.hi", f"{tag}.B{j}.lo", f"{tag}.B{j}.hi"])
+            if q in dma_at:
+                self.dma_m0(dma_at[q], st)     # (the MFMA below is the wait state between the M0 write and the LDS-DMA that reads it)
             fb = V_FB + 8 * fb_slot(j)
             fa = V_FA + 8 * i
             acc = acc_reg(i, j)
+            add = "0" if first else acc
             if self.int8:
-                self.e(f"v_mfma_i32_16x16x64_i8 {acc}, v[{fb}:{fb + 3}], v[{fa}:{fa + 3}], {acc}", f"slot {q}: m tile {i}, n tile {j}, K bytes 0-63")
+                self.e(f"v_mfma_i32_16x16x64_i8 {acc}, v[{fb}:{fb + 3}], v[{fa}:{fa + 3}], {add}", f"slot {q}: m tile {i}, n tile {j}, K bytes 0-63")
                 self.e(f"v_mfma_i32_16x16x64_i8 {acc}, v[{fb + 4}:{fb + 7}], v[{fa + 4}:{fa + 7}], {acc}", "K bytes 64-127")
             else:
-                self.e(f"v_mfma_f32_16x16x128_f8f6f4 {acc}, v[{fb}:{fb + 7}], v[{fa}:{fa + 7}], {acc}", f"slot {q}: m tile {i}, n tile {j}")
+                self.e(f"v_mfma_f32_16x16x128_f8f6f4 {acc}, v[{fb}:{fb + 7}], v[{fa}:{fa + 7}], {add}", f"slot {q}: m tile {i}, n tile {j}")
             # ---- fillers behind this MFMA ----
             if q == 0:
                 self.read_fa(7, st, tag)          # FA[7] of THIS step (its registers were busy until the previous step's last MFMA)
@@ -231,9 +262,7 @@ class Gen:
             if j == NT - 1 and ii >= 1:
                 self.read_fa(ii - 1, 1 - st, nxt)   # FA[ii - 1] was last used one slot ago
             if q in dma_at:
-                k = dma_at[q]
-                piece = k if k < PIECES_Z else k   # order: A 0-7, B tiles 0-5 | B tiles 6-10
-                self.dma_piece(piece, st)
+                self.dma_load(dma_at[q], st)       # order: A 0-7, B tiles 0-5 | B tiles 6-10
             if q == 2:
                 # the step whose pieces this step issues is t + 2: past the end of K the descriptors are switched to zero
                 # records (every lane out of range: no memory traffic, zeros land in a stage nobody reads)
@@ -243,7 +272,9 @@ class Gen:
                 self.e(f"s_cselect_b32 s{S_DB + 2}, s{S_NRB}, 0")
 
     # -- whole kernel ---------------------------------------------------------------------------------------------------------------
-    def prologue(self) -> None:
+    def setup_once(self) -> None:
+        """Arguments, wave roles, descriptors, LDS-DMA destination bases, fragment read bases: everything that does not depend
+        on the tile."""
         e = self.e
         T = S_T
         e(f"s_load_dwordx8 s[8:15], s[{S_KARG}:{S_KARG + 1}], 0x0")
@@ -253,45 +284,17 @@ class Gen:
         if self.probe:
             e(f"s_load_dwordx2 s[{S_PROBE}:{S_PROBE + 1}], s[{S_KARG}:{S_KARG + 1}], 0x68")
         self.stamp(0)
+        e(f"s_mov_b32 s{S_TILE}, s{S_WG}")
+        e(f"s_mov_b32 s{S_SCOFF}, 0")
         # lane / wave
-        e(f"v_and_b32 v{V_T}, 63, v{V_TID}", "lane")
+        vl = V_T
+        e(f"v_and_b32 v{vl}, 63, v{V_TID}", "lane")
         e(f"v_lshrrev_b32 v{V_T + 1}, 6, v{V_TID}")
         e("s_nop 0")
         e(f"v_readfirstlane_b32 s{S_WAVE}, v{V_T + 1}")
         e(f"s_lshr_b32 s{S_WR}, s{S_WAVE}, 1")
         e(f"s_and_b32 s{S_WC}, s{S_WAVE}, 1")
         e("s_waitcnt lgkmcnt(0)")
-        # ---- tile of this workgroup: XCD-contiguous runs of a GROUP_M = 8 raster ----
-        e(f"s_and_b32 s{T}, s{S_WG}, 7", "xcd")
-        e(f"s_lshr_b32 s{T + 1}, s{S_WG}, 3", "index inside the XCD's run")
-        e(f"s_lshr_b32 s{T + 2}, s{S_NWG}, 3")
-        e(f"s_and_b32 s{T + 3}, s{S_NWG}, 7")
-        e(f"s_mul_i32 s{T + 4}, s{T}, s{T + 2}")
-        e(f"s_min_u32 s{T + 5}, s{T}, s{T + 3}")
-        e(f"s_add_u32 s{T + 4}, s{T + 4}, s{T + 5}")
-        e(f"s_add_u32 s{T + 4}, s{T + 4}, s{T + 1}", "lin")
-        e(f"s_mul_hi_u32 s{T + 5}, s{T + 4}, s{S_MAGIC_PG}", "group = lin / (8 tiles_n)")
-        e(f"s_lshl_b32 s{T + 6}, s{S_TN}, 3")
-        e(f"s_mul_i32 s{T + 7}, s{T + 5}, s{T + 6}")
-        e(f"s_sub_u32 s{T + 7}, s{T + 4}, s{T + 7}", "in_group")
-        e(f"s_lshl_b32 s{T + 8}, s{T + 5}, 3", "first_m")
-        e(f"s_sub_u32 s{T + 9}, s{S_TM}, s{T + 8}")
-        e(f"s_min_u32 s{T + 9}, s{T + 9}, 8", "group height")
-        e(f"s_cmp_eq_u32 s{T + 9}, 8")
-        e(f"s_cbranch_scc0 {self.L('partial_group')}")
-        e(f"s_lshr_b32 s{T + 10}, s{T + 7}, 3", "tn")
-        e(f"s_and_b32 s{T + 11}, s{T + 7}, 7", "tm in group")
-        e(f"s_branch {self.L('tile_done')}")
-        self.label(self.L("partial_group"))
-        e(f"s_mul_hi_u32 s{T + 10}, s{T + 7}, s{S_MAGIC_LAST}", "tn = in_group / height, height 2..7 (magic = ceil(2^32 / height))")
-        e(f"s_cmp_eq_u32 s{T + 9}, 1")
-        e(f"s_cselect_b32 s{T + 10}, s{T + 7}, s{T + 10}", "height 1: tn = in_group (2^32 / 1 does not fit the magic)")
-        e(f"s_mul_i32 s{T + 11}, s{T + 10}, s{T + 9}")
-        e(f"s_sub_u32 s{T + 11}, s{T + 7}, s{T + 11}")
-        self.label(self.L("tile_done"))
-        e(f"s_add_u32 s{T + 11}, s{T + 11}, s{T + 8}", "tm")
-        e(f"s_lshl_b32 s{S_BM0}, s{T + 11}, 8")
-        e(f"s_mul_i32 s{S_BN0}, s{T + 10}, {TILE_N}")
         # ---- descriptors ----
         e(f"s_sub_u32 s{T}, s{S_M}, 1")
         e(f"s_mul_i32 s{T}, s{T}, s{S_LDA}")
@@ -308,71 +311,21 @@ class Gen:
             e(f"s_and_b32 s{d + 1}, s{p + 1}, 0xffff")
             e(f"s_mov_b32 s{d + 2}, {nr}")
             e(f"s_mov_b32 s{d + 3}, 0x00020000")
-        # ---- LDS-DMA: destination bases and per-lane source offsets ----
+        # ---- LDS-DMA destination bases; per-lane constants of the source offsets ----
         e(f"s_lshl_b32 s{S_M0A}, s{S_WAVE}, 10")
         e(f"s_mul_i32 s{T}, s{S_WR}, {B_WAVECOL}", "(wave >> 1): which wave column's B rows this wave stages")
         e(f"s_lshl_b32 s{T + 1}, s{S_WC}, 10", "(wave & 1): first or second 8 rows of the n tile")
         e(f"s_add_u32 s{S_M0B}, s{T}, s{T + 1}")
         e(f"s_add_u32 s{S_M0B}, s{S_M0B}, {A_BYTES}")
-        vl, v3, vc, vr, vt = V_T, V_T + 1, V_T + 2, V_T + 3, V_E    # lane, lane >> 3, chunk * 16, row, temp
-        e(f"v_lshrrev_b32 v{v3}, 3, v{vl}")
-        e(f"v_and_b32 v{vc}, 7, v{vl}")
-        e(f"v_lshrrev_b32 v{vt}, 1, v{v3}")
+        vt = V_E
+        e(f"v_lshrrev_b32 v{V_L3}, 3, v{vl}")
+        e(f"v_and_b32 v{V_CH16}, 7, v{vl}")
+        e(f"v_lshrrev_b32 v{vt}, 1, v{V_L3}")
         e(f"s_lshl_b32 s{T}, s{S_WC}, 2")
         e(f"v_add_u32 v{vt}, s{T}, v{vt}", "swizzle = 4 (wave & 1) + (lane >> 4)")
-        e(f"v_xor_b32 v{vc}, v{vc}, v{vt}")
-        e(f"v_lshlrev_b32 v{vc}, 4, v{vc}", "source chunk * 16")
-        e(f"s_lshl_b32 s{T}, s{S_WAVE}, 3")
-        e(f"s_add_u32 s{T}, s{T}, s{S_BM0}")
-        e(f"v_add_u32 v{vr}, s{T}, v{v3}", "A row of piece 0")
-        e(f"s_sub_u32 s{T + 1}, s{S_M}, 1")
-        for p in range(8):
-            e(f"v_add_u32 v{vt}, {32 * p}, v{vr}")
-            e(f"v_min_u32 v{vt}, s{T + 1}, v{vt}")
-            e(f"v_mul_lo_u32 v{vt}, v{vt}, s{S_LDA}")
-            e(f"v_add_u32 v{V_DMA + p}, v{vt}, v{vc}")
-        e(f"s_mul_i32 s{T}, s{S_WR}, {16 * NT}")
-        e(f"s_lshl_b32 s{T + 2}, s{S_WC}, 3")
-        e(f"s_add_u32 s{T}, s{T}, s{T + 2}")
-        e(f"s_add_u32 s{T}, s{T}, s{S_BN0}")
-        e(f"v_add_u32 v{vr}, s{T}, v{v3}", "B^T row of n tile 0's piece")
-        e(f"s_sub_u32 s{T + 1}, s{S_N}, 1")
-        for j in range(NT):
-            e(f"v_add_u32 v{vt}, {16 * j}, v{vr}")
-            e(f"v_min_u32 v{vt}, s{T + 1}, v{vt}")
-            e(f"v_mul_lo_u32 v{vt}, v{vt}, s{S_LDB}")
-            e(f"v_add_u32 v{V_DMA + 8 + j}, v{vt}, v{vc}")
-        # ---- scales of this tile: loads now, parked in LDS behind the first DMA pieces ----
-        vsa, vsb1, vsb2 = V_E + 1, V_E + 2, V_E + 3
-        e(f"v_add_u32 v{vt}, s{S_BM0}, v{V_TID}")
-        e(f"s_sub_u32 s{T}, s{S_M}, 1")
-        e(f"v_min_u32 v{vt}, s{T}, v{vt}")
-        e(f"s_cmp_lg_u32 s{S_SAVEC}, 0")
-        e(f"s_cselect_b32 s{T + 2}, -1, 0")
-        e(f"v_and_b32 v{vt}, s{T + 2}, v{vt}", "scalar scale: element 0")
-        e(f"v_lshlrev_b32 v{vt}, 2, v{vt}")
-        e(f"global_load_dword v{vsa}, v{vt}, s[{S_SA}:{S_SA + 1}]")
-        e(f"s_sub_u32 s{T}, s{S_N}, 1")
-        e(f"s_cmp_lg_u32 s{S_SBVEC}, 0")
-        e(f"s_cselect_b32 s{T + 2}, -1, 0")
-        for k, dst in ((0, vsb1), (256, vsb2)):
-            e(f"v_add_u32 v{vt}, s{S_BN0}, v{V_TID}")
-            if k:
-                e(f"v_add_u32 v{vt}, {k}, v{vt}")
-            e(f"v_min_u32 v{vt}, s{T}, v{vt}")
-            e(f"v_and_b32 v{vt}, s{T + 2}, v{vt}")
-            e(f"v_lshlrev_b32 v{vt}, 2, v{vt}")
-            e(f"global_load_dword v{dst}, v{vt}, s[{S_SB}:{S_SB + 1}]")
-        # ---- first two stages in flight ----
-        e(f"s_mov_b32 s{S_KOFF}, 0")
-        e("s_nop 3")
-        for idx in range(19):
-            self.dma_piece(idx, 0)
-        e(f"s_mov_b32 s{S_KOFF}, 128")
-        e("s_nop 3")
-        for idx in range(19):
-            self.dma_piece(idx, 1)
-        # fragment read bases
+        e(f"v_xor_b32 v{V_CH16}, v{V_CH16}, v{vt}")
+        e(f"v_lshlrev_b32 v{V_CH16}, 4, v{V_CH16}", "source chunk * 16")
+        # ---- fragment read bases ----
         r, g, lo = V_E + 4, V_E + 5, V_E + 6
         e(f"v_and_b32 v{r}, 15, v{vl}")
         e(f"v_lshrrev_b32 v{g}, 4, v{vl}")
@@ -396,34 +349,137 @@ class Gen:
         e(f"s_mov_b32 s{T}, {STAGE}")
         for pair in (V_ALO, V_AHI, V_BLO, V_BHI):
             e(f"v_add_u32 v{pair[1]}, s{T}, v{pair[0]}")
-        # accumulators
-        for k in range(256):
-            e(f"v_accvgpr_write_b32 a{k}, 0")
-        for k in range(96):
-            e(f"v_mov_b32 v{V_ACC + k}, 0")
-        # park the scales (the three loads are the oldest vector-memory operations)
-        e("s_waitcnt vmcnt(38)")
-        e(f"v_mul_f32 v{vsa}, s{S_ACCSCALE}, v{vsa}", "acc_scale: 1, or the exact 1/4 of e4m3fnuz bytes run as OCP e4m3")
+
+    def tile_coords(self, tile: int, bm0: int, bn0: int, site: str) -> None:
+        """First row / column of tile `tile` (SGPR numbers): XCD-contiguous runs of a GROUP_M = 8 raster over tile ids; the
+        persistent walk visits ids wg, wg + grid, ... (grid a multiple of 8 or the whole problem: the XCD of an id stays)."""
+        e = self.e
+        T = S_T
+        e(f"s_and_b32 s{T}, s{tile}, 7", "xcd")
+        e(f"s_lshr_b32 s{T + 1}, s{tile}, 3", "index inside the XCD's run")
+        e(f"s_lshr_b32 s{T + 2}, s{S_NWG}, 3")
+        e(f"s_and_b32 s{T + 3}, s{S_NWG}, 7")
+        e(f"s_mul_i32 s{T + 4}, s{T}, s{T + 2}")
+        e(f"s_min_u32 s{T + 5}, s{T}, s{T + 3}")
+        e(f"s_add_u32 s{T + 4}, s{T + 4}, s{T + 5}")
+        e(f"s_add_u32 s{T + 4}, s{T + 4}, s{T + 1}", "lin")
+        e(f"s_mul_hi_u32 s{T + 5}, s{T + 4}, s{S_MAGIC_PG}", "group = lin / (8 tiles_n)")
+        e(f"s_lshl_b32 s{T + 6}, s{S_TN}, 3")
+        e(f"s_mul_i32 s{T + 7}, s{T + 5}, s{T + 6}")
+        e(f"s_sub_u32 s{T + 7}, s{T + 4}, s{T + 7}", "in_group")
+        e(f"s_lshl_b32 s{T + 8}, s{T + 5}, 3", "first_m")
+        e(f"s_sub_u32 s{T + 9}, s{S_TM}, s{T + 8}")
+        e(f"s_min_u32 s{T + 9}, s{T + 9}, 8", "group height")
+        e(f"s_cmp_eq_u32 s{T + 9}, 8")
+        e(f"s_cbranch_scc0 {self.L('partial_group_' + site)}")
+        e(f"s_lshr_b32 s{T + 10}, s{T + 7}, 3", "tn")
+        e(f"s_and_b32 s{T + 11}, s{T + 7}, 7", "tm in group")
+        e(f"s_branch {self.L('tile_done_' + site)}")
+        self.label(self.L("partial_group_" + site))
+        e(f"s_mul_hi_u32 s{T + 10}, s{T + 7}, s{S_MAGIC_LAST}", "tn = in_group / height, height 2..7 (magic = ceil(2^32 / height))")
+        e(f"s_cmp_eq_u32 s{T + 9}, 1")
+        e(f"s_cselect_b32 s{T + 10}, s{T + 7}, s{T + 10}", "height 1: tn = in_group (2^32 / 1 does not fit the magic)")
+        e(f"s_mul_i32 s{T + 11}, s{T + 10}, s{T + 9}")
+        e(f"s_sub_u32 s{T + 11}, s{T + 7}, s{T + 11}")
+        self.label(self.L("tile_done_" + site))
+        e(f"s_add_u32 s{T + 11}, s{T + 11}, s{T + 8}", "tm")
+        e(f"s_lshl_b32 s{bm0}, s{T + 11}, 8")
+        e(f"s_mul_i32 s{bn0}, s{T + 10}, {TILE_N}")
+
+    def tile_sources(self, bm0: int, bn0: int) -> None:
+        """Per-lane source byte offsets of this wave's 19 LDS-DMA pieces for the tile at (s[bm0], s[bn0]) -> v1..v19, and the
+        tile's scale loads -> v[V_NSC : V_NSC + 3] (parked in LDS later)."""
+        e = self.e
+        T = S_T
+        vr, vt = V_T + 3, V_E
+        e(f"s_lshl_b32 s{T}, s{S_WAVE}, 3")
+        e(f"s_add_u32 s{T}, s{T}, s{bm0}")
+        e(f"v_add_u32 v{vr}, s{T}, v{V_L3}", "A row of piece 0")
+        e(f"s_sub_u32 s{T + 1}, s{S_M}, 1")
+        for p in range(8):
+            e(f"v_add_u32 v{vt}, {32 * p}, v{vr}")
+            e(f"v_min_u32 v{vt}, s{T + 1}, v{vt}")
+            e(f"v_mul_lo_u32 v{vt}, v{vt}, s{S_LDA}")
+            e(f"v_add_u32 v{V_DMA + p}, v{vt}, v{V_CH16}")
+        e(f"s_mul_i32 s{T}, s{S_WR}, {16 * NT}")
+        e(f"s_lshl_b32 s{T + 2}, s{S_WC}, 3")
+        e(f"s_add_u32 s{T}, s{T}, s{T + 2}")
+        e(f"s_add_u32 s{T}, s{T}, s{bn0}")
+        e(f"v_add_u32 v{vr}, s{T}, v{V_L3}", "B^T row of n tile 0's piece")
+        e(f"s_sub_u32 s{T + 1}, s{S_N}, 1")
+        for j in range(NT):
+            e(f"v_add_u32 v{vt}, {16 * j}, v{vr}")
+            e(f"v_min_u32 v{vt}, s{T + 1}, v{vt}")
+            e(f"v_mul_lo_u32 v{vt}, v{vt}, s{S_LDB}")
+            e(f"v_add_u32 v{V_DMA + 8 + j}, v{vt}, v{V_CH16}")
+        # scales
+        e(f"v_add_u32 v{vt}, s{bm0}, v{V_TID}")
+        e(f"s_sub_u32 s{T}, s{S_M}, 1")
+        e(f"v_min_u32 v{vt}, s{T}, v{vt}")
+        e(f"s_cmp_lg_u32 s{S_SAVEC}, 0")
+        e(f"s_cselect_b32 s{T + 2}, -1, 0")
+        e(f"v_and_b32 v{vt}, s{T + 2}, v{vt}", "scalar scale: element 0")
+        e(f"v_lshlrev_b32 v{vt}, 2, v{vt}")
+        e(f"global_load_dword v{V_NSC}, v{vt}, s[{S_SA}:{S_SA + 1}]")
+        e(f"s_sub_u32 s{T}, s{S_N}, 1")
+        e(f"s_cmp_lg_u32 s{S_SBVEC}, 0")
+        e(f"s_cselect_b32 s{T + 2}, -1, 0")
+        for k, dst in ((0, V_NSC + 1), (256, V_NSC + 2)):
+            e(f"v_add_u32 v{vt}, s{bn0}, v{V_TID}")
+            if k:
+                e(f"v_add_u32 v{vt}, {k}, v{vt}")
+            e(f"v_min_u32 v{vt}, s{T}, v{vt}")
+            e(f"v_and_b32 v{vt}, s{T + 2}, v{vt}")
+            e(f"v_lshlrev_b32 v{vt}, 2, v{vt}")
+            e(f"global_load_dword v{dst}, v{vt}, s[{S_SB}:{S_SB + 1}]")
+
+    def park_scales(self) -> None:
+        """v[V_NSC..] (landed) -> the scale buffer at s[S_SCOFF]."""
+        e = self.e
+        vt = V_E
+        e(f"v_mul_f32 v{V_NSC}, s{S_ACCSCALE}, v{V_NSC}", "acc_scale: 1, or the exact 1/4 of e4m3fnuz bytes run as OCP e4m3")
         e(f"v_lshlrev_b32 v{vt}, 2, v{V_TID}")
         e(f"v_add_u32 v{vt}, {LDS_SA}, v{vt}", "(DS offsets are 16 bits: the scale area's base goes into the address)")
-        e(f"ds_write_b32 v{vt}, v{vsa}")
-        e(f"ds_write_b32 v{vt}, v{vsb1} offset:{LDS_SB - LDS_SA}")
-        e(f"ds_write_b32 v{vt}, v{vsb2} offset:{LDS_SB - LDS_SA + 1024}")
-        # loop control
-        e(f"s_lshr_b32 s{S_CNT}, s{S_K}, 8", "pairs of K steps")
-        # stage 0 landed -> first fragments
-        e("s_waitcnt vmcnt(19)")
+        e(f"v_add_u32 v{vt}, s{S_SCOFF}, v{vt}")
+        e(f"ds_write_b32 v{vt}, v{V_NSC}")
+        e(f"ds_write_b32 v{vt}, v{V_NSC + 1} offset:{LDS_SB - LDS_SA}")
+        e(f"ds_write_b32 v{vt}, v{V_NSC + 2} offset:{LDS_SB - LDS_SA + 1024}")
+
+    def first_tile(self) -> None:
+        e = self.e
+        self.tile_coords(S_TILE, S_BM0, S_BN0, "first")
+        self.tile_sources(S_BM0, S_BN0)
+        self.issue_stage(0, 0)
+        self.issue_stage(1, 128)
+        e("s_waitcnt vmcnt(38)", "the three scale loads are the oldest vector-memory operations")
+        self.park_scales()
+        e("s_waitcnt vmcnt(19)", "stage 0 of this wave has landed")
         e("s_waitcnt lgkmcnt(0)")
         e("s_barrier")
-        # (the first fragment reads follow in build(): exactly the reads a step leaves outstanding for its successor)
 
-    def loop(self) -> None:
+    def k_loop(self, steady: list[str]) -> None:
+        """First fragment reads, the peeled first pair of K steps (addend 0), the loop over the remaining pairs."""
+        e = self.e
+        for t in steady:  # exactly the reads a step leaves outstanding for its successor, in their order of issue
+            _, what, half = t.split(".")
+            kind, idx = what[0], int(what[1:])
+            if kind == "A":
+                self.ds_read128(V_FA + 8 * idx + (4 if half == "hi" else 0), (V_AHI if half == "hi" else V_ALO)[0], 2048 * idx, t)
+            else:
+                self.ds_read128(V_FB + 8 * fb_slot(idx) + (4 if half == "hi" else 0), (V_BHI if half == "hi" else V_BLO)[0], 2048 * idx, t)
+        assert self.lgkm == steady
+        e(f"s_lshr_b32 s{S_CNT}, s{S_K}, 8")
+        e(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1", "pairs of K steps behind the peeled first pair (K >= 512: at least one)")
+        self.step(0, "t0", "t1", first=True)
+        self.step(1, "t1", "t0")
+        assert self.lgkm == steady
         self.label(self.L("loop"))
         self.step(0, "t0", "t1")
         self.step(1, "t1", "t0")
-        self.e(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
-        self.e(f"s_cmp_lg_u32 s{S_CNT}, 0")
-        self.e(f"s_cbranch_scc1 {self.L('loop')}")
+        e(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
+        e(f"s_cmp_lg_u32 s{S_CNT}, 0")
+        e(f"s_cbranch_scc1 {self.L('loop')}")
+        assert self.lgkm == steady, "the loop body must leave the queue as it found it"
 
     def convert_ops(self, i: int, j: int, sa: int, sb: int, x: int) -> list[str]:
         """Instructions that turn accumulator tile (i, j) into two registers v[x + 4 : x + 5] of packed 16-bit outputs:
@@ -460,35 +516,38 @@ class Gen:
             ops.append(f"v_cvt_pk_bf16_f32 v{x + 5}, v{x + 2}, v{x + 3}")
         return ops
 
+    ROWS_STORES = 48   # buffer_store_dwordx4 per wave in epilogue_rows (8 passes x 2 row groups x 3 column groups)
+
     def epilogue_rows(self, vc: int, vg: int) -> None:
-        """Whole wave sub-tiles (128 x 176 inside M x N): every wave parks its cast outputs in ITS OWN 24 KiB of the dead operand
-        LDS as a row-major image -- four passes of two m tiles (32 rows x 352 bytes at a pitch of 368) through two alternating
-        buffers -- reads the previous pass's image back 16 bytes per lane (a wave instruction = 8 rows x 128 contiguous bytes)
-        and stores it with buffer_store_dwordx4 BETWEEN the conversions of the current pass: 8 line segments per store
-        instruction instead of 64 (T21 of the programming guide; profiles/r03/store_rate.txt), and the stores drain under the
-        conversion arithmetic.  A wave's LDS operations execute in order, so no barrier separates its writes from its reads.
-        Two tiles' conversion chains are interleaved (a lone wave pays every dependent VALU latency itself), the 44 column
-        scales are read once, and every read-back / store address is one per-lane base + an immediate (+ a scalar row-group
-        offset)."""
+        """Whole wave sub-tiles (128 x 176 inside M x N): every wave parks its cast outputs in ITS OWN 19 KiB of the dead STAGE-1
+        operand LDS (stage 0 may already be receiving the next tile) as a row-major image -- eight passes of one m tile (16 rows x
+        352 bytes at a pitch of 368) through two alternating buffers -- reads the previous pass's image back 16 bytes per lane (a
+        wave instruction = 8 rows x 128 contiguous bytes) and stores it with buffer_store_dwordx4 BETWEEN the conversions of the
+        current pass: 8 line segments per store instruction instead of 64 (T21 of the programming guide;
+        profiles/r03/store_rate.txt).  A wave's LDS operations execute in order, so no barrier separates its writes from its
+        reads.  Four tiles' conversion chains are interleaved, the 44 column scales are read once, and every read-back / store
+        address is one per-lane base + an immediate (+ a scalar row-group offset)."""
         e = self.e
         T = S_T
         PITCH = 368
-        REGION = 24576
-        BUF = 32 * PITCH             # 11776: one pass's image
+        REGION = STAGE // 4          # 19456 per wave, inside stage 1
+        BUF = 16 * PITCH             # 5888: one pass's image
         sa = V_FA                    # v32..39: 8 row scales (even-aligned)
         sb = V_FA + 8                # v40..83: 4 column scales per n tile
-        waddr = V_FA + 52            # v84: LDS write address of this lane (first m tile of a pass, n tile 0, buffer 0)
+        waddr = V_FA + 52            # v84: LDS write address of this lane (row c of the pass's m tile, n tile 0, buffer 0)
         rbase = V_FA + 53            # v85: LDS read-back address of this lane (row group 0, column group 0, buffer 0)
         gbase = V_FA + 54            # v86: C byte offset of this lane's 16 bytes (row group 0, column group 0)
         gmask = V_FA + 55            # v87: the same, or out of range for the lanes past the row's 22nd chunk (column group 2)
-        xa, xb = V_FA + 56, V_FA + 62  # v88..93, v94..99: temporaries of the two interleaved conversions (even-aligned)
+        xa = V_FA + 56               # v88..: 6 temporaries per interleaved conversion chain (even-aligned)
+        xb = xa + 6
         buf = V_E                    # v120..135: 4 x 4 data registers of the read-back
-        assert buf + 16 <= V_ACC and 2 * BUF <= REGION
+        assert buf + 16 <= V_NSC and 2 * BUF <= REGION
         # row scales
         e(f"s_lshl_b32 s{T}, s{S_WR}, 7")
         e(f"v_add_u32 v{xa}, s{T}, v{vc}")
         e(f"v_lshlrev_b32 v{xa}, 2, v{xa}")
         e(f"v_add_u32 v{xa}, {LDS_SA}, v{xa}")
+        e(f"v_add_u32 v{xa}, s{S_SCOFF}, v{xa}", "this tile's scale buffer")
         for i in range(MT):
             e(f"ds_read_b32 v{sa + i}, v{xa} offset:{64 * i}")
         # column scales of all 11 n tiles
@@ -497,10 +556,12 @@ class Gen:
         e(f"v_add_u32 v{xa + 1}, s{T}, v{xa + 1}")
         e(f"v_lshlrev_b32 v{xa + 1}, 2, v{xa + 1}")
         e(f"v_add_u32 v{xa + 1}, {LDS_SB}, v{xa + 1}")
+        e(f"v_add_u32 v{xa + 1}, s{S_SCOFF}, v{xa + 1}")
         for j in range(NT):
             e(f"ds_read_b128 v[{sb + 4 * j}:{sb + 4 * j + 3}], v{xa + 1} offset:{64 * j}")
         # this lane's write address inside the wave's region: row c, byte 8 g
-        e(f"s_mul_i32 s{T + 1}, s{S_WAVE}, {REGION}", "the wave's staging region")
+        e(f"s_mul_i32 s{T + 1}, s{S_WAVE}, {REGION}")
+        e(f"s_add_u32 s{T + 1}, s{T + 1}, {STAGE}", "the wave's staging region (stage 1)")
         e(f"v_mul_u32_u24 v{waddr}, {PITCH}, v{vc}")
         e(f"v_lshl_add_u32 v{waddr}, v{vg}, 3, v{waddr}")
         e(f"v_add_u32 v{waddr}, s{T + 1}, v{waddr}")
@@ -528,7 +589,8 @@ class Gen:
         e(f"s_lshl_b32 s{T + 5}, s{T + 2}, 3", "8 rows of C in bytes: one row group")
         e(f"s_mov_b32 s{T + 6}, 0", "scalar offset of the row group being stored")
         e("s_waitcnt lgkmcnt(0)")
-        units = [(rg, cg) for rg in range(4) for cg in range(3)]   # of one pass's image: 4 row groups x 3 column groups
+        units = [(rg, cg) for rg in range(2) for cg in range(3)]   # of one pass's image: 2 row groups x 3 column groups
+        stores = 0
 
         def read_unit(p: int, u: int) -> None:
             rg, cg = units[u]
@@ -536,18 +598,20 @@ class Gen:
             e(f"ds_read_b128 v[{b}:{b + 3}], v{rbase} offset:{(p % 2) * BUF + rg * 8 * PITCH + cg * 128}")
 
         def store_unit(u: int) -> None:
+            nonlocal stores
             rg, cg = units[u]
             b = buf + 4 * (u % 4)
             e(f"buffer_store_dwordx4 v[{b}:{b + 3}], v{gmask if cg == 2 else gbase}, s[{S_DC}:{S_DC + 3}], s{T + 6} offen offset:{cg * 128}")
+            stores += 1
             if cg == 2:
                 e(f"s_add_u32 s{T + 6}, s{T + 6}, s{T + 5}", "next row group")
 
         G = self.chains             # conversion chains interleaved (a lone wave pays the VALU latency of every dependent pair)
         xs = [xa + 6 * c for c in range(G)]
         assert xs[-1] + 6 <= V_E
-        for p in range(4):
-            self.c(f"---- pass {p}: m tiles {2 * p}, {2 * p + 1} -> buffer {p % 2}" + (f"; image of pass {p - 1} read back and stored in between" if p else "") + " ----")
-            tiles = [(2 * p + ii, j) for j in range(NT) for ii in range(2)]
+        for p in range(MT):
+            self.c(f"---- pass {p}: m tile {p} -> buffer {p % 2}" + (f"; image of pass {p - 1} read back and stored in between" if p else "") + " ----")
+            tiles = [(p, j) for j in range(NT)]
             groups = [tiles[k:k + G] for k in range(0, len(tiles), G)]
             per = -(-len(units) // len(groups))          # read-back units handled per group boundary
             nxt = 0                                      # next unit of pass p - 1 to read
@@ -570,7 +634,7 @@ class Gen:
                         store_unit(u)
                     pending = []
                 for c, (i, j) in enumerate(grp):
-                    e(f"ds_write_b64 v{waddr}, v[{xs[c] + 4}:{xs[c] + 5}] offset:{(p % 2) * BUF + (i - 2 * p) * 16 * PITCH + 32 * j}")
+                    e(f"ds_write_b64 v{waddr}, v[{xs[c] + 4}:{xs[c] + 5}] offset:{(p % 2) * BUF + 32 * j}")
                 if p:
                     for _ in range(per):
                         if nxt < len(units):
@@ -582,17 +646,22 @@ class Gen:
                 for u in pending:
                     store_unit(u)
                 assert nxt == len(units)
-        self.c("---- image of pass 3 ----")
+        self.c(f"---- image of pass {MT - 1} ----")
         e("s_waitcnt lgkmcnt(0)")
-        read_unit(3, 0)
+        read_unit(MT - 1, 0)
         for u in range(len(units)):
             if u + 1 < len(units):
-                read_unit(3, u + 1)
+                read_unit(MT - 1, u + 1)
                 e("s_waitcnt lgkmcnt(1)")
             else:
                 e("s_waitcnt lgkmcnt(0)")
             store_unit(u)
-        e(f"s_branch {self.L('end')}")
+        assert stores == self.ROWS_STORES, stores
+        # the next tile's scale loads and stage-0 pieces are OLDER than these stores: all but the stores have landed
+        e(f"s_cmp_lg_u32 s{S_HASNEXT}, 0")
+        e(f"s_cbranch_scc0 {self.L('tail')}")
+        e(f"s_waitcnt vmcnt({self.ROWS_STORES})")
+        e(f"s_branch {self.L('tail')}")
 
     def epilogue(self) -> None:
         e = self.e
@@ -600,6 +669,15 @@ class Gen:
         e("s_waitcnt vmcnt(0)")
         e("s_waitcnt lgkmcnt(0)")
         e("s_barrier", "every wave is past its last fragment read and every LDS-DMA has landed: the operand LDS is dead")
+        # ---- the next tile of this workgroup: its scale loads and its whole first stage go out BEFORE this tile's epilogue ----
+        e(f"s_add_u32 s{S_TNEXT}, s{S_TILE}, s{S_GRID}")
+        e(f"s_cmp_lt_u32 s{S_TNEXT}, s{S_NWG}")
+        e(f"s_cselect_b32 s{S_HASNEXT}, 1, 0")
+        e(f"s_cbranch_scc0 {self.L('no_next')}")
+        self.tile_coords(S_TNEXT, S_BM0N, S_BN0N, "next")
+        self.tile_sources(S_BM0N, S_BN0N)
+        self.issue_stage(0, 0)
+        self.label(self.L("no_next"))
         e("s_nop 15", "last MFMA's result -> VALU")
         e("s_nop 7")
         vl, vc, vg, vt = V_T, V_T + 1, V_T + 2, V_T + 3
@@ -650,6 +728,7 @@ class Gen:
         e(f"v_add_u32 v{V_E + 1}, s{T}, v{vc}")
         e(f"v_lshlrev_b32 v{V_E + 1}, 2, v{V_E + 1}")
         e(f"v_add_u32 v{V_E + 1}, {LDS_SA}, v{V_E + 1}", "sa address")
+        e(f"v_add_u32 v{V_E + 1}, s{S_SCOFF}, v{V_E + 1}")
         for i in range(MT):
             e(f"ds_read_b32 v{sa + i}, v{V_E + 1} offset:{64 * i}")
         e(f"s_mul_i32 s{T}, s{S_WC}, {16 * NT}")
@@ -657,15 +736,16 @@ class Gen:
         e(f"v_add_u32 v{V_E + 2}, s{T}, v{V_E + 2}")
         e(f"v_lshlrev_b32 v{V_E + 2}, 2, v{V_E + 2}")
         e(f"v_add_u32 v{V_E + 2}, {LDS_SB}, v{V_E + 2}", "sb address")
+        e(f"v_add_u32 v{V_E + 2}, s{S_SCOFF}, v{V_E + 2}")
         sbreg = V_FA + 16        # 4 registers per n tile, double buffered
         # n tiles of this wave that start below N (N is a multiple of 16: whole tiles)
         e(f"s_sub_u32 s{S_NVALID}, s{S_N}, s{T + 1}", "columns left of N from this wave's first one (may be <= 0)")
         e(f"s_cmp_gt_i32 s{S_NVALID}, 0")
-        e(f"s_cbranch_scc0 {self.L('end')}")
+        e(f"s_cbranch_scc0 {self.L('direct_done')}")
         e(f"s_lshr_b32 s{S_NVALID}, s{S_NVALID}, 4")
         for j in range(NT):
             e(f"s_cmp_gt_u32 s{S_NVALID}, {j}")
-            e(f"s_cbranch_scc0 {self.L('end')}")
+            e(f"s_cbranch_scc0 {self.L('direct_done')}")
             e(f"ds_read_b128 v[{sbreg}:{sbreg + 3}], v{V_E + 2} offset:{64 * j}")
             e("s_waitcnt lgkmcnt(0)")
             for i in range(MT):
@@ -695,37 +775,41 @@ class Gen:
                     e(f"v_cvt_pk_bf16_f32 v{x + 5}, v{x + 2}, v{x + 3}")
                 e(f"buffer_store_dwordx2 v[{x + 4}:{x + 5}], v{rowoff + i}, s[{S_DC}:{S_DC + 3}], 0 offen offset:{32 * j}")
                 e("s_nop 1")
-        self.label(self.L("end"))
+        self.label(self.L("direct_done"))
+        e("s_waitcnt vmcnt(0)", "(an edge wave's store count varies: drain; the next tile's loads are older than the stores)")
+        # ---- tail: hand over to the next tile, or end ----
+        self.label(self.L("tail"))
         self.stamp(3)
         if self.probe:
-            e("s_waitcnt vmcnt(0)")
-        self.stamp(4)
-        self.write_stamps()
+            self.stamp(4)
+            self.write_stamps()
+        e(f"s_cmp_lg_u32 s{S_HASNEXT}, 0")
+        e(f"s_cbranch_scc0 {self.L('exit')}")
+        if self.probe:
+            self.stamp(0)
+        e(f"s_xor_b32 s{S_SCOFF}, s{S_SCOFF}, {SCALE_BUF}")
+        self.park_scales()
+        e(f"s_mov_b32 s{S_TILE}, s{S_TNEXT}")
+        e(f"s_mov_b32 s{S_BM0}, s{S_BM0N}")
+        e(f"s_mov_b32 s{S_BN0}, s{S_BN0N}")
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_barrier", "every wave is done with its staging region (stage 1) and its stage-0 pieces of the next tile have landed")
+        self.issue_stage(1, 128)
+        e(f"s_branch {self.L('go')}")
+        self.label(self.L("exit"))
         e("s_endpgm")
 
     def build(self) -> str:
-        self.prologue()
-        # steady-state queue: generate the pair once to learn what is outstanding at its end, then for real
-        probe = Gen(self.name, self.out_fp16)  # (a scratch generator: only its final queue state is used)
-        probe.lgkm = []
-        probe.step(0, "t0", "t1")
-        probe.step(1, "t1", "t0")
-        steady = list(probe.lgkm)
-        # the loop body's counted lgkmcnt waits assume the reads a step leaves outstanding for its successor (B tile 0 and A
-        # tiles 0-6 of the next step, in their order of issue): the prologue issues exactly those, in that order
-        for t in steady:
-            _, what, half = t.split(".")
-            kind, idx = what[0], int(what[1:])
-            if kind == "A":
-                base = V_FA + 8 * idx + (4 if half == "hi" else 0)
-                self.ds_read128(base, (V_AHI if half == "hi" else V_ALO)[0], 2048 * idx, t)
-            else:
-                base = V_FB + 8 * fb_slot(idx) + (4 if half == "hi" else 0)
-                self.ds_read128(base, (V_BHI if half == "hi" else V_BLO)[0], 2048 * idx, t)
-        assert self.lgkm == steady, (self.lgkm, steady)
+        self.setup_once()
+        self.first_tile()
+        # steady-state queue of outstanding fragment reads: generate a pair once to learn what it leaves behind
+        scratch = Gen(self.name, self.out_fp16, int8=self.int8)  # (only its final queue state is used)
+        scratch.step(0, "t0", "t1")
+        scratch.step(1, "t1", "t0")
+        steady = list(scratch.lgkm)
+        self.label(self.L("go"))
         self.stamp(1)
-        self.loop()
-        assert self.lgkm == steady, "the loop body must leave the queue as it found it"
+        self.k_loop(steady)
         self.stamp(2)
         self.epilogue()
         return self.render()

@@ -27,7 +27,7 @@ struct Gemm1wArgs {
   const float* sa;
   const float* sb;
   uint32_t m, n, k, lda, ldb, ldc;
-  uint32_t tiles_m, tiles_n, nwg, magic_pg, shift_pg, magic_last, sa_vec, sb_vec;
+  uint32_t tiles_m, tiles_n, nwg, magic_pg, grid, magic_last, sa_vec, sb_vec;
   float acc_scale;
   uint32_t out_dtype;
   unsigned long long* probe;  // diagnostic kernel only: [workgroup][5][2] 64-bit stamps (s_memtime, s_memrealtime); else ignored
@@ -111,10 +111,10 @@ struct Asm1wFit {
   double partial_base;              // a round on a fraction f of the CUs costs (partial_base + (1 - partial_base) f) of a full one
   double margin;                    // take the 352-wide tiles only when they win by this factor
 };
-// profiles/r05/asm1w_rows_epilogue_v2.txt (commit of round 5, one box, interleaved): C3 2 rounds 115.5 us / 3 rounds (2.69) 123.8 us;
-// C5 10.25 rounds 1141 us / 14 rounds 1158.5 us; 8192 x 8192 x 3584 1.375 rounds 182.1 / 1.75 rounds 149.6; 4096 x 8192 x 4096 0.75
-// rounds 91.7 / 1 round 81.0.  Full-chip round: 352-wide 57.7 us at K = 4096, 104.8 at 8192; 256-wide 41.9 / 82.75.
-constexpr Asm1wFit kAsm1wFit = {10.6, 47.1 / 32.0, 1.05, 40.85 / 32.0, 0.85, 0.98};
+// profiles/r05/asm1w_persistent.txt (the persistent form, one box, interleaved): C3 2 rounds 110.6 us / 3 rounds (2.69) 119.5 us;
+// C5 10.25 rounds 1111.9 us / 14 rounds 1135.1 us; 8192 x 8192 x 3584 1.375 rounds 178.7 / 1.75 rounds 149.7; 4096 x 8192 x 4096 0.75
+// rounds 89.8 / 1 round 79.9.  Full-chip round: 352-wide 55.3 us at K = 4096, 102.1 at 8192; 256-wide 40.5 / 81.1.
+constexpr Asm1wFit kAsm1wFit = {8.5, 1.4625, 0.5, 1.269, 0.85, 0.98};
 
 static double weighted_rounds(int64_t tiles, int cus, double base) {
   const int64_t full = tiles / cus, rem = tiles % cus;
@@ -154,7 +154,9 @@ int launch_scaled_gemm_asm1w(const ScaledGemmArgs& p, hipStream_t stream) {
   // n / d = mulhi(n, ceil(2^32 / d)) for n, d < 2^16 (the error term n e / 2^32 with e < d stays below 1 / d)
   const uint32_t per_group = 8 * a.tiles_n;
   a.magic_pg = (uint32_t)((((uint64_t)1 << 32) + per_group - 1) / per_group);
-  a.shift_pg = 0;
+  // persistent walk: workgroup w runs tiles w, w + grid, ...; grid = one workgroup per CU (a multiple of 8: a tile id keeps its XCD)
+  const uint32_t cus = (uint32_t)device_cu_count();
+  a.grid = a.nwg <= cus ? a.nwg : (cus & ~7u);
   const uint32_t last = a.tiles_m % 8;  // height of the last raster group when it is not a full one
   a.magic_last = last ? (uint32_t)((((uint64_t)1 << 32) + last - 1) / last) : 0;
   a.sa_vec = p.scale_a_numel != 1;
@@ -169,7 +171,7 @@ int launch_scaled_gemm_asm1w(const ScaledGemmArgs& p, hipStream_t stream) {
   if (!fp8) a.probe = nullptr;
   const hipFunction_t f = !fp8 ? (p.out_dtype == CONCH_DT_BF16 ? mod.i8_bf16 : mod.i8_f16)
                           : a.probe ? (alt ? mod.bf16_alt_probe : mod.bf16_probe) : alt ? mod.bf16_alt : p.out_dtype == CONCH_DT_BF16 ? mod.bf16 : mod.f16;
-  CONCH_HIP(hipModuleLaunchKernel(f, a.nwg, 1, 1, 256, 1, 1, 0, stream, nullptr, extra));
+  CONCH_HIP(hipModuleLaunchKernel(f, a.grid, 1, 1, 256, 1, 1, 0, stream, nullptr, extra));
   return CONCH_OK;
 }
 
