@@ -283,6 +283,21 @@ class Gen:
         e(f"s_load_dwordx2 s[{S_ACCSCALE}:{S_ACCSCALE + 1}], s[{S_KARG}:{S_KARG + 1}], 0x60")
         if self.probe:
             e(f"s_load_dwordx2 s[{S_PROBE}:{S_PROBE + 1}], s[{S_KARG}:{S_KARG + 1}], 0x68")
+        # gated launch (the e4m3fnuz fast path, gemm.hpp ScaledGemmArgs::gate): run only if (*gate != 0) == (run_if != 0)
+        e(f"s_load_dwordx2 s[{T}:{T + 1}], s[{S_KARG}:{S_KARG + 1}], 0x70")
+        e(f"s_load_dword s{T + 2}, s[{S_KARG}:{S_KARG + 1}], 0x78")
+        e("s_waitcnt lgkmcnt(0)")
+        e(f"s_cmp_eq_u64 s[{T}:{T + 1}], 0")
+        e(f"s_cbranch_scc1 {self.L('nogate')}")
+        e(f"s_load_dword s{T + 3}, s[{T}:{T + 1}], 0x0")
+        e("s_waitcnt lgkmcnt(0)")
+        e(f"s_cmp_lg_u32 s{T + 3}, 0")
+        e(f"s_cselect_b32 s{T + 3}, 1, 0")
+        e(f"s_cmp_lg_u32 s{T + 2}, 0")
+        e(f"s_cselect_b32 s{T + 2}, 1, 0")
+        e(f"s_cmp_eq_u32 s{T + 2}, s{T + 3}")
+        e(f"s_cbranch_scc0 {self.L('exit')}")
+        self.label(self.L("nogate"))
         self.stamp(0)
         e(f"s_mov_b32 s{S_TILE}, s{S_WG}")
         e(f"s_mov_b32 s{S_SCOFF}, 0")
@@ -833,7 +848,7 @@ class Gen:
 \t.amdhsa_kernel {name}
 \t\t.amdhsa_group_segment_fixed_size {LDS_TOTAL}
 \t\t.amdhsa_private_segment_fixed_size 0
-\t\t.amdhsa_kernarg_size 112
+\t\t.amdhsa_kernarg_size 128
 \t\t.amdhsa_user_sgpr_count 2
 \t\t.amdhsa_user_sgpr_dispatch_ptr 0
 \t\t.amdhsa_user_sgpr_queue_ptr 0
@@ -880,11 +895,11 @@ class Gen:
             kernels += f"""  - .agpr_count:     256
     .args:
       - .offset:         0
-        .size:           112
+        .size:           128
         .value_kind:     by_value
     .group_segment_fixed_size: {LDS_TOTAL}
     .kernarg_segment_align: 8
-    .kernarg_segment_size: 112
+    .kernarg_segment_size: 128
     .language:       OpenCL C
     .language_version:
       - 2

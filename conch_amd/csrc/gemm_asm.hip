@@ -30,9 +30,12 @@ struct Gemm1wArgs {
   uint32_t tiles_m, tiles_n, nwg, magic_pg, grid, magic_last, sa_vec, sb_vec;
   float acc_scale;
   uint32_t out_dtype;
-  unsigned long long* probe;  // diagnostic kernel only: [workgroup][5][2] 64-bit stamps (s_memtime, s_memrealtime); else ignored
+  unsigned long long* probe;  // diagnostic kernel only: [tile][5][2] 64-bit stamps (s_memtime, s_memrealtime); else ignored
+  const int* gate;            // NULL, or: run only if (*gate != 0) == (gate_run_if != 0)  (ScaledGemmArgs::gate)
+  uint32_t gate_run_if;
+  uint32_t pad;
 };
-static_assert(sizeof(Gemm1wArgs) == 112, "kernarg block of conch_gemm1w_*: 112 bytes");
+static_assert(sizeof(Gemm1wArgs) == 128 && offsetof(Gemm1wArgs, gate) == 112 && offsetof(Gemm1wArgs, gate_run_if) == 120, "kernarg block of conch_gemm1w_*");
 static_assert(offsetof(Gemm1wArgs, m) == 40 && offsetof(Gemm1wArgs, tiles_m) == 64 && offsetof(Gemm1wArgs, acc_scale) == 96, "kernarg offsets");
 
 constexpr int kTileM = 256, kTileN = 352;
@@ -92,7 +95,7 @@ bool scaled_gemm_asm1w_supported(const ScaledGemmArgs& p) {
   if (!scaled_gemm_mfma_supported(p)) return false;
   if (p.in_dtype != CONCH_DT_FP8_E4M3FN && p.in_dtype != CONCH_DT_INT8) return false;
   if (p.out_dtype != CONCH_DT_BF16 && p.out_dtype != CONCH_DT_FP16) return false;
-  if (p.bias || p.fuse_silu || p.n_more || p.split_steps || p.gate || p.a_src_dtype) return false;
+  if (p.bias || p.fuse_silu || p.n_more || p.split_steps || p.a_src_dtype) return false;
   if (p.k < 512 || p.k % 256 || p.n % 16 || p.c_stride_n != 1 || (((uintptr_t)p.c) & 15)) return false;
   if (!p.scale_a || !p.scale_b) return false;
   const int64_t lim = (int64_t)1 << 31;
@@ -163,6 +166,8 @@ int launch_scaled_gemm_asm1w(const ScaledGemmArgs& p, hipStream_t stream) {
   a.sb_vec = p.scale_b_numel != 1;
   a.acc_scale = p.acc_scale;
   a.out_dtype = (uint32_t)p.out_dtype;
+  a.gate = p.gate;
+  a.gate_run_if = (uint32_t)p.gate_run_if;
   size_t size = sizeof(a);
   void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
   a.probe = p.out_dtype == CONCH_DT_BF16 ? g_gemm1w_probe.load() : nullptr;

@@ -8,7 +8,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 # kernel-trace pass: the bench's sustained leg (>= 2 s of back-to-back launches) dominates the per-kernel average, so the
 # summary's avg_ns is the steady-state launch duration bench.py reports as kernel_sustained_ms / frac_sustained
-TRACE=("$ROOT/bench.py" --steps 30 --warmup 5 --no-cpu-baseline --no-cold --no-probe --no-c5-base "$@")
+TRACE=("$ROOT/bench.py" --steps 30 --warmup 5 --no-cpu-baseline --no-cold --no-probe --no-c5-base --no-side-legs --no-peak "$@")
 # counter passes: few launches (counter collection serialises dispatches)
 BENCH=("$ROOT/bench.py" --steps 30 --warmup 5 --no-cpu-baseline --quick "$@")
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "${TRACE[@]}" > "$OUT/trace.log" 2>&1
