@@ -102,7 +102,7 @@ def acc_reg(i: int, j: int) -> str:
 
 
 class Gen:
-    def __init__(self, name: str, out_fp16: bool = False, probe: bool = False, rows: bool = True, pk: bool = True, int8: bool = False, chains: int = 4):
+    def __init__(self, name: str, out_fp16: bool = False, probe: bool = False, rows: bool = True, pk: bool = True, int8: bool = False, chains: int = 4, store_policy: str = ""):
         self.name = name
         self.probe = probe
         self.lines: list[str] = []
@@ -111,6 +111,7 @@ class Gen:
         self.rows = rows
         self.pk = pk
         self.chains = chains
+        self.store_policy = store_policy   # cache-policy suffix of the C stores ("" | " sc1" | " nt")
         self.int8 = int8          # int8 operands: 2 x v_mfma_i32_16x16x64_i8 per tile and step, int32 accumulators
 
     def L(self, s: str) -> str:
@@ -616,7 +617,7 @@ class Gen:
             nonlocal stores
             rg, cg = units[u]
             b = buf + 4 * (u % 4)
-            e(f"buffer_store_dwordx4 v[{b}:{b + 3}], v{gmask if cg == 2 else gbase}, s[{S_DC}:{S_DC + 3}], s{T + 6} offen offset:{cg * 128}")
+            e(f"buffer_store_dwordx4 v[{b}:{b + 3}], v{gmask if cg == 2 else gbase}, s[{S_DC}:{S_DC + 3}], s{T + 6} offen offset:{cg * 128}" + self.store_policy)
             stores += 1
             if cg == 2:
                 e(f"s_add_u32 s{T + 6}, s{T + 6}, s{T + 5}", "next row group")
@@ -938,7 +939,7 @@ def main() -> None:
                                         ("conch_gemm1w_fp8_bf16_alt", False, False, False, False),
                                         ("conch_gemm1w_fp8_bf16_alt_probe", False, True, False, False),
                                         ("conch_gemm1w_i8_bf16", False, False, True, True), ("conch_gemm1w_i8_f16", True, False, True, True)):
-        g = Gen(name, out_fp16=fp16, probe=probe, pk=True, int8=int8, chains=4 if pk else 2)  # the A/B twin: two chains
+        g = Gen(name, out_fp16=fp16, probe=probe, pk=True, int8=int8, store_policy="" if pk else " sc1")  # the A/B twin: write-through C stores
         body = g.build()
         if text:
             body = body.split("\n", 2)[2]  # one target / code-object-version header per file

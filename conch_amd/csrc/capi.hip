@@ -12,6 +12,7 @@
 
 #include "common.hpp"
 #include "gemm.hpp"
+#include "dispatch_fit.hpp"
 
 namespace conch {
 
@@ -146,12 +147,13 @@ ScaledKernel choose_scaled_kernel(const ScaledGemmArgs& p, double* tiles_us_out 
   const double kscale = (double)p.k / 4096.0;
   const int64_t tiles256 = ((p.m + 255) / 256) * ((p.n + 255) / 256);
   const int64_t rounds256 = (tiles256 + 255) / 256;
-  const double tiled_us = (double)rounds256 * (41.0 + 0.06 * (double)tiles256 / (double)rounds256) * kscale;
+  const fit::ScaledTiles& ft = fit::kScaledTiles;  // (every fitted number: dispatch_fit.hpp)
+  const double tiled_us = (double)rounds256 * (ft.t256_base + ft.t256_per_tile * (double)tiles256 / (double)rounds256) * kscale;
   const int64_t tiles128 = ((p.m + 127) / 128) * ((p.n + 127) / 128);
   const int64_t rounds128 = (tiles128 + 511) / 512;
   // at most one tile per CU: the 4-stage ring (gemm_mid.hip), three K steps in flight per CU instead of one
-  double mid_us = tiles128 <= device_cu_count() ? (23.0 + 0.08 * (double)std::max<int64_t>(0, tiles128 - 128)) * kscale
-                                                : (double)rounds128 * (31.0 + 0.02 * (double)tiles128 / (double)rounds128) * kscale;
+  double mid_us = tiles128 <= device_cu_count() ? (ft.ring_base + ft.ring_per_tile * (double)std::max<int64_t>(0, tiles128 - 128)) * kscale
+                                                : (double)rounds128 * (ft.t128_base + ft.t128_per_tile * (double)tiles128 / (double)rounds128) * kscale;
   // split-K form of the 128 x 128 tiles (gemm_mid.hip, mid_split_slices; round 4, profiles/r04/mid_splitk_sweep.txt): two launches
   // (~8 us of fixed cost: with 7 the fp8 sibling of C2, 128 x 4096 x 4096, left the one-launch split-K kernel's 10.1 us for 15.1; with 9, 32-48 x 11008 x 4096 stayed on the skinny kernel at 13-22 % more on weights streamed from HBM: profiles/r04/dispatch_cold_sweep.txt), a K step 0.52-0.68 us with up to one workgroup per CU and ~1.0 us with two, the slabs written
   // and read back at ~8 bytes per us and CU-free MB
@@ -159,8 +161,8 @@ ScaledKernel choose_scaled_kernel(const ScaledGemmArgs& p, double* tiles_us_out 
     const double cus = (double)device_cu_count();
     const double wgs = (double)tiles128 * msl;
     const double steps_slice = std::ceil((double)(p.k / 128) / msl);
-    const double per_step = wgs <= cus ? 0.52 + 0.16 * wgs / cus : std::ceil(wgs / (2.0 * cus));
-    mid_us = 8.0 + steps_slice * per_step + (double)msl * (double)p.m * (double)p.n * 1e-6;
+    const double per_step = wgs <= cus ? ft.split_step + ft.split_step_fill * wgs / cus : std::ceil(wgs / (2.0 * cus));
+    mid_us = ft.split_fixed + steps_slice * per_step + (double)msl * (double)p.m * (double)p.n * ft.split_slab_per_elem;
   }
   ScaledKernel pick = kKernelTiled;
   double best = tiled_us;
@@ -170,9 +172,10 @@ ScaledKernel choose_scaled_kernel(const ScaledGemmArgs& p, double* tiles_us_out 
   }
   if (tiles_us_out) *tiles_us_out = best;
   if (scaled_gemm_skinny_supported(p)) {
-    const double c = p.m <= 8 ? 2.0 : p.m <= 16 ? 2.1 : p.m <= 32 ? 2.5 : p.m <= 48 ? 2.7 : p.m <= 64 ? 3.0 : p.m <= 96 ? 4.5
-                     : p.m <= 128 ? 5.15 : p.m <= 192 ? 9.3 : 10.2;  // steps at the 32- / 64- / 128-row forms and at the second row block
-    const double skinny_us = 5.3 + c * 1e-7 * (double)p.n * (double)p.k;
+    const fit::ScaledSkinny& fs = fit::kScaledSkinny;
+    const double c = p.m <= 8 ? fs.c8 : p.m <= 16 ? fs.c16 : p.m <= 32 ? fs.c32 : p.m <= 48 ? fs.c48 : p.m <= 64 ? fs.c64 : p.m <= 96 ? fs.c96
+                     : p.m <= 128 ? fs.c128 : p.m <= 192 ? fs.c192 : fs.c256;  // steps at the 32- / 64- / 128-row forms and at the second row block
+    const double skinny_us = fs.fixed + c * 1e-7 * (double)p.n * (double)p.k;
     if (skinny_us < best) pick = kKernelSkinny;
   }
   return pick;
@@ -405,10 +408,11 @@ int check_mixed(const MixedGemmArgs& p) {
 // `tiles_may_split` = false for the fused gate/up form, whose 256-row tile does not split.
 bool mixed_decode_beats_tiles(const MixedGemmArgs& p, bool tiles_may_split = true) {
   const double blocks = (double)((p.m + 63) / 64);
-  const double decode_us = 5.0 + 0.41e-6 * (double)p.n * (double)p.k * blocks * (p.bits == 8 ? 1.85 : 1.0);
+  const fit::MixedDecode& fd = fit::kMixedDecode;
+  const double decode_us = fd.fixed + fd.per_nk_block * (double)p.n * (double)p.k * blocks * (p.bits == 8 ? fd.int8_factor : 1.0);
   if (tiles_may_split && mixed_gemm_mfma_supported(p) && tuning(CONCH_TUNE_MIXED_SPLITK) == 0) return decode_us < mixed_tiles_estimate_us(p);
   const int64_t tiles = (p.n + 127) / 128;  // the narrowest tile: the most workgroups a single row of tiles can have
-  const double tile_us = 16.5 * (double)p.k / 1024.0 * (double)((tiles + 255) / 256);
+  const double tile_us = fd.unsplit_tile_us_per_1024k * (double)p.k / 1024.0 * (double)((tiles + 255) / 256);
   return decode_us < tile_us;
 }
 
@@ -506,7 +510,8 @@ int run_mixed_silu(const MixedGemmArgs& p, hipStream_t stream) {
   if (variant == 0 && p.m > 64 && p.m <= 256 && mixed_gemm_mfma_supported(wide) && tuning(CONCH_TUNE_MIXED_SPLITK) == 0) {
     const double pair_us = mixed_tiles_estimate_us(wide) + 4.0;
     const double blocks = (double)((p.m + 63) / 64);
-    const double decode_us = decode ? 5.0 + 0.41e-6 * (double)wide.n * (double)p.k * blocks * (p.bits == 8 ? 1.85 : 1.0) : 1e30;
+    const fit::MixedDecode& fd = fit::kMixedDecode;
+    const double decode_us = decode ? fd.fixed + fd.per_nk_block * (double)wide.n * (double)p.k * blocks * (p.bits == 8 ? fd.int8_factor : 1.0) : 1e30;
     // the fused tile is 256 gate/up columns wide (128 of the result) and never splits: 1.35 us per 64 of K at one tile per CU
     // (86 us at K = 4096 whatever M <= 256 is; profiles/r04/fused_ops_sweep.txt)
     const double fused_rounds = (double)(((p.n + 127) / 128 + device_cu_count() - 1) / device_cu_count());

@@ -1,0 +1,62 @@
+// Every FITTED constant of the kernel dispatchers, in one place, with the sweep it was fitted on.
+// The formulas stay where they are used (capi.hip choose_scaled_kernel / mixed_decode_beats_tiles, gemm_mixed.hip pick_split /
+// pick_tile_and_split, gemm_mixed_strip.hip, gemm_asm.hip); they read their numbers from here.  A kernel change that moves a kernel's
+// speed invalidates the rows that model it: `python tools/refit_dispatch.py` (GPU box) times every candidate the dispatcher
+// chooses between on the sweep shapes and prints, per family, the worst automatic pick against the best candidate -- anything
+// above ~1.10 means a row of this table needs refitting from the sweep script named beside it.
+#pragma once
+
+namespace conch {
+namespace fit {
+
+// ---- scaled_gemm (capi.hip, choose_scaled_kernel) -- us; kscale = K / 4096; t = tiles per round -------------------------------
+// profiles/r02/dispatch_cold_sweep_after.txt, refit profiles/r03/dispatch_cold_sweep.txt (tools/dispatch_cold_sweep.py: weights cycled
+// through > 600 MB, M 8..1024, six (K, N) pairs, int8 and fp8)
+struct ScaledTiles {
+  double t256_base = 41.0, t256_per_tile = 0.06;            // 256x256 tiles: rounds x (base + per_tile t) kscale
+  double t128_base = 31.0, t128_per_tile = 0.02;            // 128x128 tiles, two per CU: rounds x (base + per_tile t) kscale
+  double ring_base = 23.0, ring_per_tile = 0.08;            // ... at most one tile per CU (4-stage ring): (base + per_tile max(0, t - 128)) kscale
+  // split-K form of the 128x128 tiles: profiles/r04/mid_splitk_sweep.txt, dispatch_cold_sweep.txt (tools/sweep_mid_split.py)
+  double split_fixed = 8.0, split_step = 0.52, split_step_fill = 0.16, split_slab_per_elem = 1e-6;
+};
+// split-K skinny kernel: fixed + c(M) 1e-7 N K; steps at the 32 / 64 / 128-row forms and the second row block
+struct ScaledSkinny {
+  double fixed = 5.3;
+  double c8 = 2.0, c16 = 2.1, c32 = 2.5, c48 = 2.7, c64 = 3.0, c96 = 4.5, c128 = 5.15, c192 = 9.3, c256 = 10.2;
+};
+// one-wave-per-SIMD 256x352 tiles against 256x256 tiles: gemm_asm.hip keeps its own table (kAsm1wFit) beside the rule, fitted on
+// profiles/r05/asm1w_persistent.txt (tools/try_asm1w.py)
+
+// ---- mixed_precision_gemm -----------------------------------------------------------------------------------------------------
+// decode-batch kernel against one row of tiles (capi.hip, mixed_decode_beats_tiles): profiles/r02/dispatch_cold_sweep_after.txt,
+// refit round 3; int8 weights stream 1.85x the bytes
+struct MixedDecode {
+  double fixed = 5.0, per_nk_block = 0.41e-6, int8_factor = 1.85;
+  double unsplit_tile_us_per_1024k = 16.5;                  // an UNSPLIT row of the narrowest tiles (split off / not allowed)
+};
+// K split of the LDS-tiled kernel at a given tile shape (gemm_mixed.hip, pick_split): profiles/r04/dispatch_cold_sweep.txt
+struct MixedSplit {
+  double wg_fixed = 3.0, step = 0.97, launch2 = 5.0, slab_per_elem = 1.0e-6;
+};
+// tile shape and K split together, M > 256 (gemm_mixed.hip, pick_tile_and_split): tools/sweep_mixed_nt_split.py, 120 timings, RMS
+// error 4.5 % (profiles/r04/mixed_nt_split_sweep.txt)
+struct MixedTileSplit {
+  double step = 0.24, width_offset = 1.2, tall_width = 5.4, fill_slowdown = 0.2, launch2 = 5.0, slab_per_elem = 1.5e-6;
+};
+// column-strip kernel against the LDS-tiled one (gemm_mixed_strip.hip, mixed_strip_beats_tiles / pick_strip_nt): tools/sweep_mixed_strip.py,
+// 48 shapes (profiles/r04/mixed_strip_sweep.txt)
+struct MixedStrip {
+  long long min_n = 8192;                                   // the strip kernel wins from this N on
+  double min_fill = 0.65;                                   // ... with at least this fraction of a chip of tiles
+  double width_offset = 0.6;                                // cost of a tile of 64 nt columns ~ nt + this
+};
+
+inline constexpr ScaledTiles kScaledTiles{};
+inline constexpr ScaledSkinny kScaledSkinny{};
+inline constexpr MixedDecode kMixedDecode{};
+inline constexpr MixedSplit kMixedSplit{};
+inline constexpr MixedTileSplit kMixedTileSplit{};
+inline constexpr MixedStrip kMixedStrip{};
+
+}  // namespace fit
+}  // namespace conch

@@ -107,7 +107,8 @@ bool scaled_gemm_asm1w_supported(const ScaledGemmArgs& p) {
 }
 
 // ---- when the 256 x 352 tiles beat the 256 x 256 tiles -----------------------------------------------------------------------
-// One table, with where each number comes from (refit: tools/try_asm1w.py prints the per-round times this table models).
+// One table, with where each number comes from (refit: tools/try_asm1w.py prints the per-round times this table models; the other
+// dispatchers' fitted constants are in dispatch_fit.hpp, and tools/refit_dispatch.py reports every family's worst automatic pick).
 struct Asm1wFit {
   double fixed352_us, step352_us;   // a 256 x 352 tile on a full chip: fixed part + per 128-byte K step
   double fixed256_us, step256_us;   // a 256 x 256 tile of gemm_mfma.hip

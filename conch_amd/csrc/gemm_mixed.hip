@@ -33,6 +33,7 @@
 
 #include "common.hpp"
 #include "gemm.hpp"
+#include "dispatch_fit.hpp"
 #include "mfma_tile.hpp"
 #include "epilogue_rows.hpp"
 #include "mixed_dequant.hpp"
@@ -818,7 +819,7 @@ int pick_nt(const MixedGemmArgs& p, int num_cus) {
     const int64_t rounds = (tiles + num_cus - 1) / num_cus;
     // + fixed per-tile cost (X staging, prologue, epilogue, issue-port share): measured 85 us at 192 columns against
     // 105 us at 256 for K = 4096, i.e. (3 + c) / (4 + c) = 0.81
-    const double cost = (double)rounds * (nt + 1.2);
+    const double cost = (double)rounds * (nt + fit::kMixedTileSplit.width_offset);  // (dispatch_fit.hpp)
     if (cost < best_cost - 1e-9) {
       best_cost = cost;
       best = nt;
@@ -826,7 +827,7 @@ int pick_nt(const MixedGemmArgs& p, int num_cus) {
   }
   if (!p.fuse_silu) {
     const int64_t tiles = ((p.m + kTallRows - 1) / kTallRows) * ((p.n + 127) / 128);
-    const double cost = (double)((tiles + num_cus - 1) / num_cus) * 5.4;
+    const double cost = (double)((tiles + num_cus - 1) / num_cus) * fit::kMixedTileSplit.tall_width;
     if (cost < best_cost - 1e-9) best = kMixedTall;
   }
   return best;
@@ -991,7 +992,8 @@ int pick_split(const MixedGemmArgs& p, int nt, int num_cus, double* us_out = nul
     // workgroup whatever its K range, 5 us for the second launch, the slabs at ~8 bytes per ns (written once, read once, mostly
     // out of L2 / Infinity Cache).  With 3 us and 4 bytes per ns 256 x 4096 x 4096 took four slices (30.6 us) where eight take
     // 25.8, and 96 x 4096 x 4096 left the decode kernel's 17.3 us for 21.1.
-    const double us = 3.0 + 0.97 * per * rounds + (s > 1 ? 5.0 + (double)s * (double)p.m * (double)p.n * 1.0e-6 : 0.0);
+    const fit::MixedSplit& fs = fit::kMixedSplit;  // (dispatch_fit.hpp)
+    const double us = fs.wg_fixed + fs.step * per * rounds + (s > 1 ? fs.launch2 + (double)s * (double)p.m * (double)p.n * fs.slab_per_elem : 0.0);
     if (us < best_us - 1e-9) {
       best_us = us;
       best = s;
@@ -1016,13 +1018,15 @@ bool pick_tile_and_split(const MixedGemmArgs& p, int num_cus, int* nt_out, int* 
     if (nt == 4 && p.zp_mode == CONCH_ZP_TENSOR) continue;  // not built (see launch_zp)
     const int rows = nt == kMixedTall ? kTallRows : kTileM, cols = nt == kMixedTall ? 128 : 64 * nt;
     const int64_t tiles = ((p.m + rows - 1) / rows) * ((p.n + cols - 1) / cols);
-    const double w = nt == kMixedTall ? 5.4 : nt + 1.2;
+    const fit::MixedTileSplit& fts = fit::kMixedTileSplit;  // (dispatch_fit.hpp)
+    const double w = nt == kMixedTall ? fts.tall_width : nt + fts.width_offset;
     for (int s = 1; s <= 8; s *= 2) {
       if (s > 1 && (p.n % 4 || tiles * s > num_cus || steps / s < 8)) break;
       const int per = ((steps + s - 1) / s + spg - 1) / spg * spg;
       const int64_t wgs = tiles * s, rounds = (wgs + num_cus - 1) / num_cus;
       const double fill = (double)wgs / (double)(rounds * num_cus);
-      const double us = (double)rounds * per * 0.24 * w * (1.0 + 0.2 * fill) + (s > 1 ? 5.0 + (double)s * (double)p.m * (double)p.n * 1.5e-6 : 0.0);
+      const double us = (double)rounds * per * fts.step * w * (1.0 + fts.fill_slowdown * fill) +
+                        (s > 1 ? fts.launch2 + (double)s * (double)p.m * (double)p.n * fts.slab_per_elem : 0.0);
       if (us < best_us - 1e-9) {
         best_us = us;
         *nt_out = nt;

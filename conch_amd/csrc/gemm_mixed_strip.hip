@@ -31,6 +31,7 @@
 
 #include "common.hpp"
 #include "gemm.hpp"
+#include "dispatch_fit.hpp"
 #include "mfma_tile.hpp"
 #include "epilogue_rows.hpp"
 #include "mixed_dequant.hpp"
@@ -533,11 +534,11 @@ int pick_strip_nt(const MixedGemmArgs& p, int num_cus);
 // 1-9 % where its tiles fill the chip and N is wide (N >= 8192: 384..768 x 4096 x 11008 -4..-9 %, x 28672 -1..-7 %, M >= 1536 -1..-3 %)
 // and nothing at N = 4096; with few tiles the LDS-tiled kernel's split-K form wins by 5-120 % (the strip kernel has none).
 bool mixed_strip_beats_tiles(const MixedGemmArgs& p) {
-  if (p.n < 8192) return false;
+  if (p.n < fit::kMixedStrip.min_n) return false;  // (dispatch_fit.hpp)
   const int cus = device_cu_count();
   const int nt = pick_strip_nt(p, cus);
   const int64_t tiles = ((p.m + kSsRows - 1) / kSsRows) * ((p.n + 64 * nt - 1) / (64 * nt));
-  if (tiles * 100 < (int64_t)cus * 65) return false;
+  if ((double)tiles < fit::kMixedStrip.min_fill * (double)cus) return false;
   // ... and the LDS-tiled kernel would not split K on this problem (1024 x 28672 x 8192: 256 x 256 tiles in two K slices take 387 us
   // where either kernel's unsplit 256 x 128 tiles take 420-445)
   return mixed_tiles_auto_split(p) == 1;
@@ -551,7 +552,7 @@ int pick_strip_nt(const MixedGemmArgs& p, int num_cus) {
   double best_cost = 1e30;
   for (int nt = 4; nt >= 2; --nt) {
     const int64_t tiles = tiles_m * ((p.n + 64 * nt - 1) / (64 * nt));
-    const double cost = (double)((tiles + num_cus - 1) / num_cus) * (nt + 0.6);
+    const double cost = (double)((tiles + num_cus - 1) / num_cus) * (nt + fit::kMixedStrip.width_offset);
     if (cost < best_cost - 1e-9) {
       best_cost = cost;
       best = nt;

@@ -10,6 +10,7 @@ from __future__ import annotations
 import json
 import os
 import re
+import signal
 import socket
 import subprocess
 import sys
@@ -48,8 +49,21 @@ def test_bench_two_ranks_on_device0(direct):
            "--all-ranks-on-device0", "--c5-shape", "2048,1024,4096"]
     if direct:
         cmd.append("--c5-direct")
-    # a CHILD process tree (this interpreter has initialised the GPU: it must not exec into another program)
-    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, check=False)
+    # a CHILD process tree (this interpreter has initialised the GPU: it must not exec into another program), in its own session so
+    # that a stuck rendezvous can be killed as a group.  One retry: in round 5 this command hung ONCE inside a full-suite run
+    # (900 s, no output) and then passed 20 times in a row, alone, after other tests and with two processes hammering the GPU
+    # (tools/stress_two_procs.sh) -- a gloo / torchrun rendezvous stall, not a kernel; a second stall fails the test.
+    res = None
+    for attempt in range(2):
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+        try:
+            out, err = proc.communicate(timeout=300)
+            res = subprocess.CompletedProcess(cmd, proc.returncode, out, err)
+            break
+        except subprocess.TimeoutExpired:
+            os.killpg(proc.pid, signal.SIGKILL)
+            proc.communicate()
+    assert res is not None, "bench.py --gpus 2 stalled twice (300 s each)"
     assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]
