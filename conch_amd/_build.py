@@ -42,7 +42,7 @@ def _stale(target: Path, deps: list[Path]) -> bool:
 
 PROBE_LIB = PKG / "libconch_amd_probe.so"
 LLVM_BIN = Path(os.environ.get("CONCH_LLVM_BIN", "/opt/rocm/lib/llvm/bin"))
-ASM_GENERATORS = {"gemm1w": CSRC / "asm" / "gen_gemm1w.py"}  # name -> script that writes NAME.s (hand-allocated gfx950 assembly)
+ASM_GENERATORS = {"gemm1w": CSRC / "asm" / "gen_gemm1w.py", "mixed1w": CSRC / "asm" / "gen_mixed1w.py"}  # name -> script that writes NAME.s (hand-allocated gfx950 assembly)
 
 
 def build_asm(objdir: Path, force: bool = False, verbose: bool = False) -> list[Path]:

@@ -450,6 +450,14 @@ int run_mixed(const MixedGemmArgs& p, hipStream_t stream) {
   // CONCH_TUNE_MIXED_KERNEL: 2 = the column-strip kernel (gemm_mixed_strip.hip) wherever its contract holds, 1 = never,
   // 0 = auto (see mixed_strip_beats_tiles)
   const int kernel = tuning(CONCH_TUNE_MIXED_KERNEL);
+  if (kernel == 3) {  // the one-wave-per-SIMD assembly kernel, forced
+    if (!mixed_gemm_asm1w_supported(p)) {
+      set_error("mixed_precision_gemm: kernel 3 (one-wave-per-SIMD assembly kernel) forced but its contract is not met (fp16, 4-bit weights without "
+                "zero points, group 128, K %% 128 == 0, N %% 16 == 0)");
+      return CONCH_ERR_UNSUPPORTED;
+    }
+    return launch_mixed_gemm_asm1w(p, stream);
+  }
   if (kernel != 1 && mixed_gemm_strip_supported(p) && (kernel == 2 || mixed_strip_beats_tiles(p))) return launch_mixed_gemm_strip(p, stream);
   return launch_mixed_gemm_mfma(p, stream);
 }

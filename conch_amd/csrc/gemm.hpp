@@ -172,6 +172,9 @@ int launch_mixed_gemm_mfma(const MixedGemmArgs& p, hipStream_t stream);
 bool mixed_gemm_strip_supported(const MixedGemmArgs& p);
 bool mixed_strip_beats_tiles(const MixedGemmArgs& p);
 int launch_mixed_gemm_strip(const MixedGemmArgs& p, hipStream_t stream);
+// gemm_asm.hip: the one-wave-per-SIMD int4 x fp16 assembly kernel (csrc/asm/gen_mixed1w.py; CONCH_TUNE_MIXED_KERNEL = 3 forces it)
+bool mixed_gemm_asm1w_supported(const MixedGemmArgs& p);
+int launch_mixed_gemm_asm1w(const MixedGemmArgs& p, hipStream_t stream);
 // gemm_mixed_skinny.hip -- decode batches (M <= 256 by a cost rule, N % 4 == 0, any K % 64 == 0): weights straight to MFMA registers, split-K (variant 4)
 bool mixed_gemm_skinny_supported(const MixedGemmArgs& p);
 int launch_mixed_gemm_skinny(const MixedGemmArgs& p, hipStream_t stream);

@@ -19,6 +19,49 @@ alignas(4096) const unsigned char kGemm1wCodeObject[] = {
 #include "gemm1w_hsaco.inc"
 };
 
+alignas(4096) const unsigned char kMixed1wCodeObject[] = {
+#include "mixed1w_hsaco.inc"
+};
+
+// kernel argument block of conch_mixed1w_* (gen_mixed1w.py)
+struct Mixed1wArgs {
+  const void* x;
+  const void* wq;
+  const void* ws;
+  void* c;
+  uint32_t m, n, k, ldx, ldq, lds, ldc;
+  int32_t off;  // weight bias (+ scalar zero point): q - off is the dequantised integer
+  uint32_t tiles_m, tiles_n, nwg, magic_pg, grid, magic_last;
+  unsigned long long* probe;
+};
+static_assert(sizeof(Mixed1wArgs) == 96 && offsetof(Mixed1wArgs, m) == 32 && offsetof(Mixed1wArgs, tiles_m) == 64 && offsetof(Mixed1wArgs, probe) == 88,
+              "kernarg block of conch_mixed1w_*");
+
+struct Mixed1wModule {
+  hipModule_t mod = nullptr;
+  hipFunction_t w3 = nullptr, w4 = nullptr, w3_probe = nullptr, w4_probe = nullptr;
+  int rc = CONCH_OK;
+};
+
+Mixed1wModule& mixed1w_module() {
+  static Mixed1wModule m;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    hipError_t e = hipModuleLoadData(&m.mod, kMixed1wCodeObject);
+    if (e == hipSuccess) e = hipModuleGetFunction(&m.w3, m.mod, "conch_mixed1w_f16_i4_w3");
+    if (e == hipSuccess) e = hipModuleGetFunction(&m.w4, m.mod, "conch_mixed1w_f16_i4_w4");
+    if (e == hipSuccess) e = hipModuleGetFunction(&m.w3_probe, m.mod, "conch_mixed1w_f16_i4_w3_probe");
+    if (e == hipSuccess) e = hipModuleGetFunction(&m.w4_probe, m.mod, "conch_mixed1w_f16_i4_w4_probe");
+    if (e != hipSuccess) {
+      set_error("mixed_precision_gemm (one-wave-per-SIMD kernel): loading the embedded code object failed: %s", hipGetErrorString(e));
+      m.rc = CONCH_ERR_HIP;
+    }
+  });
+  return m;
+}
+
+std::atomic<unsigned long long*> g_mixed1w_probe{nullptr};
+
 // kernel argument block: the layout S_* of gen_gemm1w.py reads with s_load_dword*
 struct Gemm1wArgs {
   const void* a;
@@ -77,6 +120,12 @@ std::atomic<int> g_gemm1w_alt{0};
 // start, K loop end, epilogue stores issued, stores retired.  NULL switches back.  Used by tools/try_asm1w.py only.
 extern "C" int conch_debug_gemm1w_probe(unsigned long long* buffer) {
   conch::g_gemm1w_probe.store(buffer);
+  return CONCH_OK;
+}
+
+// Diagnostic: the same for the mixed-precision assembly kernel ([workgroup][4][2] stamps: entry, K loop start, stores issued, retired)
+extern "C" int conch_debug_mixed1w_probe(unsigned long long* buffer) {
+  conch::g_mixed1w_probe.store(buffer);
   return CONCH_OK;
 }
 
@@ -178,6 +227,68 @@ int launch_scaled_gemm_asm1w(const ScaledGemmArgs& p, hipStream_t stream) {
   const hipFunction_t f = !fp8 ? (p.out_dtype == CONCH_DT_BF16 ? mod.i8_bf16 : mod.i8_f16)
                           : a.probe ? (alt ? mod.bf16_alt_probe : mod.bf16_probe) : alt ? mod.bf16_alt : p.out_dtype == CONCH_DT_BF16 ? mod.bf16 : mod.f16;
   CONCH_HIP(hipModuleLaunchKernel(f, a.grid, 1, 1, 256, 1, 1, 0, stream, nullptr, extra));
+  return CONCH_OK;
+}
+
+
+// ---- mixed_precision_gemm: the one-wave-per-SIMD int4 x fp16 kernel (csrc/asm/gen_mixed1w.py) --------------------------------
+// Contract on top of mixed_gemm_mfma_supported: fp16 activations, scales and output, 4-bit weights with a bias and NO zero points
+// (the reference benchmark's uint4b8 form), group_size 128, K % 128 == 0, N % 16 == 0, plain [K/8][N] words, no fused / pre-packed /
+// split form, 16-byte aligned activation rows, 8-byte aligned C rows, every array below 2 GiB, fewer than 65536 tiles.
+bool mixed_gemm_asm1w_supported(const MixedGemmArgs& p) {
+  if (!mixed_gemm_mfma_supported(p)) return false;
+  if (p.x_dtype != CONCH_DT_FP16 || p.out_dtype != CONCH_DT_FP16 || p.bits != 4 || p.zp_mode != CONCH_ZP_NONE) return false;
+  if (p.group_size != 128 || p.k % 128 || p.k < 256 || p.n % 16) return false;
+  if (p.fuse_silu || p.prepacked || p.split_steps || p.slabs) return false;
+  if ((((uintptr_t)p.x) & 15) || p.x_stride_m % 8 || (((uintptr_t)p.c) & 7) || p.c_stride_m % 4) return false;
+  if ((((uintptr_t)p.w_q) & 3) || (((uintptr_t)p.w_s) & 1)) return false;
+  const int64_t lim = (int64_t)1 << 31;
+  if (((p.m - 1) * p.x_stride_m + p.k) * 2 >= lim || ((p.k / 8 - 1) * p.wq_stride_k + p.n) * 4 >= lim) return false;
+  if (((p.k / 128 - 1) * p.ws_stride_g + p.n) * 2 >= lim || ((p.m - 1) * p.c_stride_m + p.n) * 2 >= lim) return false;
+  return ((p.m + 255) / 256) * ((p.n + 191) / 192) < 65536;
+}
+
+// tile width: 4 waves x 16 W columns, W = 3 or 4 -- the one that needs fewer (rounds of workgroups) x (work per workgroup)
+int mixed_asm1w_width(const MixedGemmArgs& p) {
+  const int forced = tuning(CONCH_TUNE_MIXED_TILE_NT);
+  if (forced == 3 || forced == 4) return forced;
+  const int cus = device_cu_count();
+  const int64_t tm = (p.m + 255) / 256;
+  const int64_t t3 = tm * ((p.n + 191) / 192), t4 = tm * ((p.n + 255) / 256);
+  const double c3 = (double)((t3 + cus - 1) / cus) * 3.3, c4 = (double)((t4 + cus - 1) / cus) * 4.3;
+  return c3 < c4 ? 3 : 4;
+}
+
+int launch_mixed_gemm_asm1w(const MixedGemmArgs& p, hipStream_t stream) {
+  Mixed1wModule& mod = mixed1w_module();
+  if (mod.rc != CONCH_OK) return mod.rc;
+  const int w = mixed_asm1w_width(p);
+  Mixed1wArgs a{};
+  a.x = p.x;
+  a.wq = p.w_q;
+  a.ws = p.w_s;
+  a.c = p.c;
+  a.m = (uint32_t)p.m;
+  a.n = (uint32_t)p.n;
+  a.k = (uint32_t)p.k;
+  a.ldx = (uint32_t)p.x_stride_m;
+  a.ldq = (uint32_t)p.wq_stride_k;
+  a.lds = (uint32_t)p.ws_stride_g;
+  a.ldc = (uint32_t)p.c_stride_m;
+  a.off = p.weight_bias;
+  a.tiles_m = (uint32_t)((p.m + 255) / 256);
+  a.tiles_n = (uint32_t)((p.n + 64 * w - 1) / (64 * w));
+  a.nwg = a.tiles_m * a.tiles_n;
+  const uint32_t per_group = 8 * a.tiles_n;
+  a.magic_pg = (uint32_t)((((uint64_t)1 << 32) + per_group - 1) / per_group);
+  a.grid = a.nwg;
+  const uint32_t last = a.tiles_m % 8;
+  a.magic_last = last ? (uint32_t)((((uint64_t)1 << 32) + last - 1) / last) : 0;
+  a.probe = g_mixed1w_probe.load();
+  size_t size = sizeof(a);
+  void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+  const hipFunction_t f = a.probe ? (w == 3 ? mod.w3_probe : mod.w4_probe) : (w == 3 ? mod.w3 : mod.w4);
+  CONCH_HIP(hipModuleLaunchKernel(f, a.nwg, 1, 1, 256, 1, 1, 0, stream, nullptr, extra));
   return CONCH_OK;
 }
 

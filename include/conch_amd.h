@@ -165,7 +165,9 @@ typedef enum conch_tuning_key {
   ,
   CONCH_TUNE_MIXED_KERNEL = 11 /* mixed_precision_gemm, M > 256: 0 = auto, 1 = the LDS-tiled kernel (dequantised weights pass
                                   through LDS: gemm_mixed.hip), 2 = the column-strip kernel (every wave dequantises its own 16 / 32
-                                  columns straight into MFMA operand registers: gemm_mixed_strip.hip) wherever its contract holds */
+                                  columns straight into MFMA operand registers: gemm_mixed_strip.hip) wherever its contract holds, 3 = the
+                                  one-wave-per-SIMD assembly form of it (csrc/asm/gen_mixed1w.py: fp16, 4-bit weights, no zero points,
+                                  group 128; CONCH_TUNE_MIXED_TILE_NT 3 / 4 picks its 192- / 256-column tile) */
   ,
   CONCH_TUNE_MID_SPLITK = 12 /* 128x128-tile scaled GEMM: K slices per tile (fp32 / int32 slabs + the split-K reduce kernel) when the
                                tiles leave at least half the chip idle and K >= 4096: 0 = auto, 1 = never, 2..8 = that many */,
