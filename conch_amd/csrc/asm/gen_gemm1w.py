@@ -32,19 +32,34 @@ from __future__ import annotations
 
 import sys
 
-NT = 11                      # 16-column n tiles per wave
 MT = 8                       # 16-row m tiles per wave
-TILE_M, TILE_N = 256, 2 * 16 * NT            # 256 x 352
+TILE_M = 256
 A_BYTES = TILE_M * 128                       # 32 KiB of a stage
-B_WAVECOL = 16 * NT * 128                    # 22528: one wave column's rows of a stage
-STAGE = A_BYTES + 2 * B_WAVECOL              # 77824
-LDS_SA = 2 * STAGE                           # 155648: float sa[256] of scale buffer 0
-LDS_SB = LDS_SA + 1024                       # float sb[512] (352 used)
 SCALE_BUF = 3072                             # two scale buffers: the current tile's, and the next tile's parked under the epilogue
-LDS_TOTAL = LDS_SA + 2 * SCALE_BUF           # 161792 of 163840
-SLOTS = MT * NT                              # 88 MFMAs per step and wave
-Z_SLOT, X_SLOT = 36, 76                      # barrier in FRONT of this slot's MFMA
-PIECES_Z, PIECES_X = 14, 5                   # LDS-DMA pieces issued behind each barrier (8 A + B tiles 0-5 | B tiles 6-10)
+
+
+def configure(nt: int) -> None:
+    """Everything that follows from NT = 16-column n tiles per wave (tile width 32 NT).  NT = 11 is the form described in the module
+    docstring (256 x 352: C3 in exactly two rounds); NT = 9 / 7 (288 / 224 columns) serve shapes whose N the wider tile quantises
+    badly (the C5 shard of 3584 columns = 16 x 224: two full rounds at M = 8192).  Numbers in comments below are NT = 11's."""
+    global NT, TILE_N, B_WAVECOL, STAGE, LDS_SA, LDS_SB, LDS_TOTAL, SLOTS, Z_SLOT, X_SLOT, PIECES_Z, PIECES_X, JZ
+    assert 5 <= nt <= 11 and nt % 2 == 1, "odd: the last n tile walks the m tiles upwards, which the A-fragment reload relies on"
+    NT = nt
+    TILE_N = 2 * 16 * NT                     # 352
+    B_WAVECOL = 16 * NT * 128                # 22528: one wave column's rows of a stage
+    STAGE = A_BYTES + 2 * B_WAVECOL          # 77824
+    LDS_SA = 2 * STAGE                       # 155648: float sa[256] of scale buffer 0
+    LDS_SB = LDS_SA + 1024                   # float sb[512] (352 used)
+    LDS_TOTAL = LDS_SA + 2 * SCALE_BUF       # 161792 of 163840
+    SLOTS = MT * NT                          # 88 MFMAs per step and wave
+    JZ = NT // 2                             # 5: barrier Z sits behind the fragment read of B tile JZ
+    Z_SLOT = 8 * (JZ - 1) + 4                # 36: barriers in FRONT of this slot's MFMA
+    X_SLOT = 8 * (NT - 2) + 4                # 76
+    PIECES_Z = 8 + JZ + 1                    # 14: LDS-DMA pieces issued behind each barrier (8 A + B tiles 0-5 | B tiles 6-10)
+    PIECES_X = NT - JZ - 1                   # 5
+
+
+configure(11)
 
 # ---- register map ------------------------------------------------------------------------------------------------------------
 # SGPRs
@@ -213,7 +228,7 @@ class Gen:
         e(f"s_mov_b32 s{S_DA + 2}, s{S_NRA}")
         e(f"s_mov_b32 s{S_DB + 2}, s{S_NRB}")
         e("s_nop 3")
-        for idx in range(19):
+        for idx in range(8 + NT):
             self.dma_piece(idx, stage)
 
     # -- one K step -----------------------------------------------------------------------------------------------------------------
@@ -221,10 +236,13 @@ class Gen:
         """88 MFMA slots of the step staged in `st`; `tag` / `nxt` name this step's and the next step's fragment reads.
         `first`: the tile's first K step -- the MFMAs take the constant 0 as their addend (no accumulator is zeroed anywhere)."""
         # DMA issue slots: after Z every third slot that carries no fragment read, after X every other one
-        busy = {8 * j + h for j in range(NT) for h in (0, 1)} | {78, 79} | set(range(80, 88)) | {0}
-        z_slots = [q for q in range(Z_SLOT, X_SLOT) if q not in busy][::2][:PIECES_Z]
+        last = 8 * (NT - 1)                  # first slot of the last n tile (80)
+        busy = {8 * j + h for j in range(NT) for h in (0, 1)} | {X_SLOT + 2, X_SLOT + 3} | set(range(last, SLOTS)) | {0}
+        free = [q for q in range(Z_SLOT, X_SLOT) if q not in busy]
+        z_slots = free[::max(1, len(free) // PIECES_Z)][:PIECES_Z]
         assert len(z_slots) == PIECES_Z, z_slots
-        x_slots = [76, 77, 82, 84, 86]
+        x_slots = ([X_SLOT, X_SLOT + 1] + list(range(last + 2, SLOTS, 2)) + list(range(last + 1, SLOTS, 2)))[:PIECES_X]   # 76, 77, 82, 84, 86
+        assert len(x_slots) == PIECES_X and len(set(x_slots)) == PIECES_X
         dma_at = {q: k for k, q in enumerate(z_slots)}
         dma_at.update({q: PIECES_Z + k for k, q in enumerate(x_slots)})
         for q in range(SLOTS):
@@ -256,10 +274,10 @@ class Gen:
                 self.read_fa(7, st, tag)          # FA[7] of THIS step (its registers were busy until the previous step's last MFMA)
             if ii in (0, 1) and j + 1 <= NT - 2:
                 self.read_fb_half(j + 1, st, tag, ii)
-            if q in (72, 73):
-                self.read_fb_half(NT - 1, st, tag, q - 72)
-            if q in (78, 79):
-                self.read_fb_half(0, 1 - st, nxt, q - 78)
+            if q in (8 * (NT - 2), 8 * (NT - 2) + 1):            # 72, 73
+                self.read_fb_half(NT - 1, st, tag, q - 8 * (NT - 2))
+            if q in (X_SLOT + 2, X_SLOT + 3):                    # 78, 79
+                self.read_fb_half(0, 1 - st, nxt, q - (X_SLOT + 2))
             if j == NT - 1 and ii >= 1:
                 self.read_fa(ii - 1, 1 - st, nxt)   # FA[ii - 1] was last used one slot ago
             if q in dma_at:
@@ -467,9 +485,9 @@ class Gen:
         self.tile_sources(S_BM0, S_BN0)
         self.issue_stage(0, 0)
         self.issue_stage(1, 128)
-        e("s_waitcnt vmcnt(38)", "the three scale loads are the oldest vector-memory operations")
+        e(f"s_waitcnt vmcnt({2 * (8 + NT)})", "the three scale loads are the oldest vector-memory operations")
         self.park_scales()
-        e("s_waitcnt vmcnt(19)", "stage 0 of this wave has landed")
+        e(f"s_waitcnt vmcnt({8 + NT})", "stage 0 of this wave has landed")
         e("s_waitcnt lgkmcnt(0)")
         e("s_barrier")
 
@@ -532,7 +550,10 @@ class Gen:
             ops.append(f"v_cvt_pk_bf16_f32 v{x + 5}, v{x + 2}, v{x + 3}")
         return ops
 
-    ROWS_STORES = 48   # buffer_store_dwordx4 per wave in epilogue_rows (8 passes x 2 row groups x 3 column groups)
+    @staticmethod
+    def rows_stores() -> int:
+        """buffer_store_dwordx4 per wave in epilogue_rows: 8 passes x 2 row groups x column groups of 8 chunks (48 at NT = 11)"""
+        return MT * 2 * -(-2 * NT // 8)
 
     def epilogue_rows(self, vc: int, vg: int) -> None:
         """Whole wave sub-tiles (128 x 176 inside M x N): every wave parks its cast outputs in ITS OWN 19 KiB of the dead STAGE-1
@@ -545,7 +566,9 @@ class Gen:
         address is one per-lane base + an immediate (+ a scalar row-group offset)."""
         e = self.e
         T = S_T
-        PITCH = 368
+        PITCH = 32 * NT + 16         # 368: a wave's row of 176 outputs = 352 bytes, + 16 so that the rows of a tile spread over the banks
+        NCG = -(-2 * NT // 8)        # 3: column groups of eight 16-byte chunks in a row
+        LASTCG = 2 * NT - 8 * (NCG - 1)   # 6: chunks of the last group
         REGION = STAGE // 4          # 19456 per wave, inside stage 1
         BUF = 16 * PITCH             # 5888: one pass's image
         sa = V_FA                    # v32..39: 8 row scales (even-aligned)
@@ -599,13 +622,13 @@ class Gen:
         e(f"v_mul_lo_u32 v{gbase}, v{xb + 1}, s{T + 2}")
         e(f"v_lshl_add_u32 v{gbase}, v{xb + 2}, 4, v{gbase}")
         e(f"v_add_u32 v{gbase}, s{T + 3}, v{gbase}")
-        e(f"v_cmp_gt_u32 vcc, 6, v{xb + 2}", "chunks 16-21 of a row: six lanes of eight")
+        e(f"v_cmp_gt_u32 vcc, {LASTCG}, v{xb + 2}", "the last column group of a row: its first LASTCG lanes of eight")
         e(f"v_mov_b32 v{xb + 3}, 0x80000000")
         e(f"v_cndmask_b32 v{gmask}, v{xb + 3}, v{gbase}, vcc")
         e(f"s_lshl_b32 s{T + 5}, s{T + 2}, 3", "8 rows of C in bytes: one row group")
         e(f"s_mov_b32 s{T + 6}, 0", "scalar offset of the row group being stored")
         e("s_waitcnt lgkmcnt(0)")
-        units = [(rg, cg) for rg in range(2) for cg in range(3)]   # of one pass's image: 2 row groups x 3 column groups
+        units = [(rg, cg) for rg in range(2) for cg in range(NCG)]   # of one pass's image: 2 row groups x NCG column groups
         stores = 0
 
         def read_unit(p: int, u: int) -> None:
@@ -617,9 +640,9 @@ class Gen:
             nonlocal stores
             rg, cg = units[u]
             b = buf + 4 * (u % 4)
-            e(f"buffer_store_dwordx4 v[{b}:{b + 3}], v{gmask if cg == 2 else gbase}, s[{S_DC}:{S_DC + 3}], s{T + 6} offen offset:{cg * 128}" + self.store_policy)
+            e(f"buffer_store_dwordx4 v[{b}:{b + 3}], v{gmask if cg == NCG - 1 else gbase}, s[{S_DC}:{S_DC + 3}], s{T + 6} offen offset:{cg * 128}" + self.store_policy)
             stores += 1
-            if cg == 2:
+            if cg == NCG - 1:
                 e(f"s_add_u32 s{T + 6}, s{T + 6}, s{T + 5}", "next row group")
 
         G = self.chains             # conversion chains interleaved (a lone wave pays the VALU latency of every dependent pair)
@@ -672,11 +695,11 @@ class Gen:
             else:
                 e("s_waitcnt lgkmcnt(0)")
             store_unit(u)
-        assert stores == self.ROWS_STORES, stores
+        assert stores == self.rows_stores(), stores
         # the next tile's scale loads and stage-0 pieces are OLDER than these stores: all but the stores have landed
         e(f"s_cmp_lg_u32 s{S_HASNEXT}, 0")
         e(f"s_cbranch_scc0 {self.L('tail')}")
-        e(f"s_waitcnt vmcnt({self.ROWS_STORES})")
+        e(f"s_waitcnt vmcnt({self.rows_stores()})")
         e(f"s_branch {self.L('tail')}")
 
     def epilogue(self) -> None:
@@ -890,15 +913,16 @@ class Gen:
         return head + "\n".join(self.lines) + tail
 
     @staticmethod
-    def metadata(names: list[str]) -> str:
+    def metadata(names: list) -> str:
+        """names: (kernel name, LDS bytes) pairs"""
         kernels = ""
-        for name in names:
+        for name, lds_total in names:
             kernels += f"""  - .agpr_count:     256
     .args:
       - .offset:         0
         .size:           128
         .value_kind:     by_value
-    .group_segment_fixed_size: {LDS_TOTAL}
+    .group_segment_fixed_size: {lds_total}
     .kernarg_segment_align: 8
     .kernarg_segment_size: 128
     .language:       OpenCL C
@@ -934,17 +958,21 @@ def main() -> None:
     out = sys.argv[1]
     text = ""
     names = []
-    for name, fp16, probe, pk, int8 in (("conch_gemm1w_fp8_bf16", False, False, True, False), ("conch_gemm1w_fp8_f16", True, False, True, False),
-                                        ("conch_gemm1w_fp8_bf16_probe", False, True, True, False),
-                                        ("conch_gemm1w_fp8_bf16_alt", False, False, False, False),
-                                        ("conch_gemm1w_fp8_bf16_alt_probe", False, True, False, False),
-                                        ("conch_gemm1w_i8_bf16", False, False, True, True), ("conch_gemm1w_i8_f16", True, False, True, True)):
+    variants = []
+    for nt in (11, 9, 7):
+        sfx = "" if nt == 11 else f"_n{nt}"
+        variants += [(f"conch_gemm1w_fp8_bf16{sfx}", nt, False, False, True, False), (f"conch_gemm1w_fp8_f16{sfx}", nt, True, False, True, False),
+                     (f"conch_gemm1w_i8_bf16{sfx}", nt, False, False, True, True), (f"conch_gemm1w_i8_f16{sfx}", nt, True, False, True, True)]
+    variants += [("conch_gemm1w_fp8_bf16_probe", 11, False, True, True, False), ("conch_gemm1w_fp8_bf16_alt", 11, False, False, False, False),
+                 ("conch_gemm1w_fp8_bf16_alt_probe", 11, False, True, False, False)]
+    for name, nt, fp16, probe, pk, int8 in variants:
+        configure(nt)
         g = Gen(name, out_fp16=fp16, probe=probe, pk=True, int8=int8, store_policy="" if pk else " sc1")  # the A/B twin: write-through C stores
         body = g.build()
         if text:
             body = body.split("\n", 2)[2]  # one target / code-object-version header per file
         text += body
-        names.append(name)
+        names.append((name, LDS_TOTAL))
     text += Gen.metadata(names)
     with open(out, "w") as f:
         f.write(text)

@@ -6,7 +6,9 @@
 // The kernel is loaded from memory with hipModuleLoadData on first use (one module per process; one process per GPU) and
 // launched with hipModuleLaunchKernel on the caller's stream, so it is stream-ordered and graph-capturable like every other
 // kernel of the library.
+#include <algorithm>
 #include <atomic>
+#include <cstdio>
 #include <mutex>
 
 #include "common.hpp"
@@ -81,11 +83,13 @@ struct Gemm1wArgs {
 static_assert(sizeof(Gemm1wArgs) == 128 && offsetof(Gemm1wArgs, gate) == 112 && offsetof(Gemm1wArgs, gate_run_if) == 120, "kernarg block of conch_gemm1w_*");
 static_assert(offsetof(Gemm1wArgs, m) == 40 && offsetof(Gemm1wArgs, tiles_m) == 64 && offsetof(Gemm1wArgs, acc_scale) == 96, "kernarg offsets");
 
-constexpr int kTileM = 256, kTileN = 352;
+constexpr int kTileM = 256;
+constexpr int kWidths[3] = {11, 9, 7};  // n tiles of 16 columns per wave: tile widths 352, 288, 224 (gen_gemm1w.py configure())
 
 struct Gemm1wModule {
   hipModule_t mod = nullptr;
-  hipFunction_t bf16 = nullptr, f16 = nullptr, bf16_probe = nullptr, bf16_alt = nullptr, bf16_alt_probe = nullptr, i8_bf16 = nullptr, i8_f16 = nullptr;
+  hipFunction_t fn[3][2][2] = {};  // [width index][int8][f16 output]
+  hipFunction_t bf16_probe = nullptr, bf16_alt = nullptr, bf16_alt_probe = nullptr;
   int rc = CONCH_OK;
 };
 
@@ -94,13 +98,16 @@ Gemm1wModule& gemm1w_module() {
   static std::once_flag once;
   std::call_once(once, [] {
     hipError_t e = hipModuleLoadData(&m.mod, kGemm1wCodeObject);
-    if (e == hipSuccess) e = hipModuleGetFunction(&m.bf16, m.mod, "conch_gemm1w_fp8_bf16");
-    if (e == hipSuccess) e = hipModuleGetFunction(&m.f16, m.mod, "conch_gemm1w_fp8_f16");
+    for (int w = 0; w < 3 && e == hipSuccess; ++w)
+      for (int i8 = 0; i8 < 2 && e == hipSuccess; ++i8)
+        for (int f16 = 0; f16 < 2 && e == hipSuccess; ++f16) {
+          char name[64];
+          snprintf(name, sizeof(name), "conch_gemm1w_%s_%s%s", i8 ? "i8" : "fp8", f16 ? "f16" : "bf16", w == 0 ? "" : w == 1 ? "_n9" : "_n7");
+          e = hipModuleGetFunction(&m.fn[w][i8][f16], m.mod, name);
+        }
     if (e == hipSuccess) e = hipModuleGetFunction(&m.bf16_probe, m.mod, "conch_gemm1w_fp8_bf16_probe");
     if (e == hipSuccess) e = hipModuleGetFunction(&m.bf16_alt, m.mod, "conch_gemm1w_fp8_bf16_alt");
     if (e == hipSuccess) e = hipModuleGetFunction(&m.bf16_alt_probe, m.mod, "conch_gemm1w_fp8_bf16_alt_probe");
-    if (e == hipSuccess) e = hipModuleGetFunction(&m.i8_bf16, m.mod, "conch_gemm1w_i8_bf16");
-    if (e == hipSuccess) e = hipModuleGetFunction(&m.i8_f16, m.mod, "conch_gemm1w_i8_f16");
     if (e != hipSuccess) {
       set_error("scaled_gemm (one-wave-per-SIMD kernel): loading the embedded code object failed: %s", hipGetErrorString(e));
       m.rc = CONCH_ERR_HIP;
@@ -111,6 +118,7 @@ Gemm1wModule& gemm1w_module() {
 
 std::atomic<unsigned long long*> g_gemm1w_probe{nullptr};
 std::atomic<int> g_gemm1w_alt{0};
+std::atomic<int> g_gemm1w_nt{0};  // diagnostic: 11 / 9 / 7 forces that tile width, 0 = the cost rule's pick
 
 }  // namespace
 }  // namespace conch
@@ -126,6 +134,12 @@ extern "C" int conch_debug_gemm1w_probe(unsigned long long* buffer) {
 // Diagnostic: the same for the mixed-precision assembly kernel ([workgroup][4][2] stamps: entry, K loop start, stores issued, retired)
 extern "C" int conch_debug_mixed1w_probe(unsigned long long* buffer) {
   conch::g_mixed1w_probe.store(buffer);
+  return CONCH_OK;
+}
+
+// Diagnostic: force the assembly scaled GEMM's tile width (n tiles per wave: 11, 9 or 7 = 352, 288, 224 columns); 0 = automatic
+extern "C" int conch_debug_gemm1w_width(int nt) {
+  conch::g_gemm1w_nt.store(nt == 11 || nt == 9 || nt == 7 ? nt : 0);
   return CONCH_OK;
 }
 
@@ -151,39 +165,68 @@ bool scaled_gemm_asm1w_supported(const ScaledGemmArgs& p) {
   if ((p.m - 1) * p.a_stride_m + p.k >= lim || (p.n - 1) * p.b_stride_n + p.k >= lim) return false;
   if (((p.m - 1) * p.c_stride_m + p.n) * 2 >= lim) return false;
   if (p.a_stride_m >= lim || p.b_stride_n >= lim || p.c_stride_m >= lim) return false;
-  const int64_t tiles = ((p.m + kTileM - 1) / kTileM) * ((p.n + kTileN - 1) / kTileN);
-  return tiles >= 1 && tiles < 65536 && 8 * ((p.n + kTileN - 1) / kTileN) < 65536;
+  const int64_t cols = (p.n + 223) / 224;  // the narrowest tile: the most tiles
+  return ((p.m + kTileM - 1) / kTileM) * cols < 65536 && 8 * cols < 65536;
 }
 
-// ---- when the 256 x 352 tiles beat the 256 x 256 tiles -----------------------------------------------------------------------
+// ---- which tiling: 256 x (352 | 288 | 224) of this kernel, or the 256 x 256 tiles of gemm_mfma.hip ------------------------------
 // One table, with where each number comes from (refit: tools/try_asm1w.py prints the per-round times this table models; the other
 // dispatchers' fitted constants are in dispatch_fit.hpp, and tools/refit_dispatch.py reports every family's worst automatic pick).
 struct Asm1wFit {
-  double fixed352_us, step352_us;   // a 256 x 352 tile on a full chip: fixed part + per 128-byte K step
-  double fixed256_us, step256_us;   // a 256 x 256 tile of gemm_mfma.hip
-  double partial_base;              // a round on a fraction f of the CUs costs (partial_base + (1 - partial_base) f) of a full one
-  double margin;                    // take the 352-wide tiles only when they win by this factor
+  double fixed_base_us, fixed_per_nt_us;   // a tile of NT n tiles per wave on a full chip: fixed part = base + per_nt NT ...
+  double step_per_nt_us, step_base_us;     // ... + per 128-byte K step: base + per_nt NT
+  double dma_bytes_per_us;                 // ... but not faster than the workgroup's (256 + 32 NT) x 128 bytes arrive by LDS-DMA
+  double fixed256_us, step256_us;          // a 256 x 256 tile of gemm_mfma.hip
+  double partial_base;                     // a round on a fraction f of the CUs costs (partial_base + (1 - partial_base) f) of a full one
+  double margin;                           // take this kernel only when it wins by this factor
 };
-// profiles/r05/asm1w_persistent.txt (the persistent form, one box, interleaved): C3 2 rounds 110.6 us / 3 rounds (2.69) 119.5 us;
-// C5 10.25 rounds 1111.9 us / 14 rounds 1135.1 us; 8192 x 8192 x 3584 1.375 rounds 178.7 / 1.75 rounds 149.7; 4096 x 8192 x 4096 0.75
-// rounds 89.8 / 1 round 79.9.  Full-chip round: 352-wide 55.3 us at K = 4096, 102.1 at 8192; 256-wide 40.5 / 81.1.
-constexpr Asm1wFit kAsm1wFit = {8.5, 1.4625, 0.5, 1.269, 0.85, 0.98};
+// profiles/r05/asm1w_persistent.txt, asm1w_widths.txt (one box each, interleaved): NT = 11: C3 2 rounds 110.6 us / 256-wide 3 rounds
+// (2.69) 119.5; C5 10.25 rounds 1111.9 / 14 rounds 1135.1; full-chip round 55.3 us at K = 4096, 102.1 at 8192 -> fixed 8.5, step 1.4625;
+// 256-wide 40.5 / 81.1.  The fixed part is ~3 us of tile start + an epilogue proportional to the tile width; a K step is 8 NT MFMAs
+// of 32 cycles + ~45 cycles of barriers; the 224-column tile (NT = 7: 8192 x 8192 x 3584 in two full rounds, 142.1 us against 147.0
+// on 256-wide tiles) runs its step in 1.01 us where the MFMAs need 0.94: the L2 -> LDS stream (60 KiB per step and CU) sets it.
+constexpr Asm1wFit kAsm1wFit = {3.0, 0.5, 0.131, 0.0215, 61000.0, 0.5, 1.269, 0.85, 0.98};
 
 static double weighted_rounds(int64_t tiles, int cus, double base) {
   const int64_t full = tiles / cus, rem = tiles % cus;
   return (double)full + (rem ? base + (1.0 - base) * (double)rem / (double)cus : 0.0);
 }
 
+static double asm1w_estimate_us(const ScaledGemmArgs& p, int nt, int cus) {
+  const Asm1wFit& f = kAsm1wFit;
+  const int64_t tiles = ((p.m + kTileM - 1) / kTileM) * ((p.n + 32 * nt - 1) / (32 * nt));
+  const double steps = (double)(p.k / 128);
+  const double step_us = std::max(f.step_base_us + f.step_per_nt_us * nt, (256.0 + 32.0 * nt) * 128.0 / f.dma_bytes_per_us);
+  return weighted_rounds(tiles, cus, f.partial_base) * (f.fixed_base_us + f.fixed_per_nt_us * nt + steps * step_us);
+}
+
+// the tile width (n tiles per wave) this kernel would use on `p`: the debug override, else the cheapest by the model
+static int asm1w_width(const ScaledGemmArgs& p, double* us_out = nullptr) {
+  const int cus = device_cu_count();
+  const int forced = g_gemm1w_nt.load();
+  int best = 0;
+  double best_us = 1e30;
+  for (int nt : kWidths) {
+    if (forced && nt != forced) continue;
+    const double us = asm1w_estimate_us(p, nt, cus);
+    if (us < best_us) {
+      best_us = us;
+      best = nt;
+    }
+  }
+  if (us_out) *us_out = best_us;
+  return best;
+}
+
 bool scaled_asm1w_beats_tiles(const ScaledGemmArgs& p) {
   if (!scaled_gemm_asm1w_supported(p)) return false;
   const Asm1wFit& f = kAsm1wFit;
   const int cus = device_cu_count();
-  const double steps = (double)(p.k / 128);
-  const int64_t t352 = ((p.m + kTileM - 1) / kTileM) * ((p.n + kTileN - 1) / kTileN);
+  double us = 0.0;
+  asm1w_width(p, &us);
   const int64_t t256 = ((p.m + 255) / 256) * ((p.n + 255) / 256);
-  const double us352 = weighted_rounds(t352, cus, f.partial_base) * (f.fixed352_us + f.step352_us * steps);
-  const double us256 = weighted_rounds(t256, cus, f.partial_base) * (f.fixed256_us + f.step256_us * steps);
-  return us352 < f.margin * us256;
+  const double us256 = weighted_rounds(t256, cus, f.partial_base) * (f.fixed256_us + f.step256_us * (double)(p.k / 128));
+  return us < f.margin * us256;
 }
 
 int launch_scaled_gemm_asm1w(const ScaledGemmArgs& p, hipStream_t stream) {
@@ -201,8 +244,10 @@ int launch_scaled_gemm_asm1w(const ScaledGemmArgs& p, hipStream_t stream) {
   a.lda = (uint32_t)p.a_stride_m;
   a.ldb = (uint32_t)p.b_stride_n;
   a.ldc = (uint32_t)p.c_stride_m;
+  const int nt = asm1w_width(p);
+  const int tile_n = 32 * nt;
   a.tiles_m = (uint32_t)((p.m + kTileM - 1) / kTileM);
-  a.tiles_n = (uint32_t)((p.n + kTileN - 1) / kTileN);
+  a.tiles_n = (uint32_t)((p.n + tile_n - 1) / tile_n);
   a.nwg = a.tiles_m * a.tiles_n;
   // n / d = mulhi(n, ceil(2^32 / d)) for n, d < 2^16 (the error term n e / 2^32 with e < d stays below 1 / d)
   const uint32_t per_group = 8 * a.tiles_n;
@@ -222,10 +267,11 @@ int launch_scaled_gemm_asm1w(const ScaledGemmArgs& p, hipStream_t stream) {
   void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
   a.probe = p.out_dtype == CONCH_DT_BF16 ? g_gemm1w_probe.load() : nullptr;
   const bool fp8 = p.in_dtype == CONCH_DT_FP8_E4M3FN;
-  const bool alt = g_gemm1w_alt.load() != 0 && p.out_dtype == CONCH_DT_BF16 && fp8;
-  if (!fp8) a.probe = nullptr;
-  const hipFunction_t f = !fp8 ? (p.out_dtype == CONCH_DT_BF16 ? mod.i8_bf16 : mod.i8_f16)
-                          : a.probe ? (alt ? mod.bf16_alt_probe : mod.bf16_probe) : alt ? mod.bf16_alt : p.out_dtype == CONCH_DT_BF16 ? mod.bf16 : mod.f16;
+  const bool diag_ok = fp8 && p.out_dtype == CONCH_DT_BF16 && nt == 11;  // the stamped and A/B twins exist for that instantiation only
+  const bool alt = g_gemm1w_alt.load() != 0 && diag_ok;
+  if (!diag_ok) a.probe = nullptr;
+  const int wi = nt == 11 ? 0 : nt == 9 ? 1 : 2;
+  const hipFunction_t f = a.probe ? (alt ? mod.bf16_alt_probe : mod.bf16_probe) : alt ? mod.bf16_alt : mod.fn[wi][fp8 ? 0 : 1][p.out_dtype == CONCH_DT_BF16 ? 0 : 1];
   CONCH_HIP(hipModuleLaunchKernel(f, a.grid, 1, 1, 256, 1, 1, 0, stream, nullptr, extra));
   return CONCH_OK;
 }

@@ -463,6 +463,55 @@ def test_asm1w_kernel_is_bit_identical_and_correct(_reset_tuning, m, k, n, vec_a
     check_scaled(got, ref, IN_T[iname], DT[oname], (a, b, sa, sb, None))
 
 
+@pytest.mark.parametrize("iname", ["fn", "int8"])
+@pytest.mark.parametrize("nt", [9, 7])
+@pytest.mark.parametrize(("m", "k", "n"), [(256, 512, 224), (256, 512, 288), (300, 768, 400), (1000, 2048, 1008), (2304, 1024, 3584)])
+def test_asm1w_kernel_other_tile_widths(_reset_tuning, m, k, n, nt, iname):
+    """The 288- and 224-column instantiations of the assembly kernel (9 / 7 n tiles per wave; the dispatcher takes them where they
+    fill the chip in fuller rounds: the C5 shard of 3584 columns = 16 x 224), forced through the diagnostic width hook: bit-identical
+    to the 256 x 256-tile HIP kernel."""
+    import ctypes
+
+    hook = _C.load().conch_debug_gemm1w_width
+    hook.restype, hook.argtypes = ctypes.c_int, [ctypes.c_int]
+    a, b, sa, sb, _ = make_scaled_inputs(m, k, n, IN_T[iname], torch.bfloat16, False, False, False)
+    _C.set_gemm_variant(_C.VARIANT_MFMA_PINGPONG2)
+    want = run_scaled(a, b, sa, sb, torch.bfloat16, None)
+    _C.set_gemm_variant(_C.VARIANT_MFMA_ASM1W)
+    hook(nt)
+    try:
+        got = run_scaled(a, b, sa, sb, torch.bfloat16, None)
+    finally:
+        hook(0)
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16)), f"{(got != want).sum().item()} elements differ"
+
+
+def test_mixed_asm1w_kernel_is_bit_identical(_reset_tuning):
+    """The one-wave-per-SIMD int4 x fp16 assembly kernel (csrc/asm/gen_mixed1w.py; opt-in, CONCH_TUNE_MIXED_KERNEL = 3: it is NOT
+    faster than the column-strip HIP kernel -- a lone wave cannot issue its dequantisation beside its own MFMAs,
+    profiles/r05/mixed1w_first_ab.txt) against that kernel: the same dequantised weights, MFMA and K order -- the same bits, at both
+    tile widths, ragged M / N included; and its contract is enforced."""
+    wt = scalar_types.uint4b8
+    for m, k, n in [(256, 256, 192), (300, 384, 400), (1000, 2048, 1008), (1024, 4096, 11008)]:
+        a, w_ref, packed, w_s, _ = make_mixed_inputs(m, k, n, wt, False, torch.float16)
+        args = (a.cuda(), packed.cuda(), w_s.cuda(), None, wt.size_bits, wt.bias, 128)
+        _C.set_gemm_variant(_C.VARIANT_MFMA_PINGPONG2)
+        _C.set_tuning(_C.TUNE_MIXED_SPLITK, 1)
+        _C.set_tuning(_C.TUNE_MIXED_KERNEL, 2)
+        want = mixed_precision_gemm(*args)
+        _C.set_tuning(_C.TUNE_MIXED_KERNEL, 3)
+        for nt in (3, 4):
+            _C.set_tuning(_C.TUNE_MIXED_TILE_NT, nt)
+            got = mixed_precision_gemm(*args)
+            assert torch.equal(got, want), f"{m}x{k}x{n} width {64 * nt}: {(got != want).sum().item()} elements differ"
+        _C.set_tuning(_C.TUNE_MIXED_TILE_NT, 0)
+        if m <= 1000:
+            check_mixed(got, a, w_ref, k)
+    a, w_ref, packed, w_s, w_zp = make_mixed_inputs(256, 256, 192, scalar_types.uint4, True, torch.float16)
+    with pytest.raises(NotImplementedError):  # per-group zero points: outside the contract
+        mixed_precision_gemm(a.cuda(), packed.cuda(), w_s.cuda(), w_zp.cuda(), 4, 0, 128)
+
+
 def test_asm1w_kernel_contract_is_enforced(_reset_tuning):
     """Forced onto a problem outside its contract (bias; e4m3fnuz; K not a multiple of 256) the variant refuses with the library's
     UNSUPPORTED status -- it never runs something else silently."""

@@ -88,6 +88,21 @@ def check() -> int:
             nd = int(diff.sum().item())
             bad += 1 if nd else 0
             print((f"MISMATCH {m}x{k}x{n} int8 {str(dt)[6:]}: {nd} differ; {where(diff)}" if nd else f"ok       {m}x{k}x{n} int8 {str(dt)[6:]}"), flush=True)
+    for nt in (9, 7):
+        for m, k, n in ((256, 512, 32 * nt), (300, 768, 400), (1000, 2048, 1008), (4096, 4096, 11008), (8192, 1024, 3584)):
+            for int8 in (False, True):
+                a, b, sa, sb = inputs(m, k, n, seed=11, int8=int8)
+                ref = run(_C.VARIANT_MFMA_PINGPONG2, a, b, sa, sb, torch.bfloat16)
+                set_width(nt)
+                try:
+                    got = run(_C.VARIANT_MFMA_ASM1W, a, b, sa, sb, torch.bfloat16)
+                finally:
+                    set_width(0)
+                diff = ref.view(torch.int16) != got.view(torch.int16)
+                nd = int(diff.sum().item())
+                bad += 1 if nd else 0
+                print((f"MISMATCH {m}x{k}x{n} width {32 * nt} {'int8' if int8 else 'fp8'}: {nd} differ; {where(diff)}" if nd
+                       else f"ok       {m}x{k}x{n} width {32 * nt} {'int8' if int8 else 'fp8'}"), flush=True)
     for m, k, n in ((512, 1024, 704), (4096, 4096, 11008)):
         a, b, sa, sb = inputs(m, k, n, seed=5)
         ref = run(_C.VARIANT_MFMA_PINGPONG2, a, b, sa, sb, torch.bfloat16)
@@ -109,27 +124,37 @@ def set_alt(on: int) -> None:
     fn(on)
 
 
+def set_width(nt: int) -> None:
+    fn = _C.load().conch_debug_gemm1w_width
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_int]
+    fn(nt)
+
+
 def timer(variant, a, b, sa, sb, out, iters):
-    """variant 7 = the assembly kernel, 8 = its A/B twin (generator's `alt` choice)"""
+    """variant 7 = the assembly kernel (automatic width), 8 = its A/B twin (generator's `alt` choice), 711 / 709 / 707 = forced width"""
     md = create_scaled_metadata(a, b, sa, sb, out.dtype)
     ms = ctypes.c_float()
     set_alt(1 if variant == 8 else 0)
-    _C.set_gemm_variant(7 if variant == 8 else variant)
+    set_width(variant - 700 if variant > 700 else 0)
+    _C.set_gemm_variant(7 if variant >= 8 else variant)
     try:
         _C.check(kgemm._scaled_gemm_call("conch_time_scaled_gemm", out, a, b, sa, sb, md, None, (iters, ctypes.byref(ms))), "time")
     finally:
         _C.set_gemm_variant(_C.VARIANT_AUTO)
         set_alt(0)
+        set_width(0)
     return ms.value
 
 
 def bench(rounds: int) -> None:
-    for m, k, n in ((4096, 4096, 11008), (8192, 8192, 3584), (4096, 8192, 4096), (8192, 8192, 28672)):
+    for m, k, n in ((4096, 4096, 11008), (8192, 8192, 3584), (4096, 8192, 4096), (8192, 8192, 28672), (8192, 8192, 7168), (2048, 4096, 11008),
+                    (8192, 4096, 4096)):
         a, b, sa, sb = inputs(m, k, n)
         out = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
         flops = 2.0 * m * n * k
         iters = max(10, int(0.15 / (flops / 3.0e15)))
-        arms = (5, 7, 8)
+        arms = (5, 711, 709, 707)
         for v in arms:  # load the chip first
             t_end = time.perf_counter() + 0.7
             while time.perf_counter() < t_end:
@@ -138,7 +163,8 @@ def bench(rounds: int) -> None:
         for _ in range(rounds):
             for v in arms:
                 res[v].append(timer(v, a, b, sa, sb, out, iters))
-        for v, name in ((5, "256x256 two waves/SIMD (variant 5)"), (7, "256x352 one wave/SIMD  (variant 7)"), (8, "  ... its A/B twin (alt)          ")):
+        for v, name in ((5, "256x256 two waves/SIMD (variant 5)"), (711, "256x352 one wave/SIMD  (variant 7)"), (709, "256x288 one wave/SIMD             "),
+                        (707, "256x224 one wave/SIMD             ")):
             xs = sorted(res[v])
             med = xs[len(xs) // 2]
             print(f"{m}x{k}x{n}  {name}: median {med * 1e3:8.1f} us  min {xs[0] * 1e3:8.1f} us   {flops / med / 1e9:7.1f} TFLOP/s = {flops / med / 1e9 / 5000:.3f} of 5 PF", flush=True)
