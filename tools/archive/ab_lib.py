@@ -7,7 +7,7 @@ from pathlib import Path
 
 import torch
 
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 from conch_amd import _C  # noqa: E402
 from conch_amd.kernels.quantization import gemm as kg  # noqa: E402
 from conch_amd.ops.quantization.gemm import create_mixed_precision_metadata  # noqa: E402

@@ -9,7 +9,7 @@ from pathlib import Path
 
 import torch
 
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 from conch_amd import _C, _build  # noqa: E402
 from conch_amd.kernels.quantization import gemm as kg  # noqa: E402
 from conch_amd.ops.quantization.gemm import create_scaled_metadata  # noqa: E402

@@ -3,7 +3,7 @@ entries -- scaled_gemm 14.4 us (9 us of it the ctypes call: marshalling + hipLau
 scaled_int8_quant 7.8 us on the round-3 box.  usage: python tools/prof_host.py"""
 import cProfile, pstats, time, sys
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 import torch
 from conch_amd.ops.quantization.gemm import scaled_gemm, mixed_precision_gemm, static_quant_scaled_gemm
 from conch_amd.ops.quantization.fp8 import scaled_fp8_quant

@@ -8,7 +8,7 @@ from pathlib import Path
 import torch
 import torch.nn.functional as F
 
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 from conch_amd.ops.quantization import gemm as G  # noqa: E402
 from conch_amd.ops.quantization.bitsandbytes import functional as B  # noqa: E402
 from conch_amd.ops.quantization.fp8 import scaled_fp8_quant  # noqa: E402

@@ -5,7 +5,7 @@ from pathlib import Path
 
 import torch
 
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 from conch_amd.ops.quantization.fp8 import scaled_fp8_quant  # noqa: E402
 from conch_amd.ops.quantization.int8 import scaled_int8_quant  # noqa: E402
 

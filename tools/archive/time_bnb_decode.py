@@ -4,7 +4,7 @@ from pathlib import Path
 
 import torch
 
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 from conch_amd import _C  # noqa: E402
 from conch_amd.ops.quantization.bitsandbytes.functional import matmul_4bit, quantize_4bit  # noqa: E402
 

@@ -5,7 +5,7 @@ from pathlib import Path
 
 import torch
 
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 from conch_amd.ops.quantization.gemm import scaled_gemm  # noqa: E402
 
 
