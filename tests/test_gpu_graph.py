@@ -170,3 +170,31 @@ def test_reset_scratch_is_harmless_between_one_launch_calls():
         _C.reset_scratch()
         _C.reset_scratch()
     fresh.synchronize()
+
+
+def test_assembly_kernel_replays_from_a_hip_graph():
+    """A prefill-size fp8 projection routed to the one-wave-per-SIMD assembly kernel (loaded with hipModuleLoadData, launched with
+    hipModuleLaunchKernel: csrc/gemm_asm.hip) is captured and replayed like any other launch: the kernel-argument block is copied
+    at capture, so replays see new operand CONTENTS through the same pointers, and the result equals the eager call bit for bit."""
+    seed_everything(5)
+    m, k, n = 2048, 1024, 2816  # 8 x 8 tiles of 256 x 352: the cost rule takes the assembly kernel
+    dev = torch.device("cuda")
+    a = (0.25 * torch.rand((m, k), device=dev)).to(torch.float8_e4m3fn)
+    bt = (0.25 * torch.rand((n, k), device=dev)).to(torch.float8_e4m3fn)
+    sa, sb = 0.25 * torch.rand((m, 1), device=dev), 0.25 * torch.rand((n, 1), device=dev)
+    _C.set_gemm_variant(_C.VARIANT_MFMA_ASM1W)
+    try:
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            scaled_gemm(a, bt.T, sa, sb, torch.bfloat16)  # eager warm-up on the capture stream (loads the module)
+        stream.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            out = scaled_gemm(a, bt.T, sa, sb, torch.bfloat16)
+        for _ in range(3):
+            a.copy_((0.25 * torch.rand((m, k), device=dev)).to(torch.float8_e4m3fn))
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out, scaled_gemm(a, bt.T, sa, sb, torch.bfloat16))
+    finally:
+        _C.set_gemm_variant(_C.VARIANT_AUTO)
