@@ -967,7 +967,7 @@ def main() -> None:
                  ("conch_gemm1w_fp8_bf16_alt_probe", 11, False, True, False, False)]
     for name, nt, fp16, probe, pk, int8 in variants:
         configure(nt)
-        g = Gen(name, out_fp16=fp16, probe=probe, pk=True, int8=int8, store_policy="" if pk else " sc1")  # the A/B twin: write-through C stores
+        g = Gen(name, out_fp16=fp16, probe=probe, pk=True, int8=int8, store_policy="" if pk else " nt")  # the A/B twin: non-temporal C stores (sc1: equal, profiles/r05/asm1w_sc1_store_ab.txt)
         body = g.build()
         if text:
             body = body.split("\n", 2)[2]  # one target / code-object-version header per file
