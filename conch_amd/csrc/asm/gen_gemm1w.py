@@ -964,7 +964,7 @@ def main() -> None:
         variants += [(f"conch_gemm1w_fp8_bf16{sfx}", nt, False, False, True, False), (f"conch_gemm1w_fp8_f16{sfx}", nt, True, False, True, False),
                      (f"conch_gemm1w_i8_bf16{sfx}", nt, False, False, True, True), (f"conch_gemm1w_i8_f16{sfx}", nt, True, False, True, True)]
     variants += [("conch_gemm1w_fp8_bf16_probe", 11, False, True, True, False), ("conch_gemm1w_fp8_bf16_alt", 11, False, False, False, False),
-                 ("conch_gemm1w_fp8_bf16_alt_probe", 11, False, True, False, False)]
+                 ("conch_gemm1w_fp8_bf16_alt_probe", 11, False, True, False, False), ("conch_gemm1w_i8_bf16_probe", 11, False, True, True, True)]
     for name, nt, fp16, probe, pk, int8 in variants:
         configure(nt)
         g = Gen(name, out_fp16=fp16, probe=probe, pk=True, int8=int8, store_policy="" if pk else " nt")  # the A/B twin: non-temporal C stores (sc1: equal, profiles/r05/asm1w_sc1_store_ab.txt)

@@ -89,7 +89,7 @@ constexpr int kWidths[3] = {11, 9, 7};  // n tiles of 16 columns per wave: tile 
 struct Gemm1wModule {
   hipModule_t mod = nullptr;
   hipFunction_t fn[3][2][2] = {};  // [width index][int8][f16 output]
-  hipFunction_t bf16_probe = nullptr, bf16_alt = nullptr, bf16_alt_probe = nullptr;
+  hipFunction_t bf16_probe = nullptr, bf16_alt = nullptr, bf16_alt_probe = nullptr, i8_probe = nullptr;
   int rc = CONCH_OK;
 };
 
@@ -108,6 +108,7 @@ Gemm1wModule& gemm1w_module() {
     if (e == hipSuccess) e = hipModuleGetFunction(&m.bf16_probe, m.mod, "conch_gemm1w_fp8_bf16_probe");
     if (e == hipSuccess) e = hipModuleGetFunction(&m.bf16_alt, m.mod, "conch_gemm1w_fp8_bf16_alt");
     if (e == hipSuccess) e = hipModuleGetFunction(&m.bf16_alt_probe, m.mod, "conch_gemm1w_fp8_bf16_alt_probe");
+    if (e == hipSuccess) e = hipModuleGetFunction(&m.i8_probe, m.mod, "conch_gemm1w_i8_bf16_probe");
     if (e != hipSuccess) {
       set_error("scaled_gemm (one-wave-per-SIMD kernel): loading the embedded code object failed: %s", hipGetErrorString(e));
       m.rc = CONCH_ERR_HIP;
@@ -267,11 +268,12 @@ int launch_scaled_gemm_asm1w(const ScaledGemmArgs& p, hipStream_t stream) {
   void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
   a.probe = p.out_dtype == CONCH_DT_BF16 ? g_gemm1w_probe.load() : nullptr;
   const bool fp8 = p.in_dtype == CONCH_DT_FP8_E4M3FN;
-  const bool diag_ok = fp8 && p.out_dtype == CONCH_DT_BF16 && nt == 11;  // the stamped and A/B twins exist for that instantiation only
-  const bool alt = g_gemm1w_alt.load() != 0 && diag_ok;
+  const bool diag_ok = p.out_dtype == CONCH_DT_BF16 && nt == 11;  // the stamped twins (fp8, int8) and the A/B twin (fp8) exist for that form only
+  const bool alt = g_gemm1w_alt.load() != 0 && diag_ok && fp8;
   if (!diag_ok) a.probe = nullptr;
   const int wi = nt == 11 ? 0 : nt == 9 ? 1 : 2;
-  const hipFunction_t f = a.probe ? (alt ? mod.bf16_alt_probe : mod.bf16_probe) : alt ? mod.bf16_alt : mod.fn[wi][fp8 ? 0 : 1][p.out_dtype == CONCH_DT_BF16 ? 0 : 1];
+  const hipFunction_t f = a.probe ? (!fp8 ? mod.i8_probe : alt ? mod.bf16_alt_probe : mod.bf16_probe)
+                                  : alt ? mod.bf16_alt : mod.fn[wi][fp8 ? 0 : 1][p.out_dtype == CONCH_DT_BF16 ? 0 : 1];
   CONCH_HIP(hipModuleLaunchKernel(f, a.grid, 1, 1, 256, 1, 1, 0, stream, nullptr, extra));
   return CONCH_OK;
 }

@@ -191,13 +191,13 @@ def bench_int8(rounds: int) -> None:
         print(f"int8 {m}x{k}x{n} variant {v}: median {med * 1e3:8.1f} us   {flops / med / 1e9:7.1f} TOP/s = {flops / med / 1e9 / 5000:.3f} of 5 POP/s", flush=True)
 
 
-def probe(m=4096, k=4096, n=11008, seconds=1.5, alt=False) -> None:
+def probe(m=4096, k=4096, n=11008, seconds=1.5, alt=False, int8=False) -> None:
     """In-kernel stamps of the diagnostic twin under sustained load: where a workgroup's time goes and the clock it holds."""
     lib = _C.load()
     fn = lib.conch_debug_gemm1w_probe
     fn.restype = ctypes.c_int
     fn.argtypes = [ctypes.c_void_p]
-    a, b, sa, sb = inputs(m, k, n)
+    a, b, sa, sb = inputs(m, k, n, int8=int8)
     out = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
     nwg = -(-m // 256) * -(-n // 352)
     buf = torch.zeros((nwg, 5, 2), dtype=torch.int64, device="cuda")
@@ -213,7 +213,7 @@ def probe(m=4096, k=4096, n=11008, seconds=1.5, alt=False) -> None:
     clk, rt = st[:, :, 0], st[:, :, 1]
     names = ["entry -> K loop", "K loop", "K loop end -> stores issued", "stores issued -> retired"]
     steps = k // 128
-    print(f"probe{' (alt twin)' if alt else ''} {m}x{k}x{n}: {nwg} workgroups, {steps} K steps (medians over workgroups)")
+    print(f"probe{' (alt twin)' if alt else ''}{' int8' if int8 else ''} {m}x{k}x{n}: {nwg} workgroups, {steps} K steps (medians over workgroups)")
     for i, name in enumerate(names):
         us = ((rt[:, i + 1] - rt[:, i]) / 100.0).median().item()
         cyc = (clk[:, i + 1] - clk[:, i]).median().item()
@@ -255,5 +255,6 @@ if __name__ == "__main__":
     if args.probe:
         probe()
         probe(alt=True)
+        probe(int8=True)
         probe(8192, 8192, 28672)
     sys.exit(1 if rc else 0)
