@@ -119,6 +119,7 @@ Gemm1wModule& gemm1w_module() {
 
 std::atomic<unsigned long long*> g_gemm1w_probe{nullptr};
 std::atomic<int> g_gemm1w_alt{0};
+std::atomic<int> g_gemm1w_grid{0};  // diagnostic: caps the persistent grid (a multiple of 8), 0 = one workgroup per CU
 std::atomic<int> g_gemm1w_nt{0};  // diagnostic: 11 / 9 / 7 forces that tile width, 0 = the cost rule's pick
 
 }  // namespace
@@ -141,6 +142,12 @@ extern "C" int conch_debug_mixed1w_probe(unsigned long long* buffer) {
 // Diagnostic: force the assembly scaled GEMM's tile width (n tiles per wave: 11, 9 or 7 = 352, 288, 224 columns); 0 = automatic
 extern "C" int conch_debug_gemm1w_width(int nt) {
   conch::g_gemm1w_nt.store(nt == 11 || nt == 9 || nt == 7 ? nt : 0);
+  return CONCH_OK;
+}
+
+// Diagnostic: cap the persistent grid of the assembly scaled GEMM at `wgs` workgroups (rounded down to a multiple of 8); 0 = automatic
+extern "C" int conch_debug_gemm1w_grid(int wgs) {
+  conch::g_gemm1w_grid.store(wgs >= 8 ? (wgs & ~7) : 0);
   return CONCH_OK;
 }
 
@@ -256,6 +263,7 @@ int launch_scaled_gemm_asm1w(const ScaledGemmArgs& p, hipStream_t stream) {
   // persistent walk: workgroup w runs tiles w, w + grid, ...; grid = one workgroup per CU (a multiple of 8: a tile id keeps its XCD)
   const uint32_t cus = (uint32_t)device_cu_count();
   a.grid = a.nwg <= cus ? a.nwg : (cus & ~7u);
+  if (const uint32_t cap = (uint32_t)g_gemm1w_grid.load(); cap && cap < a.grid) a.grid = cap;
   const uint32_t last = a.tiles_m % 8;  // height of the last raster group when it is not a full one
   a.magic_last = last ? (uint32_t)((((uint64_t)1 << 32) + last - 1) / last) : 0;
   a.sa_vec = p.scale_a_numel != 1;

@@ -191,7 +191,7 @@ def bench_int8(rounds: int) -> None:
         print(f"int8 {m}x{k}x{n} variant {v}: median {med * 1e3:8.1f} us   {flops / med / 1e9:7.1f} TOP/s = {flops / med / 1e9 / 5000:.3f} of 5 POP/s", flush=True)
 
 
-def probe(m=4096, k=4096, n=11008, seconds=1.5, alt=False, int8=False) -> None:
+def probe(m=4096, k=4096, n=11008, seconds=1.5, alt=False, int8=False, grid=0) -> None:
     """In-kernel stamps of the diagnostic twin under sustained load: where a workgroup's time goes and the clock it holds."""
     lib = _C.load()
     fn = lib.conch_debug_gemm1w_probe
@@ -202,6 +202,7 @@ def probe(m=4096, k=4096, n=11008, seconds=1.5, alt=False, int8=False) -> None:
     nwg = -(-m // 256) * -(-n // 352)
     buf = torch.zeros((nwg, 5, 2), dtype=torch.int64, device="cuda")
     fn(buf.data_ptr())
+    lib.conch_debug_gemm1w_grid(grid)
     try:
         t_end = time.perf_counter() + seconds
         while time.perf_counter() < t_end:
@@ -209,11 +210,12 @@ def probe(m=4096, k=4096, n=11008, seconds=1.5, alt=False, int8=False) -> None:
         torch.cuda.synchronize()
     finally:
         fn(None)
+        lib.conch_debug_gemm1w_grid(0)
     st = buf.cpu().double()
     clk, rt = st[:, :, 0], st[:, :, 1]
     names = ["entry -> K loop", "K loop", "K loop end -> stores issued", "stores issued -> retired"]
     steps = k // 128
-    print(f"probe{' (alt twin)' if alt else ''}{' int8' if int8 else ''} {m}x{k}x{n}: {nwg} workgroups, {steps} K steps (medians over workgroups)")
+    print(f"probe{' (alt twin)' if alt else ''}{' int8' if int8 else ''}{f' grid {grid}' if grid else ''} {m}x{k}x{n}: {nwg} workgroups, {steps} K steps (medians over workgroups)")
     for i, name in enumerate(names):
         us = ((rt[:, i + 1] - rt[:, i]) / 100.0).median().item()
         cyc = (clk[:, i + 1] - clk[:, i]).median().item()
@@ -256,5 +258,8 @@ if __name__ == "__main__":
         probe()
         probe(alt=True)
         probe(int8=True)
+        probe(2048, 4096, 11008)
+        probe(2048, 4096, 11008, grid=128)
+        probe(4096, 4096, 11008, grid=128)
         probe(8192, 8192, 28672)
     sys.exit(1 if rc else 0)
