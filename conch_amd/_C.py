@@ -21,7 +21,8 @@ LIB_PATH = Path(os.environ.get("CONCH_AMD_LIBRARY", _PKG / "libconch_amd.so"))
 DT_FP32, DT_FP16, DT_BF16, DT_FP8_E4M3FN, DT_INT8, DT_UINT8, DT_INT32, DT_UINT32, DT_FP8_E5M2, DT_FP8_E4M3FNUZ = range(10)
 ZP_NONE, ZP_SCALAR, ZP_TENSOR = range(3)
 (TUNE_GEMM_VARIANT, TUNE_MIXED_TILE_NT, TUNE_SKINNY_NO_SPLITK, TUNE_SKINNY_MODE, TUNE_TILE_SCHEDULE, TUNE_PERSISTENT, TUNE_EPILOGUE, TUNE_DIAG,
- TUNE_MID_STAGES, TUNE_MIXED_SPLITK, TUNE_SKINNY_GATHER, TUNE_MIXED_KERNEL, TUNE_MID_SPLITK, TUNE_SKINNY_CHUNKS, TUNE_COUNT) = range(15)
+ TUNE_MID_STAGES, TUNE_MIXED_SPLITK, TUNE_SKINNY_GATHER, TUNE_MIXED_KERNEL, TUNE_MID_SPLITK, TUNE_SKINNY_CHUNKS, TUNE_MIXED_STRIP_ROWS,
+ TUNE_COUNT) = range(16)
 (VARIANT_AUTO, VARIANT_GENERIC, VARIANT_MFMA_SIMPLE, VARIANT_MFMA_PINGPONG, VARIANT_MFMA_SKINNY,
  VARIANT_MFMA_PINGPONG2, VARIANT_MFMA_MID, VARIANT_MFMA_ASM1W) = range(8)
 

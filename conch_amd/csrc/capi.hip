@@ -406,10 +406,15 @@ int check_mixed(const MixedGemmArgs& p) {
 // (16.5 us per 1024 of K) and the decode kernel kept 192-256 rows at up to 3.8x the split tiles' time
 // (profiles/r04/mixed_splitk_sweep.txt: 256 x 28672 x 8192 458 -> 122 us, 256 x 8192 x 8192 110 -> 46, 128 x 11008 x 4096 44 -> 31).
 // `tiles_may_split` = false for the fused gate/up form, whose 256-row tile does not split.
-bool mixed_decode_beats_tiles(const MixedGemmArgs& p, bool tiles_may_split = true) {
+double mixed_decode_estimate_us(const MixedGemmArgs& p) {
   const double blocks = (double)((p.m + 63) / 64);
   const fit::MixedDecode& fd = fit::kMixedDecode;
-  const double decode_us = fd.fixed + fd.per_nk_block * (double)p.n * (double)p.k * blocks * (p.bits == 8 ? fd.int8_factor : 1.0);
+  return fd.fixed + fd.per_nk_block * (double)p.n * (double)p.k * blocks * (p.bits == 8 ? fd.int8_factor : 1.0);
+}
+
+bool mixed_decode_beats_tiles(const MixedGemmArgs& p, bool tiles_may_split = true) {
+  const fit::MixedDecode& fd = fit::kMixedDecode;
+  const double decode_us = mixed_decode_estimate_us(p);
   if (tiles_may_split && mixed_gemm_mfma_supported(p) && tuning(CONCH_TUNE_MIXED_SPLITK) == 0) return decode_us < mixed_tiles_estimate_us(p);
   const int64_t tiles = (p.n + 127) / 128;  // the narrowest tile: the most workgroups a single row of tiles can have
   const double tile_us = fd.unsplit_tile_us_per_1024k * (double)p.k / 1024.0 * (double)((tiles + 255) / 256);
@@ -439,6 +444,16 @@ int run_mixed(const MixedGemmArgs& p, hipStream_t stream) {
   // ahead there too (48-64 x 4096/8192 x 28672: profiles/r02/dispatch_cold_sweep_before.txt)
   bool decode = variant == 4 || variant == 0;
   if (variant == 0 && p.m > 64) decode = mixed_decode_beats_tiles(p);
+  // batched-decode sizes (33..256 rows, round 5): the column-strip kernel on 64- / 128- / 256-row tiles with K split over the chip
+  // dequantises every weight once whatever M is, where the decode kernel does it per 64-row block and the LDS-tiled kernel runs the
+  // MFMAs of 256 rows -- 1.3-1.9x at 48..128 rows on wide or deep problems (64 x 8192 x 28672: 97.7 -> 50.8 us; 128 x 4096 x 11008:
+  // 43.0 -> 25.9; profiles/r05/mixed_mid_sweep.txt), nothing at N = K = 4096, which the model leaves where it was
+  if (variant == 0 && tuning(CONCH_TUNE_MIXED_KERNEL) == 0 && tuning(CONCH_TUNE_MIXED_SPLITK) == 0 && tuning(CONCH_TUNE_MIXED_TILE_NT) == 0 &&
+      p.m >= fit::kMixedStripSplit.min_m && p.m <= fit::kMixedStripSplit.max_m && fast_ok && mixed_gemm_strip_supported(p)) {
+    const bool decode_ok = decode && mixed_gemm_skinny_supported(p);
+    const double other_us = decode_ok ? mixed_decode_estimate_us(p) : mixed_tiles_estimate_us(p);
+    if (mixed_strip_estimate_us(p) * fit::kMixedStripSplit.margin < other_us) return launch_mixed_gemm_strip(p, stream);
+  }
   if (decode && mixed_gemm_skinny_supported(p)) return launch_mixed_gemm_skinny(p, stream);
   if (variant == 1 || !fast_ok) {
     if (variant >= 2 && !fast_ok) {

@@ -51,12 +51,26 @@ struct MixedStrip {
   double width_offset = 0.6;                                // cost of a tile of 64 nt columns ~ nt + this
 };
 
+// K-split forms of the column-strip kernel (gemm_mixed_strip.hip, strip_plan): 64- / 128- / 256-row tiles (mt = 4 / 8 / 16 m tiles per
+// wave) x 128 / 192 / 256 columns (nt = 2..4) x 1..8 slices.  Least squares over tools/sweep_mixed_mid.py's 972 timings on weights
+// streamed from HBM (profiles/r05/mixed_mid_sweep.txt): RMS error 5.7 %, the model's pick within 9 % of the fastest form on all 54
+// shapes, the pick's own time predicted within -15 .. +6 %.
+struct MixedStripSplit {
+  double wg_fixed = 5.3;                                    // launch, prologue, epilogue (us)
+  double step = 0.0529, step_mt = 0.0158, step_nt = 0.0629, step_mt_nt = 0.0082;  // a K step of 64: us = step + ... (mt, nt as above)
+  double fill_slowdown = 0.2;                               // ... x (1 + this x the fraction of the chip the launch fills)
+  double launch2 = 1.7, slab_per_elem = 1.51e-6;            // the reduce launch; fp32 partial sums written and read again (us / element)
+  double margin = 1.08;                                     // the dispatcher takes the strip forms when this x their time beats the others'
+  long long min_m = 33, max_m = 256;                        // ... for this many rows (below: the one-launch decode forms win everywhere)
+};
+
 inline constexpr ScaledTiles kScaledTiles{};
 inline constexpr ScaledSkinny kScaledSkinny{};
 inline constexpr MixedDecode kMixedDecode{};
 inline constexpr MixedSplit kMixedSplit{};
 inline constexpr MixedTileSplit kMixedTileSplit{};
 inline constexpr MixedStrip kMixedStrip{};
+inline constexpr MixedStripSplit kMixedStripSplit{};
 
 }  // namespace fit
 }  // namespace conch

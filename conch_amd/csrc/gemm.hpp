@@ -172,6 +172,7 @@ int launch_mixed_gemm_mfma(const MixedGemmArgs& p, hipStream_t stream);
 bool mixed_gemm_strip_supported(const MixedGemmArgs& p);
 bool mixed_strip_beats_tiles(const MixedGemmArgs& p);
 int launch_mixed_gemm_strip(const MixedGemmArgs& p, hipStream_t stream);
+double mixed_strip_estimate_us(const MixedGemmArgs& p);  // cost model: its K-split forms on one row of tiles (M <= 256)
 // gemm_asm.hip: the one-wave-per-SIMD int4 x fp16 assembly kernel (csrc/asm/gen_mixed1w.py; CONCH_TUNE_MIXED_KERNEL = 3 forces it)
 bool mixed_gemm_asm1w_supported(const MixedGemmArgs& p);
 int launch_mixed_gemm_asm1w(const MixedGemmArgs& p, hipStream_t stream);

@@ -29,7 +29,11 @@ using mixed::ChunkDequant;
 constexpr int kMsThreads = 256;
 constexpr int kMsN = 64;                  // columns per workgroup
 constexpr int kMsStepK = 64;              // k elements per step (128 bytes of fp16 / bf16)
+#ifdef CONCH_EXP_MS_STEPS
+constexpr int kMsSteps = CONCH_EXP_MS_STEPS;  // (experiment builds: tools/ab_strip_parts.py)
+#else
 constexpr int kMsSteps = 16;              // steps per slice
+#endif
 constexpr int kMsSliceK = kMsSteps * kMsStepK;
 constexpr int kMsMaxM = 256;
 constexpr int kMsMaxTiles = 16384;  // arrival counters per (device, stream): the 64 KiB slot gemm_skinny.hip uses too

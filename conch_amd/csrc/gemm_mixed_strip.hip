@@ -42,25 +42,33 @@ namespace {
 using namespace tile;
 using mixed::ChunkDequant;
 
-constexpr int kSsRows = 256;
+constexpr int kSsRows = 256;                       // rows of the full tile: MT = 16 m tiles per wave.  The split-K forms (one row of
+                                                   // tiles, M <= 128 / 64) also run MT = 8 / 4: 128- / 64-row tiles, every weight
+                                                   // still dequantised once per workgroup
 constexpr int kSsStepK = 64;                       // k elements per step = 128 bytes of fp16 / bf16
-constexpr int kSsXStage = kSsRows * kStepBytes;    // 32 KiB: 32 subtiles of 8 rows x 128 bytes
-constexpr int kSsStages = 3;                       // X ring (and every per-wave ring): step t read, t + 1 landing, t + 2 requested
 constexpr int kSsMeta = 256;                       // bytes of one 4-byte-per-lane LDS-DMA piece
 
 #ifdef CONCH_CLOCK_PROBE
 __device__ unsigned long long g_probe_mixed_strip[kProbeBlocks * 8];
 #endif
 
-template <int BITS, bool ZPT>
+template <int BITS, bool ZPT, int MT = 16>
 struct StripLds {
+  static constexpr int kXStage = MT * 16 * kStepBytes;           // one K step of X: 2 MT subtiles of 8 rows x 128 bytes (32 KiB at MT = 16)
+  static constexpr int kXPieces = MT / 4;                        // ... of which every wave requests MT / 4
   static constexpr int kWPieces = BITS == 4 ? 1 : 2;             // 8 (16) word rows x 128 bytes (32 columns) per K step
   static constexpr int kWSlot = kWPieces * 1024;
-  static constexpr int kW = kSsStages * kSsXStage;               // + (wave * kSsStages + slot) * kWSlot
-  static constexpr int kS = kW + 8 * kSsStages * kWSlot;         // + (wave * kSsStages + slot) * kSsMeta
-  static constexpr int kZ = kS + 8 * kSsStages * kSsMeta;
-  static constexpr int kRing = kZ + (ZPT ? 8 * kSsStages * kSsMeta : 0);
-  static constexpr int kOps = 4 + kWPieces + 1 + (ZPT ? 1 : 0);  // vector-memory operations per wave and K step
+  // X ring (and every per-wave ring) of S stages: step t read, t + 1 landing, t + 2 .. t + S - 1 requested.  The full tile's K step
+  // (2 W x 16 MFMAs per wave, >= 1 us) covers the memory latency with three; the 128- / 64-row tiles' steps are 2x / 4x shorter and
+  // the latency is what it was (profiles/r05/mixed_mid_sweep.txt: 0.44 us per step at 64 rows with three stages), so they keep
+  // more steps in flight -- as many as the LDS holds
+  static constexpr int kStages = MT == 16 ? 3 : MT == 8 ? (BITS == 4 ? 5 : 4) : (BITS == 4 ? 7 : 5);
+  static constexpr int kW = kStages * kXStage;                   // + (wave * kStages + slot) * kWSlot
+  static constexpr int kS = kW + 8 * kStages * kWSlot;           // + (wave * kStages + slot) * kSsMeta
+  static constexpr int kZ = kS + 8 * kStages * kSsMeta;
+  static constexpr int kRing = kZ + (ZPT ? 8 * kStages * kSsMeta : 0);
+  static_assert(kRing <= 160 * 1024, "LDS budget");
+  static constexpr int kOps = kXPieces + kWPieces + 1 + (ZPT ? 1 : 0);  // vector-memory operations per wave and K step
 };
 
 // wave-uniform descriptors and strides
@@ -88,43 +96,44 @@ struct StripIssue {
   int step, slot, q_off, s_off, z_off, left;
 };
 
-template <int BITS, bool ZPT>
+template <int BITS, bool ZPT, int MT>
 __device__ __forceinline__ void issue_op(int op, char* lds, const StripSrc& u, const StripLane& ln, int wave, const StripIssue& is) {
-  using L = StripLds<BITS, ZPT>;
-  if (op < 4) {
+  using L = StripLds<BITS, ZPT, MT>;
+  if (op < L::kXPieces) {
 #ifdef CONCH_EXP_STRIP_NOXDMA
     if (is.step > 2) return;
 #endif
-    char* dst = lds + is.slot * kSsXStage + (4 * wave + op) * 1024;
+    char* dst = lds + is.slot * L::kXStage + (L::kXPieces * wave + op) * 1024;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(u.x, (lds_void_t*)dst, 16, ln.vx[op & 1], is.step * kStepBytes + (op >> 1) * 2 * u.x_rows8, 0, 0);
-  } else if (op < 4 + L::kWPieces) {
-    const int e = op - 4;
-    char* dst = lds + L::kW + (wave * kSsStages + is.slot) * L::kWSlot + e * 1024;
+  } else if (op < L::kXPieces + L::kWPieces) {
+    const int e = op - L::kXPieces;
+    char* dst = lds + L::kW + (wave * L::kStages + is.slot) * L::kWSlot + e * 1024;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(u.q, (lds_void_t*)dst, 16, ln.vq, is.q_off + e * (u.q_step / L::kWPieces), 0, 0);
-  } else if (op == 4 + L::kWPieces) {
-    char* dst = lds + L::kS + (wave * kSsStages + is.slot) * kSsMeta;
+  } else if (op == L::kXPieces + L::kWPieces) {
+    char* dst = lds + L::kS + (wave * L::kStages + is.slot) * kSsMeta;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(u.s, (lds_void_t*)dst, 4, ln.lane4, is.s_off, 0, 0);
   } else if (ZPT) {
-    char* dst = lds + L::kZ + (wave * kSsStages + is.slot) * kSsMeta;
+    char* dst = lds + L::kZ + (wave * L::kStages + is.slot) * kSsMeta;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(u.z, (lds_void_t*)dst, 4, ln.lane4, is.z_off, 0, 0);
   }
 }
 
+template <int STAGES>
 __device__ __forceinline__ void advance(StripIssue& is, const StripSrc& u) {
   const bool wrap = is.left == 1;
   is.step += 1;
-  is.slot = is.slot == kSsStages - 1 ? 0 : is.slot + 1;
+  is.slot = is.slot == STAGES - 1 ? 0 : is.slot + 1;
   is.q_off += u.q_step;
   is.left = wrap ? u.steps_per_group : is.left - 1;
   is.s_off += wrap ? u.s_group : 0;
   is.z_off += wrap ? u.z_group : 0;
 }
 
-template <int BITS, bool ZPT>
+template <int BITS, bool ZPT, int MT>
 __device__ __forceinline__ void issue_all(char* lds, const StripSrc& u, const StripLane& ln, int wave, StripIssue& is) {
 #pragma unroll
-  for (int op = 0; op < StripLds<BITS, ZPT>::kOps; ++op) issue_op<BITS, ZPT>(op, lds, u, ln, wave, is);
-  advance(is, u);
+  for (int op = 0; op < StripLds<BITS, ZPT, MT>::kOps; ++op) issue_op<BITS, ZPT, MT>(op, lds, u, ln, wave, is);
+  advance<StripLds<BITS, ZPT, MT>::kStages>(is, u);
 }
 
 // the dequantised weights of one K step: [n tile][k half] -> the 8 halfs a lane holds of its column
@@ -141,12 +150,12 @@ struct StripRaw {
   int zp[W];
 };
 
-template <int BITS, bool ZPT, int W>
+template <int BITS, bool ZPT, int W, int MT>
 __device__ __forceinline__ void read_raw(StripRaw<BITS, W>& r, const char* lds, const StripLane& ln, int wave, int slot) {
-  using L = StripLds<BITS, ZPT>;
-  const char* wq = lds + L::kW + (wave * kSsStages + slot) * L::kWSlot;
-  const char* ws = lds + L::kS + (wave * kSsStages + slot) * kSsMeta;
-  const char* wz = lds + L::kZ + (wave * kSsStages + slot) * kSsMeta;
+  using L = StripLds<BITS, ZPT, MT>;
+  const char* wq = lds + L::kW + (wave * L::kStages + slot) * L::kWSlot;
+  const char* ws = lds + L::kS + (wave * L::kStages + slot) * kSsMeta;
+  const char* wz = lds + L::kZ + (wave * L::kStages + slot) * kSsMeta;
 #pragma unroll
   for (int nt = 0; nt < W; ++nt) {
     // n tile 1 (wide strips: the group's columns 16-31): chunk index + 4 = ^ 4 (the wave's columns start a group), i.e. ^ 64 bytes
@@ -187,24 +196,28 @@ struct StripConst {
   uint32_t and_mask, or_magic, and_mask_hi;
 };
 
-template <int W>
+template <int W, int MT = 16>
 struct StripSlots {
-  static constexpr int kSlots = 32 * W;       // MFMAs of a wave and K step: pair p = (k half p / 16, m tile p % 16) x W n tiles
-  static constexpr int kHalf = 16 * W;        // first slot of the second k half
+  static constexpr int kSlots = 2 * MT * W;   // MFMAs of a wave and K step: pair p = (k half p / MT, m tile p % MT) x W n tiles
+  static constexpr int kHalf = MT * W;        // first slot of the second k half
   static constexpr int kWait = kHalf - 2;     // the counted wait for this wave's pieces of step t + 1
   static constexpr int kRaw = kHalf - 1;      // ... whose packed words / scales are read back here
-  static constexpr int kBar = 24 * W;         // the workgroup barrier sits in FRONT of this slot's MFMA (behind m tile 7 of k half 1)
-  static constexpr int kIssue0 = kBar;        // first of the kOps request slots (step t + 3): the fillers of slot kBar run behind the barrier
+  // X fragments in flight.  A fragment feeds W MFMAs (16 W cycles) and returns from LDS after ~130: the full tile rotates eight; with
+  // MT / 2 the 64-row tile had two in flight and spent 0.44 us per K step waiting for them (profiles/r05/mixed_mid_sweep.txt)
+  static constexpr int kFrags = MT == 16 ? 8 : MT;
+  // the workgroup barrier sits in FRONT of this slot's MFMA: behind the last read of this step's X stage (pair 2 MT - kFrags - 1)
+  static constexpr int kBar = (2 * MT - kFrags) * W;
+  static constexpr int kIssue0 = kBar;        // first of the request slots (step t + 3): the fillers of slot kBar run behind the barrier
   static constexpr int kSl = 9;               // ChunkDequant slices that make a chunk (the tenth is gemm_mixed.hip's ds_write)
   static constexpr int kN = kSl * W;          // slices per k half
-  static constexpr int kSpan1 = kHalf - 2;    // k half 1 of THIS step is converted in slots [0, kSpan1), one slice per slot at most
+  static constexpr int kSpan1 = kHalf - 2;    // k half 1 of THIS step is converted in slots [0, kSpan1)
   static constexpr int kSpan0 = kHalf;        // k half 0 of the NEXT step in slots [kHalf, kSlots)
-  // slice i of a half sits at slot base + i * span / kN (span >= kN: distinct slots); -1 = no slice in this slot
-  static constexpr int slice_at(int s, int base, int span) {
-    if (s < base || s >= base + span) return -1;
-    const int i = ((s - base) * kN + span - 1) / span;
-    return (i < kN && base + i * span / kN == s) ? i : -1;
-  }
+  // Slice i of a half sits at slot base + i * span / kN: with span >= kN (MT = 16) in distinct slots, the short steps of the
+  // 128- / 64-row tiles carry several per slot.  The slices of relative slot r are [first_slice(r), first_slice(r + 1)).
+  static constexpr int first_slice(int r, int span) { return r <= 0 ? 0 : r >= span ? kN : (r * kN + span - 1) / span; }
+  // requests per slot behind the barrier: one while the slots last (MT = 16), else as many as it takes
+  template <int OPS>
+  static constexpr int ops_per_slot() { return (OPS + (kSlots - kIssue0) - 1) / (kSlots - kIssue0); }
 };
 
 // one slice of the conversion of chunk (n tile NT, k half H)
@@ -214,39 +227,48 @@ __device__ __forceinline__ void strip_slice(StripB<W>& b, const StripRaw<BITS, W
   if constexpr (SUB == StripSlots<W>::kSl - 1) b.v[NT][H] = cv.out;
 }
 
+// slices I .. END - 1 of k half H, in order
+template <int X_DT, int BITS, int W, int H, int I, int END>
+__device__ __forceinline__ void strip_slice_run(StripB<W>& b, const StripRaw<BITS, W>& raw, StripDequant<X_DT, BITS>& cv, const StripConst& k) {
+  if constexpr (I < END) {
+    strip_slice<X_DT, BITS, W, I / StripSlots<W>::kSl, H, I % StripSlots<W>::kSl>(b, raw, cv, k);
+    strip_slice_run<X_DT, BITS, W, H, I + 1, END>(b, raw, cv, k);
+  }
+}
+
 // The work placed behind MFMA number SL of a step.  Slot numbers are TEMPLATE parameters and the step below is a compile-time
 // recursion over them: as a `#pragma unroll` loop with the slot in a variable the body was "too large to unroll fully as directed"
 // for hipcc, the accumulator array stayed indexed by a run-time value and went to scratch.
-// MODE 0: steps t + 1 .. t + 3 exist (t + 3 is requested here); 1: t + 1, t + 2 exist; 2: t + 1 exists; 3: last step.
-template <int X_DT, int BITS, bool ZPT, int W, int MODE, int SL>
+// MODE (S = the ring's stages): 0 = steps t + 1 .. t + S exist (t + S is requested here); m = 1 .. S - 1: t + 1 .. t + S - m exist;
+// S = last step.
+template <int X_DT, int BITS, bool ZPT, int W, int MT, int MODE, int SL>
 __device__ __forceinline__ void strip_filler(StripB<W>& b, StripRaw<BITS, W>& raw, StripDequant<X_DT, BITS>& cv, char* lds, const StripSrc& u,
                                              const StripLane& ln, const StripConst& k, int wave, StripIssue& is, int next_slot) {
-  using L = StripLds<BITS, ZPT>;
-  using S = StripSlots<W>;
+  using L = StripLds<BITS, ZPT, MT>;
+  using S = StripSlots<W, MT>;
 #ifndef CONCH_EXP_STRIP_NODQ
-  {  // k half 1 of this step: raw still holds this step's words
-    constexpr int i = S::slice_at(SL, 0, S::kSpan1);
-    if constexpr (i >= 0) strip_slice<X_DT, BITS, W, i / S::kSl, 1, i % S::kSl>(b, raw, cv, k);
-  }
+  if constexpr (SL < S::kSpan1)  // k half 1 of this step: raw still holds this step's words
+    strip_slice_run<X_DT, BITS, W, 1, S::first_slice(SL, S::kSpan1), S::first_slice(SL + 1, S::kSpan1)>(b, raw, cv, k);
 #endif
-  if constexpr (MODE <= 2) {
+  if constexpr (MODE < L::kStages) {
 #ifndef CONCH_EXP_STRIP_NOWAIT
-    if constexpr (SL == S::kWait) {  // this wave's pieces of step t + 1 have landed; the requests of step t + 2 may stay in flight
-      if constexpr (MODE <= 1) wait_vmcnt_n<L::kOps>();
-      else CONCH_VMCNT(0);
+    if constexpr (SL == S::kWait) {  // this wave's pieces of step t + 1 have landed; the requests of the steps behind it may stay in flight
+      constexpr int behind = MODE == 0 ? L::kStages - 2 : L::kStages - MODE - 1;  // requested steps younger than t + 1
+      wait_vmcnt_n<behind * L::kOps>();
     }
 #endif
-    if constexpr (SL == S::kRaw) read_raw<BITS, ZPT, W>(raw, lds, ln, wave, next_slot);
+    if constexpr (SL == S::kRaw) read_raw<BITS, ZPT, W, MT>(raw, lds, ln, wave, next_slot);
 #ifndef CONCH_EXP_STRIP_NODQ
-    {  // k half 0 of the next step, into the registers this step's first half has finished with
-      constexpr int i = S::slice_at(SL, S::kHalf, S::kSpan0);
-      if constexpr (i >= 0) strip_slice<X_DT, BITS, W, i / S::kSl, 0, i % S::kSl>(b, raw, cv, k);
-    }
+    if constexpr (SL >= S::kHalf)  // k half 0 of the next step, into the registers this step's first half has finished with
+      strip_slice_run<X_DT, BITS, W, 0, S::first_slice(SL - S::kHalf, S::kSpan0), S::first_slice(SL - S::kHalf + 1, S::kSpan0)>(b, raw, cv, k);
 #endif
   }
-  if constexpr (MODE == 0) {
-    if constexpr (SL >= S::kIssue0 && SL < S::kIssue0 + L::kOps) issue_op<BITS, ZPT>(SL - S::kIssue0, lds, u, ln, wave, is);
-    if constexpr (SL == S::kIssue0 + L::kOps - 1) advance(is, u);
+  if constexpr (MODE == 0 && SL >= S::kIssue0) {
+    constexpr int per = S::template ops_per_slot<L::kOps>();
+    constexpr int first = (SL - S::kIssue0) * per;
+#pragma unroll
+    for (int op = first; op < first + per && op < L::kOps; ++op) issue_op<BITS, ZPT, MT>(op, lds, u, ln, wave, is);
+    if constexpr (first < L::kOps && first + per >= L::kOps) advance<L::kStages>(is, u);
   }
   __builtin_amdgcn_sched_barrier(0);
 }
@@ -258,14 +280,15 @@ struct StripPtrs {
 };
 
 // Slots SL .. 32 W - 1 of one K step of one wave: pair p = SL / W = (k half p / 16, m tile p % 16), n tile SL % W.
-template <int X_DT, int BITS, bool ZPT, int W, int MODE, int SL>
-__device__ __forceinline__ void strip_slots(f32x4 (&acc)[16][W], StripB<W>& b, StripRaw<BITS, W>& raw, StripDequant<X_DT, BITS>& cv, i32x4 (&a)[8],
+template <int X_DT, int BITS, bool ZPT, int W, int MT, int MODE, int SL>
+__device__ __forceinline__ void strip_slots(f32x4 (&acc)[MT][W], StripB<W>& b, StripRaw<BITS, W>& raw, StripDequant<X_DT, BITS>& cv, i32x4 (&a)[StripSlots<W, MT>::kFrags],
                                             const StripPtrs& px, char* lds, const StripSrc& u, const StripLane& ln, const StripConst& k, int wave,
                                             StripIssue& is, int next_slot) {
-  using S = StripSlots<W>;
-  constexpr int P = 8;  // X fragments in flight
+  using S = StripSlots<W, MT>;
+  constexpr int kLast = StripLds<BITS, ZPT, MT>::kStages;  // MODE of the last step
+  constexpr int P = S::kFrags;  // X fragments in flight
   constexpr int p = SL / W, nt = SL % W;
-  if constexpr (MODE <= 2 && SL == S::kBar) {
+  if constexpr (MODE < kLast && SL == S::kBar) {
     // Every read of this step's X stage has been ISSUED (the last refill sits behind pair 23); retire them, then meet: behind
     // the barrier every wave's pieces of step t + 1 have landed (each waited for its own at kWait) and this step's stage is
     // free for the requests of step t + 3.
@@ -276,48 +299,76 @@ __device__ __forceinline__ void strip_slots(f32x4 (&acc)[16][W], StripB<W>& b, S
     __builtin_amdgcn_sched_barrier(0);
 #endif
   }
-  strip_mma<X_DT>(acc[p & 15][nt], b.v[nt][p >> 4], a[p % P]);
+  strip_mma<X_DT>(acc[p % MT][nt], b.v[nt][p / MT], a[p % P]);
 #ifndef CONCH_EXP_STRIP_NOREAD
   if constexpr (nt == W - 1) {
     constexpr int q = p + P;
-    if constexpr (q < 32) a[p % P] = *(const i32x4*)((q >> 4 ? px.xhi : px.xlo) + (q & 15) * 2048);
-    else if constexpr (MODE <= 2) a[p % P] = *(const i32x4*)(px.nlo + (q - 32) * 2048);  // pairs 0-7 of the next step: k half 0
+    if constexpr (q < 2 * MT) a[p % P] = *(const i32x4*)((q / MT ? px.xhi : px.xlo) + (q % MT) * 2048);
+    else if constexpr (MODE < kLast) a[p % P] = *(const i32x4*)(px.nlo + (q - 2 * MT) * 2048);  // the first kFrags pairs of the next step: k half 0
   }
 #endif
-  strip_filler<X_DT, BITS, ZPT, W, MODE, SL>(b, raw, cv, lds, u, ln, k, wave, is, next_slot);
-  if constexpr (SL + 1 < S::kSlots) strip_slots<X_DT, BITS, ZPT, W, MODE, SL + 1>(acc, b, raw, cv, a, px, lds, u, ln, k, wave, is, next_slot);
+  strip_filler<X_DT, BITS, ZPT, W, MT, MODE, SL>(b, raw, cv, lds, u, ln, k, wave, is, next_slot);
+  if constexpr (SL + 1 < S::kSlots) strip_slots<X_DT, BITS, ZPT, W, MT, MODE, SL + 1>(acc, b, raw, cv, a, px, lds, u, ln, k, wave, is, next_slot);
 }
 
 // One K step of one wave.  On entry the first 8 X fragments of the step are in `a` (read behind the previous step's barrier).
 // `slot` = ring slot of step t, `next_slot` = of step t + 1.
-template <int X_DT, int BITS, bool ZPT, int W, int MODE>
-__device__ __forceinline__ void strip_step(f32x4 (&acc)[16][W], StripB<W>& b, StripRaw<BITS, W>& raw, i32x4 (&a)[8], char* lds, const StripSrc& u,
+template <int X_DT, int BITS, bool ZPT, int W, int MT, int MODE>
+__device__ __forceinline__ void strip_step(f32x4 (&acc)[MT][W], StripB<W>& b, StripRaw<BITS, W>& raw, i32x4 (&a)[StripSlots<W, MT>::kFrags], char* lds, const StripSrc& u,
                                            const StripLane& ln, const StripConst& k, int wave, StripIssue& is, int slot, int next_slot) {
-  using L = StripLds<BITS, ZPT>;
-  using S = StripSlots<W>;
-  static_assert(S::kIssue0 + L::kOps <= S::kSlots, "the step's requests fit behind its barrier");
-  static_assert(S::kSpan1 >= S::kN && S::kSpan0 >= S::kN, "one dequantisation slice per slot at most");
-  const StripPtrs px = {lds + slot * kSsXStage + ln.a_lo, lds + slot * kSsXStage + ln.a_hi, lds + next_slot * kSsXStage + ln.a_lo};
+  using L = StripLds<BITS, ZPT, MT>;
+  using S = StripSlots<W, MT>;
+  static_assert(S::kWait >= 0 && S::kSpan1 >= 1 && S::kBar >= S::kHalf && S::kBar < S::kSlots, "slot plan");
+  static_assert(MT < 16 || (S::kIssue0 + L::kOps <= S::kSlots && S::kSpan1 >= S::kN && S::kSpan0 >= S::kN),
+                "the full tile keeps one request and one dequantisation slice per slot at most");
+  const StripPtrs px = {lds + slot * L::kXStage + ln.a_lo, lds + slot * L::kXStage + ln.a_hi, lds + next_slot * L::kXStage + ln.a_lo};
   StripDequant<X_DT, BITS> cv;  // ONE conversion in progress: a chunk's slices occupy consecutive slice slots
-  strip_slots<X_DT, BITS, ZPT, W, MODE, 0>(acc, b, raw, cv, a, px, lds, u, ln, k, wave, is, next_slot);
+  strip_slots<X_DT, BITS, ZPT, W, MT, MODE, 0>(acc, b, raw, cv, a, px, lds, u, ln, k, wave, is, next_slot);
 }
 
-template <int X_DT, int BITS, bool ZPT, int W>
-__device__ __forceinline__ void strip_loop(f32x4 (&acc)[16][W], char* lds, const StripSrc& u, const StripLane& ln, const StripConst& k, int wave,
-                                           int steps, int q0, int s0, int z0) {
-  using L = StripLds<BITS, ZPT>;
-  StripIssue is = {0, 0, q0, s0, z0, u.steps_per_group};
-  issue_all<BITS, ZPT>(lds, u, ln, wave, is);
-  if (steps > 1) issue_all<BITS, ZPT>(lds, u, ln, wave, is);
-  if (steps > 2) issue_all<BITS, ZPT>(lds, u, ln, wave, is);
-  if (steps > 2) wait_vmcnt_n<2 * L::kOps>();
-  else if (steps > 1) wait_vmcnt_n<L::kOps>();
-  else CONCH_VMCNT(0);
+// the wait in front of the first step: j = min(steps, S) - 1 steps were requested behind step 0
+template <int OPS, int J>
+__device__ __forceinline__ void strip_wait_first(int steps) {
+  if constexpr (J == 0) {
+    CONCH_VMCNT(0);
+  } else {
+    if (steps > J) wait_vmcnt_n<J * OPS>();
+    else strip_wait_first<OPS, J - 1>(steps);
+  }
+}
+
+// the last min(steps, S) steps of a slice: MODE m runs when S - m steps follow it
+template <int X_DT, int BITS, bool ZPT, int W, int MT, int MODE>
+__device__ __forceinline__ void strip_tail(f32x4 (&acc)[MT][W], StripB<W>& b, StripRaw<BITS, W>& raw, i32x4 (&a)[StripSlots<W, MT>::kFrags], char* lds, const StripSrc& u,
+                                           const StripLane& ln, const StripConst& k, int wave, StripIssue& is, int slot, int steps) {
+  constexpr int S = StripLds<BITS, ZPT, MT>::kStages;
+  if constexpr (MODE == S) {
+    strip_step<X_DT, BITS, ZPT, W, MT, S>(acc, b, raw, a, lds, u, ln, k, wave, is, slot, 0);
+  } else {
+    if (steps > S - MODE) {
+      const int nxt = slot == S - 1 ? 0 : slot + 1;
+      strip_step<X_DT, BITS, ZPT, W, MT, MODE>(acc, b, raw, a, lds, u, ln, k, wave, is, slot, nxt);
+      slot = nxt;
+    }
+    strip_tail<X_DT, BITS, ZPT, W, MT, MODE + 1>(acc, b, raw, a, lds, u, ln, k, wave, is, slot, steps);
+  }
+}
+
+template <int X_DT, int BITS, bool ZPT, int W, int MT>
+__device__ __forceinline__ void strip_loop(f32x4 (&acc)[MT][W], char* lds, const StripSrc& u, const StripLane& ln, const StripConst& k, int wave,
+                                           int step0, int steps, int q0, int s0, int z0) {
+  using L = StripLds<BITS, ZPT, MT>;
+  StripIssue is = {step0, 0, q0, s0, z0, u.steps_per_group};  // (a K slice starts on a group boundary)
+  issue_all<BITS, ZPT, MT>(lds, u, ln, wave, is);
+#pragma unroll
+  for (int j = 1; j < L::kStages; ++j)
+    if (steps > j) issue_all<BITS, ZPT, MT>(lds, u, ln, wave, is);
+  strip_wait_first<L::kOps, L::kStages - 1>(steps);  // step 0's pieces have landed; the steps requested behind it stay in flight
   __builtin_amdgcn_sched_barrier(0);
   // k half 0 of step 0, converted at once (k half 1 follows inside the step, like every step's)
   StripB<W> b;
   StripRaw<BITS, W> raw;
-  read_raw<BITS, ZPT, W>(raw, lds, ln, wave, 0);
+  read_raw<BITS, ZPT, W, MT>(raw, lds, ln, wave, 0);
 #pragma unroll
   for (int nt = 0; nt < W; ++nt) {
     StripDequant<X_DT, BITS> cv;
@@ -329,38 +380,29 @@ __device__ __forceinline__ void strip_loop(f32x4 (&acc)[16][W], char* lds, const
   }
   __builtin_amdgcn_s_barrier();  // every wave's X pieces of step 0 have landed
   __builtin_amdgcn_sched_barrier(0);
-  i32x4 a[8];
+  i32x4 a[StripSlots<W, MT>::kFrags];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) a[j] = *(const i32x4*)(lds + ln.a_lo + j * 2048);
+  for (int j = 0; j < StripSlots<W, MT>::kFrags; ++j) a[j] = *(const i32x4*)(lds + ln.a_lo + j * 2048);
   int slot = 0;
-  int t = 0;
-  auto next_of = [](int sl_) { return sl_ == kSsStages - 1 ? 0 : sl_ + 1; };
-  for (; t + 3 < steps; ++t) {
-    strip_step<X_DT, BITS, ZPT, W, 0>(acc, b, raw, a, lds, u, ln, k, wave, is, slot, next_of(slot));
-    slot = next_of(slot);
+  for (int t = 0; t + L::kStages < steps; ++t) {
+    const int nxt = slot == L::kStages - 1 ? 0 : slot + 1;
+    strip_step<X_DT, BITS, ZPT, W, MT, 0>(acc, b, raw, a, lds, u, ln, k, wave, is, slot, nxt);
+    slot = nxt;
   }
-  if (steps > 2) {
-    strip_step<X_DT, BITS, ZPT, W, 1>(acc, b, raw, a, lds, u, ln, k, wave, is, slot, next_of(slot));
-    slot = next_of(slot);
-  }
-  if (steps > 1) {
-    strip_step<X_DT, BITS, ZPT, W, 2>(acc, b, raw, a, lds, u, ln, k, wave, is, slot, next_of(slot));
-    slot = next_of(slot);
-  }
-  strip_step<X_DT, BITS, ZPT, W, 3>(acc, b, raw, a, lds, u, ln, k, wave, is, slot, 0);
+  strip_tail<X_DT, BITS, ZPT, W, MT, 1>(acc, b, raw, a, lds, u, ln, k, wave, is, slot, steps);
 }
 
 // Epilogue of one wave: cast to the output dtype (one rounding of the fp32 sum, as the reference's `accumulator.to(out)`), then
 // whole tiles leave through the workgroup-built row-major image (epilogue_rows.hpp), others by direct 8-byte stores.
-template <int OUT_DT, int W, int TILE_N>
-__device__ __forceinline__ void strip_epilogue(const f32x4 (&acc)[16][W], const MixedGemmArgs& p, char* lds, int bm0, int bn0, int col0, int lane,
+template <int OUT_DT, int W, int TILE_N, int MT>
+__device__ __forceinline__ void strip_epilogue(const f32x4 (&acc)[MT][W], const MixedGemmArgs& p, char* lds, int bm0, int bn0, int col0, int lane,
                                                int wave, bool whole) {
   constexpr int kPitch = TILE_N * 2;
   const int g = lane >> 4, r = lane & 15;
   if (whole) {
     // (the caller's closing __syncthreads() made the rings dead)
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int nt = 0; nt < W; ++nt) {
         const f32x4& v = acc[i][nt];
@@ -371,7 +413,7 @@ __device__ __forceinline__ void strip_epilogue(const f32x4 (&acc)[16][W], const 
       }
   } else {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < MT; ++i) {
       const int m = bm0 + 16 * i + r;
       if (m >= (int)p.m) continue;
 #pragma unroll
@@ -392,9 +434,26 @@ __device__ __forceinline__ void strip_epilogue(const f32x4 (&acc)[16][W], const 
   }
 }
 
-template <int X_DT, int BITS, bool ZPT, int W, int TILE_N>
+// K-split form: the wave's fp32 partial sums go to its slice's slab [M][N] (N % 4 == 0: a lane's four columns are inside N or
+// outside together, and 16-byte aligned); launch_f32_slab_reduce adds the slices in slice order and casts once.
+template <int W, int MT>
+__device__ __forceinline__ void strip_epilogue_slab(const f32x4 (&acc)[MT][W], const MixedGemmArgs& p, float* slab, int bm0, int bn0, int col0, int lane) {
+  const int g = lane >> 4, r = lane & 15;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = bm0 + 16 * i + r;
+    if (m >= (int)p.m) continue;
+#pragma unroll
+    for (int nt = 0; nt < W; ++nt) {
+      const int n0 = bn0 + col0 + 16 * nt + 4 * g;
+      if (n0 < (int)p.n) *(f32x4*)(slab + (int64_t)m * p.n + n0) = acc[i][nt];
+    }
+  }
+}
+
+template <int X_DT, int BITS, bool ZPT, int W, int TILE_N, int MT>
 __device__ __forceinline__ void strip_wave(const MixedGemmArgs& p, char* lds, const StripSrc& u, StripLane& ln, const StripConst& k, int wave, int lane,
-                                           int bm0, int bn0, int col0, int steps) {
+                                           int bm0, int bn0, int col0, int step0, int steps) {
   const int r = lane & 15, g = lane >> 4;
   const int gb = col0 & ~31, local = col0 & 31;  // the 32-column group whose words / scales this wave fetches, and its place in it
   // packed words: piece row L >> 3 (a word row), 16-byte chunk L & 7 = four columns; chunks XORed with 4 for odd word rows
@@ -411,30 +470,40 @@ __device__ __forceinline__ void strip_wave(const MixedGemmArgs& p, char* lds, co
     ln.w_rd = (BITS == 4 ? g : 2 * g) * 128 + ((((c >> 2) ^ (4 * (g & 1)))) * 16) + (c & 3) * 4;
     ln.c2 = c * 2;
   }
-  const int q0 = (bn0 + gb) * 4, s0 = (bn0 + gb) * 2, z0 = (bn0 + gb) * 4;  // the column group, in the scalar offsets
+  const int group0 = step0 / u.steps_per_group;  // the slice's first group (split_steps is a multiple of steps_per_group)
+  const int q0 = (bn0 + gb) * 4 + step0 * u.q_step, s0 = (bn0 + gb) * 2 + group0 * u.s_group, z0 = (bn0 + gb) * 4 + group0 * u.z_group;
   CONCH_PROBE(g_probe_mixed_strip, 0);
-  f32x4 acc[16][W];
+  f32x4 acc[MT][W];
 #pragma unroll
-  for (int i = 0; i < 16; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int nt = 0; nt < W; ++nt) acc[i][nt] = f32x4{0, 0, 0, 0};
-  strip_loop<X_DT, BITS, ZPT, W>(acc, lds, u, ln, k, wave, steps, q0, s0, z0);
+  strip_loop<X_DT, BITS, ZPT, W, MT>(acc, lds, u, ln, k, wave, step0, steps, q0, s0, z0);
   CONCH_PROBE(g_probe_mixed_strip, 1);
-  const bool whole = p.rows_epilogue && (p.c_stride_m % 8 == 0) && (((uintptr_t)p.c & 15) == 0) && bm0 + kSsRows <= (int)p.m && bn0 + TILE_N <= (int)p.n &&
-                     ((p.m - 1) * p.c_stride_m + p.n) * 2 < ((int64_t)1 << 32);  // workgroup-uniform
-  __syncthreads();  // every wave is past its last read of the rings (a fence too: see gemm_mixed.hip, mixed_epilogue_rows)
-  strip_epilogue<X_DT, W, TILE_N>(acc, p, lds, bm0, bn0, col0, lane, wave, whole);
-  if (whole) {
-    __syncthreads();
-    image_store_rows<kSsRows, TILE_N * 2>(lds, p.c, p.m, p.n, p.c_stride_m, bm0, bn0, lane, wave);
+  if (p.slabs) {
+    strip_epilogue_slab<W, MT>(acc, p, p.slabs + (int64_t)blockIdx.y * p.m * p.n, bm0, bn0, col0, lane);
+    return;
+  }
+  if constexpr (MT == 16) {
+    const bool whole = p.rows_epilogue && (p.c_stride_m % 8 == 0) && (((uintptr_t)p.c & 15) == 0) && bm0 + kSsRows <= (int)p.m && bn0 + TILE_N <= (int)p.n &&
+                       ((p.m - 1) * p.c_stride_m + p.n) * 2 < ((int64_t)1 << 32);  // workgroup-uniform
+    __syncthreads();  // every wave is past its last read of the rings (a fence too: see gemm_mixed.hip, mixed_epilogue_rows)
+    strip_epilogue<X_DT, W, TILE_N, MT>(acc, p, lds, bm0, bn0, col0, lane, wave, whole);
+    if (whole) {
+      __syncthreads();
+      image_store_rows<kSsRows, TILE_N * 2>(lds, p.c, p.m, p.n, p.c_stride_m, bm0, bn0, lane, wave);
+    }
+  } else {
+    strip_epilogue<X_DT, W, TILE_N, MT>(acc, p, lds, bm0, bn0, col0, lane, wave, false);
   }
 }
 
-template <int X_DT, int BITS, bool ZPT, int WA, int WB>
+template <int X_DT, int BITS, bool ZPT, int WA, int WB, int MT>
 __global__ __launch_bounds__(kThreads, 2) void mixed_strip_kernel(MixedGemmArgs p) {
-  using L = StripLds<BITS, ZPT>;
+  using L = StripLds<BITS, ZPT, MT>;
+  constexpr int kRows = 16 * MT;
   constexpr int kTileN = 64 * WA + 64 * WB;
-  constexpr int kImage = kSsRows * kTileN * 2;
+  constexpr int kImage = MT == 16 ? kSsRows * kTileN * 2 : 0;
   constexpr int kLds = L::kRing > kImage ? L::kRing : kImage;
   static_assert(kLds <= 160 * 1024, "LDS budget");
   __shared__ __attribute__((aligned(1024))) char lds[kLds];
@@ -442,11 +511,13 @@ __global__ __launch_bounds__(kThreads, 2) void mixed_strip_kernel(MixedGemmArgs 
                                      // matching function", no reason given; the device pass takes it): it only needs the stub
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  const int tiles_m = ((int)p.m + kSsRows - 1) / kSsRows;
+  const int tiles_m = ((int)p.m + kRows - 1) / kRows;
   const int tiles_n = ((int)p.n + kTileN - 1) / kTileN;
   const TileCoord tc = map_tile(blockIdx.x, tiles_m, tiles_n, p.raster_magic, p.raster_shift);
-  const int bm0 = tc.tm * kSsRows, bn0 = tc.tn * kTileN;
-  const int steps = (int)(p.k / kSsStepK);
+  const int bm0 = tc.tm * kRows, bn0 = tc.tn * kTileN;
+  const int total_steps = (int)(p.k / kSsStepK);
+  const int step0 = p.split_steps ? (int)blockIdx.y * p.split_steps : 0;        // K slice (split-K form: blockIdx.y)
+  const int steps = p.split_steps ? min(p.split_steps, total_steps - step0) : total_steps;
 
   StripSrc u;
   const int64_t word_rows = p.k * BITS / 32, groups = p.k / p.group_size;
@@ -462,11 +533,11 @@ __global__ __launch_bounds__(kThreads, 2) void mixed_strip_kernel(MixedGemmArgs 
 
   StripLane ln;
   {
-    // piece j of the wave = rows 32 wave + 8 j .. + 7; rows past M are past the END of the buffer (row M starts at M ldx >=
-    // (M - 1) ldx + K): the range check of the buffer load zero-fills them, no clamp
+    // piece j of the wave = rows 8 (XP wave + j) .. + 7, XP = MT / 4 pieces per wave; rows past M are past the END of the buffer
+    // (row M starts at M ldx >= (M - 1) ldx + K): the range check of the buffer load zero-fills them, no clamp
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int row = 32 * wave + 8 * j + (lane >> 3);
+      const int row = 8 * L::kXPieces * wave + 8 * j + (lane >> 3);
       const int chunk = (lane & 7) ^ ((row >> 1) & 7);
       ln.vx[j] = (bm0 + row) * ((int)p.x_stride_m * 2) + chunk * 16;
     }
@@ -485,35 +556,46 @@ __global__ __launch_bounds__(kThreads, 2) void mixed_strip_kernel(MixedGemmArgs 
   asm volatile("" : "+v"(k.and_mask), "+s"(k.or_magic), "+v"(k.and_mask_hi));
 
   if constexpr (WA == WB) {
-    strip_wave<X_DT, BITS, ZPT, WA, kTileN>(p, lds, u, ln, k, wave, lane, bm0, bn0, wave * 16 * WA, steps);
+    strip_wave<X_DT, BITS, ZPT, WA, kTileN, MT>(p, lds, u, ln, k, wave, lane, bm0, bn0, wave * 16 * WA, step0, steps);
   } else {
-    if (wave < 4) strip_wave<X_DT, BITS, ZPT, WA, kTileN>(p, lds, u, ln, k, wave, lane, bm0, bn0, wave * 16 * WA, steps);
-    else strip_wave<X_DT, BITS, ZPT, WB, kTileN>(p, lds, u, ln, k, wave, lane, bm0, bn0, 64 * WA + (wave - 4) * 16 * WB, steps);
+    if (wave < 4) strip_wave<X_DT, BITS, ZPT, WA, kTileN, MT>(p, lds, u, ln, k, wave, lane, bm0, bn0, wave * 16 * WA, step0, steps);
+    else strip_wave<X_DT, BITS, ZPT, WB, kTileN, MT>(p, lds, u, ln, k, wave, lane, bm0, bn0, 64 * WA + (wave - 4) * 16 * WB, step0, steps);
   }
 #endif
 }
 
-template <int X_DT, int BITS, bool ZPT>
+int strip_slices(const MixedGemmArgs& p) {
+  return p.split_steps ? (int)((p.k / kSsStepK + p.split_steps - 1) / p.split_steps) : 1;
+}
+
+template <int X_DT, int BITS, bool ZPT, int MT>
 int launch_width(const MixedGemmArgs& p, int nt, hipStream_t stream) {
-  const int tile_n = 64 * nt;
-  const int tiles_m = (int)((p.m + kSsRows - 1) / kSsRows), tiles_n = (int)((p.n + tile_n - 1) / tile_n);
-  const dim3 grid((unsigned)(tiles_m * tiles_n)), block(kThreads);
-  if (nt == 4) hipLaunchKernelGGL((mixed_strip_kernel<X_DT, BITS, ZPT, 2, 2>), grid, block, 0, stream, p);
-  else if (nt == 3) hipLaunchKernelGGL((mixed_strip_kernel<X_DT, BITS, ZPT, 2, 1>), grid, block, 0, stream, p);
-  else hipLaunchKernelGGL((mixed_strip_kernel<X_DT, BITS, ZPT, 1, 1>), grid, block, 0, stream, p);
+  const int tile_n = 64 * nt, rows = 16 * MT;
+  const int tiles_m = (int)((p.m + rows - 1) / rows), tiles_n = (int)((p.n + tile_n - 1) / tile_n);
+  const dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)strip_slices(p)), block(kThreads);
+  if (nt == 4) hipLaunchKernelGGL((mixed_strip_kernel<X_DT, BITS, ZPT, 2, 2, MT>), grid, block, 0, stream, p);
+  else if (nt == 3) hipLaunchKernelGGL((mixed_strip_kernel<X_DT, BITS, ZPT, 2, 1, MT>), grid, block, 0, stream, p);
+  else hipLaunchKernelGGL((mixed_strip_kernel<X_DT, BITS, ZPT, 1, 1, MT>), grid, block, 0, stream, p);
   return check_launch("mixed_gemm_strip");
 }
 
+template <int X_DT, int BITS, bool ZPT>
+int launch_rows(const MixedGemmArgs& p, int nt, int mt, hipStream_t stream) {
+  if (mt == 4) return launch_width<X_DT, BITS, ZPT, 4>(p, nt, stream);
+  if (mt == 8) return launch_width<X_DT, BITS, ZPT, 8>(p, nt, stream);
+  return launch_width<X_DT, BITS, ZPT, 16>(p, nt, stream);
+}
+
 template <int X_DT, int BITS>
-int launch_zp(const MixedGemmArgs& p, int nt, hipStream_t stream) {
-  return p.zp_mode == CONCH_ZP_TENSOR ? launch_width<X_DT, BITS, true>(p, nt, stream) : launch_width<X_DT, BITS, false>(p, nt, stream);
+int launch_zp(const MixedGemmArgs& p, int nt, int mt, hipStream_t stream) {
+  return p.zp_mode == CONCH_ZP_TENSOR ? launch_rows<X_DT, BITS, true>(p, nt, mt, stream) : launch_rows<X_DT, BITS, false>(p, nt, mt, stream);
 }
 
 }  // namespace
 
 bool mixed_gemm_strip_supported(const MixedGemmArgs& p) {
   if (!mixed_gemm_mfma_supported(p)) return false;
-  if (p.fuse_silu || p.prepacked || p.split_steps || p.slabs) return false;
+  if (p.fuse_silu || p.prepacked || p.split_steps || p.slabs) return false;  // (the K split is this launcher's own choice)
   if (p.out_dtype != p.x_dtype) return false;
   // bf16 x 8-bit weights: the widening dequantisation (fp32 pairs, the difference rounded to bf16 first) on top of 128 accumulators
   // and 16 + 16 operand registers spills in the wide strips (288 bytes of scratch per lane inside the K loop); the LDS-tiled
@@ -527,6 +609,11 @@ bool mixed_gemm_strip_supported(const MixedGemmArgs& p) {
 }
 
 int pick_strip_nt(const MixedGemmArgs& p, int num_cus);
+
+struct StripPlan {
+  int mt = 16, nt = 4, split = 1;  // m tiles per wave (tile rows / 16), tile width / 64, K slices
+  double us = 1e30;                // the cost model's time for it (one row of tiles only)
+};
 
 // Auto rule, from the interleaved sweep of 48 shapes x the two kernels (profiles/r04/mixed_strip_sweep.txt).  On the benchmark's
 // data both kernels run against the chip's POWER limit (in-loop clock 1.75-1.85 GHz; on all-zero activations, where the clock stays
@@ -561,14 +648,72 @@ int pick_strip_nt(const MixedGemmArgs& p, int num_cus) {
   return best;
 }
 
+// Tile rows, tile width and K slices of a launch.  Tall problems (M > 256) keep the unsplit 256-row tile at pick_strip_nt's width;
+// one row of tiles (M <= 256: the batched-decode sizes) takes the smallest tile that holds M -- 64 / 128 / 256 rows: every weight is
+// still dequantised once, the MFMAs of absent rows are not issued -- and as many K slices as fill the chip once, by the cost model
+// of dispatch_fit.hpp (MixedStripSplit).  CONCH_TUNE_MIXED_STRIP_ROWS / _TILE_NT / _SPLITK force the three choices.
+StripPlan strip_plan(const MixedGemmArgs& p) {
+  const int cus = device_cu_count();
+  const int f_rows = tuning(CONCH_TUNE_MIXED_STRIP_ROWS), f_nt = tuning(CONCH_TUNE_MIXED_TILE_NT), f_split = tuning(CONCH_TUNE_MIXED_SPLITK);
+  StripPlan best;
+  best.mt = (f_rows == 64 || f_rows == 128 || f_rows == 256) ? f_rows / 16 : p.m <= 64 ? 4 : p.m <= 128 ? 8 : 16;
+  const int steps = (int)(p.k / kSsStepK), spg = p.group_size / kSsStepK;
+  const bool may_split = p.n % 4 == 0 && f_split != 1;
+  if (p.m > kSsRows && f_split <= 1) {  // the tall form
+    best.nt = (f_nt >= 2 && f_nt <= 4) ? f_nt : pick_strip_nt(p, cus);
+    return best;
+  }
+  const fit::MixedStripSplit& f = fit::kMixedStripSplit;
+  const int64_t tiles_m = (p.m + 16 * best.mt - 1) / (16 * best.mt);
+  for (int nt = 4; nt >= 2; --nt) {
+    if (f_nt >= 2 && f_nt <= 4 && nt != f_nt) continue;
+    const int64_t tiles = tiles_m * ((p.n + 64 * nt - 1) / (64 * nt));
+    for (int s = 1; s <= 8; ++s) {
+      if (s > 1 && !may_split) break;
+      if (f_split >= 2 && s != std::min(f_split, 8)) continue;
+      const int per = ((steps + s - 1) / s + spg - 1) / spg * spg;  // steps per slice, whole groups
+      const int slices = (steps + per - 1) / per;
+      if (slices != s) continue;                                     // (the rounding made it another candidate)
+      if (s > 1 && per < 4) break;
+      const double rounds = (double)((tiles * s + cus - 1) / cus), fill = (double)(tiles * s) / (rounds * cus);
+      const double us = f.wg_fixed + rounds * per * (1.0 + f.fill_slowdown * fill) *
+                            (f.step + f.step_mt * best.mt + f.step_nt * nt + f.step_mt_nt * best.mt * nt) * (p.bits == 8 ? 1.1 : 1.0) +
+                        (s > 1 ? f.launch2 + (double)s * (double)p.m * (double)p.n * f.slab_per_elem : 0.0);
+      if (us < best.us - 1e-9) {
+        best.us = us;
+        best.nt = nt;
+        best.split = s;
+      }
+    }
+  }
+  if (best.us > 1e29) {  // nothing admissible under the forced keys: the plain form
+    best.nt = (f_nt >= 2 && f_nt <= 4) ? f_nt : pick_strip_nt(p, cus);
+    best.split = 1;
+  }
+  return best;
+}
+
+// the cost model's time (us) for the strip kernel's pick on one row of tiles (the dispatcher compares it with the other kernels')
+double mixed_strip_estimate_us(const MixedGemmArgs& p) { return strip_plan(p).us; }
+
 int launch_mixed_gemm_strip(const MixedGemmArgs& p_in, hipStream_t stream) {
   MixedGemmArgs p = p_in;
   p.rows_epilogue = tuning(CONCH_TUNE_EPILOGUE) != 1;
-  const int forced = tuning(CONCH_TUNE_MIXED_TILE_NT);
-  const int nt = (forced >= 2 && forced <= 4) ? forced : pick_strip_nt(p, device_cu_count());
+  const StripPlan plan = strip_plan(p);
+  const int nt = plan.nt;
+  if (plan.split > 1) {
+    const int steps = (int)(p.k / kSsStepK), spg = p.group_size / kSsStepK;
+    p.split_steps = ((steps + plan.split - 1) / plan.split + spg - 1) / spg * spg;
+    void* ws = nullptr;
+    if (int rc = get_scratch(stream, kScratchMixedSplitK, (size_t)strip_slices(p) * p.m * p.n * 4, &ws)) return rc;
+    p.slabs = (float*)ws;
+  }
   set_raster_divisor((uint32_t)(kGroupM * ((p.n + 64 * nt - 1) / (64 * nt))), &p.raster_magic, &p.raster_shift);
-  if (p.x_dtype == CONCH_DT_FP16) return p.bits == 4 ? launch_zp<CONCH_DT_FP16, 4>(p, nt, stream) : launch_zp<CONCH_DT_FP16, 8>(p, nt, stream);
-  return launch_zp<CONCH_DT_BF16, 4>(p, nt, stream);  // (bf16 x 8-bit: not built, see mixed_gemm_strip_supported)
+  int rc;
+  if (p.x_dtype == CONCH_DT_FP16) rc = p.bits == 4 ? launch_zp<CONCH_DT_FP16, 4>(p, nt, plan.mt, stream) : launch_zp<CONCH_DT_FP16, 8>(p, nt, plan.mt, stream);
+  else rc = launch_zp<CONCH_DT_BF16, 4>(p, nt, plan.mt, stream);  // (bf16 x 8-bit: not built, see mixed_gemm_strip_supported)
+  if (rc || !p.slabs) return rc;
+  return launch_f32_slab_reduce(p.c, p.slabs, strip_slices(p), p.m, p.n, p.c_stride_m, p.out_dtype, stream);
 }
 
 }  // namespace conch

@@ -119,7 +119,8 @@ typedef enum conch_tuning_key {
                                  K % 256 == 0, N % 16 == 0, no bias).  mixed_precision_gemm has one LDS-tiled MFMA
                                  kernel: 1 = generic, any other value = that kernel */
   ,
-  CONCH_TUNE_MIXED_TILE_NT = 1 /* mixed_precision_gemm tile shape: 0 = auto, 2..4 = force 256 rows x 64 NT columns, 5 = force 512 x 128 */
+  CONCH_TUNE_MIXED_TILE_NT = 1 /* mixed_precision_gemm tile shape: 0 = auto, 2..4 = force 256 rows x 64 NT columns, 5 = force 512 x 128
+                                  (LDS-tiled kernel only) */
   ,
   CONCH_TUNE_SKINNY_NO_SPLITK = 2 /* 1 = keep the skinny-M scaled GEMM's K split inside the workgroup */
   ,
@@ -146,8 +147,9 @@ typedef enum conch_tuning_key {
   CONCH_TUNE_MID_STAGES = 8 /* 128x128-tile scaled GEMM: 0 = auto (the 4-stage ring, one workgroup per CU, when there is at
                                most one tile per CU; else the 2-stage loop, two workgroups per CU), 2 / 4 = force */
   ,
-  CONCH_TUNE_MIXED_SPLITK = 9 /* LDS-tiled mixed_precision_gemm: K slices per tile (fp32 slabs + reduce kernel) when the tiles
-                                 leave most of the chip idle: 0 = auto, 1 = never, 2 / 4 / 8 = force */
+  CONCH_TUNE_MIXED_SPLITK = 9 /* LDS-tiled and column-strip mixed_precision_gemm: K slices per tile (fp32 slabs + reduce kernel) when
+                                 the tiles leave most of the chip idle: 0 = auto, 1 = never, 2 / 4 / 8 = force (the strip kernel
+                                 takes any count from 2 to 8) */
   ,
   CONCH_TUNE_SKINNY_GATHER = 10 /* fetch order of the decode kernels' operands (all forms bit-identical):
                                    - split-K skinny-M scaled GEMM (gemm_skinny.hip), the wave's B^T fragments: 0 = auto (2 when the
@@ -173,7 +175,9 @@ typedef enum conch_tuning_key {
                                tiles leave at least half the chip idle and K >= 4096: 0 = auto, 1 = never, 2..8 = that many */,
   CONCH_TUNE_SKINNY_CHUNKS = 13 /* split-K skinny-M scaled GEMM: passes of one 1024- / 2048-byte K unit a workgroup makes before it
                                   leaves its partial sums (fewer slabs for a long K): 0 = auto, n >= 1 = that many */,
-  CONCH_TUNE__COUNT = 14 /* number of keys (array bound; not a key) */
+  CONCH_TUNE_MIXED_STRIP_ROWS = 14 /* column-strip mixed_precision_gemm (gemm_mixed_strip.hip): rows of its tile: 0 = auto (64 / 128
+                                      rows for M <= 64 / 128 in the K-split forms, else 256), 64 / 128 / 256 = force */,
+  CONCH_TUNE__COUNT = 15 /* number of keys (array bound; not a key) */
 } conch_tuning_key_t;
 
 int conch_abi_version(void);

@@ -173,6 +173,7 @@ def _reset_tuning():
     _C.set_tuning(_C.TUNE_MIXED_TILE_NT, 0)
     _C.set_tuning(_C.TUNE_MID_SPLITK, 0)
     _C.set_tuning(_C.TUNE_SKINNY_CHUNKS, 0)
+    _C.set_tuning(_C.TUNE_MIXED_STRIP_ROWS, 0)
 
 
 @pytest.mark.parametrize("slices", [2, 3, 5, 8])
@@ -882,6 +883,61 @@ def test_mixed_strip_kernel_is_bit_identical_and_correct(_reset_tuning, m, k, n,
             assert torch.equal(strip, tiled), f"tile width {64 * nt}: {(strip != tiled).sum().item()} elements differ"
     _C.set_tuning(_C.TUNE_MIXED_TILE_NT, 0)
     check_mixed(mixed_precision_gemm(*args), a, w_ref, k)
+
+
+@pytest.mark.parametrize(("m", "k", "n"), [(64, 1024, 512), (33, 512, 200), (128, 2048, 704), (100, 1152, 1000), (256, 1024, 384), (200, 768, 260),
+                                           (48, 128, 192), (1, 256, 64)])
+@pytest.mark.parametrize("wname", list(WTYPES))
+@pytest.mark.parametrize("use_zp", [True, False])
+@pytest.mark.parametrize("dname", ["f16", "bf16"])
+def test_mixed_strip_kernel_short_tiles_and_k_split(_reset_tuning, m, k, n, wname, use_zp, dname):
+    """Round 5, batched-decode sizes: the column-strip kernel on 64- / 128-row tiles (4 / 8 m tiles per wave: several
+    dequantisation slices and requests per MFMA slot, deeper rings, more X fragments in flight) and with K split over
+    workgroups (fp32 slabs [slice][M][N], added in slice order by the fp32-slab reduce).  Unsplit, every tile height and width
+    gives the LDS-tiled kernel's bits (same dequantised weights, same MFMA, same order of K per output); split, the sums are
+    grouped by slice -- checked against the oracle with the per-element bound of check_mixed -- and do not depend on the tile
+    shape (the slices are the same K ranges).  Ragged M / N / last slice, one to 32 K steps, groups inside and across slices."""
+    if dname == "bf16" and WTYPES[wname].size_bits == 8:
+        pytest.skip("bf16 x 8-bit weights: the LDS-tiled kernel keeps that combination (mixed_gemm_strip_supported)")
+    wt = WTYPES[wname]
+    a, w_ref, packed, w_s, w_zp = make_mixed_inputs(m, k, n, wt, use_zp, DT[dname])
+    args = (a.cuda(), packed.cuda(), w_s.cuda(), None if w_zp is None else w_zp.cuda(), wt.size_bits, wt.bias, 128)
+    _C.set_gemm_variant(_C.VARIANT_MFMA_PINGPONG2)
+    _C.set_tuning(_C.TUNE_MIXED_SPLITK, 1)
+    _C.set_tuning(_C.TUNE_MIXED_KERNEL, 1)
+    tiled = mixed_precision_gemm(*args)
+    _C.set_tuning(_C.TUNE_MIXED_KERNEL, 2)
+    for rows in (64, 128, 256):
+        _C.set_tuning(_C.TUNE_MIXED_STRIP_ROWS, rows)
+        for nt in (4, 3, 2):
+            _C.set_tuning(_C.TUNE_MIXED_TILE_NT, nt)
+            strip = mixed_precision_gemm(*args)
+            assert torch.equal(strip, tiled), f"{rows}-row x {64 * nt}-column tiles: {(strip != tiled).sum().item()} elements differ"
+    if n % 4 == 0:
+        for split in (2, 3, 8):
+            if k // 128 < split:
+                continue
+            _C.set_tuning(_C.TUNE_MIXED_SPLITK, split)
+            first = None
+            for rows, nt in ((64, 2), (128, 3), (256, 4), (0, 0)):
+                _C.set_tuning(_C.TUNE_MIXED_STRIP_ROWS, rows)
+                _C.set_tuning(_C.TUNE_MIXED_TILE_NT, nt)
+                got = mixed_precision_gemm(*args)
+                if first is None:
+                    first = got
+                    check_mixed(got, a, w_ref, k)
+                else:
+                    assert torch.equal(got, first), f"{split} slices: {rows}-row x {64 * nt}-column tiles differ from 64 x 128"
+
+
+@pytest.mark.parametrize(("m", "k", "n"), [(64, 4096, 11008), (128, 4096, 11008), (96, 8192, 8192), (48, 4096, 14336), (200, 5120, 13824)])
+def test_mixed_precision_gemm_batched_decode_sizes_take_the_strip_forms(_reset_tuning, m, k, n):
+    """The dispatcher's own pick at 33..256 rows on wide / deep problems (dispatch_fit.hpp MixedStripSplit) against the oracle,
+    every element (fp64 product of the reference's operands, per-element bound), on the benchmark's weight type."""
+    wt = WTYPES["uint4b8"]
+    a, w_ref, packed, w_s, w_zp = make_mixed_inputs(m, k, n, wt, False, torch.float16)
+    got = mixed_precision_gemm(a.cuda(), packed.cuda(), w_s.cuda(), None, wt.size_bits, wt.bias, 128)
+    check_mixed_whole(got, a, w_ref, k)
 
 
 @pytest.mark.parametrize(("m", "k", "n"), [(128, 256, 128), (33, 384, 200)])
