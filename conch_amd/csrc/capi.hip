@@ -530,14 +530,20 @@ int run_mixed_silu(const MixedGemmArgs& p, hipStream_t stream) {
   // 65-256 rows (round 4, profiles/r04/fused_ops_sweep.txt): the plain op now splits K over one row of tiles, and the pair
   // "split tiles into scratch + the elementwise tail" beats both fused forms there (128 x 4096 x 22016: 88 us fused, 62 as two ops)
   bool pair_wins = false;
-  if (variant == 0 && p.m > 64 && p.m <= 256 && mixed_gemm_mfma_supported(wide) && tuning(CONCH_TUNE_MIXED_SPLITK) == 0) {
-    const double pair_us = mixed_tiles_estimate_us(wide) + 4.0;
+  // (round 5: from 33 rows on, and the plain op's time is the better of its LDS-tiled and K-split strip forms -- run_mixed's own rule)
+  // ... and above 256 rows while the fused tiles (256 x 128 of the result, never split) leave CUs idle: 512 x 4096 x 2*4096 ran 88.7 us
+  // fused on 64 tiles against 57.1 us as the plain op in K slices + the elementwise tail (profiles/r05/mixed_silu_mid.txt)
+  const int64_t fused_tiles = ((p.m + 255) / 256) * ((p.n + 127) / 128);
+  if (variant == 0 && p.m >= fit::kMixedStripSplit.min_m && (p.m <= 256 || fused_tiles < device_cu_count()) && mixed_gemm_mfma_supported(wide) &&
+      tuning(CONCH_TUNE_MIXED_SPLITK) == 0) {
+    const bool strip_ok = tuning(CONCH_TUNE_MIXED_KERNEL) == 0 && tuning(CONCH_TUNE_MIXED_TILE_NT) == 0 && mixed_gemm_strip_supported(wide);
+    const double pair_us = std::min(mixed_tiles_estimate_us(wide), strip_ok ? mixed_strip_estimate_us(wide) * fit::kMixedStripSplit.margin : 1e30) + 4.0;
     const double blocks = (double)((p.m + 63) / 64);
     const fit::MixedDecode& fd = fit::kMixedDecode;
     const double decode_us = decode ? fd.fixed + fd.per_nk_block * (double)wide.n * (double)p.k * blocks * (p.bits == 8 ? fd.int8_factor : 1.0) : 1e30;
     // the fused tile is 256 gate/up columns wide (128 of the result) and never splits: 1.35 us per 64 of K at one tile per CU
     // (86 us at K = 4096 whatever M <= 256 is; profiles/r04/fused_ops_sweep.txt)
-    const double fused_rounds = (double)(((p.n + 127) / 128 + device_cu_count() - 1) / device_cu_count());
+    const double fused_rounds = (double)((fused_tiles + device_cu_count() - 1) / device_cu_count());
     const double fused_us = mixed_gemm_silu_fused_supported(p) ? 1.35 * (double)(p.k / 64) * fused_rounds : 1e30;
     pair_wins = pair_us < std::min(decode_us, fused_us);
     if (pair_wins) decode = false;

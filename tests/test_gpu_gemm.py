@@ -1312,8 +1312,9 @@ def test_mixed_precision_decode_batches(m, k, n, wname, use_zp, dname):
     tiled = mixed_precision_gemm(*args)
     _C.set_gemm_variant(_C.VARIANT_AUTO)
     auto = mixed_precision_gemm(*args)
-    assert torch.equal(auto, got if m <= 64 else auto)  # auto = the decode-batch kernel up to 64 rows (a cost rule above)
-    assert torch.equal(auto, got) or torch.equal(auto, tiled)
+    assert torch.equal(auto, got if m <= 32 else auto)  # auto = the decode-batch kernel up to 32 rows (a cost rule above)
+    if not (torch.equal(auto, got) or torch.equal(auto, tiled)):
+        check_mixed(auto, a, w_ref, k)  # 33..256 rows: the K-split strip forms (their own K slices)
     tol = 2.0 * EPS[DT[dname]] * tiled.float().abs().max().item()
     assert (got.float() - tiled.float()).abs().max().item() <= tol
 
@@ -1682,7 +1683,11 @@ def test_mixed_precision_down_projection_decode(m, wname, use_zp, dname):
     got = mixed_precision_gemm(*args)
     check_mixed(got, a, w_ref, k)
     _C.set_gemm_variant(_C.VARIANT_AUTO)
-    assert torch.equal(mixed_precision_gemm(*args), got)  # auto = the decode-batch kernel
+    auto = mixed_precision_gemm(*args)
+    if m <= 32:
+        assert torch.equal(auto, got)  # auto = the decode-batch kernel
+    else:
+        check_mixed(auto, a, w_ref, k)  # from 33 rows the K-split strip forms may take it (other K slices: other fp32 sums)
 
 
 def test_mixed_precision_ragged_slice_ignores_inf_behind_k():

@@ -64,7 +64,8 @@ def mixed_family():
     shapes = [(16, 4096, 11008), (128, 4096, 4096), (256, 8192, 8192), (512, 4096, 11008), (1024, 4096, 11008), (1024, 8192, 28672),
               (4096, 8192, 4096)]
     if not QUICK:
-        shapes += [(64, 4096, 11008), (768, 4096, 11008), (2048, 4096, 11008), (1024, 5120, 13824)]
+        shapes += [(64, 4096, 11008), (768, 4096, 11008), (2048, 4096, 11008), (1024, 5120, 13824), (48, 8192, 8192), (96, 4096, 4096), (128, 8192, 28672),
+                   (192, 5120, 13824)]
     worst = (0.0, None)
     print("== mixed_precision_gemm int4 x fp16 (us; * = fastest candidate)")
     for m, k, n in shapes:
@@ -85,12 +86,11 @@ def mixed_family():
                 cand[f"tiles{64 * nt}"] = forced(1, nt)
             except (NotImplementedError, ValueError):
                 pass
-        if m > 256:
-            try:
-                cand["strip"] = forced(2)
-            except (NotImplementedError, ValueError):
-                pass
-        else:
+        try:
+            cand["strip"] = forced(2)  # m > 256: the unsplit 256-row tile; else strip_plan's tile height, width and K slices
+        except (NotImplementedError, ValueError):
+            pass
+        if m <= 256:
             try:
                 cand["decode"] = forced(0, 0, variant=4)
             except (NotImplementedError, ValueError):
@@ -103,8 +103,8 @@ def mixed_family():
             worst = (ratio, (m, k, n))
         line = "  ".join(f"{lb}{'*' if lb == best_label else ' '}{t:8.1f}" for lb, t in cand.items())
         print(f"  {m:5d}x{k:5d}x{n:6d}  auto {auto:8.1f}  ratio {ratio:5.2f}   {line}", flush=True)
-    print(f"  worst automatic pick: {worst[0]:.2f}x at {worst[1]}  (rows MixedDecode / MixedSplit / MixedTileSplit / MixedStrip; refit: "
-          "tools/sweep_mixed_split.py, tools/sweep_mixed_nt_split.py, tools/sweep_mixed_strip.py)")
+    print(f"  worst automatic pick: {worst[0]:.2f}x at {worst[1]}  (rows MixedDecode / MixedSplit / MixedTileSplit / MixedStrip / MixedStripSplit; refit: "
+          "tools/archive/sweep_mixed_split.py, sweep_mixed_nt_split.py, sweep_mixed_strip.py, tools/sweep_mixed_mid.py)")
     return worst[0]
 
 
