@@ -472,16 +472,17 @@ __device__ __forceinline__ void strip_wave(const MixedGemmArgs& p, char* lds, co
   }
   const int group0 = step0 / u.steps_per_group;  // the slice's first group (split_steps is a multiple of steps_per_group)
   const int q0 = (bn0 + gb) * 4 + step0 * u.q_step, s0 = (bn0 + gb) * 2 + group0 * u.s_group, z0 = (bn0 + gb) * 4 + group0 * u.z_group;
-  CONCH_PROBE(g_probe_mixed_strip, 0);
+  CONCH_PROBE_AT(g_probe_mixed_strip, 0, (int)(blockIdx.x + gridDim.x * blockIdx.y));
   f32x4 acc[MT][W];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int nt = 0; nt < W; ++nt) acc[i][nt] = f32x4{0, 0, 0, 0};
   strip_loop<X_DT, BITS, ZPT, W, MT>(acc, lds, u, ln, k, wave, step0, steps, q0, s0, z0);
-  CONCH_PROBE(g_probe_mixed_strip, 1);
+  CONCH_PROBE_AT(g_probe_mixed_strip, 1, (int)(blockIdx.x + gridDim.x * blockIdx.y));
   if (p.slabs) {
     strip_epilogue_slab<W, MT>(acc, p, p.slabs + (int64_t)blockIdx.y * p.m * p.n, bm0, bn0, col0, lane);
+    CONCH_PROBE_AT(g_probe_mixed_strip, 3, (int)(blockIdx.x + gridDim.x * blockIdx.y));
     return;
   }
   if constexpr (MT == 16) {
@@ -509,6 +510,7 @@ __global__ __launch_bounds__(kThreads, 2) void mixed_strip_kernel(MixedGemmArgs 
   __shared__ __attribute__((aligned(1024))) char lds[kLds];
 #if defined(__HIP_DEVICE_COMPILE__)  // the HOST pass of hipcc (ROCm 7.2) fails to substitute issue_op<> inside strip_filler<> ("no
                                      // matching function", no reason given; the device pass takes it): it only needs the stub
+  CONCH_PROBE_AT(g_probe_mixed_strip, 2, (int)(blockIdx.x + gridDim.x * blockIdx.y));
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int tiles_m = ((int)p.m + kRows - 1) / kRows;
