@@ -109,6 +109,9 @@ struct MixedGemmArgs {
   // multiple of group_size / 64), fp32 partial sums to slabs [slice][M][N] instead of the cast-and-store epilogue
   int split_steps = 0;
   float* slabs = nullptr;
+  // column-strip kernel, K-split form in ONE launch: arrival counters, one per (tile, wave), zero between launches (library scratch);
+  // the wave that draws a tile strip's last ticket adds the slices in slice order and stores C.  NULL = the slab reduce kernel follows
+  unsigned* counters = nullptr;
   // whole tiles of the LDS-tiled kernel: 1 = row-major epilogue through LDS (whole-line write-through stores), 0 = direct stores
   // from the accumulator layout (set by the launcher from CONCH_TUNE_EPILOGUE)
   int rows_epilogue = 1;

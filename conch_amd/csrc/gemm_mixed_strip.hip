@@ -47,6 +47,7 @@ constexpr int kSsRows = 256;                       // rows of the full tile: MT 
                                                    // still dequantised once per workgroup
 constexpr int kSsStepK = 64;                       // k elements per step = 128 bytes of fp16 / bf16
 constexpr int kSsMeta = 256;                       // bytes of one 4-byte-per-lane LDS-DMA piece
+constexpr int kStripMaxCounters = 16384;           // arrival counters per (device, stream): the 64 KiB slot the decode kernels use too
 
 #ifdef CONCH_CLOCK_PROBE
 __device__ unsigned long long g_probe_mixed_strip[kProbeBlocks * 8];
@@ -451,6 +452,87 @@ __device__ __forceinline__ void strip_epilogue_slab(const f32x4 (&acc)[MT][W], c
   }
 }
 
+// K-split form in ONE launch (p.counters): the hand-off of gemm_mixed_skinny.hip's one-launch form (MI355X_MICROARCH.md, table of
+// measured hand-offs, first row).  Every wave stores its partial sums write-through (sc1) and drains its own stores; one lane draws
+// a ticket from the (tile, wave) agent-scope counter -- per wave, no workgroup barrier: wave w of every slice's workgroup owns the
+// same columns --; the wave that draws the last ticket re-reads ALL slices with sc1 loads, adds them in slice order (the order of
+// the reduce kernel: the same bits), casts, stores C and puts the counter back to zero.  CH m tiles at a time, 128 registers of
+// loads in flight.
+template <int OUT_DT, int W, int MT>
+__device__ __forceinline__ void strip_epilogue_fused(const f32x4 (&acc)[MT][W], const MixedGemmArgs& p, int tile, int bm0, int bn0, int col0, int lane,
+                                                     int wave) {
+  const int g = lane >> 4, r = lane & 15;
+  const int slices = (int)gridDim.y;
+  const uint32_t slab_bytes = (uint32_t)(p.m * p.n * 4);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.slabs, 0, slab_bytes * (uint32_t)slices, 0x00020000);
+  // byte offset of this lane's four columns of (m tile i, n tile nt) inside a slab; outside M x N: past the end of the buffer (a store
+  // is dropped, a load returns zeros -- the range check is on this offset alone, the slice goes into the scalar offset)
+  // (a macro, not a lambda: see gemm_mixed_skinny.hip on lambdas and hipcc's host pass)
+#define CONCH_SLAB_OFF(i, nt) \
+  ((bm0 + 16 * (i) + r < (int)p.m && bn0 + col0 + 16 * (nt) + 4 * g < (int)p.n) ? ((bm0 + 16 * (i) + r) * (int)p.n + bn0 + col0 + 16 * (nt) + 4 * g) * 4 : (int)0x80000000)
+  const int mine = (int)blockIdx.y * (int)slab_bytes;
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int nt = 0; nt < W; ++nt) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][nt]), rs, CONCH_SLAB_OFF(i, nt), mine, 16);  // sc1
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its own write-through stores
+  unsigned* cnt = p.counters + 8 * tile + wave;
+  unsigned ticket = 0;
+  if (lane == 0) ticket = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket);
+  if (ticket != (unsigned)(slices - 1)) return;  // wave-uniform
+  constexpr int CH = 4;                          // m tiles per pass
+  constexpr int SF = 32 / (CH * W);              // slices in flight: 128 registers of loads
+  static_assert(SF >= 1, "loads in flight");
+#pragma unroll
+  for (int c = 0; c < MT / CH; ++c) {
+    f32x4 sum[CH][W];
+    for (int sb = 0; sb < slices; sb += SF) {
+      u32x4 part[SF][CH][W];
+#pragma unroll
+      for (int j = 0; j < SF; ++j) {
+        const int soff = min(sb + j, slices - 1) * (int)slab_bytes;
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+#pragma unroll
+          for (int nt = 0; nt < W; ++nt) part[j][i][nt] = __builtin_amdgcn_raw_buffer_load_b128(rs, CONCH_SLAB_OFF(c * CH + i, nt), soff, 16);  // sc1
+      }
+#pragma unroll
+      for (int j = 0; j < SF; ++j) {
+        const bool first = sb + j == 0, live = sb + j < slices;
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+#pragma unroll
+          for (int nt = 0; nt < W; ++nt) {
+            const f32x4 v = __builtin_bit_cast(f32x4, part[j][i][nt]);
+            sum[i][nt] = first ? v : live ? sum[i][nt] + v : sum[i][nt];
+          }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int m = bm0 + 16 * (c * CH + i) + r;
+      if (m >= (int)p.m) continue;
+#pragma unroll
+      for (int nt = 0; nt < W; ++nt) {
+        const f32x4& v = sum[i][nt];
+        const i32x2 pk = {(int)pack2_bits16<OUT_DT>(f32x2{v[0], v[1]}), (int)pack2_bits16<OUT_DT>(f32x2{v[2], v[3]})};
+        const int n0 = bn0 + col0 + 16 * nt + 4 * g;
+        if (n0 >= (int)p.n) continue;  // (N % 4 == 0 in the split forms: the four columns are inside together)
+        uint16_t* dst = (uint16_t*)p.c + (int64_t)m * p.c_stride_m + n0;
+        if ((((uintptr_t)dst) & 7) == 0) {
+          *(i32x2*)dst = pk;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dst[e] = (uint16_t)((uint32_t)pk[e >> 1] >> (16 * (e & 1)));
+        }
+      }
+    }
+  }
+  if (lane == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+#undef CONCH_SLAB_OFF
+}
+
 template <int X_DT, int BITS, bool ZPT, int W, int TILE_N, int MT>
 __device__ __forceinline__ void strip_wave(const MixedGemmArgs& p, char* lds, const StripSrc& u, StripLane& ln, const StripConst& k, int wave, int lane,
                                            int bm0, int bn0, int col0, int step0, int steps) {
@@ -481,6 +563,15 @@ __device__ __forceinline__ void strip_wave(const MixedGemmArgs& p, char* lds, co
   strip_loop<X_DT, BITS, ZPT, W, MT>(acc, lds, u, ln, k, wave, step0, steps, q0, s0, z0);
   CONCH_PROBE_AT(g_probe_mixed_strip, 1, (int)(blockIdx.x + gridDim.x * blockIdx.y));
   if (p.slabs) {
+    // (the 256-row tile keeps the reduce kernel: its loop runs at the 256-register limit and the fused epilogue's loads in flight
+    // would be paid for with spills)
+    if constexpr (MT < 16) {
+      if (p.counters) {
+        strip_epilogue_fused<X_DT, W, MT>(acc, p, (int)blockIdx.x, bm0, bn0, col0, lane, wave);
+        CONCH_PROBE_AT(g_probe_mixed_strip, 3, (int)(blockIdx.x + gridDim.x * blockIdx.y));
+        return;
+      }
+    }
     strip_epilogue_slab<W, MT>(acc, p, p.slabs + (int64_t)blockIdx.y * p.m * p.n, bm0, bn0, col0, lane);
     CONCH_PROBE_AT(g_probe_mixed_strip, 3, (int)(blockIdx.x + gridDim.x * blockIdx.y));
     return;
@@ -707,14 +798,25 @@ int launch_mixed_gemm_strip(const MixedGemmArgs& p_in, hipStream_t stream) {
     const int steps = (int)(p.k / kSsStepK), spg = p.group_size / kSsStepK;
     p.split_steps = ((steps + plan.split - 1) / plan.split + spg - 1) / spg * spg;
     void* ws = nullptr;
-    if (int rc = get_scratch(stream, kScratchMixedSplitK, (size_t)strip_slices(p) * p.m * p.n * 4, &ws)) return rc;
+    const size_t bytes = (size_t)strip_slices(p) * p.m * p.n * 4;
+    if (int rc = get_scratch(stream, kScratchMixedSplitK, bytes, &ws)) return rc;
     p.slabs = (float*)ws;
+    // CONCH_TUNE_SKINNY_MODE (shared with the decode kernels) = 2: ONE launch (the wave that arrives last at a tile strip adds the
+    // slices).  Opt-in: built, bit-identical, and SLOWER at these tile sizes -- 64 x 4096 x 11008 22.6 us against 17.5, 128 x 4096 x
+    // 11008 34.8 against 23.3 (profiles/r05/mixed_mid_one_launch.txt): draining 48-96 KiB of write-through stores per workgroup
+    // and re-reading them past the L2 costs more than the second launch; the decode kernels' one-launch forms win at <= 8 KiB
+    const int64_t tiles = ((p.m + 16 * plan.mt - 1) / (16 * plan.mt)) * ((p.n + 64 * nt - 1) / (64 * nt));
+    if (tuning(CONCH_TUNE_SKINNY_MODE) == 2 && plan.mt < 16 && strip_slices(p) > 1 && bytes < ((size_t)1 << 31) && tiles * 8 <= kStripMaxCounters) {
+      void* cbuf = nullptr;
+      if (int rc = get_scratch(stream, kScratchCounters, (size_t)kStripMaxCounters * 4, &cbuf, /*zero_on_alloc=*/true)) return rc;
+      p.counters = (unsigned*)cbuf;
+    }
   }
   set_raster_divisor((uint32_t)(kGroupM * ((p.n + 64 * nt - 1) / (64 * nt))), &p.raster_magic, &p.raster_shift);
   int rc;
   if (p.x_dtype == CONCH_DT_FP16) rc = p.bits == 4 ? launch_zp<CONCH_DT_FP16, 4>(p, nt, plan.mt, stream) : launch_zp<CONCH_DT_FP16, 8>(p, nt, plan.mt, stream);
   else rc = launch_zp<CONCH_DT_BF16, 4>(p, nt, plan.mt, stream);  // (bf16 x 8-bit: not built, see mixed_gemm_strip_supported)
-  if (rc || !p.slabs) return rc;
+  if (rc || !p.slabs || p.counters) return rc;
   return launch_f32_slab_reduce(p.c, p.slabs, strip_slices(p), p.m, p.n, p.c_stride_m, p.out_dtype, stream);
 }
 
