@@ -22,6 +22,7 @@ LIB = _C.load()
 COLD_BYTES = 640 << 20
 ms = ctypes.c_float()
 QUICK = "--quick" in sys.argv
+BITS = 8 if "--int8" in sys.argv else 4   # weight width of the timing sweep (uint4b8 / uint8b128)
 
 
 def force(rows=0, nt=0, split=0, kernel=0, variant=0):
@@ -91,11 +92,11 @@ def sweep():
     rows_list = (64, 128, 256) if QUICK else (32, 48, 64, 96, 128, 192, 256, 384, 512)
     for k, n in dims:
         for m in rows_list:
-            words = k // 8
+            words = k * BITS // 32
             count = max(2, -(-COLD_BYTES // (words * n * 4)))
-            x, wq, ws, _ = make(m, k, n, count=count)
+            x, wq, ws, _ = make(m, k, n, bits=BITS, count=count)
             out = torch.empty((m, n), dtype=torch.float16, device="cuda")
-            md = create_mixed_precision_metadata(x, wq[0], ws, None, 4, 8, 128)
+            md = create_mixed_precision_metadata(x, wq[0], ws, None, BITS, 8 if BITS == 4 else 128, 128)
 
             def run(iters):
                 _C.check(kg._mixed_gemm_call("conch_time_mixed_precision_gemm", out, x, wq[0], ws, None, md, (iters, ctypes.byref(ms))), "time")
