@@ -637,7 +637,7 @@ extern "C" int64_t conch_mixed_precision_gemm_workspace_bytes(int64_t m, int64_t
   if (m <= 0 || n <= 0 || k < 0) return 0;
   int64_t need = m * n * 2;
   if (m <= 256) need = std::max(need, (k / 1024 + 1) * m * n * 4);  // gemm_mixed_skinny.hip slabs
-  need = std::max(need, (int64_t)8 * m * n * 4);                     // gemm_mixed.hip split-K slabs (at most 8 slices, any M)
+  need = std::max(need, (int64_t)8 * m * n * 4);                     // gemm_mixed.hip / gemm_mixed_strip.hip split-K slabs (at most 8 slices, any M)
   return need + ((int64_t)1 << 20);
 }
 

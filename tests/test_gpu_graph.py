@@ -150,6 +150,29 @@ def test_split_k_forms_capture_after_the_reservation_alone(m, k, n):
         assert torch.equal(out, want)
 
 
+@pytest.mark.parametrize(("m", "k", "n"), [(64, 4096, 11008), (128, 4096, 11008), (200, 8192, 8192)])
+def test_mixed_k_split_strip_forms_capture_after_the_reservation_alone(m, k, n):
+    """Batched-decode sizes of mixed_precision_gemm (round 5: the column-strip kernel on 64- / 128- / 256-row tiles, K split into
+    fp32 slabs in library scratch + the slab reduce): conch_mixed_precision_gemm_workspace_bytes covers the slabs -- a fresh
+    stream, the reservation, a capture without an eager warm-up, replays equal to the eager call."""
+    seed_everything(16)
+    dev = torch.device("cuda")
+    x = (torch.rand((m, k), device=dev) - 0.3).to(torch.float16)
+    w, s = _int4_weights(k, n)
+    want = mixed_precision_gemm(x, w, s, None, 4, 8, 128)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        _C.reserve_scratch(_C.load().conch_mixed_precision_gemm_workspace_bytes(m, n, k))
+    stream.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=stream):
+        out = mixed_precision_gemm(x, w, s, None, 4, 8, 128)
+    for _ in range(2):
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want)
+
+
 def test_reset_scratch_is_harmless_between_one_launch_calls():
     """conch_reset_scratch zeroes the arrival counters of the current stream with a memset ordered ON that stream: between two
     one-launch split-K calls it changes nothing (the counters are zero there by construction); on a stream that never used a
