@@ -2,7 +2,8 @@
 
 scaled_gemm: int8 bit-for-bit, fp8 within 2 eps of max|C|; mixed_precision_gemm: 2 eps of max|C|.  Shapes are drawn so
 that every dispatcher branch (split-K 32/64/128 rows, 128x128 tiles, 256x256 tiles, repack, generic; decode-batch and tiled
-mixed kernels) is hit.  usage: python tools/fuzz_dispatch.py [cases] [seed]
+mixed kernels) is hit.  usage: python tools/fuzz_dispatch.py [cases] [seed] [--mixed-mid]
+--mixed-mid: mixed_precision_gemm only, at batched-decode sizes on wide problems (the K-split strip forms of round 5).
 """
 import random
 import sys
@@ -14,6 +15,8 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from conch_amd import _C  # noqa: E402
 from conch_amd.ops.quantization.gemm import mixed_precision_gemm, scaled_gemm  # noqa: E402
 
+MIXED_MID = "--mixed-mid" in sys.argv
+sys.argv = [a for a in sys.argv if not a.startswith("--")]
 CASES = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 random.seed(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 EPS = {torch.float16: 2.0**-10, torch.bfloat16: 2.0**-7}
@@ -24,7 +27,10 @@ for case in range(CASES):
     n = random.choice([8, 24, 64, 100, 128, 260, 520, 1376, 2048, 4096, 4100, 11008])
     out_dt = random.choice([torch.float16, torch.bfloat16])
     torch.manual_seed(case)
-    if random.random() < 0.6:
+    if MIXED_MID:
+        m = random.choice([33, 40, 48, 64, 65, 96, 100, 128, 129, 192, 200, 256])
+        n = random.choice([1376, 2048, 4096, 4100, 5120, 8192, 11008, 13824])
+    if not MIXED_MID and random.random() < 0.6:
         in_dt = random.choice([torch.int8, torch.float8_e4m3fn])
         if in_dt == torch.int8:
             a = torch.randint(-32, 32, (m, k), dtype=torch.int8, device="cuda")
