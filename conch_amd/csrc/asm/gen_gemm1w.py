@@ -30,6 +30,7 @@ usage: gen_gemm1w.py OUT.s
 """
 from __future__ import annotations
 
+import os
 import sys
 
 MT = 8                       # 16-row m tiles per wave
@@ -117,7 +118,8 @@ def acc_reg(i: int, j: int) -> str:
 
 
 class Gen:
-    def __init__(self, name: str, out_fp16: bool = False, probe: bool = False, rows: bool = True, pk: bool = True, int8: bool = False, chains: int = 4, store_policy: str = ""):
+    def __init__(self, name: str, out_fp16: bool = False, probe: bool = False, rows: bool = True, pk: bool = True, int8: bool = False, chains: int = 4, store_policy: str = "",
+                 fused_tail: bool = False):
         self.name = name
         self.probe = probe
         self.lines: list[str] = []
@@ -128,6 +130,10 @@ class Gen:
         self.chains = chains
         self.store_policy = store_policy   # cache-policy suffix of the C stores ("" | " sc1" | " nt")
         self.int8 = int8          # int8 operands: 2 x v_mfma_i32_16x16x64_i8 per tile and step, int32 accumulators
+        # TIMING EXPERIMENT (the A/B twin only; WRONG results): the tile's conversion and stores ride in its LAST K step (8-byte
+        # stores, lanes regrouped by ds_bpermute so that a quad covers one 32-byte row piece), the last two steps fetch the NEXT
+        # tile's first two stages, and the separate epilogue disappears -- what would that buy?  (profiles/r05/asm1w_fused_tail_timing.txt)
+        self.fused_tail = fused_tail
 
     def L(self, s: str) -> str:
         return f".L{self.name}_{s}"
@@ -232,7 +238,7 @@ class Gen:
             self.dma_piece(idx, stage)
 
     # -- one K step -----------------------------------------------------------------------------------------------------------------
-    def step(self, st: int, tag: str, nxt: str, first: bool = False) -> None:
+    def step(self, st: int, tag: str, nxt: str, first: bool = False, tail: int = 0) -> None:
         """88 MFMA slots of the step staged in `st`; `tag` / `nxt` name this step's and the next step's fragment reads.
         `first`: the tile's first K step -- the MFMAs take the constant 0 as their addend (no accumulator is zeroed anywhere)."""
         # DMA issue slots: after Z every third slot that carries no fragment read, after X every other one
@@ -254,7 +260,10 @@ class Gen:
                 self.e("s_barrier")
             if q == X_SLOT:
                 self.c("---- barrier X: the next stage has landed; this stage's B tiles 6-10 are dead ----")
-                self.e(f"s_waitcnt vmcnt({PIECES_Z})")
+                # (tail step of the timing experiment: the 8-byte stores issued so far are younger than the awaited pieces too)
+                # ... and in the step before it the next tile's three scale loads (the experiment does not care that a walk's last
+                # tile issues none; the real thing would issue them unconditionally)
+                self.e(f"s_waitcnt vmcnt({min(63, PIECES_Z + (max(0, q - 4) if tail == 2 else 3 if tail == 1 else 0))})")
                 self.wait_all_lds()
                 self.e("s_barrier")
             self.wait_tags([f"{tag}.A{i}.lo", f"{tag}.A{i}.hi", f"{tag}.B{j}.lo", f"{tag}.B{j}.hi"])
@@ -282,13 +291,95 @@ class Gen:
                 self.read_fa(ii - 1, 1 - st, nxt)   # FA[ii - 1] was last used one slot ago
             if q in dma_at:
                 self.dma_load(dma_at[q], st)       # order: A 0-7, B tiles 0-5 | B tiles 6-10
-            if q == 2:
+            if q == 2 and tail:
+                # the last two steps of a tile (timing experiment): their pieces are the NEXT tile's steps 0 and 1 (v1..v19 already
+                # hold its source offsets), or nothing when the walk ends here
+                self.e(f"s_mov_b32 s{S_KOFF}, {128 * (tail - 1)}")
+                self.e(f"s_cmp_lg_u32 s{S_HASNEXT}, 0")
+                self.e(f"s_cselect_b32 s{S_DA + 2}, s{S_NRA}, 0")
+                self.e(f"s_cselect_b32 s{S_DB + 2}, s{S_NRB}, 0")
+            elif q == 2:
                 # the step whose pieces this step issues is t + 2: past the end of K the descriptors are switched to zero
                 # records (every lane out of range: no memory traffic, zeros land in a stage nobody reads)
                 self.e(f"s_add_u32 s{S_KOFF}, s{S_KOFF}, 128")
                 self.e(f"s_cmp_lt_u32 s{S_KOFF}, s{S_K}")
                 self.e(f"s_cselect_b32 s{S_DA + 2}, s{S_NRA}, 0")
                 self.e(f"s_cselect_b32 s{S_DB + 2}, s{S_NRB}, 0")
+            if tail == 2:
+                self.tail_convert(q)
+
+    # -- timing experiment: conversion and stores inside the last K step ------------------------------------------------------------
+    FT_X, FT_PK, FT_PM, FT_SA, FT_SB, FT_PERM, FT_VOFF = V_E, V_E + 8, V_E + 12, V_E + 18, V_E + 26, V_E + 30, V_E + 31
+
+    def tail_prepare(self) -> None:
+        """Before the last pair of steps: row-block store offsets s[S_T : S_T + 8), the lane regrouping and the per-lane store offset."""
+        e = self.e
+        T = S_T
+        e(f"s_lshl_b32 s{T + 8}, s{S_WR}, 7")
+        e(f"s_add_u32 s{T + 8}, s{T + 8}, s{S_BM0}", "first row of this wave")
+        e(f"s_lshl_b32 s{T + 9}, s{S_LDC}, 1", "row pitch in bytes")
+        e(f"s_mul_i32 s{T + 8}, s{T + 8}, s{T + 9}")
+        e(f"s_mul_i32 s{T + 10}, s{S_WC}, {16 * NT}")
+        e(f"s_add_u32 s{T + 10}, s{T + 10}, s{S_BN0}")
+        e(f"s_lshl_b32 s{T + 10}, s{T + 10}, 1")
+        e(f"s_add_u32 s{T + 8}, s{T + 8}, s{T + 10}", "byte offset of this wave's sub-tile in C")
+        e(f"s_lshl_b32 s{T + 9}, s{T + 9}, 4", "16 rows")
+        for i in range(MT):
+            e(f"s_mov_b32 s{T + i}, s{T + 8}")
+            e(f"s_add_u32 s{T + 8}, s{T + 8}, s{T + 9}")
+        vl = V_T
+        e(f"v_and_b32 v{vl}, 63, v{V_TID}")
+        e(f"v_and_b32 v{self.FT_PERM}, 3, v{vl}", "g' = lane & 3")
+        e(f"v_lshlrev_b32 v{self.FT_VOFF}, 3, v{self.FT_PERM}", "8 g' bytes")
+        e(f"v_lshlrev_b32 v{self.FT_PERM}, 4, v{self.FT_PERM}")
+        e(f"v_lshrrev_b32 v{vl}, 2, v{vl}", "c' = lane >> 2")
+        e(f"v_add_u32 v{self.FT_PERM}, v{self.FT_PERM}, v{vl}", "source lane 16 g' + c'")
+        e(f"v_lshlrev_b32 v{self.FT_PERM}, 2, v{self.FT_PERM}", "ds_bpermute address")
+        e(f"s_lshl_b32 s{T + 9}, s{S_LDC}, 1")
+        e(f"v_mul_lo_u32 v{vl}, v{vl}, s{T + 9}")
+        e(f"v_add_u32 v{self.FT_VOFF}, v{self.FT_VOFF}, v{vl}", "c' rows + 8 g' bytes")
+        for k in range(12):  # (stand-ins for the row / column scales)
+            e(f"v_mov_b32 v{self.FT_SA + k}, 1.0")
+
+    def tail_convert_rest(self, q: int) -> None:
+        """slots past the end of the step: what tail_convert still owes"""
+        self.tail_convert_parts(q, convert=True, store=True)
+
+    def tail_convert(self, q: int) -> None:
+        self.tail_convert_parts(q, convert=True, store=True)
+
+    def tail_convert_parts(self, q: int, convert: bool, store: bool) -> None:
+        """Fillers of slot q of a tile's last K step: convert the tile of slot q - 2, store the one of slot q - 4."""
+        e = self.e
+        if convert and 2 <= q < SLOTS + 2:
+            c = q - 2
+            j, ii = divmod(c, MT)
+            i = ii if j % 2 == 0 else MT - 1 - ii
+            t = 8 * j + i
+            x, pk = self.FT_X + 4 * (c % 2), self.FT_PK + 2 * (c % 2)
+            pm = self.FT_PM + 2 * (c % 3)
+            if t < 64:
+                for k in range(4):
+                    e(f"v_accvgpr_read_b32 v{x + k}, a{4 * t + k}")
+                src = x
+            else:
+                src = V_ACC + 4 * (t - 64)
+            e(f"v_pk_mul_f32 v[{x}:{x + 1}], v[{src}:{src + 1}], v[{self.FT_SA}:{self.FT_SA + 1}]")
+            e(f"v_pk_mul_f32 v[{x + 2}:{x + 3}], v[{src + 2}:{src + 3}], v[{self.FT_SA}:{self.FT_SA + 1}]")
+            e(f"v_pk_mul_f32 v[{x}:{x + 1}], v[{x}:{x + 1}], v[{self.FT_SB}:{self.FT_SB + 1}]")
+            e(f"v_pk_mul_f32 v[{x + 2}:{x + 3}], v[{x + 2}:{x + 3}], v[{self.FT_SB + 2}:{self.FT_SB + 3}]")
+            e(f"v_cvt_pk_bf16_f32 v{pk}, v{x}, v{x + 1}")
+            e(f"v_cvt_pk_bf16_f32 v{pk + 1}, v{x + 2}, v{x + 3}")
+            for k in range(2):
+                e(f"ds_bpermute_b32 v{pm + k}, v{self.FT_PERM}, v{pk + k}", f"ft.{c}.{k}")
+                self.lgkm.append(f"ft.{c}.{k}")
+        if store and 4 <= q < SLOTS + 4:
+            c = q - 4
+            j, ii = divmod(c, MT)
+            i = ii if j % 2 == 0 else MT - 1 - ii
+            pm = self.FT_PM + 2 * (c % 3)
+            self.wait_tags([f"ft.{c}.0", f"ft.{c}.1"])
+            e(f"buffer_store_dwordx2 v[{pm}:{pm + 1}], v{self.FT_VOFF}, s[{S_DC}:{S_DC + 3}], s{S_T + i} offen offset:{32 * j}" + self.store_policy)
 
     # -- whole kernel ---------------------------------------------------------------------------------------------------------------
     def setup_once(self) -> None:
@@ -502,11 +593,18 @@ class Gen:
             else:
                 self.ds_read128(V_FB + 8 * fb_slot(idx) + (4 if half == "hi" else 0), (V_BHI if half == "hi" else V_BLO)[0], 2048 * idx, t)
         assert self.lgkm == steady
+        if self.fused_tail:
+            self.label(self.L("go2"))  # (a tile whose predecessor's last step already read these fragments enters here)
+            self.stamp(1)
         e(f"s_lshr_b32 s{S_CNT}, s{S_K}, 8")
         e(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1", "pairs of K steps behind the peeled first pair (K >= 512: at least one)")
         self.step(0, "t0", "t1", first=True)
         self.step(1, "t1", "t0")
         assert self.lgkm == steady
+        if self.fused_tail:
+            e(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1", "(the last pair is peeled too)")
+            e(f"s_cmp_eq_u32 s{S_CNT}, 0")
+            e(f"s_cbranch_scc1 {self.L('lastpair')}")
         self.label(self.L("loop"))
         self.step(0, "t0", "t1")
         self.step(1, "t1", "t0")
@@ -514,6 +612,22 @@ class Gen:
         e(f"s_cmp_lg_u32 s{S_CNT}, 0")
         e(f"s_cbranch_scc1 {self.L('loop')}")
         assert self.lgkm == steady, "the loop body must leave the queue as it found it"
+        if self.fused_tail:
+            self.label(self.L("lastpair"))
+            # the next tile of this workgroup: its LDS-DMA source offsets replace this tile's (which the remaining steps no longer
+            # request), its scale loads go out
+            e(f"s_add_u32 s{S_TNEXT}, s{S_TILE}, s{S_GRID}")
+            e(f"s_cmp_lt_u32 s{S_TNEXT}, s{S_NWG}")
+            e(f"s_cselect_b32 s{S_HASNEXT}, 1, 0")
+            e(f"s_cbranch_scc0 {self.L('ft_no_next')}")
+            self.tile_coords(S_TNEXT, S_BM0N, S_BN0N, "next")
+            self.tile_sources(S_BM0N, S_BN0N)
+            self.label(self.L("ft_no_next"))
+            self.tail_prepare()
+            self.step(0, "t0", "t1", tail=1)
+            self.step(1, "t1", "t0", tail=2)
+            for q in range(SLOTS, SLOTS + 4):  # the last tiles' conversions and stores
+                self.tail_convert_rest(q)
 
     def convert_ops(self, i: int, j: int, sa: int, sb: int, x: int) -> list[str]:
         """Instructions that turn accumulator tile (i, j) into two registers v[x + 4 : x + 5] of packed 16-bit outputs:
@@ -838,6 +952,31 @@ class Gen:
         self.label(self.L("exit"))
         e("s_endpgm")
 
+    def fused_exit(self) -> None:
+        """Timing experiment: behind a tile whose stores rode in its last K step.  The next tile's two stages and its scale loads
+        are in flight (or nothing is): drain, park the scales, swap, meet, enter the next tile's loop behind its fragment reads."""
+        e = self.e
+        self.stamp(3)
+        if self.probe:
+            self.stamp(4)
+            self.write_stamps()
+        e(f"s_cmp_lg_u32 s{S_HASNEXT}, 0")
+        e(f"s_cbranch_scc0 {self.L('exit')}")
+        if self.probe:
+            self.stamp(0)
+        e("s_waitcnt vmcnt(0)", "(the experiment drains here; the real thing would wait for the scale loads and the two stages only)")
+        e(f"s_xor_b32 s{S_SCOFF}, s{S_SCOFF}, {SCALE_BUF}")
+        self.park_scales()
+        e(f"s_mov_b32 s{S_TILE}, s{S_TNEXT}")
+        e(f"s_mov_b32 s{S_BM0}, s{S_BM0N}")
+        e(f"s_mov_b32 s{S_BN0}, s{S_BN0N}")
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_barrier")
+        e(f"s_branch {self.L('go2')}")
+        self.label(self.L("exit"))
+        e("s_waitcnt vmcnt(0)")
+        e("s_endpgm")
+
     def build(self) -> str:
         self.setup_once()
         self.first_tile()
@@ -847,10 +986,14 @@ class Gen:
         scratch.step(1, "t1", "t0")
         steady = list(scratch.lgkm)
         self.label(self.L("go"))
-        self.stamp(1)
+        if not self.fused_tail:
+            self.stamp(1)
         self.k_loop(steady)
         self.stamp(2)
-        self.epilogue()
+        if self.fused_tail:
+            self.fused_exit()
+        else:
+            self.epilogue()
         return self.render()
 
     def render(self) -> str:
@@ -967,7 +1110,11 @@ def main() -> None:
                  ("conch_gemm1w_fp8_bf16_alt_probe", 11, False, True, False, False), ("conch_gemm1w_i8_bf16_probe", 11, False, True, True, True)]
     for name, nt, fp16, probe, pk, int8 in variants:
         configure(nt)
-        g = Gen(name, out_fp16=fp16, probe=probe, pk=True, int8=int8, store_policy="" if pk else " nt")  # the A/B twin: non-temporal C stores (sc1: equal, profiles/r05/asm1w_sc1_store_ab.txt)
+        # the A/B twin (pk False): non-temporal C stores (correct results; profiles/r05/asm1w_nt_store_ab.txt; sc1: asm1w_sc1_store_ab.txt).
+        # CONCH_GEN_EXPERIMENT=fused_tail at build time makes it the fused-tail TIMING experiment instead (WRONG results: never
+        # in a library that ships; profiles/r05/asm1w_fused_tail_timing.txt)
+        fused = (not pk) and os.environ.get("CONCH_GEN_EXPERIMENT") == "fused_tail"
+        g = Gen(name, out_fp16=fp16, probe=probe, pk=True, int8=int8, store_policy="" if pk or fused else " nt", fused_tail=fused)
         body = g.build()
         if text:
             body = body.split("\n", 2)[2]  # one target / code-object-version header per file
