@@ -474,6 +474,12 @@ int run_mixed(const MixedGemmArgs& p, hipStream_t stream) {
     return launch_mixed_gemm_asm1w(p, stream);
   }
   if (kernel != 1 && mixed_gemm_strip_supported(p) && (kernel == 2 || mixed_strip_beats_tiles(p))) return launch_mixed_gemm_strip(p, stream);
+  // a few rows of tiles that leave CUs idle (round 5): the strip kernel on 128- / 64-row tiles or in K slices, where its model beats
+  // the LDS-tiled kernel's by the margin (mixed_strip_estimate_us is finite only when strip_plan left the unsplit 256-row tile)
+  if (variant == 0 && kernel == 0 && tuning(CONCH_TUNE_MIXED_SPLITK) == 0 && tuning(CONCH_TUNE_MIXED_TILE_NT) == 0 && p.m > fit::kMixedStripSplit.max_m &&
+      p.m <= fit::kMixedStripSplit.max_m_search && mixed_gemm_strip_supported(p) &&
+      mixed_strip_short_or_split_us(p) * fit::kMixedStripSplit.tall_vs_tiles < mixed_tiles_estimate_us(p))
+    return launch_mixed_gemm_strip(p, stream);
   return launch_mixed_gemm_mfma(p, stream);
 }
 

@@ -51,17 +51,23 @@ struct MixedStrip {
   double width_offset = 0.6;                                // cost of a tile of 64 nt columns ~ nt + this
 };
 
-// K-split forms of the column-strip kernel (gemm_mixed_strip.hip, strip_plan): 64- / 128- / 256-row tiles (mt = 4 / 8 / 16 m tiles per
-// wave) x 128 / 192 / 256 columns (nt = 2..4) x 1..8 slices.  Least squares over tools/sweep_mixed_mid.py's 972 timings on weights
-// streamed from HBM (profiles/r05/mixed_mid_sweep.txt): RMS error 5.7 %, the model's pick within 9 % of the fastest form on all 54
-// shapes, the pick's own time predicted within -15 .. +6 %.
+// Tile height, width and K slices of the column-strip kernel (gemm_mixed_strip.hip, strip_plan): 64- / 128- / 256-row tiles (mt = 4 /
+// 8 / 16 m tiles per wave) x 128 / 192 / 256 columns (nt = 2..4) x 1..8 slices.  Least squares over 2 457 timings on weights
+// streamed from HBM -- tools/sweep_mixed_mid.py (M = 32..512, profiles/r05/mixed_mid_sweep.txt) and tools/archive/
+// sweep_mixed_rows_tall.py --full (M = 288..1536, every tile height, profiles/r05/mixed_rows_tall_sweep.txt): RMS error 5.0 %, the
+// model's pick within 9 % of the fastest form on all 109 shapes (0.7 % on average), the pick's own time predicted within -15 .. +11 %.
 struct MixedStripSplit {
-  double wg_fixed = 5.3;                                    // launch, prologue, epilogue (us)
-  double step = 0.0529, step_mt = 0.0158, step_nt = 0.0629, step_mt_nt = 0.0082;  // a K step of 64: us = step + ... (mt, nt as above)
-  double fill_slowdown = 0.2;                               // ... x (1 + this x the fraction of the chip the launch fills)
-  double launch2 = 1.7, slab_per_elem = 1.51e-6;            // the reduce launch; fp32 partial sums written and read again (us / element)
-  double margin = 1.08;                                     // the dispatcher takes the strip forms when this x their time beats the others'
-  long long min_m = 33, max_m = 256;                        // ... for this many rows (below: the one-launch decode forms win everywhere)
+  double wg_fixed = 5.98;                                   // launch, prologue, epilogue (us)
+  double step = 0.0623, step_mt = 0.0132, step_nt = 0.0494, step_mt_nt = 0.0089;  // a K step of 64: us = step + ... (mt, nt as above)
+  double fill_slowdown = 0.3;                               // ... x (1 + this x the fraction of the chip the launch fills)
+  double launch2 = 1.385, slab_per_elem = 1.4115e-6;        // the reduce launch; fp32 partial sums written and read again (us / element)
+  double margin = 1.08;                                     // the dispatcher takes these forms when this x their time beats the others'
+  long long min_m = 33, max_m = 256;                        // ... one row of tiles: for this many rows (below: the one-launch decode forms)
+  long long max_m_search = 1536;                            // several rows of tiles: short tiles / K slices are candidates up to here
+  double tall_margin = 1.05;                                // ... and replace the unsplit 256-row tile for a modelled gain beyond this
+  double tall_vs_tiles = 1.0;                               // ... and the LDS-tiled kernel when this x their time beats its estimate (the two
+                                                            // models err in opposite directions there: 320 x 4096 x 4096 26.0 for 24.4 measured
+                                                            // against 27.6 for 29.8)
 };
 
 inline constexpr ScaledTiles kScaledTiles{};

@@ -745,49 +745,73 @@ int pick_strip_nt(const MixedGemmArgs& p, int num_cus) {
 // one row of tiles (M <= 256: the batched-decode sizes) takes the smallest tile that holds M -- 64 / 128 / 256 rows: every weight is
 // still dequantised once, the MFMAs of absent rows are not issued -- and as many K slices as fill the chip once, by the cost model
 // of dispatch_fit.hpp (MixedStripSplit).  CONCH_TUNE_MIXED_STRIP_ROWS / _TILE_NT / _SPLITK force the three choices.
+// the cost model's time (us) for tiles of 16 mt rows x 64 nt columns in s K slices; < 0 = not a candidate
+double strip_model_us(const MixedGemmArgs& p, int cus, int mt, int nt, int s) {
+  const fit::MixedStripSplit& f = fit::kMixedStripSplit;
+  const int steps = (int)(p.k / kSsStepK), spg = p.group_size / kSsStepK;
+  const int per = ((steps + s - 1) / s + spg - 1) / spg * spg;  // steps per slice, whole groups
+  if ((steps + per - 1) / per != s) return -1.0;                 // (the rounding made it another candidate)
+  if (s > 1 && per < 4) return -1.0;
+  const int64_t tiles = ((p.m + 16 * mt - 1) / (16 * mt)) * ((p.n + 64 * nt - 1) / (64 * nt));
+  const double rounds = (double)((tiles * s + cus - 1) / cus), fill = (double)(tiles * s) / (rounds * cus);
+  return f.wg_fixed + rounds * per * (1.0 + f.fill_slowdown * fill) * (f.step + f.step_mt * mt + f.step_nt * nt + f.step_mt_nt * mt * nt) * (p.bits == 8 ? 1.1 : 1.0) +
+         (s > 1 ? f.launch2 + (double)s * (double)p.m * (double)p.n * f.slab_per_elem : 0.0);
+}
+
 StripPlan strip_plan(const MixedGemmArgs& p) {
   const int cus = device_cu_count();
   const int f_rows = tuning(CONCH_TUNE_MIXED_STRIP_ROWS), f_nt = tuning(CONCH_TUNE_MIXED_TILE_NT), f_split = tuning(CONCH_TUNE_MIXED_SPLITK);
-  StripPlan best;
-  best.mt = (f_rows == 64 || f_rows == 128 || f_rows == 256) ? f_rows / 16 : p.m <= 64 ? 4 : p.m <= 128 ? 8 : 16;
-  const int steps = (int)(p.k / kSsStepK), spg = p.group_size / kSsStepK;
-  const bool may_split = p.n % 4 == 0 && f_split != 1;
-  if (p.m > kSsRows && f_split <= 1) {  // the tall form
-    best.nt = (f_nt >= 2 && f_nt <= 4) ? f_nt : pick_strip_nt(p, cus);
-    return best;
-  }
   const fit::MixedStripSplit& f = fit::kMixedStripSplit;
-  const int64_t tiles_m = (p.m + 16 * best.mt - 1) / (16 * best.mt);
-  for (int nt = 4; nt >= 2; --nt) {
-    if (f_nt >= 2 && f_nt <= 4 && nt != f_nt) continue;
-    const int64_t tiles = tiles_m * ((p.n + 64 * nt - 1) / (64 * nt));
-    for (int s = 1; s <= 8; ++s) {
-      if (s > 1 && !may_split) break;
-      if (f_split >= 2 && s != std::min(f_split, 8)) continue;
-      const int per = ((steps + s - 1) / s + spg - 1) / spg * spg;  // steps per slice, whole groups
-      const int slices = (steps + per - 1) / per;
-      if (slices != s) continue;                                     // (the rounding made it another candidate)
-      if (s > 1 && per < 4) break;
-      const double rounds = (double)((tiles * s + cus - 1) / cus), fill = (double)(tiles * s) / (rounds * cus);
-      const double us = f.wg_fixed + rounds * per * (1.0 + f.fill_slowdown * fill) *
-                            (f.step + f.step_mt * best.mt + f.step_nt * nt + f.step_mt_nt * best.mt * nt) * (p.bits == 8 ? 1.1 : 1.0) +
-                        (s > 1 ? f.launch2 + (double)s * (double)p.m * (double)p.n * f.slab_per_elem : 0.0);
-      if (us < best.us - 1e-9) {
-        best.us = us;
-        best.nt = nt;
-        best.split = s;
+  const bool forced_rows = f_rows == 64 || f_rows == 128 || f_rows == 256;
+  const bool forced = forced_rows || (f_nt >= 2 && f_nt <= 4) || f_split >= 2;
+  const bool may_split = p.n % 4 == 0 && f_split != 1;
+  // tile heights in the race: the forced one; one row of tiles -- the smallest that holds M; a few rows of tiles (M <= max_m_search):
+  // all three -- 128- / 64-row tiles pad M less and make more workgroups (384 x 4096 x 11008: 53.1 us on two rows of 256-row tiles
+  // = 116 workgroups, 42.9 on three rows of 128-row tiles; 1024 x 4096 x 4096: 48.1 -> 39.6; profiles/r05/mixed_rows_tall_sweep.txt);
+  // taller problems: the 256-row tile
+  int mts[3], n_mt = 0;
+  if (forced_rows) mts[n_mt++] = f_rows / 16;
+  else if (p.m <= kSsRows) mts[n_mt++] = p.m <= 64 ? 4 : p.m <= 128 ? 8 : 16;
+  else if (p.m <= f.max_m_search) mts[n_mt++] = 16, mts[n_mt++] = 8, mts[n_mt++] = 4;
+  else mts[n_mt++] = 16;
+  StripPlan tall;  // the unsplit 256-row tile at pick_strip_nt's width: what M > 256 ran before round 5
+  tall.nt = (f_nt >= 2 && f_nt <= 4) ? f_nt : pick_strip_nt(p, cus);
+  tall.us = strip_model_us(p, cus, 16, tall.nt, 1);
+  if (p.m > f.max_m_search && !forced) return tall;
+  StripPlan best;
+  for (int im = 0; im < n_mt; ++im)
+    for (int nt = 4; nt >= 2; --nt) {
+      if (f_nt >= 2 && f_nt <= 4 && nt != f_nt) continue;
+      for (int s = 1; s <= 8; ++s) {
+        if (s > 1 && !may_split) break;
+        if (f_split >= 2 && s != std::min(f_split, 8)) continue;
+        const double us = strip_model_us(p, cus, mts[im], nt, s);
+        if (us >= 0.0 && us < best.us - 1e-9) {
+          best.us = us;
+          best.mt = mts[im];
+          best.nt = nt;
+          best.split = s;
+        }
       }
     }
+  if (best.us > 1e29) {  // nothing admissible under the forced keys: the plain form at the (forced) tile height
+    best = tall;
+    best.mt = mts[0];
+    return best;
   }
-  if (best.us > 1e29) {  // nothing admissible under the forced keys: the plain form
-    best.nt = (f_nt >= 2 && f_nt <= 4) ? f_nt : pick_strip_nt(p, cus);
-    best.split = 1;
-  }
+  // several rows of tiles, nothing forced: leave the 256-row tile only for a modelled gain beyond the model's own error
+  if (p.m > kSsRows && !forced && (best.mt < 16 || best.split > 1) && !(best.us * f.tall_margin < tall.us)) return tall;
+  if (p.m > kSsRows && !forced && best.mt == 16 && best.split == 1) return tall;  // (the width rule of round 4 stays)
   return best;
 }
 
 // the cost model's time (us) for the strip kernel's pick on one row of tiles (the dispatcher compares it with the other kernels')
 double mixed_strip_estimate_us(const MixedGemmArgs& p) { return strip_plan(p).us; }
+
+double mixed_strip_short_or_split_us(const MixedGemmArgs& p) {
+  const StripPlan plan = strip_plan(p);
+  return (plan.mt < 16 || plan.split > 1) && plan.us > 0.0 ? plan.us : 1e30;
+}
 
 int launch_mixed_gemm_strip(const MixedGemmArgs& p_in, hipStream_t stream) {
   MixedGemmArgs p = p_in;
