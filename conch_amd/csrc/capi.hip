@@ -452,7 +452,8 @@ int run_mixed(const MixedGemmArgs& p, hipStream_t stream) {
       p.m >= fit::kMixedStripSplit.min_m && p.m <= fit::kMixedStripSplit.max_m && fast_ok && mixed_gemm_strip_supported(p)) {
     const bool decode_ok = decode && mixed_gemm_skinny_supported(p);
     const double other_us = decode_ok ? mixed_decode_estimate_us(p) : mixed_tiles_estimate_us(p);
-    if (mixed_strip_estimate_us(p) * fit::kMixedStripSplit.margin < other_us) return launch_mixed_gemm_strip(p, stream);
+    const double margin = decode_ok ? fit::kMixedStripSplit.margin : fit::kMixedStripSplit.tall_vs_tiles;
+    if (mixed_strip_estimate_us(p) * margin < other_us) return launch_mixed_gemm_strip(p, stream);
   }
   if (decode && mixed_gemm_skinny_supported(p)) return launch_mixed_gemm_skinny(p, stream);
   if (variant == 1 || !fast_ok) {

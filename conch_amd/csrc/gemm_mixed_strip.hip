@@ -765,13 +765,14 @@ StripPlan strip_plan(const MixedGemmArgs& p) {
   const bool forced_rows = f_rows == 64 || f_rows == 128 || f_rows == 256;
   const bool forced = forced_rows || (f_nt >= 2 && f_nt <= 4) || f_split >= 2;
   const bool may_split = p.n % 4 == 0 && f_split != 1;
-  // tile heights in the race: the forced one; one row of tiles -- the smallest that holds M; a few rows of tiles (M <= max_m_search):
-  // all three -- 128- / 64-row tiles pad M less and make more workgroups (384 x 4096 x 11008: 53.1 us on two rows of 256-row tiles
+  // tile heights in the race: the forced one; else every height up to the smallest that holds M, all three from 129 rows to
+  // max_m_search -- 128- / 64-row tiles pad M less and make more workgroups (384 x 4096 x 11008: 53.1 us on two rows of 256-row tiles
   // = 116 workgroups, 42.9 on three rows of 128-row tiles; 1024 x 4096 x 4096: 48.1 -> 39.6; profiles/r05/mixed_rows_tall_sweep.txt);
   // taller problems: the 256-row tile
   int mts[3], n_mt = 0;
   if (forced_rows) mts[n_mt++] = f_rows / 16;
-  else if (p.m <= kSsRows) mts[n_mt++] = p.m <= 64 ? 4 : p.m <= 128 ? 8 : 16;
+  else if (p.m <= 64) mts[n_mt++] = 4;
+  else if (p.m <= 128) mts[n_mt++] = 8, mts[n_mt++] = 4;
   else if (p.m <= f.max_m_search) mts[n_mt++] = 16, mts[n_mt++] = 8, mts[n_mt++] = 4;
   else mts[n_mt++] = 16;
   StripPlan tall;  // the unsplit 256-row tile at pick_strip_nt's width: what M > 256 ran before round 5

@@ -17,6 +17,9 @@ from sweep_mixed_mid import COLD_BYTES, LIB, force, make, ms, timed  # noqa: E40
 FULL = "--full" in sys.argv  # every timing on one line (the fit's input: profiles/r05/mixed_rows_tall_sweep.txt)
 DIMS = ((4096, 11008), (4096, 4096), (8192, 8192), (11008, 4096), (5120, 13824)) if FULL else ((4096, 11008), (4096, 4096), (8192, 8192))
 MS = (288, 320, 384, 448, 512, 640, 768, 896, 1024, 1280, 1536) if FULL else (320, 384, 448, 512, 640, 768, 1024)
+for arg in sys.argv[1:]:
+    if arg.startswith("--ms="):  # e.g. --ms=144,160,192,224: other row counts (one row of 256-row tiles against two or three shorter ones)
+        MS = tuple(int(v) for v in arg[5:].split(","))
 for k, n in DIMS:
     for m in MS:
         words = k // 8
@@ -36,7 +39,7 @@ for k, n in DIMS:
         res = {}
         for rows in (64, 128, 256):
             for nt in (2, 3, 4):
-                for split in (1, 2, 4):
+                for split in (1, 2, 3, 4, 8):
                     force(rows, nt, split, kernel=2, variant=5)
                     try:
                         res[(rows, 64 * nt, split)] = timed(run)
