@@ -421,23 +421,26 @@ bool mixed_decode_beats_tiles(const MixedGemmArgs& p, bool tiles_may_split = tru
   return decode_us < tile_us;
 }
 
-int run_mixed(const MixedGemmArgs& p, hipStream_t stream) {
-  if (int rc = check_mixed(p)) return rc;
-  if (p.m == 0 || p.n == 0) return CONCH_OK;
+// Which kernel mixed_precision_gemm runs for `p` under the current tuning keys -- no launch, no device access beyond the CU count.
+// A forced kernel whose contract `p` does not meet: kMixedPickError (+ the error text).  run_mixed launches exactly this pick;
+// conch_debug_mixed_plan reports it (tests/test_host_helpers.py pins the picks of the benchmark shapes without a GPU).
+enum MixedPick { kMixedPickError = -1, kMixedPickGeneric = 0, kMixedPickDecode = 1, kMixedPickTiles = 2, kMixedPickStrip = 3, kMixedPickAsm = 4 };
+
+MixedPick pick_mixed(const MixedGemmArgs& p) {
   // variant 1 forces the generic kernel, 4 the decode-batch kernel (gemm_mixed_skinny.hip: M <= 256), any other non-zero
   // value the LDS-tiled MFMA kernel (gemm_mixed.hip); auto = decode-batch kernel when its contract is met, else tiled
   const int variant = tuning(CONCH_TUNE_GEMM_VARIANT);
   const bool fast_ok = mixed_gemm_mfma_supported(p);
   if (variant == 4 && !mixed_gemm_skinny_supported(p)) {
     set_error("mixed_precision_gemm: skinny variant forced but its contract is not met (M <= 256, N %% 4 == 0)");
-    return CONCH_ERR_UNSUPPORTED;
+    return kMixedPickError;
   }
   if (p.x_dtype == CONCH_DT_FP32) {
     if (variant >= 2) {
       set_error("mixed_precision_gemm: MFMA variant %d forced but fp32 activations run on the generic kernel only", variant);
-      return CONCH_ERR_UNSUPPORTED;
+      return kMixedPickError;
     }
-    return launch_mixed_gemm_generic(p, stream);
+    return kMixedPickGeneric;
   }
   // auto: the decode-batch kernel for every shape it takes (M <= 64; up to four row blocks = 256 rows where mixed_decode_beats_tiles says so).  Round 1 stopped at 32 rows for N x K >= 9e7, where the two
   // kernels tie on a cache-resident weight (64x4096x28672: 58 us each); on weights streamed from HBM the decode kernel is 6-13 %
@@ -453,15 +456,15 @@ int run_mixed(const MixedGemmArgs& p, hipStream_t stream) {
     const bool decode_ok = decode && mixed_gemm_skinny_supported(p);
     const double other_us = decode_ok ? mixed_decode_estimate_us(p) : mixed_tiles_estimate_us(p);
     const double margin = decode_ok ? fit::kMixedStripSplit.margin : fit::kMixedStripSplit.tall_vs_tiles;
-    if (mixed_strip_estimate_us(p) * margin < other_us) return launch_mixed_gemm_strip(p, stream);
+    if (mixed_strip_estimate_us(p) * margin < other_us) return kMixedPickStrip;
   }
-  if (decode && mixed_gemm_skinny_supported(p)) return launch_mixed_gemm_skinny(p, stream);
+  if (decode && mixed_gemm_skinny_supported(p)) return kMixedPickDecode;
   if (variant == 1 || !fast_ok) {
     if (variant >= 2 && !fast_ok) {
       set_error("mixed_precision_gemm: MFMA variant %d forced but the layout contract is not met", variant);
-      return CONCH_ERR_UNSUPPORTED;
+      return kMixedPickError;
     }
-    return launch_mixed_gemm_generic(p, stream);
+    return kMixedPickGeneric;
   }
   // CONCH_TUNE_MIXED_KERNEL: 2 = the column-strip kernel (gemm_mixed_strip.hip) wherever its contract holds, 1 = never,
   // 0 = auto (see mixed_strip_beats_tiles)
@@ -470,18 +473,31 @@ int run_mixed(const MixedGemmArgs& p, hipStream_t stream) {
     if (!mixed_gemm_asm1w_supported(p)) {
       set_error("mixed_precision_gemm: kernel 3 (one-wave-per-SIMD assembly kernel) forced but its contract is not met (fp16, 4-bit weights without "
                 "zero points, group 128, K %% 128 == 0, N %% 16 == 0)");
-      return CONCH_ERR_UNSUPPORTED;
+      return kMixedPickError;
     }
-    return launch_mixed_gemm_asm1w(p, stream);
+    return kMixedPickAsm;
   }
-  if (kernel != 1 && mixed_gemm_strip_supported(p) && (kernel == 2 || mixed_strip_beats_tiles(p))) return launch_mixed_gemm_strip(p, stream);
+  if (kernel != 1 && mixed_gemm_strip_supported(p) && (kernel == 2 || mixed_strip_beats_tiles(p))) return kMixedPickStrip;
   // a few rows of tiles that leave CUs idle (round 5): the strip kernel on 128- / 64-row tiles or in K slices, where its model beats
-  // the LDS-tiled kernel's by the margin (mixed_strip_estimate_us is finite only when strip_plan left the unsplit 256-row tile)
+  // the LDS-tiled kernel's (mixed_strip_short_or_split_us is finite only when strip_plan left the unsplit 256-row tile)
   if (variant == 0 && kernel == 0 && tuning(CONCH_TUNE_MIXED_SPLITK) == 0 && tuning(CONCH_TUNE_MIXED_TILE_NT) == 0 && p.m > fit::kMixedStripSplit.max_m &&
       p.m <= fit::kMixedStripSplit.max_m_search && mixed_gemm_strip_supported(p) &&
       mixed_strip_short_or_split_us(p) * fit::kMixedStripSplit.tall_vs_tiles < mixed_tiles_estimate_us(p))
-    return launch_mixed_gemm_strip(p, stream);
-  return launch_mixed_gemm_mfma(p, stream);
+    return kMixedPickStrip;
+  return kMixedPickTiles;
+}
+
+int run_mixed(const MixedGemmArgs& p, hipStream_t stream) {
+  if (int rc = check_mixed(p)) return rc;
+  if (p.m == 0 || p.n == 0) return CONCH_OK;
+  switch (pick_mixed(p)) {
+    case kMixedPickGeneric: return launch_mixed_gemm_generic(p, stream);
+    case kMixedPickDecode: return launch_mixed_gemm_skinny(p, stream);
+    case kMixedPickStrip: return launch_mixed_gemm_strip(p, stream);
+    case kMixedPickAsm: return launch_mixed_gemm_asm1w(p, stream);
+    case kMixedPickTiles: return launch_mixed_gemm_mfma(p, stream);
+    default: return CONCH_ERR_UNSUPPORTED;
+  }
 }
 
 int run_mixed_modes(const MixedGemmArgs& p, const void* scales, const void* zeros, int64_t zeros_stride_g, int group_mode, int zeros_kind,
@@ -613,6 +629,30 @@ using namespace conch;
 
 extern "C" int conch_abi_version(void) { return CONCH_AMD_ABI_VERSION; }
 extern "C" const char* conch_last_error(void) { return g_error; }
+
+// Diagnostic (not in include/conch_amd.h; tests/test_host_helpers.py, no GPU needed): the kernel mixed_precision_gemm would run for a
+// contiguous, aligned problem of this shape under the current tuning keys, and the strip kernel's plan when that is the pick.
+// out[0] = 0 generic / 1 decode-batch / 2 LDS-tiled / 3 column-strip / 4 assembly (-1: a forced kernel's contract is not met),
+// out[1..3] = tile rows, tile columns, K slices of the strip plan (0 otherwise).  Nothing is launched, no pointer is dereferenced.
+extern "C" int conch_debug_mixed_plan(int64_t m, int64_t n, int64_t k, int bits, int x_dtype, int per_group_zero_points, int* out) {
+  CONCH_CHECK_ARG(out && m > 0 && n > 0 && k > 0 && (bits == 4 || bits == 8), "conch_debug_mixed_plan: bad arguments");
+  MixedGemmArgs p{};
+  p.c = (void*)(uintptr_t)0x10000000;
+  p.x = (const void*)(uintptr_t)0x20000000;
+  p.w_q = (const int32_t*)(uintptr_t)0x30000000;
+  p.w_s = (const void*)(uintptr_t)0x40000000;
+  p.w_zp = per_group_zero_points ? (const int32_t*)(uintptr_t)0x50000000 : nullptr;
+  p.m = m, p.n = n, p.k = k;
+  p.x_stride_m = k, p.wq_stride_k = n, p.ws_stride_g = n, p.wzp_stride_g = n, p.c_stride_m = n;
+  p.bits = bits, p.weight_bias = per_group_zero_points ? 0 : 1 << (bits - 1), p.group_size = 128;
+  p.zp_mode = per_group_zero_points ? CONCH_ZP_TENSOR : CONCH_ZP_NONE;
+  p.x_dtype = x_dtype, p.out_dtype = x_dtype;
+  if (int rc = check_mixed(p)) return rc;
+  out[0] = (int)pick_mixed(p);
+  out[1] = out[2] = out[3] = 0;
+  if (out[0] == kMixedPickStrip) mixed_strip_plan_query(p, &out[1], &out[2], &out[3]);
+  return CONCH_OK;
+}
 
 extern "C" int conch_set_tuning(int key, int value) {
   CONCH_CHECK_ARG(key >= 0 && key < CONCH_TUNE__COUNT, "conch_set_tuning: unknown key %d", key);

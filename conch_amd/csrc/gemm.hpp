@@ -176,6 +176,7 @@ bool mixed_gemm_strip_supported(const MixedGemmArgs& p);
 bool mixed_strip_beats_tiles(const MixedGemmArgs& p);
 int launch_mixed_gemm_strip(const MixedGemmArgs& p, hipStream_t stream);
 double mixed_strip_estimate_us(const MixedGemmArgs& p);  // cost model: its K-split forms on one row of tiles (M <= 256)
+void mixed_strip_plan_query(const MixedGemmArgs& p, int* rows, int* cols, int* slices);  // strip_plan's pick (diagnostics)
 double mixed_strip_short_or_split_us(const MixedGemmArgs& p);  // ... its time if strip_plan leaves the unsplit 256-row tile, else 1e30
 // gemm_asm.hip: the one-wave-per-SIMD int4 x fp16 assembly kernel (csrc/asm/gen_mixed1w.py; CONCH_TUNE_MIXED_KERNEL = 3 forces it)
 bool mixed_gemm_asm1w_supported(const MixedGemmArgs& p);

@@ -809,6 +809,13 @@ StripPlan strip_plan(const MixedGemmArgs& p) {
 // the cost model's time (us) for the strip kernel's pick on one row of tiles (the dispatcher compares it with the other kernels')
 double mixed_strip_estimate_us(const MixedGemmArgs& p) { return strip_plan(p).us; }
 
+void mixed_strip_plan_query(const MixedGemmArgs& p, int* rows, int* cols, int* slices) {
+  const StripPlan plan = strip_plan(p);
+  *rows = 16 * plan.mt;
+  *cols = 64 * plan.nt;
+  *slices = plan.split;
+}
+
 double mixed_strip_short_or_split_us(const MixedGemmArgs& p) {
   const StripPlan plan = strip_plan(p);
   return (plan.mt < 16 || plan.split > 1) && plan.us > 0.0 ? plan.us : 1e30;

@@ -370,3 +370,48 @@ def test_install_as_conch_aliases_the_reference_import_paths():
     )
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, check=False)
     assert res.returncode == 0 and res.stdout.strip().endswith("ok"), res.stdout + res.stderr
+
+
+def test_mixed_dispatcher_picks_are_pinned_without_a_gpu():
+    """conch_debug_mixed_plan: the kernel (and the strip kernel's tile rows x columns x K slices) run_mixed would launch, from the
+    cost models alone (csrc/dispatch_fit.hpp; 256 CUs assumed without a device).  Pins the picks the round-5 sweeps measured as the
+    fastest forms (profiles/r05/mixed_mid_sweep.txt, mixed_rows_tall_after.txt), so that a refit that moves one shows up here."""
+    import ctypes
+
+    lib = _C.load()
+    fn = lib.conch_debug_mixed_plan
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_int64] * 3 + [ctypes.c_int] * 3 + [ctypes.POINTER(ctypes.c_int)]
+    out = (ctypes.c_int * 4)()
+
+    def plan(m, k, n, bits=4, zp=0):
+        assert fn(m, n, k, bits, 1, zp, out) == 0, lib.conch_last_error()
+        return tuple(out)
+
+    decode, tiles, strip = 1, 2, 3
+    for m in (1, 16, 32):
+        assert plan(m, 4096, 11008)[0] == decode                 # GEMV / small decode batches: the one-launch decode kernel
+    assert plan(64, 4096, 4096)[0] == decode                      # narrow and shallow: nothing to gain from K slices
+    assert plan(64, 4096, 11008) == (strip, 64, 192, 4)           # batched decode on a wide problem: 64-row tiles, four K slices
+    assert plan(128, 4096, 11008) == (strip, 128, 192, 4)
+    assert plan(64, 8192, 28672) == (strip, 64, 256, 2)
+    assert plan(384, 4096, 11008) == (strip, 128, 192, 1)         # three rows of 128-row tiles instead of two of 256
+    assert plan(1024, 4096, 4096) == (strip, 128, 128, 1)
+    assert plan(1024, 4096, 11008) == (strip, 256, 192, 1)        # C4: the full-chip 256-row tile, unsplit (unchanged since round 4)
+    assert plan(4096, 8192, 4096)[0] == tiles                     # the reference's README shape: 256 x 256 LDS tiles, one round
+    try:
+        _C.set_tuning(_C.TUNE_MIXED_SPLITK, 1)                    # "never split K": back to the round-4 choices
+        assert plan(64, 4096, 11008)[0] == decode
+        _C.set_tuning(_C.TUNE_MIXED_SPLITK, 0)
+        _C.set_tuning(_C.TUNE_MIXED_KERNEL, 3)                    # the assembly kernel forced outside its contract (8-bit weights)
+        assert fn(1024, 11008, 4096, 8, 1, 0, out) == 0 and out[0] == -1
+        _C.set_tuning(_C.TUNE_MIXED_KERNEL, 2)                    # the strip kernel forced at a decode size
+        _C.set_gemm_variant(_C.VARIANT_MFMA_PINGPONG2)
+        _C.set_tuning(_C.TUNE_MIXED_STRIP_ROWS, 128)
+        _C.set_tuning(_C.TUNE_MIXED_TILE_NT, 2)
+        _C.set_tuning(_C.TUNE_MIXED_SPLITK, 3)
+        assert plan(100, 4096, 4096) == (strip, 128, 128, 3)
+    finally:
+        for key in (_C.TUNE_MIXED_SPLITK, _C.TUNE_MIXED_KERNEL, _C.TUNE_MIXED_STRIP_ROWS, _C.TUNE_MIXED_TILE_NT):
+            _C.set_tuning(key, 0)
+        _C.set_gemm_variant(_C.VARIANT_AUTO)
