@@ -190,25 +190,39 @@ double scaled_tiles_estimate_us(const ScaledGemmArgs& p) {
 }
 namespace {
 
-int run_scaled_fast(const ScaledGemmArgs& p, int variant, hipStream_t stream) {
+// Which kernel the MFMA-contract path of scaled_gemm runs for `p` at GEMM variant `variant` -- no launch (run_scaled_fast launches
+// exactly this; conch_debug_scaled_plan reports it).  kScaledPickError: a forced kernel's contract is not met (+ the error text).
+enum ScaledPick { kScaledPickError = -1, kScaledPickTiles = 0, kScaledPickMid = 1, kScaledPickSkinny = 2, kScaledPickAsm = 3 };
+
+ScaledPick pick_scaled_fast(const ScaledGemmArgs& p, int variant) {
   if (variant == 4 && !scaled_gemm_skinny_supported(p)) {
     set_error("scaled_gemm: skinny variant forced but its contract is not met (M <= 256; N %% 4 == 0 or K %% 1024 == 0)");
-    return CONCH_ERR_UNSUPPORTED;
+    return kScaledPickError;
   }
   if (variant == 7) {
     if (!scaled_gemm_asm1w_supported(p)) {
       set_error("scaled_gemm: variant 7 (one-wave-per-SIMD assembly kernel) forced but its contract is not met (e4m3fn, K %% 256 == 0, K >= 512, "
                 "N %% 16 == 0, bf16 / fp16 row-major C, no bias, arrays below 2 GiB)");
-      return CONCH_ERR_UNSUPPORTED;
+      return kScaledPickError;
     }
-    return launch_scaled_gemm_asm1w(p, stream);
+    return kScaledPickAsm;
   }
   const ScaledKernel pick = variant == 4 ? kKernelSkinny : variant == 6 ? kKernelMid : variant == 0 ? choose_scaled_kernel(p) : kKernelTiled;
-  if (pick == kKernelSkinny && scaled_gemm_skinny_supported(p)) return launch_scaled_gemm_skinny(p, stream);
-  if (pick == kKernelMid) return launch_scaled_gemm_mid(p, stream);
+  if (pick == kKernelSkinny && scaled_gemm_skinny_supported(p)) return kScaledPickSkinny;
+  if (pick == kKernelMid) return kScaledPickMid;
   // large fp8 problems whose 256 x 352 tiling fills the chip in fewer, fuller rounds: the one-wave-per-SIMD assembly kernel
-  if (variant == 0 && pick == kKernelTiled && scaled_asm1w_beats_tiles(p)) return launch_scaled_gemm_asm1w(p, stream);
-  return launch_scaled_gemm_mfma(p, (variant == 2 || variant == 3) ? variant : 5, stream);
+  if (variant == 0 && pick == kKernelTiled && scaled_asm1w_beats_tiles(p)) return kScaledPickAsm;
+  return kScaledPickTiles;
+}
+
+int run_scaled_fast(const ScaledGemmArgs& p, int variant, hipStream_t stream) {
+  switch (pick_scaled_fast(p, variant)) {
+    case kScaledPickSkinny: return launch_scaled_gemm_skinny(p, stream);
+    case kScaledPickMid: return launch_scaled_gemm_mid(p, stream);
+    case kScaledPickAsm: return launch_scaled_gemm_asm1w(p, stream);
+    case kScaledPickTiles: return launch_scaled_gemm_mfma(p, (variant == 2 || variant == 3) ? variant : 5, stream);
+    default: return CONCH_ERR_UNSUPPORTED;
+  }
 }
 
 }  // namespace
@@ -629,6 +643,28 @@ using namespace conch;
 
 extern "C" int conch_abi_version(void) { return CONCH_AMD_ABI_VERSION; }
 extern "C" const char* conch_last_error(void) { return g_error; }
+
+// Diagnostic (not in include/conch_amd.h; tests/test_host_helpers.py, no GPU needed): the kernel scaled_gemm would run for K-contiguous,
+// aligned operands of this shape (per-row / per-column scales, bf16 result, no bias) under the current GEMM variant.
+// out[0] = 0 256 x 256 tiles / 1 128 x 128 tiles / 2 split-K skinny / 3 the assembly kernel (-1: forced outside its contract),
+// out[1] = the assembly kernel's tile width in columns (0 otherwise).  Nothing is launched, no pointer is dereferenced.
+extern "C" int conch_debug_scaled_plan(int64_t m, int64_t n, int64_t k, int in_dtype, int* out) {
+  CONCH_CHECK_ARG(out && m > 0 && n > 0 && k > 0, "conch_debug_scaled_plan: bad arguments");
+  ScaledGemmArgs p{};
+  p.c = (void*)(uintptr_t)0x10000000;
+  p.a = (const void*)(uintptr_t)0x20000000;
+  p.b = (const void*)(uintptr_t)0x30000000;
+  p.scale_a = (const float*)(uintptr_t)0x40000000;
+  p.scale_b = (const float*)(uintptr_t)0x50000000;
+  p.m = m, p.n = n, p.k = k;
+  p.a_stride_m = k, p.a_stride_k = 1, p.b_stride_n = k, p.b_stride_k = 1, p.c_stride_m = n, p.c_stride_n = 1;
+  p.scale_a_numel = m, p.scale_b_numel = n;
+  p.in_dtype = in_dtype, p.out_dtype = CONCH_DT_BF16;
+  CONCH_CHECK_ARG(scaled_gemm_mfma_supported(p), "conch_debug_scaled_plan: the shape is outside the MFMA kernels' contract");
+  out[0] = (int)pick_scaled_fast(p, tuning(CONCH_TUNE_GEMM_VARIANT));
+  out[1] = out[0] == kScaledPickAsm ? scaled_asm1w_tile_columns(p) : 0;
+  return CONCH_OK;
+}
 
 // Diagnostic (not in include/conch_amd.h; tests/test_host_helpers.py, no GPU needed): the kernel mixed_precision_gemm would run for a
 // contiguous, aligned problem of this shape under the current tuning keys, and the strip kernel's plan when that is the pick.

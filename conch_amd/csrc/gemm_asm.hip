@@ -226,6 +226,8 @@ static int asm1w_width(const ScaledGemmArgs& p, double* us_out = nullptr) {
   return best;
 }
 
+int scaled_asm1w_tile_columns(const ScaledGemmArgs& p) { return 32 * asm1w_width(p); }
+
 bool scaled_asm1w_beats_tiles(const ScaledGemmArgs& p) {
   if (!scaled_gemm_asm1w_supported(p)) return false;
   const Asm1wFit& f = kAsm1wFit;

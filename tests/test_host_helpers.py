@@ -415,3 +415,36 @@ def test_mixed_dispatcher_picks_are_pinned_without_a_gpu():
         for key in (_C.TUNE_MIXED_SPLITK, _C.TUNE_MIXED_KERNEL, _C.TUNE_MIXED_STRIP_ROWS, _C.TUNE_MIXED_TILE_NT):
             _C.set_tuning(key, 0)
         _C.set_gemm_variant(_C.VARIANT_AUTO)
+
+
+def test_scaled_dispatcher_picks_are_pinned_without_a_gpu():
+    """conch_debug_scaled_plan: the kernel the MFMA path of scaled_gemm would launch (cost models of csrc/dispatch_fit.hpp and
+    kAsm1wFit; 256 CUs assumed without a device).  The BASELINE configurations and the shapes profiles/r05/asm1w_widths.txt
+    measured: a refit that takes C3 off the assembly kernel fails here, not in a benchmark three rounds later."""
+    import ctypes
+
+    lib = _C.load()
+    fn = lib.conch_debug_scaled_plan
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_int64] * 3 + [ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    out = (ctypes.c_int * 2)()
+    fp8, int8 = 3, 4  # CONCH_DT_FP8_E4M3FN, CONCH_DT_INT8 (include/conch_amd.h)
+
+    def plan(m, k, n, dt):
+        assert fn(m, n, k, dt, out) == 0, lib.conch_last_error()
+        return tuple(out)
+
+    tiles256, tiles128, skinny, asm = 0, 1, 2, 3
+    for dt in (fp8, int8):
+        assert plan(4096, 4096, 11008, dt) == (asm, 352)      # C3: exactly two 256 x 352 tiles per CU
+        assert plan(8192, 8192, 28672, dt) == (asm, 288)      # C5 on one GPU
+        assert plan(8192, 8192, 3584, dt) == (asm, 224)       # C5's shard at 8 GPUs
+        assert plan(2048, 4096, 11008, dt) == (asm, 352)
+        assert plan(128, 4096, 4096, dt)[0] == skinny          # C2
+        assert plan(512, 4096, 4096, dt)[0] == tiles128
+        assert plan(4096, 8192, 4096, dt)[0] == tiles256       # 256 tiles of 256 x 256: one full round
+    try:
+        _C.set_gemm_variant(_C.VARIANT_MFMA_ASM1W)             # forced outside its contract (K = 384): an error, not another kernel
+        assert fn(4096, 11008, 384, fp8, out) == 0 and out[0] == -1
+    finally:
+        _C.set_gemm_variant(_C.VARIANT_AUTO)
