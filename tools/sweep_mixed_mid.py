@@ -23,6 +23,7 @@ COLD_BYTES = 640 << 20
 ms = ctypes.c_float()
 QUICK = "--quick" in sys.argv
 BITS = 8 if "--int8" in sys.argv else 4   # weight width of the timing sweep (uint4b8 / uint8b128)
+XDT = torch.bfloat16 if "--bf16" in sys.argv else torch.float16  # activation / result dtype of the timing sweep
 
 
 def force(rows=0, nt=0, split=0, kernel=0, variant=0):
@@ -94,8 +95,8 @@ def sweep():
         for m in rows_list:
             words = k * BITS // 32
             count = max(2, -(-COLD_BYTES // (words * n * 4)))
-            x, wq, ws, _ = make(m, k, n, bits=BITS, count=count)
-            out = torch.empty((m, n), dtype=torch.float16, device="cuda")
+            x, wq, ws, _ = make(m, k, n, XDT, bits=BITS, count=count)
+            out = torch.empty((m, n), dtype=XDT, device="cuda")
             md = create_mixed_precision_metadata(x, wq[0], ws, None, BITS, 8 if BITS == 4 else 128, 128)
 
             def run(iters):
