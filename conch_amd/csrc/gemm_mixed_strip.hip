@@ -59,11 +59,12 @@ struct StripLds {
   static constexpr int kXPieces = MT / 4;                        // ... of which every wave requests MT / 4
   static constexpr int kWPieces = BITS == 4 ? 1 : 2;             // 8 (16) word rows x 128 bytes (32 columns) per K step
   static constexpr int kWSlot = kWPieces * 1024;
-  // X ring (and every per-wave ring) of S stages: step t read, t + 1 landing, t + 2 .. t + S - 1 requested.  The full tile's K step
-  // (2 W x 16 MFMAs per wave, >= 1 us) covers the memory latency with three; the 128- / 64-row tiles' steps are 2x / 4x shorter and
-  // the latency is what it was (profiles/r05/mixed_mid_sweep.txt: 0.44 us per step at 64 rows with three stages), so they keep
-  // more steps in flight -- as many as the LDS holds
-  static constexpr int kStages = MT == 16 ? 3 : MT == 8 ? (BITS == 4 ? 5 : 4) : (BITS == 4 ? 7 : 5);
+  // X ring (and every per-wave ring) of S stages: step t read, t + 1 landing, t + 2 .. t + S - 1 requested.  Three for the full
+  // tile (its K step, 2 W x 16 MFMAs per wave, >= 1 us, covers the memory latency).  The short tiles' steps are 2x / 4x shorter;
+  // deeper rings (5 at 128 rows; 7 were tried at 64) changed nothing measurable -- a short step is not waiting for its operands
+  // (profiles/r05/mixed_mid_parts.txt) -- so the 64-row tile keeps three, fits 54 KiB and 102 registers, and TWO workgroups share a
+  // CU: forms with more workgroups than CUs gain 15-20 %, the best form of a shape ~3 % (profiles/r05/mixed_mid_occupancy_ab.txt)
+  static constexpr int kStages = MT == 8 ? (BITS == 4 ? 5 : 4) : 3;
   static constexpr int kW = kStages * kXStage;                   // + (wave * kStages + slot) * kWSlot
   static constexpr int kS = kW + 8 * kStages * kWSlot;           // + (wave * kStages + slot) * kSsMeta
   static constexpr int kZ = kS + 8 * kStages * kSsMeta;
@@ -565,6 +566,7 @@ __device__ __forceinline__ void strip_wave(const MixedGemmArgs& p, char* lds, co
   if (p.slabs) {
     // (the 256-row tile keeps the reduce kernel: its loop runs at the 256-register limit and the fused epilogue's loads in flight
     // would be paid for with spills)
+#ifdef CONCH_STRIP_ONE_LAUNCH
     if constexpr (MT < 16) {
       if (p.counters) {
         strip_epilogue_fused<X_DT, W, MT>(acc, p, (int)blockIdx.x, bm0, bn0, col0, lane, wave);
@@ -572,6 +574,7 @@ __device__ __forceinline__ void strip_wave(const MixedGemmArgs& p, char* lds, co
         return;
       }
     }
+#endif
     strip_epilogue_slab<W, MT>(acc, p, p.slabs + (int64_t)blockIdx.y * p.m * p.n, bm0, bn0, col0, lane);
     CONCH_PROBE_AT(g_probe_mixed_strip, 3, (int)(blockIdx.x + gridDim.x * blockIdx.y));
     return;
@@ -591,7 +594,7 @@ __device__ __forceinline__ void strip_wave(const MixedGemmArgs& p, char* lds, co
 }
 
 template <int X_DT, int BITS, bool ZPT, int WA, int WB, int MT>
-__global__ __launch_bounds__(kThreads, 2) void mixed_strip_kernel(MixedGemmArgs p) {
+__global__ __launch_bounds__(kThreads, MT == 4 ? 4 : 2) void mixed_strip_kernel(MixedGemmArgs p) {
   using L = StripLds<BITS, ZPT, MT>;
   constexpr int kRows = 16 * MT;
   constexpr int kTileN = 64 * WA + 64 * WB;
@@ -833,16 +836,19 @@ int launch_mixed_gemm_strip(const MixedGemmArgs& p_in, hipStream_t stream) {
     const size_t bytes = (size_t)strip_slices(p) * p.m * p.n * 4;
     if (int rc = get_scratch(stream, kScratchMixedSplitK, bytes, &ws)) return rc;
     p.slabs = (float*)ws;
-    // CONCH_TUNE_SKINNY_MODE (shared with the decode kernels) = 2: ONE launch (the wave that arrives last at a tile strip adds the
-    // slices).  Opt-in: built, bit-identical, and SLOWER at these tile sizes -- 64 x 4096 x 11008 22.6 us against 17.5, 128 x 4096 x
-    // 11008 34.8 against 23.3 (profiles/r05/mixed_mid_one_launch.txt): draining 48-96 KiB of write-through stores per workgroup
-    // and re-reading them past the L2 costs more than the second launch; the decode kernels' one-launch forms win at <= 8 KiB
+    // ONE launch (the wave that arrives last at a tile strip adds the slices) was built, is bit-identical and SLOWER at these tile
+    // sizes -- 64 x 4096 x 11008 22.6 us against 17.5, 128 x 4096 x 11008 34.8 against 23.3 (profiles/r05/mixed_mid_one_launch.txt):
+    // draining 48-96 KiB of write-through stores per workgroup and re-reading them past the L2 costs more than the second launch
+    // (the decode kernels' one-launch forms win at <= 8 KiB), and its 128 registers of loads in flight cost the 64-row tile its
+    // second workgroup per CU.  Compiled only with -DCONCH_STRIP_ONE_LAUNCH (then CONCH_TUNE_SKINNY_MODE = 2 selects it).
+#ifdef CONCH_STRIP_ONE_LAUNCH
     const int64_t tiles = ((p.m + 16 * plan.mt - 1) / (16 * plan.mt)) * ((p.n + 64 * nt - 1) / (64 * nt));
     if (tuning(CONCH_TUNE_SKINNY_MODE) == 2 && plan.mt < 16 && strip_slices(p) > 1 && bytes < ((size_t)1 << 31) && tiles * 8 <= kStripMaxCounters) {
       void* cbuf = nullptr;
       if (int rc = get_scratch(stream, kScratchCounters, (size_t)kStripMaxCounters * 4, &cbuf, /*zero_on_alloc=*/true)) return rc;
       p.counters = (unsigned*)cbuf;
     }
+#endif
   }
   set_raster_divisor((uint32_t)(kGroupM * ((p.n + 64 * nt - 1) / (64 * nt))), &p.raster_magic, &p.raster_shift);
   int rc;

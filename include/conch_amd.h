@@ -127,8 +127,8 @@ typedef enum conch_tuning_key {
   CONCH_TUNE_SKINNY_MODE = 3 /* split-K skinny-M scaled GEMM and the mixed decode-batch kernel: 0 = auto (one launch at GEMV sizes,
                                 M <= 32, and for 64 < M <= 128 where it fills one round of the chip), 1 = two launches (partial
                                 sums, then a reduce kernel), 2 = ONE launch (the last-arriving slice of a tile reduces it), 1024-byte
-                                K slices, 3 = one launch, 2048-byte slices and <= 64-row blocks (scaled kernel only).  The column-strip mixed kernel's K-split
-                                forms on 64- / 128-row tiles: 2 = one launch (opt-in: slower there), else the slab reduce kernel */
+                                K slices, 3 = one launch, 2048-byte slices and <= 64-row blocks (scaled kernel only).  (The column-strip mixed kernel's K-split
+                                forms always use the slab reduce kernel: their one-launch form is a build-time experiment.) */
   ,
   CONCH_TUNE_TILE_SCHEDULE = 4 /* 256x256-tile scaled GEMM: 0 = auto (= 1), 1 = uniform 256-column tiles, 2 = two tile
                                  widths (256-column tiles, then 192-column tiles: no idle last round), wide first on
