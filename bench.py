@@ -730,9 +730,17 @@ def main() -> None:
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
+        watchdog = float(os.environ.get("CONCH_BENCH_WATCHDOG_S", "0") or 0)
+        if watchdog > 0:  # a rank still alive after this long writes every thread's stack to stderr (tests/test_gpu_distributed.py)
+            import faulthandler
+
+            faulthandler.dump_traceback_later(watchdog, exit=False)
         if args.backend == "nccl":
             torch.distributed.init_process_group("nccl", device_id=device)
         else:
+            # every rank of this benchmark is on one node: gloo's pairs go over loopback, whatever other interfaces the box has
+            # and whatever its hostname resolves to
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
             torch.distributed.init_process_group(args.backend)
 
     kind, m, k, n = WORKLOADS[args.workload]

@@ -1,4 +1,5 @@
-// mixed_precision_gemm, M > 256: the COLUMN-STRIP kernel (round 4).
+// mixed_precision_gemm: the COLUMN-STRIP kernel (round 4: M > 256; round 5: from 33 rows, on 64- / 128- / 256-row tiles, with K
+// split over workgroups where the tiles alone would leave CUs idle).
 //
 // Replaces, like gemm_mixed.hip, the mixed-precision instantiation of the reference's Triton kernel
 // (conch/kernels/quantization/gemm.py:176-216 dequantisation, :219-457 K loop, launcher :482-545).
@@ -25,8 +26,14 @@
 //   * per step and wave: 32 (16) x W MFMAs, 32 X-fragment reads, 2 W chunks dequantised for the NEXT step between the MFMAs
 //     (hand-placed slots, as in gemm_mixed.hip), one workgroup barrier.
 //
+//   * (round 5) the tile height is a template parameter MT = m tiles per wave: 16 (256 rows, the description above), 8 or 4 --
+//     the X stage, the wave's X pieces, the slot plan (several dequantisation slices and requests per MFMA slot in the short
+//     steps) and the X fragments in flight scale with it; every weight is dequantised once per workgroup whatever MT is.  K
+//     slices (blockIdx.y) leave fp32 partial sums in slabs [slice][M][N]; launch_f32_slab_reduce adds them in slice order.
+//     strip_plan picks (MT, width, slices) from the cost model of dispatch_fit.hpp (MixedStripSplit).
+//
 // Contract on top of mixed_gemm_mfma_supported: plain [K/pf][N] weights with 16-byte aligned word rows, output dtype =
-// activation dtype, no fused gate/up form, no split-K (the LDS-tiled kernel keeps those).
+// activation dtype, no fused gate/up form, N % 4 == 0 for the K-split forms.
 #include <algorithm>
 
 #include "common.hpp"

@@ -166,7 +166,9 @@ typedef enum conch_tuning_key {
                                      order into registers, anything else = LDS-DMA staging + gather; a packed-weight pointer that is
                                      not 16-byte aligned takes the register form whatever the key says */
   ,
-  CONCH_TUNE_MIXED_KERNEL = 11 /* mixed_precision_gemm, M > 256: 0 = auto, 1 = the LDS-tiled kernel (dequantised weights pass
+  CONCH_TUNE_MIXED_KERNEL = 11 /* mixed_precision_gemm above the decode sizes (any M with a non-zero CONCH_TUNE_GEMM_VARIANT other than 1 / 4):
+                                  0 = auto (from 33 rows the strip kernel's tile height / width / K slices race the other kernels by
+                                  cost model), 1 = the LDS-tiled kernel (dequantised weights pass
                                   through LDS: gemm_mixed.hip), 2 = the column-strip kernel (every wave dequantises its own 16 / 32
                                   columns straight into MFMA operand registers: gemm_mixed_strip.hip) wherever its contract holds, 3 = the
                                   one-wave-per-SIMD assembly form of it (csrc/asm/gen_mixed1w.py: fp16, 4-bit weights, no zero points,
