@@ -780,11 +780,12 @@ StripPlan strip_plan(const MixedGemmArgs& p) {
   // = 116 workgroups, 42.9 on three rows of 128-row tiles; 1024 x 4096 x 4096: 48.1 -> 39.6; profiles/r05/mixed_rows_tall_sweep.txt);
   // taller problems: the 256-row tile
   int mts[3], n_mt = 0;
-  if (forced_rows) mts[n_mt++] = f_rows / 16;
-  else if (p.m <= 64) mts[n_mt++] = 4;
-  else if (p.m <= 128) mts[n_mt++] = 8, mts[n_mt++] = 4;
-  else if (p.m <= f.max_m_search) mts[n_mt++] = 16, mts[n_mt++] = 8, mts[n_mt++] = 4;
-  else mts[n_mt++] = 16;
+  if (forced_rows) {
+    mts[n_mt++] = f_rows / 16;
+  } else {
+    const int tallest = p.m <= 64 ? 4 : p.m <= 128 ? 8 : 16;
+    for (int mt = tallest; mt >= (p.m <= f.max_m_search ? 4 : tallest); mt /= 2) mts[n_mt++] = mt;
+  }
   StripPlan tall;  // the unsplit 256-row tile at pick_strip_nt's width: what M > 256 ran before round 5
   tall.nt = (f_nt >= 2 && f_nt <= 4) ? f_nt : pick_strip_nt(p, cus);
   tall.us = strip_model_us(p, cus, 16, tall.nt, 1);

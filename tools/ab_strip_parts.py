@@ -3,6 +3,9 @@ out (gemm_mixed_strip.hip's CONCH_EXP_STRIP_* macros: WRONG results, timing only
 
     python tools/ab_strip_parts.py --build      (here: compiles the variants; the .so files travel with the tree)
     python tools/ab_strip_parts.py              (GPU box)            -> stdout (profiles/r05/mixed_mid_parts.txt)
+    python tools/ab_strip_parts.py --build-decode / --decode: the decode kernel with 512-element K slices (not adopted)
+(profiles/r05/mixed_mid_occupancy_ab.txt came from the same harness with a build that no longer exists as a switch: the 64-row tile's
+three-stage ring and 128-register bound are the default now.)
 """
 import ctypes
 import sys
@@ -19,13 +22,6 @@ if "--build-decode" in sys.argv:
     print(_build.build(variant="ms8", defines=("-DCONCH_EXP_MS_STEPS=8",), only=("gemm_mixed_skinny.hip",)))
     sys.exit(0)
 
-if "--build-occ" in sys.argv:
-    from conch_amd import _build
-
-    # (the experiment that made the three-stage, two-workgroups-per-CU form of the 64-row tile the default; the macro is gone)
-    print(_build.build(variant="strip_occ", defines=("-DCONCH_EXP_STRIP_STAGES4=3",), only=("gemm_mixed_strip.hip",)))
-    sys.exit(0)
-
 if "--build" in sys.argv:
     from conch_amd import _build
 
@@ -40,9 +36,7 @@ from conch_amd.kernels.quantization import gemm as kg  # noqa: E402
 from conch_amd.ops.quantization.gemm import create_mixed_precision_metadata  # noqa: E402
 
 LIBS = {"base": _C.load()}
-if "--occ" in sys.argv:  # 64-row tiles with a three-stage ring and <= 128 registers: two workgroups per CU
-    LIBS["occ"] = _C.load_library(Path(_C.LIB_PATH).with_name("libconch_amd_strip_occ.so"))
-elif "--decode" not in sys.argv:
+if "--decode" not in sys.argv:
     for name in VARIANTS:
         LIBS[name] = _C.load_library(Path(_C.LIB_PATH).with_name(f"libconch_amd_strip_{name}.so"))
 ms = ctypes.c_float()
@@ -90,13 +84,6 @@ def decode_case(m, k, n):
 
 
 if __name__ == "__main__":
-    if "--occ" in sys.argv:
-        for m in (48, 64):
-            for k, n in ((4096, 11008), (4096, 4096), (8192, 8192)):
-                for nt in (2, 3, 4):
-                    for split in (2, 4, 8):
-                        case(m, k, n, 64, nt, split)
-        sys.exit(0)
     if "--decode" in sys.argv:
         for m in (16, 32, 64, 128, 256):
             for k, n in ((4096, 4096), (4096, 11008), (8192, 8192)):
