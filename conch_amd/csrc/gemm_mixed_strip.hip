@@ -66,12 +66,13 @@ struct StripLds {
   static constexpr int kXPieces = MT / 4;                        // ... of which every wave requests MT / 4
   static constexpr int kWPieces = BITS == 4 ? 1 : 2;             // 8 (16) word rows x 128 bytes (32 columns) per K step
   static constexpr int kWSlot = kWPieces * 1024;
-  // X ring (and every per-wave ring) of S stages: step t read, t + 1 landing, t + 2 .. t + S - 1 requested.  Three for the full
-  // tile (its K step, 2 W x 16 MFMAs per wave, >= 1 us, covers the memory latency).  The short tiles' steps are 2x / 4x shorter;
-  // deeper rings (5 at 128 rows; 7 were tried at 64) changed nothing measurable -- a short step is not waiting for its operands
-  // (profiles/r05/mixed_mid_parts.txt) -- so the 64-row tile keeps three, fits 54 KiB and 102 registers, and TWO workgroups share a
-  // CU: forms with more workgroups than CUs gain 15-20 %, the best form of a shape ~3 % (profiles/r05/mixed_mid_occupancy_ab.txt)
-  static constexpr int kStages = MT == 8 ? (BITS == 4 ? 5 : 4) : 3;
+  // X ring (and every per-wave ring) of S stages: step t read, t + 1 landing, t + 2 .. t + S - 1 requested (the step / tail code
+  // below takes any S).  Three at every tile height: the full tile's K step (2 W x 16 MFMAs per wave, >= 1 us) covers the memory
+  // latency, and the short tiles' 2x / 4x shorter steps are not waiting for their operands either (profiles/r05/mixed_mid_parts.txt)
+  // -- rings of 5 (128 rows) and 7 (64 rows) were built and changed nothing except the LDS they took: with three the 64-row tile fits
+  // 54 KiB and 102 registers and the 128-row tile 78 KiB, so two workgroups share a CU where the registers allow: forms with more
+  // workgroups than CUs gain 15-20 %, the best form of a shape 1-3 % (profiles/r05/mixed_mid_occupancy_ab.txt)
+  static constexpr int kStages = 3;
   static constexpr int kW = kStages * kXStage;                   // + (wave * kStages + slot) * kWSlot
   static constexpr int kS = kW + 8 * kStages * kWSlot;           // + (wave * kStages + slot) * kSsMeta
   static constexpr int kZ = kS + 8 * kStages * kSsMeta;

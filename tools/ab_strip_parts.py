@@ -5,7 +5,7 @@ out (gemm_mixed_strip.hip's CONCH_EXP_STRIP_* macros: WRONG results, timing only
     python tools/ab_strip_parts.py              (GPU box)            -> stdout (profiles/r05/mixed_mid_parts.txt)
     python tools/ab_strip_parts.py --build-decode / --decode: the decode kernel with 512-element K slices (not adopted)
 (profiles/r05/mixed_mid_occupancy_ab.txt came from the same harness with a build that no longer exists as a switch: the 64-row tile's
-three-stage ring and 128-register bound are the default now.)
+three-stage ring and 128-register bound, and the 128-row tile's three-stage ring, are the default now.)
 """
 import ctypes
 import sys
