@@ -448,3 +448,39 @@ def test_scaled_dispatcher_picks_are_pinned_without_a_gpu():
         assert fn(4096, 11008, 384, fp8, out) == 0 and out[0] == -1
     finally:
         _C.set_gemm_variant(_C.VARIANT_AUTO)
+
+
+def test_mixed_plan_invariants_on_random_shapes():
+    """conch_debug_mixed_plan on 400 random aligned shapes: whatever the cost models pick is a form the kernels have -- a known
+    kernel; strip tiles of 64 / 128 / 256 rows x 128 / 192 / 256 columns in 1..8 K slices, never more slices than 128-element groups,
+    K slices only where N % 4 == 0, the short tiles and the slices only up to the row count the models were fitted on; the decode
+    kernel only up to its 256 rows."""
+    import ctypes
+    import random
+
+    lib = _C.load()
+    fn = lib.conch_debug_mixed_plan
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_int64] * 3 + [ctypes.c_int] * 3 + [ctypes.POINTER(ctypes.c_int)]
+    out = (ctypes.c_int * 4)()
+    rng = random.Random(5)
+    for _ in range(400):
+        m = rng.choice([1, 7, 16, 32, 33, 48, 64, 65, 100, 128, 129, 200, 256, 257, 300, 384, 512, 700, 1024, 1500, 1536, 1537, 2048, 4096])
+        k = 128 * rng.randint(1, 224)
+        n = rng.choice([64, 128, 260, 520, 1376, 2048, 4096, 4100, 5120, 8192, 11008, 13824, 28672])
+        bits, zp, x_dt = rng.choice([4, 8]), rng.choice([0, 1]), rng.choice([1, 2])  # CONCH_DT_FP16 / _BF16
+        assert fn(m, n, k, bits, x_dt, zp, out) == 0, lib.conch_last_error()
+        pick, rows, cols, slices = tuple(out)
+        assert pick in (0, 1, 2, 3), (m, k, n, pick)
+        if pick == 1:
+            assert m <= 256
+        if pick == 3:
+            assert rows in (64, 128, 256) and cols in (128, 192, 256) and 1 <= slices <= 8, (m, k, n, tuple(out))
+            assert slices <= k // 128 and (slices == 1 or n % 4 == 0), (m, k, n, tuple(out))
+            assert not (x_dt == 2 and bits == 8)  # bf16 x 8-bit stays on the LDS-tiled kernel
+            if m > 1536:
+                assert rows == 256 and slices == 1, (m, k, n, tuple(out))
+            if m <= 64:
+                assert rows == 64
+        else:
+            assert (rows, cols, slices) == (0, 0, 0)
