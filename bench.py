@@ -293,10 +293,15 @@ def load_traffic(workload: str) -> tuple[float | None, str | None]:
     return None, None
 
 
-def barrier_sync(world: int) -> None:
+def device_sync(device: torch.device | None = None) -> None:
+    if device is None or device.type == "cuda":  # (a CPU device only in tests/test_distributed_cpu.py's rank script)
+        torch.cuda.synchronize()
+
+
+def barrier_sync(world: int, device: torch.device | None = None) -> None:
     if world > 1:
         torch.distributed.barrier()
-    torch.cuda.synchronize()
+    device_sync(device)
 
 
 def timed_region(fn, steps: int, warmup: int, world: int, device: torch.device, ramp_s: float = CLOCK_RAMP_S, load=None) -> float:
@@ -305,18 +310,31 @@ def timed_region(fn, steps: int, warmup: int, world: int, device: torch.device, 
     if load is not None:
         load()
     else:
+        # `fn` may hold collectives (the N-sharded legs: all-gather per panel, dist.barrier in direct mode), so EVERY rank must
+        # make the same number of calls: a loop bounded by each rank's own wall clock lets one rank leave a batch earlier than its
+        # peer, whose extra all-gathers then pair with the first rank's warm-up calls and, at the end, with its barrier -- a
+        # mismatched collective, i.e. a hang (the intermittent stall of round 5's two-rank test; it would have hung the N = 8 run
+        # the same way).  With more than one rank the ranks vote after every batch: the loop ends on all of them in the same batch.
         t_end = time.perf_counter() + ramp_s
-        while time.perf_counter() < t_end:
+        go = torch.ones(1, dtype=torch.int32, device=device) if world > 1 else None
+        while True:
             for _ in range(20):
                 fn()
-            torch.cuda.synchronize()
+            device_sync(device)
+            more = time.perf_counter() < t_end
+            if world > 1:
+                go.fill_(1 if more else 0)
+                torch.distributed.all_reduce(go, op=torch.distributed.ReduceOp.MIN)
+                more = bool(go.item())
+            if not more:
+                break
     for _ in range(warmup):
         fn()
-    barrier_sync(world)
+    barrier_sync(world, device)
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()
-    barrier_sync(world)
+    barrier_sync(world, device)
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -655,22 +673,101 @@ def emit(result: dict, world: int, rank: int) -> None:
         _flush_c_stdio()
 
 
-def spawn_ranks(n: int, argv: list[str], script: Path | None = None) -> int:
-    """`python bench.py --gpus N` called bare (no torchrun environment): start the N ranks as CHILD processes and relay the one
-    JSON line rank 0 prints.  This parent never touches the GPU -- no HIP call, no torch.cuda.is_available(), no exec: on this
-    pool replacing a process that has initialised the GPU takes the machine down, so the launcher is a child
-    (`python -m torch.distributed.run`, the command the driver itself uses for N > 1) and this process only waits for it."""
-    import subprocess
+def _free_port() -> int:
+    import socket
 
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this host driver
-    env.setdefault("MASTER_ADDR", "127.0.0.1")
-    # --standalone: torchrun picks a free rendezvous port itself (no bind-then-close race with another launcher on the box)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", f"--nproc-per-node={n}",
-           str(script or Path(__file__).resolve()), *argv]
-    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, check=False)  # stderr passes through
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n: int, argv: list[str], script: Path | None = None, launch_timeout_s: float = 0.0) -> int:
+    """`python bench.py --gpus N` called bare (no torchrun environment): start the N ranks as plain CHILD processes of this one
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in their environment -- the env:// rendezvous
+    torch.distributed.run would set up, without its elastic agent) and relay the one JSON line rank 0 prints.  This parent never
+    touches the GPU -- no HIP call, no torch.cuda.is_available(), no exec: on this pool replacing a process that has initialised
+    the GPU takes the machine down.
+
+    The parent OWNS its ranks: it knows their PIDs (printed to stderr as `bench.py ranks: <pid> ...`), they share its process
+    group, and it is the one that ends them --
+      * a rank that exits non-zero takes the others down (SIGTERM, then SIGKILL) and its code is returned;
+      * with `launch_timeout_s` > 0 (--launch-timeout / $CONCH_BENCH_LAUNCH_TIMEOUT_S) ranks still alive after that long are sent
+        SIGUSR1 (each writes every thread's stack into its own file: faulthandler, async-signal-safe, so a rank blocked inside a
+        collective answers too), then SIGKILL; the stacks are printed to stderr and 124 is returned.
+    (Round 5 started `python -m torch.distributed.run` here; its workers live in sessions of their own, so killing the launcher's
+    process group from a test left the ranks alive, holding the pipes and the GPU.)"""
+    import signal
+    import subprocess
+    import tempfile
+
+    target = str(script or Path(__file__).resolve())
+    with tempfile.TemporaryDirectory(prefix="conch_bench_") as tmp:
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this host driver
+        env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   CONCH_BENCH_STACKS_DIR=tmp)
+        env.setdefault("OMP_NUM_THREADS", "1")
+        out0 = open(os.path.join(tmp, "rank0.stdout"), "w+b")  # a file, not a pipe: nothing a rank writes can ever block it
+        procs: list[subprocess.Popen] = []
+        for r in range(n):
+            renv = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+            procs.append(subprocess.Popen([sys.executable, target, *argv], env=renv, stdout=out0 if r == 0 else subprocess.DEVNULL))
+        print("bench.py ranks: " + " ".join(str(p.pid) for p in procs), file=sys.stderr, flush=True)
+
+        def end_all(sig: int) -> None:
+            for p in procs:
+                if p.poll() is None:
+                    try:
+                        p.send_signal(sig)
+                    except ProcessLookupError:
+                        pass
+
+        def reap(grace_s: float) -> None:
+            t_stop = time.monotonic() + grace_s
+            for p in procs:
+                try:
+                    p.wait(timeout=max(0.05, t_stop - time.monotonic()))
+                except subprocess.TimeoutExpired:
+                    pass
+            end_all(signal.SIGKILL)
+            for p in procs:
+                p.wait()
+
+        rc, t0 = 0, time.monotonic()
+        try:
+            while True:
+                codes = [p.poll() for p in procs]
+                bad = [c for c in codes if c not in (None, 0)]
+                if bad:
+                    rc = bad[0] if bad[0] > 0 else 128 - bad[0]
+                    end_all(signal.SIGTERM)
+                    reap(5.0)
+                    break
+                if all(c == 0 for c in codes):
+                    break
+                if launch_timeout_s > 0 and time.monotonic() - t0 > launch_timeout_s:
+                    print(f"bench.py: ranks still running after {launch_timeout_s:.0f} s -- collecting stacks, then ending them",
+                          file=sys.stderr, flush=True)
+                    end_all(signal.SIGUSR1)
+                    time.sleep(1.5)
+                    end_all(signal.SIGKILL)
+                    reap(5.0)
+                    for r in range(n):
+                        f = Path(tmp) / f"rank{r}.stacks"
+                        txt = f.read_text(errors="replace") if f.exists() else "(no stack file: the rank had not reached main())"
+                        print(f"---- rank {r} (pid {procs[r].pid}) stacks ----\n{txt[-6000:]}", file=sys.stderr, flush=True)
+                    rc = 124
+                    break
+                time.sleep(0.05)
+        finally:
+            end_all(signal.SIGKILL)  # whatever ended the loop (KeyboardInterrupt included): no rank outlives its launcher
+            for p in procs:
+                p.wait()
+        out0.seek(0)
+        text = out0.read().decode("utf-8", "replace")
+        out0.close()
     line = None
-    for raw in proc.stdout.decode("utf-8", "replace").splitlines():
+    for raw in text.splitlines():
         raw = raw.strip()
         if raw.startswith("{") and raw.endswith("}"):
             try:
@@ -678,13 +775,37 @@ def spawn_ranks(n: int, argv: list[str], script: Path | None = None) -> int:
             except ValueError:
                 continue
             line = raw  # the last JSON object wins (there is one)
-    if line is not None:
+    if line is not None and rc == 0:
         sys.stdout.write(line + "\n")
         sys.stdout.flush()
-    elif proc.returncode == 0:
+    elif rc == 0:
         print("bench.py: the ranks exited 0 without printing a JSON line", file=sys.stderr)
         return 1
-    return proc.returncode
+    return rc
+
+
+def stall_if_asked(rank: int) -> None:
+    """Test switch: $CONCH_BENCH_STALL_RANK=<r> makes that rank sit here for ever after the rendezvous, so its peers block in
+    their next collective -- the failure tests/test_gpu_distributed.py must see end in ONE failed test, with stacks, no orphan."""
+    want = os.environ.get("CONCH_BENCH_STALL_RANK", "")
+    if want != "" and int(want) == rank:
+        while True:
+            time.sleep(1.0)
+
+
+def arm_stack_dumps(rank: int) -> None:
+    """A rank of a multi-process run writes every thread's stack into $CONCH_BENCH_STACKS_DIR/rank<r>.stacks when its launcher
+    sends SIGUSR1 (spawn_ranks' launch timeout) and, if $CONCH_BENCH_WATCHDOG_S is set, by itself after that many seconds."""
+    import faulthandler
+    import signal
+
+    d = os.environ.get("CONCH_BENCH_STACKS_DIR")
+    f = open(os.path.join(d, f"rank{rank}.stacks"), "w") if d and os.path.isdir(d) else sys.stderr  # noqa: SIM115 -- lives as long as the process
+    faulthandler.register(signal.SIGUSR1, file=f, all_threads=True)
+    watchdog = float(os.environ.get("CONCH_BENCH_WATCHDOG_S", "0") or 0)
+    if watchdog > 0:
+        faulthandler.dump_traceback_later(watchdog, exit=False, file=f)
+    arm_stack_dumps.file = f  # keep the descriptor open
 
 
 def main() -> None:
@@ -711,12 +832,14 @@ def main() -> None:
     ap.add_argument("--c5-shape", default=None, metavar="M,K,N",
                     help="dry-run aid: another (smaller) problem for the N-sharded C5 path; the line says so in config.workload")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
+    ap.add_argument("--launch-timeout", type=float, default=float(os.environ.get("CONCH_BENCH_LAUNCH_TIMEOUT_S", "0") or 0), metavar="S",
+                    help="bare --gpus N > 1 only: ranks still alive after S seconds dump their stacks and are killed; exit code 124 (0 = wait for ever)")
     ap.add_argument("--all-ranks-on-device0", action="store_true",
                     help="dry-run aid: put every rank on cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # called bare, as the driver calls N = 1: be the launcher (before anything touches the GPU)
-        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:], launch_timeout_s=args.launch_timeout))
     claim_stdout()
 
     rank, local_rank, world = dist_env()
@@ -730,11 +853,7 @@ def main() -> None:
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        watchdog = float(os.environ.get("CONCH_BENCH_WATCHDOG_S", "0") or 0)
-        if watchdog > 0:  # a rank still alive after this long writes every thread's stack to stderr (tests/test_gpu_distributed.py)
-            import faulthandler
-
-            faulthandler.dump_traceback_later(watchdog, exit=False)
+        arm_stack_dumps(rank)
         if args.backend == "nccl":
             torch.distributed.init_process_group("nccl", device_id=device)
         else:
@@ -742,6 +861,8 @@ def main() -> None:
             # and whatever its hostname resolves to
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
             torch.distributed.init_process_group(args.backend)
+
+        stall_if_asked(rank)
 
     kind, m, k, n = WORKLOADS[args.workload]
     result: dict = {}

@@ -22,6 +22,26 @@ def pytest_configure(config: pytest.Config) -> None:
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Files of the -m gpu run that start OTHER processes (two-rank runs, torch.compile workers): they run LAST, so that with -x a
+# failure in them can never again hide the hot-path parity files (round 5: the driver's run died in the third of six files with
+# 2 712 parity tests behind it).  Within the parity files: the BASELINE-config tests first, then the rest in file order.
+_LAST_FILES = ("test_gpu_compile.py", "test_gpu_distributed.py")
+_FIRST_FILES = ("test_gpu_gemm.py", "test_gpu_quant.py")
+
+
+def pytest_collection_modifyitems(config: pytest.Config, items: list) -> None:
+    def rank(item) -> tuple[int, int]:
+        name = Path(str(item.fspath)).name
+        if name in _LAST_FILES:
+            return (3, _LAST_FILES.index(name))
+        if name in _FIRST_FILES:
+            headline = any(tag in item.name for tag in ("c1_config", "c2_config", "c3_config", "c4_config", "c5_", "readme_shape"))
+            return (0 if headline else 1, _FIRST_FILES.index(name))
+        return (2, 0)
+
+    items.sort(key=rank)  # stable: file order and definition order survive inside every class
+
+
 def from_bits(arr: np.ndarray, dtype: torch.dtype) -> torch.Tensor:
     """Inverse of make_golden.bits(): raw storage -> torch tensor of `dtype`."""
     if dtype in (torch.float16, torch.bfloat16):

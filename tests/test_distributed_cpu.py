@@ -214,6 +214,96 @@ def test_bench_starts_its_own_ranks_when_called_bare(tmp_path, capfd):
     assert capfd.readouterr().out.strip() == ""
 
 
+_RANK_SCRIPT = '''
+"""Stand-in rank for bench.py's launcher and timing loop (gloo, CPU): the functions under test are bench.py's own."""
+import json, os, sys, time
+from pathlib import Path
+sys.path.insert(0, os.environ["CONCH_REPO_ROOT"])
+import torch
+import torch.distributed as dist
+import bench
+
+rank = int(os.environ["RANK"])
+bench.arm_stack_dumps(rank)
+os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+dist.init_process_group("gloo")
+world = dist.get_world_size()
+bench.stall_if_asked(rank)
+calls = [0]
+buf = torch.zeros(4)
+
+def step_with_a_collective():
+    calls[0] += 1
+    dist.all_reduce(buf)
+
+if rank == 1:
+    time.sleep(0.11)  # rank 1 enters the load phase late: its own wall clock would run out one batch after rank 0's
+for _ in range(3):  # three timed regions back to back, as nshard_c5 runs them
+    bench.timed_region(step_with_a_collective, 3, 2, world, torch.device("cpu"), ramp_s=0.05)
+seen = [None] * world
+dist.all_gather_object(seen, calls[0])
+if rank == 0:
+    print(json.dumps({"calls": seen}), flush=True)
+dist.destroy_process_group()
+'''
+
+
+def _rank_script(tmp_path, monkeypatch):
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    monkeypatch.setenv("CONCH_REPO_ROOT", str(root))
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT)
+    return script
+
+
+def _import_bench():
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    import bench
+
+    return bench
+
+
+def test_timed_region_ranks_make_the_same_number_of_calls(tmp_path, monkeypatch, capfd):
+    """Root cause of round 5's intermittent two-rank stall: the load phase in front of a timed region was a loop bounded by
+    each rank's OWN wall clock around a step that holds collectives, so a rank that entered late made one more batch of
+    all-gathers than its peer -- which by then sat in a barrier.  The ranks now vote after every batch.  Two gloo ranks, rank 1
+    entering 0.11 s late into a 0.05 s load phase: the run must end, and both ranks must have made the same number of calls."""
+    import json
+
+    bench = _import_bench()
+    rc = bench.spawn_ranks(2, [], script=_rank_script(tmp_path, monkeypatch), launch_timeout_s=60)
+    cap = capfd.readouterr()
+    assert rc == 0, cap.err[-3000:]
+    calls = json.loads(cap.out.strip().splitlines()[-1])["calls"]
+    assert calls[0] == calls[1] and calls[0] >= 3 * (20 + 2 + 3), calls
+
+
+def test_launcher_ends_a_stalled_run_with_stacks_and_leaves_no_rank_behind(tmp_path, monkeypatch, capfd):
+    """A rank that stops taking part (CONCH_BENCH_STALL_RANK: the switch tests/test_gpu_distributed.py uses on the device) must
+    cost ONE launch timeout: the launcher collects every rank's stacks (SIGUSR1 -> faulthandler, which answers from inside a
+    blocked collective too), kills the exact PIDs it started, returns 124 and prints no JSON line."""
+    import re
+    import time
+
+    bench = _import_bench()
+    monkeypatch.setenv("CONCH_BENCH_STALL_RANK", "1")
+    t0 = time.monotonic()
+    rc = bench.spawn_ranks(2, [], script=_rank_script(tmp_path, monkeypatch), launch_timeout_s=12)
+    took = time.monotonic() - t0
+    cap = capfd.readouterr()
+    assert rc == 124 and took < 40, (rc, took, cap.err[-2000:])
+    assert cap.out.strip() == ""
+    assert "stall_if_asked" in cap.err, cap.err[-3000:]  # rank 1: where it sits
+    assert "rank 0" in cap.err and "rank 1" in cap.err
+    pids = [int(p) for p in re.search(r"bench.py ranks: ([\d ]+)", cap.err).group(1).split()]
+    assert len(pids) == 2 and not any(os.path.exists(f"/proc/{p}") for p in pids), pids
+
+
 def _direct_worker(rank: int, world: int, port: int, results) -> None:
     """Direct mode: every rank's row-major result is visible to every rank (here: CPU tensors in shared memory standing in for
     peer-mapped HBM), the product is stored into ALL of them by ONE call per panel (here: the oracle, injected), and the only

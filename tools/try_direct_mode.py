@@ -1,6 +1,9 @@
 """Dry run of NShardedScaledGemm's DIRECT mode with two ranks on ONE GPU (development aid): torch symmetric memory between two
 processes that share device 0, the multi-destination tile kernel storing into its own and the peer's result.  Functional only --
-same-device "peers" say nothing about xGMI.  usage: python -m torch.distributed.run --nproc-per-node 2 tools/try_direct_mode.py"""
+same-device "peers" say nothing about xGMI.  Rank 0 prints ONE JSON line with every rank's verdicts.
+usage: python -c "import bench, sys; sys.exit(bench.spawn_ranks(2, [], script='tools/try_direct_mode.py', launch_timeout_s=120))"
+(or python -m torch.distributed.run --nproc-per-node 2 tools/try_direct_mode.py)"""
+import json
 import os
 import sys
 from pathlib import Path
@@ -15,8 +18,12 @@ from conch_amd.ops.quantization.gemm import scaled_gemm  # noqa: E402
 
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    import bench
+
+    bench.arm_stack_dumps(rank)  # the launcher's timeout collects every rank's stacks
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
     dist.init_process_group("gloo")
     torch.manual_seed(0)
     m, k, n = 1024, 512, 1024
@@ -27,14 +34,20 @@ def main():
     try:
         op = NShardedScaledGemm(m, n, torch.bfloat16, dev, direct=True, panels=2)
     except Exception as exc:  # noqa: BLE001
-        print(f"rank {rank}: symmetric memory unavailable here: {exc!r}", flush=True)
+        print(f"rank {rank}: direct mode unavailable here: {exc!r}", file=sys.stderr, flush=True)
         dist.destroy_process_group()
-        return
+        sys.exit(3)
     lo, hi = op.lo, op.hi
+    mine = []
     for it in range(3):
         got = op(a, bt[lo:hi].T, sa, sb[lo:hi])
         torch.cuda.synchronize()
-        print(f"rank {rank} call {it}: direct result equals the unsharded product: {torch.equal(got, full)}", flush=True)
+        mine.append(bool(torch.equal(got, full)))
+        print(f"rank {rank} call {it}: direct result equals the unsharded product: {mine[-1]}", file=sys.stderr, flush=True)
+    seen = [None] * world
+    dist.all_gather_object(seen, mine)
+    if rank == 0:
+        print(json.dumps({"direct_equals_unsharded": seen, "scheme": op.direct_scheme}), flush=True)
     dist.destroy_process_group()
 
 
