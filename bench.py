@@ -441,7 +441,7 @@ class Leg:
             self.x = torch.rand(m, n, dtype=torch.float16, device=device) * 1000
             self.scale = torch.tensor([2.1], dtype=torch.float32, device=device)
             self.step = lambda: scaled_int8_quant(self.x, self.scale)
-            out = torch.empty_like(self.x, dtype=torch.int8)
+            out = self.out = torch.empty_like(self.x, dtype=torch.int8)
 
             def timer(iters: int) -> float:  # the quantiser launches on torch's current stream: torch events see it
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -460,7 +460,7 @@ class Leg:
         elif kind.startswith("scaled"):
             self.a, self.b, self.sa, self.sb = make_scaled(kind, m, k, n, device, seed)
             self.step = lambda: scaled_gemm(self.a, self.b, self.sa, self.sb, torch.bfloat16)
-            out = torch.empty((m, n), dtype=torch.bfloat16, device=device)
+            out = self.out = torch.empty((m, n), dtype=torch.bfloat16, device=device)
             self.timer_for_lib = lambda lib: (lambda iters: kernel_avg_ms_scaled(self.a, self.b, self.sa, self.sb, out, iters, lib))
             self.flops = 2.0 * m * n * k
             self.bytes_alg = m * k + k * n + 2 * m * n + 4 * (m + n)
@@ -471,7 +471,7 @@ class Leg:
         else:
             self.x, self.packed, self.w_s, self.w_ref, self.wt = make_mixed(m, k, n, device, seed)
             self.step = lambda: mixed_precision_gemm(self.x, self.packed, self.w_s, None, self.wt.size_bits, self.wt.bias, 128)
-            out = torch.empty((m, n), dtype=torch.float16, device=device)
+            out = self.out = torch.empty((m, n), dtype=torch.float16, device=device)
             self.timer_for_lib = lambda lib: (lambda iters: kernel_avg_ms_mixed(self.x, self.packed, self.w_s, out, self.wt, iters, lib))
             self.flops = 2.0 * m * n * k
             self.bytes_alg = 2 * m * k + k * n // 2 + 2 * (k // 128) * n + 2 * m * n
@@ -499,6 +499,88 @@ class Leg:
         """Whole-job throughput in the metric's unit: TFLOP/s for the GEMMs, GB/s for the quantiser."""
         work = self.bytes_alg / 1e9 if self.kind == "quant_int8" else self.flops / 1e12
         return work * steps * world / elapsed
+
+    def picked_kernel(self) -> str:
+        """The kernel the automatic dispatcher launches for this leg's call (conch_debug_*_plan: the same pure function of the
+        problem that run_scaled_fast / run_mixed act on), by its symbol name."""
+        lib = _C.load()
+        if self.kind == "quant_int8":
+            return "quant_flat_kernel (quant.hip)"
+        if self.kind.startswith("scaled"):
+            fn = lib.conch_debug_scaled_plan
+            fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_int64] * 3 + [ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+            out = (ctypes.c_int * 2)()
+            if fn(self.m, self.n, self.k, 3 if self.kind == "scaled_fp8" else 4, out) != 0:
+                return "unknown"
+            tag = "fp8" if self.kind == "scaled_fp8" else "i8"
+            width = {352: "", 288: "_n9", 224: "_n7"}.get(out[1], "?")
+            return {0: "scaled_gemm_pp2_persistent_kernel 256x256 (gemm_mfma.hip)", 1: "scaled_gemm_mid_kernel 128x128 (gemm_mid.hip)",
+                    2: "skinny_splitk_kernel + skinny_reduce_kernel (gemm_skinny.hip)",
+                    3: f"conch_gemm1w_{tag}_bf16{width} 256x{out[1]} (asm/gen_gemm1w.py)"}.get(out[0], f"pick {out[0]}")
+        fn = lib.conch_debug_mixed_plan
+        fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_int64] * 3 + [ctypes.c_int] * 3 + [ctypes.POINTER(ctypes.c_int)]
+        out = (ctypes.c_int * 4)()
+        if fn(self.m, self.n, self.k, 4, 1, 0, out) != 0:
+            return "unknown"
+        return {0: "mixed generic kernel (gemm_generic.hip)", 1: "mixed_skinny_kernel (gemm_mixed_skinny.hip)",
+                2: "mixed_gemm_kernel 256x256 (gemm_mixed.hip)", 3: f"mixed_strip_kernel {out[1]}x{out[2]} tiles, {out[3]} K slice(s) (gemm_mixed_strip.hip)",
+                4: "conch_mixed1w (asm/gen_mixed1w.py)"}.get(out[0], f"pick {out[0]}")
+
+    def parity(self, got: torch.Tensor, rows: int = 256) -> dict:
+        """`got` = an output of THIS leg's `step` (the public op under the automatic dispatcher: the call that is timed) against the
+        CPU oracle, as the reference's benchmarks check before they time (benchmarks/scaled_gemm_benchmark.py:216-227).  The
+        oracle is the checker here, never the thing measured.
+          quantiser   every element, bit for bit (oracle.scaled_int8_quant_ref)
+          scaled      `rows` rows spread over M (every row tile of the kernels is hit), every column: int8 bit for bit; fp8 within
+                      the per-element bound of tests/test_gpu_gemm.py::check_scaled -- two roundings to bf16 plus the worst-case
+                      fp32 accumulation-order error of that element's own products
+          mixed       the same rows against oracle.mixed_precision_gemm_ref (reference bar: rtol 1e-1, atol min(5e-2 sqrt K, 1))
+                      and against the fp64 product of the reference's own operands within check_mixed's per-element bound
+        max_excess = max(|got - ref| - bound) over the checked elements (<= 0 passes; mismatching elements for bit-exact legs)."""
+        import oracle
+
+        t0 = time.perf_counter()
+        if self.kind == "quant_int8":
+            q = got[0] if isinstance(got, tuple) else got
+            want = oracle.scaled_int8_quant_ref(self.x.cpu(), self.scale.cpu())
+            bad = int((q.cpu() != want).sum().item())
+            res = {"checked_rows": self.m, "bit_exact": True, "max_excess": bad, "ok": bad == 0, "oracle": "oracle.scaled_int8_quant_ref"}
+        else:
+            g = torch.Generator().manual_seed(1234)
+            take = min(rows, self.m)
+            if self.m <= rows:
+                idx = torch.arange(self.m)
+            else:
+                idx = torch.unique(torch.cat([torch.linspace(0, self.m - 1, take // 2).long(), torch.randint(0, self.m, (take - take // 2,), generator=g)]))
+            got_rows = got[idx.to(got.device)].cpu()
+            if self.kind.startswith("scaled"):
+                a, b, sa, sb = self.a[idx.to(self.device)].cpu(), self.b.cpu(), self.sa[idx.to(self.device)].cpu(), self.sb.cpu()
+                ref = oracle.scaled_gemm_ref(a, b, sa, sb, torch.bfloat16)
+                if self.kind == "scaled_int8":
+                    bad = int((got_rows.view(torch.int16) != ref.view(torch.int16)).sum().item())
+                    res = {"bit_exact": True, "max_excess": bad, "ok": bad == 0}
+                else:
+                    s_abs = a.float().abs() @ b.float().abs()
+                    bound = 2.0 * 2.0**-7 * ref.float().abs() + (sa.reshape(-1, 1) * sb.reshape(1, -1)).abs() * (self.k * 2.0**-24) * s_abs + 2.0 * 2.0**-133
+                    excess = ((got_rows.float() - ref.float()).abs() - bound).max().item()
+                    res = {"bit_exact": False, "max_excess": excess, "ok": excess <= 0,
+                           "max_abs_diff": (got_rows.float() - ref.float()).abs().max().item(), "max_abs_ref": ref.float().abs().max().item()}
+                res["oracle"] = "oracle.scaled_gemm_ref"
+            else:
+                a = self.x[idx.to(self.device)].cpu()
+                ref = oracle.mixed_precision_gemm_ref(a, self.w_ref).float()
+                exact = a.double() @ self.w_ref.double()
+                bound = 2.0**-10 * exact.abs() + (self.k * 2.0**-24) * (a.double().abs() @ self.w_ref.double().abs()) + 1e-30
+                excess = ((got_rows.double() - exact).abs() - bound).max().item()
+                atol = min(5e-2 * self.k**0.5, 1.0)
+                ref_bar = bool(((got_rows.float() - ref).abs() <= atol + 1e-1 * ref.abs()).all().item())
+                res = {"bit_exact": False, "max_excess": excess, "ok": excess <= 0 and ref_bar, "reference_tolerance_met": ref_bar,
+                       "max_abs_diff": (got_rows.float() - ref).abs().max().item(), "max_abs_ref": ref.abs().max().item(),
+                       "oracle": "oracle.mixed_precision_gemm_ref (+ fp64 product of w_ref)"}
+            res["checked_rows"] = int(idx.numel())
+        res["kernel"] = self.picked_kernel()
+        res["seconds"] = round(time.perf_counter() - t0, 2)
+        return res
 
     def cpu_baseline(self) -> dict:
         if self.kind == "quant_int8":
@@ -570,11 +652,17 @@ def measured_peak(leg: Leg, seconds: float) -> dict | None:
 
 
 def measure_leg(leg: Leg, steps: int, warmup: int, world: int, sustained_s: float, with_burst: bool, with_cold: bool, with_probe: bool,
-                with_peak: bool, with_cpu: bool) -> dict:
+                with_peak: bool, with_cpu: bool, with_parity: bool = True) -> dict:
     """One workload, measured: op-level timed region after `sustained_s` of the kernel's own load, kernel-level roofline
-    (sustained / burst / cold), the measured ceiling and the CPU oracle's rate."""
+    (sustained / burst / cold), the measured ceiling and the CPU oracle's rate.  `with_parity`: BEFORE anything is timed an output
+    of the op that will be timed is checked against the CPU oracle (Leg.parity), and AFTER the timed region the buffer the
+    kernel-event timer wrote under sustained load (`leg.out`: the launches behind `roofline`) is checked the same way."""
     device = leg.device
     burst = None
+    parity = None
+    if with_parity:
+        leg.out.zero_()
+        parity = leg.parity(leg.step())
     if with_burst:  # a cold chip's figure (rounds 1-4's headline protocol), taken FIRST
         t = timed_region(leg.step, steps, warmup, world, device)
         k_burst_ms = leg.timer(max(20, min(steps, 200)))
@@ -625,6 +713,13 @@ def measure_leg(leg: Leg, steps: int, warmup: int, world: int, sustained_s: floa
            "config": {"workload": leg.desc}, "roofline": roofline}
     if burst is not None:
         res["burst"] = burst
+    if parity is not None:
+        torch.cuda.synchronize()
+        after = leg.parity(leg.out)
+        parity["timed_buffer_max_excess"], parity["timed_buffer_ok"] = after["max_excess"], after["ok"]
+        parity["seconds"] = round(parity["seconds"] + after["seconds"], 2)
+        parity["ok"] = bool(parity["ok"] and after["ok"])
+        res["parity"] = parity
     if with_cpu:
         res["cpu_baseline"] = leg.cpu_baseline()
     return res
@@ -816,6 +911,7 @@ def main() -> None:
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--quick", action="store_true", help="skip the sustained / cold / clock legs (PMC profiling passes)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the timed op's output (rocprofv3 passes: fewer kernels in the trace)")
     ap.add_argument("--no-cold", action="store_true", help="skip the cache-flushed op-level leg")
     ap.add_argument("--no-probe", action="store_true", help="skip the diagnostic-twin clock probe (kernel-trace profiling: its kernels share names)")
     ap.add_argument("--no-peak", action="store_true", help="skip the measured-ceiling microbenchmark (libconch_micro.so)")
@@ -888,7 +984,8 @@ def main() -> None:
     sustained_s = (SUSTAINED_S if world == 1 else 0.0) if full else 0.0
     res = measure_leg(leg, args.steps, args.warmup, world, sustained_s, with_burst=full and world == 1,
                       with_cold=full and not args.no_cold and leg.kind != "quant_int8", with_probe=world == 1 and full and not args.no_probe,
-                      with_peak=world == 1 and full and not args.no_peak, with_cpu=world == 1 and rank == 0 and not args.no_cpu_baseline)
+                      with_peak=world == 1 and full and not args.no_peak, with_cpu=world == 1 and rank == 0 and not args.no_cpu_baseline,
+                      with_parity=not args.no_parity)
     if args.workload == "c3":
         metric = "effective TFLOP/s + % MFMA roofline, scaled-GEMM fp8xbf16 4096x4096x11008"
     elif leg.kind == "quant_int8":
@@ -907,6 +1004,8 @@ def main() -> None:
         },
         "roofline": res["roofline"],
     }
+    if "parity" in res:
+        result["parity"] = res["parity"]
     if "burst" in res:
         result["burst"] = res["burst"]
     if world == 1 and args.workload == "c3" and full and not args.no_side_legs:
@@ -916,7 +1015,8 @@ def main() -> None:
             try:
                 side = Leg(name, device, seed=0)
                 result[name] = measure_leg(side, 50, 10, 1, SIDE_SUSTAINED_S, with_burst=False, with_cold=False, with_probe=False,
-                                           with_peak=not args.no_peak and name == "c4", with_cpu=not args.no_cpu_baseline)
+                                           with_peak=not args.no_peak and name == "c4", with_cpu=not args.no_cpu_baseline,
+                                           with_parity=not args.no_parity)
                 del side
             except Exception as exc:  # noqa: BLE001 -- a side field must not take the headline down
                 result[name] = {"error": repr(exc)}
@@ -936,7 +1036,14 @@ def main() -> None:
             result["c5_one_gpu"] = {"error": repr(exc)}
     if "cpu_baseline" in res:
         result["cpu_baseline"] = res["cpu_baseline"]
+    # a fast kernel whose results differ from the oracle's is not a result: the line still prints (with parity.ok false), the
+    # exit code says so (what the reference's benchmarks do before they time: benchmarks/scaled_gemm_benchmark.py:216-227)
+    checks = [result.get("parity")] + [result[nm].get("parity") for nm in ("c1", "c2", "c4", "c4readme") if isinstance(result.get(nm), dict)]
+    failed = [c for c in checks if c is not None and not c["ok"]]
     emit(result, world, rank)
+    if failed:
+        print(f"bench.py: PARITY FAILED against the oracle: {failed}", file=sys.stderr)
+        sys.exit(1)
 
 
 if __name__ == "__main__":

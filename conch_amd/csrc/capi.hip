@@ -201,7 +201,7 @@ ScaledPick pick_scaled_fast(const ScaledGemmArgs& p, int variant) {
   }
   if (variant == 7) {
     if (!scaled_gemm_asm1w_supported(p)) {
-      set_error("scaled_gemm: variant 7 (one-wave-per-SIMD assembly kernel) forced but its contract is not met (e4m3fn, K %% 256 == 0, K >= 512, "
+      set_error("scaled_gemm: variant 7 (one-wave-per-SIMD assembly kernel) forced but its contract is not met (e4m3fn or int8, K %% 256 == 0, K >= 512, "
                 "N %% 16 == 0, bf16 / fp16 row-major C, no bias, arrays below 2 GiB)");
       return kScaledPickError;
     }
@@ -219,7 +219,11 @@ int run_scaled_fast(const ScaledGemmArgs& p, int variant, hipStream_t stream) {
   switch (pick_scaled_fast(p, variant)) {
     case kScaledPickSkinny: return launch_scaled_gemm_skinny(p, stream);
     case kScaledPickMid: return launch_scaled_gemm_mid(p, stream);
-    case kScaledPickAsm: return launch_scaled_gemm_asm1w(p, stream);
+    case kScaledPickAsm:
+      // the automatic pick on a device where the embedded code object did not load: the 256 x 256 HIP tiles serve (bit-identical
+      // results); a FORCED assembly variant reports the load error instead
+      if (variant == 0 && !scaled_asm1w_loadable()) return launch_scaled_gemm_mfma(p, 5, stream);
+      return launch_scaled_gemm_asm1w(p, stream);
     case kScaledPickTiles: return launch_scaled_gemm_mfma(p, (variant == 2 || variant == 3) ? variant : 5, stream);
     default: return CONCH_ERR_UNSUPPORTED;
   }
@@ -730,6 +734,7 @@ extern "C" int conch_reserve_scratch(void* stream, int64_t bytes) {
   for (int slot = 0; slot < kScratchCounters; ++slot)
     if (int rc = get_scratch((hipStream_t)stream, slot, (size_t)bytes, &ignored)) return rc;
   if (int rc = get_scratch((hipStream_t)stream, kScratchFlags, kFlagsBytes, &ignored)) return rc;  // e4m3fnuz dispatch word + scaled scale_a
+  preload_asm_modules();  // the assembly kernels' code objects for this device: never loaded inside a capture
   return get_scratch((hipStream_t)stream, kScratchCounters, (size_t)64 * 1024, &ignored, /*zero_on_alloc=*/true);
 }
 

@@ -29,7 +29,7 @@ struct ScaledSkinny {
 
 // ---- mixed_precision_gemm -----------------------------------------------------------------------------------------------------
 // decode-batch kernel against one row of tiles (capi.hip, mixed_decode_beats_tiles): profiles/r02/dispatch_cold_sweep_after.txt,
-// refit round 3; int8 weights stream 1.85x the bytes
+// refit round 3; int8 weights: int8_factor below (1.85 = the byte ratio was the model until round 5 measured 1.07-1.19x)
 struct MixedDecode {
   double fixed = 5.0, per_nk_block = 0.41e-6, int8_factor = 1.2;   // (int8: 1.07-1.19x measured in round 5, mixed_mid_sweep_int8.txt; 1.85 until then)
   double unsplit_tile_us_per_1024k = 16.5;                  // an UNSPLIT row of the narrowest tiles (split off / not allowed)

@@ -130,6 +130,9 @@ int launch_scaled_gemm_mfma(const ScaledGemmArgs& p, int variant, hipStream_t st
 // gemm_asm.hip -- the one-wave-per-SIMD 256 x 352-tile fp8 kernel (hand-allocated assembly, csrc/asm/gen_gemm1w.py; variant 7)
 bool scaled_gemm_asm1w_supported(const ScaledGemmArgs& p);
 int launch_scaled_gemm_asm1w(const ScaledGemmArgs& p, hipStream_t stream);
+bool scaled_asm1w_loadable();  // the embedded code object is (or can be) loaded on the current device
+bool mixed_asm1w_loadable();
+void preload_asm_modules();    // load both assembly modules for the current device (conch_reserve_scratch: before any capture)
 int scaled_asm1w_tile_columns(const ScaledGemmArgs& p);  // the tile width it would use on `p` (352 / 288 / 224)
 bool scaled_asm1w_beats_tiles(const ScaledGemmArgs& p);  // cost rule: its 256 x 352 tiles against the 256 x 256 tiles (full rounds, fewer epilogues)
 // gemm_mid.hip -- 128x128 tiles, two workgroups per CU, for shapes with few 256x256 tiles (variant 6); same contract

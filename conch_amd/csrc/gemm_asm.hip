@@ -3,9 +3,13 @@
 // reference's Triton `_gemm_kernel` + `scaled_gemm_launcher` (conch/kernels/quantization/gemm.py:219-457, :564-627) for large
 // fp8 problems -- 256 x 352 output tiles, four waves of 128 x 176, every register of the SIMD in one wave.
 //
-// The kernel is loaded from memory with hipModuleLoadData on first use (one module per process; one process per GPU) and
+// The kernel is loaded from memory with hipModuleLoadData on first use ON EACH DEVICE (HIP modules and their functions belong to
+// the device that was current at load time: one table per device id, under a mutex, like unit_scale / device_cu_count) and
 // launched with hipModuleLaunchKernel on the caller's stream, so it is stream-ordered and graph-capturable like every other
-// kernel of the library.
+// kernel of the library.  A load allocates and uploads the code object, which a stream capture may not contain:
+// conch_reserve_scratch (the call every capture is preceded by) loads both modules for the current device
+// (preload_asm_modules).  A failed load is remembered per device; under the automatic dispatcher the caller falls back to the
+// HIP kernels (capi.hip), only a FORCED assembly variant reports the error.
 #include <algorithm>
 #include <atomic>
 #include <cstdio>
@@ -39,27 +43,47 @@ struct Mixed1wArgs {
 static_assert(sizeof(Mixed1wArgs) == 96 && offsetof(Mixed1wArgs, m) == 32 && offsetof(Mixed1wArgs, tiles_m) == 64 && offsetof(Mixed1wArgs, probe) == 88,
               "kernarg block of conch_mixed1w_*");
 
+constexpr int kMaxDevices = 64;
+
+// Per-device table of lazily loaded modules: `load(M&)` runs once per device id (under the mutex), on the thread that first
+// needs the module there.  Returns NULL (error text set) when the current device id is out of range.
+template <class M, class Load>
+M* module_of_current_device(M (&table)[kMaxDevices], bool (&loaded)[kMaxDevices], std::mutex& mu, Load load) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+    set_error("assembly kernels: device id %d out of range", dev);
+    return nullptr;
+  }
+  std::lock_guard<std::mutex> lock(mu);
+  if (!loaded[dev]) {
+    load(table[dev]);
+    loaded[dev] = true;
+  }
+  return &table[dev];
+}
+
 struct Mixed1wModule {
   hipModule_t mod = nullptr;
   hipFunction_t w3 = nullptr, w4 = nullptr, w3_probe = nullptr, w4_probe = nullptr;
   int rc = CONCH_OK;
 };
 
-Mixed1wModule& mixed1w_module() {
-  static Mixed1wModule m;
-  static std::once_flag once;
-  std::call_once(once, [] {
+Mixed1wModule* mixed1w_module() {
+  static Mixed1wModule table[kMaxDevices];
+  static bool loaded[kMaxDevices] = {};
+  static std::mutex mu;
+  return module_of_current_device(table, loaded, mu, [](Mixed1wModule& m) {
     hipError_t e = hipModuleLoadData(&m.mod, kMixed1wCodeObject);
     if (e == hipSuccess) e = hipModuleGetFunction(&m.w3, m.mod, "conch_mixed1w_f16_i4_w3");
     if (e == hipSuccess) e = hipModuleGetFunction(&m.w4, m.mod, "conch_mixed1w_f16_i4_w4");
     if (e == hipSuccess) e = hipModuleGetFunction(&m.w3_probe, m.mod, "conch_mixed1w_f16_i4_w3_probe");
     if (e == hipSuccess) e = hipModuleGetFunction(&m.w4_probe, m.mod, "conch_mixed1w_f16_i4_w4_probe");
     if (e != hipSuccess) {
+      (void)hipGetLastError();
       set_error("mixed_precision_gemm (one-wave-per-SIMD kernel): loading the embedded code object failed: %s", hipGetErrorString(e));
       m.rc = CONCH_ERR_HIP;
     }
   });
-  return m;
 }
 
 std::atomic<unsigned long long*> g_mixed1w_probe{nullptr};
@@ -93,10 +117,11 @@ struct Gemm1wModule {
   int rc = CONCH_OK;
 };
 
-Gemm1wModule& gemm1w_module() {
-  static Gemm1wModule m;
-  static std::once_flag once;
-  std::call_once(once, [] {
+Gemm1wModule* gemm1w_module() {
+  static Gemm1wModule table[kMaxDevices];
+  static bool loaded[kMaxDevices] = {};
+  static std::mutex mu;
+  return module_of_current_device(table, loaded, mu, [](Gemm1wModule& m) {
     hipError_t e = hipModuleLoadData(&m.mod, kGemm1wCodeObject);
     for (int w = 0; w < 3 && e == hipSuccess; ++w)
       for (int i8 = 0; i8 < 2 && e == hipSuccess; ++i8)
@@ -110,11 +135,11 @@ Gemm1wModule& gemm1w_module() {
     if (e == hipSuccess) e = hipModuleGetFunction(&m.bf16_alt_probe, m.mod, "conch_gemm1w_fp8_bf16_alt_probe");
     if (e == hipSuccess) e = hipModuleGetFunction(&m.i8_probe, m.mod, "conch_gemm1w_i8_bf16_probe");
     if (e != hipSuccess) {
+      (void)hipGetLastError();
       set_error("scaled_gemm (one-wave-per-SIMD kernel): loading the embedded code object failed: %s", hipGetErrorString(e));
       m.rc = CONCH_ERR_HIP;
     }
   });
-  return m;
 }
 
 std::atomic<unsigned long long*> g_gemm1w_probe{nullptr};
@@ -239,9 +264,31 @@ bool scaled_asm1w_beats_tiles(const ScaledGemmArgs& p) {
   return us < f.margin * us256;
 }
 
+// Both assembly modules loaded for the CURRENT device (conch_reserve_scratch: before any capture; a load inside a capture would
+// put an allocation + upload into the graph).  Load failures are not errors here: they are remembered and the dispatchers fall back.
+void preload_asm_modules() {
+  (void)gemm1w_module();
+  (void)mixed1w_module();
+}
+
+bool scaled_asm1w_loadable() {
+  const Gemm1wModule* m = gemm1w_module();
+  return m && m->rc == CONCH_OK;
+}
+
+bool mixed_asm1w_loadable() {
+  const Mixed1wModule* m = mixed1w_module();
+  return m && m->rc == CONCH_OK;
+}
+
 int launch_scaled_gemm_asm1w(const ScaledGemmArgs& p, hipStream_t stream) {
-  Gemm1wModule& mod = gemm1w_module();
-  if (mod.rc != CONCH_OK) return mod.rc;
+  Gemm1wModule* modp = gemm1w_module();
+  if (!modp) return CONCH_ERR_HIP;
+  if (modp->rc != CONCH_OK) {
+    set_error("scaled_gemm (one-wave-per-SIMD kernel): the embedded code object did not load on this device");
+    return modp->rc;
+  }
+  Gemm1wModule& mod = *modp;
   Gemm1wArgs a{};
   a.a = p.a;
   a.b = p.b;
@@ -318,8 +365,13 @@ int mixed_asm1w_width(const MixedGemmArgs& p) {
 }
 
 int launch_mixed_gemm_asm1w(const MixedGemmArgs& p, hipStream_t stream) {
-  Mixed1wModule& mod = mixed1w_module();
-  if (mod.rc != CONCH_OK) return mod.rc;
+  Mixed1wModule* modp = mixed1w_module();
+  if (!modp) return CONCH_ERR_HIP;
+  if (modp->rc != CONCH_OK) {
+    set_error("mixed_precision_gemm (one-wave-per-SIMD kernel): the embedded code object did not load on this device");
+    return modp->rc;
+  }
+  Mixed1wModule& mod = *modp;
   const int w = mixed_asm1w_width(p);
   Mixed1wArgs a{};
   a.x = p.x;

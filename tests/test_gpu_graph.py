@@ -221,3 +221,56 @@ def test_assembly_kernel_replays_from_a_hip_graph():
             assert torch.equal(out, scaled_gemm(a, bt.T, sa, sb, torch.bfloat16))
     finally:
         _C.set_gemm_variant(_C.VARIANT_AUTO)
+
+
+_COLD_CAPTURE = '''
+import sys
+sys.path.insert(0, sys.argv[1])
+import torch
+from conch_amd import _C
+from conch_amd.ops.quantization.gemm import scaled_gemm
+
+torch.manual_seed(5)
+m, k, n = 2048, 1024, 2816  # 8 x 8 tiles of 256 x 352: the automatic dispatcher takes the assembly kernel
+dev = torch.device("cuda")
+a = (0.25 * torch.rand((m, k), device=dev)).to(torch.float8_e4m3fn)
+bt = (0.25 * torch.rand((n, k), device=dev)).to(torch.float8_e4m3fn)
+sa, sb = 0.25 * torch.rand((m, 1), device=dev), 0.25 * torch.rand((n, 1), device=dev)
+stream = torch.cuda.Stream()
+with torch.cuda.stream(stream):
+    _C.reserve_scratch(_C.load().conch_scaled_gemm_workspace_bytes(m, n, k))  # the ONLY library call in front of the capture
+stream.synchronize()
+graph = torch.cuda.CUDAGraph()
+with torch.cuda.graph(graph, stream=stream):
+    out = scaled_gemm(a, bt.T, sa, sb, torch.bfloat16)  # VARIANT_AUTO: first launch of the assembly kernel in this process
+graph.replay()
+torch.cuda.synchronize()
+_C.set_gemm_variant(_C.VARIANT_MFMA_PINGPONG2)
+want = scaled_gemm(a, bt.T, sa, sb, torch.bfloat16)
+assert torch.equal(out, want), "captured assembly launch differs from the eager HIP kernel"
+print("cold capture ok")
+'''
+
+
+def test_cold_capture_of_the_automatic_assembly_pick(tmp_path):
+    """ADVICE r5: the assembly kernel's first use loads a code object (hipModuleLoadData: an allocation + upload), which must not
+    happen inside a capture.  conch_reserve_scratch -- the call in front of every capture -- loads the modules for the device, so a
+    FRESH process may capture a C3-like fp8 scaled_gemm under the automatic dispatcher with no eager warm-up at all.  A child
+    process (this one has long loaded the module), outputs in files, bounded wait."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    script = tmp_path / "cold_capture.py"
+    script.write_text(_COLD_CAPTURE)
+    with open(tmp_path / "out", "wb") as fo, open(tmp_path / "err", "wb") as fe:
+        proc = subprocess.Popen([sys.executable, str(script), str(root)], stdout=fo, stderr=fe, stdin=subprocess.DEVNULL)
+        try:
+            rc = proc.wait(timeout=180)
+        except subprocess.TimeoutExpired:
+            proc.kill()
+            proc.wait(timeout=15)
+            rc = -9
+    out, err = (tmp_path / "out").read_text(errors="replace"), (tmp_path / "err").read_text(errors="replace")
+    assert rc == 0 and "cold capture ok" in out, f"rc {rc}\n{out[-1500:]}\n{err[-3000:]}"
