@@ -23,8 +23,9 @@ hipcc cannot allocate without shuffling accumulators through v_accvgpr moves (pr
     t + 1 has landed: `s_waitcnt vmcnt(14)` before it).  vmcnt retires in order, so the counts are exact.
 
 The kernel takes M, N, K, leading dimensions and scale vectors at run time; what is fixed: fp8 e4m3 (OCP) operands, K-contiguous
-A and B^T with 16-byte aligned rows, K a multiple of 256 bytes, bf16 or fp16 row-major C, N a multiple of 16, no bias (the
-launcher in gemm_asm.hip checks; other problems keep the HIP kernels).
+A and B^T with 16-byte aligned rows, K a multiple of 256 bytes, bf16 or fp16 row-major C, N a multiple of 16; an optional bias vector
+of the output dtype is added by the *_bias twins of every kernel (the launcher in gemm_asm.hip checks the contract; other problems
+keep the HIP kernels).
 
 usage: gen_gemm1w.py OUT.s
 """
@@ -37,13 +38,14 @@ MT = 8                       # 16-row m tiles per wave
 TILE_M = 256
 A_BYTES = TILE_M * 128                       # 32 KiB of a stage
 SCALE_BUF = 3072                             # two scale buffers: the current tile's, and the next tile's parked under the epilogue
+BIAS_BUF = 1024                              # (bias variants) ... and two buffers of the tile's 352 bias values, 16 bits each
 
 
 def configure(nt: int) -> None:
     """Everything that follows from NT = 16-column n tiles per wave (tile width 32 NT).  NT = 11 is the form described in the module
     docstring (256 x 352: C3 in exactly two rounds); NT = 9 / 7 (288 / 224 columns) serve shapes whose N the wider tile quantises
     badly (the C5 shard of 3584 columns = 16 x 224: two full rounds at M = 8192).  Numbers in comments below are NT = 11's."""
-    global NT, TILE_N, B_WAVECOL, STAGE, LDS_SA, LDS_SB, LDS_TOTAL, SLOTS, Z_SLOT, X_SLOT, PIECES_Z, PIECES_X, JZ
+    global NT, TILE_N, B_WAVECOL, STAGE, LDS_SA, LDS_SB, LDS_TOTAL, LDS_BIAS, SLOTS, Z_SLOT, X_SLOT, PIECES_Z, PIECES_X, JZ
     assert 5 <= nt <= 11 and nt % 2 == 1, "odd: the last n tile walks the m tiles upwards, which the A-fragment reload relies on"
     NT = nt
     TILE_N = 2 * 16 * NT                     # 352
@@ -52,6 +54,7 @@ def configure(nt: int) -> None:
     LDS_SA = 2 * STAGE                       # 155648: float sa[256] of scale buffer 0
     LDS_SB = LDS_SA + 1024                   # float sb[512] (352 used)
     LDS_TOTAL = LDS_SA + 2 * SCALE_BUF       # 161792 of 163840
+    LDS_BIAS = LDS_TOTAL                     # bias variants: two buffers of 512 16-bit values behind the scale buffers (163840 in all)
     SLOTS = MT * NT                          # 88 MFMAs per step and wave
     JZ = NT // 2                             # 5: barrier Z sits behind the fragment read of B tile JZ
     Z_SLOT = 8 * (JZ - 1) + 4                # 36: barriers in FRONT of this slot's MFMA
@@ -81,6 +84,7 @@ S_NRA, S_NRB = 57, 58                        # num_records of the operand descri
 S_DA, S_DB, S_DC = 60, 64, 68                # buffer descriptors s[60:63], s[64:67], s[68:71]
 S_NVALID = 72                                # n tiles of this wave that start below N
 S_PROBE = 74                                 # s[74:75]: debug buffer of the diagnostic build (kernarg offset 104; 0 = none)
+S_BIAS = 74                                  # ... in the bias variants (never diagnostic builds): the bias vector, same kernarg slot
 S_STAMP = 76                                 # s[76:76+4*NSTAMPS): (s_memtime, s_memrealtime) pairs of the diagnostic build
 NSTAMPS = 5
 S_END = S_STAMP + 4 * NSTAMPS                # 96 (s0..s101 exist)
@@ -102,6 +106,7 @@ V_FA = 32           # v32..v95: A fragments of the 8 m tiles (8 registers each)
 V_FB = 96           # v96..v119: three B fragment slots
 V_E = 120           # v120..v151: epilogue temporaries
 V_NSC = 152         # v152..154: the NEXT tile's sa / sb / sb + 256 values, loaded before the epilogue, parked in LDS after it
+V_NBIAS = 157       # v157..158 (bias variants): the NEXT tile's bias / bias + 256 values (16 bits each), parked the same way
 V_L3 = 155          # lane >> 3                       } per-lane constants of the LDS-DMA source offsets
 V_CH16 = 156        # swizzled source chunk * 16      }
 V_ACC = 160         # v160..v255: accumulator tiles 64..87
@@ -119,8 +124,14 @@ def acc_reg(i: int, j: int) -> str:
 
 class Gen:
     def __init__(self, name: str, out_fp16: bool = False, probe: bool = False, rows: bool = True, pk: bool = True, int8: bool = False, chains: int = 4, store_policy: str = "",
-                 fused_tail: bool = False):
+                 fused_tail: bool = False, bias: bool = False):
         self.name = name
+        # bias variant: out = cast(sb * (sa * acc)) + bias, the sum formed in fp32 from the two 16-bit values and rounded to the
+        # output dtype (conch/reference/quantization/scaled_gemm.py:24-25: `out + bias` on tensors of the output dtype) -- the
+        # same operations, element for element, as the HIP kernels' epilogue (gemm_mfma.hip)
+        self.bias = bias
+        assert not (bias and (probe or fused_tail))
+        self.lds_total = LDS_TOTAL + (2 * BIAS_BUF if bias else 0)
         self.probe = probe
         self.lines: list[str] = []
         self.lgkm: list[str] = []        # outstanding LDS reads, oldest first (tags)
@@ -391,8 +402,8 @@ class Gen:
         e(f"s_load_dwordx8 s[16:23], s[{S_KARG}:{S_KARG + 1}], 0x20")
         e(f"s_load_dwordx8 s[24:31], s[{S_KARG}:{S_KARG + 1}], 0x40")
         e(f"s_load_dwordx2 s[{S_ACCSCALE}:{S_ACCSCALE + 1}], s[{S_KARG}:{S_KARG + 1}], 0x60")
-        if self.probe:
-            e(f"s_load_dwordx2 s[{S_PROBE}:{S_PROBE + 1}], s[{S_KARG}:{S_KARG + 1}], 0x68")
+        if self.probe or self.bias:
+            e(f"s_load_dwordx2 s[{S_PROBE}:{S_PROBE + 1}], s[{S_KARG}:{S_KARG + 1}], 0x68", "debug buffer | bias vector")
         # gated launch (the e4m3fnuz fast path, gemm.hpp ScaledGemmArgs::gate): run only if (*gate != 0) == (run_if != 0)
         e(f"s_load_dwordx2 s[{T}:{T + 1}], s[{S_KARG}:{S_KARG + 1}], 0x70")
         e(f"s_load_dword s{T + 2}, s[{S_KARG}:{S_KARG + 1}], 0x78")
@@ -557,6 +568,14 @@ class Gen:
             e(f"v_and_b32 v{vt}, s{T + 2}, v{vt}")
             e(f"v_lshlrev_b32 v{vt}, 2, v{vt}")
             e(f"global_load_dword v{dst}, v{vt}, s[{S_SB}:{S_SB + 1}]")
+        if self.bias:
+            for k, dst in ((0, V_NBIAS), (256, V_NBIAS + 1)):
+                e(f"v_add_u32 v{vt}, s{bn0}, v{V_TID}")
+                if k:
+                    e(f"v_add_u32 v{vt}, {k}, v{vt}")
+                e(f"v_min_u32 v{vt}, s{T}, v{vt}", "columns past N: element N - 1 (never stored)")
+                e(f"v_lshlrev_b32 v{vt}, 1, v{vt}")
+                e(f"global_load_ushort v{dst}, v{vt}, s[{S_BIAS}:{S_BIAS + 1}]")
 
     def park_scales(self) -> None:
         """v[V_NSC..] (landed) -> the scale buffer at s[S_SCOFF]."""
@@ -569,6 +588,15 @@ class Gen:
         e(f"ds_write_b32 v{vt}, v{V_NSC}")
         e(f"ds_write_b32 v{vt}, v{V_NSC + 1} offset:{LDS_SB - LDS_SA}")
         e(f"ds_write_b32 v{vt}, v{V_NSC + 2} offset:{LDS_SB - LDS_SA + 1024}")
+        if self.bias:
+            T = S_T
+            e(f"s_lshr_b32 s{T}, s{S_SCOFF}, 11", "scale buffer 0 / 1 ...")
+            e(f"s_lshl_b32 s{T}, s{T}, {BIAS_BUF.bit_length() - 1}", "... -> bias buffer 0 / 1")
+            e(f"v_lshlrev_b32 v{vt}, 1, v{V_TID}")
+            e(f"v_add_u32 v{vt}, {LDS_BIAS}, v{vt}")
+            e(f"v_add_u32 v{vt}, s{T}, v{vt}")
+            e(f"ds_write_b16 v{vt}, v{V_NBIAS}")
+            e(f"ds_write_b16 v{vt}, v{V_NBIAS + 1} offset:512")
 
     def first_tile(self) -> None:
         e = self.e
@@ -629,6 +657,27 @@ class Gen:
             for q in range(SLOTS, SLOTS + 4):  # the last tiles' conversions and stores
                 self.tail_convert_rest(q)
 
+    @staticmethod
+    def bias_pair(j: int) -> int:
+        """First of the two registers holding n tile j's four bias values of this lane, packed as stored (epilogue_rows: the
+        free even-aligned pairs v112..119 and v136..151)."""
+        return 112 + 2 * j if j < 4 else 136 + 2 * (j - 4)
+
+    def bias_ops(self, x: int, b: int, mask: str) -> list[str]:
+        """v[x + 4 : x + 5] (four packed 16-bit outputs) += v[b : b + 1] (four packed 16-bit bias values), in the output dtype:
+        bf16 -- both sides widened to fp32 (a shift / a mask), v_pk_add_f32, RNE cast (what torch's bf16 add does); fp16 --
+        v_pk_add_f16 (the exact sum rounded once; equal to the fp32 route: a sum of two fp16 values that fp32 cannot hold exactly
+        is more than 2^13 ulps of the smaller operand away from any fp16 rounding boundary)."""
+        if self.out_fp16:
+            return [f"v_pk_add_f16 v{x + 4}, v{x + 4}, v{b}", f"v_pk_add_f16 v{x + 5}, v{x + 5}, v{b + 1}"]
+        return [f"v_lshlrev_b32 v{x}, 16, v{x + 4}", f"v_and_b32 v{x + 1}, {mask}, v{x + 4}",
+                f"v_lshlrev_b32 v{x + 2}, 16, v{x + 5}", f"v_and_b32 v{x + 3}, {mask}, v{x + 5}",
+                f"v_lshlrev_b32 v{x + 4}, 16, v{b}", f"v_and_b32 v{x + 5}, {mask}, v{b}",
+                f"v_pk_add_f32 v[{x}:{x + 1}], v[{x}:{x + 1}], v[{x + 4}:{x + 5}]",
+                f"v_lshlrev_b32 v{x + 4}, 16, v{b + 1}", f"v_and_b32 v{x + 5}, {mask}, v{b + 1}",
+                f"v_pk_add_f32 v[{x + 2}:{x + 3}], v[{x + 2}:{x + 3}], v[{x + 4}:{x + 5}]",
+                f"v_cvt_pk_bf16_f32 v{x + 4}, v{x}, v{x + 1}", f"v_cvt_pk_bf16_f32 v{x + 5}, v{x + 2}, v{x + 3}"]
+
     def convert_ops(self, i: int, j: int, sa: int, sb: int, x: int) -> list[str]:
         """Instructions that turn accumulator tile (i, j) into two registers v[x + 4 : x + 5] of packed 16-bit outputs:
         cast(sb * (sa * acc)), both products rounded to fp32 (conch/reference/quantization/scaled_gemm.py:21-23).  `sa` = first of
@@ -662,6 +711,8 @@ class Gen:
         else:
             ops.append(f"v_cvt_pk_bf16_f32 v{x + 4}, v{x}, v{x + 1}")
             ops.append(f"v_cvt_pk_bf16_f32 v{x + 5}, v{x + 2}, v{x + 3}")
+        if self.bias:
+            ops += self.bias_ops(x, self.bias_pair(j), f"s{S_T + 7}")
         return ops
 
     @staticmethod
@@ -712,6 +763,19 @@ class Gen:
         e(f"v_add_u32 v{xa + 1}, s{S_SCOFF}, v{xa + 1}")
         for j in range(NT):
             e(f"ds_read_b128 v[{sb + 4 * j}:{sb + 4 * j + 3}], v{xa + 1} offset:{64 * j}")
+        if self.bias:
+            # the 4 bias values of this lane's columns in every n tile, packed as stored: 8 bytes at 2 (16 NT wc + 16 j + 4 g)
+            e(f"s_mul_i32 s{T}, s{S_WC}, {32 * NT}")
+            e(f"s_lshr_b32 s{T + 1}, s{S_SCOFF}, 11")
+            e(f"s_lshl_b32 s{T + 1}, s{T + 1}, {BIAS_BUF.bit_length() - 1}", "this tile's bias buffer")
+            e(f"s_add_u32 s{T}, s{T}, s{T + 1}")
+            e(f"v_lshlrev_b32 v{xa + 2}, 3, v{vg}")
+            e(f"v_add_u32 v{xa + 2}, s{T}, v{xa + 2}")
+            e(f"v_add_u32 v{xa + 2}, {LDS_BIAS}, v{xa + 2}")
+            for j in range(NT):
+                b = self.bias_pair(j)
+                e(f"ds_read_b64 v[{b}:{b + 1}], v{xa + 2} offset:{32 * j}")
+            e(f"s_mov_b32 s{T + 7}, 0xffff0000", "high half of a packed pair of bf16")
         # this lane's write address inside the wave's region: row c, byte 8 g
         e(f"s_mul_i32 s{T + 1}, s{S_WAVE}, {REGION}")
         e(f"s_add_u32 s{T + 1}, s{T + 1}, {STAGE}", "the wave's staging region (stage 1)")
@@ -891,6 +955,16 @@ class Gen:
         e(f"v_add_u32 v{V_E + 2}, {LDS_SB}, v{V_E + 2}", "sb address")
         e(f"v_add_u32 v{V_E + 2}, s{S_SCOFF}, v{V_E + 2}")
         sbreg = V_FA + 16        # 4 registers per n tile, double buffered
+        bsreg = V_FA + 20        # (bias variants) the n tile's four packed bias values: 2 registers
+        if self.bias:
+            e(f"s_mul_i32 s{T + 3}, s{S_WC}, {32 * NT}")
+            e(f"s_lshr_b32 s{T + 4}, s{S_SCOFF}, 11")
+            e(f"s_lshl_b32 s{T + 4}, s{T + 4}, {BIAS_BUF.bit_length() - 1}")
+            e(f"s_add_u32 s{T + 3}, s{T + 3}, s{T + 4}")
+            e(f"v_lshlrev_b32 v{V_E + 3}, 3, v{vg}")
+            e(f"v_add_u32 v{V_E + 3}, s{T + 3}, v{V_E + 3}")
+            e(f"v_add_u32 v{V_E + 3}, {LDS_BIAS}, v{V_E + 3}", "bias address")
+            e(f"s_mov_b32 s{T + 7}, 0xffff0000")
         # n tiles of this wave that start below N (N is a multiple of 16: whole tiles)
         e(f"s_sub_u32 s{S_NVALID}, s{S_N}, s{T + 1}", "columns left of N from this wave's first one (may be <= 0)")
         e(f"s_cmp_gt_i32 s{S_NVALID}, 0")
@@ -900,6 +974,8 @@ class Gen:
             e(f"s_cmp_gt_u32 s{S_NVALID}, {j}")
             e(f"s_cbranch_scc0 {self.L('direct_done')}")
             e(f"ds_read_b128 v[{sbreg}:{sbreg + 3}], v{V_E + 2} offset:{64 * j}")
+            if self.bias:
+                e(f"ds_read_b64 v[{bsreg}:{bsreg + 1}], v{V_E + 3} offset:{32 * j}")
             e("s_waitcnt lgkmcnt(0)")
             for i in range(MT):
                 t = 8 * j + i
@@ -926,6 +1002,9 @@ class Gen:
                 else:
                     e(f"v_cvt_pk_bf16_f32 v{x + 4}, v{x}, v{x + 1}")
                     e(f"v_cvt_pk_bf16_f32 v{x + 5}, v{x + 2}, v{x + 3}")
+                if self.bias:
+                    for op in self.bias_ops(x, bsreg, f"s{T + 7}"):
+                        e(op)
                 e(f"buffer_store_dwordx2 v[{x + 4}:{x + 5}], v{rowoff + i}, s[{S_DC}:{S_DC + 3}], 0 offen offset:{32 * j}")
                 e("s_nop 1")
         self.label(self.L("direct_done"))
@@ -981,7 +1060,7 @@ class Gen:
         self.setup_once()
         self.first_tile()
         # steady-state queue of outstanding fragment reads: generate a pair once to learn what it leaves behind
-        scratch = Gen(self.name, self.out_fp16, int8=self.int8)  # (only its final queue state is used)
+        scratch = Gen(self.name, self.out_fp16, int8=self.int8)  # (only its final queue state is used: no bias, no probe)
         scratch.step(0, "t0", "t1")
         scratch.step(1, "t1", "t0")
         steady = list(scratch.lgkm)
@@ -1013,7 +1092,7 @@ class Gen:
 \t.rodata
 \t.p2align\t6, 0x0
 \t.amdhsa_kernel {name}
-\t\t.amdhsa_group_segment_fixed_size {LDS_TOTAL}
+\t\t.amdhsa_group_segment_fixed_size {self.lds_total}
 \t\t.amdhsa_private_segment_fixed_size 0
 \t\t.amdhsa_kernarg_size 128
 \t\t.amdhsa_user_sgpr_count 2
@@ -1106,6 +1185,8 @@ def main() -> None:
         sfx = "" if nt == 11 else f"_n{nt}"
         variants += [(f"conch_gemm1w_fp8_bf16{sfx}", nt, False, False, True, False), (f"conch_gemm1w_fp8_f16{sfx}", nt, True, False, True, False),
                      (f"conch_gemm1w_i8_bf16{sfx}", nt, False, False, True, True), (f"conch_gemm1w_i8_f16{sfx}", nt, True, False, True, True)]
+        # ... and each with the bias add in its epilogue (name + "_bias"; the kernarg slot of the diagnostic buffer holds the vector)
+        variants += [(name + "_bias", nt_, f16_, probe_, pk_, i8_) for name, nt_, f16_, probe_, pk_, i8_ in variants[-4:]]
     variants += [("conch_gemm1w_fp8_bf16_probe", 11, False, True, True, False), ("conch_gemm1w_fp8_bf16_alt", 11, False, False, False, False),
                  ("conch_gemm1w_fp8_bf16_alt_probe", 11, False, True, False, False), ("conch_gemm1w_i8_bf16_probe", 11, False, True, True, True)]
     for name, nt, fp16, probe, pk, int8 in variants:
@@ -1114,12 +1195,13 @@ def main() -> None:
         # CONCH_GEN_EXPERIMENT=fused_tail at build time makes it the fused-tail TIMING experiment instead (WRONG results: never
         # in a library that ships; profiles/r05/asm1w_fused_tail_timing.txt)
         fused = (not pk) and os.environ.get("CONCH_GEN_EXPERIMENT") == "fused_tail"
-        g = Gen(name, out_fp16=fp16, probe=probe, pk=True, int8=int8, store_policy="" if pk or fused else " nt", fused_tail=fused)
+        g = Gen(name, out_fp16=fp16, probe=probe, pk=True, int8=int8, store_policy="" if pk or fused else " nt", fused_tail=fused,
+                bias=name.endswith("_bias"))
         body = g.build()
         if text:
             body = body.split("\n", 2)[2]  # one target / code-object-version header per file
         text += body
-        names.append((name, LDS_TOTAL))
+        names.append((name, g.lds_total))
     text += Gen.metadata(names)
     with open(out, "w") as f:
         f.write(text)

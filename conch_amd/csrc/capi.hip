@@ -202,7 +202,7 @@ ScaledPick pick_scaled_fast(const ScaledGemmArgs& p, int variant) {
   if (variant == 7) {
     if (!scaled_gemm_asm1w_supported(p)) {
       set_error("scaled_gemm: variant 7 (one-wave-per-SIMD assembly kernel) forced but its contract is not met (e4m3fn or int8, K %% 256 == 0, K >= 512, "
-                "N %% 16 == 0, bf16 / fp16 row-major C, no bias, arrays below 2 GiB)");
+                "N %% 16 == 0, bf16 / fp16 row-major C, arrays below 2 GiB)");
       return kScaledPickError;
     }
     return kScaledPickAsm;

@@ -99,7 +99,8 @@ struct Gemm1wArgs {
   uint32_t tiles_m, tiles_n, nwg, magic_pg, grid, magic_last, sa_vec, sb_vec;
   float acc_scale;
   uint32_t out_dtype;
-  unsigned long long* probe;  // diagnostic kernel only: [tile][5][2] 64-bit stamps (s_memtime, s_memrealtime); else ignored
+  unsigned long long* probe;  // diagnostic kernels: [tile][5][2] 64-bit stamps (s_memtime, s_memrealtime); *_bias kernels: the bias
+                              // vector (N values of the output dtype); else ignored
   const int* gate;            // NULL, or: run only if (*gate != 0) == (gate_run_if != 0)  (ScaledGemmArgs::gate)
   uint32_t gate_run_if;
   uint32_t pad;
@@ -112,7 +113,7 @@ constexpr int kWidths[3] = {11, 9, 7};  // n tiles of 16 columns per wave: tile 
 
 struct Gemm1wModule {
   hipModule_t mod = nullptr;
-  hipFunction_t fn[3][2][2] = {};  // [width index][int8][f16 output]
+  hipFunction_t fn[3][2][2][2] = {};  // [width index][int8][f16 output][bias in the epilogue]
   hipFunction_t bf16_probe = nullptr, bf16_alt = nullptr, bf16_alt_probe = nullptr, i8_probe = nullptr;
   int rc = CONCH_OK;
 };
@@ -125,11 +126,13 @@ Gemm1wModule* gemm1w_module() {
     hipError_t e = hipModuleLoadData(&m.mod, kGemm1wCodeObject);
     for (int w = 0; w < 3 && e == hipSuccess; ++w)
       for (int i8 = 0; i8 < 2 && e == hipSuccess; ++i8)
-        for (int f16 = 0; f16 < 2 && e == hipSuccess; ++f16) {
-          char name[64];
-          snprintf(name, sizeof(name), "conch_gemm1w_%s_%s%s", i8 ? "i8" : "fp8", f16 ? "f16" : "bf16", w == 0 ? "" : w == 1 ? "_n9" : "_n7");
-          e = hipModuleGetFunction(&m.fn[w][i8][f16], m.mod, name);
-        }
+        for (int f16 = 0; f16 < 2 && e == hipSuccess; ++f16)
+          for (int bias = 0; bias < 2 && e == hipSuccess; ++bias) {
+            char name[64];
+            snprintf(name, sizeof(name), "conch_gemm1w_%s_%s%s%s", i8 ? "i8" : "fp8", f16 ? "f16" : "bf16", w == 0 ? "" : w == 1 ? "_n9" : "_n7",
+                     bias ? "_bias" : "");
+            e = hipModuleGetFunction(&m.fn[w][i8][f16][bias], m.mod, name);
+          }
     if (e == hipSuccess) e = hipModuleGetFunction(&m.bf16_probe, m.mod, "conch_gemm1w_fp8_bf16_probe");
     if (e == hipSuccess) e = hipModuleGetFunction(&m.bf16_alt, m.mod, "conch_gemm1w_fp8_bf16_alt");
     if (e == hipSuccess) e = hipModuleGetFunction(&m.bf16_alt_probe, m.mod, "conch_gemm1w_fp8_bf16_alt_probe");
@@ -185,13 +188,15 @@ extern "C" int conch_debug_gemm1w_alt(int on) {
 namespace conch {
 
 // Contract on top of scaled_gemm_mfma_supported (K-contiguous A and B^T, 16-byte aligned rows): OCP fp8, K a multiple of 256 bytes
-// and >= 512, N a multiple of 16, unit-stride C rows of bf16 / fp16, no bias, no fused gate/up form, one destination, every
+// and >= 512, N a multiple of 16, unit-stride C rows of bf16 / fp16 (a bias vector of that dtype is added in the epilogue by the
+// *_bias kernels), no fused gate/up form, one destination, every
 // array below 2 GiB (32-bit buffer offsets with the sign bit kept for "row out of range"), at most 65535 tiles.
 bool scaled_gemm_asm1w_supported(const ScaledGemmArgs& p) {
   if (!scaled_gemm_mfma_supported(p)) return false;
   if (p.in_dtype != CONCH_DT_FP8_E4M3FN && p.in_dtype != CONCH_DT_INT8) return false;
   if (p.out_dtype != CONCH_DT_BF16 && p.out_dtype != CONCH_DT_FP16) return false;
-  if (p.bias || p.fuse_silu || p.n_more || p.split_steps || p.a_src_dtype) return false;
+  if (p.fuse_silu || p.n_more || p.split_steps || p.a_src_dtype) return false;
+  if (p.bias && (((uintptr_t)p.bias) & 1)) return false;
   if (p.k < 512 || p.k % 256 || p.n % 16 || p.c_stride_n != 1 || (((uintptr_t)p.c) & 15)) return false;
   if (!p.scale_a || !p.scale_b) return false;
   const int64_t lim = (int64_t)1 << 31;
@@ -325,12 +330,13 @@ int launch_scaled_gemm_asm1w(const ScaledGemmArgs& p, hipStream_t stream) {
   void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
   a.probe = p.out_dtype == CONCH_DT_BF16 ? g_gemm1w_probe.load() : nullptr;
   const bool fp8 = p.in_dtype == CONCH_DT_FP8_E4M3FN;
-  const bool diag_ok = p.out_dtype == CONCH_DT_BF16 && nt == 11;  // the stamped twins (fp8, int8) and the A/B twin (fp8) exist for that form only
+  const bool diag_ok = p.out_dtype == CONCH_DT_BF16 && nt == 11 && !p.bias;  // the stamped twins (fp8, int8) and the A/B twin (fp8) exist for that form only
   const bool alt = g_gemm1w_alt.load() != 0 && diag_ok && fp8;
   if (!diag_ok) a.probe = nullptr;
   const int wi = nt == 11 ? 0 : nt == 9 ? 1 : 2;
   const hipFunction_t f = a.probe ? (!fp8 ? mod.i8_probe : alt ? mod.bf16_alt_probe : mod.bf16_probe)
-                                  : alt ? mod.bf16_alt : mod.fn[wi][fp8 ? 0 : 1][p.out_dtype == CONCH_DT_BF16 ? 0 : 1];
+                                  : alt ? mod.bf16_alt : mod.fn[wi][fp8 ? 0 : 1][p.out_dtype == CONCH_DT_BF16 ? 0 : 1][p.bias ? 1 : 0];
+  if (p.bias) a.probe = (unsigned long long*)p.bias;  // the *_bias kernels read their vector from the diagnostic buffer's slot
   CONCH_HIP(hipModuleLaunchKernel(f, a.grid, 1, 1, 256, 1, 1, 0, stream, nullptr, extra));
   return CONCH_OK;
 }

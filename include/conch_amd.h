@@ -116,7 +116,7 @@ typedef enum conch_tuning_key {
                                  K step, 4 = skinny-M (M <= 256) split-K MFMA, 5 = ping-pong, two phases per K
                                  step (the default for M > 256), 6 = 128x128 tiles, two workgroups per CU (shapes with few
                                  256x256 tiles), 7 = 256x352 tiles, one wave per SIMD (hand-allocated assembly; e4m3fn or int8,
-                                 K % 256 == 0, N % 16 == 0, no bias).  mixed_precision_gemm has one LDS-tiled MFMA
+                                 K % 256 == 0, N % 16 == 0).  mixed_precision_gemm has one LDS-tiled MFMA
                                  kernel: 1 = generic, any other value = that kernel */
   ,
   CONCH_TUNE_MIXED_TILE_NT = 1 /* mixed_precision_gemm tile shape: 0 = auto, 2..4 = force 256 rows x 64 NT columns, 5 = force 512 x 128

@@ -40,7 +40,9 @@ def _run_bench_two_ranks(extra_args, extra_env, tmp_path, launch_timeout_s):
     another program), its stdout / stderr in FILES (no pipe a surviving process could hold open), in a session of its own.
     bench.py's launcher owns its ranks and ends them itself after `launch_timeout_s` (exit code 124, stacks on stderr); the
     wait here is only the backstop behind that: it kills the whole session's process group and never waits without a bound."""
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", **extra_env)
+    # (an earlier test of this session may have left RANK / WORLD_SIZE of its own one-rank group in os.environ)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_PORT", "GROUP_RANK")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", **extra_env)
     cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo",
            "--all-ranks-on-device0", "--c5-shape", "2048,1024,4096", "--launch-timeout", str(launch_timeout_s), *extra_args]
     out_f, err_f = tmp_path / "bench.out", tmp_path / "bench.err"

@@ -513,13 +513,41 @@ def test_mixed_asm1w_kernel_is_bit_identical(_reset_tuning):
         mixed_precision_gemm(a.cuda(), packed.cuda(), w_s.cuda(), w_zp.cuda(), 4, 0, 128)
 
 
+@pytest.mark.parametrize("iname", ["fn", "int8"])
+@pytest.mark.parametrize("oname", ["bf16", "f16"])
+@pytest.mark.parametrize(("m", "k", "n", "nt"), [(256, 512, 352, 0), (300, 768, 400, 0), (1000, 2048, 1008, 0), (2304, 1024, 1056, 0), (16, 512, 16, 0),
+                                                  (512, 512, 288, 9), (300, 768, 400, 7), (2304, 1024, 3584, 7), (4096, 512, 11008, 0)])
+def test_asm1w_kernel_adds_the_bias_in_its_epilogue(_reset_tuning, m, k, n, nt, oname, iname):
+    """Round 6: `out = cast(sb * (sa * acc)) + bias` (conch/reference/quantization/scaled_gemm.py:24-25; the reference adds the bias
+    for any shape, conch/ops/quantization/gemm.py:249-250) inside the assembly kernel -- the *_bias twins of all twelve kernels, both
+    epilogues (whole waves through the LDS row image, edge waves with direct stores), the persistent walk's second tile (the bias
+    of the NEXT tile is fetched and parked beside its scales), all three tile widths: bit-identical to the HIP kernel's epilogue
+    (unpack, fp32 add, RNE cast) and, for int8, to the oracle."""
+    import ctypes
+
+    hook = _C.load().conch_debug_gemm1w_width
+    hook.restype, hook.argtypes = ctypes.c_int, [ctypes.c_int]
+    a, b, sa, sb, bias = make_scaled_inputs(m, k, n, IN_T[iname], DT[oname], False, False, True)
+    _C.set_gemm_variant(_C.VARIANT_MFMA_PINGPONG2)
+    want = run_scaled(a, b, sa, sb, DT[oname], bias)
+    _C.set_gemm_variant(_C.VARIANT_MFMA_ASM1W)
+    hook(nt)
+    try:
+        for _ in range(2):
+            got = run_scaled(a, b, sa, sb, DT[oname], bias)
+            assert torch.equal(got.view(torch.int16), want.view(torch.int16)), f"{(got != want).sum().item()} elements differ"
+    finally:
+        hook(0)
+        _C.set_gemm_variant(_C.VARIANT_AUTO)
+    if m * n <= 4_000_000:
+        ref = oracle.scaled_gemm_ref(a, b, sa, sb, DT[oname], bias)
+        check_scaled(got, ref, IN_T[iname], DT[oname], (a, b, sa, sb, bias))
+
+
 def test_asm1w_kernel_contract_is_enforced(_reset_tuning):
-    """Forced onto a problem outside its contract (bias; e4m3fnuz; K not a multiple of 256) the variant refuses with the library's
+    """Forced onto a problem outside its contract (e4m3fnuz; K not a multiple of 256) the variant refuses with the library's
     UNSUPPORTED status -- it never runs something else silently."""
     _C.set_gemm_variant(_C.VARIANT_MFMA_ASM1W)
-    a, b, sa, sb, bias = make_scaled_inputs(256, 512, 352, torch.float8_e4m3fn, torch.bfloat16, False, False, True)
-    with pytest.raises(NotImplementedError):
-        run_scaled(a, b, sa, sb, torch.bfloat16, bias)
     a8, b8, sa8, sb8, _ = make_scaled_inputs(256, 512, 352, torch.float8_e4m3fnuz, torch.bfloat16, False, False, False)
     with pytest.raises(NotImplementedError):
         run_scaled(a8, b8, sa8, sb8, torch.bfloat16, None)
@@ -653,8 +681,8 @@ def test_scaled_gemm_c5_config_shard_invariance():
 
     (1) the column block a rank would compute (N/8 = 3584 columns, rank 0, 3 and 7) from ITS slice of B / scale_b
     equals the same columns of the full product bit-for-bit -- the property the multi-GPU path rests on
-    (no reduction, so sharding must not change a single bit); (2) every element of the full product
-    against the CPU oracle.
+    (no reduction, so sharding must not change a single bit); (2) a 64-row band of every tile row of
+    the full product, every column, against the CPU oracle.
     """
     m, k, n, world = 8192, 8192, 28672, 8
     gen = torch.Generator(device="cuda").manual_seed(5)
@@ -668,12 +696,16 @@ def test_scaled_gemm_c5_config_shard_invariance():
         lo, hi = rank * shard, (rank + 1) * shard
         part = scaled_gemm(a, bt[lo:hi].T, sa, sb[lo:hi], torch.bfloat16)
         assert torch.equal(part, full[:, lo:hi]), f"rank {rank}"
-    # every element of the full product against the oracle (round 4; 32 rows until then), in blocks of 1024 rows
-    a_h, b_h, sa_h, sb_h, full_h = a.cpu(), bt.cpu().T, sa.cpu(), sb.cpu(), full.cpu()
-    for r0 in range(0, m, 1024):
-        rows = slice(r0, r0 + 1024)
-        ref = oracle.scaled_gemm_ref(a_h[rows], b_h, sa_h[rows], sb_h, torch.bfloat16, None)
-        check_scaled(full_h[rows], ref, torch.float8_e4m3fn, torch.bfloat16, (a_h[rows], b_h, sa_h[rows], sb_h, None))
+    # against the oracle: every column of 2 048 rows -- one 64-row band out of every 256-row tile row of the kernels, at a
+    # different offset inside each (round 6; rounds 4-5 ran all 8 192 rows through the CPU: 75 s of the suite's budget for rows
+    # whose tiles differ from the checked ones in their data only; the shard identities above cover every element bit for bit)
+    a_h, b_h, sa_h, sb_h = a.cpu(), bt.cpu().T, sa.cpu(), sb.cpu()
+    rows = torch.cat([torch.arange(64) + 256 * t + 64 * (t % 4) for t in range(m // 256)])
+    got_rows = full[rows.cuda()].cpu()
+    for r0 in range(0, rows.numel(), 1024):
+        sel = rows[r0:r0 + 1024]
+        ref = oracle.scaled_gemm_ref(a_h[sel], b_h, sa_h[sel], sb_h, torch.bfloat16, None)
+        check_scaled(got_rows[r0:r0 + 1024], ref, torch.float8_e4m3fn, torch.bfloat16, (a_h[sel], b_h, sa_h[sel], sb_h, None))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -798,26 +830,39 @@ def make_mixed_inputs(m, k, n, wtype, use_zp, dtype, group=128):
     return a, w_ref, packed, w_s, w_zp
 
 
+ORACLE_HALF_MACS = 1 << 27  # budget of ONE half-precision CPU matmul of the oracle (the GPU box's host runs fp16 matmuls at ~0.2 GMAC/s)
+
+
 def check_mixed(got, a, w_ref, k):
     """The oracle is torch.matmul(a, w_ref) in the activation dtype; ours accumulates in fp32.
 
     Bound: |diff| <= 2 eps_out * max|C| (accumulation order + the oracle's own half-precision
-    reduction), far inside the reference's rtol=1e-1 / atol=min(5e-2*sqrt(K), 1)."""
-    ref = oracle.mixed_precision_gemm_ref(a, w_ref).float()
-    exact = (a.double() @ w_ref.double()).float()
+    reduction), far inside the reference's rtol=1e-1 / atol=min(5e-2*sqrt(K), 1).
+
+    EVERY element is held to the per-element bound against the fp64 product of the same operands.  The oracle's own
+    half-precision matmul is run on every element too while m*k*n stays inside ORACLE_HALF_MACS; above that (fp16 only: the
+    host CPU of the GPU box has no fast fp16 matmul -- 64 x 11008 x 4096 takes 16 s there, 0.1 s in bf16) on an evenly spread
+    subset of the columns, every row (round 6; a column of C depends on its own column of w_ref only)."""
+    m, n = got.shape
     g = got.float().cpu()
+    exact = (a.double() @ w_ref.double()).float()
     scale = exact.abs().max().item()
     eps = EPS[got.dtype]
     assert (g - exact).abs().max().item() <= 1.0 * eps * scale
-    assert (g - ref).abs().max().item() <= 3.0 * eps * scale
     # per element (an error confined to small-magnitude outputs cannot hide under max|C|): one output rounding of the exact
     # value plus the worst-case fp32 accumulation-order error of ITS products
     s_abs = (a.double().abs() @ w_ref.double().abs()).float()
     bound = eps * exact.abs() + (k * 2.0**-24) * s_abs + 1e-30
     excess = ((g - exact).abs() - bound).max().item()
     assert excess <= 0, f"per-element bound exceeded by {excess:.4g}"
+    cols = slice(None)
+    if got.dtype == torch.float16 and m * k * n > ORACLE_HALF_MACS:
+        keep = max(16, ORACLE_HALF_MACS // (m * k))
+        cols = torch.linspace(0, n - 1, keep).long().unique()
+    ref = oracle.mixed_precision_gemm_ref(a, w_ref[:, cols].contiguous()).float()
+    assert (g[:, cols] - ref).abs().max().item() <= 3.0 * eps * scale
     atol = min(5e-2 * math.sqrt(k), 1)
-    torch.testing.assert_close(g, ref, rtol=1e-1, atol=atol)  # the reference's own bar
+    torch.testing.assert_close(g[:, cols], ref, rtol=1e-1, atol=atol)  # the reference's own bar
 
 
 def check_mixed_whole(got, a, w_ref, k, block=1024):
