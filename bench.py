@@ -366,7 +366,7 @@ def nshard_c5(world: int, rank: int, device: torch.device, steps: int, warmup: i
         return bt[:cols], sb[:cols]
 
     bt_loc, sb_loc = shard(rank, n_loc)
-    op = NShardedScaledGemm(m, n, torch.bfloat16, device)
+    op = NShardedScaledGemm(m, n, torch.bfloat16, device, k=k, in_dtype=torch.float8_e4m3fn)
     c = op(a, bt_loc.T, sa, sb_loc)
     torch.cuda.synchronize()
     band = 256  # rows checked per foreign block; 64 of its columns
@@ -385,7 +385,7 @@ def nshard_c5(world: int, rank: int, device: torch.device, steps: int, warmup: i
         # opt-in (--c5-direct): the epilogue-writes-to-peers form (conch_scaled_gemm_multi; no collective on the data path).  Never
         # on by default: it has not met real xGMI links in any round, and a hang here would take the headline with it.
         try:
-            op_d = NShardedScaledGemm(m, n, torch.bfloat16, device, direct=True)
+            op_d = NShardedScaledGemm(m, n, torch.bfloat16, device, direct=True, k=k, in_dtype=torch.float8_e4m3fn)
             c_d = op_d(a, bt_loc.T, sa, sb_loc)
             torch.cuda.synchronize()
             same = bool(torch.equal(c_d, c))

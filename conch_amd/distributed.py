@@ -131,13 +131,22 @@ def direct_results(m: int, n: int, dtype: torch.dtype, device: torch.device, gro
         raise ValueError(f"direct mode: unknown scheme {scheme!r} (want auto, symmetric or ipc)")
     if scheme == "auto":
         world = dist.get_world_size(group)
+        # can THIS rank have symmetric memory?  The module must import AND its allocator must hand out a buffer here (a local
+        # allocation, no rendezvous: an allocator this ROCm build lacks shows up now, on every rank alike, not inside the
+        # collective constructor)
         try:
-            import torch.distributed._symmetric_memory  # noqa: F401
+            import torch.distributed._symmetric_memory as symm
 
+            symm.empty(16, dtype=torch.uint8, device=device)
             can = 1
-        except ImportError:
+        except Exception:  # noqa: BLE001 -- any refusal selects the IPC scheme on all ranks
             can = 0
-        mine = (device.index if device.index is not None else torch.cuda.current_device()) if device.type == "cuda" else -1
+        # which PHYSICAL device: per-rank HIP_VISIBLE_DEVICES makes every rank "cuda:0", so the index says nothing
+        mine = -1
+        if device.type == "cuda":
+            idx = device.index if device.index is not None else torch.cuda.current_device()
+            props = torch.cuda.get_device_properties(idx)
+            mine = str(getattr(props, "uuid", "")) or f"{getattr(props, 'pci_domain_id', 0)}:{getattr(props, 'pci_bus_id', idx)}:{getattr(props, 'pci_device_id', 0)}"
         seen = [None] * world
         dist.all_gather_object(seen, (can, os.uname().nodename, mine), group=group)
         shared_device = len({(host, idx) for _, host, idx in seen}) < world
@@ -152,17 +161,43 @@ def direct_results(m: int, n: int, dtype: torch.dtype, device: torch.device, gro
     return results, barrier, scheme
 
 
-def default_panels(m: int, n_local: int, tile: int = 256, cus: int | None = None, device=None) -> int:
-    """Row panels per call: as many as keep every panel's GEMM at >= ~0.85 of one full round of 256x256 tiles (a panel
-    below one round idles CUs; C5 on 8 GPUs: 32 x 14 tiles -> 2 panels of 224 tiles).  `cus` defaults to the device's count."""
+def planned_tile_columns(m: int, n_local: int, k: int, in_dtype: torch.dtype) -> int:
+    """Tile width (columns) of the kernel the library's dispatcher launches for an [m, k] x [k, n_local] scaled GEMM of
+    `in_dtype`: 352 / 288 / 224 on the one-wave-per-SIMD assembly kernel, 128 on the few-tile kernel, else 256 (the plan is a pure
+    function of the problem -- conch_debug_scaled_plan, no GPU needed; shapes outside the MFMA kernels' contract: 256)."""
+    import ctypes
+
+    from conch_amd import _C
+
+    code = {torch.float8_e4m3fn: 3, torch.int8: 4}.get(in_dtype)
+    if code is None or min(m, n_local, k) <= 0:
+        return 256
+    fn = _C.load().conch_debug_scaled_plan
+    fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_int64] * 3 + [ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    out = (ctypes.c_int * 2)()
+    if fn(m, n_local, k, code, out) != 0:
+        return 256
+    return {3: int(out[1]) or 352, 1: 128, 2: 0}.get(out[0], 256)  # (0: the split-K decode kernel has no output tiles to count)
+
+
+def default_panels(m: int, n_local: int, tile: int = 256, cus: int | None = None, device=None, k: int | None = None,
+                   in_dtype: torch.dtype | None = None) -> int:
+    """Row panels per call: as many as keep every panel's GEMM at >= ~0.85 of one full round of tiles (a panel below one round
+    idles CUs).  Tiles are `tile` rows high; their WIDTH is the one the dispatcher's kernel uses for a panel of that height when
+    `k` and `in_dtype` are given (C5 on 8 GPUs: the 3584-column shard runs 256 x 224 assembly tiles, 32 x 16 of them -> 2 panels
+    of one full round each), else 256 columns (the HIP tile kernel; round 5's rule).  `cus` defaults to the device's count."""
     if cus is None:
         cus = device_cus(device)
-    tiles_n = -(-n_local // tile)
     tiles_m = -(-m // tile)
     best = 1
     for p in range(2, 9):
         # a panel is a whole number of rows AND of tile rows: M = 1001 or 515 rows stay one panel
-        if m % p == 0 and (m // p) % tile == 0 and tiles_m % p == 0 and (tiles_m // p) * tiles_n >= 0.85 * cus:
+        if m % p or (m // p) % tile or tiles_m % p:
+            continue
+        width = planned_tile_columns(m // p, n_local, k, in_dtype) if k is not None and in_dtype is not None else 256
+        if width < 224:
+            continue  # a panel this small leaves the 256-row tile kernels (128 x 128 tiles, split K): not a full round of anything
+        if (tiles_m // p) * -(-n_local // width) >= 0.85 * cus:
             best = p
     return best
 
@@ -189,6 +224,8 @@ class NShardedScaledGemm:
         peer_results=None,
         gemm_multi_fn: Callable | None = None,
         scheme: str | None = None,
+        k: int | None = None,
+        in_dtype: torch.dtype | None = None,
     ) -> None:
         self.group = group
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -205,7 +242,8 @@ class NShardedScaledGemm:
         # row panels exist to overlap the gather of one panel with the GEMM of the next: with one rank there is no gather,
         # the heuristic is not consulted and an explicit `panels` only shapes gathered_panels()' view
         if panels is None:
-            panels = default_panels(m, self.n_local, device=self.device if self.device.type == "cuda" else None) if self.world_size > 1 else 1
+            # (`k`, `in_dtype`: optional hints -- with them the panel rule counts the tiles of the kernel that will run)
+            panels = default_panels(m, self.n_local, device=self.device if self.device.type == "cuda" else None, k=k, in_dtype=in_dtype) if self.world_size > 1 else 1
         self.panels = panels
         if self.panels < 1 or m % self.panels:
             raise ValueError(f"M={m} is not divisible into {self.panels} panels")

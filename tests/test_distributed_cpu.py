@@ -116,6 +116,19 @@ def test_default_panels_only_returns_divisors_of_m():
         for n_local in (64, 3584, 28672, 65536):
             p = default_panels(m, n_local)
             assert p >= 1 and m % p == 0
+    # with the problem's K and dtype the rule counts the tiles of the kernel the dispatcher will launch: the
+    # C5 shard of 3584 columns runs 256 x 224 assembly tiles -- 16 tile columns, not the 14 of the 256-wide model
+    from conch_amd.distributed import planned_tile_columns
+
+    assert planned_tile_columns(8192, 3584, 8192, torch.float8_e4m3fn) == 224
+    assert planned_tile_columns(4096, 11008, 4096, torch.float8_e4m3fn) == 352
+    assert planned_tile_columns(4096, 4096, 8192, torch.int8) == 256      # one full round of 256 x 256 HIP tiles
+    assert planned_tile_columns(4096, 4096, 8192, torch.float16) == 256   # not a scaled-GEMM input dtype: the default
+    assert default_panels(8192, 3584, cus=256, k=8192, in_dtype=torch.float8_e4m3fn) == 2   # two panels of 16 x 16 tiles = one full round each
+    assert default_panels(8192, 3584, cus=256) == 2
+    for m in (255, 4096, 8192, 12288):
+        p = default_panels(m, 3584, cus=256, k=4096, in_dtype=torch.float8_e4m3fn)
+        assert p >= 1 and m % p == 0
     # default arguments must construct for any M (one rank: no panels are used at all)
     for m, n in ((1001, 28672), (515, 65536), (7, 8)):
         op = NShardedScaledGemm(m, n, torch.bfloat16, torch.device("cpu"), gemm_fn=oracle.scaled_gemm_ref)

@@ -105,7 +105,7 @@ def test_a_stalled_rank_fails_once_with_stacks_and_no_orphan(tmp_path):
     """A rank that stops taking part after the rendezvous (CONCH_BENCH_STALL_RANK) must cost one bounded failure: bench.py's
     launcher returns 124 inside its launch timeout, the stacks of BOTH ranks are in its stderr (the stalled one inside
     stall_if_asked, its peer inside the collective it waits in), no JSON line, and neither rank process survives."""
-    rc, out, err, pids, took = _run_bench_two_ranks([], {"CONCH_BENCH_STALL_RANK": "1"}, tmp_path, launch_timeout_s=60)
+    rc, out, err, pids, took = _run_bench_two_ranks([], {"CONCH_BENCH_STALL_RANK": "1"}, tmp_path, launch_timeout_s=40)
     assert rc == 124, f"rc {rc} after {took:.0f} s\n" + err[-4000:]
     assert took < 200
     assert not [ln for ln in out.splitlines() if ln.startswith("{")]
