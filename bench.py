@@ -282,15 +282,37 @@ def cpu_baseline_mixed(a, w_ref, m: int, k: int, n: int) -> dict:
 
 
 def load_traffic(workload: str) -> tuple[float | None, str | None]:
-    """(HBM bytes per launch measured by rocprofv3 --pmc, where that number comes from), from profiles/traffic.json."""
+    """(HBM-side bytes per launch measured by rocprofv3 --pmc, where that number comes from), from profiles/traffic.json -- which
+    tools/write_traffic.py WRITES from the counter passes of tools/gpu_profile.sh.  An entry is used only if it was measured on
+    the kernel sources this run executes (`sources_sha256` over the files that define the workload's dominant kernel): anything
+    else is reported as null with the reason, not carried along."""
     f = ROOT / "profiles" / "traffic.json"
-    if f.exists():
-        try:
-            rec = json.loads(f.read_text()).get(workload, {})
-            return rec.get("hbm_bytes_per_launch"), rec.get("source")
-        except (ValueError, AttributeError):
+    if not f.exists():
+        return None, None
+    try:
+        rec = json.loads(f.read_text()).get(workload)
+        if not isinstance(rec, dict):
             return None, None
-    return None, None
+        want = rec.get("sources_sha256")
+        if not want:
+            return None, f"refused: the entry of {workload!r} carries no sources_sha256 (hand-maintained until round 5); re-run tools/gpu_profile.sh"
+        sys.path.insert(0, str(ROOT / "tools"))
+        from write_traffic import sources_sha256
+
+        have = sources_sha256(workload, ROOT)
+        if have != want:
+            return None, (f"refused: measured at commit {rec.get('commit')} on sources {want}, this run executes {have} "
+                          f"({', '.join(rec.get('sources', []))} changed since); re-run tools/gpu_profile.sh")
+        return rec.get("hbm_bytes_per_launch"), rec.get("source")
+    except Exception as exc:  # noqa: BLE001 -- a side figure
+        return None, f"unreadable: {exc!r}"
+
+
+def traffic_commit(workload: str) -> str | None:
+    try:
+        return json.loads((ROOT / "profiles" / "traffic.json").read_text()).get(workload, {}).get("commit")
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def device_sync(device: torch.device | None = None) -> None:
@@ -685,6 +707,7 @@ def measure_leg(leg: Leg, steps: int, warmup: int, world: int, sustained_s: floa
     roofline = {"bound": "hbm" if leg.hbm_bound else "mfma", "achieved": round(leg.rate(k_ms), 2), "peak": leg.roof_peak, "unit": leg.unit,
                 "frac": round(leg.rate(k_ms) / leg.roof_peak, 4)}
     roofline["traffic"], roofline["traffic_source"] = load_traffic(leg.workload)
+    roofline["traffic_commit"] = traffic_commit(leg.workload)
     roofline["kernel_avg_ms"] = round(k_ms, 5)
     roofline["sustained_seconds"] = round(sus["s"], 2)
     if burst is not None:

@@ -1,6 +1,9 @@
 #!/bin/bash
 # rocprofv3 passes for one bench workload (run on the GPU box through gpurun).
-# usage: tools/gpu_profile.sh <tag> [bench args...]   -> gpurun_out/prof_<tag>/
+# usage: [CONCH_COMMIT=<short id>] tools/gpu_profile.sh <tag> [bench args...]   -> gpurun_out/prof_<tag>/
+# With `--workload W` among the bench args the counter passes are turned into gpurun_out/prof_<tag>/traffic_entry.json
+# (tools/write_traffic.py entry); `python tools/write_traffic.py merge gpurun_out/prof_*/traffic_entry.json` in the build container
+# then writes profiles/traffic.json (the GPU box has no .git: the commit id travels in $CONCH_COMMIT).
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 TAG="$1"; shift
 OUT="$ROOT/gpurun_out/prof_$TAG"
@@ -17,6 +20,10 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_AC
 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_fetch" -- python3 "${BENCH[@]}" > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$OUT/pmc_write" -- python3 "${BENCH[@]}" > "$OUT/pmc_write.log" 2>&1
 python3 "$ROOT/tools/summarize_prof.py" "$OUT" > "$OUT/summary.txt" 2>&1
+WL=c3
+prev=""
+for arg in "$@"; do if [ "$prev" = "--workload" ]; then WL="$arg"; fi; prev="$arg"; done
+python3 "$ROOT/tools/write_traffic.py" entry "$WL" "$OUT" --commit "${CONCH_COMMIT:-unknown}" > "$OUT/traffic_entry.log" 2>&1
 # keep only the small summaries
 find "$OUT" -name "*_kernel_trace.csv" -delete
 find "$OUT" -name "*.csv" -size +1M -delete

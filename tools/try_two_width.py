@@ -72,6 +72,36 @@ def main() -> None:
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / iters * 1e3
 
+    def free_running(two: bool, iters: int) -> float:
+        """us per iteration when nothing joins the streams between iterations: each stream runs its launches back to back (the
+        sustained, power-limited regime of the benchmark; the per-iteration fork / join above leaves the chip idle for ~28 us of
+        every 134).  Two widths: the halves drift against each other freely; the time is that of the stream that ends last."""
+        main_s = torch.cuda.current_stream()
+        e0 = torch.cuda.Event(enable_timing=True)
+        ends = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+        e0.record(main_s)
+        s1.wait_stream(main_s)
+        s2.wait_stream(main_s)
+        if two:
+            lib.conch_debug_gemm1w_grid(128)
+            for _ in range(iters):
+                lib.conch_debug_gemm1w_width(11)
+                with torch.cuda.stream(s1):
+                    scaled_gemm_launcher(out2[:, :s], a, bt[:s].T, sa, sb[:s], md_l)
+                lib.conch_debug_gemm1w_width(7)
+                with torch.cuda.stream(s2):
+                    scaled_gemm_launcher(out2[:, s:], a, bt[s:].T, sa, sb[s:], md_r)
+        else:
+            lib.conch_debug_gemm1w_width(11)
+            lib.conch_debug_gemm1w_grid(0)
+            with torch.cuda.stream(s1):
+                for _ in range(iters):
+                    scaled_gemm_launcher(out1, a, bt.T, sa, sb, md_full)
+        ends[0].record(s1)
+        ends[1].record(s2)
+        torch.cuda.synchronize()
+        return max(e0.elapsed_time(ends[0]), e0.elapsed_time(ends[1])) / iters * 1e3, [round(e0.elapsed_time(e) / iters * 1e3, 2) for e in ends]
+
     try:
         one_launch()
         two_widths()
@@ -83,6 +113,12 @@ def main() -> None:
             t1 = timed(one_launch, args.iters)
             t2 = timed(two_widths, args.iters)
             print(f"round {r}: one launch (512 tiles of 256x352) {t1:7.2f} us   two widths at once (256 of 352 | 384 of 224, 128 workgroups each) {t2:7.2f} us")
+        for _ in range(2):
+            free_running(False, args.iters)
+        for r in range(args.rounds):
+            t1, _ = free_running(False, 2 * args.iters)
+            t2, per = free_running(True, 2 * args.iters)
+            print(f"free-running round {r}: one launch {t1:7.2f} us   two widths on two streams {t2:7.2f} us (352-wide stream {per[0]}, 224-wide stream {per[1]} us per launch)")
     finally:
         lib.conch_debug_gemm1w_width(0)
         lib.conch_debug_gemm1w_grid(0)
