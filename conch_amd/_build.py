@@ -41,7 +41,25 @@ def _stale(target: Path, deps: list[Path]) -> bool:
 
 
 PROBE_LIB = PKG / "libconch_amd_probe.so"
-LLVM_BIN = Path(os.environ.get("CONCH_LLVM_BIN", "/opt/rocm/lib/llvm/bin"))
+def _llvm_bin() -> Path:
+    """Directory of the ROCm LLVM tools that assemble and link the hand-written kernels (clang, ld.lld): $CONCH_LLVM_BIN, the usual
+    place under the ROCm root, else wherever hipcc's own clang lives (`hipcc --print-prog-name=clang`: hipcc is a clang driver)."""
+    env = os.environ.get("CONCH_LLVM_BIN")
+    if env:
+        return Path(env)
+    for root in (os.environ.get("ROCM_PATH"), "/opt/rocm"):
+        if root and (Path(root) / "lib" / "llvm" / "bin" / "clang").exists():
+            return Path(root) / "lib" / "llvm" / "bin"
+    try:
+        out = subprocess.run([HIPCC, "--print-prog-name=clang"], capture_output=True, text=True, check=True, timeout=60).stdout.strip()
+        if out and Path(out).exists():
+            return Path(out).resolve().parent
+    except (OSError, subprocess.SubprocessError):
+        pass
+    return Path("/opt/rocm/lib/llvm/bin")
+
+
+LLVM_BIN = _llvm_bin()
 ASM_GENERATORS = {"gemm1w": CSRC / "asm" / "gen_gemm1w.py", "mixed1w": CSRC / "asm" / "gen_mixed1w.py"}  # name -> script that writes NAME.s (hand-allocated gfx950 assembly)
 
 
