@@ -26,6 +26,9 @@ struct ScaledSkinny {
 };
 // one-wave-per-SIMD 256x352 tiles against 256x256 tiles: gemm_asm.hip keeps its own table (kAsm1wFit) beside the rule, fitted on
 // profiles/r05/asm1w_persistent.txt (tools/try_asm1w.py)
+// kAsm1wFit (csrc/gemm_asm.hip) and int8: int8 runs BOTH tilings ~12.5 % slower than fp8 (C3: assembly 119.0 against 105.8 us,
+// 256 x 256 tiles 133.4 against 118.8: profiles/r06/asm1w_bias_ab.txt; round 5: 124.4 / 139.8), so the ratio the rule compares is
+// the fp8 one and the table serves both dtypes; a bias adds ~1.4 us to the assembly kernel, inside the rule's margin.
 
 // ---- mixed_precision_gemm -----------------------------------------------------------------------------------------------------
 // decode-batch kernel against one row of tiles (capi.hip, mixed_decode_beats_tiles): profiles/r02/dispatch_cold_sweep_after.txt,
