@@ -73,3 +73,64 @@ def test_picked_kernel_names_the_assembly_kernel_for_c3():
     assert leg.picked_kernel().startswith("skinny_splitk_kernel")
     leg.kind, leg.m, leg.k, leg.n = "mixed_int4", 1024, 4096, 11008
     assert leg.picked_kernel().startswith("mixed_strip_kernel 256x192 tiles, 1 K slice")
+
+
+def test_traffic_entries_are_written_from_counter_passes_and_refused_when_stale(tmp_path, monkeypatch):
+    """profiles/traffic.json is written by tools/write_traffic.py from rocprofv3 --pmc CSVs (per-launch averages of the workload's
+    dominant kernel; FETCH_SIZE doubled, KiB) and bench.load_traffic uses an entry only while the kernel's sources hash to what was
+    measured (no hand-maintained numbers carried from round to round)."""
+    import csv
+    import json
+    import shutil
+
+    sys.path.insert(0, str(Path(bench.ROOT) / "tools"))
+    import write_traffic as wt
+
+    head = ["Correlation_Id", "Dispatch_Id", "Agent_Id", "Queue_Id", "Process_Id", "Thread_Id", "Grid_Size", "Kernel_Id", "Kernel_Name",
+            "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Counter_Name", "Counter_Value",
+            "Start_Timestamp", "End_Timestamp"]
+
+    def write(sub, rows):
+        d = tmp_path / "prof" / sub / "runc"
+        d.mkdir(parents=True)
+        with open(d / "1_counter_collection.csv", "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(head)
+            for disp, kernel, counter, value in rows:
+                w.writerow([disp, disp, "Agent 2", 1, 1, 1, 65536, 3, kernel, 256, 0, 0, 512, 0, 96, counter, value, 0, 1])
+
+    k = "conch_gemm1w_fp8_bf16"
+    write("pmc_fetch", [(1, k, "FETCH_SIZE", 100000.0), (2, k, "FETCH_SIZE", 110000.0), (3, "some_other_kernel", "FETCH_SIZE", 5.0)])
+    write("pmc_write", [(1, k, "WRITE_SIZE", 88000.0), (1, k, "TCC_HIT_sum", 900.0), (1, k, "TCC_MISS_sum", 100.0)])
+    rec = wt.entry("c3", tmp_path / "prof", "abc1234")
+    assert rec["fetch_kib"] == 105000.0 and rec["write_kib"] == 88000.0 and rec["tcc_hit_rate"] == 0.9
+    assert rec["hbm_bytes_per_launch"] == 1024 * (2 * 105000 + 88000) and rec["commit"] == "abc1234"
+    assert rec["sources_sha256"] == wt.sources_sha256("c3") and rec["algorithmic_bytes"] == 152103936
+
+    # bench.load_traffic against a repo copy whose table holds this entry: accepted; after the kernel source changes: refused
+    root = tmp_path / "repo"
+    (root / "profiles").mkdir(parents=True)
+    for rel in wt.WORKLOADS["c3"][2]:
+        (root / rel).parent.mkdir(parents=True, exist_ok=True)
+        shutil.copy(Path(bench.ROOT) / rel, root / rel)
+    (root / "profiles" / "traffic.json").write_text(json.dumps({"c3": rec, "c1": {"hbm_bytes_per_launch": 1}}))
+    monkeypatch.setattr(bench, "ROOT", root)
+    assert bench.load_traffic("c3")[0] == rec["hbm_bytes_per_launch"] and bench.traffic_commit("c3") == "abc1234"
+    value, why = bench.load_traffic("c1")
+    assert value is None and "sources_sha256" in why          # a hand-written entry (no hash) is refused
+    with open(root / wt.WORKLOADS["c3"][2][1], "a") as f:
+        f.write("\n// changed\n")
+    value, why = bench.load_traffic("c3")
+    assert value is None and why.startswith("refused") and "abc1234" in why
+    assert bench.load_traffic("c2") == (None, None)             # no entry at all
+
+
+def test_committed_traffic_table_matches_the_kernel_sources():
+    """Every entry of the committed profiles/traffic.json was measured on the kernel sources of this tree (else bench.py would
+    report traffic null on the driver's box): a kernel edit without a new counter pass fails HERE."""
+    import json
+
+    table = json.loads((Path(bench.ROOT) / "profiles" / "traffic.json").read_text())
+    for name in ("c1", "c2", "c3", "c4", "c4readme"):
+        value, why = bench.load_traffic(name)
+        assert value == table[name]["hbm_bytes_per_launch"], (name, why)
