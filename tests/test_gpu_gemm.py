@@ -2025,6 +2025,20 @@ def test_randomised_dispatch_cross_check():
     from pathlib import Path
 
     root = Path(__file__).resolve().parent.parent
-    r = subprocess.run([sys.executable, str(root / "tools" / "fuzz_dispatch.py"), "600", "3"], capture_output=True, text=True, timeout=900, cwd=root)
+    r = subprocess.run([sys.executable, str(root / "tools" / "fuzz_dispatch.py"), "600", "3"], capture_output=True, text=True, timeout=200, cwd=root)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert "600 cases, 0 mismatches" in r.stdout
+
+
+def test_randomised_assembly_kernel_cross_check():
+    """tools/fuzz_dispatch.py --asm: 150 random draws FORCED onto the one-wave-per-SIMD assembly kernel -- int8 / fp8, bf16 / fp16,
+    scalar / vector scales, with and without a bias (round 6's *_bias twins), the three tile widths, ragged M and N -- against the
+    generic device kernel: int8 bit for bit, fp8 within 2 eps of max|C|."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "tools" / "fuzz_dispatch.py"), "150", "11", "--asm"], capture_output=True, text=True, timeout=200, cwd=root)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "150 cases, 0 mismatches" in r.stdout

@@ -2,9 +2,12 @@
 
 scaled_gemm: int8 bit-for-bit, fp8 within 2 eps of max|C|; mixed_precision_gemm: 2 eps of max|C|.  Shapes are drawn so
 that every dispatcher branch (split-K 32/64/128 rows, 128x128 tiles, 256x256 tiles, repack, generic; decode-batch and tiled
-mixed kernels) is hit.  usage: python tools/fuzz_dispatch.py [cases] [seed] [--mixed-mid]
+mixed kernels) is hit.  usage: python tools/fuzz_dispatch.py [cases] [seed] [--mixed-mid | --asm]
 --mixed-mid: mixed_precision_gemm only, at batched-decode sizes on wide problems (the K-split strip forms of round 5).
+--asm: scaled_gemm only, FORCED onto the one-wave-per-SIMD assembly kernel (round 6: with and without a bias -- the *_bias twins --,
+       all three tile widths, both input and output dtypes, scalar and vector scales, ragged M and N inside its contract).
 """
+import ctypes
 import random
 import sys
 from pathlib import Path
@@ -16,6 +19,9 @@ from conch_amd import _C  # noqa: E402
 from conch_amd.ops.quantization.gemm import mixed_precision_gemm, scaled_gemm  # noqa: E402
 
 MIXED_MID = "--mixed-mid" in sys.argv
+ASM = "--asm" in sys.argv
+_width_hook = _C.load().conch_debug_gemm1w_width
+_width_hook.restype, _width_hook.argtypes = ctypes.c_int, [ctypes.c_int]
 sys.argv = [a for a in sys.argv if not a.startswith("--")]
 CASES = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 random.seed(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
@@ -30,7 +36,11 @@ for case in range(CASES):
     if MIXED_MID:
         m = random.choice([33, 40, 48, 64, 65, 96, 100, 128, 129, 192, 200, 256])
         n = random.choice([1376, 2048, 4096, 4100, 5120, 8192, 11008, 13824])
-    if not MIXED_MID and random.random() < 0.6:
+    if ASM:
+        m = random.choice([16, 128, 256, 257, 300, 512, 1000, 1024, 2304])
+        k = random.choice([512, 768, 1024, 2048])
+        n = random.choice([16, 176, 352, 368, 400, 1008, 1056, 2816, 3584])
+    if ASM or (not MIXED_MID and random.random() < 0.6):
         in_dt = random.choice([torch.int8, torch.float8_e4m3fn])
         if in_dt == torch.int8:
             a = torch.randint(-32, 32, (m, k), dtype=torch.int8, device="cuda")
@@ -41,7 +51,15 @@ for case in range(CASES):
         sa = 0.01 * torch.rand((m, 1), device="cuda") if random.random() < 0.7 else torch.tensor([[0.01]], device="cuda")
         sb = 0.01 * torch.rand((n, 1), device="cuda") if random.random() < 0.7 else torch.tensor([[0.02]], device="cuda")
         bias = torch.rand((n,), device="cuda").to(out_dt) if random.random() < 0.5 else None
-        got = scaled_gemm(a, bt.T, sa, sb, out_dt, bias)
+        if ASM:
+            width = random.choice([0, 0, 9, 7])
+            _C.set_gemm_variant(_C.VARIANT_MFMA_ASM1W)
+            _width_hook(width)
+        try:
+            got = scaled_gemm(a, bt.T, sa, sb, out_dt, bias)
+        finally:
+            if ASM:
+                _width_hook(0)
         _C.set_gemm_variant(_C.VARIANT_GENERIC)
         ref = scaled_gemm(a, bt.T, sa, sb, out_dt, bias)
         _C.set_gemm_variant(_C.VARIANT_AUTO)
@@ -49,7 +67,7 @@ for case in range(CASES):
             ok = torch.equal(got, ref)
         else:
             ok = (got.float() - ref.float()).abs().max().item() <= 2 * EPS[out_dt] * max(ref.float().abs().max().item(), 1e-6)
-        what = f"scaled {in_dt} {m}x{k}x{n} -> {out_dt} bias={bias is not None}"
+        what = f"scaled {in_dt} {m}x{k}x{n} -> {out_dt} bias={bias is not None}" + (f" assembly kernel, width hook {width}" if ASM else "")
     else:
         bits = random.choice([4, 8])
         k = max(k // 128 * 128, 128)
