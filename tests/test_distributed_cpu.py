@@ -76,6 +76,12 @@ def test_nsharded_gemm_world2_gloo(in_dtype_name):
     mp.spawn(_worker, args=(2, _free_port(), in_dtype_name), nprocs=2, join=True)
 
 
+def test_nsharded_gemm_world4_gloo():
+    """Four ranks (24 columns each): the same sharding arithmetic, collective and block -> row-major unpack as the two-rank test,
+    with more than one FOREIGN block on either side of a rank's own (ranks 1 and 2) -- the layout the 4- and 8-GPU runs use."""
+    mp.spawn(_worker, args=(4, _free_port(), "int8"), nprocs=4, join=True)
+
+
 def test_shard_bounds():
     assert shard_bounds(11008, 8, 3) == (4128, 5504)
     assert shard_bounds(28672, 8, 7) == (25088, 28672)
