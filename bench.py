@@ -29,6 +29,8 @@ synthetic inputs that are already resident in HBM, built with the reference benc
              passes; `traffic_source` names the profile and the commit it was taken at), or null.
   cpu_baseline  the CPU oracle (oracle.scaled_gemm_ref: the reference's PyTorch-only path restated)
              timed on this host on the same workload, rank 0, N=1 only.
+  fnuz       (N = 1, workload c3) e4m3fnuz operands at the C3 size and at 16 rows, clean and saturated (+-240 in every row / column):
+             op-level ms per call, each form checked against the oracle first.  --no-side-legs leaves it out.
   c1 c2 c4 c4readme   (N = 1, workload c3) the other BASELINE configs and the reference README's mixed-GEMM shape, each
              measured the same way in the same run: op-level `ms_per_step` / `value` after sustained load, `roofline`
              (kernel events, sustained), `cpu_baseline` (bounded sample).  --no-side-legs leaves them out.
@@ -751,6 +753,46 @@ def measure_leg(leg: Leg, steps: int, warmup: int, world: int, sustained_s: floa
     return res
 
 
+def fnuz_side_legs(device: torch.device) -> dict:
+    """e4m3fnuz operands -- the dtype the reference hands AMD users (conch/ops/quantization/fp8.py:54) -- at the C3 size and at a
+    decode size, op-level (torch events around 30 calls after 10): `clean` = no code that OCP e4m3 cannot hold (scan + the fp8
+    kernel on the raw bytes), `saturated` = every row of A and every column of B holds one +-240 (0x7F / 0xFF: what a clamping
+    absmax quantiser emits; the exact bf16 expansion serves it).  Each form is checked on 64 rows against the oracle
+    with the tests' per-element bound before it is timed."""
+    import oracle
+
+    out: dict = {}
+    for name, (m, k, n) in (("c3_size", (4096, 4096, 11008)), ("decode_16_rows", (16, 4096, 11008))):
+        torch.manual_seed(0)
+        a = (0.25 * torch.rand((m, k), dtype=torch.float32, device=device)).to(torch.float8_e4m3fnuz)
+        bt = (0.25 * torch.rand((n, k), dtype=torch.float32, device=device)).to(torch.float8_e4m3fnuz)
+        sa = 0.25 * torch.rand((m, 1), dtype=torch.float32, device=device)
+        sb = 0.25 * torch.rand((n, 1), dtype=torch.float32, device=device)
+        a_sat, bt_sat = a.clone(), bt.clone()
+        ra, rb = torch.arange(m, device=device), torch.arange(n, device=device)
+        a_sat.view(torch.uint8)[ra, (ra * 37) % k] = torch.where(ra % 2 == 0, 0x7F, 0xFF).to(torch.uint8)
+        bt_sat.view(torch.uint8)[rb, (rb * 53) % k] = torch.where(rb % 3 == 0, 0xFF, 0x7F).to(torch.uint8)
+        rows = torch.linspace(0, m - 1, min(m, 64)).long().unique()
+        leg: dict = {"workload": f"scaled_gemm e4m3fnuz x e4m3fnuz -> bf16, M={m} K={k} N={n}"}
+        for form, (aa, bb) in (("clean", (a, bt)), ("saturated", (a_sat, bt_sat))):
+            got = scaled_gemm(aa, bb.T, sa, sb, torch.bfloat16)
+            ac, bc, sac, sbc = aa[rows.to(device)].cpu(), bb.cpu().T, sa[rows.to(device)].cpu(), sb.cpu()
+            ref = oracle.scaled_gemm_ref(ac, bc, sac, sbc, torch.bfloat16).float()
+            bound = 2.0 * 2.0**-7 * ref.abs() + (sac * sbc.T).abs() * (k * 2.0**-24) * (ac.float().abs() @ bc.float().abs()) + 2.0**-132
+            excess = ((got[rows.to(device)].float().cpu() - ref).abs() - bound).max().item()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _ in range(10):
+                scaled_gemm(aa, bb.T, sa, sb, torch.bfloat16)
+            e0.record()
+            for _ in range(30):
+                scaled_gemm(aa, bb.T, sa, sb, torch.bfloat16)
+            e1.record()
+            torch.cuda.synchronize()
+            leg[form] = {"ms_per_call": round(e0.elapsed_time(e1) / 30, 5), "parity_ok": bool(excess <= 0), "max_excess": excess, "checked_rows": int(rows.numel())}
+        out[name] = leg
+    return out
+
+
 def _flush_c_stdio() -> None:
     """RCCL writes its version banner through C stdio, which is block-buffered on a pipe and would otherwise be flushed at process
     exit -- BEHIND the JSON line.  Flush it now."""
@@ -1061,11 +1103,20 @@ def main() -> None:
                                     "ms_per_step": r5["ms_gemm_plus_allgather_rowmajor"], "steps": 10, "warmup": 3}
         except Exception as exc:  # noqa: BLE001 -- a side field must not take the headline down
             result["c5_one_gpu"] = {"error": repr(exc)}
+    if world == 1 and args.workload == "c3" and full and not args.no_side_legs:
+        try:
+            result["fnuz"] = fnuz_side_legs(device)
+        except Exception as exc:  # noqa: BLE001 -- a side field must not take the headline down
+            result["fnuz"] = {"error": repr(exc)}
+        torch.cuda.empty_cache()
     if "cpu_baseline" in res:
         result["cpu_baseline"] = res["cpu_baseline"]
     # a fast kernel whose results differ from the oracle's is not a result: the line still prints (with parity.ok false), the
     # exit code says so (what the reference's benchmarks do before they time: benchmarks/scaled_gemm_benchmark.py:216-227)
     checks = [result.get("parity")] + [result[nm].get("parity") for nm in ("c1", "c2", "c4", "c4readme") if isinstance(result.get(nm), dict)]
+    for leg_ in (result.get("fnuz") or {}).values():
+        if isinstance(leg_, dict):
+            checks += [{"ok": f["parity_ok"], "what": "fnuz"} for f in leg_.values() if isinstance(f, dict) and "parity_ok" in f]
     failed = [c for c in checks if c is not None and not c["ok"]]
     emit(result, world, rank)
     if failed:
