@@ -192,6 +192,10 @@ namespace {
 
 // Which kernel the MFMA-contract path of scaled_gemm runs for `p` at GEMM variant `variant` -- no launch (run_scaled_fast launches
 // exactly this; conch_debug_scaled_plan reports it).  kScaledPickError: a forced kernel's contract is not met (+ the error text).
+// Diagnostic A/B switch (conch_debug_fnuz_in_registers; tools/time_fnuz_decode.py): 0 = e4m3fnuz decode shapes take round 5's scan +
+// gated kernels again instead of the split-K kernel that splits the special codes off in registers
+std::atomic<int> g_fnuz_in_registers{1};
+
 enum ScaledPick { kScaledPickError = -1, kScaledPickTiles = 0, kScaledPickMid = 1, kScaledPickSkinny = 2, kScaledPickAsm = 3 };
 
 ScaledPick pick_scaled_fast(const ScaledGemmArgs& p, int variant) {
@@ -269,6 +273,12 @@ int run_scaled(const ScaledGemmArgs& p_in, hipStream_t stream) {
     // if one is there).  Three of the launches return at once; the host never learns which.
     ScaledGemmArgs f = p;
     f.in_dtype = CONCH_DT_FP8_E4M3FN;
+    // decode sizes (round 6): the split-K skinny kernel passes both operands through registers and splits the special codes off
+    // there (gemm_skinny.hip, fnuz_split) -- no scan, no flag, no expansion, saturated or not
+    if (g_fnuz_in_registers.load() && scaled_gemm_mfma_supported(f) && choose_scaled_kernel(f) == kKernelSkinny && scaled_gemm_skinny_fnuz_supported(f)) {
+      ScaledGemmArgs g = p;  // (in_dtype stays e4m3fnuz: launch_scaled_gemm_skinny picks the splitting instantiation by it)
+      return launch_scaled_gemm_skinny(g, stream);
+    }
     if (scaled_gemm_mfma_supported(f) && fnuz_expansion_fits(p) && p.scale_a_numel <= kFnuzMaxScales) {
       void* flag = nullptr;
       if (int rc = get_scratch(stream, kScratchFlags, kFlagsBytes, &flag)) return rc;
@@ -691,6 +701,11 @@ extern "C" int conch_debug_mixed_plan(int64_t m, int64_t n, int64_t k, int bits,
   out[0] = (int)pick_mixed(p);
   out[1] = out[2] = out[3] = 0;
   if (out[0] == kMixedPickStrip) mixed_strip_plan_query(p, &out[1], &out[2], &out[3]);
+  return CONCH_OK;
+}
+
+extern "C" int conch_debug_fnuz_in_registers(int on) {
+  g_fnuz_in_registers.store(on ? 1 : 0);
   return CONCH_OK;
 }
 

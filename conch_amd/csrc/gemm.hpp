@@ -145,6 +145,7 @@ double scaled_tiles_estimate_us(const ScaledGemmArgs& p);  // the same model's t
 int unit_scale(const float** out);                          // one fp32 1.0 on the current device ("no scale on this side")
 // gemm_skinny.hip -- M <= 256: 128x16 blocks, K split over the waves, register streaming (variant 4)
 bool scaled_gemm_skinny_supported(const ScaledGemmArgs& p);
+bool scaled_gemm_skinny_fnuz_supported(const ScaledGemmArgs& f);  // e4m3fnuz operands (dtype rewritten to e4m3fn in `f`) on the split-K kernel, all codes in registers
 int launch_scaled_gemm_skinny(const ScaledGemmArgs& p, hipStream_t stream);
 // the split-K reduce kernel on its own: C = epilogue(sum over `slices` slabs [slice][M][N] of fp32 / int32 partial sums, in slice
 // order); N % 4 == 0.  Used by the 128 x 128-tile kernel's split-K form (gemm_mid.hip)

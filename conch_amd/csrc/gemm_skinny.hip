@@ -143,10 +143,59 @@ constexpr int kSpSteps = 8;       // 128-byte K steps per slice: a slice is 1024
 constexpr int kSpSliceK = kSpSteps * kStepBytes;
 constexpr int kSpCountersPerTile = 4;  // one-launch form: one arrival counter per (tile, wave)
 
-// ROWS = rows of A a workgroup handles (32, 64 or 128): a decode batch of 32 rows stages, multiplies and writes a quarter
-// of what the 128-row form does.  Per step and wave: 2 register loads of B^T + ROWS/32 LDS-DMA pieces of A.
-// GATHER: the B^T fragments were fetched with lane L on (row L >> 2, 16-byte chunk L & 3) -- every quad of lanes inside one
-// 128-byte line, the access shape the texture path takes at full rate -- and lane (r, g) of the MFMA operand collects its
+// ---- e4m3fnuz operands on the OCP fp8 MFMA, every code handled in registers (round 6; split-K kernel only) --------------------
+// Read as OCP e4m3fn a fnuz byte is exactly TWICE its value -- except 0x7F / 0xFF (+-240: 480 does not exist in OCP, the byte is
+// its NaN) and 0x80 (the fnuz NaN: OCP's -0).  The tile kernels stage both operands by LDS-DMA and can only run clean data that
+// way (capi.hip: scan, gate, else the bf16 expansion).  HERE both operands pass through registers on their way into the MFMA, and
+// at decode sizes the MFMA pipe is nearly idle, so the special codes are split off on the spot:
+//     x = clean + rem      clean: 0x7F -> 0x7E, 0xFF -> 0xFE (+-448 = 2 x 224), 0x80 -> 0x00
+//                          rem:   +-32 (0x60 / 0xE0 = 2 x 16) where the byte was +-240, OCP NaN (0x7F) where it was 0x80, else 0
+//     acc += b_clean a_clean (+ b_rem a_clean) (+ b_clean a_rem + b_rem a_rem)     -- exact products, the extra MFMAs only for a
+//                          fragment pair that holds a special code at all (wave-uniform)
+// and the accumulator takes the exact 1/4 once, behind the K loop.  A fnuz NaN reaches the MFMA as an OCP NaN in `rem` and poisons
+// exactly its row (A) or column (B), as the reference's fp32 matmul does.  No scan of the operands, no flag, no expansion pass:
+// a weight matrix that was clamped by its quantiser costs what a clean one costs (16 x 4096 x 11008: 96 us through the expansion).
+constexpr int kMmaFp8Fnuz = 4;  // (mfma_tile.hpp's kinds are 0..3; AccT<4> is the fp32 accumulator of the primary template)
+
+// wave-uniform: does ANY lane's part of this fragment hold 0x7F / 0xFF / 0x80?  Five VALU operations per dword (and, add, add,
+// bfi, or3) -- the cost of the fnuz path on clean data: a fragment without special codes goes to the MFMA as it is
+__device__ __forceinline__ bool fnuz_special(const Frag& x) {
+  uint32_t any = 0;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t u = (uint32_t)(h ? x.hi[e] : x.lo[e]);
+      const uint32_t t = u & 0x7F7F7F7Fu;
+      any |= (t + 0x01010101u) | (~(t + 0x7F7F7F7Fu) & u);  // bit 7 of a byte: low seven bits all ones | all zeros under a set sign
+    }
+  }
+  return __builtin_amdgcn_ballot_w64((any & 0x80808080u) != 0) != 0;
+}
+
+__device__ __forceinline__ void fnuz_split(const Frag& x, Frag& clean, Frag& rem) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t u = (uint32_t)(h ? x.hi[e] : x.lo[e]);
+      const uint32_t t = u & 0x7F7F7F7Fu;
+      const uint32_t sat = (t + 0x01010101u) & 0x80808080u;        // 0x80 in every byte that is 0x7F / 0xFF
+      const uint32_t nan = ~(t + 0x7F7F7F7Fu) & u & 0x80808080u;   // 0x80 in every byte that is 0x80
+      const uint32_t c = (u - (sat >> 7)) & ~nan;
+      const uint32_t r = (sat >> 1) | (sat >> 2) | (u & sat) | (nan - (nan >> 7));
+      if (h) {
+        clean.hi[e] = (int)c;
+        rem.hi[e] = (int)r;
+      } else {
+        clean.lo[e] = (int)c;
+        rem.lo[e] = (int)r;
+      }
+    }
+  }
+}
+
+// The whole slice's B^T fragments and A units are consumed step by step; step S: wait for its operands, (gather form) fetch this lane's
 // chunk from lane 4 r + g (`gather` = that lane's ds_bpermute address)
 template <int MMA, int ROWS, int STEPS, bool GATHER, int S>
 __device__ __forceinline__ void sp_consume(typename AccT<MMA>::type (&acc)[ROWS / 16], const Frag (&fb)[STEPS], const char* lds,
@@ -162,11 +211,35 @@ __device__ __forceinline__ void sp_consume(typename AccT<MMA>::type (&acc)[ROWS 
         b.hi[j] = __builtin_amdgcn_ds_bpermute(gather, fb[S].hi[j]);
       }
     }
-    __builtin_amdgcn_s_barrier();            // ... and so has every other wave's quarter of unit S
+    if constexpr (MMA == kMmaFp8Fnuz) {
+      Frag bc = b, br;
+      const bool b_special = fnuz_special(b);
+      if (b_special) fnuz_split(b, bc, br);
+      __builtin_amdgcn_s_barrier();
 #pragma unroll
-    for (int i = 0; i < ROWS / 16; ++i) {
-      const Frag fa = read_frag(lds, S * (ROWS * kStepBytes) + lane_off + i * 2048);
-      mma_step<MMA>(acc[i], b, fa);  // D rows = n, D cols = m
+      for (int i = 0; i < ROWS / 16; ++i) {
+        const Frag fa = read_frag(lds, S * (ROWS * kStepBytes) + lane_off + i * 2048);
+        if (!fnuz_special(fa)) {
+          mma_step<kMmaFp8>(acc[i], bc, fa);
+          if (b_special) mma_step<kMmaFp8>(acc[i], br, fa);
+        } else {
+          Frag ac, ar;
+          fnuz_split(fa, ac, ar);
+          mma_step<kMmaFp8>(acc[i], bc, ac);
+          mma_step<kMmaFp8>(acc[i], bc, ar);
+          if (b_special) {
+            mma_step<kMmaFp8>(acc[i], br, ac);
+            mma_step<kMmaFp8>(acc[i], br, ar);
+          }
+        }
+      }
+    } else {
+      __builtin_amdgcn_s_barrier();            // ... and so has every other wave's quarter of unit S
+#pragma unroll
+      for (int i = 0; i < ROWS / 16; ++i) {
+        const Frag fa = read_frag(lds, S * (ROWS * kStepBytes) + lane_off + i * 2048);
+        mma_step<MMA>(acc[i], b, fa);  // D rows = n, D cols = m
+      }
     }
     sp_consume<MMA, ROWS, STEPS, GATHER, S + 1>(acc, fb, lds, lane_off, gather);
   }
@@ -431,6 +504,10 @@ pass_begin: __attribute__((unused));
     if (++chunk < chunks) goto pass_begin;
   }
 pass_end: __attribute__((unused));
+  if constexpr (MMA == kMmaFp8Fnuz) {  // both operands ran as twice their values: the exact 1/4 (fnuz_split)
+#pragma unroll
+    for (int i = 0; i < ROWS / 16; ++i) acc[i] = acc[i] * 0.25f;
+  }
   SK_STAMP(2);
   SK_CLOCK(1);
 
@@ -636,7 +713,7 @@ void launch_splitk_kernel(int rows, int steps, bool gather, dim3 grid, const Sca
       return;
     }
   }
-  if constexpr (!FUSED) {
+  if constexpr (!FUSED && MMA != kMmaFp8Fnuz) {
     if (p.a_src_dtype) {  // quantise A on the way in (conch_static_quant_scaled_gemm)
 #define CONCH_QA(R)                                                                                                              \
   do {                                                                                                                           \
@@ -690,6 +767,13 @@ int splitk_chunks(const ScaledGemmArgs& p, int slices, int rows) {
 // `wide` = the plain GEMM on [gate | up] (n = 2d): can the split-K form run it with the silu fused into its reduce kernel?
 bool scaled_gemm_skinny_fused_supported(const ScaledGemmArgs& wide) {
   return scaled_gemm_skinny_supported(wide) && wide.n % 8 == 0 && splitk_slices(wide) >= 1;
+}
+
+// e4m3fnuz through the split-K kernel with the special codes split off in registers: `f` = the problem with in_dtype already
+// rewritten to e4m3fn (the contract checks are dtype-agnostic beyond "one byte per element")
+bool scaled_gemm_skinny_fnuz_supported(const ScaledGemmArgs& f) {
+  return scaled_gemm_skinny_supported(f) && !f.fuse_silu && !f.a_src_dtype && !f.n_more && splitk_slices(f) >= 1 &&
+         tuning(CONCH_TUNE_SKINNY_NO_SPLITK) != 1;
 }
 
 bool scaled_gemm_skinny_supported(const ScaledGemmArgs& p) {
@@ -793,13 +877,20 @@ int launch_scaled_gemm_skinny(const ScaledGemmArgs& p, hipStream_t stream) {
   const int slices = (tuning(CONCH_TUNE_SKINNY_NO_SPLITK) == 1 && !p.fuse_silu && !p.a_src_dtype && in_wg_ok) ? 0 : splitk_slices(p);
   if (slices >= 1) {
     int rc;
-    if (p.in_dtype == CONCH_DT_FP8_E4M3FN)
+    if (p.in_dtype == CONCH_DT_FP8_E4M3FNUZ)  // every fnuz code handled in registers (fnuz_split); capi.hip routes it here
+      rc = p.out_dtype == CONCH_DT_BF16 ? launch_splitk<kMmaFp8Fnuz, CONCH_DT_BF16>(p, slices, stream)
+                                        : launch_splitk<kMmaFp8Fnuz, CONCH_DT_FP16>(p, slices, stream);
+    else if (p.in_dtype == CONCH_DT_FP8_E4M3FN)
       rc = p.out_dtype == CONCH_DT_BF16 ? launch_splitk<kMmaFp8, CONCH_DT_BF16>(p, slices, stream)
                                         : launch_splitk<kMmaFp8, CONCH_DT_FP16>(p, slices, stream);
     else
       rc = p.out_dtype == CONCH_DT_BF16 ? launch_splitk<kMmaInt8, CONCH_DT_BF16>(p, slices, stream)
                                         : launch_splitk<kMmaInt8, CONCH_DT_FP16>(p, slices, stream);
     return rc;  // a scratch failure is an error, not a reason to fall through: the in-workgroup kernel has no fused reduce
+  }
+  if (p.in_dtype == CONCH_DT_FP8_E4M3FNUZ) {
+    set_error("scaled_gemm (skinny): e4m3fnuz operands run on the split-K form only (N %% 4 == 0)");
+    return CONCH_ERR_UNSUPPORTED;
   }
   const dim3 grid((unsigned)((p.n + kSkN - 1) / kSkN), (unsigned)((p.m + kSkM - 1) / kSkM));
 #define CONCH_LAUNCH(MMA, OUT)                                                                          \

@@ -1175,6 +1175,48 @@ def test_scaled_gemm_e4m3fnuz_special_codes_take_the_exact_path(m, k, n, where):
     check_scaled(clean, oracle.scaled_gemm_ref(a, b, sa, sb, torch.bfloat16, bias), torch.float8_e4m3fnuz, torch.bfloat16, (a, b, sa, sb, bias))
 
 
+@pytest.mark.parametrize(("m", "k", "n"), [(1, 4096, 4096), (16, 4096, 11008), (33, 1024, 520), (64, 2048, 2048), (128, 4096, 1024)])
+def test_e4m3fnuz_decode_sizes_split_the_special_codes_in_registers(m, k, n):
+    """Round 6: at decode sizes the split-K kernel takes e4m3fnuz bytes as they are -- no scan of the operands, no flag, no bf16
+    expansion -- and splits +-240 (0x7F / 0xFF: OCP's NaN) and the fnuz NaN (0x80: OCP's -0) off in registers (gemm_skinny.hip,
+    fnuz_split): x = clean + rem, up to four MFMAs per fragment pair, the exact 1/4 behind the K loop.  Data with +-240 in EVERY
+    row of A and EVERY column of B (what an absmax quantiser emits) against the oracle per element, and against round 5's path
+    (scan + gated kernels; conch_debug_fnuz_in_registers(0)) within the accumulation-order bound; a NaN poisons its row / column."""
+    import ctypes
+
+    hook = _C.load().conch_debug_fnuz_in_registers
+    hook.restype, hook.argtypes = ctypes.c_int, [ctypes.c_int]
+    a, b, sa, sb, bias = make_scaled_inputs(m, k, n, torch.float8_e4m3fnuz, torch.bfloat16, False, False, True)
+    ab, bb = a.view(torch.uint8).clone(), b.T.contiguous().view(torch.uint8).clone()  # [M][K], [N][K]
+    ra, rb = torch.arange(m), torch.arange(n)
+    ab[ra, (ra * 37) % k] = torch.where(ra % 2 == 0, 0x7F, 0xFF).to(torch.uint8)
+    bb[rb, (rb * 53) % k] = torch.where(rb % 3 == 0, 0xFF, 0x7F).to(torch.uint8)
+    bb[n - 1, k - 1] = 0x7F  # the very last byte of the operand
+    ab[0, 5], bb[0, 5] = 0x7F, 0xFF  # both operands saturated at the same k: the rem x rem product
+    a2, b2 = ab.view(torch.float8_e4m3fnuz), bb.view(torch.float8_e4m3fnuz).T
+    ref = oracle.scaled_gemm_ref(a2, b2, sa, sb, torch.bfloat16, bias)
+    got = run_scaled(a2, b2, sa, sb, torch.bfloat16, bias)
+    check_scaled(got, ref, torch.float8_e4m3fnuz, torch.bfloat16, (a2, b2, sa, sb, bias))
+    hook(0)
+    try:
+        old = run_scaled(a2, b2, sa, sb, torch.bfloat16, bias)
+    finally:
+        hook(1)
+    check_scaled(old, ref, torch.float8_e4m3fnuz, torch.bfloat16, (a2, b2, sa, sb, bias))
+    ab[m // 2, 9] = 0x80
+    bb[3, k - 2] = 0x80
+    a3, b3 = ab.view(torch.float8_e4m3fnuz), bb.view(torch.float8_e4m3fnuz).T
+    got = run_scaled(a3, b3, sa, sb, torch.bfloat16, bias).float().cpu()
+    bad = torch.zeros((m, n), dtype=torch.bool)
+    bad[m // 2, :] = True
+    bad[:, 3] = True
+    assert torch.equal(torch.isnan(got), bad)
+    ref3 = oracle.scaled_gemm_ref(a3, b3, sa, sb, torch.bfloat16, bias).float()
+    assert torch.equal(torch.isnan(ref3), bad)
+    if (~bad).any():  # (one row: everything is poisoned)
+        assert (got[~bad] - ref3[~bad]).abs().max().item() <= 2.0 * EPS[torch.bfloat16] * ref3[~bad].abs().max().item()
+
+
 @pytest.mark.parametrize("wname", list(WTYPES))
 @pytest.mark.parametrize("zp", [1, 0])
 @pytest.mark.parametrize("dname", ["f16", "bf16"])
