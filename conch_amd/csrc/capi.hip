@@ -275,7 +275,13 @@ int run_scaled(const ScaledGemmArgs& p_in, hipStream_t stream) {
     f.in_dtype = CONCH_DT_FP8_E4M3FN;
     // decode sizes (round 6): the split-K skinny kernel passes both operands through registers and splits the special codes off
     // there (gemm_skinny.hip, fnuz_split) -- no scan, no flag, no expansion, saturated or not
-    if (g_fnuz_in_registers.load() && scaled_gemm_mfma_supported(f) && choose_scaled_kernel(f) == kKernelSkinny && scaled_gemm_skinny_fnuz_supported(f)) {
+    // Taken where the dispatcher gives the e4m3fn twin of the problem to that kernel, and up to 64 rows whatever it picks: there the
+    // 128 x 128 tiles it may prefer for e4m3fn cost a scan + (saturated data) the expansion on top -- 64 x 8192 x 8192: 28.8 / 33.0 us
+    // clean / saturated on this kernel against 42.4 / 103.5; from 96 rows the per-fragment test of eight A fragments per step loses
+    // to the scan on clean data (profiles/r06/fnuz_decode_ab.txt).  (g_fnuz_in_registers: 0 = never, 2 = wherever the kernel runs.)
+    const int in_regs = g_fnuz_in_registers.load();
+    if (in_regs && scaled_gemm_mfma_supported(f) && (in_regs == 2 || p.m <= 64 || choose_scaled_kernel(f) == kKernelSkinny) &&
+        scaled_gemm_skinny_fnuz_supported(f)) {
       ScaledGemmArgs g = p;  // (in_dtype stays e4m3fnuz: launch_scaled_gemm_skinny picks the splitting instantiation by it)
       return launch_scaled_gemm_skinny(g, stream);
     }
@@ -705,7 +711,7 @@ extern "C" int conch_debug_mixed_plan(int64_t m, int64_t n, int64_t k, int bits,
 }
 
 extern "C" int conch_debug_fnuz_in_registers(int on) {
-  g_fnuz_in_registers.store(on ? 1 : 0);
+  g_fnuz_in_registers.store(on < 0 ? 0 : on > 2 ? 2 : on);
   return CONCH_OK;
 }
 

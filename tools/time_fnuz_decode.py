@@ -17,7 +17,7 @@ def main() -> None:
     dev = torch.device("cuda")
     hook = _C.load().conch_debug_fnuz_in_registers
     hook.restype, hook.argtypes = ctypes.c_int, [ctypes.c_int]
-    for m, k, n in ((16, 4096, 11008), (1, 4096, 4096), (32, 4096, 4096), (64, 4096, 11008), (128, 4096, 4096), (128, 4096, 11008), (256, 4096, 4096), (200, 8192, 2048)):
+    for m, k, n in ((16, 4096, 11008), (1, 4096, 4096), (32, 4096, 4096), (64, 4096, 11008), (128, 4096, 4096), (32, 8192, 8192), (48, 8192, 8192), (64, 8192, 8192), (64, 8192, 28672), (96, 8192, 8192), (128, 4096, 11008), (256, 4096, 4096)):
         torch.manual_seed(0)
         base = 0.25 * torch.rand((m, k), device=dev)
         wbase = 0.25 * torch.rand((n, k), device=dev)
@@ -26,7 +26,8 @@ def main() -> None:
         line = f"{m:4d} x {k:5d} x {n:5d}:"
         for name, dt, sat, inreg in (("e4m3fn", torch.float8_e4m3fn, False, 1), ("fnuz clean", torch.float8_e4m3fnuz, False, 1),
                                      ("fnuz clean, round-5 path", torch.float8_e4m3fnuz, False, 0), ("fnuz saturated", torch.float8_e4m3fnuz, True, 1),
-                                     ("fnuz saturated, round-5 path", torch.float8_e4m3fnuz, True, 0)):
+                                     ("fnuz saturated, round-5 path", torch.float8_e4m3fnuz, True, 0),
+                                     ("fnuz clean, skinny forced", torch.float8_e4m3fnuz, False, 2), ("fnuz saturated, skinny forced", torch.float8_e4m3fnuz, True, 2)):
             hook(inreg)
             a, bt = base.to(dt), wbase.to(dt)
             if sat:
