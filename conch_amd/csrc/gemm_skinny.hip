@@ -199,7 +199,7 @@ __device__ __forceinline__ void fnuz_split(const Frag& x, Frag& clean, Frag& rem
 // chunk from lane 4 r + g (`gather` = that lane's ds_bpermute address)
 template <int MMA, int ROWS, int STEPS, bool GATHER, int S>
 __device__ __forceinline__ void sp_consume(typename AccT<MMA>::type (&acc)[ROWS / 16], const Frag (&fb)[STEPS], const char* lds,
-                                           int lane_off, int gather) {
+                                           int lane_off, int gather, int live_blocks) {
   constexpr int kOps = 2 + ROWS / 32;
   if constexpr (S < STEPS) {
     wait_vmcnt_n<kOps * (STEPS - 1 - S)>();  // step S of this wave has landed ...
@@ -218,6 +218,12 @@ __device__ __forceinline__ void sp_consume(typename AccT<MMA>::type (&acc)[ROWS 
       __builtin_amdgcn_s_barrier();
 #pragma unroll
       for (int i = 0; i < ROWS / 16; ++i) {
+        // (<= 16 rows of a 32-row workgroup: the second block holds copies of row M - 1 and is never stored -- no test, no MFMA: a
+        // third of the step's VALU work.  Workgroup-uniform.  Only there: the same test in front of every block of the taller
+        // workgroups cost them 2 us, profiles/r06/fnuz_decode_ab.txt.)
+        if constexpr (ROWS == 32) {
+          if (i >= live_blocks) break;
+        }
         const Frag fa = read_frag(lds, S * (ROWS * kStepBytes) + lane_off + i * 2048);
         if (!fnuz_special(fa)) {
           mma_step<kMmaFp8>(acc[i], bc, fa);
@@ -241,7 +247,7 @@ __device__ __forceinline__ void sp_consume(typename AccT<MMA>::type (&acc)[ROWS 
         mma_step<MMA>(acc[i], b, fa);  // D rows = n, D cols = m
       }
     }
-    sp_consume<MMA, ROWS, STEPS, GATHER, S + 1>(acc, fb, lds, lane_off, gather);
+    sp_consume<MMA, ROWS, STEPS, GATHER, S + 1>(acc, fb, lds, lane_off, gather, live_blocks);
   }
 }
 
@@ -498,7 +504,7 @@ pass_begin: __attribute__((unused));
 #pragma unroll
     for (int i = 0; i < ROWS / 16; ++i) acc[i] = typename AccT<MMA>::type{0, 0, 0, 0};
   }
-  sp_consume<MMA, ROWS, STEPS, GATHER, 0>(acc, fb, lds, lane_off, gather);
+  sp_consume<MMA, ROWS, STEPS, GATHER, 0>(acc, fb, lds, lane_off, gather, min(ROWS / 16, ((int)p.m - m0 + 15) / 16));
   }  // pass
   if constexpr (LOOP) {
     if (++chunk < chunks) goto pass_begin;

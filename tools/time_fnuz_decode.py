@@ -17,7 +17,7 @@ def main() -> None:
     dev = torch.device("cuda")
     hook = _C.load().conch_debug_fnuz_in_registers
     hook.restype, hook.argtypes = ctypes.c_int, [ctypes.c_int]
-    for m, k, n in ((16, 4096, 11008), (1, 4096, 4096), (32, 4096, 4096), (64, 4096, 11008), (128, 4096, 4096), (32, 8192, 8192), (48, 8192, 8192), (64, 8192, 8192), (64, 8192, 28672), (96, 8192, 8192), (128, 4096, 11008), (256, 4096, 4096)):
+    for m, k, n in ((16, 4096, 11008), (1, 4096, 4096), (32, 4096, 4096), (64, 4096, 11008), (128, 4096, 4096), (8, 8192, 8192), (40, 4096, 11008)):
         torch.manual_seed(0)
         base = 0.25 * torch.rand((m, k), device=dev)
         wbase = 0.25 * torch.rand((n, k), device=dev)
