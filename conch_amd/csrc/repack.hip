@@ -123,6 +123,27 @@ __global__ __launch_bounds__(256) void fnuz_to_bf16_vec_kernel(uint16_t* __restr
   }
 }
 
+// both operands in ONE launch (blockIdx.y = 0: A, 1: B^T): the flow's launches are usually gated off, and an empty launch costs
+// ~4.7 us of stream time whatever it would have done (profiles/r06/fnuz_c3_flow_trace.txt)
+__global__ __launch_bounds__(256) void fnuz_to_bf16_vec2_kernel(uint16_t* __restrict__ dst_a, const uint8_t* __restrict__ src_a, int64_t rows_a, int64_t sr_a,
+                                                                uint16_t* __restrict__ dst_b, const uint8_t* __restrict__ src_b, int64_t rows_b, int64_t sr_b,
+                                                                int64_t k_dim, int64_t kp, const int* __restrict__ gate) {
+  if (gated_off(gate, 1)) return;
+  uint16_t* dst = blockIdx.y ? dst_b : dst_a;
+  const uint8_t* src = blockIdx.y ? src_b : src_a;
+  const int64_t rows = blockIdx.y ? rows_b : rows_a, sr = blockIdx.y ? sr_b : sr_a;
+  for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+    for (int64_t k = (int64_t)threadIdx.x * 8; k < kp; k += 256 * 8) {
+      i32x2 w = {0, 0};
+      if (k < k_dim) w = *(const i32x2*)(src + r * sr + k);
+      u16x8 o;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = float_to_bf16_bits(decode_fp8_sw<true>((uint8_t)((uint32_t)w[i >> 2] >> (8 * (i & 3)))));
+      *(u16x8*)(dst + r * kp + k) = o;
+    }
+  }
+}
+
 bool k_major_ok(const void* ptr, int64_t stride_k, int64_t stride_row, int64_t k_dim, int64_t k_mult) {
   return stride_k == 1 && stride_row % 16 == 0 && ((uintptr_t)ptr & 15) == 0 && k_dim % k_mult == 0;
 }
@@ -181,7 +202,7 @@ int repack_for_mfma(const ScaledGemmArgs& p, ScaledGemmArgs* q, void** scratch, 
 // BYTE units (a 128-byte K step = 64 elements).  The MI300-era flavour cannot use gfx950's OCP fp8 MFMA
 // (different bias, 0x7F/0xFF are numbers, 0x80 is NaN), so it runs at the bf16 MFMA rate instead.
 // Does A or B^T hold 0x80 (fnuz NaN; OCP -0), 0x7F or 0xFF (fnuz +-240; OCP NaN)?  One pass over both operands, 16 bytes per
-// lane; `flag` was zeroed on the stream before.  Rows are K-contiguous and 16-byte aligned, K % 16 == 0 (the tile contract).
+// lane (fnuz_scan_kernel says how the verdict reaches the dispatch word).  Rows are K-contiguous and 16-byte aligned, K % 16 == 0 (the tile contract).
 __device__ __forceinline__ uint32_t fnuz_special_in(uint32_t x) {
   const uint32_t t = x & 0x7f7f7f7fu;                                   // a byte is 0x7F or 0xFF  <=>  its low seven bits are all set
   const uint32_t top = (t + 0x01010101u) & 0x80808080u;                 // (no carry between bytes: 0x7F + 1 = 0x80)
@@ -190,6 +211,10 @@ __device__ __forceinline__ uint32_t fnuz_special_in(uint32_t x) {
   return top | nan;                                                     // for the lowest zero byte; any hit means "some byte")
 }
 
+// `flag` was zeroed on the stream in front of the launch.  ONE atomicOr per workgroup that found a code (round 6: one per THREAD
+// made the scan of saturated operands -- every row holds +-240 -- 42 us where clean ones take 10).  (A form without the 4-byte
+// memset -- last-arriving workgroup publishes the verdict and resets the bookkeeping -- was tried: its agent-scope fences write
+// the L2s back, 67 us per scan behind a GEMM's 90 MB of dirty C lines.)
 __global__ __launch_bounds__(256) void fnuz_scan_kernel(const uint8_t* __restrict__ a, int rows_a, int64_t stride_a,
                                                         const uint8_t* __restrict__ b, int rows_b, int64_t stride_b, int k_vecs,
                                                         int* __restrict__ flag, const float* __restrict__ sa, int sa_numel,
@@ -215,7 +240,9 @@ __global__ __launch_bounds__(256) void fnuz_scan_kernel(const uint8_t* __restric
         for (int e = 0; e < 4; ++e) found |= fnuz_special_in(v[j][e]);
     }
   }
-  if (found) atomicOr(flag, 1);
+  const int any = __syncthreads_or(found != 0);
+  // (... and none once the word is set: 2048 atomics on one address are 18 us of the scan)
+  if (any && threadIdx.x == 0 && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(flag, 1);
 }
 
 int launch_fnuz_scan(const ScaledGemmArgs& p, int* flag, hipStream_t stream, float* sa_quarter) {
@@ -253,9 +280,18 @@ int expand_fnuz_to_bf16(const ScaledGemmArgs& p, ScaledGemmArgs* q, hipStream_t 
       hipLaunchKernelGGL(fnuz_to_bf16_rows_kernel, grid, block, 0, stream, out, (const uint8_t*)src, rows, p.k, kp, stride_row, stride_k, gate);
     }
   };
-  expand((uint16_t*)ws, p.a, p.m, p.a_stride_m, p.a_stride_k);
   uint8_t* bt = (uint8_t*)ws + a_bytes;
-  expand((uint16_t*)bt, p.b, p.n, p.b_stride_n, p.b_stride_k);
+  auto vec_ok = [&](const void* src, int64_t stride_row, int64_t stride_k) {
+    return stride_k == 1 && stride_row % 8 == 0 && ((uintptr_t)src & 7) == 0 && p.k % 8 == 0;
+  };
+  if (vec_ok(p.a, p.a_stride_m, p.a_stride_k) && vec_ok(p.b, p.b_stride_n, p.b_stride_k)) {
+    const dim3 grid((unsigned)std::min<int64_t>(std::max(p.m, p.n), 1024), 2);
+    hipLaunchKernelGGL(fnuz_to_bf16_vec2_kernel, grid, block, 0, stream, (uint16_t*)ws, (const uint8_t*)p.a, p.m, p.a_stride_m, (uint16_t*)bt,
+                       (const uint8_t*)p.b, p.n, p.b_stride_n, p.k, kp, gate);
+  } else {
+    expand((uint16_t*)ws, p.a, p.m, p.a_stride_m, p.a_stride_k);
+    expand((uint16_t*)bt, p.b, p.n, p.b_stride_n, p.b_stride_k);
+  }
   q->a = ws;
   q->b = bt;
   q->a_stride_m = q->b_stride_n = kp * 2;  // bytes
