@@ -212,7 +212,7 @@ __device__ __forceinline__ uint32_t fnuz_special_in(uint32_t x) {
 }
 
 // `flag` was zeroed on the stream in front of the launch.  ONE atomicOr per workgroup that found a code (round 6: one per THREAD
-// made the scan of saturated operands -- every row holds +-240 -- 42 us where clean ones take 10).  (A form without the 4-byte
+// put up to half a million atomics on one address when every row holds +-240).  (A form without the 4-byte
 // memset -- last-arriving workgroup publishes the verdict and resets the bookkeeping -- was tried: its agent-scope fences write
 // the L2s back, 67 us per scan behind a GEMM's 90 MB of dirty C lines.)
 __global__ __launch_bounds__(256) void fnuz_scan_kernel(const uint8_t* __restrict__ a, int rows_a, int64_t stride_a,
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void fnuz_scan_kernel(const uint8_t* __restric
     }
   }
   const int any = __syncthreads_or(found != 0);
-  // (... and none once the word is set: 2048 atomics on one address are 18 us of the scan)
+  // (... and none once the word is set)
   if (any && threadIdx.x == 0 && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(flag, 1);
 }
 
